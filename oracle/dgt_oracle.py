@@ -1,0 +1,411 @@
+"""CPU oracle for the JODO DGT denoising hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch restatement, in plain PyTorch fp32 on the CPU, of what the reference's
+score network computes in one call (the reference is pure Python; /root/reference never travels to
+the GPU box, this file does).  It is the *checker*: only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import it.  Nothing under `jodo_amd/` does, and the product
+path has no CPU fallback.
+
+Pinning: `oracle/make_golden.py` imports the real reference (under `oracle/standins`) in the build
+container and (a) asserts both functions below agree with it on random-init weights for the QM9,
+GEOM and conditional configs, (b) writes the fixtures in `tests/golden/`, which
+`tests/test_oracle_golden.py` re-checks without the reference.  Parity with the real PyG /
+torch_scatter CUDA kernels is unpinned (they cannot be run here).
+
+Two formulations, same numbers to fp32 reorder noise:
+
+* `forward_faithful` — op-for-op the reference's *sparse* formulation: dense->edge-list conversion,
+  per-edge gathered time embedding, per-edge time MLPs, scatter softmax/aggregation.  Mirrors
+    DGT_concat.forward            models/mol_gnn.py:491-594
+    Cond_DGT_concat.forward       models/mol_gnn.py:687-794
+    EquivariantMixBlock.forward   models/mol_gnn.py:270-322
+    TransMixLayer.forward/message models/layers.py:131-186
+    MultiCondEquiUpdate.forward   models/mol_gnn.py:71-94
+    CondGaussianLayer / gaussian  models/layers.py:291-295, 328-334
+    CoorsNorm                     models/layers.py:344-347
+    LearnedSinusodialposEmb       models/layers.py:283-288
+    helpers                       models/utils.py:38-45, 111-137
+  This is also the CPU baseline that bench.py times ("port").
+
+* `forward_dense` — the per-molecule dense [n,n] formulation the HIP kernels implement
+  (SURVEY.md §3.2b): time MLPs hoisted to one GEMV per molecule, node2edge_lin and input_lin
+  factored per node, softmax/aggregation over the source axis of the dense tile.  Optionally
+  returns per-block intermediates for kernel-level tests.
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class Hyper:
+    nf: int = 256
+    n_layers: int = 8
+    n_heads: int = 16
+    n_extra_heads: int = 2
+    mlp_ratio: int = 2
+    in_node_dim: int = 6          # atom_types + include_fc_charge
+    edge_ch: int = 2
+    spatial_cut_off: float = 2.0
+    edge_quan_th: float = 0.0
+    cond_ch: int = 0              # >0 => cond_DGT_concat
+
+    @staticmethod
+    def from_config(config):
+        m = config.model
+        return Hyper(nf=m.nf, n_layers=m.n_layers, n_heads=m.n_heads, n_extra_heads=m.n_extra_heads,
+                     mlp_ratio=m.mlp_ratio,
+                     in_node_dim=config.data.atom_types + int(m.include_fc_charge),
+                     edge_ch=m.edge_ch, spatial_cut_off=float(m.spatial_cut_off),
+                     edge_quan_th=float(m.edge_quan_th),
+                     cond_ch=int(m.cond_ch) if m.name == 'cond_DGT_concat' else 0)
+
+    @property
+    def de(self):
+        return self.nf // 4
+
+    @property
+    def tdim(self):
+        return self.nf * 4
+
+    @property
+    def sub_heads(self):
+        return self.n_heads - self.n_extra_heads
+
+    @property
+    def head_ch(self):                      # C
+        return self.nf // self.n_heads
+
+    @property
+    def sub_ch(self):                       # SC
+        return (self.n_heads * self.head_ch) // self.sub_heads
+
+
+def _lin(p, name, x, bias=True):
+    return F.linear(x, p[name + '.weight'], p[name + '.bias'] if bias else None)
+
+
+def _ln(x):
+    return F.layer_norm(x, (x.shape[-1],), None, None, 1e-6)
+
+
+def _gbf(p, prefix, d2, tau_silu):
+    """CondGaussianLayer: (scale, shift) chunk order; pi literal 3.14159; sigma = |w| + 1e-5."""
+    ss = _lin(p, prefix + '.time_mlp.1', tau_silu)
+    scale, shift = ss[..., 0:1], ss[..., 1:2]
+    x = d2 * (scale + 1) + shift
+    mean = p[prefix + '.means.weight'].float().view(-1)
+    std = p[prefix + '.stds.weight'].float().view(-1).abs() + 1e-5
+    a = (2 * 3.14159) ** 0.5
+    g = torch.exp(-0.5 * (((x - mean) / std) ** 2)) / (a * std)
+    return torch.cat([x, g], dim=-1)
+
+
+def time_embedding(p, hp, noise_level, context=None):
+    """time_mlp: [x, sin, cos] -> Linear -> GELU(erf) -> Linear (+ cond_lin(cond_mlp(context)))."""
+    x = noise_level.unsqueeze(-1)
+    fr = x * p['time_mlp.0.weights'].unsqueeze(0) * 2 * math.pi
+    feat = torch.cat([x, fr.sin(), fr.cos()], dim=-1)
+    t = _lin(p, 'time_mlp.3', F.gelu(_lin(p, 'time_mlp.1', feat)))
+    if hp.cond_ch > 0:
+        c = context.unsqueeze(-1)
+        c = _lin(p, 'cond_mlp.2', F.gelu(_lin(p, 'cond_mlp.0', c)))
+        t = t + _lin(p, 'cond_lin', c.reshape(c.shape[0], -1))
+    return t
+
+
+# ----------------------------------------------------------------------------------------------
+# faithful sparse formulation
+# ----------------------------------------------------------------------------------------------
+def forward_faithful(p, hp, xh, node_mask, edge_mask, edge_x, cond_x=None, cond_edge_x=None,
+                     noise_level=None, context=None):
+    bs, N, _ = xh.shape
+    D, De, L = hp.nf, hp.de, hp.n_layers
+    SH, SC, H, C = hp.sub_heads, hp.sub_ch, hp.n_heads, hp.head_ch
+    pos = xh[:, :, 0:3].reshape(bs * N, 3).clone()
+    h = xh[:, :, 3:].reshape(bs * N, -1)
+    nmask = node_mask.reshape(bs * N, 1)
+
+    adj = edge_mask.reshape(bs, N, N)
+    bidx, iidx, jidx = adj.nonzero(as_tuple=True)
+    row = bidx * N + iidx                       # edge_index[0]  (source of attention, row of pos update)
+    col = bidx * N + jidx                       # edge_index[1]  (attention target)
+    E = row.numel()
+    n_rows = bs * N
+
+    if cond_x is None:
+        cond_x = torch.zeros_like(xh)
+        cond_edge_x = torch.zeros_like(edge_x)
+        adj2d = torch.ones(E, 1)
+    else:
+        adj2d = (cond_edge_x[bidx, iidx, jidx][:, 0:1] >= hp.edge_quan_th).float()
+    cpos = cond_x[:, :, 0:3].reshape(bs * N, 3)
+    h = torch.cat([h, cond_x[:, :, 3:].reshape(bs * N, -1)], dim=-1)
+
+    temb = time_embedding(p, hp, noise_level, context)          # [B, T]
+    node_t = F.silu(temb).unsqueeze(1).expand(-1, N, -1).reshape(bs * N, -1)
+    edge_t = F.silu(temb)[bidx]                                   # [E, T] (the reference's big gather)
+
+    cd = cpos[row] - cpos[col]
+    d2c = (cd ** 2).sum(1, keepdim=True)
+    adjsp = (d2c <= hp.spatial_cut_off).float()
+    if d2c.sum() == 0:
+        dist0 = d2c.repeat(1, De)
+    else:
+        dist0 = _gbf(p, 'dist_layer', d2c, edge_t)
+    extra = torch.cat([adj2d, adjsp], dim=-1)
+    e = torch.cat([edge_x[bidx, iidx, jidx], cond_edge_x[bidx, iidx, jidx], dist0], dim=-1)
+    h = _lin(p, 'node_emb', h)
+    e = _lin(p, 'edge_emb', e)
+
+    atom_hids, edge_hids = [h], [e]
+    for l in range(L):
+        b = 'e_block_%d' % l
+        h_in, e_in = h, e
+        diff = pos[row] - pos[col]
+        d2 = (diff ** 2).sum(1, keepdim=True)
+        G = _gbf(p, b + '.dist_layer', d2, edge_t)
+        e = _lin(p, b + '.edge_emb', torch.cat([G, e], dim=-1))
+        ns1, nc1, ng1, ns2, nc2, ng2 = _lin(p, b + '.node_time_mlp.1', node_t).chunk(6, dim=1)
+        es1, ec1, eg1, es2, ec2, eg2 = _lin(p, b + '.edge_time_mlp.1', edge_t).chunk(6, dim=1)
+        ht = _ln(h) * (1 + nc1) + ns1
+        et = _ln(e) * (1 + ec1) + es1
+        # attention (target = col = edge_index[1], source = row)
+        q = _lin(p, b + '.attn_mpnn.lin_query', ht).reshape(-1, SH, SC)
+        k = _lin(p, b + '.attn_mpnn.lin_key', ht).reshape(-1, SH, SC)
+        v = _lin(p, b + '.attn_mpnn.lin_value', ht).reshape(-1, H, C)
+        t0 = torch.tanh(_lin(p, b + '.attn_mpnn.lin_edge0', et, bias=False).view(-1, SH, SC))
+        s = (q[col] * k[row] * t0).sum(-1) / math.sqrt(C)
+        xh_heads = extra.clone()
+        xh_heads[xh_heads == 0.] = -1e10
+        s = torch.cat([xh_heads, s], dim=-1)                      # [E, H]
+        idx = col.view(-1, 1).expand_as(s)
+        smax = torch.full((n_rows, H), float('-inf')).scatter_reduce(0, idx, s, 'amax', include_self=True)
+        ex = (s - smax[col]).exp()
+        ssum = torch.zeros(n_rows, H).scatter_add_(0, idx, ex)
+        alpha = ex / (ssum[col] + 1e-16)
+        t1 = torch.tanh(_lin(p, b + '.attn_mpnn.lin_edge1', et, bias=False).view(-1, H, C))
+        msg = (v[row] * t1 * alpha.view(-1, H, 1)).reshape(E, D)
+        hhat = torch.zeros(n_rows, D).index_add_(0, col, msg)
+        ehat = _lin(p, b + '.node2edge_lin', hhat[row] + hhat[col])
+        hn = h_in + ng1 * hhat
+        hn = (_ln(hn) * (1 + nc2) + ns2) * nmask
+        h = (hn + ng2 * _lin(p, b + '.ff_linear2', F.silu(_lin(p, b + '.ff_linear1', hn)))) * nmask
+        en = e_in + eg1 * ehat
+        en = _ln(en) * (1 + ec2) + es2
+        e = en + eg2 * _lin(p, b + '.ff_linear4', F.silu(_lin(p, b + '.ff_linear3', en)))
+        # equivariant update: note (shift, scale) order, row-grouped aggregation
+        u = _lin(p, b + '.equi_update.input_lin', torch.cat([h[row], h[col], e, G], dim=1))
+        shsc = _lin(p, b + '.equi_update.time_mlp.1', edge_t)
+        sh, sc = shsc.chunk(2, dim=1)
+        u = _ln(u) * (1 + sc) + sh
+        inv = torch.tanh(F.linear(F.silu(_lin(p, b + '.equi_update.coord_mlp.0', u)),
+                                  p[b + '.equi_update.coord_mlp.2.weight']))
+        inv = (inv * torch.cat([torch.ones(E, 1), extra], dim=-1)).mean(-1, keepdim=True)
+        nrm = diff.norm(dim=-1, keepdim=True).clamp(min=1e-8)
+        trans = diff / nrm * p[b + '.equi_update.coord_norm.scale'] * inv
+        pos = pos + torch.zeros(n_rows, 3).index_add_(0, row, trans)
+        # centre of mass
+        pm = pos.reshape(bs, N, 3)
+        pm = pm - pm.sum(1, keepdim=True) / node_mask.sum(1, keepdim=True) * node_mask
+        pos = pm.reshape(bs * N, 3)
+        atom_hids.append(_lin(p, 'node_%d' % l, h))
+        edge_hids.append(_lin(p, 'edge_%d' % l, e))
+
+    ah = torch.cat(atom_hids, dim=-1)
+    eh = torch.cat(edge_hids, dim=-1)
+    atom_pred = _mlp3(p, 'node_pred_mlp', ah).reshape(bs, N, -1) * node_mask
+    epred = torch.cat([_mlp3(p, 'edge_exist_mlp', eh), _mlp3(p, 'edge_type_mlp', eh)], dim=-1)
+    edge_final = torch.zeros(bs, N, N, epred.shape[-1])
+    edge_final[bidx, iidx, jidx] = epred
+    edge_final = 0.5 * (edge_final + edge_final.permute(0, 2, 1, 3))
+    pos = pos * nmask
+    if torch.any(torch.isnan(pos)):
+        pos = torch.zeros_like(pos)
+    pm = pos.reshape(bs, N, 3)
+    pm = pm - pm.sum(1, keepdim=True) / node_mask.sum(1, keepdim=True) * node_mask
+    return torch.cat([pm, atom_pred], dim=2), edge_final
+
+
+def _mlp3(p, name, x):
+    x = F.silu(_lin(p, name + '.0', x))
+    x = F.silu(_lin(p, name + '.2', x))
+    return _lin(p, name + '.4', x)
+
+
+# ----------------------------------------------------------------------------------------------
+# dense per-molecule formulation (what the kernels compute)
+# ----------------------------------------------------------------------------------------------
+def forward_dense(p, hp, xh, node_mask, edge_mask, edge_x, cond_x=None, cond_edge_x=None,
+                  noise_level=None, context=None, return_intermediates=False):
+    """Dense restatement; loops over molecules (kept simple: it is a checker, not a product).
+
+    Index convention inside one molecule: tensors are [a, c, ...] with a = row = source,
+    c = column = target.  Softmax/aggregation run over a (dim 0); the position update sums over c.
+    """
+    bs, N, _ = xh.shape
+    D, De, L = hp.nf, hp.de, hp.n_layers
+    SH, SC, H, C = hp.sub_heads, hp.sub_ch, hp.n_heads, hp.head_ch
+    n_nodes = node_mask.reshape(bs, N).sum(1).long().tolist()
+    has_cond = cond_x is not None
+    temb = time_embedding(p, hp, noise_level, context)
+    tau = F.silu(temb)                                           # [B, T]
+
+    # batch-global first-step switch (mol_gnn.py:544): sum of squared self-cond distances == 0
+    if has_cond:
+        tot = 0.0
+        for b in range(bs):
+            n = n_nodes[b]
+            cp = cond_x[b, :n, 0:3]
+            dd = ((cp[:, None, :] - cp[None, :, :]) ** 2).sum(-1)
+            tot = tot + dd.sum()
+        first = bool(tot == 0)
+    else:
+        first = True
+
+    out_x = torch.zeros(bs, N, 3 + hp.in_node_dim)
+    out_e = torch.zeros(bs, N, N, hp.edge_ch)
+    inter = [] if return_intermediates else None
+    pos_all = []
+    for b in range(bs):
+        n = n_nodes[b]
+        tb = tau[b:b + 1]                                         # [1, T]
+        x = xh[b, :n, 0:3].clone()
+        feat = xh[b, :n, 3:]
+        ex = edge_x[b, :n, :n]
+        offd = ~torch.eye(n, dtype=torch.bool)
+        if has_cond:
+            cpos = cond_x[b, :n, 0:3]
+            cfeat = cond_x[b, :n, 3:]
+            cex = cond_edge_x[b, :n, :n]
+            adj2d = (cex[..., 0] >= hp.edge_quan_th).float()
+        else:
+            cpos = torch.zeros(n, 3)
+            cfeat = torch.zeros_like(feat)
+            cex = torch.zeros_like(ex)
+            adj2d = torch.ones(n, n)
+        d2c = ((cpos[:, None, :] - cpos[None, :, :]) ** 2).sum(-1, keepdim=True)   # [n,n,1]
+        adjsp = (d2c[..., 0] <= hp.spatial_cut_off).float()
+        if first:
+            G0 = torch.zeros(n, n, De)
+        else:
+            G0 = _gbf(p, 'dist_layer', d2c, tb)
+        e = _lin(p, 'edge_emb', torch.cat([ex, cex, G0], dim=-1))                   # [n,n,De]
+        h = _lin(p, 'node_emb', torch.cat([feat, cfeat], dim=-1))                  # [n,D]
+        ah, eh = [h], [e]
+        negmask = torch.where(offd, 0.0, float('-inf'))                             # exclude a == c
+        blocks = []
+        for l in range(L):
+            bk = 'e_block_%d' % l
+            diff = x[:, None, :] - x[None, :, :]                                    # x_a - x_c
+            d2 = (diff ** 2).sum(-1, keepdim=True)
+            G = _gbf(p, bk + '.dist_layer', d2, tb)
+            ns1, nc1, ng1, ns2, nc2, ng2 = _lin(p, bk + '.node_time_mlp.1', tb).chunk(6, dim=1)
+            es1, ec1, eg1, es2, ec2, eg2 = _lin(p, bk + '.edge_time_mlp.1', tb).chunk(6, dim=1)
+            ht = _ln(h) * (1 + nc1) + ns1
+            et = _ln(_lin(p, bk + '.edge_emb', torch.cat([G, e], dim=-1))) * (1 + ec1) + es1
+            q = _lin(p, bk + '.attn_mpnn.lin_query', ht).reshape(n, SH, SC)
+            k = _lin(p, bk + '.attn_mpnn.lin_key', ht).reshape(n, SH, SC)
+            v = _lin(p, bk + '.attn_mpnn.lin_value', ht).reshape(n, H, C)
+            t0 = torch.tanh(_lin(p, bk + '.attn_mpnn.lin_edge0', et, bias=False)).reshape(n, n, SH, SC)
+            S = (q[None, :, :, :] * k[:, None, :, :] * t0).sum(-1) / math.sqrt(C)   # [a,c,SH]
+            h0 = torch.where(adj2d > 0, 1.0, -1e10)
+            h1 = torch.where(adjsp > 0, 1.0, -1e10)
+            S = torch.cat([h0[..., None], h1[..., None], S], dim=-1)               # [a,c,H]
+            Sm = S + negmask[..., None]
+            if n > 1:
+                m = Sm.max(dim=0, keepdim=True).values
+                ex_ = (Sm - m).exp()
+                alpha = ex_ / (ex_.sum(0, keepdim=True) + 1e-16)
+            else:
+                alpha = torch.zeros_like(S)
+            t1 = torch.tanh(_lin(p, bk + '.attn_mpnn.lin_edge1', et, bias=False)).reshape(n, n, H, C)
+            hhat = (v[:, None, :, :] * t1 * alpha[..., None]).sum(0).reshape(n, D)  # sum over sources a
+            n2e = F.linear(hhat, p[bk + '.node2edge_lin.weight'])                  # per node
+            ehat = n2e[:, None, :] + n2e[None, :, :] + p[bk + '.node2edge_lin.bias']
+            hn = _ln(h + ng1 * hhat) * (1 + nc2) + ns2
+            h = hn + ng2 * _lin(p, bk + '.ff_linear2', F.silu(_lin(p, bk + '.ff_linear1', hn)))
+            en = _ln(e + eg1 * ehat) * (1 + ec2) + es2
+            e = en + eg2 * _lin(p, bk + '.ff_linear4', F.silu(_lin(p, bk + '.ff_linear3', en)))
+            W = p[bk + '.equi_update.input_lin.weight']
+            Wr, Wc, We, Wd = W[:, :D], W[:, D:2 * D], W[:, 2 * D:2 * D + De], W[:, 2 * D + De:]
+            pre = (F.linear(h, Wr)[:, None, :] + F.linear(h, Wc)[None, :, :] + F.linear(e, We)
+                   + F.linear(G, Wd) + p[bk + '.equi_update.input_lin.bias'])
+            sh, sc = _lin(p, bk + '.equi_update.time_mlp.1', tb).chunk(2, dim=1)
+            u = _ln(pre) * (1 + sc) + sh
+            inv = torch.tanh(F.linear(F.silu(_lin(p, bk + '.equi_update.coord_mlp.0', u)),
+                                      p[bk + '.equi_update.coord_mlp.2.weight']))   # [a,c,3]
+            adjs = torch.stack([torch.ones(n, n), adj2d, adjsp], dim=-1)
+            iota = (inv * adjs).mean(-1, keepdim=True)
+            nrm = diff.norm(dim=-1, keepdim=True).clamp(min=1e-8)
+            trans = diff / nrm * p[bk + '.equi_update.coord_norm.scale'] * iota
+            trans = trans * offd[..., None]
+            x = x + trans.sum(1)                                                    # sum over c
+            x = x - x.mean(0, keepdim=True)
+            ah.append(_lin(p, 'node_%d' % l, h))
+            eh.append(_lin(p, 'edge_%d' % l, e))
+            if return_intermediates:
+                blocks.append(dict(h=h.clone(), e=e.clone(), pos=x.clone(), hhat=hhat.clone(),
+                                   S=S.clone(), alpha=alpha.clone()))
+        ahc = torch.cat(ah, dim=-1)
+        ehc = torch.cat(eh, dim=-1)
+        atom = _mlp3(p, 'node_pred_mlp', ahc)
+        Ep = torch.cat([_mlp3(p, 'edge_exist_mlp', ehc), _mlp3(p, 'edge_type_mlp', ehc)], dim=-1)
+        Ep = Ep * offd[..., None]
+        out_e[b, :n, :n] = 0.5 * (Ep + Ep.transpose(0, 1))
+        out_x[b, :n, 3:] = atom
+        pos_all.append(x)
+        if return_intermediates:
+            inter.append(blocks)
+    nan = any(bool(torch.isnan(x).any()) for x in pos_all)
+    for b in range(bs):
+        n = n_nodes[b]
+        x = torch.zeros_like(pos_all[b]) if nan else pos_all[b]
+        out_x[b, :n, 0:3] = x - x.mean(0, keepdim=True)
+    if return_intermediates:
+        return out_x, out_e, inter
+    return out_x, out_e
+
+
+# ----------------------------------------------------------------------------------------------
+# algorithmic work model — used by bench.py for roofline.achieved
+# ----------------------------------------------------------------------------------------------
+def algorithmic_flops(hp, n_nodes):
+    """FLOPs (multiply-add = 2) of one forward for molecules with the given atom counts."""
+    D, De, T, L, r = hp.nf, hp.de, hp.tdim, hp.n_layers, hp.mlp_ratio
+    QK = hp.sub_heads * hp.sub_ch
+    XH = hp.n_extra_heads
+    f_edge = (2 * (2 * De) * De + 2 * De * QK + 2 * De * D + 2 * 2 * De * r * De + 2 * (2 * De) * D
+              + 2 * D * D + 2 * D * (1 + XH) + 2 * De * ((2 * De) // L) + (3 * QK + 3 * D)
+              + 8 * (De - 1) + (24 * De + 8 * D))
+    f_node = (2 * D * (2 * QK + D) + 2 * 2 * D * r * D + 2 * D * ((2 * D) // L) + 2 * D * De
+              + 2 * 2 * D * D)
+    f_mol = 2 * T * (6 * D + 6 * De + 2 * D + 2)
+    n = torch.as_tensor(n_nodes, dtype=torch.float64)
+    E = float((n * (n - 1)).sum())
+    Nn = float(n.sum())
+    B = float(n.numel())
+    nd, ch = hp.in_node_dim, hp.edge_ch
+    catn = ((2 * D) // L) * L + D
+    cate = ((2 * De) // L) * L + De
+    f_pro_edge = 2 * (2 * ch + De) * De + 8 * (De - 1)
+    f_pro_node = 2 * (2 * nd) * D
+    f_head_node = 2 * catn * D + 2 * D * (D // 2) + 2 * (D // 2) * nd
+    f_head_edge = 2 * (2 * cate * De + 2 * De * (De // 2)) + 2 * (De // 2) * ch
+    f_time = 2 * 17 * T + 2 * T * T
+    total = (L * (E * f_edge + Nn * f_node + B * f_mol) + E * (f_pro_edge + f_head_edge)
+             + Nn * (f_pro_node + f_head_node) + B * f_time)
+    return dict(total=total, per_edge_block=f_edge, per_node_block=f_node, per_mol_block=f_mol,
+                E=E, Nn=Nn)
+
+
+def algorithmic_bytes(hp, n_nodes):
+    """Fused-per-block HBM floor: edge state read+write once per block, node state
+    likewise, plus dense input/output edge tensors."""
+    D, De, L, ch = hp.nf, hp.de, hp.n_layers, hp.edge_ch
+    n = torch.as_tensor(n_nodes, dtype=torch.float64)
+    E = float((n * (n - 1)).sum())
+    Nn = float(n.sum())
+    return L * (E * (2 * De * 4 + 8) + Nn * (2 * D * 4 + 24)) + E * (2 * ch * 4 * 2 + ch * 4)
