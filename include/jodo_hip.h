@@ -1,4 +1,26 @@
-/* libjodo_hip.so — C ABI of the MI355X-native JODO DGT denoising hot path.  (placeholder; grows) */
+/* libjodo_hip.so — C ABI of the MI355X-native JODO DGT denoising hot path.
+ *
+ * What this replaces in the reference (GRAPH-0/JODO, pure Python; there is no upstream FFI, so the
+ * "reference interface" each entry point stands for is the Python call it makes redundant):
+ *
+ *   jodo_plan_*          <- the per-call dense->sparse conversion in DGT_concat.forward
+ *                           (models/mol_gnn.py:512-514: edge_mask.nonzero(), dense_to_sparse) —
+ *                           built once per (batch of atom counts) instead of once per step
+ *   jodo_dgt_forward     <- DGT_concat.forward          models/mol_gnn.py:491-594
+ *                           Cond_DGT_concat.forward     models/mol_gnn.py:687-794
+ *                           (incl. EquivariantMixBlock.forward :270-322, TransMixLayer
+ *                           models/layers.py:131-186, MultiCondEquiUpdate :71-94,
+ *                           CondGaussianLayer models/layers.py:328-334, time_mlp :481-489)
+ *   jodo_debug_mlp       <- (no reference counterpart) hardware self-test of the MFMA lane maps
+ *
+ * Conventions: every function returns 0 on success or a negative JODO_ERR_* code and records a
+ * message retrievable with jodo_last_error() (thread-local).  The library never allocates or frees
+ * device memory: the caller (PyTorch) owns every device buffer and passes raw pointers; sizes are
+ * queried up front.  All launches go to the hipStream_t passed in (as void*); there are no hidden
+ * synchronisations and no internal streams.  A plan handle is host memory owned by the library
+ * (jodo_plan_destroy frees it); handles are independent and re-entrant, one handle is not
+ * thread-safe.  Tensors are contiguous row-major fp32 in the reference's dense layouts.
+ */
 #ifndef JODO_HIP_H
 #define JODO_HIP_H
 #include <stddef.h>
@@ -6,13 +28,96 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
 #define JODO_OK 0
 #define JODO_ERR_ARG (-1)
 #define JODO_ERR_LAUNCH (-2)
 #define JODO_ERR_UNSUPPORTED (-3)
+
+/* Model hyper-parameters (config.model.* / config.data.* of the reference's configs). */
+typedef struct {
+    int32_t nf;          /* D: node hidden width (256)                          */
+    int32_t n_layers;    /* L                                                   */
+    int32_t n_heads;     /* H (16)                                              */
+    int32_t n_extra;     /* XH: adjacency heads (2)                             */
+    int32_t mlp_ratio;   /* r                                                   */
+    int32_t in_node_dim; /* nd = atom_types + include_fc_charge                 */
+    int32_t edge_ch;     /* ch                                                  */
+    int32_t cond_ch;     /* 0 = DGT_concat, >0 = cond_DGT_concat                */
+    float spatial_cut_off;
+    float edge_quan_th;
+} jodo_cfg;
+
+/* Slots of the weight-offset table handed to jodo_dgt_forward (offsets in floats into the packed
+ * weight blob produced by jodo_amd/packing_model.py; the Python packer and this enum are kept in
+ * lock-step by tests/test_packing.py). */
+enum jodo_wslot_global {
+    JW_TIME_FREQ = 0, JW_TIME_W1, JW_TIME_B1, JW_TIME_W3, JW_TIME_B3,
+    JW_COND_W0, JW_COND_B0, JW_COND_W2, JW_COND_B2, JW_COND_LIN_W, JW_COND_LIN_B,
+    JW_MOD_W, JW_MOD_B,
+    JW_NODE_EMB_W, JW_NODE_EMB_B, JW_EDGE_EMB_W, JW_EDGE_EMB_B, JW_GBF_TOP,
+    JW_NH1_W, JW_NH1_B, JW_NH2_W, JW_NH2_B, JW_NH3_W, JW_NH3_B,
+    JW_EH1_W, JW_EH1_B, JW_EH2_W, JW_EH2_B, JW_EH3_W, JW_EH3_B,
+    JW_GLOBAL_COUNT
+};
+enum jodo_wslot_block {
+    JB_WQ = 0, JB_BQ, JB_WK, JB_BK, JB_WV, JB_BV,
+    JB_EE_W, JB_EE_B, JB_LE0_W, JB_LE1_W, JB_N2E_W, JB_N2E_B,
+    JB_FF1_W, JB_FF1_B, JB_FF2_W, JB_FF2_B, JB_FF3_W, JB_FF3_B, JB_FF4_W, JB_FF4_B,
+    JB_INE_W, JB_ROW_W, JB_COL_W, JB_IN_B, JB_C0_W, JB_C0_B, JB_C2_W, JB_CSCALE,
+    JB_NRO_W, JB_NRO_B, JB_ERO_W, JB_ERO_B, JB_GBF,
+    JB_BLOCK_COUNT
+};
+/* table length = JW_GLOBAL_COUNT + n_layers * JB_BLOCK_COUNT; block l slot s lives at
+ * JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + s */
+
+typedef struct jodo_plan jodo_plan;
+
+/* Build the execution plan for a batch: B molecules with n_nodes[b] atoms (host array), padded
+ * width N of the dense API tensors.  Molecules are ordered by size internally; masks are implied
+ * (prefix masks, diagonal excluded), which is what the reference's samplers produce
+ * (sampling.py:193-201).  max_chunk = sources per edge work item (0 = default). */
+int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes_host, int max_chunk,
+                     jodo_plan** out);
+void jodo_plan_destroy(jodo_plan* plan);
+/* bytes of the device-side descriptor tables / of the scratch workspace for this plan */
+size_t jodo_plan_desc_bytes(const jodo_plan* plan);
+size_t jodo_plan_workspace_bytes(const jodo_plan* plan);
+/* number of floats in the time-modulation vector of one molecule (for sizing/debug) */
+int64_t jodo_plan_mod_len(const jodo_plan* plan);
+/* copy the descriptor tables into caller-owned device memory (async on stream) */
+int jodo_plan_upload(jodo_plan* plan, void* desc_dev, void* stream);
+/* plan statistics: out[0]=packed nodes, [1]=dense edge rows (sum n^2), [2]=directed edges
+ * (sum n(n-1)), [3]=node strips, [4]=edge work items, [5]=max parts */
+int jodo_plan_stats(const jodo_plan* plan, int64_t* out6);
+
+/* One evaluation of the score network.
+ *   packed_w / woff: packed weight blob (device) and its offset table (host, see enums above)
+ *   xh [B,N,3+nd], edge_x [B,N,N,ch]; cond_x / cond_edge_x same shapes or NULL (first step);
+ *   noise_level [B]; context [B,cond_ch] or NULL
+ *   out_xh [B,N,3+nd], out_edge [B,N,N,ch] (fully written, zeros on padding)
+ *   flags_dev: int32[8] device scratch; after the call [0] = NaN guard fired (mol_gnn.py:587-589),
+ *              [1] = first-step branch taken (:544), [2] = all molecules shared one noise level
+ *   workspace: jodo_plan_workspace_bytes() bytes of device scratch
+ *   dbg: optional device buffer for intermediates (tests) or NULL */
+int jodo_dgt_forward(jodo_plan* plan, const void* desc_dev, const float* packed_w, const int64_t* woff,
+                     int n_woff, const float* xh, const float* edge_x, const float* cond_x,
+                     const float* cond_edge_x, const float* noise_level, const float* context,
+                     float* out_xh, float* out_edge, int32_t* flags_dev, void* workspace, void* stream);
+
+/* debug: copy an internal per-block intermediate out of the workspace after a forward.
+ * what: 0 = h [Nn,D], 1 = e [rows,De], 2 = pos [Nn,4] (raw, not centred), 3 = hhat [Nn,D] of the last
+ * block run.  dst must hold the full array; returns element count via *count. */
+int jodo_debug_fetch(jodo_plan* plan, const void* workspace, int what, float* dst_dev, int64_t* count,
+                     void* stream);
+/* limit the number of DGT blocks executed by jodo_dgt_forward (tests; <0 = all) */
+int jodo_debug_set_max_blocks(jodo_plan* plan, int max_blocks);
+
 const char* jodo_last_error(void);
+
 int jodo_debug_mlp(const float* x, int rows, const float* w1, const float* b1, const float* w2,
                    const float* b2, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

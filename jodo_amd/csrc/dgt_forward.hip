@@ -1,0 +1,207 @@
+// jodo_dgt_forward: launch sequence of one score-network evaluation (see include/jodo_hip.h).
+// Host code only builds the argument block and enqueues kernels on the caller's stream; no
+// synchronisation, no allocation.
+#include "dgt_kernels_pre.h"
+#include "dgt_kernels_block.h"
+#include "dgt_kernels_post.h"
+#include "jodo_hip_internal.h"
+
+using namespace jd;
+
+namespace {
+
+PlanDev make_plan_dev(const jodo_plan* p, const void* desc_dev) {
+    const int* base = static_cast<const int*>(desc_dev);
+    PlanDev d;
+    d.node_b = base + p->off_node_b; d.node_i = base + p->off_node_i; d.node_n = base + p->off_node_n;
+    d.node_noff = base + p->off_node_noff; d.node_eoff = base + p->off_node_eoff;
+    d.orig_n = base + p->off_orig_n; d.orig_noff = base + p->off_orig_noff; d.orig_eoff = base + p->off_orig_eoff;
+    d.item_strip = base + p->off_item_strip; d.item_t0 = base + p->off_item_t0; d.item_t1 = base + p->off_item_t1;
+    d.item_part = base + p->off_item_part; d.strip_parts = base + p->off_strip_parts;
+    d.Nn = p->Nn; d.Nn_pad = p->Nn_pad; d.n_strips = p->n_strips; d.n_items = p->n_items; d.B = p->B; d.N = p->N;
+    d.max_parts = p->max_parts; d.rows = p->rows;
+    return d;
+}
+
+template <typename T>
+T* ws_ptr(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(ws) + off); }
+
+void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
+    const WsLayout& w = p->ws;
+    A.hid1 = ws_ptr<float>(ws, w.hid1); A.temb = ws_ptr<float>(ws, w.temb); A.mods = ws_ptr<float>(ws, w.mods);
+    A.condh = ws_ptr<float>(ws, w.condh); A.condh2 = ws_ptr<float>(ws, w.condh2);
+    A.dpos = ws_ptr<float>(ws, w.dpos); A.cpos = ws_ptr<float>(ws, w.cpos); A.feat = ws_ptr<float>(ws, w.feat);
+    A.h = ws_ptr<float>(ws, w.h); A.hhat = ws_ptr<float>(ws, w.hhat); A.q = ws_ptr<float>(ws, w.q);
+    A.k = ws_ptr<float>(ws, w.k); A.v = ws_ptr<float>(ws, w.v); A.n2e = ws_ptr<float>(ws, w.n2e);
+    A.wrow = ws_ptr<float>(ws, w.wrow); A.wcol = ws_ptr<float>(ws, w.wcol); A.ahid = ws_ptr<float>(ws, w.ahid);
+    A.stats = ws_ptr<float>(ws, w.stats); A.apred = ws_ptr<float>(ws, w.apred);
+    A.eflag = ws_ptr<int>(ws, w.eflag); A.e = ws_ptr<float>(ws, w.e); A.et = ws_ptr<float>(ws, w.et);
+    A.S = ws_ptr<float>(ws, w.S); A.ehid = ws_ptr<float>(ws, w.ehid); A.epred = ws_ptr<float>(ws, w.epred);
+}
+
+int rowgemm(hipStream_t st, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* Wp, const float* bias,
+            int rows, int K, int NB, int in_act, int accumulate, const int* uniform_flag) {
+    if (K % 64 != 0) return jodo_set_error(JODO_ERR_ARG, "rowgemm: K=%d not a multiple of 64", K);
+    RowGemmArgs G{X, ldx, Y, ldy, Wp, bias, rows, K, NB, in_act, accumulate, uniform_flag};
+    dim3 grid((rows + 31) / 32, (NB + 3) / 4);
+    hipLaunchKernelGGL(k_rowgemm, grid, dim3(64), 0, st, G);
+    return jodo_check_launch("k_rowgemm");
+}
+
+#define LAUNCH(kern, grid, block, ...)                                  \
+    do {                                                                \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, __VA_ARGS__); \
+        int rc_ = jodo_check_launch(#kern);                             \
+        if (rc_ != JODO_OK) return rc_;                                 \
+    } while (0)
+
+template <int KQ>
+int launch_embed_nodes(hipStream_t st, const KArgs& A) {
+    LAUNCH(k_embed_nodes<KQ>, A.pd.n_strips, 64, A);
+    return JODO_OK;
+}
+
+template <int NBK>
+int launch_edge_head(hipStream_t st, const KArgs& A) {
+    LAUNCH(k_edge_head<NBK>, (unsigned)((A.pd.rows + 31) / 32), 64, A);
+    return JODO_OK;
+}
+
+}  // namespace
+
+extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float* packed_w, const int64_t* woff,
+                                int n_woff, const float* xh, const float* edge_x, const float* cond_x,
+                                const float* cond_edge_x, const float* noise_level, const float* context,
+                                float* out_xh, float* out_edge, int32_t* flags_dev, void* workspace, void* stream) {
+    if (!p || !desc_dev || !packed_w || !woff || !xh || !edge_x || !noise_level || !out_xh || !out_edge || !flags_dev ||
+        !workspace)
+        return jodo_set_error(JODO_ERR_ARG, "dgt_forward: null argument");
+    const DgtDims& d = p->dims;
+    if (n_woff != JW_GLOBAL_COUNT + d.L * JB_BLOCK_COUNT)
+        return jodo_set_error(JODO_ERR_ARG, "dgt_forward: weight table has %d slots, expected %d", n_woff,
+                              JW_GLOBAL_COUNT + d.L * JB_BLOCK_COUNT);
+    if ((cond_x == nullptr) != (cond_edge_x == nullptr))
+        return jodo_set_error(JODO_ERR_ARG, "dgt_forward: cond_x and cond_edge_x must both be given or both NULL");
+    if (d.cond_ch > 0 && !context) return jodo_set_error(JODO_ERR_ARG, "dgt_forward: conditional model needs context");
+    hipStream_t st = (hipStream_t)stream;
+
+    KArgs A;
+    A.pd = make_plan_dev(p, desc_dev);
+    A.d = d;
+    A.W = packed_w;
+    for (int i = 0; i < JW_GLOBAL_COUNT; ++i) A.wg[i] = woff[i];
+    for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = 0;
+    A.mod_base = 0; A.layer = 0;
+    fill_ws(A, p, workspace);
+    float* posbuf[2] = {ws_ptr<float>(workspace, p->ws.pos0), ws_ptr<float>(workspace, p->ws.pos1)};
+    A.pos_in = posbuf[0]; A.pos_out = posbuf[1];
+    A.flags = flags_dev;
+    A.xh = xh; A.edge_x = edge_x; A.cond_x = cond_x; A.cond_edge_x = cond_edge_x; A.noise = noise_level; A.context = context;
+    A.out_xh = out_xh; A.out_edge = out_edge;
+    const float* W = packed_w;
+    int rc;
+
+    // ---- time embedding -> modulation vectors ----
+    LAUNCH(k_flags_init, 1, 256, A);
+    LAUNCH(k_time1, p->B, 256, A);
+    const int* uflag = flags_dev + FLAG_UNIFORM_T;
+    rc = rowgemm(st, A.hid1, d.T, A.temb, d.T, W + A.wg[JW_TIME_W3], W + A.wg[JW_TIME_B3], p->B, d.T, d.T / 32, 0, 0, uflag);
+    if (rc) return rc;
+    if (d.cond_ch > 0) {
+        LAUNCH(k_cond1, p->B * d.cond_ch, 256, A);
+        rc = rowgemm(st, A.condh, d.D, A.condh2, d.D, W + A.wg[JW_COND_W2], W + A.wg[JW_COND_B2], p->B * d.cond_ch, d.D,
+                     d.D / 32, 0, 0, nullptr);
+        if (rc) return rc;
+        rc = rowgemm(st, A.condh2, (int64_t)d.cond_ch * d.D, A.temb, d.T, W + A.wg[JW_COND_LIN_W], W + A.wg[JW_COND_LIN_B],
+                     p->B, d.cond_ch * d.D, d.T / 32, 0, 1, nullptr);
+        if (rc) return rc;
+    }
+    rc = rowgemm(st, A.temb, d.T, A.mods, d.Mtot, W + A.wg[JW_MOD_W], W + A.wg[JW_MOD_B], p->B, d.T, (int)(d.Mtot / 32), 1, 0,
+                 uflag);
+    if (rc) return rc;
+
+    // ---- pack inputs, embeddings ----
+    LAUNCH(k_pack_nodes, (p->Nn_pad + 255) / 256, 256, A);
+    switch (d.ndp / 8) {
+        case 1: rc = launch_embed_nodes<1>(st, A); break;
+        case 2: rc = launch_embed_nodes<2>(st, A); break;
+        case 3: rc = launch_embed_nodes<3>(st, A); break;
+        case 4: rc = launch_embed_nodes<4>(st, A); break;
+        case 5: rc = launch_embed_nodes<5>(st, A); break;
+        case 6: rc = launch_embed_nodes<6>(st, A); break;
+        case 7: rc = launch_embed_nodes<7>(st, A); break;
+        case 8: rc = launch_embed_nodes<8>(st, A); break;
+        default: return jodo_set_error(JODO_ERR_UNSUPPORTED, "node input width %d", d.ndp);
+    }
+    if (rc) return rc;
+    if (p->n_items > 0) LAUNCH(k_embed_edges, p->n_items, 64, A);
+
+    // ---- DGT blocks ----
+    const int nblocks = (p->max_blocks >= 0 && p->max_blocks < d.L) ? p->max_blocks : d.L;
+    int cur = 0;                                   // posbuf[cur] holds the positions entering the block
+    for (int l = 0; l < nblocks; ++l) {
+        A.layer = l;
+        A.mod_base = 32 + (int64_t)l * d.MB;
+        for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + i];
+        A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
+        LAUNCH(k_node_pre, p->n_strips, 64, A);
+        cur ^= 1;                                  // k_node_pre wrote the block's positions to pos_out
+        if (p->n_items > 0) LAUNCH(k_edge_scores, p->n_items, 64, A);
+        LAUNCH(k_softmax, (p->Nn + 15) / 16, 256, A);
+        if (p->n_items > 0) LAUNCH(k_edge_msgs, p->n_items, 64, A);
+        if (d.r == 2) LAUNCH(k_node_post<2>, p->n_strips, 64, A); else LAUNCH(k_node_post<4>, p->n_strips, 64, A);
+        if (p->n_items > 0) {
+            if (d.r == 2) LAUNCH(k_edge_update<2>, p->n_items, 64, A); else LAUNCH(k_edge_update<4>, p->n_items, 64, A);
+        }
+    }
+    // ---- heads + outputs ----
+    A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
+    A.layer = nblocks;                             // k_pos_final adds the last block's partial updates if any ran
+    if (nblocks == 0) {                            // no update to add: copy through
+        hipError_t e = hipMemsetAsync(A.dpos, 0, (size_t)p->Nn_pad * p->max_parts * 4 * sizeof(float), st);
+        if (e != hipSuccess) return jodo_set_error(JODO_ERR_LAUNCH, "memset: %s", hipGetErrorString(e));
+    }
+    LAUNCH(k_pos_final, (p->Nn_pad + 255) / 256, 256, A);
+    p->last_pos_buf = cur ^ 1;
+    LAUNCH(k_node_head, p->n_strips, 64, A);
+    switch (d.KEH / 32) {
+        case 3: rc = launch_edge_head<3>(st, A); break;
+        case 4: rc = launch_edge_head<4>(st, A); break;
+        case 5: rc = launch_edge_head<5>(st, A); break;
+        case 6: rc = launch_edge_head<6>(st, A); break;
+        case 7: rc = launch_edge_head<7>(st, A); break;
+        case 8: rc = launch_edge_head<8>(st, A); break;
+        case 9: rc = launch_edge_head<9>(st, A); break;
+        case 10: rc = launch_edge_head<10>(st, A); break;
+        default: return jodo_set_error(JODO_ERR_UNSUPPORTED, "edge head width %d", d.KEH);
+    }
+    if (rc) return rc;
+    LAUNCH(k_finalize_nodes, (p->B * p->N + 255) / 256, 256, A);
+    {
+        const size_t tot = (size_t)p->B * p->N * p->N;
+        LAUNCH(k_finalize_edges, (unsigned)((tot + 255) / 256), 256, A);
+    }
+    return JODO_OK;
+}
+
+extern "C" int jodo_debug_fetch(jodo_plan* p, const void* workspace, int what, float* dst, int64_t* count, void* stream) {
+    if (!p || !workspace || !dst || !count) return jodo_set_error(JODO_ERR_ARG, "debug_fetch: null");
+    const char* ws = static_cast<const char*>(workspace);
+    const void* src = nullptr;
+    int64_t n = 0;
+    switch (what) {
+        case 0: src = ws + p->ws.h; n = (int64_t)p->Nn * p->dims.D; break;
+        case 1: src = ws + p->ws.e; n = p->rows * p->dims.De; break;
+        case 2: src = ws + (p->last_pos_buf ? p->ws.pos1 : p->ws.pos0); n = (int64_t)p->Nn * 4; break;
+        case 3: src = ws + p->ws.hhat; n = (int64_t)p->Nn * p->max_parts * p->dims.D; break;
+        case 4: src = ws + p->ws.S; n = p->rows * 16; break;
+        case 5: src = ws + p->ws.mods; n = p->dims.Mtot; break;
+        case 6: src = ws + p->ws.q; n = (int64_t)p->Nn * p->dims.QKP; break;
+        case 7: src = ws + p->ws.et; n = p->rows * p->dims.De; break;
+        default: return jodo_set_error(JODO_ERR_ARG, "debug_fetch: unknown selector %d", what);
+    }
+    hipError_t e = hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) return jodo_set_error(JODO_ERR_LAUNCH, "debug_fetch: %s", hipGetErrorString(e));
+    *count = n;
+    return JODO_OK;
+}

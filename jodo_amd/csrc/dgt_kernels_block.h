@@ -1,0 +1,455 @@
+// The six kernels of one DGT block (EquivariantMixBlock.forward, models/mol_gnn.py:270-322):
+//   k_node_pre    LN1 + modulate + q/k/v projections per node            (layers.py:147-149)
+//   k_edge_scores GBF, edge_emb, LN1 + modulate, lin_edge0, q*k*tanh head scores   (:284-297, layers.py:165-174)
+//   k_softmax     per (target node, head) max / 1/sum over its sources   (layers.py:178)
+//   k_edge_msgs   lin_edge1, tanh, * v * alpha, summed over the sources of each target (layers.py:182-184)
+//   k_node_post   node2edge_lin (per node), gated residual + LN2 + FFN, W_row/W_col h, readout (:304-311, :567)
+//   k_edge_update gated residual + LN2 + FFN on edges, readout, MultiCondEquiUpdate (:313-320, :71-94, :568)
+// Lanes hold the *group* index (attention target c for scores/msgs, row a for the update) and the
+// wave iterates over the reduced index, so softmax statistics, message sums and coordinate sums
+// never cross lanes.  Edge rows are indexed r = eoff + a*n + c (a = row = source, c = column = target)
+// everywhere; the attention phases walk a column (stride n rows), the update phase a row, so no
+// symmetry of the edge state is assumed (asymmetric caller inputs behave as in the reference).
+#pragma once
+#include "dgt_kernels_common.h"
+
+namespace jd {
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_node_pre(KArgs A) {
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int strip = blockIdx.x;
+    const LaneNode L = lane_node(A, strip, j);
+    // positions entering this block: previous positions + the partial sums of the previous update
+    {
+        float4 p = reinterpret_cast<const float4*>(A.pos_in)[L.v];
+        if (A.layer > 0) {
+            const int parts = A.pd.strip_parts[strip];
+            for (int q = 0; q < parts; ++q) {
+                const float4 dp = reinterpret_cast<const float4*>(A.dpos)[(size_t)L.v * A.pd.max_parts + q];
+                p.x += dp.x; p.y += dp.y; p.z += dp.z;
+            }
+        }
+        if (half == 0) reinterpret_cast<float4*>(A.pos_out)[L.v] = p;
+    }
+    const float* mr = mod_row(A, L.b) + A.mod_base;          // node chunks: ns1, nc1, ng1, ns2, nc2, ng2
+    float hx[128];
+    load_nat<8>(A.h + (size_t)L.v * 256, half, hx);
+    layer_norm<128>(hx);
+    modulate<8>(hx, mr, mr + 256, half);
+    const int wslot[3] = {JB_WQ, JB_WK, JB_WV};
+    const int bslot[3] = {JB_BQ, JB_BK, JB_BV};
+    float* outp[3] = {A.q, A.k, A.v};
+#pragma unroll
+    for (int pj = 0; pj < 3; ++pj) {
+        const float4* w = wq(A, A.wb[wslot[pj]], lane);
+        const float* bias = A.W + A.wb[bslot[pj]];
+#pragma unroll 1
+        for (int b = 0; b < 8; ++b) {
+            f32x16 acc = mfma_block<32>(w + (size_t)b * 32 * 64, hx, zero16());
+            float r[16];
+            acc_bias(acc, bias + b * 32 + half * 16, r);
+            store16(outp[pj] + (size_t)L.v * 256 + b * 32 + half * 16, r);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scores: S stored as [row][half*8 + b] = head 2b+half  (head 0/1 = adjacency heads, 2.. learned)
+__global__ __launch_bounds__(64) void k_edge_scores(KArgs A) {
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int it = blockIdx.x;
+    const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it];
+    const LaneNode L = lane_node(A, strip, j);
+    const float* mrow = mod_row(A, L.b) + A.mod_base;
+    const float* es1 = mrow + 6 * 256;                       // edge chunks: es1, ec1, eg1, es2, ec2, eg2
+    const float* ec1 = es1 + 64;
+    const float gscale = mrow[6 * 256 + 6 * 64 + 2 * 256 + 0], gshift = mrow[6 * 256 + 6 * 64 + 2 * 256 + 1];
+    const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
+    const float* tab = A.W + A.wb[JB_GBF];
+    const float4* wEE = wq(A, A.wb[JB_EE_W], lane);
+    const float* bEE = A.W + A.wb[JB_EE_B];
+    const float4* wL0 = wq(A, A.wb[JB_LE0_W], lane);
+    const float* qrow = A.q + (size_t)L.v * 256;
+    for (int t = t0; t < t1; ++t) {
+        const bool ok = L.valid && t < L.n;
+        const int tc = ok ? t : 0;
+        const int u = L.noff + tc;
+        const size_t r = (size_t)L.eoff + (size_t)tc * L.n + L.i;      // edge (source a = t) -> (target c = i)
+        const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[u];
+        const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
+        float G[32], e[32], x[32];
+        gbf64(dx * dx + dy * dy + dz * dz, gscale, gshift, tab, half, G);
+        load_nat<2>(A.e + r * 64, half, e);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x16 acc = mfma_block<8>(wEE + (size_t)(b * 16) * 64, G, zero16());
+            acc = mfma_block<8>(wEE + (size_t)(b * 16 + 8) * 64, e, acc);
+            float rr[16];
+            acc_bias(acc, bEE + b * 32 + half * 16, rr);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) x[b * 16 + s] = rr[s];
+        }
+        layer_norm<32>(x);
+        modulate<2>(x, es1, ec1, half);
+        if (ok) store_nat<2>(A.et + r * 64, half, x);
+        // lin_edge0 -> tanh -> * q_target * k_source, reduced per head
+        const float* krow = A.k + (size_t)u * 256;
+        float mainsum[7];
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            f32x16 acc = mfma_block<8>(wL0 + (size_t)b * 8 * 64, x, zero16());
+            float qq[16], kk[16];
+            load16(qrow + b * 32 + half * 16, qq);
+            load16(krow + b * 32 + half * 16, kk);
+            float s_ = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) s_ = fmaf(tanh_f(acc[s]) * qq[s], kk[s], s_);
+            mainsum[b] = s_;                              // head 2b+half, channels 0..15
+        }
+        float tail[14];
+        {
+            f32x16 acc = mfma_block<8>(wL0 + (size_t)7 * 8 * 64, x, zero16());
+            float qq[16], kk[16];
+            load16(qrow + 7 * 32 + half * 16, qq);
+            load16(krow + 7 * 32 + half * 16, kk);
+#pragma unroll
+            for (int g = 0; g < 14; ++g) tail[g] = tanh_f(acc[g]) * qq[g] * kk[g];   // head g, channel 16+half
+        }
+        const int fl = A.eflag[r];
+        // S_g = main_g (half g&1, block g>>1) + tail_g(half 0) + tail_g(half 1), scaled by 1/sqrt(C)
+        float Sg[14];
+#pragma unroll
+        for (int g = 0; g < 14; ++g) {
+            const float own = ((g & 1) == half) ? mainsum[g >> 1] : 0.f;
+            Sg[g] = pair_sum(own + tail[g]) * 0.25f;
+        }
+        float Sout[8];                                  // slot b of this half = head 2b + half
+        Sout[0] = half == 0 ? ((fl & 1) ? 1.f : -1e10f) : ((fl & 2) ? 1.f : -1e10f);
+#pragma unroll
+        for (int b = 1; b < 8; ++b) Sout[b] = half == 0 ? Sg[2 * (b - 1)] : Sg[2 * (b - 1) + 1];
+        if (ok) {
+            float4* sp = reinterpret_cast<float4*>(A.S + r * 16 + half * 8);
+            sp[0] = make_float4(Sout[0], Sout[1], Sout[2], Sout[3]);
+            sp[1] = make_float4(Sout[4], Sout[5], Sout[6], Sout[7]);
+        }
+    }
+}
+
+// per (target node, stored head slot): max and 1/(sum exp + 1e-16) over its sources t != i
+__global__ void k_softmax(KArgs A) {
+    const int v = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int slot = threadIdx.x & 15;
+    if (v >= A.pd.Nn) return;
+    const int n = A.pd.node_n[v], i = A.pd.node_i[v];
+    const float* Sr = A.S + ((size_t)A.pd.node_eoff[v] + i) * 16 + slot;   // rows (t, i), stride n
+    const size_t st = (size_t)n * 16;
+    float m = -INFINITY;
+    for (int t = 0; t < n; ++t)
+        if (t != i) m = fmaxf(m, Sr[t * st]);
+    float sum = 0.f;
+    for (int t = 0; t < n; ++t)
+        if (t != i) sum += __expf(Sr[t * st] - m);
+    if (n <= 1) { m = 0.f; sum = 0.f; }
+    A.stats[(size_t)v * 32 + slot] = m;
+    A.stats[(size_t)v * 32 + 16 + slot] = n > 1 ? 1.f / (sum + 1e-16f) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_edge_msgs(KArgs A) {
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int it = blockIdx.x;
+    const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it], part = A.pd.item_part[it];
+    const LaneNode L = lane_node(A, strip, j);
+    float mx[8], inv[8];
+    {
+        const float4* sp = reinterpret_cast<const float4*>(A.stats + (size_t)L.v * 32 + half * 8);
+        const float4 a = sp[0], b = sp[1];
+        mx[0] = a.x; mx[1] = a.y; mx[2] = a.z; mx[3] = a.w; mx[4] = b.x; mx[5] = b.y; mx[6] = b.z; mx[7] = b.w;
+        const float4* ip = reinterpret_cast<const float4*>(A.stats + (size_t)L.v * 32 + 16 + half * 8);
+        const float4 c = ip[0], d = ip[1];
+        inv[0] = c.x; inv[1] = c.y; inv[2] = c.z; inv[3] = c.w; inv[4] = d.x; inv[5] = d.y; inv[6] = d.z; inv[7] = d.w;
+    }
+    const float4* wL1 = wq(A, A.wb[JB_LE1_W], lane);
+    float macc[128];
+#pragma unroll
+    for (int s = 0; s < 128; ++s) macc[s] = 0.f;
+    for (int t = t0; t < t1; ++t) {
+        const bool ok = L.valid && t < L.n && t != L.i;
+        const int tc = (L.valid && t < L.n) ? t : 0;
+        const int u = L.noff + tc;
+        const size_t r = (size_t)L.eoff + (size_t)tc * L.n + L.i;      // edge (source a = t) -> (target c = i)
+        float x[32];
+        load_nat<2>(A.et + r * 64, half, x);
+        float al[8];
+        {
+            const float4* sp = reinterpret_cast<const float4*>(A.S + r * 16 + half * 8);
+            const float4 a = sp[0], b = sp[1];
+            const float sv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int b2 = 0; b2 < 8; ++b2) al[b2] = ok ? fast_exp(sv[b2] - mx[b2]) * inv[b2] : 0.f;
+        }
+        const float* vrow = A.v + (size_t)u * 256;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            f32x16 acc = mfma_block<8>(wL1 + (size_t)b * 8 * 64, x, zero16());
+            float vv[16];
+            load16(vrow + b * 32 + half * 16, vv);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) macc[b * 16 + s] = fmaf(tanh_f(acc[s]) * vv[s], al[b], macc[b * 16 + s]);
+        }
+    }
+    store_nat<8>(A.hhat + ((size_t)L.v * A.pd.max_parts + part) * 256, half, macc);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int R>   // mlp_ratio
+__global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int strip = blockIdx.x;
+    const LaneNode L = lane_node(A, strip, j);
+    const float* mr = mod_row(A, L.b) + A.mod_base;
+    const float* ng1 = mr + 2 * 256, *ns2 = mr + 3 * 256, *nc2 = mr + 4 * 256, *ng2 = mr + 5 * 256;
+    float hh[128];
+#pragma unroll
+    for (int s = 0; s < 128; ++s) hh[s] = 0.f;
+    const int parts = A.pd.strip_parts[strip];
+    for (int q = 0; q < parts; ++q) {
+        float tmp[128];
+        load_nat<8>(A.hhat + ((size_t)L.v * A.pd.max_parts + q) * 256, half, tmp);
+#pragma unroll
+        for (int s = 0; s < 128; ++s) hh[s] += tmp[s];
+    }
+    // node2edge_lin applied per node (bias added on the edge side)
+    {
+        const float4* w = wq(A, A.wb[JB_N2E_W], lane);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x16 acc = mfma_block<32>(w + (size_t)b * 32 * 64, hh, zero16());
+            float r[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) r[s] = acc[s];
+            store16(A.n2e + (size_t)L.v * 64 + b * 32 + half * 16, r);
+        }
+    }
+    float hx[128];
+    load_nat<8>(A.h + (size_t)L.v * 256, half, hx);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        float g[16];
+        load16(ng1 + b * 32 + half * 16, g);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) hx[b * 16 + s] = fmaf(g[s], hh[b * 16 + s], hx[b * 16 + s]);
+    }
+    layer_norm<128>(hx);
+    modulate<8>(hx, ns2, nc2, half);
+    // FFN: hidden R*256 in chunks of 64 features; ff2 accumulates over the chunks
+    f32x16 o[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) o[b] = zero16();
+    {
+        const float4* w1 = wq(A, A.wb[JB_FF1_W], lane);
+        const float* b1 = A.W + A.wb[JB_FF1_B];
+        const float4* w2 = wq(A, A.wb[JB_FF2_W], lane);
+        constexpr int KQ2 = R * 256 / 8;                      // quads per ff2 output block
+#pragma unroll 1
+        for (int c = 0; c < R * 4; ++c) {
+            float hid[32];
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+                f32x16 acc = mfma_block<32>(w1 + (size_t)(c * 2 + b2) * 32 * 64, hx, zero16());
+                float r[16];
+                acc_bias(acc, b1 + (c * 2 + b2) * 32 + half * 16, r);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(r[s]);
+            }
+#pragma unroll
+            for (int ob = 0; ob < 8; ++ob) o[ob] = mfma_block<8>(w2 + ((size_t)ob * KQ2 + c * 8) * 64, hid, o[ob]);
+        }
+    }
+    {
+        const float* b2 = A.W + A.wb[JB_FF2_B];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            float r[16], g[16];
+            acc_bias(o[b], b2 + b * 32 + half * 16, r);
+            load16(ng2 + b * 32 + half * 16, g);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) hx[b * 16 + s] = fmaf(g[s], r[s], hx[b * 16 + s]);
+        }
+    }
+    store_nat<8>(A.h + (size_t)L.v * 256, half, hx);
+    // per-node halves of equi_update.input_lin: W_row h (+ bias), W_col h
+    {
+        const float4* wr = wq(A, A.wb[JB_ROW_W], lane);
+        const float4* wc = wq(A, A.wb[JB_COL_W], lane);
+        const float* bin = A.W + A.wb[JB_IN_B];
+#pragma unroll 1
+        for (int b = 0; b < 8; ++b) {
+            f32x16 acc = mfma_block<32>(wr + (size_t)b * 32 * 64, hx, zero16());
+            float r[16];
+            acc_bias(acc, bin + b * 32 + half * 16, r);
+            store16(A.wrow + (size_t)L.v * 256 + b * 32 + half * 16, r);
+            acc = mfma_block<32>(wc + (size_t)b * 32 * 64, hx, zero16());
+#pragma unroll
+            for (int s = 0; s < 16; ++s) r[s] = acc[s];
+            store16(A.wcol + (size_t)L.v * 256 + b * 32 + half * 16, r);
+        }
+    }
+    // readout node_l(h) -> atom_hids[:, D + l*64 ...]
+    {
+        const float4* w = wq(A, A.wb[JB_NRO_W], lane);
+        const float* bias = A.W + A.wb[JB_NRO_B];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x16 acc = mfma_block<32>(w + (size_t)b * 32 * 64, hx, zero16());
+            float r[16];
+            acc_bias(acc, bias + b * 32 + half * 16, r);
+            store16(A.ahid + (size_t)L.v * A.d.KNH + 256 + A.layer * 64 + b * 32 + half * 16, r);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int it = blockIdx.x;
+    const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it], part = A.pd.item_part[it];
+    const LaneNode L = lane_node(A, strip, j);
+    const float* mrow = mod_row(A, L.b) + A.mod_base;
+    const float* eg1 = mrow + 6 * 256 + 2 * 64, *es2 = eg1 + 64, *ec2 = es2 + 64, *eg2 = ec2 + 64;
+    const float* qsh = mrow + 6 * 256 + 6 * 64;              // equi_update.time_mlp: (shift, scale)
+    const float* qsc = qsh + 256;
+    const float gscale = mrow[6 * 256 + 6 * 64 + 2 * 256 + 0], gshift = mrow[6 * 256 + 6 * 64 + 2 * 256 + 1];
+    const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
+    const float cscale = A.W[A.wb[JB_CSCALE]];
+    const float* tab = A.W + A.wb[JB_GBF];
+    float n2a[32];
+    load_nat<2>(A.n2e + (size_t)L.v * 64, half, n2a);
+    {
+        float bb[32];
+        load_nat<2>(A.W + A.wb[JB_N2E_B], half, bb);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) n2a[s] += bb[s];
+    }
+    float dax = 0.f, day = 0.f, daz = 0.f;
+    for (int t = t0; t < t1; ++t) {
+        const bool inr = L.valid && t < L.n;
+        const bool ok = inr && t != L.i;
+        const int tc = inr ? t : 0;
+        const int u = L.noff + tc;
+        const size_t r = (size_t)L.eoff + (size_t)L.i * L.n + tc;
+        // ---- edge residual + LN2 + modulate ----
+        float en[32];
+        {
+            float e[32], n2c[32], g[32];
+            load_nat<2>(A.e + r * 64, half, e);
+            load_nat<2>(A.n2e + (size_t)u * 64, half, n2c);
+            load_nat<2>(eg1, half, g);
+#pragma unroll
+            for (int s = 0; s < 32; ++s) en[s] = fmaf(g[s], n2a[s] + n2c[s], e[s]);
+        }
+        layer_norm<32>(en);
+        modulate<2>(en, es2, ec2, half);
+        // ---- edge FFN (hidden R*64, chunks of 64) ----
+        {
+            f32x16 o[2] = {zero16(), zero16()};
+            const float4* w3 = wq(A, A.wb[JB_FF3_W], lane);
+            const float* b3 = A.W + A.wb[JB_FF3_B];
+            const float4* w4 = wq(A, A.wb[JB_FF4_W], lane);
+            constexpr int KQ4 = R * 64 / 8;
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                float hid[32];
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    f32x16 acc = mfma_block<8>(w3 + (size_t)(c * 2 + b2) * 8 * 64, en, zero16());
+                    float rr[16];
+                    acc_bias(acc, b3 + (c * 2 + b2) * 32 + half * 16, rr);
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(rr[s]);
+                }
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob) o[ob] = mfma_block<8>(w4 + ((size_t)ob * KQ4 + c * 8) * 64, hid, o[ob]);
+            }
+            const float* b4 = A.W + A.wb[JB_FF4_B];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float rr[16], g[16];
+                acc_bias(o[b], b4 + b * 32 + half * 16, rr);
+                load16(eg2 + b * 32 + half * 16, g);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) en[b * 16 + s] = fmaf(g[s], rr[s], en[b * 16 + s]);
+            }
+        }
+        if (inr) store_nat<2>(A.e + r * 64, half, en);
+        // ---- readout edge_l(e) -> edge_hids[:, De + l*16 ...] (valid outputs live in half 0) ----
+        {
+            f32x16 acc = mfma_block<8>(wq(A, A.wb[JB_ERO_W], lane), en, zero16());
+            float rr[16];
+            acc_bias(acc, A.W + A.wb[JB_ERO_B] + half * 16, rr);
+            if (inr && half == 0) store16(A.ehid + r * A.d.KEH + 64 + A.layer * 16, rr);
+        }
+        // ---- equivariant update ----
+        const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[u];
+        const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        float uu[128];
+        {
+            float G[32];
+            gbf64(d2, gscale, gshift, tab, half, G);
+            const float4* wi = wq(A, A.wb[JB_INE_W], lane);
+            const float* wrow = A.wrow + (size_t)L.v * 256;
+            const float* wcol = A.wcol + (size_t)u * 256;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                f32x16 acc = mfma_block<8>(wi + (size_t)(b * 16) * 64, en, zero16());
+                acc = mfma_block<8>(wi + (size_t)(b * 16 + 8) * 64, G, acc);
+                float a1[16], a2[16];
+                load16(wrow + b * 32 + half * 16, a1);
+                load16(wcol + b * 32 + half * 16, a2);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) uu[b * 16 + s] = acc[s] + a1[s] + a2[s];
+            }
+        }
+        layer_norm<128>(uu);
+        modulate<8>(uu, qsh, qsc, half);
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        {
+            const float4* w0 = wq(A, A.wb[JB_C0_W], lane);
+            const float* b0 = A.W + A.wb[JB_C0_B];
+            const float* w2 = A.W + A.wb[JB_C2_W];          // [3][256] natural
+#pragma unroll 1
+            for (int b = 0; b < 8; ++b) {
+                f32x16 acc = mfma_block<32>(w0 + (size_t)b * 32 * 64, uu, zero16());
+                float y[16], k0[16], k1[16], k2[16];
+                acc_bias(acc, b0 + b * 32 + half * 16, y);
+                load16(w2 + b * 32 + half * 16, k0);
+                load16(w2 + 256 + b * 32 + half * 16, k1);
+                load16(w2 + 512 + b * 32 + half * 16, k2);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float ys = silu_f(y[s]);
+                    c0 = fmaf(ys, k0[s], c0);
+                    c1 = fmaf(ys, k1[s], c1);
+                    c2 = fmaf(ys, k2[s], c2);
+                }
+            }
+        }
+        c0 = tanh_f(pair_sum(c0));
+        c1 = tanh_f(pair_sum(c1));
+        c2 = tanh_f(pair_sum(c2));
+        const int fl = A.eflag[r];
+        const float iota = (c0 + ((fl & 1) ? c1 : 0.f) + ((fl & 2) ? c2 : 0.f)) * (1.f / 3.f);
+        const float nrm = fmaxf(sqrtf(d2), 1e-8f);
+        const float f = ok ? cscale * iota / nrm : 0.f;
+        dax = fmaf(dx, f, dax);
+        day = fmaf(dy, f, day);
+        daz = fmaf(dz, f, daz);
+    }
+    if (half == 0)
+        reinterpret_cast<float4*>(A.dpos)[(size_t)L.v * A.pd.max_parts + part] = make_float4(dax, day, daz, 0.f);
+}
+
+}  // namespace jd

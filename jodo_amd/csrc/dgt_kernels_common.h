@@ -1,0 +1,59 @@
+// Kernel argument block and small shared device helpers for the DGT forward kernels.
+#pragma once
+#include "dgt_device.h"
+#include "dgt_plan.h"
+
+// flags_dev layout (int32[8])
+enum { FLAG_NAN = 0, FLAG_FIRST = 1, FLAG_UNIFORM_T = 2, FLAG_COND_NONZERO = 3 };
+
+struct KArgs {
+    PlanDev pd;
+    DgtDims d;
+    const float* W;                       // packed weight blob
+    int64_t wg[JW_GLOBAL_COUNT];          // global slot offsets (floats)
+    int64_t wb[JB_BLOCK_COUNT];           // slot offsets of the current block (floats)
+    int64_t mod_base;                     // offset of the current block inside a modulation vector
+    int layer;
+    // workspace
+    float *hid1, *temb, *mods, *condh, *condh2;
+    float *pos_in, *pos_out, *dpos, *cpos, *feat, *h, *hhat, *q, *k, *v, *n2e, *wrow, *wcol, *ahid, *stats, *apred;
+    int* eflag;
+    float *e, *et, *S, *ehid, *epred;
+    int* flags;
+    // API tensors
+    const float *xh, *edge_x, *cond_x, *cond_edge_x, *noise, *context;
+    float *out_xh, *out_edge;
+};
+
+namespace jd {
+
+__device__ __forceinline__ const float4* wq(const KArgs& A, int64_t off, int lane) {
+    return reinterpret_cast<const float4*>(A.W + off) + lane;
+}
+
+// modulation row of the molecule that owns packed node v
+__device__ __forceinline__ const float* mod_row(const KArgs& A, int node_b) {
+    const int trow = A.flags[FLAG_UNIFORM_T] ? 0 : node_b;
+    return A.mods + (size_t)trow * A.d.Mtot;
+}
+
+struct LaneNode {      // per-lane view of "its" packed node
+    int v, b, i, n, noff, eoff;
+    bool valid;
+};
+
+__device__ __forceinline__ LaneNode lane_node(const KArgs& A, int strip, int j) {
+    LaneNode L;
+    L.v = strip * 32 + j;
+    L.b = A.pd.node_b[L.v];
+    L.i = A.pd.node_i[L.v];
+    L.n = A.pd.node_n[L.v];
+    L.noff = A.pd.node_noff[L.v];
+    L.eoff = A.pd.node_eoff[L.v];
+    L.valid = L.n > 0;
+    return L;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+}  // namespace jd

@@ -1,0 +1,222 @@
+// Prologue kernels: time embedding / modulation vectors, input packing, node and edge embeddings.
+// Reference: DGT_concat.forward models/mol_gnn.py:509-557, time_mlp :481-489 + layers.py:283-288,
+// Cond_DGT_concat context path :728-734.
+#pragma once
+#include "dgt_kernels_common.h"
+
+namespace jd {
+
+// flags: zero + decide whether all molecules share one time row (uncond model, equal noise levels)
+__global__ void k_flags_init(KArgs A) {
+    __shared__ int differs;
+    if (threadIdx.x == 0) differs = 0;
+    __syncthreads();
+    const float x0 = A.noise[0];
+    int d = 0;
+    for (int b = threadIdx.x; b < A.pd.B; b += blockDim.x) d |= (A.noise[b] != x0);
+    if (d) atomicOr(&differs, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        A.flags[FLAG_NAN] = 0;
+        A.flags[FLAG_FIRST] = 0;
+        A.flags[FLAG_COND_NONZERO] = 0;
+        A.flags[FLAG_UNIFORM_T] = (A.d.cond_ch == 0 && !differs) ? 1 : 0;
+    }
+}
+
+// hid1[b] = GELU(W1 * [x, sin(2 pi x w), cos(2 pi x w)] + b1)      (LearnedSinusodialposEmb + Linear + GELU)
+__global__ void k_time1(KArgs A) {
+    const int b = blockIdx.x;
+    if (A.flags[FLAG_UNIFORM_T] && b > 0) return;
+    __shared__ float ft[17];
+    const float x = A.noise[b];
+    if (threadIdx.x < 8) {
+        const float fr = x * A.W[A.wg[JW_TIME_FREQ] + threadIdx.x] * 2.f * 3.14159265358979323846f;
+        ft[1 + threadIdx.x] = sinf(fr);
+        ft[9 + threadIdx.x] = cosf(fr);
+    }
+    if (threadIdx.x == 0) ft[0] = x;
+    __syncthreads();
+    const float* W1 = A.W + A.wg[JW_TIME_W1];
+    const float* b1 = A.W + A.wg[JW_TIME_B1];
+    for (int f = threadIdx.x; f < A.d.T; f += blockDim.x) {
+        float acc = b1[f];
+#pragma unroll
+        for (int k = 0; k < 17; ++k) acc = fmaf(W1[f * 17 + k], ft[k], acc);
+        A.hid1[(size_t)b * A.d.T + f] = gelu_erf(acc);
+    }
+}
+
+// condh[(b*cc + c)][f] = GELU(w0[f] * context[b][c] + b0[f])   (cond_mlp.0 + GELU)
+__global__ void k_cond1(KArgs A) {
+    const int row = blockIdx.x;               // b * cond_ch + c
+    const float x = A.context[row];
+    const float* w0 = A.W + A.wg[JW_COND_W0];
+    const float* b0 = A.W + A.wg[JW_COND_B0];
+    for (int f = threadIdx.x; f < A.d.D; f += blockDim.x)
+        A.condh[(size_t)row * A.d.D + f] = gelu_erf(fmaf(w0[f], x, b0[f]));
+}
+
+// Generic row GEMM on the strip model: Y[row, :] (+)= act_in(X[row, :]) * W^T + bias
+// rows in lanes, K in chunks of 64 features, 4 output blocks per wave.
+struct RowGemmArgs {
+    const float* X; int64_t ldx;
+    float* Y; int64_t ldy;
+    const float* Wp; const float* bias;     // packed [NB][K/8][64][4]; bias in slot (= natural) order
+    int rows, K, NB;
+    int in_act;                              // 0 none, 1 SiLU
+    int accumulate;                          // Y += result
+    const int* uniform_flag;                 // if non-null and *flag != 0: only row 0 is computed
+};
+
+__global__ __launch_bounds__(64) void k_rowgemm(RowGemmArgs G) {
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int rows = (G.uniform_flag && *G.uniform_flag) ? 1 : G.rows;
+    const int r0 = blockIdx.x * 32;
+    if (r0 >= rows) return;
+    const int row = r0 + j;
+    const int rowc = row < rows ? row : rows - 1;
+    const int ob0 = blockIdx.y * 4;
+    const int kq = G.K / 8;                  // quads per output block
+    f32x16 acc[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) acc[o] = zero16();
+    const float4* wp = reinterpret_cast<const float4*>(G.Wp) + lane;
+    for (int c = 0; c < G.K / 64; ++c) {
+        float x[32];
+        load_nat<2>(G.X + (size_t)rowc * G.ldx + c * 64, half, x);
+        if (G.in_act == 1) {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) x[s] = silu_f(x[s]);
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (ob0 + o < G.NB) acc[o] = mfma_block<8>(wp + ((size_t)(ob0 + o) * kq + c * 8) * 64, x, acc[o]);
+        }
+    }
+    if (row >= rows) return;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        if (ob0 + o < G.NB) {
+            float r[16];
+            acc_bias(acc[o], G.bias + (ob0 + o) * 32 + half * 16, r);
+            float* yp = G.Y + (size_t)row * G.ldy + (ob0 + o) * 32 + half * 16;
+            if (G.accumulate) {
+                float old[16];
+                load16(yp, old);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) r[s] += old[s];
+            }
+            store16(yp, r);
+        }
+    }
+}
+
+// gather node inputs into the packed layout; detect "any self-cond distance non-zero"
+__global__ void k_pack_nodes(KArgs A) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= A.pd.Nn_pad) return;
+    const int nd = A.d.nd, ndp = A.d.ndp, dims = 3 + nd;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), cp = p;
+    float* ft = A.feat + (size_t)v * ndp;
+    for (int f = 0; f < ndp; ++f) ft[f] = 0.f;
+    if (v < A.pd.Nn) {
+        const int b = A.pd.node_b[v], i = A.pd.node_i[v];
+        const float* x = A.xh + ((size_t)b * A.pd.N + i) * dims;
+        p = make_float4(x[0], x[1], x[2], 0.f);
+        for (int f = 0; f < nd; ++f) ft[f] = x[3 + f];
+        if (A.cond_x) {
+            const float* c = A.cond_x + ((size_t)b * A.pd.N + i) * dims;
+            cp = make_float4(c[0], c[1], c[2], 0.f);
+            for (int f = 0; f < nd; ++f) ft[nd + f] = c[3 + f];
+            const float* c0 = A.cond_x + ((size_t)b * A.pd.N) * dims;      // first atom of the molecule
+            if (c[0] != c0[0] || c[1] != c0[1] || c[2] != c0[2]) atomicOr(&A.flags[FLAG_COND_NONZERO], 1);
+        }
+    }
+    reinterpret_cast<float4*>(A.pos_in)[v] = p;
+    reinterpret_cast<float4*>(A.cpos)[v] = cp;
+}
+
+// h0 = node_emb([feat ; cond_feat]);  KQ = ndp / 8 quads
+template <int KQ>
+__global__ __launch_bounds__(64) void k_embed_nodes(KArgs A) {
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int v = blockIdx.x * 32 + j;
+    float x[KQ * 4];
+    const float4* src = reinterpret_cast<const float4*>(A.feat + (size_t)v * (KQ * 8) + half * (KQ * 4));
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        const float4 t = src[q];
+        x[q * 4 + 0] = t.x; x[q * 4 + 1] = t.y; x[q * 4 + 2] = t.z; x[q * 4 + 3] = t.w;
+    }
+    const float4* w = wq(A, A.wg[JW_NODE_EMB_W], lane);
+    const float* bias = A.W + A.wg[JW_NODE_EMB_B];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        f32x16 acc = mfma_block<KQ>(w + (size_t)b * KQ * 64, x, zero16());
+        float r[16];
+        acc_bias(acc, bias + b * 32 + half * 16, r);
+        store16(A.h + (size_t)v * 256 + b * 32 + half * 16, r);
+        store16(A.ahid + (size_t)v * A.d.KNH + b * 32 + half * 16, r);
+    }
+}
+
+// e0 = edge_emb([edge_x ; cond_edge_x ; G0]) per dense edge row; also adjacency flags
+__global__ __launch_bounds__(64) void k_embed_edges(KArgs A) {
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int it = blockIdx.x;
+    const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it];
+    const LaneNode L = lane_node(A, strip, j);
+    const int ch = A.d.ch;
+    const bool first = A.flags[FLAG_COND_NONZERO] == 0;
+    const float* mr = mod_row(A, L.b);
+    const float gscale = mr[0], gshift = mr[1];
+    const float4 pc = reinterpret_cast<const float4*>(A.cpos)[L.v];
+    const float* tab = A.W + A.wg[JW_GBF_TOP];
+    const float4* w = wq(A, A.wg[JW_EDGE_EMB_W], lane);
+    const float* bias = A.W + A.wg[JW_EDGE_EMB_B];
+    for (int t = t0; t < t1; ++t) {
+        const bool ok = L.valid && t < L.n;
+        const int tc = ok ? t : 0;
+        const int u = L.noff + tc;
+        const size_t r = (size_t)L.eoff + (size_t)L.i * L.n + tc;
+        const float4 pu = reinterpret_cast<const float4*>(A.cpos)[u];
+        const float dx = pc.x - pu.x, dy = pc.y - pu.y, dz = pc.z - pu.z;
+        const float d2c = dx * dx + dy * dy + dz * dz;
+        // raw inputs of this edge: features f = half*4 + s of [edge_x(ch) ; cond_edge_x(ch)]
+        const size_t din = (((size_t)L.b * A.pd.N + L.i) * A.pd.N + tc) * ch;
+        float ein[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int f = half * 4 + s;
+            float val = 0.f;
+            if (f < ch) val = A.edge_x[din + f];
+            else if (f < 2 * ch && A.cond_edge_x) val = A.cond_edge_x[din + (f - ch)];
+            ein[s] = val;
+        }
+        int adj2d = 1;
+        if (A.cond_edge_x) adj2d = A.cond_edge_x[din] >= A.d.edge_th ? 1 : 0;
+        const int adjsp = d2c <= A.d.cutoff ? 1 : 0;
+        float G[32];
+        if (first) {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) G[s] = 0.f;
+        } else {
+            gbf64(d2c, gscale, gshift, tab, half, G);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x16 acc = mfma_block<8>(w + (size_t)(b * 9) * 64, G, zero16());
+            acc = mfma_block<1>(w + (size_t)(b * 9 + 8) * 64, ein, acc);
+            float rr[16];
+            acc_bias(acc, bias + b * 32 + half * 16, rr);
+            if (ok) {
+                store16(A.e + r * 64 + b * 32 + half * 16, rr);
+                store16(A.ehid + r * A.d.KEH + b * 32 + half * 16, rr);
+            }
+        }
+        if (ok && half == 0) A.eflag[r] = adj2d | (adjsp << 1);
+    }
+}
+
+}  // namespace jd

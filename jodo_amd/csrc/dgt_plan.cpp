@@ -1,0 +1,147 @@
+// Plan builder: turns the batch's atom counts into the packed, size-sorted layout and the work-item
+// lists the kernels iterate over.  Replaces the reference's per-forward dense->sparse conversion
+// (models/mol_gnn.py:512-514) with a once-per-batch host computation.
+#include <algorithm>
+#include <numeric>
+#include <new>
+#include "dgt_plan.h"
+#include "jodo_hip_internal.h"
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int dgt_dims_from_cfg(const jodo_cfg* c, DgtDims* d) {
+    if (c->nf != 256)
+        return jodo_set_error(JODO_ERR_UNSUPPORTED, "nf=%d: only nf=256 kernels are built (nf=384 is the next tier)", c->nf);
+    if (c->n_heads != 16 || c->n_extra != 2)
+        return jodo_set_error(JODO_ERR_UNSUPPORTED, "n_heads=%d n_extra_heads=%d: kernels are built for 16/2", c->n_heads, c->n_extra);
+    if (c->mlp_ratio != 2 && c->mlp_ratio != 4)
+        return jodo_set_error(JODO_ERR_UNSUPPORTED, "mlp_ratio=%d: supported 2, 4", c->mlp_ratio);
+    if (c->n_layers < 1 || c->n_layers > 32) return jodo_set_error(JODO_ERR_ARG, "n_layers=%d", c->n_layers);
+    if (c->in_node_dim < 1 || 2 * c->in_node_dim > 64) return jodo_set_error(JODO_ERR_ARG, "in_node_dim=%d", c->in_node_dim);
+    if (c->edge_ch < 1 || c->edge_ch > 4) return jodo_set_error(JODO_ERR_ARG, "edge_ch=%d (1..4)", c->edge_ch);
+    if (c->cond_ch < 0 || c->cond_ch > 8) return jodo_set_error(JODO_ERR_ARG, "cond_ch=%d", c->cond_ch);
+    d->D = c->nf; d->De = c->nf / 4; d->T = c->nf * 4; d->L = c->n_layers; d->H = c->n_heads; d->XH = c->n_extra;
+    d->SH = d->H - d->XH; d->C = d->D / d->H; d->SC = (d->H * d->C) / d->SH; d->r = c->mlp_ratio;
+    d->nd = c->in_node_dim; d->ch = c->edge_ch; d->cond_ch = c->cond_ch;
+    int tail = d->SC - 16;
+    d->QKP = (d->SH / 2 + (tail + 1) / 2) * 32;
+    d->ndp = (2 * d->nd + 7) / 8 * 8;
+    d->einp = (2 * d->ch + 7) / 8 * 8;
+    d->cnp = 64; d->cep = 16;
+    if ((2 * d->D) / d->L > d->cnp || (2 * d->De) / d->L > d->cep)
+        return jodo_set_error(JODO_ERR_UNSUPPORTED, "n_layers=%d gives readout widths beyond the padded slots", d->L);
+    d->KNH = d->D + d->L * d->cnp; d->KEH = d->De + d->L * d->cep;
+    if (d->KEH % 32 != 0) return jodo_set_error(JODO_ERR_UNSUPPORTED, "edge head width %d not a multiple of 32", d->KEH);
+    d->MB = 6 * d->D + 6 * d->De + 2 * d->D + 32;
+    d->Mtot = 32 + (int64_t)d->L * d->MB;
+    d->cutoff = c->spatial_cut_off; d->edge_th = c->edge_quan_th;
+    return JODO_OK;
+}
+
+extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes, int max_chunk,
+                                jodo_plan** out) {
+    if (!cfg || !n_nodes || !out || B <= 0 || N <= 0) return jodo_set_error(JODO_ERR_ARG, "plan_create: bad argument");
+    jodo_plan* p = new (std::nothrow) jodo_plan();
+    if (!p) return jodo_set_error(JODO_ERR_ARG, "plan_create: out of host memory");
+    p->cfg = *cfg;
+    int rc = dgt_dims_from_cfg(cfg, &p->dims);
+    if (rc != JODO_OK) { delete p; return rc; }
+    for (int b = 0; b < B; ++b)
+        if (n_nodes[b] < 1 || n_nodes[b] > N) {
+            delete p;
+            return jodo_set_error(JODO_ERR_ARG, "plan_create: n_nodes[%d]=%d outside [1,%d]", b, n_nodes[b], N);
+        }
+    if (max_chunk <= 0) max_chunk = 8;
+    p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0;
+
+    // molecules by descending size (stable): neighbouring lanes share n, big work first
+    std::vector<int> order(B);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_nodes[a] > n_nodes[b]; });
+
+    int64_t Nn = 0, rows = 0, dir = 0;
+    for (int b = 0; b < B; ++b) { Nn += n_nodes[b]; rows += (int64_t)n_nodes[b] * n_nodes[b]; dir += (int64_t)n_nodes[b] * (n_nodes[b] - 1); }
+    if (rows >= (int64_t)1 << 31) { delete p; return jodo_set_error(JODO_ERR_UNSUPPORTED, "batch too large: %lld dense edge rows", (long long)rows); }
+    p->Nn = (int)Nn; p->Nn_pad = (int)align_up((size_t)Nn, 32); p->n_strips = p->Nn_pad / 32;
+    p->rows = rows; p->dir_edges = dir;
+
+    std::vector<int32_t> node_b(p->Nn_pad, 0), node_i(p->Nn_pad, 0), node_n(p->Nn_pad, 0), node_noff(p->Nn_pad, 0),
+        node_eoff(p->Nn_pad, 0), orig_n(B), orig_noff(B), orig_eoff(B);
+    int v = 0; int64_t eoff = 0;
+    for (int m = 0; m < B; ++m) {
+        int b = order[m], n = n_nodes[b];
+        orig_n[b] = n; orig_noff[b] = v; orig_eoff[b] = (int32_t)eoff;
+        for (int i = 0; i < n; ++i) {
+            node_b[v + i] = b; node_i[v + i] = i; node_n[v + i] = n; node_noff[v + i] = v; node_eoff[v + i] = (int32_t)eoff;
+        }
+        v += n; eoff += (int64_t)n * n;
+    }
+    // edge work items: (strip, [t0,t1)) with balanced chunks
+    std::vector<int32_t> it_strip, it_t0, it_t1, it_part, strip_parts(p->n_strips, 0);
+    int max_parts = 1;
+    for (int s = 0; s < p->n_strips; ++s) {
+        int nmax = 0;
+        for (int j = 0; j < 32; ++j) nmax = std::max(nmax, (int)node_n[s * 32 + j]);
+        if (nmax == 0) continue;
+        int parts = (nmax + max_chunk - 1) / max_chunk;
+        int chunk = (nmax + parts - 1) / parts;
+        parts = (nmax + chunk - 1) / chunk;
+        max_parts = std::max(max_parts, parts);
+        strip_parts[s] = parts;
+        for (int q = 0; q < parts; ++q) {
+            it_strip.push_back(s); it_t0.push_back(q * chunk); it_t1.push_back(std::min(nmax, (q + 1) * chunk)); it_part.push_back(q);
+        }
+    }
+    p->n_items = (int)it_strip.size(); p->max_parts = max_parts;
+
+    auto put = [&](const std::vector<int32_t>& a, size_t* off) {
+        *off = p->desc.size();
+        p->desc.insert(p->desc.end(), a.begin(), a.end());
+        while (p->desc.size() % 64) p->desc.push_back(0);
+    };
+    put(node_b, &p->off_node_b); put(node_i, &p->off_node_i); put(node_n, &p->off_node_n);
+    put(node_noff, &p->off_node_noff); put(node_eoff, &p->off_node_eoff);
+    put(orig_n, &p->off_orig_n); put(orig_noff, &p->off_orig_noff); put(orig_eoff, &p->off_orig_eoff);
+    put(it_strip, &p->off_item_strip); put(it_t0, &p->off_item_t0); put(it_t1, &p->off_item_t1); put(it_part, &p->off_item_part); put(strip_parts, &p->off_strip_parts);
+
+    // workspace layout
+    const DgtDims& d = p->dims;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    const size_t f = sizeof(float), NP = (size_t)p->Nn_pad, R = (size_t)rows + 32, Bp = align_up((size_t)B, 32);
+    WsLayout& w = p->ws;
+    w.hid1 = take(Bp * d.T * f); w.temb = take(Bp * d.T * f); w.mods = take(Bp * (size_t)d.Mtot * f);
+    w.condh = take(Bp * (size_t)std::max(1, d.cond_ch) * d.D * f); w.condh2 = take(Bp * (size_t)std::max(1, d.cond_ch) * d.D * f);
+    w.pos0 = take(NP * 4 * f); w.pos1 = take(NP * 4 * f); w.dpos = take(NP * max_parts * 4 * f); w.cpos = take(NP * 4 * f);
+    w.feat = take(NP * d.ndp * f); w.h = take(NP * d.D * f); w.hhat = take(NP * max_parts * d.D * f);
+    w.q = take(NP * d.QKP * f); w.k = take(NP * d.QKP * f); w.v = take(NP * d.D * f); w.n2e = take(NP * d.De * f);
+    w.wrow = take(NP * d.D * f); w.wcol = take(NP * d.D * f); w.ahid = take(NP * d.KNH * f); w.stats = take(NP * 32 * f);
+    w.apred = take(NP * 32 * f);
+    w.eflag = take(R * sizeof(int32_t)); w.e = take(R * d.De * f); w.et = take(R * d.De * f); w.S = take(R * 16 * f);
+    w.ehid = take(R * d.KEH * f); w.epred = take(R * 4 * f);
+    w.total = o;
+    *out = p;
+    return JODO_OK;
+}
+
+extern "C" void jodo_plan_destroy(jodo_plan* p) { delete p; }
+extern "C" size_t jodo_plan_desc_bytes(const jodo_plan* p) { return p ? p->desc.size() * sizeof(int32_t) : 0; }
+extern "C" size_t jodo_plan_workspace_bytes(const jodo_plan* p) { return p ? p->ws.total : 0; }
+extern "C" int64_t jodo_plan_mod_len(const jodo_plan* p) { return p ? p->dims.Mtot : 0; }
+extern "C" int jodo_plan_stats(const jodo_plan* p, int64_t* o) {
+    if (!p || !o) return jodo_set_error(JODO_ERR_ARG, "plan_stats: null");
+    o[0] = p->Nn; o[1] = p->rows; o[2] = p->dir_edges; o[3] = p->n_strips; o[4] = p->n_items; o[5] = p->max_parts;
+    return JODO_OK;
+}
+extern "C" int jodo_plan_upload(jodo_plan* p, void* desc_dev, void* stream) {
+    if (!p || !desc_dev) return jodo_set_error(JODO_ERR_ARG, "plan_upload: null");
+    hipError_t e = hipMemcpyAsync(desc_dev, p->desc.data(), p->desc.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+                                  (hipStream_t)stream);
+    if (e != hipSuccess) return jodo_set_error(JODO_ERR_LAUNCH, "plan_upload: %s", hipGetErrorString(e));
+    return JODO_OK;
+}
+extern "C" int jodo_debug_set_max_blocks(jodo_plan* p, int mb) {
+    if (!p) return jodo_set_error(JODO_ERR_ARG, "null plan");
+    p->max_blocks = mb;
+    return JODO_OK;
+}

@@ -1,0 +1,59 @@
+// Host-side execution plan shared by dgt_plan.cpp (builder) and dgt_forward.hip (launcher).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <vector>
+#include "../../include/jodo_hip.h"
+
+struct DgtDims {
+    int D, De, T, L, H, XH, SH, SC, C, r, nd, ch, cond_ch;
+    int QKP;        // padded q/k width in floats (slot order)
+    int ndp;        // padded node input width (2*nd rounded up to 8)
+    int einp;       // padded raw edge input width (2*ch rounded up to 8)
+    int cnp, cep;   // padded per-block readout widths (node 64, edge 16)
+    int KNH, KEH;   // head-MLP input widths  D + L*cnp,  De + L*cep
+    int MB;         // modulation floats per block
+    int64_t Mtot;   // modulation floats per molecule
+    float cutoff, edge_th;
+};
+
+// device views into the descriptor buffer (all int32)
+struct PlanDev {
+    const int* node_b;     // packed node -> original batch index
+    const int* node_i;     // index inside its molecule
+    const int* node_n;     // atoms in its molecule (0 = padding lane)
+    const int* node_noff;  // first packed node of its molecule
+    const int* node_eoff;  // first dense edge row of its molecule
+    const int* orig_n;     // [B] original b -> n
+    const int* orig_noff;  // [B] original b -> first packed node
+    const int* orig_eoff;  // [B] original b -> first dense edge row
+    const int* item_strip; // edge work items
+    const int* item_t0;
+    const int* item_t1;
+    const int* item_part;
+    const int* strip_parts; // [n_strips] number of parts (work items) of each node strip
+    int Nn, Nn_pad, n_strips, n_items, B, N, max_parts;
+    int64_t rows;
+};
+
+struct WsLayout {   // byte offsets into the workspace
+    size_t hid1, temb, mods, condh, condh2;
+    size_t pos0, pos1, dpos, cpos, feat, h, hhat, q, k, v, n2e, wrow, wcol, ahid, stats, apred;
+    size_t eflag, e, et, S, ehid, epred;
+    size_t total;
+};
+
+struct jodo_plan {
+    jodo_cfg cfg;
+    DgtDims dims;
+    int B, N, Nn, Nn_pad, n_strips, n_items, max_parts;
+    int64_t rows, dir_edges;
+    std::vector<int32_t> desc;       // concatenated descriptor tables
+    size_t off_node_b, off_node_i, off_node_n, off_node_noff, off_node_eoff, off_orig_n, off_orig_noff,
+        off_orig_eoff, off_item_strip, off_item_t0, off_item_t1, off_item_part, off_strip_parts;   // in int32 elements
+    WsLayout ws;
+    int max_blocks;                  // debug: limit blocks executed (<0 = all)
+    int last_pos_buf;                // debug: which pos buffer holds the latest positions
+};
+
+int dgt_dims_from_cfg(const jodo_cfg* cfg, DgtDims* d);

@@ -1,0 +1,276 @@
+"""MI355X-native Diffusion Graph Transformer score networks, registered under the reference's names.
+
+`DGT_concat` / `Cond_DGT_concat` are drop-in replacements for the classes of the same registry name
+in /root/reference/models/mol_gnn.py (:410-594, :597-794):
+
+  * same constructor argument (`config`) and the same config keys are read;
+  * same parameter names, shapes and registration order (state_dict keys, EMA shadow-list order,
+    `strict=True` checkpoint loading) — the parameter tree below is built from stock torch containers
+    in the reference's construction order, so even `torch.manual_seed(s); Model(config)` yields the
+    same initial weights;
+  * same call: `model(t, xh, node_mask, edge_mask, context=None, edge_x=..., cond_x=..., cond_edge_x=...,
+    noise_level=...)` -> `(xh_pred [B,N,3+nd], edge_pred [B,N,N,ch])`, inputs untouched.
+
+The arithmetic is NOT done by these torch modules: `forward` packs the weights once (MFMA operand
+order, jodo_amd/packing_model.py), builds a plan per batch of atom counts, and calls
+`jodo_dgt_forward` in libjodo_hip.so on the current HIP stream.  There is no CPU or eager fallback:
+on a non-GPU tensor, with gradients enabled, or with an unsupported config, forward raises.
+"""
+import ctypes
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import capi
+from ..packing_model import ModelDims, pack_model
+from . import utils
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter containers (hold weights only; mirror the reference's module tree)
+# ---------------------------------------------------------------------------------------------
+def _time_seq(time_dim, out_dim):
+    return nn.Sequential(nn.SiLU(), nn.Linear(time_dim, out_dim))
+
+
+class _SinusoidParams(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.weights = nn.Parameter(torch.randn(dim // 2))
+
+
+class _GaussianParams(nn.Module):
+    def __init__(self, K, time_dim):
+        super().__init__()
+        self.means = nn.Embedding(1, K - 1)
+        self.stds = nn.Embedding(1, K - 1)
+        self.time_mlp = _time_seq(time_dim, 2)
+        nn.init.uniform_(self.means.weight, 0, 3)
+        nn.init.uniform_(self.stds.weight, 0, 3)
+
+
+class _CoorsNormParams(nn.Module):
+    def __init__(self, scale_init):
+        super().__init__()
+        self.scale = nn.Parameter(torch.zeros(1).fill_(scale_init))
+
+
+class _AttnParams(nn.Module):
+    def __init__(self, node_dim, head_ch, n_extra, n_heads, edge_dim):
+        super().__init__()
+        sub_heads = n_heads - n_extra
+        sub_ch = (n_heads * head_ch) // sub_heads
+        self.lin_key = nn.Linear(node_dim, sub_heads * sub_ch)
+        self.lin_query = nn.Linear(node_dim, sub_heads * sub_ch)
+        self.lin_value = nn.Linear(node_dim, n_heads * head_ch)
+        self.lin_edge0 = nn.Linear(edge_dim, sub_heads * sub_ch, bias=False)
+        self.lin_edge1 = nn.Linear(edge_dim, n_heads * head_ch, bias=False)
+        for m in (self.lin_key, self.lin_query, self.lin_value, self.lin_edge0, self.lin_edge1):
+            m.reset_parameters()          # the reference layer re-initialises after construction
+
+
+class _EquiUpdateParams(nn.Module):
+    def __init__(self, hidden, edge_dim, dist_dim, time_dim, n_extra):
+        super().__init__()
+        self.coord_norm = _CoorsNormParams(1e-2)
+        self.time_mlp = _time_seq(time_dim, hidden * 2)
+        self.input_lin = nn.Linear(hidden * 2 + edge_dim + dist_dim, hidden)
+        self.coord_mlp = nn.Sequential(nn.Linear(hidden, hidden), nn.SiLU(), nn.Linear(hidden, 1 + n_extra, bias=False))
+
+
+class _BlockParams(nn.Module):
+    def __init__(self, node_dim, edge_dim, time_dim, n_extra, n_heads, mlp_ratio):
+        super().__init__()
+        self.edge_emb = nn.Linear(edge_dim * 2, edge_dim)
+        self.node2edge_lin = nn.Linear(node_dim, edge_dim)
+        self.attn_mpnn = _AttnParams(node_dim, node_dim // n_heads, n_extra, n_heads, edge_dim)
+        self.ff_linear1 = nn.Linear(node_dim, node_dim * mlp_ratio)
+        self.ff_linear2 = nn.Linear(node_dim * mlp_ratio, node_dim)
+        self.ff_linear3 = nn.Linear(edge_dim, edge_dim * mlp_ratio)
+        self.ff_linear4 = nn.Linear(edge_dim * mlp_ratio, edge_dim)
+        self.equi_update = _EquiUpdateParams(node_dim, edge_dim, edge_dim, time_dim, n_extra)
+        self.node_time_mlp = _time_seq(time_dim, node_dim * 6)
+        self.edge_time_mlp = _time_seq(time_dim, edge_dim * 6)
+        self.dist_layer = _GaussianParams(edge_dim, time_dim)
+
+
+def _mlp3(i, h, m, o):
+    return nn.Sequential(nn.Linear(i, h), nn.SiLU(), nn.Linear(h, m), nn.SiLU(), nn.Linear(m, o))
+
+
+_UNSUPPORTED = (('dist_gbf', True), ('cond_time', True), ('pred_data', True), ('gbf_name', 'CondGaussianLayer'),
+                ('CoM', True), ('softmax_inf', True))
+
+
+class _DGTBase(nn.Module):
+    conditional = False
+
+    def __init__(self, config):
+        super().__init__()
+        m = config.model
+        for key, want in _UNSUPPORTED:
+            if getattr(m, key) != want:
+                raise NotImplementedError(
+                    "config.model.%s=%r: the HIP path implements %r only (the JODO configs' setting)"
+                    % (key, getattr(m, key), want))
+        if not self.conditional and getattr(m, 'trans_name', 'TransMixLayer') != 'TransMixLayer':
+            raise NotImplementedError("config.model.trans_name=%r: only TransMixLayer is implemented" % m.trans_name)
+        in_node_dim = config.data.atom_types + int(m.include_fc_charge)
+        D, De, L = m.nf, m.nf // 4, m.n_layers
+        T = D * 4
+        cond_ch = int(m.cond_ch) if self.conditional else 0
+        self.dims = ModelDims(D, L, m.n_heads, m.n_extra_heads, m.mlp_ratio, in_node_dim, m.edge_ch, cond_ch)
+        if D != 256 or m.n_heads != 16 or m.n_extra_heads != 2 or m.mlp_ratio not in (2, 4):
+            raise NotImplementedError("HIP kernels are built for nf=256, n_heads=16, n_extra_heads=2, mlp_ratio in {2,4} "
+                                      "(got nf=%d heads=%d/%d ratio=%d); nf=384 is the next tier" %
+                                      (D, m.n_heads, m.n_extra_heads, m.mlp_ratio))
+        if self.dims.cn > self.dims.cnp or self.dims.ce > self.dims.cep or L % 2:
+            raise NotImplementedError("n_layers=%d: per-block readout widths (%d, %d) exceed the padded slots (64, 16) "
+                                      "or n_layers is odd; supported: even n_layers >= 8" % (L, self.dims.cn, self.dims.ce))
+        self.edge_th = float(m.edge_quan_th)
+        self.spatial_cut_off = float(m.spatial_cut_off)
+        self.n_layers = L
+        self.dropout_p = m.dropout           # identity at inference; kept for config parity
+
+        # ---- parameter tree, reference construction/registration order ----
+        self.node_emb = nn.Linear(in_node_dim * 2, D)
+        self.edge_emb = nn.Linear(m.edge_ch * 2 + De, De)
+        self.dist_layer = _GaussianParams(De, T)
+        cat_node, cat_edge = (D * 2) // L, (De * 2) // L
+        for i in range(L):
+            self.add_module("e_block_%d" % i, _BlockParams(D, De, T, m.n_extra_heads, m.n_heads, m.mlp_ratio))
+            self.add_module("node_%d" % i, nn.Linear(D, cat_node))
+            self.add_module("edge_%d" % i, nn.Linear(De, cat_edge))
+        self.node_pred_mlp = _mlp3(cat_node * L + D, D, D // 2, in_node_dim)
+        self.edge_type_mlp = _mlp3(cat_edge * L + De, De, De // 2, m.edge_ch - 1)
+        self.edge_exist_mlp = _mlp3(cat_edge * L + De, De, De // 2, 1)
+        self.time_mlp = nn.Sequential(_SinusoidParams(16), nn.Linear(17, T), nn.GELU(), nn.Linear(T, T))
+        if self.conditional:
+            self.cond_mlp = nn.Sequential(nn.Linear(1, D), nn.GELU(), nn.Linear(D, D))
+            self.cond_lin = nn.Linear(cond_ch * D, T)
+
+        # ---- runtime state (not part of state_dict) ----
+        self._packed = None           # (version_key, blob_dev, woff_host ctypes array)
+        self._plans = {}              # plan cache keyed by the mask tensor identity
+        self._cfg_struct = None
+        self.last_flags = None        # device int32[8] of the last call (NaN guard etc.)
+        self.warn_nan = True
+
+    # -- C structs ---------------------------------------------------------------------------
+    class _Cfg(ctypes.Structure):
+        _fields_ = [('nf', ctypes.c_int32), ('n_layers', ctypes.c_int32), ('n_heads', ctypes.c_int32),
+                    ('n_extra', ctypes.c_int32), ('mlp_ratio', ctypes.c_int32), ('in_node_dim', ctypes.c_int32),
+                    ('edge_ch', ctypes.c_int32), ('cond_ch', ctypes.c_int32),
+                    ('spatial_cut_off', ctypes.c_float), ('edge_quan_th', ctypes.c_float)]
+
+    def _cfg(self):
+        if self._cfg_struct is None:
+            d = self.dims
+            self._cfg_struct = self._Cfg(d.D, d.L, d.H, d.XH, d.r, d.nd, d.ch, d.cond_ch, self.spatial_cut_off,
+                                         self.edge_th)
+        return self._cfg_struct
+
+    # -- weights -----------------------------------------------------------------------------
+    def _weights(self, device):
+        key = (str(device),) + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+        if self._packed is None or self._packed[0] != key:
+            sd = {k: v.detach().float().cpu() for k, v in self.state_dict().items()}
+            blob, woff = pack_model(sd, self.dims)
+            blob_dev = torch.from_numpy(blob).to(device)
+            woff_c = (ctypes.c_int64 * len(woff))(*woff.tolist())
+            self._packed = (key, blob_dev, woff_c, len(woff))
+        return self._packed
+
+    # -- plans ---------------------------------------------------------------------------------
+    def _plan(self, node_mask, edge_mask, device, validate=True):
+        key = (node_mask.data_ptr(), tuple(node_mask.shape), node_mask._version, str(device))
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
+        B, N = node_mask.shape[0], node_mask.shape[1]
+        nm = node_mask.reshape(B, N)
+        n_nodes = nm.sum(1).round().to(torch.int32)
+        if validate:
+            prefix = (torch.arange(N, device=nm.device).unsqueeze(0) < n_nodes.unsqueeze(1)).to(nm.dtype)
+            if not torch.equal(prefix, nm):
+                raise ValueError("node_mask must be a prefix mask (real atoms first), as the samplers build it")
+            em = edge_mask.reshape(B, N, N)
+            want = prefix.unsqueeze(1) * prefix.unsqueeze(2) * (~torch.eye(N, dtype=torch.bool, device=nm.device))
+            if not torch.equal(want.to(em.dtype), em):
+                raise ValueError("edge_mask must be node_mask x node_mask with the diagonal removed")
+        n_host = np.ascontiguousarray(n_nodes.cpu().numpy(), dtype=np.int32)     # one sync per new batch
+        L = capi.lib()
+        handle = ctypes.c_void_p()
+        capi.check(L.jodo_plan_create(ctypes.byref(self._cfg()), B, N, n_host.ctypes.data_as(ctypes.c_void_p),
+                                      int(getattr(self, 'max_chunk', 0)), ctypes.byref(handle)), 'jodo_plan_create')
+        L.jodo_plan_desc_bytes.restype = ctypes.c_size_t
+        L.jodo_plan_workspace_bytes.restype = ctypes.c_size_t
+        desc = torch.empty(L.jodo_plan_desc_bytes(handle), dtype=torch.uint8, device=device)
+        ws = torch.empty(L.jodo_plan_workspace_bytes(handle), dtype=torch.uint8, device=device)
+        capi.check(L.jodo_plan_upload(handle, capi.ptr(desc), capi.current_stream_ptr()), 'jodo_plan_upload')
+        torch.cuda.current_stream().synchronize()        # host staging buffer lives in the plan; be safe
+        plan = dict(handle=handle, desc=desc, ws=ws, n_nodes=n_host, B=B, N=N,
+                    flags=torch.zeros(8, dtype=torch.int32, device=device))
+        if len(self._plans) >= 8:                        # bounded cache
+            old = self._plans.pop(next(iter(self._plans)))
+            L.jodo_plan_destroy(old['handle'])
+        self._plans[key] = plan
+        return plan
+
+    def __del__(self):
+        try:
+            L = capi.lib()
+            for p in self._plans.values():
+                L.jodo_plan_destroy(p['handle'])
+        except Exception:
+            pass
+
+    # -- forward -------------------------------------------------------------------------------
+    def forward(self, t, xh, node_mask, edge_mask, context=None, *args, **kwargs):
+        edge_x, cond_x, cond_edge_x = kwargs['edge_x'], kwargs.get('cond_x'), kwargs.get('cond_edge_x')
+        noise_level = kwargs['noise_level']
+        if not xh.is_cuda:
+            raise RuntimeError("jodo_amd DGT runs on an MI355X only (got a %s tensor); there is no CPU fallback — "
+                               "use oracle/dgt_oracle.py for CPU checks" % xh.device)
+        if torch.is_grad_enabled() and (xh.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise RuntimeError("backward through the HIP DGT is not implemented: call under torch.no_grad()")
+        if self.conditional and context is None:
+            raise ValueError("cond_DGT_concat needs `context`")
+        dev = xh.device
+        d = self.dims
+        B, N, dims = xh.shape
+        if dims != 3 + d.nd or edge_x.shape != (B, N, N, d.ch):
+            raise ValueError("shape mismatch: xh %s edge_x %s" % (tuple(xh.shape), tuple(edge_x.shape)))
+        f32 = lambda x: None if x is None else x.detach().to(torch.float32).contiguous()
+        xh_, ex_, cx_, cex_, nl_ = f32(xh), f32(edge_x), f32(cond_x), f32(cond_edge_x), f32(noise_level)
+        ctx_ = f32(context) if self.conditional else None
+        _, blob, woff_c, n_woff = self._weights(dev)
+        plan = self._plan(node_mask, edge_mask, dev)
+        out_x = torch.empty_like(xh_)
+        out_e = torch.empty_like(ex_)
+        L = capi.lib()
+        capi.check(L.jodo_dgt_forward(plan['handle'], capi.ptr(plan['desc']), capi.ptr(blob), woff_c, n_woff,
+                                      capi.ptr(xh_), capi.ptr(ex_), capi.ptr(cx_), capi.ptr(cex_), capi.ptr(nl_),
+                                      capi.ptr(ctx_), capi.ptr(out_x), capi.ptr(out_e), capi.ptr(plan['flags']),
+                                      capi.ptr(plan['ws']), capi.current_stream_ptr()), 'jodo_dgt_forward')
+        self.last_flags = plan['flags']
+        self._last_plan = plan
+        return out_x, out_e
+
+    def nan_guard_fired(self):
+        """Lazy read of the device NaN-guard flag of the last call (the reference prints a warning and
+        zeroes all positions, mol_gnn.py:587-589; the zeroing already happened on the device)."""
+        return self.last_flags is not None and bool(self.last_flags[0].item())
+
+
+@utils.register_model(name='DGT_concat')
+class DGT_concat(_DGTBase):
+    """Diffusion Graph Transformer with self-conditioning (HIP)."""
+    conditional = False
+
+
+@utils.register_model(name='cond_DGT_concat')
+class Cond_DGT_concat(_DGTBase):
+    """Conditional Diffusion Graph Transformer with self-conditioning (HIP)."""
+    conditional = True

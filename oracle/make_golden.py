@@ -1,0 +1,191 @@
+"""Generate tests/golden/*.npz from the REAL reference (build container only).
+
+Imports /root/reference under oracle/standins, initialises the reference's own DGT_concat /
+cond_DGT_concat with `jodo_amd.models.init_utils.deterministic_init_` (weights are a pure function of
+(seed, parameter name), so they need not be stored) and records inputs and the reference's outputs:
+
+  fwd_qm9.npz / fwd_geom.npz / fwd_cond.npz   one first-step call (cond = None) and one
+                                               self-conditioned call, non-uniform noise levels
+  traj_qm9_anc5.npz                            5-step ancestral trajectory (reference AncestralSampler)
+                                               with every noise tensor recorded, + decoded molecules
+  traj_cond_dpm4.npz                           4-NFE hybrid DPM-solver trajectory on the conditional
+                                               model (BASELINE config 5 path), recorded position noise
+
+While doing so it asserts the oracle restatement (oracle/dgt_oracle.py) against the reference:
+faithful == reference bit-for-bit, dense within 1e-5.  Run:  python oracle/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle.ref_import import load_reference, reference_config          # noqa: E402
+from oracle import dgt_oracle as O                                      # noqa: E402
+from jodo_amd.models.init_utils import deterministic_init_              # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+HEAD_GAIN = 30.0      # scale the heads' last layers so that argmax / threshold decodes are not degenerate
+
+
+def build_reference_model(ref, cfg_name, seed, head_gain=1.0):
+    cfg = reference_config(cfg_name)
+    cfg.device = torch.device('cpu')
+    model = ref.models.utils._MODELS[cfg.model.name](cfg).eval()
+    deterministic_init_(model, seed=seed)
+    if head_gain != 1.0:
+        with torch.no_grad():
+            for k in ('node_pred_mlp.4.weight', 'edge_type_mlp.4.weight', 'edge_exist_mlp.4.weight'):
+                model.state_dict()[k].mul_(head_gain)
+    return cfg, model
+
+
+def masks(n_nodes):
+    B, N = len(n_nodes), max(n_nodes)
+    nm = torch.zeros(B, N)
+    for i, n in enumerate(n_nodes):
+        nm[i, :n] = 1
+    em = nm.unsqueeze(1) * nm.unsqueeze(2) * (~torch.eye(N, dtype=torch.bool)).unsqueeze(0)
+    return nm.unsqueeze(2), em.reshape(-1, 1)
+
+
+def forward_fixture(ref, cfg_name, n_nodes, seed, fname):
+    cfg, model = build_reference_model(ref, cfg_name, seed)
+    hp = O.Hyper.from_config(cfg)
+    g = torch.Generator().manual_seed(seed + 100)
+    B, N = len(n_nodes), max(n_nodes)
+    nm, em = masks(n_nodes)
+    xh = torch.randn(B, N, 3 + hp.in_node_dim, generator=g) * nm
+    xh[:, :, :3] = xh[:, :, :3] - xh[:, :, :3].sum(1, keepdim=True) / nm.sum(1, keepdim=True) * nm
+    ex = torch.randn(B, N, N, hp.edge_ch, generator=g)
+    ex = (torch.tril(ex.permute(0, 3, 1, 2), -1) + torch.tril(ex.permute(0, 3, 1, 2), -1).transpose(-1, -2)).permute(0, 2, 3, 1)
+    ex = ex * em.reshape(B, N, N, 1)
+    nl = torch.randn(B, generator=g) * 2.0                        # per-molecule noise levels (training-like)
+    ctx = torch.randn(B, 1, generator=g) if hp.cond_ch else None
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        kw = dict(edge_x=ex, noise_level=nl, context=ctx)
+        r1 = model(torch.ones(B), xh, nm, em, cond_x=None, cond_edge_x=None, **kw)
+        r2 = model(torch.ones(B), xh, nm, em, cond_x=r1[0], cond_edge_x=r1[1], **kw)
+        for cx, cex, want in ((None, None, r1), (r1[0], r1[1], r2)):
+            f = O.forward_faithful(sd, hp, xh, nm, em, ex, cx, cex, nl, ctx)
+            d = O.forward_dense(sd, hp, xh, nm, em, ex, cx, cex, nl, ctx)
+            assert torch.equal(f[0], want[0]) and torch.equal(f[1], want[1]), "faithful oracle != reference"
+            err = max((d[0] - want[0]).abs().max().item(), (d[1] - want[1]).abs().max().item())
+            assert err < 1e-5, "dense oracle vs reference: %g" % err
+    np.savez_compressed(os.path.join(OUT, fname), cfg_name=cfg_name, seed=seed, n_nodes=np.array(n_nodes),
+                        xh=xh.numpy(), edge_x=ex.numpy(), noise_level=nl.numpy(),
+                        context=ctx.numpy() if ctx is not None else np.zeros(0, np.float32),
+                        out1_x=r1[0].numpy(), out1_e=r1[1].numpy(), out2_x=r2[0].numpy(), out2_e=r2[1].numpy())
+    print(fname, 'ok; |out| =', r2[0].abs().max().item(), r2[1].abs().max().item())
+
+
+def ancestral_fixture(ref, fname, steps=5, n_nodes=(9, 5, 17, 12), seed=21):
+    cfg, model = build_reference_model(ref, 'vpsde_qm9_uncond_jodo', seed, head_gain=HEAD_GAIN)
+    cfg.sampling.steps = steps
+    S = ref.sampling
+    ns = ref.diffusion.noise_schedule.NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0,
+                                                      continuous_beta_1=cfg.sde.continuous_beta_1)
+    time_steps = torch.linspace(ns.T, 1e-3, steps)
+    sampler = S.AncestralSampler(ns, time_steps, cfg.model.pred_data, cfg.pred_edge, cfg.model.self_cond,
+                                 ref.utils.get_self_cond_fn(cfg))
+    n_nodes = list(n_nodes)
+    B, N = len(n_nodes), max(n_nodes)
+    nm, em = masks(n_nodes)
+    torch.manual_seed(seed)
+    node_nf = cfg.data.atom_types + int(cfg.model.include_fc_charge)
+    z = S.sample_combined_position_feature_noise(B, N, node_nf, nm)
+    ez = S.sample_symmetric_edge_feature_noise(B, N, cfg.model.edge_ch, em)
+    rec_node, rec_edge = [], []
+    orig_n, orig_e = S.sample_combined_position_feature_noise, S.sample_symmetric_edge_feature_noise
+
+    def rn(*a, **k):
+        v = orig_n(*a, **k)
+        rec_node.append(v.clone())
+        return v
+
+    def re_(*a, **k):
+        v = orig_e(*a, **k)
+        rec_edge.append(v.clone())
+        return v
+
+    S.sample_combined_position_feature_noise, S.sample_symmetric_edge_feature_noise = rn, re_
+    try:
+        with torch.no_grad():
+            x_mean, e_mean = sampler.sampling(model, z, nm, em, ez, None)
+    finally:
+        S.sample_combined_position_feature_noise, S.sample_symmetric_edge_feature_noise = orig_n, orig_e
+    inv = ref.utils.get_data_inverse_scaler(cfg)
+    pos, one_hot, fc, et = S.post_process(x_mean.clone(), cfg.data.atom_types, cfg.model.include_fc_charge, nm, inv,
+                                          e_mean.clone(), em, cfg.data.compress_edge)
+    # decision margins of the discrete decodes (distance of the decisive value to its threshold)
+    _, h_cat, h_int, h_edge = inv(x_mean[:, :, :3], x_mean[:, :, 3:-1], x_mean[:, :, -1:], nm, e_mean, em)
+    top2 = h_cat.topk(2, dim=2).values
+    m_atom = (top2[..., 0] - top2[..., 1])[nm[..., 0] > 0].min().item()
+    m_fc = (0.5 - (h_int - h_int.round()).abs())[nm[..., 0] > 0].min().item()
+    emk = em.reshape(B, N, N) > 0
+    m_exist = (h_edge[..., 0] - 0.5).abs()[emk].min().item()
+    o3 = h_edge[..., 1] * 3.
+    m_order = torch.stack([(o3 - t).abs() for t in (0.5, 1.5, 2.5)]).min(0).values[emk].min().item() / 3.
+    np.savez_compressed(os.path.join(OUT, fname), seed=seed, steps=steps, head_gain=HEAD_GAIN, n_nodes=np.array(n_nodes),
+                        z=z.numpy(), edge_z=ez.numpy(), node_noise=torch.stack(rec_node).numpy(),
+                        edge_noise=torch.stack(rec_edge).numpy(), x_mean=x_mean.numpy(), edge_x_mean=e_mean.numpy(),
+                        pos=pos.numpy(), atom_type=one_hot.argmax(2).numpy(), fc=fc.numpy(), edge_type=et.numpy(),
+                        margins=np.array([m_atom, m_fc, m_exist, m_order]))
+    print(fname, 'ok; margins atom/fc/exist/order =', m_atom, m_fc, m_exist, m_order,
+          'atom types', np.unique(one_hot.argmax(2).numpy()), 'bond types', np.unique(et.numpy()))
+
+
+def dpm_fixture(ref, fname, nfe=4, n_nodes=(9, 5, 17, 12), seed=31):
+    cfg, model = build_reference_model(ref, 'vpsde_qm9_cond_jodo', seed, head_gain=HEAD_GAIN)
+    cfg.sampling.steps = nfe
+    cfg.sampling.method = 'fast'
+    cfg.sampling.dpm_solver_method = 'singlestep_fixed'       # keys the cond config lacks
+    cfg.sampling.dpm_solver_order = 2
+    M = ref.mix_dpm_solver
+    S = ref.sampling
+    ns = ref.diffusion.noise_schedule.NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0,
+                                                      continuous_beta_1=cfg.sde.continuous_beta_1)
+    solver = M.DPM_Solver_hybrid(ns, cfg)
+    n_nodes = list(n_nodes)
+    B, N = len(n_nodes), max(n_nodes)
+    nm, em = masks(n_nodes)
+    torch.manual_seed(seed)
+    node_nf = cfg.data.atom_types + int(cfg.model.include_fc_charge)
+    z = S.sample_combined_position_feature_noise(B, N, node_nf, nm)
+    ez = S.sample_symmetric_edge_feature_noise(B, N, cfg.model.edge_ch, em)
+    ctx = torch.randn(B, 1)
+    rec = []
+    orig = M.sample_center_gravity_zero_gaussian_with_mask
+
+    def rp(*a, **k):
+        v = orig(*a, **k)
+        rec.append(v.clone())
+        return v
+
+    M.sample_center_gravity_zero_gaussian_with_mask = rp
+    try:
+        x, ex = solver.sampling(model, z, nm, em, ez, ctx)
+    finally:
+        M.sample_center_gravity_zero_gaussian_with_mask = orig
+    np.savez_compressed(os.path.join(OUT, fname), seed=seed, nfe=nfe, head_gain=HEAD_GAIN, n_nodes=np.array(n_nodes),
+                        z=z.numpy(), edge_z=ez.numpy(), context=ctx.numpy(), pos_noise=torch.stack(rec).numpy(),
+                        x=x.numpy(), edge_x=ex.numpy())
+    print(fname, 'ok; noise draws', len(rec))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = load_reference()
+    forward_fixture(ref, 'vpsde_qm9_uncond_jodo', [3, 5, 9, 12, 17, 29], 11, 'fwd_qm9.npz')
+    forward_fixture(ref, 'vpsde_geom_uncond_jodo', [5, 23, 44, 61], 12, 'fwd_geom.npz')
+    forward_fixture(ref, 'vpsde_qm9_cond_jodo', [4, 9, 18, 18, 27], 13, 'fwd_cond.npz')
+    ancestral_fixture(ref, 'traj_qm9_anc5.npz')
+    dpm_fixture(ref, 'traj_cond_dpm4.npz')
+
+
+if __name__ == '__main__':
+    main()
