@@ -1,0 +1,231 @@
+"""Headline benchmark: QM9 unconditional JODO, 1000-step ancestral sampling, batch 2500 per GPU
+(BASELINE.json configs[1]) — molecules/s and ms per denoise step on MI355X.
+
+A "step" is one pass of the hot path over one batch: one score-network evaluation (HIP kernels via
+libjodo_hip.so) plus the ancestral update of the reference's sampler, inputs resident in HBM.
+`value` = molecules/s of a full 1000-step sampling round = (B * n_gpus) / (1000 * step_time);
+per-step cost is independent of the step index, so K timed steps measure it directly.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload qm9|geom|cond]
+
+N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; one
+process per GPU, every rank samples its own B molecules (weak scaling), no collective on the data
+path; RCCL is only used for the timing reduction and the final gather of generated molecules.
+
+The JSON line also carries
+  roofline      fp32-MFMA roofline of the dominant kernel (k_edge_update), timed live with HIP events
+                on the launch stream (jodo_profile_* in the C ABI); algorithmic FLOPs per launch =
+                directed edges x per-edge FLOPs of that kernel
+  cpu_baseline  oracle/dgt_oracle.py forward_faithful (op-for-op port of the reference's sparse
+                formulation) timed on the host cores on a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    'qm9': dict(cfg='vpsde_qm9_uncond_jodo', info='qm9_with_h', batch=2500,
+                name='QM9 uncond JODO (DGT_concat nf=256 L=8), 1000-step ancestral, batch 2500 per GPU'),
+    'geom': dict(cfg='vpsde_geom_uncond_jodo', info='geom_with_h_1', batch=512,
+                 name='GEOM-Drugs uncond JODO medium (nf=256 L=10), 1000-step ancestral, batch 512 per GPU'),
+    'cond': dict(cfg='vpsde_qm9_cond_jodo', info='qm9_second_half', batch=313,
+                 name='QM9 cond JODO (cond_DGT_concat), ancestral steps, batch 313 per GPU'),
+}
+PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+SAMPLING_STEPS = 1000
+
+
+def edge_update_flops_per_edge(hp):
+    """Algorithmic FLOPs per directed edge per launch of k_edge_update (share of SURVEY.md §8d F_edge)."""
+    D, De, L, r = hp.nf, hp.de, hp.n_layers, hp.mlp_ratio
+    return (2 * 2 * De * r * De            # edge FFN
+            + 2 * (2 * De) * D             # input_lin, edge + distance part
+            + 2 * D * D + 2 * D * (1 + hp.n_extra_heads)   # coord_mlp
+            + 2 * De * ((2 * De) // L)     # readout
+            + 12 * De + 8 * D)             # LN2/modulate on e, LN/modulate on u
+
+
+def cpu_baseline(seed=42):
+    """Bounded CPU sample: QM9 model, B = 64 (BASELINE config 1 shape), a few denoise-step forwards of the
+    faithful port, extrapolated to molecules/s of a 1000-step round."""
+    from jodo_amd import configs
+    from jodo_amd.models import get_model_class, deterministic_init_, load_dataset_info, get_node_dist
+    from jodo_amd.sampling import build_masks
+    from oracle import dgt_oracle as O
+    cfg = configs.get('vpsde_qm9_uncond_jodo')
+    model = deterministic_init_(get_model_class('DGT_concat')(cfg), seed=seed)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    hp = O.Hyper.from_config(cfg)
+    torch.manual_seed(seed)
+    n_nodes = get_node_dist(load_dataset_info('qm9_with_h')).sample(64).tolist()
+    B, N = 64, max(n_nodes)
+    nm, em = build_masks(n_nodes, N, 'cpu')
+    xh = torch.randn(B, N, 9) * nm
+    ex = torch.randn(B, N, N, 2)
+    ex = (ex + ex.transpose(1, 2)) * em.reshape(B, N, N, 1)
+    nl = torch.full((B,), 0.5)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        c = O.forward_faithful(sd, hp, xh, nm, em, ex, None, None, nl)        # warm-up + self-cond input
+        t0 = time.perf_counter()
+        n_steps = 0
+        while n_steps < 3 or (time.perf_counter() - t0 < 10.0 and n_steps < 20):
+            c = O.forward_faithful(sd, hp, xh, nm, em, ex, c[0], c[1], nl)
+            n_steps += 1
+        dt = (time.perf_counter() - t0) / n_steps
+    return dict(value=B / (SAMPLING_STEPS * dt), unit='molecules/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d self-conditioned denoise-step forwards of oracle.forward_faithful at B=64 '
+                       '(BASELINE config 1 shape), %.3f s/step, extrapolated x1000 steps' % (n_steps, dt),
+                ms_per_step=dt * 1e3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='qm9', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=0)
+    ap.add_argument('--max-chunk', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--breakdown', action='store_true', help='print per-kernel-class times to stderr')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
+                             % (args.gpus, args.gpus, args.gpus))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl')
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    from jodo_amd import configs, capi
+    from jodo_amd.diffusion import NoiseScheduleVP
+    from jodo_amd.models import get_model_class, deterministic_init_, load_dataset_info, get_node_dist
+    from jodo_amd.sampling import AncestralSampler, build_masks, post_process, mol_process
+    from jodo_amd.models.utils import sample_combined_position_feature_noise, sample_symmetric_edge_feature_noise
+    from jodo_amd.utils import get_self_cond_fn, get_data_inverse_scaler
+    from oracle import dgt_oracle as O        # only for the FLOP model and the cpu_baseline leg
+
+    wl = WORKLOADS[args.workload]
+    cfg = configs.get(wl['cfg'])
+    cfg.device = dev
+    B = args.batch or wl['batch']
+    hp = O.Hyper.from_config(cfg)
+    model = deterministic_init_(get_model_class(cfg.model.name)(cfg), seed=cfg.seed).to(dev).eval()
+    model.max_chunk = args.max_chunk
+
+    # synthetic inputs: atom counts from the training histogram (seed 42 + rank), reference noise shapes
+    torch.manual_seed(cfg.seed + rank)
+    n_nodes = get_node_dist(load_dataset_info(wl['info'])).sample(B).tolist()
+    N = max(n_nodes)
+    node_mask, edge_mask = build_masks(n_nodes, N, dev)
+    node_nf = cfg.data.atom_types + int(cfg.model.include_fc_charge)
+    z = sample_combined_position_feature_noise(B, N, node_nf, node_mask)
+    edge_z = sample_symmetric_edge_feature_noise(B, N, cfg.model.edge_ch, edge_mask)
+    context = torch.randn(B, hp.cond_ch, device=dev) if hp.cond_ch else None
+    ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0,
+                         continuous_beta_1=cfg.sde.continuous_beta_1)
+    time_steps = torch.linspace(ns.T, 1e-3, SAMPLING_STEPS, device=dev)
+    sampler = AncestralSampler(ns, time_steps, True, True, True, get_self_cond_fn(cfg))
+
+    L = capi.lib()
+    with torch.no_grad():
+        st = sampler.init_state(z, edge_z)
+        for i in range(args.warmup):
+            st = sampler.step(model, i, st, node_mask, edge_mask, context)
+        plan = model._last_plan
+        capi.check(L.jodo_profile_enable(plan['handle'], 1), 'profile_enable')
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, args.warmup + args.steps):
+            st = sampler.step(model, i, st, node_mask, edge_mask, context)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    ms = (ctypes.c_float * 8)()
+    cnt = (ctypes.c_int32 * 8)()
+    capi.check(L.jodo_profile_read(plan['handle'], ms, cnt), 'profile_read')
+    capi.check(L.jodo_profile_enable(plan['handle'], 0), 'profile_enable')
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    step_s = elapsed / args.steps
+
+    # not timed: finish the round's host side once so the whole path is exercised (decode + gather)
+    with torch.no_grad():
+        inv = get_data_inverse_scaler(cfg)
+        pos, one_hot, fc, et = post_process(st['x_mean'], cfg.data.atom_types, cfg.model.include_fc_charge, node_mask,
+                                            inv, st['edge_x_mean'], edge_mask, cfg.data.compress_edge)
+    if world > 1:
+        from jodo_amd.dist import gather_molecules
+        gathered = gather_molecules(pos, one_hot.argmax(2), fc[..., 0], et, torch.tensor(n_nodes, device=dev))
+        n_total = gathered['n_nodes'].numel() if rank == 0 else 0
+    else:
+        n_total = len(mol_process(one_hot, pos, fc, n_nodes, et))
+    nan_fired = model.nan_guard_fired()
+
+    if rank == 0:
+        E = sum(n * (n - 1) for n in n_nodes)
+        flops_launch = E * edge_update_flops_per_edge(hp)
+        names = ['prologue', 'node_pre', 'edge_scores', 'softmax', 'edge_msgs', 'node_post', 'edge_update', 'epilogue']
+        per_class = {names[c]: (ms[c] / max(cnt[c], 1), cnt[c]) for c in range(8)}
+        upd_ms, upd_n = per_class['edge_update']
+        achieved = flops_launch / (upd_ms * 1e-3) if upd_ms > 0 else 0.0
+        total_flops = O.algorithmic_flops(hp, n_nodes)['total']
+        out = {
+            'metric': 'molecules/sec (1000-step ancestral)',
+            'value': B * world / (SAMPLING_STEPS * step_s),
+            'unit': 'molecules/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': step_s * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': wl['name'], 'batch_per_gpu': B, 'sampling_steps': SAMPLING_STEPS,
+                       'directed_edges_per_step': E, 'nodes_per_step': sum(n_nodes), 'max_n': N,
+                       'weights': 'deterministic random init (trained checkpoints are external downloads)',
+                       'parallelism': 'batch shard x%d, no data-path collective' % world},
+            'roofline': {'bound': 'mfma', 'kernel': 'k_edge_update', 'achieved': achieved / 1e12, 'peak': PEAK_FP32_MFMA / 1e12,
+                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA, 'traffic': None,
+                         'avg_launch_ms': upd_ms, 'launches': upd_n, 'alg_flops_per_launch': flops_launch,
+                         'whole_step_TFLOPs': total_flops / step_s / 1e12,
+                         'whole_step_frac': total_flops / step_s / PEAK_FP32_MFMA},
+            'kernel_ms': {k: round(v[0] * (v[1] / args.steps), 4) for k, v in per_class.items()},
+            'molecules_decoded': n_total, 'nan_guard': bool(nan_fired),
+        }
+        if args.breakdown:
+            print(json.dumps(per_class), file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg.seed)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

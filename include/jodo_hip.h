@@ -113,6 +113,17 @@ int jodo_debug_fetch(jodo_plan* plan, const void* workspace, int what, float* ds
 /* limit the number of DGT blocks executed by jodo_dgt_forward (tests; <0 = all) */
 int jodo_debug_set_max_blocks(jodo_plan* plan, int max_blocks);
 
+/* Per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+ * enable != 0 makes every subsequent jodo_dgt_forward bracket its launches with events (small
+ * overhead); jodo_profile_read synchronises those events and returns, per class, the summed
+ * milliseconds and launch counts since the last read (arrays of JODO_PROF_COUNT), then resets. */
+enum jodo_prof_class {
+    JODO_PROF_PROLOGUE = 0, JODO_PROF_NODE_PRE, JODO_PROF_EDGE_SCORES, JODO_PROF_SOFTMAX, JODO_PROF_EDGE_MSGS,
+    JODO_PROF_NODE_POST, JODO_PROF_EDGE_UPDATE, JODO_PROF_EPILOGUE, JODO_PROF_COUNT
+};
+int jodo_profile_enable(jodo_plan* plan, int enable);
+int jodo_profile_read(jodo_plan* plan, float* ms_sum, int32_t* launches);
+
 const char* jodo_last_error(void);
 
 int jodo_debug_mlp(const float* x, int rows, const float* w1, const float* b1, const float* w2,

@@ -48,6 +48,21 @@ int rowgemm(hipStream_t st, const float* X, int64_t ldx, float* Y, int64_t ldy, 
     return jodo_check_launch("k_rowgemm");
 }
 
+// event bracket for one launch class (no-op unless profiling is enabled on the plan)
+struct ProfScope {
+    jodo_plan* p; hipStream_t st; int cls; bool on;
+    static hipEvent_t get(jodo_plan* p) {
+        if (!p->prof_pool.empty()) { hipEvent_t e = (hipEvent_t)p->prof_pool.back(); p->prof_pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    ProfScope(jodo_plan* p_, hipStream_t st_, int cls_) : p(p_), st(st_), cls(cls_), on(p_->prof_enabled != 0) {
+        if (on) { hipEvent_t e = get(p); (void)hipEventRecord(e, st); p->prof_ev.push_back(e); }
+    }
+    ~ProfScope() {
+        if (on) { hipEvent_t e = get(p); (void)hipEventRecord(e, st); p->prof_ev.push_back(e); p->prof_cls.push_back(cls); }
+    }
+};
+
 #define LAUNCH(kern, grid, block, ...)                                  \
     do {                                                                \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, __VA_ARGS__); \
@@ -102,6 +117,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     int rc;
 
     // ---- time embedding -> modulation vectors ----
+    ProfScope* pro = new ProfScope(p, st, JODO_PROF_PROLOGUE);
     LAUNCH(k_flags_init, 1, 256, A);
     LAUNCH(k_time1, p->B, 256, A);
     const int* uflag = flags_dev + FLAG_UNIFORM_T;
@@ -136,6 +152,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     if (rc) return rc;
     if (p->n_items > 0) LAUNCH(k_embed_edges, p->n_items, 64, A);
 
+    delete pro;
     // ---- DGT blocks ----
     const int nblocks = (p->max_blocks >= 0 && p->max_blocks < d.L) ? p->max_blocks : d.L;
     int cur = 0;                                   // posbuf[cur] holds the positions entering the block
@@ -144,17 +161,20 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
         A.mod_base = 32 + (int64_t)l * d.MB;
         for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + i];
         A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
-        LAUNCH(k_node_pre, p->n_strips, 64, A);
+        { ProfScope ps(p, st, JODO_PROF_NODE_PRE); LAUNCH(k_node_pre, p->n_strips, 64, A); }
         cur ^= 1;                                  // k_node_pre wrote the block's positions to pos_out
-        if (p->n_items > 0) LAUNCH(k_edge_scores, p->n_items, 64, A);
-        LAUNCH(k_softmax, (p->Nn + 15) / 16, 256, A);
-        if (p->n_items > 0) LAUNCH(k_edge_msgs, p->n_items, 64, A);
-        if (d.r == 2) LAUNCH(k_node_post<2>, p->n_strips, 64, A); else LAUNCH(k_node_post<4>, p->n_strips, 64, A);
+        if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_SCORES); LAUNCH(k_edge_scores, p->n_items, 64, A); }
+        { ProfScope ps(p, st, JODO_PROF_SOFTMAX); LAUNCH(k_softmax, (p->Nn + 15) / 16, 256, A); }
+        if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_MSGS); LAUNCH(k_edge_msgs, p->n_items, 64, A); }
+        { ProfScope ps(p, st, JODO_PROF_NODE_POST);
+          if (d.r == 2) LAUNCH(k_node_post<2>, p->n_strips, 64, A); else LAUNCH(k_node_post<4>, p->n_strips, 64, A); }
         if (p->n_items > 0) {
+            ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);
             if (d.r == 2) LAUNCH(k_edge_update<2>, p->n_items, 64, A); else LAUNCH(k_edge_update<4>, p->n_items, 64, A);
         }
     }
     // ---- heads + outputs ----
+    ProfScope epi(p, st, JODO_PROF_EPILOGUE);
     A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
     A.layer = nblocks;                             // k_pos_final adds the last block's partial updates if any ran
     if (nblocks == 0) {                            // no update to add: copy through

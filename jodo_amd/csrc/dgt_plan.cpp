@@ -52,7 +52,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
             return jodo_set_error(JODO_ERR_ARG, "plan_create: n_nodes[%d]=%d outside [1,%d]", b, n_nodes[b], N);
         }
     if (max_chunk <= 0) max_chunk = 8;
-    p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0;
+    p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->prof_enabled = 0;
 
     // molecules by descending size (stable): neighbouring lanes share n, big work first
     std::vector<int> order(B);
@@ -124,7 +124,33 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     return JODO_OK;
 }
 
-extern "C" void jodo_plan_destroy(jodo_plan* p) { delete p; }
+extern "C" void jodo_plan_destroy(jodo_plan* p) {
+    if (!p) return;
+    for (void* e : p->prof_ev) (void)hipEventDestroy((hipEvent_t)e);
+    for (void* e : p->prof_pool) (void)hipEventDestroy((hipEvent_t)e);
+    delete p;
+}
+extern "C" int jodo_profile_enable(jodo_plan* p, int enable) {
+    if (!p) return jodo_set_error(JODO_ERR_ARG, "null plan");
+    p->prof_enabled = enable;
+    return JODO_OK;
+}
+extern "C" int jodo_profile_read(jodo_plan* p, float* ms_sum, int32_t* launches) {
+    if (!p || !ms_sum || !launches) return jodo_set_error(JODO_ERR_ARG, "profile_read: null");
+    for (int c = 0; c < JODO_PROF_COUNT; ++c) { ms_sum[c] = 0.f; launches[c] = 0; }
+    for (size_t i = 0; i + 1 < p->prof_ev.size(); i += 2) {
+        hipEvent_t a = (hipEvent_t)p->prof_ev[i], b = (hipEvent_t)p->prof_ev[i + 1];
+        hipError_t e = hipEventSynchronize(b);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+        if (e != hipSuccess) return jodo_set_error(JODO_ERR_LAUNCH, "profile_read: %s", hipGetErrorString(e));
+        const int c = p->prof_cls[i / 2];
+        ms_sum[c] += ms; launches[c] += 1;
+        p->prof_pool.push_back(p->prof_ev[i]); p->prof_pool.push_back(p->prof_ev[i + 1]);
+    }
+    p->prof_ev.clear(); p->prof_cls.clear();
+    return JODO_OK;
+}
 extern "C" size_t jodo_plan_desc_bytes(const jodo_plan* p) { return p ? p->desc.size() * sizeof(int32_t) : 0; }
 extern "C" size_t jodo_plan_workspace_bytes(const jodo_plan* p) { return p ? p->ws.total : 0; }
 extern "C" int64_t jodo_plan_mod_len(const jodo_plan* p) { return p ? p->dims.Mtot : 0; }

@@ -52,6 +52,11 @@ struct jodo_plan {
     size_t off_node_b, off_node_i, off_node_n, off_node_noff, off_node_eoff, off_orig_n, off_orig_noff,
         off_orig_eoff, off_item_strip, off_item_t0, off_item_t1, off_item_part, off_strip_parts;   // in int32 elements
     WsLayout ws;
+    // profiling (jodo_profile_*): pairs of events per launch class, recorded on the launch stream
+    int prof_enabled;
+    std::vector<void*> prof_ev;      // hipEvent_t start/stop pairs in record order
+    std::vector<int> prof_cls;       // class of each pair
+    std::vector<void*> prof_pool;    // reusable events
     int max_blocks;                  // debug: limit blocks executed (<0 = all)
     int last_pos_buf;                // debug: which pos buffer holds the latest positions
 };

@@ -189,40 +189,48 @@ class AncestralSampler:
         return sample_symmetric_edge_feature_noise(edge_mean.shape[0], edge_mean.shape[1], edge_mean.shape[-1],
                                                    edge_mask)
 
+    def init_state(self, z_T, edge_z_T):
+        return dict(x=z_T, edge_x=edge_z_T, cond_x=None, cond_edge_x=None, x_mean=None, edge_x_mean=None)
+
+    def step(self, model, i, st, node_mask, edge_mask, context=None):
+        """One denoising step i (model evaluation + ancestral update) on the state dict `st`."""
+        ns = self.noise_scheduler
+        x, edge_x = st['x'], st['edge_x']
+        bs = x.shape[0]
+        t, s = self.t_array[i], self.s_array[i]
+        c_x, c_pred, sigma, alpha_t, sigma_t, a_ts, var_ts = posterior_coefficients(ns, t, s)
+        vec_t = torch.ones(bs, device=x.device) * t
+        noise_level = torch.ones(bs, device=x.device) * torch.log(alpha_t ** 2 / sigma_t ** 2)
+        if self.self_cond:
+            assert self.model_pred_data
+            pred_t, edge_pred_t = model(vec_t, x, node_mask, edge_mask, edge_x=edge_x, noise_level=noise_level,
+                                        cond_x=st['cond_x'], cond_edge_x=st['cond_edge_x'], context=context)
+            st['cond_x'], st['cond_edge_x'] = self.cond_process_fn(pred_t, edge_pred_t)
+        else:
+            pred_t, edge_pred_t = model(vec_t, x, node_mask, edge_mask, edge_x=edge_x, noise_level=noise_level,
+                                        context=context)
+        if self.model_pred_data:
+            x_mean = (expand_dims(c_x.repeat(bs), x.dim()) * x
+                      + expand_dims(c_pred.repeat(bs), pred_t.dim()) * pred_t)
+            edge_x_mean = (expand_dims(c_x.repeat(bs), edge_x.dim()) * edge_x
+                           + expand_dims(c_pred.repeat(bs), edge_pred_t.dim()) * edge_pred_t)
+        else:
+            k = var_ts / a_ts / sigma_t
+            x_mean = x / expand_dims(a_ts.repeat(bs), x.dim()) - expand_dims(k.repeat(bs), pred_t.dim()) * pred_t
+            edge_x_mean = (edge_x / expand_dims(a_ts.repeat(bs), edge_x.dim())
+                           - expand_dims(k.repeat(bs), edge_pred_t.dim()) * edge_pred_t)
+        # RNG order: node noise, then edge noise (as the reference)
+        st['x'] = x_mean + expand_dims(sigma.repeat(bs), x_mean.dim()) * self._node_noise(i, x_mean, node_mask)
+        st['edge_x'] = edge_x_mean + expand_dims(sigma.repeat(bs), edge_x_mean.dim()) * \
+            self._edge_noise(i, edge_x_mean, edge_mask)
+        st['x_mean'], st['edge_x_mean'] = x_mean, edge_x_mean
+        return st
+
     def sampling(self, model, z_T, node_mask, edge_mask, edge_z_T=None, context=None):
         if not self.pred_edge:
             raise NotImplementedError("edge-free sampling is out of scope")
-        x, edge_x = z_T, edge_z_T
-        bs = z_T.shape[0]
-        cond_x = cond_edge_x = None
-        ns = self.noise_scheduler
+        st = self.init_state(z_T, edge_z_T)
         for i in range(len(self.t_array)):
-            t, s = self.t_array[i], self.s_array[i]
-            c_x, c_pred, sigma, alpha_t, sigma_t, a_ts, var_ts = posterior_coefficients(ns, t, s)
-            vec_t = torch.ones(bs, device=x.device) * t
-            noise_level = torch.ones(bs, device=x.device) * torch.log(alpha_t ** 2 / sigma_t ** 2)
-            if self.self_cond:
-                assert self.model_pred_data
-                pred_t, edge_pred_t = model(vec_t, x, node_mask, edge_mask, edge_x=edge_x,
-                                            noise_level=noise_level, cond_x=cond_x, cond_edge_x=cond_edge_x,
-                                            context=context)
-                cond_x, cond_edge_x = self.cond_process_fn(pred_t, edge_pred_t)
-            else:
-                pred_t, edge_pred_t = model(vec_t, x, node_mask, edge_mask, edge_x=edge_x,
-                                            noise_level=noise_level, context=context)
-            if self.model_pred_data:
-                x_mean = (expand_dims(c_x.repeat(bs), x.dim()) * x
-                          + expand_dims(c_pred.repeat(bs), pred_t.dim()) * pred_t)
-                edge_x_mean = (expand_dims(c_x.repeat(bs), edge_x.dim()) * edge_x
-                               + expand_dims(c_pred.repeat(bs), edge_pred_t.dim()) * edge_pred_t)
-            else:
-                k = var_ts / a_ts / sigma_t
-                x_mean = x / expand_dims(a_ts.repeat(bs), x.dim()) - expand_dims(k.repeat(bs), pred_t.dim()) * pred_t
-                edge_x_mean = (edge_x / expand_dims(a_ts.repeat(bs), edge_x.dim())
-                               - expand_dims(k.repeat(bs), edge_pred_t.dim()) * edge_pred_t)
-            # RNG order: node noise, then edge noise (as the reference)
-            x = x_mean + expand_dims(sigma.repeat(bs), x_mean.dim()) * self._node_noise(i, x_mean, node_mask)
-            edge_x = edge_x_mean + expand_dims(sigma.repeat(bs), edge_x_mean.dim()) * \
-                self._edge_noise(i, edge_x_mean, edge_mask)
-        assert_mean_zero_with_mask(x_mean[:, :, :3], node_mask)
-        return x_mean, edge_x_mean
+            st = self.step(model, i, st, node_mask, edge_mask, context)
+        assert_mean_zero_with_mask(st['x_mean'][:, :, :3], node_mask)
+        return st['x_mean'], st['edge_x_mean']

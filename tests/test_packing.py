@@ -1,0 +1,84 @@
+"""CPU: packer <-> C header lock-step, exported C-ABI symbols, plan building (host-only code)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from jodo_amd import capi, packing as P
+from jodo_amd.packing_model import BLOCK_SLOTS, GLOBAL_SLOTS, ModelDims
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'jodo_hip.h')
+
+
+def _enum(body_name, text):
+    m = re.search(r'enum %s \{(.*?)\};' % body_name, text, re.S)
+    names = [t.strip().split('=')[0].strip() for t in m.group(1).replace('\n', ' ').split(',') if t.strip()]
+    return names
+
+
+def test_slot_enums_match_python_packer():
+    text = open(HEADER).read()
+    g = _enum('jodo_wslot_global', text)
+    b = _enum('jodo_wslot_block', text)
+    assert g[-1] == 'JW_GLOBAL_COUNT' and b[-1] == 'JB_BLOCK_COUNT'
+    assert [n[3:] for n in g[:-1]] == GLOBAL_SLOTS
+    assert [n[3:] for n in b[:-1]] == BLOCK_SLOTS
+
+
+def test_library_exports_every_declared_symbol():
+    text = open(HEADER).read()
+    decl = set(re.findall(r'\b(jodo_[a-z0-9_]+)\s*\(', text))
+    lib = capi.lib()
+    missing = [s for s in sorted(decl) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert {'jodo_dgt_forward', 'jodo_plan_create', 'jodo_last_error', 'jodo_profile_read'} <= decl
+
+
+class _Cfg(ctypes.Structure):
+    _fields_ = [('nf', ctypes.c_int32), ('n_layers', ctypes.c_int32), ('n_heads', ctypes.c_int32),
+                ('n_extra', ctypes.c_int32), ('mlp_ratio', ctypes.c_int32), ('in_node_dim', ctypes.c_int32),
+                ('edge_ch', ctypes.c_int32), ('cond_ch', ctypes.c_int32),
+                ('spatial_cut_off', ctypes.c_float), ('edge_quan_th', ctypes.c_float)]
+
+
+def _plan(n_nodes, N=None, cfg=None, chunk=0):
+    lib = capi.lib()
+    cfg = cfg or _Cfg(256, 8, 16, 2, 2, 6, 2, 0, 2.0, 0.0)
+    n = np.asarray(n_nodes, dtype=np.int32)
+    h = ctypes.c_void_p()
+    rc = lib.jodo_plan_create(ctypes.byref(cfg), len(n), int(N or n.max()), n.ctypes.data_as(ctypes.c_void_p), chunk,
+                              ctypes.byref(h))
+    return lib, rc, h
+
+
+def test_plan_statistics_and_errors():
+    lib, rc, h = _plan([3, 29, 18, 18, 1])
+    assert rc == 0
+    st = (ctypes.c_int64 * 6)()
+    assert lib.jodo_plan_stats(h, st) == 0
+    n = np.array([3, 29, 18, 18, 1])
+    assert st[0] == n.sum() and st[1] == (n * n).sum() and st[2] == (n * (n - 1)).sum()
+    assert st[3] == (n.sum() + 31) // 32 and st[4] >= st[3] and st[5] >= 1
+    lib.jodo_plan_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.jodo_plan_workspace_bytes(h) > 0
+    lib.jodo_plan_destroy(h)
+    # ragged / invalid inputs are rejected with a message, never a crash
+    lib2, rc, _ = _plan([3, 0, 5])
+    assert rc < 0 and b'n_nodes' in lib2.jodo_last_error()
+    _, rc, _ = _plan([3, 40], N=29)
+    assert rc < 0
+    _, rc, _ = _plan([5, 6], cfg=_Cfg(384, 10, 16, 2, 4, 17, 3, 0, 3.0, 0.0))
+    assert rc < 0 and b'nf=384' in capi.lib().jodo_last_error()
+
+
+def test_small_and_qk_maps_are_bijections():
+    for sh, sc in ((14, 18), (14, 27)):
+        m = P.qk_out_map(sh, sc).reshape(-1)
+        assert sorted(m[m >= 0].tolist()) == list(range(sh * sc))
+    m = P.small_in_map(12).reshape(-1)
+    assert sorted(m[m >= 0].tolist()) == list(range(12))
+    d = ModelDims(256, 10, 16, 2, 4, 17, 3)
+    assert (d.KNH, d.KEH, d.QKP, d.ndp) == (896, 224, 256, 40)
