@@ -37,6 +37,16 @@ __device__ __forceinline__ float tanh_f(float x) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x * fast_rcp(1.f + fast_exp(-x)); }
 
+// Make a pointer opaque to the optimiser at this program point.  Used at the top of per-edge loops:
+// without it LICM hoists every loop-invariant vector (modulation rows, biases, GBF tables: hundreds
+// of registers) out of the loop and the kernel spills; re-reading them from L1 each iteration is
+// far cheaper than the scratch traffic.
+template <typename T>
+__device__ __forceinline__ T* launder(T* p) {
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
 // sum of a per-half partial over the two half-lanes of an item
 __device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32); }
 
@@ -97,6 +107,78 @@ __device__ __forceinline__ f32x16 mfma_block(const float4* __restrict__ w, const
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, act[4 * q + 1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, act[4 * q + 2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, act[4 * q + 3], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// ---- software-pipelined variant ---------------------------------------------------------------------
+// The weight stream is read straight from L2 (it is shared by every wave of the launch and far
+// larger than LDS); one 16-byte load per lane feeds 4 MFMAs = 256 matrix-pipe cycles, while an L2
+// hit costs a few hundred.  Left to itself hipcc issues load -> s_waitcnt vmcnt(0) -> 4 MFMAs, i.e.
+// fully serialised, and materialises a 64-bit VGPR address per load (hundreds of registers, spilled).
+// Here:
+//   * weights are addressed through ONE buffer descriptor (SGPRs) + a per-lane 32-bit byte offset
+//     (lane * 16) + a wave-uniform scalar byte offset per quad (SALU arithmetic, no VGPR addresses);
+//   * WPipe keeps one group of PG quads in flight: while the MFMAs of group g run, the loads of
+//     group g+1 (or of the first group of the NEXT block, `next`) are already issued;
+//   * sched_barrier(0) pins that order.  Requires KQ % PG == 0.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct WSrc {
+    __amdgpu_buffer_rsrc_t rs;   // descriptor of the whole packed-weight blob (wave-uniform)
+    unsigned voff;               // lane * 16
+};
+
+__device__ __forceinline__ WSrc make_wsrc(const float* blob, int lane) {
+    WSrc w;
+    w.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(blob), 0, 0x7fffffff, 0x00020000);
+    w.voff = (unsigned)lane * 16u;
+    return w;
+}
+
+// quad q (1 KiB each) of the block that starts at byte offset `soff` of the blob
+__device__ __forceinline__ float4 wload(const WSrc& w, unsigned soff, int q) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.voff, soff + (unsigned)q * 1024u, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+constexpr int PG = 4;
+struct WPipe {
+    float4 q[PG];
+};
+
+__device__ __forceinline__ void wpipe_prime(WPipe& p, const WSrc& w, unsigned soff) {
+#pragma unroll
+    for (int i = 0; i < PG; ++i) p.q[i] = wload(w, soff, i);
+}
+
+// cur: byte offset of this block; next: byte offset of the block that will be consumed after it
+template <int KQ>
+__device__ __forceinline__ f32x16 mfma_block_p(WPipe& p, const WSrc& w, unsigned cur_off, unsigned next_off,
+                                               const float (&act)[KQ * 4], f32x16 acc) {
+    static_assert(KQ % PG == 0, "block length must be a multiple of the prefetch group");
+#pragma unroll
+    for (int g = 0; g < KQ / PG; ++g) {
+        float4 cur[PG];
+#pragma unroll
+        for (int i = 0; i < PG; ++i) cur[i] = p.q[i];
+        if (g + 1 < KQ / PG) {
+#pragma unroll
+            for (int i = 0; i < PG; ++i) p.q[i] = wload(w, cur_off, (g + 1) * PG + i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PG; ++i) p.q[i] = wload(w, next_off, i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < PG; ++i) {
+            const int k = (g * PG + i) * 4;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i].x, act[k + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i].y, act[k + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i].z, act[k + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i].w, act[k + 3], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     return acc;
 }

@@ -16,7 +16,7 @@
 namespace jd {
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_node_pre(KArgs A) {
+__global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
     const int strip = blockIdx.x;
     const LaneNode L = lane_node(A, strip, j);
@@ -37,16 +37,20 @@ __global__ __launch_bounds__(64) void k_node_pre(KArgs A) {
     load_nat<8>(A.h + (size_t)L.v * 256, half, hx);
     layer_norm<128>(hx);
     modulate<8>(hx, mr, mr + 256, half);
-    const int wslot[3] = {JB_WQ, JB_WK, JB_WV};
+    const WSrc ws = make_wsrc(A.W, lane);
+    const unsigned woff[3] = {(unsigned)(A.wb[JB_WQ] * 4), (unsigned)(A.wb[JB_WK] * 4), (unsigned)(A.wb[JB_WV] * 4)};
     const int bslot[3] = {JB_BQ, JB_BK, JB_BV};
     float* outp[3] = {A.q, A.k, A.v};
+    WPipe wp;
+    wpipe_prime(wp, ws, woff[0]);
 #pragma unroll
     for (int pj = 0; pj < 3; ++pj) {
-        const float4* w = wq(A, A.wb[wslot[pj]], lane);
         const float* bias = A.W + A.wb[bslot[pj]];
 #pragma unroll 1
         for (int b = 0; b < 8; ++b) {
-            f32x16 acc = mfma_block<32>(w + (size_t)b * 32 * 64, hx, zero16());
+            const unsigned cur = woff[pj] + (unsigned)b * 32 * 1024;
+            const unsigned nxt = b < 7 ? cur + 32 * 1024 : woff[pj < 2 ? pj + 1 : 0];
+            f32x16 acc = mfma_block_p<32>(wp, ws, cur, nxt, hx, zero16());
             float r[16];
             acc_bias(acc, bias + b * 32 + half * 16, r);
             store16(outp[pj] + (size_t)L.v * 256 + b * 32 + half * 16, r);
@@ -56,39 +60,46 @@ __global__ __launch_bounds__(64) void k_node_pre(KArgs A) {
 
 // ------------------------------------------------------------------------------------------------
 // scores: S stored as [row][half*8 + b] = head 2b+half  (head 0/1 = adjacency heads, 2.. learned)
-__global__ __launch_bounds__(64) void k_edge_scores(KArgs A) {
+__global__ __launch_bounds__(64, 2) void k_edge_scores(KArgs A) {
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
     const int it = blockIdx.x;
     const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it];
     const LaneNode L = lane_node(A, strip, j);
     const float* mrow = mod_row(A, L.b) + A.mod_base;
-    const float* es1 = mrow + 6 * 256;                       // edge chunks: es1, ec1, eg1, es2, ec2, eg2
-    const float* ec1 = es1 + 64;
     const float gscale = mrow[6 * 256 + 6 * 64 + 2 * 256 + 0], gshift = mrow[6 * 256 + 6 * 64 + 2 * 256 + 1];
     const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
-    const float* tab = A.W + A.wb[JB_GBF];
-    const float4* wEE = wq(A, A.wb[JB_EE_W], lane);
-    const float* bEE = A.W + A.wb[JB_EE_B];
-    const float4* wL0 = wq(A, A.wb[JB_LE0_W], lane);
-    const float* qrow = A.q + (size_t)L.v * 256;
+    const WSrc ws = make_wsrc(A.W, lane);
+    const unsigned oEE = (unsigned)(A.wb[JB_EE_W] * 4), oL0 = (unsigned)(A.wb[JB_LE0_W] * 4);
+    WPipe wp;
+    wpipe_prime(wp, ws, oEE);
     for (int t = t0; t < t1; ++t) {
         const bool ok = L.valid && t < L.n;
         const int tc = ok ? t : 0;
         const int u = L.noff + tc;
         const size_t r = (size_t)L.eoff + (size_t)tc * L.n + L.i;      // edge (source a = t) -> (target c = i)
+        const float* es1 = launder(mrow + 6 * 256);                 // edge chunks: es1, ec1, ...
+        const float* ec1 = es1 + 64;
+        const float* cst = launder(A.W);
+        const float* tab = cst + A.wb[JB_GBF];
+        const float* bEE = cst + A.wb[JB_EE_B];
+        const float* qrow = launder(A.q + (size_t)L.v * 256);
         const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[u];
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
-        float G[32], e[32], x[32];
-        gbf64(dx * dx + dy * dy + dz * dz, gscale, gshift, tab, half, G);
-        load_nat<2>(A.e + r * 64, half, e);
+        float x[32];
+        {
+            float G[32], e[32];
+            gbf64(dx * dx + dy * dy + dz * dz, gscale, gshift, tab, half, G);
+            load_nat<2>(A.e + r * 64, half, e);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            f32x16 acc = mfma_block<8>(wEE + (size_t)(b * 16) * 64, G, zero16());
-            acc = mfma_block<8>(wEE + (size_t)(b * 16 + 8) * 64, e, acc);
-            float rr[16];
-            acc_bias(acc, bEE + b * 32 + half * 16, rr);
+            for (int b = 0; b < 2; ++b) {
+                const unsigned cur = oEE + (unsigned)(b * 16) * 1024;
+                f32x16 acc = mfma_block_p<8>(wp, ws, cur, cur + 8 * 1024, G, zero16());
+                acc = mfma_block_p<8>(wp, ws, cur + 8 * 1024, b == 0 ? cur + 16 * 1024 : oL0, e, acc);
+                float rr[16];
+                acc_bias(acc, bEE + b * 32 + half * 16, rr);
 #pragma unroll
-            for (int s = 0; s < 16; ++s) x[b * 16 + s] = rr[s];
+                for (int s = 0; s < 16; ++s) x[b * 16 + s] = rr[s];
+            }
         }
         layer_norm<32>(x);
         modulate<2>(x, es1, ec1, half);
@@ -98,7 +109,8 @@ __global__ __launch_bounds__(64) void k_edge_scores(KArgs A) {
         float mainsum[7];
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
-            f32x16 acc = mfma_block<8>(wL0 + (size_t)b * 8 * 64, x, zero16());
+            const unsigned cur = oL0 + (unsigned)b * 8 * 1024;
+            f32x16 acc = mfma_block_p<8>(wp, ws, cur, cur + 8 * 1024, x, zero16());
             float qq[16], kk[16];
             load16(qrow + b * 32 + half * 16, qq);
             load16(krow + b * 32 + half * 16, kk);
@@ -109,7 +121,7 @@ __global__ __launch_bounds__(64) void k_edge_scores(KArgs A) {
         }
         float tail[14];
         {
-            f32x16 acc = mfma_block<8>(wL0 + (size_t)7 * 8 * 64, x, zero16());
+            f32x16 acc = mfma_block_p<8>(wp, ws, oL0 + 7u * 8 * 1024, oEE, x, zero16());
             float qq[16], kk[16];
             load16(qrow + 7 * 32 + half * 16, qq);
             load16(krow + 7 * 32 + half * 16, kk);
@@ -156,7 +168,7 @@ __global__ void k_softmax(KArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_edge_msgs(KArgs A) {
+__global__ __launch_bounds__(64, 2) void k_edge_msgs(KArgs A) {
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
     const int it = blockIdx.x;
     const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it], part = A.pd.item_part[it];
@@ -170,7 +182,10 @@ __global__ __launch_bounds__(64) void k_edge_msgs(KArgs A) {
         const float4 c = ip[0], d = ip[1];
         inv[0] = c.x; inv[1] = c.y; inv[2] = c.z; inv[3] = c.w; inv[4] = d.x; inv[5] = d.y; inv[6] = d.z; inv[7] = d.w;
     }
-    const float4* wL1 = wq(A, A.wb[JB_LE1_W], lane);
+    const WSrc ws = make_wsrc(A.W, lane);
+    const unsigned oL1 = (unsigned)(A.wb[JB_LE1_W] * 4);
+    WPipe wp;
+    wpipe_prime(wp, ws, oL1);
     float macc[128];
 #pragma unroll
     for (int s = 0; s < 128; ++s) macc[s] = 0.f;
@@ -192,7 +207,8 @@ __global__ __launch_bounds__(64) void k_edge_msgs(KArgs A) {
         const float* vrow = A.v + (size_t)u * 256;
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            f32x16 acc = mfma_block<8>(wL1 + (size_t)b * 8 * 64, x, zero16());
+            const unsigned cur = oL1 + (unsigned)b * 8 * 1024;
+            f32x16 acc = mfma_block_p<8>(wp, ws, cur, b < 7 ? cur + 8 * 1024 : oL1, x, zero16());
             float vv[16];
             load16(vrow + b * 32 + half * 16, vv);
 #pragma unroll
@@ -210,6 +226,11 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
     const LaneNode L = lane_node(A, strip, j);
     const float* mr = mod_row(A, L.b) + A.mod_base;
     const float* ng1 = mr + 2 * 256, *ns2 = mr + 3 * 256, *nc2 = mr + 4 * 256, *ng2 = mr + 5 * 256;
+    const WSrc ws = make_wsrc(A.W, lane);
+    const unsigned oN2E = (unsigned)(A.wb[JB_N2E_W] * 4), oF1 = (unsigned)(A.wb[JB_FF1_W] * 4), oF2 = (unsigned)(A.wb[JB_FF2_W] * 4);
+    const unsigned oRow = (unsigned)(A.wb[JB_ROW_W] * 4), oCol = (unsigned)(A.wb[JB_COL_W] * 4), oNro = (unsigned)(A.wb[JB_NRO_W] * 4);
+    WPipe wp;
+    wpipe_prime(wp, ws, oN2E);
     float hh[128];
 #pragma unroll
     for (int s = 0; s < 128; ++s) hh[s] = 0.f;
@@ -221,16 +242,14 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
         for (int s = 0; s < 128; ++s) hh[s] += tmp[s];
     }
     // node2edge_lin applied per node (bias added on the edge side)
-    {
-        const float4* w = wq(A, A.wb[JB_N2E_W], lane);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            f32x16 acc = mfma_block<32>(w + (size_t)b * 32 * 64, hh, zero16());
-            float r[16];
+    for (int b = 0; b < 2; ++b) {
+        const unsigned cur = oN2E + (unsigned)b * 32 * 1024;
+        f32x16 acc = mfma_block_p<32>(wp, ws, cur, b == 0 ? cur + 32 * 1024 : oF1, hh, zero16());
+        float r[16];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) r[s] = acc[s];
-            store16(A.n2e + (size_t)L.v * 64 + b * 32 + half * 16, r);
-        }
+        for (int s = 0; s < 16; ++s) r[s] = acc[s];
+        store16(A.n2e + (size_t)L.v * 64 + b * 32 + half * 16, r);
     }
     float hx[128];
     load_nat<8>(A.h + (size_t)L.v * 256, half, hx);
@@ -248,23 +267,28 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
 #pragma unroll
     for (int b = 0; b < 8; ++b) o[b] = zero16();
     {
-        const float4* w1 = wq(A, A.wb[JB_FF1_W], lane);
         const float* b1 = A.W + A.wb[JB_FF1_B];
-        const float4* w2 = wq(A, A.wb[JB_FF2_W], lane);
         constexpr int KQ2 = R * 256 / 8;                      // quads per ff2 output block
 #pragma unroll 1
         for (int c = 0; c < R * 4; ++c) {
             float hid[32];
 #pragma unroll
             for (int b2 = 0; b2 < 2; ++b2) {
-                f32x16 acc = mfma_block<32>(w1 + (size_t)(c * 2 + b2) * 32 * 64, hx, zero16());
+                const unsigned cur = oF1 + (unsigned)(c * 2 + b2) * 32 * 1024;
+                const unsigned nxt = b2 == 0 ? cur + 32 * 1024 : oF2 + (unsigned)(c * 8) * 1024;
+                f32x16 acc = mfma_block_p<32>(wp, ws, cur, nxt, hx, zero16());
                 float r[16];
                 acc_bias(acc, b1 + (c * 2 + b2) * 32 + half * 16, r);
 #pragma unroll
                 for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(r[s]);
             }
 #pragma unroll
-            for (int ob = 0; ob < 8; ++ob) o[ob] = mfma_block<8>(w2 + ((size_t)ob * KQ2 + c * 8) * 64, hid, o[ob]);
+            for (int ob = 0; ob < 8; ++ob) {
+                const unsigned cur = oF2 + (unsigned)(ob * KQ2 + c * 8) * 1024;
+                const unsigned nxt = ob < 7 ? oF2 + (unsigned)((ob + 1) * KQ2 + c * 8) * 1024
+                                            : (c + 1 < R * 4 ? oF1 + (unsigned)((c + 1) * 2) * 32 * 1024 : oRow);
+                o[ob] = mfma_block_p<8>(wp, ws, cur, nxt, hid, o[ob]);
+            }
         }
     }
     {
@@ -281,16 +305,15 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
     store_nat<8>(A.h + (size_t)L.v * 256, half, hx);
     // per-node halves of equi_update.input_lin: W_row h (+ bias), W_col h
     {
-        const float4* wr = wq(A, A.wb[JB_ROW_W], lane);
-        const float4* wc = wq(A, A.wb[JB_COL_W], lane);
         const float* bin = A.W + A.wb[JB_IN_B];
 #pragma unroll 1
         for (int b = 0; b < 8; ++b) {
-            f32x16 acc = mfma_block<32>(wr + (size_t)b * 32 * 64, hx, zero16());
+            const unsigned cr = oRow + (unsigned)b * 32 * 1024, cc = oCol + (unsigned)b * 32 * 1024;
+            f32x16 acc = mfma_block_p<32>(wp, ws, cr, cc, hx, zero16());
             float r[16];
             acc_bias(acc, bin + b * 32 + half * 16, r);
             store16(A.wrow + (size_t)L.v * 256 + b * 32 + half * 16, r);
-            acc = mfma_block<32>(wc + (size_t)b * 32 * 64, hx, zero16());
+            acc = mfma_block_p<32>(wp, ws, cc, b < 7 ? cr + 32 * 1024 : oNro, hx, zero16());
 #pragma unroll
             for (int s = 0; s < 16; ++s) r[s] = acc[s];
             store16(A.wcol + (size_t)L.v * 256 + b * 32 + half * 16, r);
@@ -298,11 +321,11 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
     }
     // readout node_l(h) -> atom_hids[:, D + l*64 ...]
     {
-        const float4* w = wq(A, A.wb[JB_NRO_W], lane);
         const float* bias = A.W + A.wb[JB_NRO_B];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            f32x16 acc = mfma_block<32>(w + (size_t)b * 32 * 64, hx, zero16());
+            const unsigned cur = oNro + (unsigned)b * 32 * 1024;
+            f32x16 acc = mfma_block_p<32>(wp, ws, cur, b == 0 ? cur + 32 * 1024 : oNro, hx, zero16());
             float r[16];
             acc_bias(acc, bias + b * 32 + half * 16, r);
             store16(A.ahid + (size_t)L.v * A.d.KNH + 256 + A.layer * 64 + b * 32 + half * 16, r);
@@ -325,14 +348,18 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
     const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
     const float cscale = A.W[A.wb[JB_CSCALE]];
     const float* tab = A.W + A.wb[JB_GBF];
-    float n2a[32];
-    load_nat<2>(A.n2e + (size_t)L.v * 64, half, n2a);
-    {
-        float bb[32];
-        load_nat<2>(A.W + A.wb[JB_N2E_B], half, bb);
-#pragma unroll
-        for (int s = 0; s < 32; ++s) n2a[s] += bb[s];
-    }
+    const float* n2bias = A.W + A.wb[JB_N2E_B];
+    const WSrc ws = make_wsrc(A.W, lane);
+    // byte offsets of the weight blocks inside the blob (wave-uniform)
+    const unsigned o3 = (unsigned)(A.wb[JB_FF3_W] * 4), o4 = (unsigned)(A.wb[JB_FF4_W] * 4);
+    const unsigned oro = (unsigned)(A.wb[JB_ERO_W] * 4), oi = (unsigned)(A.wb[JB_INE_W] * 4), o0 = (unsigned)(A.wb[JB_C0_W] * 4);
+    const float* b3 = A.W + A.wb[JB_FF3_B];
+    const float* b4 = A.W + A.wb[JB_FF4_B];
+    const float* b0 = A.W + A.wb[JB_C0_B];
+    const float* w2 = A.W + A.wb[JB_C2_W];                    // [3][256] natural
+    constexpr int KQ4 = R * 64 / 8;
+    WPipe wp;
+    wpipe_prime(wp, ws, o3);
     float dax = 0.f, day = 0.f, daz = 0.f;
     for (int t = t0; t < t1; ++t) {
         const bool inr = L.valid && t < L.n;
@@ -340,45 +367,63 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
         const int tc = inr ? t : 0;
         const int u = L.noff + tc;
         const size_t r = (size_t)L.eoff + (size_t)L.i * L.n + tc;
+        // keep loop-invariant vectors out of registers (see launder())
+        const float* eg1_ = launder(eg1);
+        const float* es2_ = eg1_ + 64, *ec2_ = es2_ + 64, *eg2_ = ec2_ + 64;
+        const float* qsh_ = launder(qsh);
+        const float* qsc_ = qsh_ + 256;
+        const float* cst = launder(A.W);                       // biases / tables / raw coord_mlp.2
+        const float* n2bias_ = cst + A.wb[JB_N2E_B], *b3_ = cst + A.wb[JB_FF3_B], *b4_ = cst + A.wb[JB_FF4_B];
+        const float* b0_ = cst + A.wb[JB_C0_B], *w2_ = cst + A.wb[JB_C2_W], *tab_ = cst + A.wb[JB_GBF];
+        const float* bro_ = cst + A.wb[JB_ERO_B];
         // ---- edge residual + LN2 + modulate ----
         float en[32];
         {
-            float e[32], n2c[32], g[32];
+            float e[32], n2a[32], n2c[32];
             load_nat<2>(A.e + r * 64, half, e);
+            load_nat<2>(A.n2e + (size_t)L.v * 64, half, n2a);
             load_nat<2>(A.n2e + (size_t)u * 64, half, n2c);
-            load_nat<2>(eg1, half, g);
 #pragma unroll
-            for (int s = 0; s < 32; ++s) en[s] = fmaf(g[s], n2a[s] + n2c[s], e[s]);
+            for (int b = 0; b < 2; ++b) {
+                float g[16], bb[16];
+                load16(eg1_ + b * 32 + half * 16, g);
+                load16(n2bias_ + b * 32 + half * 16, bb);
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    en[b * 16 + s] = fmaf(g[s], n2a[b * 16 + s] + n2c[b * 16 + s] + bb[s], e[b * 16 + s]);
+            }
         }
         layer_norm<32>(en);
-        modulate<2>(en, es2, ec2, half);
+        modulate<2>(en, es2_, ec2_, half);
         // ---- edge FFN (hidden R*64, chunks of 64) ----
         {
             f32x16 o[2] = {zero16(), zero16()};
-            const float4* w3 = wq(A, A.wb[JB_FF3_W], lane);
-            const float* b3 = A.W + A.wb[JB_FF3_B];
-            const float4* w4 = wq(A, A.wb[JB_FF4_W], lane);
-            constexpr int KQ4 = R * 64 / 8;
 #pragma unroll
             for (int c = 0; c < R; ++c) {
                 float hid[32];
 #pragma unroll
                 for (int b2 = 0; b2 < 2; ++b2) {
-                    f32x16 acc = mfma_block<8>(w3 + (size_t)(c * 2 + b2) * 8 * 64, en, zero16());
+                    const unsigned wcur = o3 + (unsigned)(c * 2 + b2) * 8 * 1024;
+                    const unsigned wnx = b2 == 0 ? wcur + 8 * 1024 : o4 + (unsigned)(c * 8) * 1024;
+                    f32x16 acc = mfma_block_p<8>(wp, ws, wcur, wnx, en, zero16());
                     float rr[16];
-                    acc_bias(acc, b3 + (c * 2 + b2) * 32 + half * 16, rr);
+                    acc_bias(acc, b3_ + (c * 2 + b2) * 32 + half * 16, rr);
 #pragma unroll
                     for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(rr[s]);
                 }
 #pragma unroll
-                for (int ob = 0; ob < 2; ++ob) o[ob] = mfma_block<8>(w4 + ((size_t)ob * KQ4 + c * 8) * 64, hid, o[ob]);
+                for (int ob = 0; ob < 2; ++ob) {
+                    const unsigned wcur = o4 + (unsigned)(ob * KQ4 + c * 8) * 1024;
+                    const unsigned wnx = ob == 0 ? o4 + (unsigned)(KQ4 + c * 8) * 1024
+                                                 : (c + 1 < R ? o3 + (unsigned)((c + 1) * 2) * 8 * 1024 : oro);
+                    o[ob] = mfma_block_p<8>(wp, ws, wcur, wnx, hid, o[ob]);
+                }
             }
-            const float* b4 = A.W + A.wb[JB_FF4_B];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 float rr[16], g[16];
-                acc_bias(o[b], b4 + b * 32 + half * 16, rr);
-                load16(eg2 + b * 32 + half * 16, g);
+                acc_bias(o[b], b4_ + b * 32 + half * 16, rr);
+                load16(eg2_ + b * 32 + half * 16, g);
 #pragma unroll
                 for (int s = 0; s < 16; ++s) en[b * 16 + s] = fmaf(g[s], rr[s], en[b * 16 + s]);
             }
@@ -386,55 +431,64 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
         if (inr) store_nat<2>(A.e + r * 64, half, en);
         // ---- readout edge_l(e) -> edge_hids[:, De + l*16 ...] (valid outputs live in half 0) ----
         {
-            f32x16 acc = mfma_block<8>(wq(A, A.wb[JB_ERO_W], lane), en, zero16());
+            f32x16 acc = mfma_block_p<8>(wp, ws, oro, oi, en, zero16());
             float rr[16];
-            acc_bias(acc, A.W + A.wb[JB_ERO_B] + half * 16, rr);
+            acc_bias(acc, bro_ + half * 16, rr);
             if (inr && half == 0) store16(A.ehid + r * A.d.KEH + 64 + A.layer * 16, rr);
         }
-        // ---- equivariant update ----
+        // ---- equivariant update: u = W_e e + W_d G + W_row h_a + W_col h_c (+b) held in 8 accumulators ----
         const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[u];
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
-        float uu[128];
+        f32x16 U[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned wcur = oi + (unsigned)(b * 16) * 1024;
+            const unsigned wnx = b < 7 ? oi + (unsigned)((b + 1) * 16) * 1024 : oi + 8u * 1024;
+            U[b] = mfma_block_p<8>(wp, ws, wcur, wnx, en, zero16());
+        }
         {
             float G[32];
-            gbf64(d2, gscale, gshift, tab, half, G);
-            const float4* wi = wq(A, A.wb[JB_INE_W], lane);
+            gbf64(d2, gscale, gshift, tab_, half, G);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const unsigned wcur = oi + (unsigned)(b * 16 + 8) * 1024;
+                const unsigned wnx = b < 7 ? oi + (unsigned)((b + 1) * 16 + 8) * 1024 : o0;
+                U[b] = mfma_block_p<8>(wp, ws, wcur, wnx, G, U[b]);
+            }
+        }
+        float uu[128];
+        {
             const float* wrow = A.wrow + (size_t)L.v * 256;
             const float* wcol = A.wcol + (size_t)u * 256;
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
-                f32x16 acc = mfma_block<8>(wi + (size_t)(b * 16) * 64, en, zero16());
-                acc = mfma_block<8>(wi + (size_t)(b * 16 + 8) * 64, G, acc);
                 float a1[16], a2[16];
                 load16(wrow + b * 32 + half * 16, a1);
                 load16(wcol + b * 32 + half * 16, a2);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) uu[b * 16 + s] = acc[s] + a1[s] + a2[s];
+                for (int s = 0; s < 16; ++s) uu[b * 16 + s] = U[b][s] + a1[s] + a2[s];
             }
         }
         layer_norm<128>(uu);
-        modulate<8>(uu, qsh, qsc, half);
+        modulate<8>(uu, qsh_, qsc_, half);
         float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-        {
-            const float4* w0 = wq(A, A.wb[JB_C0_W], lane);
-            const float* b0 = A.W + A.wb[JB_C0_B];
-            const float* w2 = A.W + A.wb[JB_C2_W];          // [3][256] natural
 #pragma unroll 1
-            for (int b = 0; b < 8; ++b) {
-                f32x16 acc = mfma_block<32>(w0 + (size_t)b * 32 * 64, uu, zero16());
-                float y[16], k0[16], k1[16], k2[16];
-                acc_bias(acc, b0 + b * 32 + half * 16, y);
-                load16(w2 + b * 32 + half * 16, k0);
-                load16(w2 + 256 + b * 32 + half * 16, k1);
-                load16(w2 + 512 + b * 32 + half * 16, k2);
+        for (int b = 0; b < 8; ++b) {
+            const unsigned wcur = o0 + (unsigned)b * 32 * 1024;
+            const unsigned wnx = b < 7 ? wcur + 32 * 1024 : o3;
+            f32x16 acc = mfma_block_p<32>(wp, ws, wcur, wnx, uu, zero16());
+            float y[16], k0[16], k1[16], k2[16];
+            acc_bias(acc, b0_ + b * 32 + half * 16, y);
+            load16(w2_ + b * 32 + half * 16, k0);
+            load16(w2_ + 256 + b * 32 + half * 16, k1);
+            load16(w2_ + 512 + b * 32 + half * 16, k2);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const float ys = silu_f(y[s]);
-                    c0 = fmaf(ys, k0[s], c0);
-                    c1 = fmaf(ys, k1[s], c1);
-                    c2 = fmaf(ys, k2[s], c2);
-                }
+            for (int s = 0; s < 16; ++s) {
+                const float ys = silu_f(y[s]);
+                c0 = fmaf(ys, k0[s], c0);
+                c1 = fmaf(ys, k1[s], c1);
+                c2 = fmaf(ys, k2[s], c2);
             }
         }
         c0 = tanh_f(pair_sum(c0));

@@ -184,9 +184,11 @@ class _DGTBase(nn.Module):
 
     # -- plans ---------------------------------------------------------------------------------
     def _plan(self, node_mask, edge_mask, device, validate=True):
-        key = (node_mask.data_ptr(), tuple(node_mask.shape), node_mask._version, str(device))
+        # keyed by tensor identity; the entry keeps the mask alive so its storage cannot be recycled
+        # for a different mask while the plan is cached (data_ptr alone is not a safe key)
+        key = id(node_mask)
         plan = self._plans.get(key)
-        if plan is not None:
+        if plan is not None and plan['mask'] is node_mask and plan['mask_version'] == node_mask._version:
             return plan
         B, N = node_mask.shape[0], node_mask.shape[1]
         nm = node_mask.reshape(B, N)
@@ -210,9 +212,12 @@ class _DGTBase(nn.Module):
         ws = torch.empty(L.jodo_plan_workspace_bytes(handle), dtype=torch.uint8, device=device)
         capi.check(L.jodo_plan_upload(handle, capi.ptr(desc), capi.current_stream_ptr()), 'jodo_plan_upload')
         torch.cuda.current_stream().synchronize()        # host staging buffer lives in the plan; be safe
-        plan = dict(handle=handle, desc=desc, ws=ws, n_nodes=n_host, B=B, N=N,
-                    flags=torch.zeros(8, dtype=torch.int32, device=device))
-        if len(self._plans) >= 8:                        # bounded cache
+        plan = dict(handle=handle, desc=desc, ws=ws, n_nodes=n_host, B=B, N=N, mask=node_mask,
+                    mask_version=node_mask._version, flags=torch.zeros(8, dtype=torch.int32, device=device))
+        stale = self._plans.pop(key, None)
+        if stale is not None:
+            L.jodo_plan_destroy(stale['handle'])
+        if len(self._plans) >= 4:                        # bounded cache
             old = self._plans.pop(next(iter(self._plans)))
             L.jodo_plan_destroy(old['handle'])
         self._plans[key] = plan

@@ -53,7 +53,7 @@ def test_hip_matches_reference_fixture(fname):
 
 @pytest.mark.parametrize("cfg_name,n_nodes,gain,chunk", [
     ('vpsde_qm9_uncond_jodo', [29, 1, 2, 18, 18, 7, 23], 1.0, 0),
-    ('vpsde_qm9_uncond_jodo', [5] * 40 + [19] * 30, 2.0, 3),      # multi-strip, odd chunking, larger activations
+    ('vpsde_qm9_uncond_jodo', [5] * 40 + [19] * 30, 1.5, 3),      # multi-strip, odd chunking, larger activations
     ('vpsde_geom_uncond_jodo', [70, 33, 12], 1.5, 16),
     ('vpsde_qm9_cond_jodo', [9, 9, 14], 1.0, 5),
 ])
