@@ -145,7 +145,7 @@ def main():
     context = torch.randn(B, hp.cond_ch, device=dev) if hp.cond_ch else None
     ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0,
                          continuous_beta_1=cfg.sde.continuous_beta_1)
-    time_steps = torch.linspace(ns.T, 1e-3, SAMPLING_STEPS, device=dev)
+    time_steps = torch.linspace(ns.T, 1e-3, SAMPLING_STEPS)
     sampler = AncestralSampler(ns, time_steps, True, True, True, get_self_cond_fn(cfg))
 
     L = capi.lib()

@@ -223,7 +223,8 @@ class DPM_Solver_hybrid:
         t_0 = 1. / ns.total_N if t_end is None else t_end
         t_T = ns.T if t_start is None else t_start
         assert t_0 > 0 and t_T > 0, "Time range needs to be greater than 0."
-        device = x.device
+        device = 'cpu'       # schedule scalars on the host (see sampling.get_sampling_fn); 0-dim CPU tensors
+                             # broadcast against device tensors
 
         if self.method == 'singlestep_fixed':
             K = steps // order

@@ -110,7 +110,10 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
 
     rounds = int(np.ceil(n_samples / batch_size))
     if config.sampling.method == 'ancestral':
-        time_steps = torch.linspace(noise_scheduler.T, eps, steps, device=device)
+        # schedule scalars are computed on the host: the VP coefficients near t -> 0 are ill-conditioned
+        # in fp32 (sigma_s = sqrt(1 - exp(2 log alpha_s)) with log alpha_s ~ 1e-7), so their low bits depend
+        # on the math library; keeping them on the CPU makes trajectories reproducible across devices
+        time_steps = torch.linspace(noise_scheduler.T, eps, steps)
         sampler = AncestralSampler(noise_scheduler, time_steps, config.model.pred_data, pred_edge,
                                    config.model.self_cond, get_self_cond_fn(config))
     elif config.sampling.method == 'fast':
@@ -209,20 +212,18 @@ class AncestralSampler:
         else:
             pred_t, edge_pred_t = model(vec_t, x, node_mask, edge_mask, edge_x=edge_x, noise_level=noise_level,
                                         context=context)
+        # the coefficients are scalars shared by the batch (the reference broadcasts them through
+        # .repeat(bs) + expand_dims, sampling.py:569-589 — same values, same products)
         if self.model_pred_data:
-            x_mean = (expand_dims(c_x.repeat(bs), x.dim()) * x
-                      + expand_dims(c_pred.repeat(bs), pred_t.dim()) * pred_t)
-            edge_x_mean = (expand_dims(c_x.repeat(bs), edge_x.dim()) * edge_x
-                           + expand_dims(c_pred.repeat(bs), edge_pred_t.dim()) * edge_pred_t)
+            x_mean = c_x * x + c_pred * pred_t
+            edge_x_mean = c_x * edge_x + c_pred * edge_pred_t
         else:
             k = var_ts / a_ts / sigma_t
-            x_mean = x / expand_dims(a_ts.repeat(bs), x.dim()) - expand_dims(k.repeat(bs), pred_t.dim()) * pred_t
-            edge_x_mean = (edge_x / expand_dims(a_ts.repeat(bs), edge_x.dim())
-                           - expand_dims(k.repeat(bs), edge_pred_t.dim()) * edge_pred_t)
+            x_mean = x / a_ts - k * pred_t
+            edge_x_mean = edge_x / a_ts - k * edge_pred_t
         # RNG order: node noise, then edge noise (as the reference)
-        st['x'] = x_mean + expand_dims(sigma.repeat(bs), x_mean.dim()) * self._node_noise(i, x_mean, node_mask)
-        st['edge_x'] = edge_x_mean + expand_dims(sigma.repeat(bs), edge_x_mean.dim()) * \
-            self._edge_noise(i, edge_x_mean, edge_mask)
+        st['x'] = x_mean + sigma * self._node_noise(i, x_mean, node_mask)
+        st['edge_x'] = edge_x_mean + sigma * self._edge_noise(i, edge_x_mean, edge_mask)
         st['x_mean'], st['edge_x_mean'] = x_mean, edge_x_mean
         return st
 

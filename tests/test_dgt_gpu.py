@@ -164,7 +164,7 @@ def test_ancestral_trajectory_with_hip_model():
     nm, em = masks(fx['n_nodes'].tolist(), DEV)
     ns = NoiseScheduleVP(cfg.sde.schedule)
     noise = {'node': torch.from_numpy(fx['node_noise']).to(DEV), 'edge': torch.from_numpy(fx['edge_noise']).to(DEV)}
-    sampler = AncestralSampler(ns, torch.linspace(ns.T, 1e-3, int(fx['steps']), device=DEV), True, True, True,
+    sampler = AncestralSampler(ns, torch.linspace(ns.T, 1e-3, int(fx['steps'])), True, True, True,
                                get_self_cond_fn(cfg), noise_fn=lambda i, kind, like: noise[kind][i])
     with torch.no_grad():
         x_mean, e_mean = sampler.sampling(model, torch.from_numpy(fx['z']).to(DEV), nm, em,
