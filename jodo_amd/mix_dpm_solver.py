@@ -87,7 +87,7 @@ class DPM_Solver_hybrid:
         ns = self.noise_schedule
         lam0, lam1 = ns.marginal_lambda(t_start), ns.marginal_lambda(t_end)
         h = lam1 - lam0
-        s1 = ns.inverse_lambda(lam0 + r1 * h)
+        s1 = ns.inverse_lambda(lam0 + r1 * h).reshape(())     # scalar (0-dim): broadcasts across devices
         sigma_start, sigma_s1, sigma_end = ns.marginal_std(t_start), ns.marginal_std(s1), ns.marginal_std(t_end)
         alpha_s1 = torch.exp(ns.marginal_log_mean_coeff(s1))
         alpha_end = torch.exp(ns.marginal_log_mean_coeff(t_end))
@@ -119,8 +119,8 @@ class DPM_Solver_hybrid:
         ns = self.noise_schedule
         lam0, lam1 = ns.marginal_lambda(t_start), ns.marginal_lambda(t_end)
         h = lam1 - lam0
-        s1 = ns.inverse_lambda(lam0 + r1 * h)
-        s2 = ns.inverse_lambda(lam0 + r2 * h)
+        s1 = ns.inverse_lambda(lam0 + r1 * h).reshape(())     # scalar (0-dim): broadcasts across devices
+        s2 = ns.inverse_lambda(lam0 + r2 * h).reshape(())
         sigma_start, sigma_s1, sigma_s2, sigma_end = (ns.marginal_std(t_start), ns.marginal_std(s1),
                                                       ns.marginal_std(s2), ns.marginal_std(t_end))
         alpha_s1 = torch.exp(ns.marginal_log_mean_coeff(s1))

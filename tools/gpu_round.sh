@@ -9,7 +9,7 @@ timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 | tee $OUT/pytes
 timeout 900 python bench.py --steps 10 --warmup 3 --breakdown > $OUT/bench.json 2> $OUT/bench.err
 tail -2 $OUT/bench.err; cat $OUT/bench.json
 # kernel-trace profile of the same command (fewer steps; no CPU baseline)
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o trace -- \
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o trace -- \
     python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err )
 find $OUT/prof -name "*kernel_stats*" | head -3
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
