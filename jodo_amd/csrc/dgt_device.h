@@ -142,19 +142,20 @@ __device__ __forceinline__ float4 wload(const WSrc& w, unsigned soff, int q) {
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-constexpr int PG = 4;
+template <int PG>          // quads per prefetch group: PG * 4 MFMAs (PG * 256 cycles) of cover per group
 struct WPipe {
     float4 q[PG];
 };
 
-__device__ __forceinline__ void wpipe_prime(WPipe& p, const WSrc& w, unsigned soff) {
+template <int PG>
+__device__ __forceinline__ void wpipe_prime(WPipe<PG>& p, const WSrc& w, unsigned soff) {
 #pragma unroll
     for (int i = 0; i < PG; ++i) p.q[i] = wload(w, soff, i);
 }
 
 // cur: byte offset of this block; next: byte offset of the block that will be consumed after it
-template <int KQ>
-__device__ __forceinline__ f32x16 mfma_block_p(WPipe& p, const WSrc& w, unsigned cur_off, unsigned next_off,
+template <int KQ, int PG>
+__device__ __forceinline__ f32x16 mfma_block_p(WPipe<PG>& p, const WSrc& w, unsigned cur_off, unsigned next_off,
                                                const float (&act)[KQ * 4], f32x16 acc) {
     static_assert(KQ % PG == 0, "block length must be a multiple of the prefetch group");
 #pragma unroll

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
     const unsigned woff[3] = {(unsigned)(A.wb[JB_WQ] * 4), (unsigned)(A.wb[JB_WK] * 4), (unsigned)(A.wb[JB_WV] * 4)};
     const int bslot[3] = {JB_BQ, JB_BK, JB_BV};
     float* outp[3] = {A.q, A.k, A.v};
-    WPipe wp;
+    WPipe<8> wp;
     wpipe_prime(wp, ws, woff[0]);
 #pragma unroll
     for (int pj = 0; pj < 3; ++pj) {
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64, 2) void k_edge_scores(KArgs A) {
     const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned oEE = (unsigned)(A.wb[JB_EE_W] * 4), oL0 = (unsigned)(A.wb[JB_LE0_W] * 4);
-    WPipe wp;
+    WPipe<4> wp;
     wpipe_prime(wp, ws, oEE);
     for (int t = t0; t < t1; ++t) {
         const bool ok = L.valid && t < L.n;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64, 2) void k_edge_msgs(KArgs A) {
     }
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned oL1 = (unsigned)(A.wb[JB_LE1_W] * 4);
-    WPipe wp;
+    WPipe<4> wp;
     wpipe_prime(wp, ws, oL1);
     float macc[128];
 #pragma unroll
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned oN2E = (unsigned)(A.wb[JB_N2E_W] * 4), oF1 = (unsigned)(A.wb[JB_FF1_W] * 4), oF2 = (unsigned)(A.wb[JB_FF2_W] * 4);
     const unsigned oRow = (unsigned)(A.wb[JB_ROW_W] * 4), oCol = (unsigned)(A.wb[JB_COL_W] * 4), oNro = (unsigned)(A.wb[JB_NRO_W] * 4);
-    WPipe wp;
+    WPipe<8> wp;
     wpipe_prime(wp, ws, oN2E);
     float hh[128];
 #pragma unroll
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
     const float* b0 = A.W + A.wb[JB_C0_B];
     const float* w2 = A.W + A.wb[JB_C2_W];                    // [3][256] natural
     constexpr int KQ4 = R * 64 / 8;
-    WPipe wp;
+    WPipe<8> wp;
     wpipe_prime(wp, ws, o3);
     float dax = 0.f, day = 0.f, daz = 0.f;
     for (int t = t0; t < t1; ++t) {
