@@ -43,8 +43,18 @@ __device__ __forceinline__ float silu_f(float x) { return x * fast_rcp(1.f + fas
 // far cheaper than the scratch traffic.
 template <typename T>
 __device__ __forceinline__ T* launder(T* p) {
-    asm volatile("" : "+v"(p));
-    return p;
+    // an opaque zero added to the pointer: the address space (global) stays visible to the compiler,
+    // so these remain global_load (not flat_load) instructions
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    return p + z;
+}
+
+// Full compiler + scheduler fence.  sched_barrier alone does not order the (readonly, unchained)
+// buffer-load intrinsics at instruction-selection time; the "memory" clobber does.
+__device__ __forceinline__ void pipeline_fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // sum of a per-half partial over the two half-lanes of an item
@@ -170,7 +180,7 @@ __device__ __forceinline__ f32x16 mfma_block_p(WPipe<PG>& p, const WSrc& w, unsi
 #pragma unroll
             for (int i = 0; i < PG; ++i) p.q[i] = wload(w, next_off, i);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        pipeline_fence();
 #pragma unroll
         for (int i = 0; i < PG; ++i) {
             const int k = (g * PG + i) * 4;
@@ -179,7 +189,7 @@ __device__ __forceinline__ f32x16 mfma_block_p(WPipe<PG>& p, const WSrc& w, unsi
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i].z, act[k + 2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i].w, act[k + 3], acc, 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        pipeline_fence();
     }
     return acc;
 }

@@ -341,26 +341,21 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
     const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it], part = A.pd.item_part[it];
     const LaneNode L = lane_node(A, strip, j);
     const float* mrow = mod_row(A, L.b) + A.mod_base;
-    const float* eg1 = mrow + 6 * 256 + 2 * 64, *es2 = eg1 + 64, *ec2 = es2 + 64, *eg2 = ec2 + 64;
+    const float* eg1 = mrow + 6 * 256 + 2 * 64;               // edge chunks: .., eg1, es2, ec2, eg2
     const float* qsh = mrow + 6 * 256 + 6 * 64;              // equi_update.time_mlp: (shift, scale)
-    const float* qsc = qsh + 256;
     const float gscale = mrow[6 * 256 + 6 * 64 + 2 * 256 + 0], gshift = mrow[6 * 256 + 6 * 64 + 2 * 256 + 1];
     const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
     const float cscale = A.W[A.wb[JB_CSCALE]];
-    const float* tab = A.W + A.wb[JB_GBF];
-    const float* n2bias = A.W + A.wb[JB_N2E_B];
     const WSrc ws = make_wsrc(A.W, lane);
     // byte offsets of the weight blocks inside the blob (wave-uniform)
     const unsigned o3 = (unsigned)(A.wb[JB_FF3_W] * 4), o4 = (unsigned)(A.wb[JB_FF4_W] * 4);
     const unsigned oro = (unsigned)(A.wb[JB_ERO_W] * 4), oi = (unsigned)(A.wb[JB_INE_W] * 4), o0 = (unsigned)(A.wb[JB_C0_W] * 4);
-    const float* b3 = A.W + A.wb[JB_FF3_B];
-    const float* b4 = A.W + A.wb[JB_FF4_B];
-    const float* b0 = A.W + A.wb[JB_C0_B];
-    const float* w2 = A.W + A.wb[JB_C2_W];                    // [3][256] natural
     constexpr int KQ4 = R * 64 / 8;
     WPipe<8> wp;
     wpipe_prime(wp, ws, o3);
     float dax = 0.f, day = 0.f, daz = 0.f;
+    // Operand loads of every VALU epilogue are issued BEFORE the MFMA block they follow (the blocks
+    // contain scheduling barriers), so they land while the matrix pipe is busy.
     for (int t = t0; t < t1; ++t) {
         const bool inr = L.valid && t < L.n;
         const bool ok = inr && t != L.i;
@@ -376,6 +371,14 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
         const float* n2bias_ = cst + A.wb[JB_N2E_B], *b3_ = cst + A.wb[JB_FF3_B], *b4_ = cst + A.wb[JB_FF4_B];
         const float* b0_ = cst + A.wb[JB_C0_B], *w2_ = cst + A.wb[JB_C2_W], *tab_ = cst + A.wb[JB_GBF];
         const float* bro_ = cst + A.wb[JB_ERO_B];
+        const float* wrow = launder(A.wrow + (size_t)L.v * 256);
+        const float* wcol = A.wcol + (size_t)u * 256;
+        // ---- geometry + Gaussian basis (needed by the equivariant update; computed up front) ----
+        const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[u];
+        const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        float G[32];
+        gbf64(d2, gscale, gshift, tab_, half, G);
         // ---- edge residual + LN2 + modulate ----
         float en[32];
         {
@@ -398,6 +401,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
         // ---- edge FFN (hidden R*64, chunks of 64) ----
         {
             f32x16 o[2] = {zero16(), zero16()};
+            float ob4[32], og2[32];
 #pragma unroll
             for (int c = 0; c < R; ++c) {
                 float hid[32];
@@ -405,11 +409,15 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
                 for (int b2 = 0; b2 < 2; ++b2) {
                     const unsigned wcur = o3 + (unsigned)(c * 2 + b2) * 8 * 1024;
                     const unsigned wnx = b2 == 0 ? wcur + 8 * 1024 : o4 + (unsigned)(c * 8) * 1024;
+                    float bb[16];
+                    load16(b3_ + (c * 2 + b2) * 32 + half * 16, bb);
                     f32x16 acc = mfma_block_p<8>(wp, ws, wcur, wnx, en, zero16());
-                    float rr[16];
-                    acc_bias(acc, b3_ + (c * 2 + b2) * 32 + half * 16, rr);
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(rr[s]);
+                    for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(acc[s] + bb[s]);
+                }
+                if (c == R - 1) {                               // operands of the FFN epilogue
+                    load_nat<2>(b4_, half, ob4);
+                    load_nat<2>(eg2_, half, og2);
                 }
 #pragma unroll
                 for (int ob = 0; ob < 2; ++ob) {
@@ -420,56 +428,47 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
                 }
             }
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                float rr[16], g[16];
-                acc_bias(o[b], b4_ + b * 32 + half * 16, rr);
-                load16(eg2_ + b * 32 + half * 16, g);
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int s = 0; s < 16; ++s) en[b * 16 + s] = fmaf(g[s], rr[s], en[b * 16 + s]);
-            }
+                for (int s = 0; s < 16; ++s)
+                    en[b * 16 + s] = fmaf(og2[b * 16 + s], o[b][s] + ob4[b * 16 + s], en[b * 16 + s]);
         }
         if (inr) store_nat<2>(A.e + r * 64, half, en);
         // ---- readout edge_l(e) -> edge_hids[:, De + l*16 ...] (valid outputs live in half 0) ----
         {
+            float bb[16];
+            load16(bro_ + half * 16, bb);
             f32x16 acc = mfma_block_p<8>(wp, ws, oro, oi, en, zero16());
             float rr[16];
-            acc_bias(acc, bro_ + half * 16, rr);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) rr[s] = acc[s] + bb[s];
             if (inr && half == 0) store16(A.ehid + r * A.d.KEH + 64 + A.layer * 16, rr);
         }
-        // ---- equivariant update: u = W_e e + W_d G + W_row h_a + W_col h_c (+b) held in 8 accumulators ----
-        const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[u];
-        const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
-        const float d2 = dx * dx + dy * dy + dz * dz;
+        // ---- equivariant update: u = W_e e + W_d G + (W_row h_a + b) + W_col h_c, 8 accumulators that
+        //      start from the per-node terms ----
         f32x16 U[8];
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const unsigned wcur = oi + (unsigned)(b * 16) * 1024;
             const unsigned wnx = b < 7 ? oi + (unsigned)((b + 1) * 16) * 1024 : oi + 8u * 1024;
+            float a1[16], a2[16];
+            load16(wrow + b * 32 + half * 16, a1);
+            load16(wcol + b * 32 + half * 16, a2);
             U[b] = mfma_block_p<8>(wp, ws, wcur, wnx, en, zero16());
-        }
-        {
-            float G[32];
-            gbf64(d2, gscale, gshift, tab_, half, G);
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const unsigned wcur = oi + (unsigned)(b * 16 + 8) * 1024;
-                const unsigned wnx = b < 7 ? oi + (unsigned)((b + 1) * 16 + 8) * 1024 : o0;
-                U[b] = mfma_block_p<8>(wp, ws, wcur, wnx, G, U[b]);
-            }
+            for (int s = 0; s < 16; ++s) U[b][s] += a1[s] + a2[s];
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned wcur = oi + (unsigned)(b * 16 + 8) * 1024;
+            const unsigned wnx = b < 7 ? oi + (unsigned)((b + 1) * 16 + 8) * 1024 : o0;
+            U[b] = mfma_block_p<8>(wp, ws, wcur, wnx, G, U[b]);
         }
         float uu[128];
-        {
-            const float* wrow = A.wrow + (size_t)L.v * 256;
-            const float* wcol = A.wcol + (size_t)u * 256;
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                float a1[16], a2[16];
-                load16(wrow + b * 32 + half * 16, a1);
-                load16(wcol + b * 32 + half * 16, a2);
+        for (int b = 0; b < 8; ++b)
 #pragma unroll
-                for (int s = 0; s < 16; ++s) uu[b * 16 + s] = U[b][s] + a1[s] + a2[s];
-            }
-        }
+            for (int s = 0; s < 16; ++s) uu[b * 16 + s] = U[b][s];
         layer_norm<128>(uu);
         modulate<8>(uu, qsh_, qsc_, half);
         float c0 = 0.f, c1 = 0.f, c2 = 0.f;
@@ -477,15 +476,15 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
         for (int b = 0; b < 8; ++b) {
             const unsigned wcur = o0 + (unsigned)b * 32 * 1024;
             const unsigned wnx = b < 7 ? wcur + 32 * 1024 : o3;
-            f32x16 acc = mfma_block_p<32>(wp, ws, wcur, wnx, uu, zero16());
-            float y[16], k0[16], k1[16], k2[16];
-            acc_bias(acc, b0_ + b * 32 + half * 16, y);
+            float bb[16], k0[16], k1[16], k2[16];
+            load16(b0_ + b * 32 + half * 16, bb);
             load16(w2_ + b * 32 + half * 16, k0);
             load16(w2_ + 256 + b * 32 + half * 16, k1);
             load16(w2_ + 512 + b * 32 + half * 16, k2);
+            f32x16 acc = mfma_block_p<32>(wp, ws, wcur, wnx, uu, zero16());
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const float ys = silu_f(y[s]);
+                const float ys = silu_f(acc[s] + bb[s]);
                 c0 = fmaf(ys, k0[s], c0);
                 c1 = fmaf(ys, k1[s], c1);
                 c2 = fmaf(ys, k2[s], c2);
