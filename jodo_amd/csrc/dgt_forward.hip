@@ -163,9 +163,9 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
         A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
         { ProfScope ps(p, st, JODO_PROF_NODE_PRE); LAUNCH(k_node_pre, p->n_strips, 64, A); }
         cur ^= 1;                                  // k_node_pre wrote the block's positions to pos_out
-        if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_SCORES); LAUNCH(k_edge_scores, p->n_items, 64, A); }
+        if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_SCORES); LAUNCH(k_edge_scores, (p->n_items + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A); }
         { ProfScope ps(p, st, JODO_PROF_SOFTMAX); LAUNCH(k_softmax, (p->Nn + 15) / 16, 256, A); }
-        if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_MSGS); LAUNCH(k_edge_msgs, p->n_items, 64, A); }
+        if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_MSGS); LAUNCH(k_edge_msgs, (p->n_items + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A); }
         { ProfScope ps(p, st, JODO_PROF_NODE_POST);
           if (d.r == 2) LAUNCH(k_node_post<2>, p->n_strips, 64, A); else LAUNCH(k_node_post<4>, p->n_strips, 64, A); }
         if (p->n_items > 0) {

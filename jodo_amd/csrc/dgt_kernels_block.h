@@ -50,28 +50,58 @@ __global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
         for (int b = 0; b < 8; ++b) {
             const unsigned cur = woff[pj] + (unsigned)b * 32 * 1024;
             const unsigned nxt = b < 7 ? cur + 32 * 1024 : woff[pj < 2 ? pj + 1 : 0];
+            float bb[16], r[16];
+            load16(bias + b * 32 + half * 16, bb);
             f32x16 acc = mfma_block_p<32>(wp, ws, cur, nxt, hx, zero16());
-            float r[16];
-            acc_bias(acc, bias + b * 32 + half * 16, r);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
             store16(outp[pj] + (size_t)L.v * 256 + b * 32 + half * 16, r);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS-resident weights: the two edge-attention kernels use small projections (K = 64) whose whole
+// weight set fits in LDS (scores: edge_emb 32 KiB + lin_edge0 64 KiB; msgs: lin_edge1 64 KiB).  A
+// workgroup of 8 waves (8 work items) loads it once; every iteration then reads its A operands with
+// conflict-free ds_read_b128 instead of streaming them from L2 (which was the L1-bandwidth limiter:
+// 256 B of weights per MFMA at K = 64).
+constexpr int WG_WAVES = 8;
+
+template <int NQ>   // cooperative copy of NQ quads (1 KiB each) global -> LDS
+__device__ __forceinline__ void stage_weights(float4* __restrict__ dst, const float4* __restrict__ src) {
+    for (int i = threadIdx.x; i < NQ * 64; i += WG_WAVES * 64) dst[i] = src[i];
+}
+
+template <int KQ>
+__device__ __forceinline__ f32x16 mfma_block_lds(const float4* wl, const float (&act)[KQ * 4], f32x16 acc) {
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        const float4 a = wl[q * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, act[4 * q + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, act[4 * q + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, act[4 * q + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, act[4 * q + 3], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 // scores: S stored as [row][half*8 + b] = head 2b+half  (head 0/1 = adjacency heads, 2.. learned)
-__global__ __launch_bounds__(64, 2) void k_edge_scores(KArgs A) {
+__global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_scores(KArgs A) {
+    __shared__ float4 wl[(32 + 64) * 64];                       // edge_emb (2 x 16 quads) | lin_edge0 (8 x 8 quads)
+    stage_weights<32>(wl, reinterpret_cast<const float4*>(A.W + A.wb[JB_EE_W]));
+    stage_weights<64>(wl + 32 * 64, reinterpret_cast<const float4*>(A.W + A.wb[JB_LE0_W]));
+    __syncthreads();
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int it = blockIdx.x;
+    const int it = blockIdx.x * WG_WAVES + (threadIdx.x >> 6);
+    if (it >= A.pd.n_items) return;
     const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it];
     const LaneNode L = lane_node(A, strip, j);
     const float* mrow = mod_row(A, L.b) + A.mod_base;
     const float gscale = mrow[6 * 256 + 6 * 64 + 2 * 256 + 0], gshift = mrow[6 * 256 + 6 * 64 + 2 * 256 + 1];
     const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
-    const WSrc ws = make_wsrc(A.W, lane);
-    const unsigned oEE = (unsigned)(A.wb[JB_EE_W] * 4), oL0 = (unsigned)(A.wb[JB_LE0_W] * 4);
-    WPipe<4> wp;
-    wpipe_prime(wp, ws, oEE);
+    const float4* wEE = wl + lane;
+    const float4* wL0 = wl + 32 * 64 + lane;
     for (int t = t0; t < t1; ++t) {
         const bool ok = L.valid && t < L.n;
         const int tc = ok ? t : 0;
@@ -83,6 +113,7 @@ __global__ __launch_bounds__(64, 2) void k_edge_scores(KArgs A) {
         const float* tab = cst + A.wb[JB_GBF];
         const float* bEE = cst + A.wb[JB_EE_B];
         const float* qrow = launder(A.q + (size_t)L.v * 256);
+        const float* krow = A.k + (size_t)u * 256;
         const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[u];
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
         float x[32];
@@ -92,41 +123,41 @@ __global__ __launch_bounds__(64, 2) void k_edge_scores(KArgs A) {
             load_nat<2>(A.e + r * 64, half, e);
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const unsigned cur = oEE + (unsigned)(b * 16) * 1024;
-                f32x16 acc = mfma_block_p<8>(wp, ws, cur, cur + 8 * 1024, G, zero16());
-                acc = mfma_block_p<8>(wp, ws, cur + 8 * 1024, b == 0 ? cur + 16 * 1024 : oL0, e, acc);
-                float rr[16];
-                acc_bias(acc, bEE + b * 32 + half * 16, rr);
+                float bb[16];
+                load16(bEE + b * 32 + half * 16, bb);
+                f32x16 acc = mfma_block_lds<8>(wEE + (b * 16) * 64, G, zero16());
+                acc = mfma_block_lds<8>(wEE + (b * 16 + 8) * 64, e, acc);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) x[b * 16 + s] = rr[s];
+                for (int s = 0; s < 16; ++s) x[b * 16 + s] = acc[s] + bb[s];
             }
         }
         layer_norm<32>(x);
         modulate<2>(x, es1, ec1, half);
         if (ok) store_nat<2>(A.et + r * 64, half, x);
         // lin_edge0 -> tanh -> * q_target * k_source, reduced per head
-        const float* krow = A.k + (size_t)u * 256;
         float mainsum[7];
+        float qn[16], kn[16];
+        load16(qrow + half * 16, qn);
+        load16(krow + half * 16, kn);
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
-            const unsigned cur = oL0 + (unsigned)b * 8 * 1024;
-            f32x16 acc = mfma_block_p<8>(wp, ws, cur, cur + 8 * 1024, x, zero16());
             float qq[16], kk[16];
-            load16(qrow + b * 32 + half * 16, qq);
-            load16(krow + b * 32 + half * 16, kk);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { qq[s] = qn[s]; kk[s] = kn[s]; }
+            load16(qrow + (b + 1) * 32 + half * 16, qn);               // one block ahead
+            load16(krow + (b + 1) * 32 + half * 16, kn);
+            f32x16 acc = mfma_block_lds<8>(wL0 + (b * 8) * 64, x, zero16());
             float s_ = 0.f;
 #pragma unroll
             for (int s = 0; s < 16; ++s) s_ = fmaf(tanh_f(acc[s]) * qq[s], kk[s], s_);
             mainsum[b] = s_;                              // head 2b+half, channels 0..15
+            pipeline_fence();
         }
         float tail[14];
         {
-            f32x16 acc = mfma_block_p<8>(wp, ws, oL0 + 7u * 8 * 1024, oEE, x, zero16());
-            float qq[16], kk[16];
-            load16(qrow + 7 * 32 + half * 16, qq);
-            load16(krow + 7 * 32 + half * 16, kk);
+            f32x16 acc = mfma_block_lds<8>(wL0 + (7 * 8) * 64, x, zero16());
 #pragma unroll
-            for (int g = 0; g < 14; ++g) tail[g] = tanh_f(acc[g]) * qq[g] * kk[g];   // head g, channel 16+half
+            for (int g = 0; g < 14; ++g) tail[g] = tanh_f(acc[g]) * qn[g] * kn[g];   // head g, channel 16+half
         }
         const int fl = A.eflag[r];
         // S_g = main_g (half g&1, block g>>1) + tail_g(half 0) + tail_g(half 1), scaled by 1/sqrt(C)
@@ -168,9 +199,13 @@ __global__ void k_softmax(KArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64, 2) void k_edge_msgs(KArgs A) {
+__global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_msgs(KArgs A) {
+    __shared__ float4 wl[64 * 64];                              // lin_edge1 (8 x 8 quads)
+    stage_weights<64>(wl, reinterpret_cast<const float4*>(A.W + A.wb[JB_LE1_W]));
+    __syncthreads();
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int it = blockIdx.x;
+    const int it = blockIdx.x * WG_WAVES + (threadIdx.x >> 6);
+    if (it >= A.pd.n_items) return;
     const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it], part = A.pd.item_part[it];
     const LaneNode L = lane_node(A, strip, j);
     float mx[8], inv[8];
@@ -182,10 +217,7 @@ __global__ __launch_bounds__(64, 2) void k_edge_msgs(KArgs A) {
         const float4 c = ip[0], d = ip[1];
         inv[0] = c.x; inv[1] = c.y; inv[2] = c.z; inv[3] = c.w; inv[4] = d.x; inv[5] = d.y; inv[6] = d.z; inv[7] = d.w;
     }
-    const WSrc ws = make_wsrc(A.W, lane);
-    const unsigned oL1 = (unsigned)(A.wb[JB_LE1_W] * 4);
-    WPipe<4> wp;
-    wpipe_prime(wp, ws, oL1);
+    const float4* wL1 = wl + lane;
     float macc[128];
 #pragma unroll
     for (int s = 0; s < 128; ++s) macc[s] = 0.f;
@@ -205,14 +237,18 @@ __global__ __launch_bounds__(64, 2) void k_edge_msgs(KArgs A) {
             for (int b2 = 0; b2 < 8; ++b2) al[b2] = ok ? fast_exp(sv[b2] - mx[b2]) * inv[b2] : 0.f;
         }
         const float* vrow = A.v + (size_t)u * 256;
+        float vnext[16];
+        load16(vrow + half * 16, vnext);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            const unsigned cur = oL1 + (unsigned)b * 8 * 1024;
-            f32x16 acc = mfma_block_p<8>(wp, ws, cur, b < 7 ? cur + 8 * 1024 : oL1, x, zero16());
             float vv[16];
-            load16(vrow + b * 32 + half * 16, vv);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) vv[s] = vnext[s];
+            if (b < 7) load16(vrow + (b + 1) * 32 + half * 16, vnext);   // one block ahead
+            f32x16 acc = mfma_block_lds<8>(wL1 + (b * 8) * 64, x, zero16());
 #pragma unroll
             for (int s = 0; s < 16; ++s) macc[b * 16 + s] = fmaf(tanh_f(acc[s]) * vv[s], al[b], macc[b * 16 + s]);
+            pipeline_fence();                                          // keep hoisting (and registers) bounded
         }
     }
     store_nat<8>(A.hhat + ((size_t)L.v * A.pd.max_parts + part) * 256, half, macc);
@@ -276,11 +312,11 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
             for (int b2 = 0; b2 < 2; ++b2) {
                 const unsigned cur = oF1 + (unsigned)(c * 2 + b2) * 32 * 1024;
                 const unsigned nxt = b2 == 0 ? cur + 32 * 1024 : oF2 + (unsigned)(c * 8) * 1024;
+                float bb[16];
+                load16(b1 + (c * 2 + b2) * 32 + half * 16, bb);
                 f32x16 acc = mfma_block_p<32>(wp, ws, cur, nxt, hx, zero16());
-                float r[16];
-                acc_bias(acc, b1 + (c * 2 + b2) * 32 + half * 16, r);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(r[s]);
+                for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(acc[s] + bb[s]);
             }
 #pragma unroll
             for (int ob = 0; ob < 8; ++ob) {
@@ -309,9 +345,11 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
 #pragma unroll 1
         for (int b = 0; b < 8; ++b) {
             const unsigned cr = oRow + (unsigned)b * 32 * 1024, cc = oCol + (unsigned)b * 32 * 1024;
+            float bb[16], r[16];
+            load16(bin + b * 32 + half * 16, bb);
             f32x16 acc = mfma_block_p<32>(wp, ws, cr, cc, hx, zero16());
-            float r[16];
-            acc_bias(acc, bin + b * 32 + half * 16, r);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
             store16(A.wrow + (size_t)L.v * 256 + b * 32 + half * 16, r);
             acc = mfma_block_p<32>(wp, ws, cc, b < 7 ? cr + 32 * 1024 : oNro, hx, zero16());
 #pragma unroll
@@ -325,9 +363,11 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const unsigned cur = oNro + (unsigned)b * 32 * 1024;
+            float bb[16], r[16];
+            load16(bias + b * 32 + half * 16, bb);
             f32x16 acc = mfma_block_p<32>(wp, ws, cur, b == 0 ? cur + 32 * 1024 : oNro, hx, zero16());
-            float r[16];
-            acc_bias(acc, bias + b * 32 + half * 16, r);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
             store16(A.ahid + (size_t)L.v * A.d.KNH + 256 + A.layer * 64 + b * 32 + half * 16, r);
         }
     }
