@@ -98,6 +98,7 @@ def main():
     ap.add_argument('--workload', default='qm9', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--max-chunk', type=int, default=0)
+    ap.add_argument('--pair-chunk', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print per-kernel-class times to stderr')
     args = ap.parse_args()
@@ -133,6 +134,8 @@ def main():
     hp = O.Hyper.from_config(cfg)
     model = deterministic_init_(get_model_class(cfg.model.name)(cfg), seed=cfg.seed).to(dev).eval()
     model.max_chunk = args.max_chunk
+    model.pair_chunk = args.pair_chunk
+    model.force_directed = bool(int(os.environ.get("JODO_FORCE_DIRECTED", "0")))   # debug: skip the symmetric pair kernels
 
     # synthetic inputs: atom counts from the training histogram (seed 42 + rank), reference noise shapes
     torch.manual_seed(cfg.seed + rank)
@@ -217,6 +220,8 @@ def main():
                          'whole_step_frac': total_flops / step_s / PEAK_FP32_MFMA},
             'kernel_ms': {k: round(v[0] * (v[1] / args.steps), 4) for k, v in per_class.items()},
             'molecules_decoded': n_total, 'nan_guard': bool(nan_fired),
+            'device_flags': dict(zip(('nan', 'first_step', 'uniform_t', 'cond_nonzero', 'asymmetric_edges'),
+                                     model.last_flags.cpu().tolist()[:5])),
         }
         if args.breakdown:
             print(json.dumps(per_class), file=sys.stderr)

@@ -76,7 +76,8 @@ typedef struct jodo_plan jodo_plan;
 /* Build the execution plan for a batch: B molecules with n_nodes[b] atoms (host array), padded
  * width N of the dense API tensors.  Molecules are ordered by size internally; masks are implied
  * (prefix masks, diagonal excluded), which is what the reference's samplers produce
- * (sampling.py:193-201).  max_chunk = sources per edge work item (0 = default). */
+ * (sampling.py:193-201).  max_chunk: low 16 bits = sources per directed edge work item, high 16 bits =
+ * offsets per pair work item of the symmetric path (0 = defaults 8 / 2). */
 int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes_host, int max_chunk,
                      jodo_plan** out);
 void jodo_plan_destroy(jodo_plan* plan);
@@ -97,7 +98,8 @@ int jodo_plan_stats(const jodo_plan* plan, int64_t* out6);
  *   noise_level [B]; context [B,cond_ch] or NULL
  *   out_xh [B,N,3+nd], out_edge [B,N,N,ch] (fully written, zeros on padding)
  *   flags_dev: int32[8] device scratch; after the call [0] = NaN guard fired (mol_gnn.py:587-589),
- *              [1] = first-step branch taken (:544), [2] = all molecules shared one noise level
+ *              [1] = first-step branch taken (:544), [2] = all molecules shared one noise level,
+ *              [4] = edge inputs were not symmetric (directed kernels used)
  *   workspace: jodo_plan_workspace_bytes() bytes of device scratch
  *   dbg: optional device buffer for intermediates (tests) or NULL */
 int jodo_dgt_forward(jodo_plan* plan, const void* desc_dev, const float* packed_w, const int64_t* woff,
@@ -112,6 +114,9 @@ int jodo_debug_fetch(jodo_plan* plan, const void* workspace, int what, float* ds
                      void* stream);
 /* limit the number of DGT blocks executed by jodo_dgt_forward (tests; <0 = all) */
 int jodo_debug_set_max_blocks(jodo_plan* plan, int max_blocks);
+/* force the directed (per directed edge) kernels even for symmetric inputs (tests; default 0: the
+ * symmetric pair kernels are chosen on the device whenever edge_x / cond_edge_x are symmetric) */
+int jodo_debug_set_force_directed(jodo_plan* plan, int on);
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * enable != 0 makes every subsequent jodo_dgt_forward bracket its launches with events (small

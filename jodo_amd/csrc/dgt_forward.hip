@@ -2,7 +2,9 @@
 // Host code only builds the argument block and enqueues kernels on the caller's stream; no
 // synchronisation, no allocation.
 #include "dgt_kernels_pre.h"
+#include "dgt_kernels_node.h"
 #include "dgt_kernels_block.h"
+#include "dgt_kernels_sym.h"
 #include "dgt_kernels_post.h"
 #include "jodo_hip_internal.h"
 
@@ -18,6 +20,8 @@ PlanDev make_plan_dev(const jodo_plan* p, const void* desc_dev) {
     d.orig_n = base + p->off_orig_n; d.orig_noff = base + p->off_orig_noff; d.orig_eoff = base + p->off_orig_eoff;
     d.item_strip = base + p->off_item_strip; d.item_t0 = base + p->off_item_t0; d.item_t1 = base + p->off_item_t1;
     d.item_part = base + p->off_item_part; d.strip_parts = base + p->off_strip_parts;
+    d.pitem_strip = base + p->off_pitem_strip; d.pitem_t0 = base + p->off_pitem_t0; d.pitem_t1 = base + p->off_pitem_t1;
+    d.n_pitems = p->n_pitems;
     d.Nn = p->Nn; d.Nn_pad = p->Nn_pad; d.n_strips = p->n_strips; d.n_items = p->n_items; d.B = p->B; d.N = p->N;
     d.max_parts = p->max_parts; d.rows = p->rows;
     return d;
@@ -37,6 +41,8 @@ void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
     A.stats = ws_ptr<float>(ws, w.stats); A.apred = ws_ptr<float>(ws, w.apred);
     A.eflag = ws_ptr<int>(ws, w.eflag); A.e = ws_ptr<float>(ws, w.e); A.et = ws_ptr<float>(ws, w.et);
     A.S = ws_ptr<float>(ws, w.S); A.ehid = ws_ptr<float>(ws, w.ehid); A.epred = ws_ptr<float>(ws, w.epred);
+    A.dposE = ws_ptr<float>(ws, w.dposE);
+    A.h_out = ws_ptr<float>(ws, w.h2); A.ffp = ws_ptr<float>(ws, w.ffp);
 }
 
 int rowgemm(hipStream_t st, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* Wp, const float* bias,
@@ -106,7 +112,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     A.W = packed_w;
     for (int i = 0; i < JW_GLOBAL_COUNT; ++i) A.wg[i] = woff[i];
     for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = 0;
-    A.mod_base = 0; A.layer = 0;
+    A.mod_base = 0; A.layer = 0; A.force_directed = p->force_directed;
     fill_ws(A, p, workspace);
     float* posbuf[2] = {ws_ptr<float>(workspace, p->ws.pos0), ws_ptr<float>(workspace, p->ws.pos1)};
     A.pos_in = posbuf[0]; A.pos_out = posbuf[1];
@@ -119,6 +125,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     // ---- time embedding -> modulation vectors ----
     ProfScope* pro = new ProfScope(p, st, JODO_PROF_PROLOGUE);
     LAUNCH(k_flags_init, 1, 256, A);
+    { const size_t tot = (size_t)p->B * p->N * p->N; LAUNCH(k_check_sym, (unsigned)((tot + 255) / 256), 256, A); }
     LAUNCH(k_time1, p->B, 256, A);
     const int* uflag = flags_dev + FLAG_UNIFORM_T;
     rc = rowgemm(st, A.hid1, d.T, A.temb, d.T, W + A.wg[JW_TIME_W3], W + A.wg[JW_TIME_B3], p->B, d.T, d.T / 32, 0, 0, uflag);
@@ -156,20 +163,30 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     // ---- DGT blocks ----
     const int nblocks = (p->max_blocks >= 0 && p->max_blocks < d.L) ? p->max_blocks : d.L;
     int cur = 0;                                   // posbuf[cur] holds the positions entering the block
+    int hcur = 0;                                  // which node-state buffer is current (0 = ws.h, 1 = ws.h2)
     for (int l = 0; l < nblocks; ++l) {
         A.layer = l;
         A.mod_base = 32 + (int64_t)l * d.MB;
         for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + i];
         A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
-        { ProfScope ps(p, st, JODO_PROF_NODE_PRE); LAUNCH(k_node_pre, p->n_strips, 64, A); }
+        { ProfScope ps(p, st, JODO_PROF_NODE_PRE); LAUNCH(k_node_pre, p->n_strips * 3, 64, A); }
         cur ^= 1;                                  // k_node_pre wrote the block's positions to pos_out
-        if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_SCORES); LAUNCH(k_edge_scores, (p->n_items + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A); }
+        if (p->n_items > 0) {
+            ProfScope ps(p, st, JODO_PROF_EDGE_SCORES);           // exactly one of the two does the work (device flag)
+            if (p->n_pitems > 0) LAUNCH(k_edge_scores_sym, (p->n_pitems + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A);
+            LAUNCH(k_edge_scores, (p->n_items + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A);
+        }
         { ProfScope ps(p, st, JODO_PROF_SOFTMAX); LAUNCH(k_softmax, (p->Nn + 15) / 16, 256, A); }
         if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_MSGS); LAUNCH(k_edge_msgs, (p->n_items + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A); }
         { ProfScope ps(p, st, JODO_PROF_NODE_POST);
-          if (d.r == 2) LAUNCH(k_node_post<2>, p->n_strips, 64, A); else LAUNCH(k_node_post<4>, p->n_strips, 64, A); }
+          if (d.r == 2) LAUNCH(k_node_post1<2>, p->n_strips * 2, 64, A); else LAUNCH(k_node_post1<4>, p->n_strips * 2, 64, A);
+          LAUNCH(k_node_post2, p->n_strips * 2, 64, A);
+          float* t = A.h; A.h = A.h_out; A.h_out = t; hcur ^= 1; }     // node state is ping-ponged (post2 reads the old one)
         if (p->n_items > 0) {
             ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);
+            if (p->n_pitems > 0) {
+                if (d.r == 2) LAUNCH(k_edge_update_sym<2>, p->n_pitems, 64, A); else LAUNCH(k_edge_update_sym<4>, p->n_pitems, 64, A);
+            }
             if (d.r == 2) LAUNCH(k_edge_update<2>, p->n_items, 64, A); else LAUNCH(k_edge_update<4>, p->n_items, 64, A);
         }
     }
@@ -177,12 +194,8 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     ProfScope epi(p, st, JODO_PROF_EPILOGUE);
     A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
     A.layer = nblocks;                             // k_pos_final adds the last block's partial updates if any ran
-    if (nblocks == 0) {                            // no update to add: copy through
-        hipError_t e = hipMemsetAsync(A.dpos, 0, (size_t)p->Nn_pad * p->max_parts * 4 * sizeof(float), st);
-        if (e != hipSuccess) return jodo_set_error(JODO_ERR_LAUNCH, "memset: %s", hipGetErrorString(e));
-    }
     LAUNCH(k_pos_final, (p->Nn_pad + 255) / 256, 256, A);
-    p->last_pos_buf = cur ^ 1;
+    p->last_pos_buf = cur ^ 1; p->last_h_buf = hcur;
     LAUNCH(k_node_head, p->n_strips, 64, A);
     switch (d.KEH / 32) {
         case 3: rc = launch_edge_head<3>(st, A); break;
@@ -210,7 +223,7 @@ extern "C" int jodo_debug_fetch(jodo_plan* p, const void* workspace, int what, f
     const void* src = nullptr;
     int64_t n = 0;
     switch (what) {
-        case 0: src = ws + p->ws.h; n = (int64_t)p->Nn * p->dims.D; break;
+        case 0: src = ws + (p->last_h_buf ? p->ws.h2 : p->ws.h); n = (int64_t)p->Nn * p->dims.D; break;
         case 1: src = ws + p->ws.e; n = p->rows * p->dims.De; break;
         case 2: src = ws + (p->last_pos_buf ? p->ws.pos1 : p->ws.pos0); n = (int64_t)p->Nn * 4; break;
         case 3: src = ws + p->ws.hhat; n = (int64_t)p->Nn * p->max_parts * p->dims.D; break;

@@ -1,10 +1,9 @@
-// The six kernels of one DGT block (EquivariantMixBlock.forward, models/mol_gnn.py:270-322):
-//   k_node_pre    LN1 + modulate + q/k/v projections per node            (layers.py:147-149)
+// Edge-side kernels of one DGT block (EquivariantMixBlock.forward, models/mol_gnn.py:270-322), directed form:
 //   k_edge_scores GBF, edge_emb, LN1 + modulate, lin_edge0, q*k*tanh head scores   (:284-297, layers.py:165-174)
 //   k_softmax     per (target node, head) max / 1/sum over its sources   (layers.py:178)
 //   k_edge_msgs   lin_edge1, tanh, * v * alpha, summed over the sources of each target (layers.py:182-184)
-//   k_node_post   node2edge_lin (per node), gated residual + LN2 + FFN, W_row/W_col h, readout (:304-311, :567)
 //   k_edge_update gated residual + LN2 + FFN on edges, readout, MultiCondEquiUpdate (:313-320, :71-94, :568)
+// (node-side kernels: dgt_kernels_node.h; symmetric pair variants: dgt_kernels_sym.h)
 // Lanes hold the *group* index (attention target c for scores/msgs, row a for the update) and the
 // wave iterates over the reduced index, so softmax statistics, message sums and coordinate sums
 // never cross lanes.  Edge rows are indexed r = eoff + a*n + c (a = row = source, c = column = target)
@@ -14,51 +13,6 @@
 #include "dgt_kernels_common.h"
 
 namespace jd {
-
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
-    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int strip = blockIdx.x;
-    const LaneNode L = lane_node(A, strip, j);
-    // positions entering this block: previous positions + the partial sums of the previous update
-    {
-        float4 p = reinterpret_cast<const float4*>(A.pos_in)[L.v];
-        if (A.layer > 0) {
-            const int parts = A.pd.strip_parts[strip];
-            for (int q = 0; q < parts; ++q) {
-                const float4 dp = reinterpret_cast<const float4*>(A.dpos)[(size_t)L.v * A.pd.max_parts + q];
-                p.x += dp.x; p.y += dp.y; p.z += dp.z;
-            }
-        }
-        if (half == 0) reinterpret_cast<float4*>(A.pos_out)[L.v] = p;
-    }
-    const float* mr = mod_row(A, L.b) + A.mod_base;          // node chunks: ns1, nc1, ng1, ns2, nc2, ng2
-    float hx[128];
-    load_nat<8>(A.h + (size_t)L.v * 256, half, hx);
-    layer_norm<128>(hx);
-    modulate<8>(hx, mr, mr + 256, half);
-    const WSrc ws = make_wsrc(A.W, lane);
-    const unsigned woff[3] = {(unsigned)(A.wb[JB_WQ] * 4), (unsigned)(A.wb[JB_WK] * 4), (unsigned)(A.wb[JB_WV] * 4)};
-    const int bslot[3] = {JB_BQ, JB_BK, JB_BV};
-    float* outp[3] = {A.q, A.k, A.v};
-    WPipe<8> wp;
-    wpipe_prime(wp, ws, woff[0]);
-#pragma unroll
-    for (int pj = 0; pj < 3; ++pj) {
-        const float* bias = A.W + A.wb[bslot[pj]];
-#pragma unroll 1
-        for (int b = 0; b < 8; ++b) {
-            const unsigned cur = woff[pj] + (unsigned)b * 32 * 1024;
-            const unsigned nxt = b < 7 ? cur + 32 * 1024 : woff[pj < 2 ? pj + 1 : 0];
-            float bb[16], r[16];
-            load16(bias + b * 32 + half * 16, bb);
-            f32x16 acc = mfma_block_p<32>(wp, ws, cur, nxt, hx, zero16());
-#pragma unroll
-            for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
-            store16(outp[pj] + (size_t)L.v * 256 + b * 32 + half * 16, r);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // LDS-resident weights: the two edge-attention kernels use small projections (K = 64) whose whole
@@ -88,6 +42,7 @@ __device__ __forceinline__ f32x16 mfma_block_lds(const float4* wl, const float (
 
 // scores: S stored as [row][half*8 + b] = head 2b+half  (head 0/1 = adjacency heads, 2.. learned)
 __global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_scores(KArgs A) {
+    if (!A.flags[FLAG_ASYM]) return;                            // symmetric inputs: k_edge_scores_sym runs instead
     __shared__ float4 wl[(32 + 64) * 64];                       // edge_emb (2 x 16 quads) | lin_edge0 (8 x 8 quads)
     stage_weights<32>(wl, reinterpret_cast<const float4*>(A.W + A.wb[JB_EE_W]));
     stage_weights<64>(wl + 32 * 64, reinterpret_cast<const float4*>(A.W + A.wb[JB_LE0_W]));
@@ -255,127 +210,9 @@ __global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_msgs(KArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int R>   // mlp_ratio
-__global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
-    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int strip = blockIdx.x;
-    const LaneNode L = lane_node(A, strip, j);
-    const float* mr = mod_row(A, L.b) + A.mod_base;
-    const float* ng1 = mr + 2 * 256, *ns2 = mr + 3 * 256, *nc2 = mr + 4 * 256, *ng2 = mr + 5 * 256;
-    const WSrc ws = make_wsrc(A.W, lane);
-    const unsigned oN2E = (unsigned)(A.wb[JB_N2E_W] * 4), oF1 = (unsigned)(A.wb[JB_FF1_W] * 4), oF2 = (unsigned)(A.wb[JB_FF2_W] * 4);
-    const unsigned oRow = (unsigned)(A.wb[JB_ROW_W] * 4), oCol = (unsigned)(A.wb[JB_COL_W] * 4), oNro = (unsigned)(A.wb[JB_NRO_W] * 4);
-    WPipe<8> wp;
-    wpipe_prime(wp, ws, oN2E);
-    float hh[128];
-#pragma unroll
-    for (int s = 0; s < 128; ++s) hh[s] = 0.f;
-    const int parts = A.pd.strip_parts[strip];
-    for (int q = 0; q < parts; ++q) {
-        float tmp[128];
-        load_nat<8>(A.hhat + ((size_t)L.v * A.pd.max_parts + q) * 256, half, tmp);
-#pragma unroll
-        for (int s = 0; s < 128; ++s) hh[s] += tmp[s];
-    }
-    // node2edge_lin applied per node (bias added on the edge side)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const unsigned cur = oN2E + (unsigned)b * 32 * 1024;
-        f32x16 acc = mfma_block_p<32>(wp, ws, cur, b == 0 ? cur + 32 * 1024 : oF1, hh, zero16());
-        float r[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) r[s] = acc[s];
-        store16(A.n2e + (size_t)L.v * 64 + b * 32 + half * 16, r);
-    }
-    float hx[128];
-    load_nat<8>(A.h + (size_t)L.v * 256, half, hx);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        float g[16];
-        load16(ng1 + b * 32 + half * 16, g);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) hx[b * 16 + s] = fmaf(g[s], hh[b * 16 + s], hx[b * 16 + s]);
-    }
-    layer_norm<128>(hx);
-    modulate<8>(hx, ns2, nc2, half);
-    // FFN: hidden R*256 in chunks of 64 features; ff2 accumulates over the chunks
-    f32x16 o[8];
-#pragma unroll
-    for (int b = 0; b < 8; ++b) o[b] = zero16();
-    {
-        const float* b1 = A.W + A.wb[JB_FF1_B];
-        constexpr int KQ2 = R * 256 / 8;                      // quads per ff2 output block
-#pragma unroll 1
-        for (int c = 0; c < R * 4; ++c) {
-            float hid[32];
-#pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2) {
-                const unsigned cur = oF1 + (unsigned)(c * 2 + b2) * 32 * 1024;
-                const unsigned nxt = b2 == 0 ? cur + 32 * 1024 : oF2 + (unsigned)(c * 8) * 1024;
-                float bb[16];
-                load16(b1 + (c * 2 + b2) * 32 + half * 16, bb);
-                f32x16 acc = mfma_block_p<32>(wp, ws, cur, nxt, hx, zero16());
-#pragma unroll
-                for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(acc[s] + bb[s]);
-            }
-#pragma unroll
-            for (int ob = 0; ob < 8; ++ob) {
-                const unsigned cur = oF2 + (unsigned)(ob * KQ2 + c * 8) * 1024;
-                const unsigned nxt = ob < 7 ? oF2 + (unsigned)((ob + 1) * KQ2 + c * 8) * 1024
-                                            : (c + 1 < R * 4 ? oF1 + (unsigned)((c + 1) * 2) * 32 * 1024 : oRow);
-                o[ob] = mfma_block_p<8>(wp, ws, cur, nxt, hid, o[ob]);
-            }
-        }
-    }
-    {
-        const float* b2 = A.W + A.wb[JB_FF2_B];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            float r[16], g[16];
-            acc_bias(o[b], b2 + b * 32 + half * 16, r);
-            load16(ng2 + b * 32 + half * 16, g);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) hx[b * 16 + s] = fmaf(g[s], r[s], hx[b * 16 + s]);
-        }
-    }
-    store_nat<8>(A.h + (size_t)L.v * 256, half, hx);
-    // per-node halves of equi_update.input_lin: W_row h (+ bias), W_col h
-    {
-        const float* bin = A.W + A.wb[JB_IN_B];
-#pragma unroll 1
-        for (int b = 0; b < 8; ++b) {
-            const unsigned cr = oRow + (unsigned)b * 32 * 1024, cc = oCol + (unsigned)b * 32 * 1024;
-            float bb[16], r[16];
-            load16(bin + b * 32 + half * 16, bb);
-            f32x16 acc = mfma_block_p<32>(wp, ws, cr, cc, hx, zero16());
-#pragma unroll
-            for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
-            store16(A.wrow + (size_t)L.v * 256 + b * 32 + half * 16, r);
-            acc = mfma_block_p<32>(wp, ws, cc, b < 7 ? cr + 32 * 1024 : oNro, hx, zero16());
-#pragma unroll
-            for (int s = 0; s < 16; ++s) r[s] = acc[s];
-            store16(A.wcol + (size_t)L.v * 256 + b * 32 + half * 16, r);
-        }
-    }
-    // readout node_l(h) -> atom_hids[:, D + l*64 ...]
-    {
-        const float* bias = A.W + A.wb[JB_NRO_B];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const unsigned cur = oNro + (unsigned)b * 32 * 1024;
-            float bb[16], r[16];
-            load16(bias + b * 32 + half * 16, bb);
-            f32x16 acc = mfma_block_p<32>(wp, ws, cur, b == 0 ? cur + 32 * 1024 : oNro, hx, zero16());
-#pragma unroll
-            for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
-            store16(A.ahid + (size_t)L.v * A.d.KNH + 256 + A.layer * 64 + b * 32 + half * 16, r);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 template <int R>
 __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
+    if (!A.flags[FLAG_ASYM]) return;                            // symmetric inputs: k_edge_update_sym runs instead
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
     const int it = blockIdx.x;
     const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it], part = A.pd.item_part[it];

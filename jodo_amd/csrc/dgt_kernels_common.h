@@ -4,7 +4,7 @@
 #include "dgt_plan.h"
 
 // flags_dev layout (int32[8])
-enum { FLAG_NAN = 0, FLAG_FIRST = 1, FLAG_UNIFORM_T = 2, FLAG_COND_NONZERO = 3 };
+enum { FLAG_NAN = 0, FLAG_FIRST = 1, FLAG_UNIFORM_T = 2, FLAG_COND_NONZERO = 3, FLAG_ASYM = 4 };
 
 struct KArgs {
     PlanDev pd;
@@ -14,11 +14,12 @@ struct KArgs {
     int64_t wb[JB_BLOCK_COUNT];           // slot offsets of the current block (floats)
     int64_t mod_base;                     // offset of the current block inside a modulation vector
     int layer;
+    int force_directed;                   // debug: never take the symmetric pair path
     // workspace
     float *hid1, *temb, *mods, *condh, *condh2;
-    float *pos_in, *pos_out, *dpos, *cpos, *feat, *h, *hhat, *q, *k, *v, *n2e, *wrow, *wcol, *ahid, *stats, *apred;
+    float *pos_in, *pos_out, *dpos, *cpos, *feat, *h, *hhat, *q, *k, *v, *n2e, *wrow, *wcol, *ahid, *stats, *apred, *h_out, *ffp;
     int* eflag;
-    float *e, *et, *S, *ehid, *epred;
+    float *e, *et, *S, *ehid, *epred, *dposE;
     int* flags;
     // API tensors
     const float *xh, *edge_x, *cond_x, *cond_edge_x, *noise, *context;

@@ -12,10 +12,22 @@ __global__ void k_pos_final(KArgs A) {
     if (v >= A.pd.Nn_pad) return;
     float4 p = reinterpret_cast<const float4*>(A.pos_in)[v];
     if (v < A.pd.Nn) {
-        const int parts = A.pd.strip_parts[v >> 5];
-        for (int q = 0; q < parts; ++q) {
-            const float4 dp = reinterpret_cast<const float4*>(A.dpos)[(size_t)v * A.pd.max_parts + q];
-            p.x += dp.x; p.y += dp.y; p.z += dp.z;
+        if (A.layer > 0) {                                    // at least one block ran
+            if (A.flags[FLAG_ASYM]) {
+                const int parts = A.pd.strip_parts[v >> 5];
+                for (int q = 0; q < parts; ++q) {
+                    const float4 dp = reinterpret_cast<const float4*>(A.dpos)[(size_t)v * A.pd.max_parts + q];
+                    p.x += dp.x; p.y += dp.y; p.z += dp.z;
+                }
+            } else {
+                const int n = A.pd.node_n[v], i = A.pd.node_i[v];
+                const float4* row = reinterpret_cast<const float4*>(A.dposE) + (size_t)A.pd.node_eoff[v] + (size_t)i * n;
+                for (int c = 0; c < n; ++c) {
+                    if (c == i) continue;
+                    const float4 dp = row[c];
+                    p.x += dp.x; p.y += dp.y; p.z += dp.z;
+                }
+            }
         }
         if (isnan(p.x) || isnan(p.y) || isnan(p.z)) atomicOr(&A.flags[FLAG_NAN], 1);
     }

@@ -20,8 +20,30 @@ __global__ void k_flags_init(KArgs A) {
         A.flags[FLAG_NAN] = 0;
         A.flags[FLAG_FIRST] = 0;
         A.flags[FLAG_COND_NONZERO] = 0;
+        A.flags[FLAG_ASYM] = A.force_directed ? 1 : 0;
         A.flags[FLAG_UNIFORM_T] = (A.d.cond_ch == 0 && !differs) ? 1 : 0;
     }
+}
+
+// Symmetry test of the caller's edge tensors (edge_x, cond_edge_x): the samplers always pass symmetric
+// tensors (symmetric noise, symmetrised predictions), which makes the edge hidden state exactly
+// symmetric and lets the pair kernels (dgt_kernels_sym.h) do the symmetric work once per unordered
+// pair.  Anything else (or a NaN) selects the directed kernels — decided on the device, no host sync.
+__global__ void k_check_sym(KArgs A) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (b, a, c)
+    const size_t NN = (size_t)A.pd.N * A.pd.N;
+    if (idx >= (size_t)A.pd.B * NN) return;
+    const int b = (int)(idx / NN);
+    const int a = (int)((idx % NN) / A.pd.N), c = (int)(idx % A.pd.N);
+    const int n = A.pd.orig_n[b], ch = A.d.ch;
+    if (a >= n || c >= n || a >= c) return;
+    const size_t r1 = idx * ch, r2 = ((size_t)b * NN + (size_t)c * A.pd.N + a) * ch;
+    bool diff = false;
+    for (int f = 0; f < ch; ++f) {
+        diff |= !(A.edge_x[r1 + f] == A.edge_x[r2 + f]);
+        if (A.cond_edge_x) diff |= !(A.cond_edge_x[r1 + f] == A.cond_edge_x[r2 + f]);
+    }
+    if (diff) atomicOr(&A.flags[FLAG_ASYM], 1);
 }
 
 // hid1[b] = GELU(W1 * [x, sin(2 pi x w), cos(2 pi x w)] + b1)      (LearnedSinusodialposEmb + Linear + GELU)

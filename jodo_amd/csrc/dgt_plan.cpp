@@ -51,8 +51,13 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
             delete p;
             return jodo_set_error(JODO_ERR_ARG, "plan_create: n_nodes[%d]=%d outside [1,%d]", b, n_nodes[b], N);
         }
+    // low 16 bits: sources per directed work item (default 8); high 16 bits: pair offsets per pair work
+    // item (default 2: the pair kernels write per-edge results, so small items cost nothing downstream)
+    int pair_chunk = (max_chunk >> 16) & 0xffff;
+    max_chunk &= 0xffff;
     if (max_chunk <= 0) max_chunk = 8;
-    p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->prof_enabled = 0;
+    if (pair_chunk <= 0) pair_chunk = 1;     // measured best on MI355X (QM9 B=2500: 26.7 ms/step vs 27.7 at 2)
+    p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->prof_enabled = 0; p->force_directed = 0;
 
     // molecules by descending size (stable): neighbouring lanes share n, big work first
     std::vector<int> order(B);
@@ -93,6 +98,20 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         }
     }
     p->n_items = (int)it_strip.size(); p->max_parts = max_parts;
+    // pair work items for the symmetric path: lane i meets partner (i + d) mod n for d = 1 .. floor(n/2)
+    // (circulant enumeration: every unordered pair exactly once, the same number of iterations per lane)
+    std::vector<int32_t> pi_strip, pi_t0, pi_t1;
+    for (int s = 0; s < p->n_strips; ++s) {
+        int nmax = 0;
+        for (int j = 0; j < 32; ++j) nmax = std::max(nmax, (int)node_n[s * 32 + j]);
+        const int dmax = nmax / 2;
+        if (dmax == 0) continue;
+        int parts = (dmax + pair_chunk - 1) / pair_chunk;
+        int chunk = (dmax + parts - 1) / parts;
+        parts = (dmax + chunk - 1) / chunk;
+        for (int q = 0; q < parts; ++q) { pi_strip.push_back(s); pi_t0.push_back(q * chunk); pi_t1.push_back(std::min(dmax, (q + 1) * chunk)); }
+    }
+    p->n_pitems = (int)pi_strip.size();
 
     auto put = [&](const std::vector<int32_t>& a, size_t* off) {
         *off = p->desc.size();
@@ -103,6 +122,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     put(node_noff, &p->off_node_noff); put(node_eoff, &p->off_node_eoff);
     put(orig_n, &p->off_orig_n); put(orig_noff, &p->off_orig_noff); put(orig_eoff, &p->off_orig_eoff);
     put(it_strip, &p->off_item_strip); put(it_t0, &p->off_item_t0); put(it_t1, &p->off_item_t1); put(it_part, &p->off_item_part); put(strip_parts, &p->off_strip_parts);
+    put(pi_strip, &p->off_pitem_strip); put(pi_t0, &p->off_pitem_t0); put(pi_t1, &p->off_pitem_t1);
 
     // workspace layout
     const DgtDims& d = p->dims;
@@ -113,12 +133,12 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     w.hid1 = take(Bp * d.T * f); w.temb = take(Bp * d.T * f); w.mods = take(Bp * (size_t)d.Mtot * f);
     w.condh = take(Bp * (size_t)std::max(1, d.cond_ch) * d.D * f); w.condh2 = take(Bp * (size_t)std::max(1, d.cond_ch) * d.D * f);
     w.pos0 = take(NP * 4 * f); w.pos1 = take(NP * 4 * f); w.dpos = take(NP * max_parts * 4 * f); w.cpos = take(NP * 4 * f);
-    w.feat = take(NP * d.ndp * f); w.h = take(NP * d.D * f); w.hhat = take(NP * max_parts * d.D * f);
+    w.feat = take(NP * d.ndp * f); w.h = take(NP * d.D * f); w.h2 = take(NP * d.D * f); w.ffp = take(NP * 2 * d.D * f); w.hhat = take(NP * max_parts * d.D * f);
     w.q = take(NP * d.QKP * f); w.k = take(NP * d.QKP * f); w.v = take(NP * d.D * f); w.n2e = take(NP * d.De * f);
     w.wrow = take(NP * d.D * f); w.wcol = take(NP * d.D * f); w.ahid = take(NP * d.KNH * f); w.stats = take(NP * 32 * f);
     w.apred = take(NP * 32 * f);
     w.eflag = take(R * sizeof(int32_t)); w.e = take(R * d.De * f); w.et = take(R * d.De * f); w.S = take(R * 16 * f);
-    w.ehid = take(R * d.KEH * f); w.epred = take(R * 4 * f);
+    w.ehid = take(R * d.KEH * f); w.epred = take(R * 4 * f); w.dposE = take(R * 4 * f);
     w.total = o;
     *out = p;
     return JODO_OK;
@@ -164,6 +184,11 @@ extern "C" int jodo_plan_upload(jodo_plan* p, void* desc_dev, void* stream) {
     hipError_t e = hipMemcpyAsync(desc_dev, p->desc.data(), p->desc.size() * sizeof(int32_t), hipMemcpyHostToDevice,
                                   (hipStream_t)stream);
     if (e != hipSuccess) return jodo_set_error(JODO_ERR_LAUNCH, "plan_upload: %s", hipGetErrorString(e));
+    return JODO_OK;
+}
+extern "C" int jodo_debug_set_force_directed(jodo_plan* p, int on) {
+    if (!p) return jodo_set_error(JODO_ERR_ARG, "null plan");
+    p->force_directed = on;
     return JODO_OK;
 }
 extern "C" int jodo_debug_set_max_blocks(jodo_plan* p, int mb) {

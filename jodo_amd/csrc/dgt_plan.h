@@ -32,33 +32,38 @@ struct PlanDev {
     const int* item_t1;
     const int* item_part;
     const int* strip_parts; // [n_strips] number of parts (work items) of each node strip
-    int Nn, Nn_pad, n_strips, n_items, B, N, max_parts;
+    const int* pitem_strip; // pair work items (symmetric path): strip, [d0, d1) over circulant offsets d = t + 1
+    const int* pitem_t0;
+    const int* pitem_t1;
+    int Nn, Nn_pad, n_strips, n_items, n_pitems, B, N, max_parts;
     int64_t rows;
 };
 
 struct WsLayout {   // byte offsets into the workspace
     size_t hid1, temb, mods, condh, condh2;
-    size_t pos0, pos1, dpos, cpos, feat, h, hhat, q, k, v, n2e, wrow, wcol, ahid, stats, apred;
-    size_t eflag, e, et, S, ehid, epred;
+    size_t pos0, pos1, dpos, cpos, feat, h, hhat, q, k, v, n2e, wrow, wcol, ahid, stats, apred, h2, ffp;
+    size_t eflag, e, et, S, ehid, epred, dposE;
     size_t total;
 };
 
 struct jodo_plan {
     jodo_cfg cfg;
     DgtDims dims;
-    int B, N, Nn, Nn_pad, n_strips, n_items, max_parts;
+    int B, N, Nn, Nn_pad, n_strips, n_items, n_pitems, max_parts;
     int64_t rows, dir_edges;
     std::vector<int32_t> desc;       // concatenated descriptor tables
     size_t off_node_b, off_node_i, off_node_n, off_node_noff, off_node_eoff, off_orig_n, off_orig_noff,
-        off_orig_eoff, off_item_strip, off_item_t0, off_item_t1, off_item_part, off_strip_parts;   // in int32 elements
+        off_orig_eoff, off_item_strip, off_item_t0, off_item_t1, off_item_part, off_strip_parts, off_pitem_strip, off_pitem_t0, off_pitem_t1;   // in int32 elements
     WsLayout ws;
     // profiling (jodo_profile_*): pairs of events per launch class, recorded on the launch stream
     int prof_enabled;
     std::vector<void*> prof_ev;      // hipEvent_t start/stop pairs in record order
     std::vector<int> prof_cls;       // class of each pair
     std::vector<void*> prof_pool;    // reusable events
+    int force_directed;              // debug: always take the directed (non-pair) kernels
     int max_blocks;                  // debug: limit blocks executed (<0 = all)
     int last_pos_buf;                // debug: which pos buffer holds the latest positions
+    int last_h_buf;                  // debug: which node-state buffer holds the latest h
 };
 
 int dgt_dims_from_cfg(const jodo_cfg* cfg, DgtDims* d);

@@ -205,11 +205,15 @@ class _DGTBase(nn.Module):
         L = capi.lib()
         handle = ctypes.c_void_p()
         capi.check(L.jodo_plan_create(ctypes.byref(self._cfg()), B, N, n_host.ctypes.data_as(ctypes.c_void_p),
-                                      int(getattr(self, 'max_chunk', 0)), ctypes.byref(handle)), 'jodo_plan_create')
+                                      int(getattr(self, 'max_chunk', 0)) | (int(getattr(self, 'pair_chunk', 0)) << 16),
+                                      ctypes.byref(handle)), 'jodo_plan_create')
         L.jodo_plan_desc_bytes.restype = ctypes.c_size_t
         L.jodo_plan_workspace_bytes.restype = ctypes.c_size_t
         desc = torch.empty(L.jodo_plan_desc_bytes(handle), dtype=torch.uint8, device=device)
-        ws = torch.empty(L.jodo_plan_workspace_bytes(handle), dtype=torch.uint8, device=device)
+        # zero-filled once: rows the kernels never write (diagonal edge rows on the pair path) must stay finite
+        ws = torch.zeros(L.jodo_plan_workspace_bytes(handle), dtype=torch.uint8, device=device)
+        if getattr(self, 'force_directed', False):       # tests: never use the symmetric pair kernels
+            capi.check(L.jodo_debug_set_force_directed(handle, 1), 'jodo_debug_set_force_directed')
         capi.check(L.jodo_plan_upload(handle, capi.ptr(desc), capi.current_stream_ptr()), 'jodo_plan_upload')
         torch.cuda.current_stream().synchronize()        # host staging buffer lives in the plan; be safe
         plan = dict(handle=handle, desc=desc, ws=ws, n_nodes=n_host, B=B, N=N, mask=node_mask,

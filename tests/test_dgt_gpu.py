@@ -228,3 +228,32 @@ def test_cpu_tensor_and_grad_are_rejected_loudly():
     d = lambda x: x.to(DEV)
     with pytest.raises(RuntimeError, match="backward"):
         model(d(nl), d(xh), d(nm), d(em), edge_x=d(ex), cond_x=None, cond_edge_x=None, noise_level=d(nl))
+
+
+@pytest.mark.parametrize("cfg_name,n_nodes", [
+    ('vpsde_qm9_uncond_jodo', [1, 2, 3, 4, 9, 10, 18, 29, 28]),       # odd/even sizes, n = 1, 2
+    ('vpsde_geom_uncond_jodo', [44, 45, 7]),
+])
+def test_pair_path_equals_directed_path(cfg_name, n_nodes):
+    """Symmetric inputs take the pair kernels (decided on the device); forcing the directed kernels on the
+    same inputs must give the same result (and both match the oracle)."""
+    cfg = make_config(cfg_name)
+    hp = O.Hyper.from_config(cfg)
+    xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=11)
+    m_pair = make_model(cfg, 3, DEV, gain=1.5, coord_scale=0.05)
+    m_dir = make_model(cfg, 3, DEV, gain=1.5, coord_scale=0.05)
+    m_dir.force_directed = True
+    sd = state_dict_cpu(m_pair)
+    with torch.no_grad():
+        r1 = O.forward_dense(sd, hp, xh, nm, em, ex, None, None, nl)
+        r2 = O.forward_dense(sd, hp, xh, nm, em, ex, r1[0], r1[1], nl)
+    for cx, cex, want in ((None, None, r1), (r1[0], r1[1], r2)):
+        a = run(m_pair, xh, ex, nl, nm, em, cx, cex)
+        assert m_pair.last_flags.cpu().tolist()[4] == 0          # pair path taken
+        b = run(m_dir, xh, ex, nl, nm, em, cx, cex)
+        assert m_dir.last_flags.cpu().tolist()[4] == 1           # directed path taken
+        for got in (a, b):
+            close(got[0], want[0], atol=5e-5)
+            close(got[1], want[1], atol=5e-5)
+        close(a[0], b[0], atol=1e-5)
+        close(a[1], b[1], atol=1e-5)
