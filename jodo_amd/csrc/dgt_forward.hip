@@ -42,7 +42,6 @@ void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
     A.eflag = ws_ptr<int>(ws, w.eflag); A.e = ws_ptr<float>(ws, w.e); A.et = ws_ptr<float>(ws, w.et);
     A.S = ws_ptr<float>(ws, w.S); A.ehid = ws_ptr<float>(ws, w.ehid); A.epred = ws_ptr<float>(ws, w.epred);
     A.dposE = ws_ptr<float>(ws, w.dposE);
-    A.h_out = ws_ptr<float>(ws, w.h2); A.ffp = ws_ptr<float>(ws, w.ffp);
 }
 
 int rowgemm(hipStream_t st, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* Wp, const float* bias,
@@ -163,7 +162,6 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     // ---- DGT blocks ----
     const int nblocks = (p->max_blocks >= 0 && p->max_blocks < d.L) ? p->max_blocks : d.L;
     int cur = 0;                                   // posbuf[cur] holds the positions entering the block
-    int hcur = 0;                                  // which node-state buffer is current (0 = ws.h, 1 = ws.h2)
     for (int l = 0; l < nblocks; ++l) {
         A.layer = l;
         A.mod_base = 32 + (int64_t)l * d.MB;
@@ -179,9 +177,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
         { ProfScope ps(p, st, JODO_PROF_SOFTMAX); LAUNCH(k_softmax, (p->Nn + 15) / 16, 256, A); }
         if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_MSGS); LAUNCH(k_edge_msgs, (p->n_items + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A); }
         { ProfScope ps(p, st, JODO_PROF_NODE_POST);
-          if (d.r == 2) LAUNCH(k_node_post1<2>, p->n_strips * 2, 64, A); else LAUNCH(k_node_post1<4>, p->n_strips * 2, 64, A);
-          LAUNCH(k_node_post2, p->n_strips * 2, 64, A);
-          float* t = A.h; A.h = A.h_out; A.h_out = t; hcur ^= 1; }     // node state is ping-ponged (post2 reads the old one)
+          if (d.r == 2) LAUNCH(k_node_post<2>, p->n_strips, 64, A); else LAUNCH(k_node_post<4>, p->n_strips, 64, A); }
         if (p->n_items > 0) {
             ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);
             if (p->n_pitems > 0) {
@@ -195,7 +191,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
     A.layer = nblocks;                             // k_pos_final adds the last block's partial updates if any ran
     LAUNCH(k_pos_final, (p->Nn_pad + 255) / 256, 256, A);
-    p->last_pos_buf = cur ^ 1; p->last_h_buf = hcur;
+    p->last_pos_buf = cur ^ 1;
     LAUNCH(k_node_head, p->n_strips, 64, A);
     switch (d.KEH / 32) {
         case 3: rc = launch_edge_head<3>(st, A); break;
@@ -223,7 +219,7 @@ extern "C" int jodo_debug_fetch(jodo_plan* p, const void* workspace, int what, f
     const void* src = nullptr;
     int64_t n = 0;
     switch (what) {
-        case 0: src = ws + (p->last_h_buf ? p->ws.h2 : p->ws.h); n = (int64_t)p->Nn * p->dims.D; break;
+        case 0: src = ws + p->ws.h; n = (int64_t)p->Nn * p->dims.D; break;
         case 1: src = ws + p->ws.e; n = p->rows * p->dims.De; break;
         case 2: src = ws + (p->last_pos_buf ? p->ws.pos1 : p->ws.pos0); n = (int64_t)p->Nn * 4; break;
         case 3: src = ws + p->ws.hhat; n = (int64_t)p->Nn * p->max_parts * p->dims.D; break;

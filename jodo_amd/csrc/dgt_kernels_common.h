@@ -17,7 +17,7 @@ struct KArgs {
     int force_directed;                   // debug: never take the symmetric pair path
     // workspace
     float *hid1, *temb, *mods, *condh, *condh2;
-    float *pos_in, *pos_out, *dpos, *cpos, *feat, *h, *hhat, *q, *k, *v, *n2e, *wrow, *wcol, *ahid, *stats, *apred, *h_out, *ffp;
+    float *pos_in, *pos_out, *dpos, *cpos, *feat, *h, *hhat, *q, *k, *v, *n2e, *wrow, *wcol, *ahid, *stats, *apred;
     int* eflag;
     float *e, *et, *S, *ehid, *epred, *dposE;
     int* flags;

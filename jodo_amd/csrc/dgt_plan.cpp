@@ -133,7 +133,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     w.hid1 = take(Bp * d.T * f); w.temb = take(Bp * d.T * f); w.mods = take(Bp * (size_t)d.Mtot * f);
     w.condh = take(Bp * (size_t)std::max(1, d.cond_ch) * d.D * f); w.condh2 = take(Bp * (size_t)std::max(1, d.cond_ch) * d.D * f);
     w.pos0 = take(NP * 4 * f); w.pos1 = take(NP * 4 * f); w.dpos = take(NP * max_parts * 4 * f); w.cpos = take(NP * 4 * f);
-    w.feat = take(NP * d.ndp * f); w.h = take(NP * d.D * f); w.h2 = take(NP * d.D * f); w.ffp = take(NP * 2 * d.D * f); w.hhat = take(NP * max_parts * d.D * f);
+    w.feat = take(NP * d.ndp * f); w.h = take(NP * d.D * f); w.hhat = take(NP * max_parts * d.D * f);
     w.q = take(NP * d.QKP * f); w.k = take(NP * d.QKP * f); w.v = take(NP * d.D * f); w.n2e = take(NP * d.De * f);
     w.wrow = take(NP * d.D * f); w.wcol = take(NP * d.D * f); w.ahid = take(NP * d.KNH * f); w.stats = take(NP * 32 * f);
     w.apred = take(NP * 32 * f);

@@ -41,7 +41,7 @@ struct PlanDev {
 
 struct WsLayout {   // byte offsets into the workspace
     size_t hid1, temb, mods, condh, condh2;
-    size_t pos0, pos1, dpos, cpos, feat, h, hhat, q, k, v, n2e, wrow, wcol, ahid, stats, apred, h2, ffp;
+    size_t pos0, pos1, dpos, cpos, feat, h, hhat, q, k, v, n2e, wrow, wcol, ahid, stats, apred;
     size_t eflag, e, et, S, ehid, epred, dposE;
     size_t total;
 };
@@ -63,7 +63,6 @@ struct jodo_plan {
     int force_directed;              // debug: always take the directed (non-pair) kernels
     int max_blocks;                  // debug: limit blocks executed (<0 = all)
     int last_pos_buf;                // debug: which pos buffer holds the latest positions
-    int last_h_buf;                  // debug: which node-state buffer holds the latest h
 };
 
 int dgt_dims_from_cfg(const jodo_cfg* cfg, DgtDims* d);
