@@ -99,6 +99,7 @@ def main():
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--max-chunk', type=int, default=0)
     ap.add_argument('--pair-chunk', type=int, default=0)
+    ap.add_argument('--spair-chunk', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print per-kernel-class times to stderr')
     args = ap.parse_args()
@@ -135,6 +136,7 @@ def main():
     model = deterministic_init_(get_model_class(cfg.model.name)(cfg), seed=cfg.seed).to(dev).eval()
     model.max_chunk = args.max_chunk
     model.pair_chunk = args.pair_chunk
+    model.spair_chunk = args.spair_chunk
     model.force_directed = bool(int(os.environ.get("JODO_FORCE_DIRECTED", "0")))   # debug: skip the symmetric pair kernels
 
     # synthetic inputs: atom counts from the training histogram (seed 42 + rank), reference noise shapes

@@ -22,6 +22,8 @@ PlanDev make_plan_dev(const jodo_plan* p, const void* desc_dev) {
     d.item_part = base + p->off_item_part; d.strip_parts = base + p->off_strip_parts;
     d.pitem_strip = base + p->off_pitem_strip; d.pitem_t0 = base + p->off_pitem_t0; d.pitem_t1 = base + p->off_pitem_t1;
     d.n_pitems = p->n_pitems;
+    d.sitem_strip = base + p->off_sitem_strip; d.sitem_t0 = base + p->off_sitem_t0; d.sitem_t1 = base + p->off_sitem_t1;
+    d.n_sitems = p->n_sitems;
     d.Nn = p->Nn; d.Nn_pad = p->Nn_pad; d.n_strips = p->n_strips; d.n_items = p->n_items; d.B = p->B; d.N = p->N;
     d.max_parts = p->max_parts; d.rows = p->rows;
     return d;
@@ -47,8 +49,11 @@ void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
 int rowgemm(hipStream_t st, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* Wp, const float* bias,
             int rows, int K, int NB, int in_act, int accumulate, const int* uniform_flag) {
     if (K % 64 != 0) return jodo_set_error(JODO_ERR_ARG, "rowgemm: K=%d not a multiple of 64", K);
-    RowGemmArgs G{X, ldx, Y, ldy, Wp, bias, rows, K, NB, in_act, accumulate, uniform_flag};
-    dim3 grid((rows + 31) / 32, (NB + 3) / 4);
+    // few rows (the sampling case: one shared time row): one output block per wave so that the launch
+    // still has hundreds of waves; many rows: four blocks per wave to reuse the activation chunk
+    const int nob = (rows <= 64 || uniform_flag) ? 1 : 4;
+    RowGemmArgs G{X, ldx, Y, ldy, Wp, bias, rows, K, NB, in_act, accumulate, uniform_flag, nob};
+    dim3 grid((rows + 31) / 32, (NB + nob - 1) / nob);
     hipLaunchKernelGGL(k_rowgemm, grid, dim3(64), 0, st, G);
     return jodo_check_launch("k_rowgemm");
 }
@@ -171,7 +176,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
         cur ^= 1;                                  // k_node_pre wrote the block's positions to pos_out
         if (p->n_items > 0) {
             ProfScope ps(p, st, JODO_PROF_EDGE_SCORES);           // exactly one of the two does the work (device flag)
-            if (p->n_pitems > 0) LAUNCH(k_edge_scores_sym, (p->n_pitems + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A);
+            if (p->n_sitems > 0) LAUNCH(k_edge_scores_sym, (p->n_sitems + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A);
             LAUNCH(k_edge_scores, (p->n_items + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A);
         }
         { ProfScope ps(p, st, JODO_PROF_SOFTMAX); LAUNCH(k_softmax, (p->Nn + 15) / 16, 256, A); }

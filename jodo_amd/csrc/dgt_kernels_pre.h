@@ -89,6 +89,7 @@ struct RowGemmArgs {
     int in_act;                              // 0 none, 1 SiLU
     int accumulate;                          // Y += result
     const int* uniform_flag;                 // if non-null and *flag != 0: only row 0 is computed
+    int nob;                                 // output blocks per wave (1 for few rows: more waves; 4 otherwise)
 };
 
 __global__ __launch_bounds__(64) void k_rowgemm(RowGemmArgs G) {
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(64) void k_rowgemm(RowGemmArgs G) {
     if (r0 >= rows) return;
     const int row = r0 + j;
     const int rowc = row < rows ? row : rows - 1;
-    const int ob0 = blockIdx.y * 4;
+    const int ob0 = blockIdx.y * G.nob;
     const int kq = G.K / 8;                  // quads per output block
     f32x16 acc[4];
 #pragma unroll
@@ -113,13 +114,13 @@ __global__ __launch_bounds__(64) void k_rowgemm(RowGemmArgs G) {
         }
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            if (ob0 + o < G.NB) acc[o] = mfma_block<8>(wp + ((size_t)(ob0 + o) * kq + c * 8) * 64, x, acc[o]);
+            if (o < G.nob && ob0 + o < G.NB) acc[o] = mfma_block<8>(wp + ((size_t)(ob0 + o) * kq + c * 8) * 64, x, acc[o]);
         }
     }
     if (row >= rows) return;
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-        if (ob0 + o < G.NB) {
+        if (o < G.nob && ob0 + o < G.NB) {
             float r[16];
             acc_bias(acc[o], G.bias + (ob0 + o) * 32 + half * 16, r);
             float* yp = G.Y + (size_t)row * G.ldy + (ob0 + o) * 32 + half * 16;

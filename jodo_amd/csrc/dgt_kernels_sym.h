@@ -45,8 +45,8 @@ __global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_scores_sym(KArgs A) {
     __syncthreads();
     const int lane = threadIdx.x & 63, jl = lane & 31, half = lane >> 5;
     const int it = blockIdx.x * WG_WAVES + (threadIdx.x >> 6);
-    if (it >= A.pd.n_pitems) return;
-    const int strip = A.pd.pitem_strip[it], t0 = A.pd.pitem_t0[it], t1 = A.pd.pitem_t1[it];
+    if (it >= A.pd.n_sitems) return;
+    const int strip = A.pd.sitem_strip[it], t0 = A.pd.sitem_t0[it], t1 = A.pd.sitem_t1[it];
     const LaneNode L = lane_node(A, strip, jl);
     const float* mrow = mod_row(A, L.b) + A.mod_base;
     const float gscale = mrow[6 * 256 + 6 * 64 + 2 * 256 + 0], gshift = mrow[6 * 256 + 6 * 64 + 2 * 256 + 1];

@@ -53,10 +53,14 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         }
     // low 16 bits: sources per directed work item (default 8); high 16 bits: pair offsets per pair work
     // item (default 2: the pair kernels write per-edge results, so small items cost nothing downstream)
-    int pair_chunk = (max_chunk >> 16) & 0xffff;
+    // bits 16-23: pair offsets per item of the pair UPDATE kernel (default 1: long iterations, balance
+    // matters most); bits 24-31: the same for the pair SCORES kernel (default 4: short iterations, the
+    // per-item prologue and the per-workgroup LDS weight staging must be amortised)
+    int pair_chunk = (max_chunk >> 16) & 0xff, spair_chunk = (max_chunk >> 24) & 0xff;
     max_chunk &= 0xffff;
     if (max_chunk <= 0) max_chunk = 8;
     if (pair_chunk <= 0) pair_chunk = 1;     // measured best on MI355X (QM9 B=2500: 26.7 ms/step vs 27.7 at 2)
+    if (spair_chunk <= 0) spair_chunk = pair_chunk;   // sweep on MI355X: 1 and 4 tie, 6 is 35 % slower
     p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->prof_enabled = 0; p->force_directed = 0;
 
     // molecules by descending size (stable): neighbouring lanes share n, big work first
@@ -112,6 +116,18 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         for (int q = 0; q < parts; ++q) { pi_strip.push_back(s); pi_t0.push_back(q * chunk); pi_t1.push_back(std::min(dmax, (q + 1) * chunk)); }
     }
     p->n_pitems = (int)pi_strip.size();
+    std::vector<int32_t> si_strip, si_t0, si_t1;
+    for (int s = 0; s < p->n_strips; ++s) {
+        int nmax = 0;
+        for (int j = 0; j < 32; ++j) nmax = std::max(nmax, (int)node_n[s * 32 + j]);
+        const int dmax = nmax / 2;
+        if (dmax == 0) continue;
+        int parts = (dmax + spair_chunk - 1) / spair_chunk;
+        int chunk = (dmax + parts - 1) / parts;
+        parts = (dmax + chunk - 1) / chunk;
+        for (int q = 0; q < parts; ++q) { si_strip.push_back(s); si_t0.push_back(q * chunk); si_t1.push_back(std::min(dmax, (q + 1) * chunk)); }
+    }
+    p->n_sitems = (int)si_strip.size();
 
     auto put = [&](const std::vector<int32_t>& a, size_t* off) {
         *off = p->desc.size();
@@ -123,6 +139,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     put(orig_n, &p->off_orig_n); put(orig_noff, &p->off_orig_noff); put(orig_eoff, &p->off_orig_eoff);
     put(it_strip, &p->off_item_strip); put(it_t0, &p->off_item_t0); put(it_t1, &p->off_item_t1); put(it_part, &p->off_item_part); put(strip_parts, &p->off_strip_parts);
     put(pi_strip, &p->off_pitem_strip); put(pi_t0, &p->off_pitem_t0); put(pi_t1, &p->off_pitem_t1);
+    put(si_strip, &p->off_sitem_strip); put(si_t0, &p->off_sitem_t0); put(si_t1, &p->off_sitem_t1);
 
     // workspace layout
     const DgtDims& d = p->dims;

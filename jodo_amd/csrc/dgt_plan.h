@@ -35,7 +35,10 @@ struct PlanDev {
     const int* pitem_strip; // pair work items (symmetric path): strip, [d0, d1) over circulant offsets d = t + 1
     const int* pitem_t0;
     const int* pitem_t1;
-    int Nn, Nn_pad, n_strips, n_items, n_pitems, B, N, max_parts;
+    const int* sitem_strip; // pair work items of the scores kernel (coarser chunks)
+    const int* sitem_t0;
+    const int* sitem_t1;
+    int Nn, Nn_pad, n_strips, n_items, n_pitems, n_sitems, B, N, max_parts;
     int64_t rows;
 };
 
@@ -49,11 +52,11 @@ struct WsLayout {   // byte offsets into the workspace
 struct jodo_plan {
     jodo_cfg cfg;
     DgtDims dims;
-    int B, N, Nn, Nn_pad, n_strips, n_items, n_pitems, max_parts;
+    int B, N, Nn, Nn_pad, n_strips, n_items, n_pitems, n_sitems, max_parts;
     int64_t rows, dir_edges;
     std::vector<int32_t> desc;       // concatenated descriptor tables
     size_t off_node_b, off_node_i, off_node_n, off_node_noff, off_node_eoff, off_orig_n, off_orig_noff,
-        off_orig_eoff, off_item_strip, off_item_t0, off_item_t1, off_item_part, off_strip_parts, off_pitem_strip, off_pitem_t0, off_pitem_t1;   // in int32 elements
+        off_orig_eoff, off_item_strip, off_item_t0, off_item_t1, off_item_part, off_strip_parts, off_pitem_strip, off_pitem_t0, off_pitem_t1, off_sitem_strip, off_sitem_t0, off_sitem_t1;   // in int32 elements
     WsLayout ws;
     // profiling (jodo_profile_*): pairs of events per launch class, recorded on the launch stream
     int prof_enabled;

@@ -205,7 +205,8 @@ class _DGTBase(nn.Module):
         L = capi.lib()
         handle = ctypes.c_void_p()
         capi.check(L.jodo_plan_create(ctypes.byref(self._cfg()), B, N, n_host.ctypes.data_as(ctypes.c_void_p),
-                                      int(getattr(self, 'max_chunk', 0)) | (int(getattr(self, 'pair_chunk', 0)) << 16),
+                                      int(getattr(self, 'max_chunk', 0)) | (int(getattr(self, 'pair_chunk', 0)) << 16)
+                                      | (int(getattr(self, 'spair_chunk', 0)) << 24),
                                       ctypes.byref(handle)), 'jodo_plan_create')
         L.jodo_plan_desc_bytes.restype = ctypes.c_size_t
         L.jodo_plan_workspace_bytes.restype = ctypes.c_size_t
