@@ -117,6 +117,9 @@ int jodo_debug_set_max_blocks(jodo_plan* plan, int max_blocks);
 /* force the directed (per directed edge) kernels even for symmetric inputs (tests; default 0: the
  * symmetric pair kernels are chosen on the device whenever edge_x / cond_edge_x are symmetric) */
 int jodo_debug_set_force_directed(jodo_plan* plan, int on);
+/* phase-cycle instrumentation of k_edge_update_sym (only in builds with -DJODO_PHASE_TIMING): device
+ * buffer of 16 uint64 sums, [15] = number of instrumented waves; NULL disables */
+int jodo_debug_set_timing_buffer(jodo_plan* plan, void* dev16xu64);
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * enable != 0 makes every subsequent jodo_dgt_forward bracket its launches with events (small

@@ -105,6 +105,33 @@ __device__ __forceinline__ void store16(float* __restrict__ p16, const float (&r
     for (int q = 0; q < 4; ++q) p[q] = make_float4(r[q * 4 + 0], r[q * 4 + 1], r[q * 4 + 2], r[q * 4 + 3]);
 }
 
+// ---- node arrays read by the edge kernels: strip-transposed layout ---------------------------------
+// q, k, v, W_row h, W_col h, node2edge(hhat) are stored as [strip][block][quad][lane][4 floats], lane =
+// (node & 31) + 32 * half — i.e. exactly the register image of a 32-node strip.  A strip's own rows are
+// then read/written with fully coalesced 1-KiB instructions, and partner rows (j = i + d inside the same
+// molecule) are a *shifted* contiguous read touching 8-16 cache lines instead of 32 scattered ones
+// (row-major rows cost ~250 issue cycles per 16-byte gather instruction and starved the weight stream).
+struct TRow {
+    const float4* p;     // array base + strip * NB * 256 + lane'
+};
+__device__ __forceinline__ TRow trow(const float* arr, int NB, int node, int half) {
+    TRow r;
+    r.p = reinterpret_cast<const float4*>(arr) + (size_t)(node >> 5) * NB * 256 + (node & 31) + 32 * half;
+    return r;
+}
+__device__ __forceinline__ void load16T(const TRow& r, int b, float (&x)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = r.p[(b * 4 + q) * 64];
+        x[q * 4 + 0] = v.x; x[q * 4 + 1] = v.y; x[q * 4 + 2] = v.z; x[q * 4 + 3] = v.w;
+    }
+}
+__device__ __forceinline__ void store16T(float* arr, int NB, int node, int half, int b, const float (&x)[16]) {
+    float4* p = reinterpret_cast<float4*>(arr) + (size_t)(node >> 5) * NB * 256 + (node & 31) + 32 * half;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[(b * 4 + q) * 64] = make_float4(x[q * 4 + 0], x[q * 4 + 1], x[q * 4 + 2], x[q * 4 + 3]);
+}
+
 // ---- one output block of a projection -------------------------------------------------------------
 // w: this lane's float4 of quad 0 of the block (= block base + lane); KQ quads of 4 k-steps;
 // act: KQ*4 activation registers.  acc += W_block * act.

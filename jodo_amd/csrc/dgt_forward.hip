@@ -121,6 +121,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     float* posbuf[2] = {ws_ptr<float>(workspace, p->ws.pos0), ws_ptr<float>(workspace, p->ws.pos1)};
     A.pos_in = posbuf[0]; A.pos_out = posbuf[1];
     A.flags = flags_dev;
+    A.dbgt = static_cast<unsigned long long*>(p->dbg_timing);
     A.xh = xh; A.edge_x = edge_x; A.cond_x = cond_x; A.cond_edge_x = cond_edge_x; A.noise = noise_level; A.context = context;
     A.out_xh = out_xh; A.out_edge = out_edge;
     const float* W = packed_w;

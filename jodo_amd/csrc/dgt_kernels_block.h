@@ -67,8 +67,8 @@ __global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_scores(KArgs A) {
         const float* cst = launder(A.W);
         const float* tab = cst + A.wb[JB_GBF];
         const float* bEE = cst + A.wb[JB_EE_B];
-        const float* qrow = launder(A.q + (size_t)L.v * 256);
-        const float* krow = A.k + (size_t)u * 256;
+        TRow qrow = trow(A.q, 8, L.v, half), krow = trow(A.k, 8, u, half);
+        qrow.p = launder(qrow.p);
         const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[u];
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
         float x[32];
@@ -92,15 +92,15 @@ __global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_scores(KArgs A) {
         // lin_edge0 -> tanh -> * q_target * k_source, reduced per head
         float mainsum[7];
         float qn[16], kn[16];
-        load16(qrow + half * 16, qn);
-        load16(krow + half * 16, kn);
+        load16T(qrow, 0, qn);
+        load16T(krow, 0, kn);
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
             float qq[16], kk[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) { qq[s] = qn[s]; kk[s] = kn[s]; }
-            load16(qrow + (b + 1) * 32 + half * 16, qn);               // one block ahead
-            load16(krow + (b + 1) * 32 + half * 16, kn);
+            load16T(qrow, b + 1, qn);               // one block ahead
+            load16T(krow, b + 1, kn);
             f32x16 acc = mfma_block_lds<8>(wL0 + (b * 8) * 64, x, zero16());
             float s_ = 0.f;
 #pragma unroll
@@ -191,15 +191,15 @@ __global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_msgs(KArgs A) {
 #pragma unroll
             for (int b2 = 0; b2 < 8; ++b2) al[b2] = ok ? fast_exp(sv[b2] - mx[b2]) * inv[b2] : 0.f;
         }
-        const float* vrow = A.v + (size_t)u * 256;
+        const TRow vrow = trow(A.v, 8, u, half);
         float vnext[16];
-        load16(vrow + half * 16, vnext);
+        load16T(vrow, 0, vnext);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             float vv[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) vv[s] = vnext[s];
-            if (b < 7) load16(vrow + (b + 1) * 32 + half * 16, vnext);   // one block ahead
+            if (b < 7) load16T(vrow, b + 1, vnext);   // one block ahead
             f32x16 acc = mfma_block_lds<8>(wL1 + (b * 8) * 64, x, zero16());
 #pragma unroll
             for (int s = 0; s < 16; ++s) macc[b * 16 + s] = fmaf(tanh_f(acc[s]) * vv[s], al[b], macc[b * 16 + s]);
@@ -248,8 +248,9 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
         const float* n2bias_ = cst + A.wb[JB_N2E_B], *b3_ = cst + A.wb[JB_FF3_B], *b4_ = cst + A.wb[JB_FF4_B];
         const float* b0_ = cst + A.wb[JB_C0_B], *w2_ = cst + A.wb[JB_C2_W], *tab_ = cst + A.wb[JB_GBF];
         const float* bro_ = cst + A.wb[JB_ERO_B];
-        const float* wrow = launder(A.wrow + (size_t)L.v * 256);
-        const float* wcol = A.wcol + (size_t)u * 256;
+        TRow wrow = trow(A.wrow, 8, L.v, half);
+        wrow.p = launder(wrow.p);
+        const TRow wcol = trow(A.wcol, 8, u, half);
         // ---- geometry + Gaussian basis (needed by the equivariant update; computed up front) ----
         const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[u];
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
@@ -261,8 +262,17 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
         {
             float e[32], n2a[32], n2c[32];
             load_nat<2>(A.e + r * 64, half, e);
-            load_nat<2>(A.n2e + (size_t)L.v * 64, half, n2a);
-            load_nat<2>(A.n2e + (size_t)u * 64, half, n2c);
+            {
+                const TRow ra = trow(A.n2e, 2, L.v, half), rc = trow(A.n2e, 2, u, half);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float ta[16], tc2[16];
+                    load16T(ra, b, ta);
+                    load16T(rc, b, tc2);
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) { n2a[b * 16 + s] = ta[s]; n2c[b * 16 + s] = tc2[s]; }
+                }
+            }
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 float g[16], bb[16];
@@ -329,8 +339,8 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
             const unsigned wcur = oi + (unsigned)(b * 16) * 1024;
             const unsigned wnx = b < 7 ? oi + (unsigned)((b + 1) * 16) * 1024 : oi + 8u * 1024;
             float a1[16], a2[16];
-            load16(wrow + b * 32 + half * 16, a1);
-            load16(wcol + b * 32 + half * 16, a2);
+            load16T(wrow, b, a1);
+            load16T(wcol, b, a2);
             U[b] = mfma_block_p<8>(wp, ws, wcur, wnx, en, zero16());
 #pragma unroll
             for (int s = 0; s < 16; ++s) U[b][s] += a1[s] + a2[s];

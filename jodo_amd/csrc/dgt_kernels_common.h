@@ -21,6 +21,7 @@ struct KArgs {
     int* eflag;
     float *e, *et, *S, *ehid, *epred, *dposE;
     int* flags;
+    unsigned long long* dbgt;             // debug: per-phase cycle sums (builds with -DJODO_PHASE_TIMING only)
     // API tensors
     const float *xh, *edge_x, *cond_x, *cond_edge_x, *noise, *context;
     float *out_xh, *out_edge;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
         f32x16 acc = mfma_block_p<32>(wp, ws, cur, nxt, hx, zero16());
 #pragma unroll
         for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
-        store16(outp + (size_t)L.v * 256 + b * 32 + half * 16, r);
+        store16T(outp, 8, L.v, half, b, r);
     }
 }
 
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
         float r[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) r[s] = acc[s];
-        store16(A.n2e + (size_t)L.v * 64 + b * 32 + half * 16, r);
+        store16T(A.n2e, 2, L.v, half, b, r);
     }
     node_residual_ln(A, L, half, mr, hx);
     // FFN: hidden R*256 in chunks of 64 features; ff2 accumulates over the chunks
@@ -170,11 +170,11 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
             f32x16 acc = mfma_block_p<32>(wp, ws, cr, cc, hx, zero16());
 #pragma unroll
             for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
-            store16(A.wrow + (size_t)L.v * 256 + b * 32 + half * 16, r);
+            store16T(A.wrow, 8, L.v, half, b, r);
             acc = mfma_block_p<32>(wp, ws, cc, b < 7 ? cr + 32 * 1024 : oNro, hx, zero16());
 #pragma unroll
             for (int s = 0; s < 16; ++s) r[s] = acc[s];
-            store16(A.wcol + (size_t)L.v * 256 + b * 32 + half * 16, r);
+            store16T(A.wcol, 8, L.v, half, b, r);
         }
     }
     // readout node_l(h) -> atom_hids[:, D + l*64 ...]

@@ -18,6 +18,16 @@
 
 namespace jd {
 
+#ifdef JODO_PHASE_TIMING
+#define PT_INIT unsigned long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_last = __builtin_readcyclecounter();
+#define PT(ph) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_readcyclecounter(); pt_acc[ph] += n_ - pt_last; pt_last = n_; } while (0)
+#define PT_FLUSH do { if (A.dbgt && lane == 0 && (blockIdx.x % 61) == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&A.dbgt[i_], pt_acc[i_]); atomicAdd(&A.dbgt[15], 1ull); } } while (0)
+#else
+#define PT_INIT
+#define PT(ph)
+#define PT_FLUSH
+#endif
+
 struct PairLane {
     int j, u;          // partner index inside the molecule, packed node id
     size_t rij, rji;   // edge rows (i -> j as a=i,c=j) and (a=j,c=i)
@@ -60,8 +70,9 @@ __global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_scores_sym(KArgs A) {
         const float* cst = launder(A.W);
         const float* tab = cst + A.wb[JB_GBF];
         const float* bEE = cst + A.wb[JB_EE_B];
-        const float* qi = launder(A.q + (size_t)L.v * 256), *ki = launder(A.k + (size_t)L.v * 256);
-        const float* qj = A.q + (size_t)P.u * 256, *kj = A.k + (size_t)P.u * 256;
+        TRow qi = trow(A.q, 8, L.v, half), ki = trow(A.k, 8, L.v, half);
+        qi.p = launder(qi.p); ki.p = launder(ki.p);
+        const TRow qj = trow(A.q, 8, P.u, half), kj = trow(A.k, 8, P.u, half);
         const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[P.u];
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
         float x[32];
@@ -88,15 +99,15 @@ __global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_scores_sym(KArgs A) {
         // tanh(lin_edge0) once; direction 1 = edge (j -> i): q_i . k_j ; direction 2 = edge (i -> j): q_j . k_i
         float m1[7], m2[7];
         float qin[16], kin[16], qjn[16], kjn[16];
-        load16(qi + half * 16, qin); load16(ki + half * 16, kin);
-        load16(qj + half * 16, qjn); load16(kj + half * 16, kjn);
+        load16T(qi, 0, qin); load16T(ki, 0, kin);
+        load16T(qj, 0, qjn); load16T(kj, 0, kjn);
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
             float a1[16], a2[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) { a1[s] = qin[s] * kjn[s]; a2[s] = qjn[s] * kin[s]; }
-            load16(qi + (b + 1) * 32 + half * 16, qin); load16(ki + (b + 1) * 32 + half * 16, kin);
-            load16(qj + (b + 1) * 32 + half * 16, qjn); load16(kj + (b + 1) * 32 + half * 16, kjn);
+            load16T(qi, b + 1, qin); load16T(ki, b + 1, kin);
+            load16T(qj, b + 1, qjn); load16T(kj, b + 1, kjn);
             f32x16 acc = mfma_block_lds<8>(wL0 + (b * 8) * 64, x, zero16());
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -166,6 +177,8 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
     constexpr int KQ4 = R * 64 / 8;
     WPipe<8> wp;
     wpipe_prime(wp, ws, o3);
+    __shared__ float4 pre1[32 * 64];                           // u of direction 1 (pre-LayerNorm) of this wave, [quad][lane]
+    PT_INIT
     for (int t = t0; t < t1; ++t) {
         const PairLane P = pair_of(L, t + 1);
         const float* eg1_ = launder(eg1);
@@ -176,8 +189,9 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
         const float* n2bias_ = cst + A.wb[JB_N2E_B], *b3_ = cst + A.wb[JB_FF3_B], *b4_ = cst + A.wb[JB_FF4_B];
         const float* b0_ = cst + A.wb[JB_C0_B], *w2_ = cst + A.wb[JB_C2_W], *tab_ = cst + A.wb[JB_GBF];
         const float* bro_ = cst + A.wb[JB_ERO_B];
-        const float* wrow_i = launder(A.wrow + (size_t)L.v * 256), *wcol_i = launder(A.wcol + (size_t)L.v * 256);
-        const float* wrow_j = A.wrow + (size_t)P.u * 256, *wcol_j = A.wcol + (size_t)P.u * 256;
+        TRow wrow_i = trow(A.wrow, 8, L.v, half), wcol_i = trow(A.wcol, 8, L.v, half);
+        wrow_i.p = launder(wrow_i.p); wcol_i.p = launder(wcol_i.p);
+        const TRow wrow_j = trow(A.wrow, 8, P.u, half), wcol_j = trow(A.wcol, 8, P.u, half);
         const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[P.u];
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
@@ -188,8 +202,17 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
         {
             float e[32], n2a[32], n2c[32];
             load_nat<2>(A.e + P.rij * 64, half, e);
-            load_nat<2>(A.n2e + (size_t)L.v * 64, half, n2a);
-            load_nat<2>(A.n2e + (size_t)P.u * 64, half, n2c);
+            {
+                const TRow ra = trow(A.n2e, 2, L.v, half), rc = trow(A.n2e, 2, P.u, half);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float ta[16], tc2[16];
+                    load16T(ra, b, ta);
+                    load16T(rc, b, tc2);
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) { n2a[b * 16 + s] = ta[s]; n2c[b * 16 + s] = tc2[s]; }
+                }
+            }
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 float g[16], bb[16];
@@ -202,6 +225,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
         }
         layer_norm<32>(en);
         modulate<2>(en, es2_, ec2_, half);
+        PT(0);
         // ---- edge FFN ----
         {
             f32x16 o[2] = {zero16(), zero16()};
@@ -241,6 +265,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             store_nat<2>(A.e + P.rij * 64, half, en);
             store_nat<2>(A.e + P.rji * 64, half, en);
         }
+        PT(1);
         // ---- readout ----
         {
             float bb[16];
@@ -254,47 +279,81 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                 store16(A.ehid + P.rji * A.d.KEH + 64 + A.layer * 16, rr);
             }
         }
-        // ---- symmetric part of input_lin: W_e e + W_d G, shared by both directions ----
-        f32x16 U[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const unsigned wcur = oi + (unsigned)(b * 16) * 1024;
-            const unsigned wnx = b < 7 ? oi + (unsigned)((b + 1) * 16) * 1024 : oi + 8u * 1024;
-            U[b] = mfma_block_p<8>(wp, ws, wcur, wnx, en, zero16());
-        }
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const unsigned wcur = oi + (unsigned)(b * 16 + 8) * 1024;
-            const unsigned wnx = b < 7 ? oi + (unsigned)((b + 1) * 16 + 8) * 1024 : o0;
-            U[b] = mfma_block_p<8>(wp, ws, wcur, wnx, G, U[b]);
-        }
-        // ---- two directed evaluations of LN -> modulate -> coord_mlp ----
-#pragma unroll 1
-        for (int dir = 0; dir < 2; ++dir) {
-            const float* wr = dir == 0 ? wrow_i : wrow_j;      // row atom a
-            const float* wc = dir == 0 ? wcol_j : wcol_i;      // column atom c
-            float uu[128];
+        PT(2);
+        // ---- symmetric part of input_lin: S = W_e e + W_d G, shared by both directions.  The per-node terms
+        //      W_row h_a + W_col h_c of BOTH directions are gathered under these MFMAs; as soon as block b of S
+        //      is complete, u(dir 0) = S + (W_row h_i + W_col h_j) replaces the gathered terms in registers and
+        //      u(dir 1) = S + (W_row h_j + W_col h_i) is parked in this wave's LDS slab ----
+        float uu0[128];
+        {
+            f32x16 U[8];
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
+                const unsigned wcur = oi + (unsigned)(b * 16) * 1024;
+                const unsigned wnx = b < 7 ? oi + (unsigned)((b + 1) * 16) * 1024 : oi + 8u * 1024;
                 float a1[16], a2[16];
-                load16(wr + b * 32 + half * 16, a1);
-                load16(wc + b * 32 + half * 16, a2);
+                load16T(wrow_i, b, a1);
+                load16T(wcol_j, b, a2);
+                U[b] = mfma_block_p<8>(wp, ws, wcur, wnx, en, zero16());
 #pragma unroll
-                for (int s = 0; s < 16; ++s) uu[b * 16 + s] = U[b][s] + a1[s] + a2[s];
+                for (int s = 0; s < 16; ++s) uu0[b * 16 + s] = a1[s] + a2[s];
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const unsigned wcur = oi + (unsigned)(b * 16 + 8) * 1024;
+                const unsigned wnx = b < 7 ? oi + (unsigned)((b + 1) * 16 + 8) * 1024 : o3;
+                U[b] = mfma_block_p<8>(wp, ws, wcur, wnx, G, U[b]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)          // S parked for direction 1 (its per-node terms are added later)
+                    pre1[(b * 4 + q) * 64 + lane] = make_float4(U[b][q * 4 + 0], U[b][q * 4 + 1], U[b][q * 4 + 2], U[b][q * 4 + 3]);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) uu0[b * 16 + s] += U[b][s];
+            }
+        }
+        PT(3);
+        // ---- two directed evaluations of LN -> modulate -> coord_mlp ----
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            float uu[128];
+            if (dir == 0) {
+#pragma unroll
+                for (int s = 0; s < 128; ++s) uu[s] = uu0[s];
+            } else {
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 t = pre1[(b * 4 + q) * 64 + lane];
+                        uu[b * 16 + q * 4 + 0] = t.x;
+                        uu[b * 16 + q * 4 + 1] = t.y;
+                        uu[b * 16 + q * 4 + 2] = t.z;
+                        uu[b * 16 + q * 4 + 3] = t.w;
+                    }
             }
             layer_norm<128>(uu);
             modulate<8>(uu, qsh_, qsc_, half);
+            PT(4);
             float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+            // coord_mlp.0 runs on its own, deeper weight pipe (16 quads = 4096 MFMA cycles of cover): the
+            // per-node gathers issued in this loop come from HBM/MALL (~2 us) and, because vmcnt retires in
+            // order, would otherwise stall the weight stream once per block
+            WPipe<16> wc;
+            wpipe_prime(wc, ws, o0);
 #pragma unroll 1
             for (int b = 0; b < 8; ++b) {
                 const unsigned wcur = o0 + (unsigned)b * 32 * 1024;
-                const unsigned wnx = b < 7 ? wcur + 32 * 1024 : (dir == 0 ? o0 : o3);
+                const unsigned wnx = b < 7 ? wcur + 32 * 1024 : o0;
                 float bb[16], k0[16], k1[16], k2[16];
                 load16(b0_ + b * 32 + half * 16, bb);
                 load16(w2_ + b * 32 + half * 16, k0);
                 load16(w2_ + 256 + b * 32 + half * 16, k1);
                 load16(w2_ + 512 + b * 32 + half * 16, k2);
-                f32x16 acc = mfma_block_p<32>(wp, ws, wcur, wnx, uu, zero16());
+                float a1[16], a2[16];
+                if (dir == 0) {                          // direction 1's W_row h_j + W_col h_i, hidden under this block
+                    load16T(wrow_j, b, a1);
+                    load16T(wcol_i, b, a2);
+                }
+                f32x16 acc = mfma_block_p<32>(wc, ws, wcur, wnx, uu, zero16());
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const float ys = silu_f(acc[s] + bb[s]);
@@ -302,7 +361,16 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                     c1 = fmaf(ys, k1[s], c1);
                     c2 = fmaf(ys, k2[s], c2);
                 }
+                if (dir == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 t = pre1[(b * 4 + q) * 64 + lane];
+                        pre1[(b * 4 + q) * 64 + lane] = make_float4(t.x + (a1[q * 4 + 0] + a2[q * 4 + 0]), t.y + (a1[q * 4 + 1] + a2[q * 4 + 1]),
+                                                                    t.z + (a1[q * 4 + 2] + a2[q * 4 + 2]), t.w + (a1[q * 4 + 3] + a2[q * 4 + 3]));
+                    }
+                }
             }
+            PT(dir == 0 ? 5 : 7);
             c0 = tanh_f(pair_sum(c0));
             c1 = tanh_f(pair_sum(c1));
             c2 = tanh_f(pair_sum(c2));
@@ -314,8 +382,10 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             const float sgn = dir == 0 ? 1.f : -1.f;          // x_a - x_c
             if (P.ok && half == 0)
                 reinterpret_cast<float4*>(A.dposE)[rr] = make_float4(sgn * dx * f, sgn * dy * f, sgn * dz * f, 0.f);
+            PT(6);
         }
     }
+    PT_FLUSH;
 }
 
 }  // namespace jd

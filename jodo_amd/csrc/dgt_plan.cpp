@@ -9,6 +9,35 @@
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// XCD-aware work-item order (MI355X: 8 XCDs with private L2s; workgroup w is observed to run on XCD
+// w % 8).  All items of a node strip re-read the same few node rows (q/k/v, W_row h, W_col h of one or
+// two molecules); keeping a strip's items on ONE XCD turns those gathers into L2 hits instead of
+// HBM/MALL round trips (~2 us each).  Items are queued per class strip % 8 and dealt to workgroups
+// round-robin, `group` items per workgroup; a drained class borrows from the next one (speed only —
+// correctness never depends on placement).
+static std::vector<int> xcd_order(const std::vector<int32_t>& strip, int group) {
+    const int n = (int)strip.size();
+    std::vector<std::vector<int>> q(8);
+    for (int i = 0; i < n; ++i) q[strip[i] & 7].push_back(i);
+    size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<int> out;
+    out.reserve(n);
+    int wg = 0;
+    while ((int)out.size() < n) {
+        int c = wg & 7, tries = 0;
+        while (pos[c] >= q[c].size() && tries < 8) { c = (c + 1) & 7; ++tries; }
+        for (int k = 0; k < group && pos[c] < q[c].size(); ++k) out.push_back(q[c][pos[c]++]);
+        ++wg;
+    }
+    return out;
+}
+
+static void permute(std::vector<int32_t>& a, const std::vector<int>& ord) {
+    std::vector<int32_t> b(a.size());
+    for (size_t i = 0; i < ord.size(); ++i) b[i] = a[ord[i]];
+    a.swap(b);
+}
+
 int dgt_dims_from_cfg(const jodo_cfg* c, DgtDims* d) {
     if (c->nf != 256)
         return jodo_set_error(JODO_ERR_UNSUPPORTED, "nf=%d: only nf=256 kernels are built (nf=384 is the next tier)", c->nf);
@@ -61,7 +90,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     if (max_chunk <= 0) max_chunk = 8;
     if (pair_chunk <= 0) pair_chunk = 1;     // measured best on MI355X (QM9 B=2500: 26.7 ms/step vs 27.7 at 2)
     if (spair_chunk <= 0) spair_chunk = pair_chunk;   // sweep on MI355X: 1 and 4 tie, 6 is 35 % slower
-    p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->prof_enabled = 0; p->force_directed = 0;
+    p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->prof_enabled = 0; p->force_directed = 0; p->dbg_timing = nullptr;
 
     // molecules by descending size (stable): neighbouring lanes share n, big work first
     std::vector<int> order(B);
@@ -102,6 +131,10 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         }
     }
     p->n_items = (int)it_strip.size(); p->max_parts = max_parts;
+    {   // directed items are consumed 8 per workgroup by the attention kernels
+        const std::vector<int> ord = xcd_order(it_strip, 8);
+        permute(it_strip, ord); permute(it_t0, ord); permute(it_t1, ord); permute(it_part, ord);
+    }
     // pair work items for the symmetric path: lane i meets partner (i + d) mod n for d = 1 .. floor(n/2)
     // (circulant enumeration: every unordered pair exactly once, the same number of iterations per lane)
     std::vector<int32_t> pi_strip, pi_t0, pi_t1;
@@ -116,6 +149,10 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         for (int q = 0; q < parts; ++q) { pi_strip.push_back(s); pi_t0.push_back(q * chunk); pi_t1.push_back(std::min(dmax, (q + 1) * chunk)); }
     }
     p->n_pitems = (int)pi_strip.size();
+    {   // one pair-update item per workgroup
+        const std::vector<int> ord = xcd_order(pi_strip, 1);
+        permute(pi_strip, ord); permute(pi_t0, ord); permute(pi_t1, ord);
+    }
     std::vector<int32_t> si_strip, si_t0, si_t1;
     for (int s = 0; s < p->n_strips; ++s) {
         int nmax = 0;
@@ -128,6 +165,10 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         for (int q = 0; q < parts; ++q) { si_strip.push_back(s); si_t0.push_back(q * chunk); si_t1.push_back(std::min(dmax, (q + 1) * chunk)); }
     }
     p->n_sitems = (int)si_strip.size();
+    {   // eight pair-scores items per workgroup
+        const std::vector<int> ord = xcd_order(si_strip, 8);
+        permute(si_strip, ord); permute(si_t0, ord); permute(si_t1, ord);
+    }
 
     auto put = [&](const std::vector<int32_t>& a, size_t* off) {
         *off = p->desc.size();
@@ -201,6 +242,11 @@ extern "C" int jodo_plan_upload(jodo_plan* p, void* desc_dev, void* stream) {
     hipError_t e = hipMemcpyAsync(desc_dev, p->desc.data(), p->desc.size() * sizeof(int32_t), hipMemcpyHostToDevice,
                                   (hipStream_t)stream);
     if (e != hipSuccess) return jodo_set_error(JODO_ERR_LAUNCH, "plan_upload: %s", hipGetErrorString(e));
+    return JODO_OK;
+}
+extern "C" int jodo_debug_set_timing_buffer(jodo_plan* p, void* dev16xu64) {
+    if (!p) return jodo_set_error(JODO_ERR_ARG, "null plan");
+    p->dbg_timing = dev16xu64;
     return JODO_OK;
 }
 extern "C" int jodo_debug_set_force_directed(jodo_plan* p, int on) {

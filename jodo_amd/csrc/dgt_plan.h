@@ -64,6 +64,7 @@ struct jodo_plan {
     std::vector<int> prof_cls;       // class of each pair
     std::vector<void*> prof_pool;    // reusable events
     int force_directed;              // debug: always take the directed (non-pair) kernels
+    void* dbg_timing;                // debug: device buffer of 16 x u64 phase-cycle sums (or null)
     int max_blocks;                  // debug: limit blocks executed (<0 = all)
     int last_pos_buf;                // debug: which pos buffer holds the latest positions
 };
