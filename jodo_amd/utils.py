@@ -95,3 +95,23 @@ def save_checkpoint(ckpt_dir, state):
                 'model': state['model'].state_dict(),
                 'ema': state['ema'].state_dict() if state.get('ema') is not None else None,
                 'step': state['step']}, ckpt_dir)
+
+
+def load_for_sampling(ckpt_path, config, device=None, use_ema=True):
+    """The reference's evaluation prologue in one call (run_lib.py:175-176, 221-222): build the model
+    from `config`, restore a reference-format checkpoint and overwrite the parameters with the EMA
+    shadow weights.  Returns (model, ema, step).  The packed kernel weights are rebuilt lazily on the
+    next forward (the cache is keyed on parameter versions)."""
+    from .models import utils as mutils
+    from .models.ema import ExponentialMovingAverage
+    if not os.path.exists(ckpt_path):
+        raise FileNotFoundError(ckpt_path)         # the reference silently continues with random weights
+    device = device or config.device
+    model = mutils.create_model(config)
+    ema = ExponentialMovingAverage(model.parameters(), decay=config.model.ema_decay)
+    state = dict(optimizer=None, model=model, ema=ema, step=0)
+    state = restore_checkpoint(ckpt_path, state, device)
+    if use_ema:
+        ema.copy_to(model.parameters())
+    model.eval()
+    return model, ema, state['step']
