@@ -6,7 +6,7 @@ libjodo_hip.so) plus the ancestral update of the reference's sampler, inputs res
 `value` = molecules/s of a full 1000-step sampling round = (B * n_gpus) / (1000 * step_time);
 per-step cost is independent of the step index, so K timed steps measure it directly.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload qm9|geom|cond]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload qm9|geom|geom384|cond]
 
 N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; one
 process per GPU, every rank samples its own B molecules (weak scaling), no collective on the data
@@ -37,6 +37,8 @@ WORKLOADS = {
                 name='QM9 uncond JODO (DGT_concat nf=256 L=8), 1000-step ancestral, batch 2500 per GPU'),
     'geom': dict(cfg='vpsde_geom_uncond_jodo', info='geom_with_h_1', batch=512,
                  name='GEOM-Drugs uncond JODO medium (nf=256 L=10), 1000-step ancestral, batch 512 per GPU'),
+    'geom384': dict(cfg='vpsde_geom_uncond_jodo', info='geom_with_h_1', batch=1250, nf=384,
+                    name='GEOM-Drugs uncond JODO large (nf=384 L=10), 1000-step ancestral, batch 1250 per GPU'),
     'cond': dict(cfg='vpsde_qm9_cond_jodo', info='qm9_second_half', batch=313,
                  name='QM9 cond JODO (cond_DGT_concat), ancestral steps, batch 313 per GPU'),
 }
@@ -100,6 +102,7 @@ def main():
     ap.add_argument('--max-chunk', type=int, default=0)
     ap.add_argument('--pair-chunk', type=int, default=0)
     ap.add_argument('--spair-chunk', type=int, default=0)
+    ap.add_argument('--layout', default='auto', choices=['auto', 'wide'], help="'wide': width-generic kernels at nf=256")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print per-kernel-class times to stderr')
     args = ap.parse_args()
@@ -131,6 +134,10 @@ def main():
     wl = WORKLOADS[args.workload]
     cfg = configs.get(wl['cfg'])
     cfg.device = dev
+    if 'nf' in wl:
+        cfg.model.nf = wl['nf']                 # README.md:168 `--config.model.nf 384`
+    if args.layout != 'auto':
+        cfg.model['kernel_layout'] = args.layout
     B = args.batch or wl['batch']
     hp = O.Hyper.from_config(cfg)
     model = deterministic_init_(get_model_class(cfg.model.name)(cfg), seed=cfg.seed).to(dev).eval()

@@ -36,7 +36,7 @@ extern "C" {
 
 /* Model hyper-parameters (config.model.* / config.data.* of the reference's configs). */
 typedef struct {
-    int32_t nf;          /* D: node hidden width (256)                          */
+    int32_t nf;          /* D: node hidden width (256 tuned kernels; 384 width-generic set) */
     int32_t n_layers;    /* L                                                   */
     int32_t n_heads;     /* H (16)                                              */
     int32_t n_extra;     /* XH: adjacency heads (2)                             */
@@ -46,6 +46,8 @@ typedef struct {
     int32_t cond_ch;     /* 0 = DGT_concat, >0 = cond_DGT_concat                */
     float spatial_cut_off;
     float edge_quan_th;
+    int32_t layout;      /* 0 = automatic (nf 256: tuned kernel set, otherwise the width-generic set);
+                            1 = width-generic kernel set and weight layout even for nf 256 (tests)  */
 } jodo_cfg;
 
 /* Slots of the weight-offset table handed to jodo_dgt_forward (offsets in floats into the packed

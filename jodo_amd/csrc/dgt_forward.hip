@@ -6,6 +6,7 @@
 #include "dgt_kernels_block.h"
 #include "dgt_kernels_sym.h"
 #include "dgt_kernels_post.h"
+#include "dgt_kernels_wide.h"
 #include "jodo_hip_internal.h"
 
 using namespace jd;
@@ -75,7 +76,8 @@ struct ProfScope {
 
 #define LAUNCH(kern, grid, block, ...)                                  \
     do {                                                                \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, __VA_ARGS__); \
+        auto kf_ = kern;                                                \
+        hipLaunchKernelGGL(kf_, dim3(grid), dim3(block), 0, st, __VA_ARGS__); \
         int rc_ = jodo_check_launch(#kern);                             \
         if (rc_ != JODO_OK) return rc_;                                 \
     } while (0)
@@ -89,6 +91,84 @@ int launch_embed_nodes(hipStream_t st, const KArgs& A) {
 template <int NBK>
 int launch_edge_head(hipStream_t st, const KArgs& A) {
     LAUNCH(k_edge_head<NBK>, (unsigned)((A.pd.rows + 31) / 32), 64, A);
+    return JODO_OK;
+}
+
+// ---- width-generic kernel set (dgt_kernels_wide.h): everything after the time/modulation prologue ----
+template <int D, int KQ>
+int launch_embed_nodes_w(hipStream_t st, const KArgs& A) {
+    LAUNCH((wide::k_embed_nodes<D, KQ>), A.pd.n_strips, 64, A);
+    return JODO_OK;
+}
+template <int D, int NBK>
+int launch_edge_head_w(hipStream_t st, const KArgs& A) {
+    LAUNCH((wide::k_edge_head<D, NBK>), (unsigned)((A.pd.rows + 31) / 32), 64, A);
+    return JODO_OK;
+}
+
+template <int D>
+int forward_wide(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, float* const posbuf[2], ProfScope* pro) {
+    const DgtDims& d = p->dims;
+    int rc = JODO_OK;
+    LAUNCH(k_pack_nodes, (p->Nn_pad + 255) / 256, 256, A);
+    switch (d.ndp / 8) {
+        case 1: rc = launch_embed_nodes_w<D, 1>(st, A); break;
+        case 2: rc = launch_embed_nodes_w<D, 2>(st, A); break;
+        case 3: rc = launch_embed_nodes_w<D, 3>(st, A); break;
+        case 4: rc = launch_embed_nodes_w<D, 4>(st, A); break;
+        case 5: rc = launch_embed_nodes_w<D, 5>(st, A); break;
+        case 6: rc = launch_embed_nodes_w<D, 6>(st, A); break;
+        case 7: rc = launch_embed_nodes_w<D, 7>(st, A); break;
+        case 8: rc = launch_embed_nodes_w<D, 8>(st, A); break;
+        default: return jodo_set_error(JODO_ERR_UNSUPPORTED, "node input width %d", d.ndp);
+    }
+    if (rc) return rc;
+    if (p->n_items > 0) LAUNCH((wide::k_embed_edges<D>), p->n_items, 64, A);
+    delete pro;
+    const int nblocks = (p->max_blocks >= 0 && p->max_blocks < d.L) ? p->max_blocks : d.L;
+    int cur = 0;
+    for (int l = 0; l < nblocks; ++l) {
+        A.layer = l;
+        A.mod_base = 32 + (int64_t)l * d.MB;
+        for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + i];
+        A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
+        { ProfScope ps(p, st, JODO_PROF_NODE_PRE); LAUNCH((wide::k_node_pre<D>), p->n_strips * 3, 64, A); }
+        cur ^= 1;
+        if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_SCORES); LAUNCH((wide::k_edge_scores<D>), p->n_items, 64, A); }
+        { ProfScope ps(p, st, JODO_PROF_SOFTMAX); LAUNCH(k_softmax, (p->Nn + 15) / 16, 256, A); }
+        if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_MSGS); LAUNCH((wide::k_edge_msgs<D>), p->n_items, 64, A); }
+        { ProfScope ps(p, st, JODO_PROF_NODE_POST);
+          if (d.r == 2) LAUNCH((wide::k_node_post<D, 2>), p->n_strips, 64, A); else LAUNCH((wide::k_node_post<D, 4>), p->n_strips, 64, A); }
+        if (p->n_items > 0) {
+            ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);
+            if (d.r == 2) LAUNCH((wide::k_edge_update<D, 2>), p->n_items, 64, A); else LAUNCH((wide::k_edge_update<D, 4>), p->n_items, 64, A);
+        }
+    }
+    ProfScope epi(p, st, JODO_PROF_EPILOGUE);
+    A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
+    A.layer = nblocks;
+    LAUNCH(k_pos_final, (p->Nn_pad + 255) / 256, 256, A);
+    p->last_pos_buf = cur ^ 1;
+    LAUNCH((wide::k_node_head<D>), p->n_strips, 64, A);
+    switch (d.KEH / 32) {
+        case 5: rc = launch_edge_head_w<D, 5>(st, A); break;
+        case 6: rc = launch_edge_head_w<D, 6>(st, A); break;
+        case 7: rc = launch_edge_head_w<D, 7>(st, A); break;
+        case 8: rc = launch_edge_head_w<D, 8>(st, A); break;
+        case 9: rc = launch_edge_head_w<D, 9>(st, A); break;
+        case 10: rc = launch_edge_head_w<D, 10>(st, A); break;
+        case 11: rc = launch_edge_head_w<D, 11>(st, A); break;
+        case 12: rc = launch_edge_head_w<D, 12>(st, A); break;
+        case 13: rc = launch_edge_head_w<D, 13>(st, A); break;
+        case 15: rc = launch_edge_head_w<D, 15>(st, A); break;
+        default: return jodo_set_error(JODO_ERR_UNSUPPORTED, "edge head width %d", d.KEH);
+    }
+    if (rc) return rc;
+    LAUNCH(k_finalize_nodes, (p->B * p->N + 255) / 256, 256, A);
+    {
+        const size_t tot = (size_t)p->B * p->N * p->N;
+        LAUNCH(k_finalize_edges, (unsigned)((tot + 255) / 256), 256, A);
+    }
     return JODO_OK;
 }
 
@@ -147,6 +227,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     rc = rowgemm(st, A.temb, d.T, A.mods, d.Mtot, W + A.wg[JW_MOD_W], W + A.wg[JW_MOD_B], p->B, d.T, (int)(d.Mtot / 32), 1, 0,
                  uflag);
     if (rc) return rc;
+    if (d.wide) return d.D == 256 ? forward_wide<256>(p, st, A, woff, posbuf, pro) : forward_wide<384>(p, st, A, woff, posbuf, pro);
 
     // ---- pack inputs, embeddings ----
     LAUNCH(k_pack_nodes, (p->Nn_pad + 255) / 256, 256, A);

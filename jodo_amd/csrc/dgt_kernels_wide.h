@@ -1,0 +1,716 @@
+// Width-generic kernel set (template <int D>): every per-block kernel of dgt_kernels_{pre,node,block,post}.h
+// restated for any node width D = 128 * k (BASELINE config 4 runs nf = 384: De = 96, T = 1536, 14 x 27
+// score channels, 16 x 24 value channels).  Same strip model, same HBM layouts, same launch sequence;
+// what differs from the tuned nf = 256 set:
+//   * all weights are streamed from L2 through the software-pipelined ring (the K = De projections of
+//     the attention kernels no longer fit in LDS at De = 96), prefetch group of 4 quads (K = 96 gives
+//     12-quad blocks);
+//   * score heads use the "one head per 32-row block" arrangement (jodo_amd/packing.py
+//     qk_out_map_wide): SC = 27 has no 16 + 2 split, and padding a head to 32 rows keeps its reduction
+//     in-lane;
+//   * a value block no longer coincides with two attention heads (C = 24), so every lane carries all
+//     16 softmax weights and picks per register;
+//   * the node FFN accumulates its D outputs in passes of <= 8 blocks (register budget at D = 384);
+//   * directed kernels only (FLAG_ASYM is forced): the symmetric pair path is an optimisation of the
+//     nf = 256 set (dgt_kernels_sym.h).
+// Instantiated for D = 384; D = 256 is instantiated too so that the whole set can be pinned against
+// the tuned kernels and the nf = 256 fixtures (jodo_cfg.layout = 1, tests only).
+#pragma once
+#include "dgt_kernels_common.h"
+
+namespace jd {
+namespace wide {
+
+constexpr int PG = 4;            // weight quads in flight per prefetch group
+constexpr int NHEAD_BLOCKS = 14; // learned score heads, one 32-row block each
+
+template <int D_>
+struct Dim {
+    static constexpr int D = D_, De = D_ / 4, ND = D_ / 32, NE = D_ / 128;
+    static constexpr int HD = D_ / 2, HE = D_ / 8;                // registers per half-lane: node / edge vector
+    static constexpr int KQD = D_ / 8, KQE = D_ / 32;             // weight quads per output block for K = D / K = De
+    static constexpr int C = D_ / 16;                              // value channels per head
+    static constexpr float INV_SQRT_C = D_ == 256 ? 0.25f : (D_ == 384 ? 0.20412414523193150f : 0.f);
+    static constexpr int CNP = D_ / 4, NRO = CNP / 32;             // padded node readout width / blocks
+    static constexpr int CEP = (D_ / 16 + 15) / 16 * 16;           // padded edge readout width (16 or 32)
+    // modulation slice of one block: node 6 x D | edge 6 x De | equi (shift, scale) 2 x D | gbf (scale, shift)
+    static constexpr int M_EDGE = 6 * D_, M_EQUI = 6 * D_ + 6 * (D_ / 4), M_GBF = 6 * D_ + 6 * (D_ / 4) + 2 * D_;
+};
+
+template <int NB>
+__device__ __forceinline__ void gbf(float d2, float scale, float shift, const float* __restrict__ tab, int half,
+                                    float (&g)[NB * 16]) {
+    constexpr int De = NB * 32;
+    const float x = fmaf(d2, scale + 1.f, shift);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float mu[16], is[16], cf[16];
+        load16(tab + b * 32 + half * 16, mu);
+        load16(tab + De + b * 32 + half * 16, is);
+        load16(tab + 2 * De + b * 32 + half * 16, cf);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float z = (x - mu[s]) * is[s];
+            g[b * 16 + s] = fast_exp(-0.5f * z * z) * cf[s];
+        }
+    }
+    if (half == 0) g[0] = x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prologue
+template <int D, int KQ>
+__global__ __launch_bounds__(64) void k_embed_nodes(KArgs A) {
+    using X = Dim<D>;
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int v = blockIdx.x * 32 + j;
+    float x[KQ * 4];
+    const float4* src = reinterpret_cast<const float4*>(A.feat + (size_t)v * (KQ * 8) + half * (KQ * 4));
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        const float4 t = src[q];
+        x[q * 4 + 0] = t.x; x[q * 4 + 1] = t.y; x[q * 4 + 2] = t.z; x[q * 4 + 3] = t.w;
+    }
+    const float4* w = wq(A, A.wg[JW_NODE_EMB_W], lane);
+    const float* bias = A.W + A.wg[JW_NODE_EMB_B];
+#pragma unroll
+    for (int b = 0; b < X::ND; ++b) {
+        f32x16 acc = mfma_block<KQ>(w + (size_t)b * KQ * 64, x, zero16());
+        float r[16];
+        acc_bias(acc, bias + b * 32 + half * 16, r);
+        store16(A.h + (size_t)v * D + b * 32 + half * 16, r);
+        store16(A.ahid + (size_t)v * A.d.KNH + b * 32 + half * 16, r);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void k_embed_edges(KArgs A) {
+    using X = Dim<D>;
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int it = blockIdx.x;
+    const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it];
+    const LaneNode L = lane_node(A, strip, j);
+    const int ch = A.d.ch;
+    const bool first = A.flags[FLAG_COND_NONZERO] == 0;
+    const float* mr = mod_row(A, L.b);
+    const float gscale = mr[0], gshift = mr[1];
+    const float4 pc = reinterpret_cast<const float4*>(A.cpos)[L.v];
+    const float* tab = A.W + A.wg[JW_GBF_TOP];
+    const float4* w = wq(A, A.wg[JW_EDGE_EMB_W], lane);
+    const float* bias = A.W + A.wg[JW_EDGE_EMB_B];
+    for (int t = t0; t < t1; ++t) {
+        const bool ok = L.valid && t < L.n;
+        const int tc = ok ? t : 0;
+        const int u = L.noff + tc;
+        const size_t r = (size_t)L.eoff + (size_t)L.i * L.n + tc;
+        const float4 pu = reinterpret_cast<const float4*>(A.cpos)[u];
+        const float dx = pc.x - pu.x, dy = pc.y - pu.y, dz = pc.z - pu.z;
+        const float d2c = dx * dx + dy * dy + dz * dz;
+        const size_t din = (((size_t)L.b * A.pd.N + L.i) * A.pd.N + tc) * ch;
+        float ein[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int f = half * 4 + s;
+            float val = 0.f;
+            if (f < ch) val = A.edge_x[din + f];
+            else if (f < 2 * ch && A.cond_edge_x) val = A.cond_edge_x[din + (f - ch)];
+            ein[s] = val;
+        }
+        int adj2d = 1;
+        if (A.cond_edge_x) adj2d = A.cond_edge_x[din] >= A.d.edge_th ? 1 : 0;
+        const int adjsp = d2c <= A.d.cutoff ? 1 : 0;
+        float G[X::HE];
+        if (first) {
+#pragma unroll
+            for (int s = 0; s < X::HE; ++s) G[s] = 0.f;
+        } else {
+            gbf<X::NE>(d2c, gscale, gshift, tab, half, G);
+        }
+#pragma unroll
+        for (int b = 0; b < X::NE; ++b) {
+            f32x16 acc = mfma_block<X::KQE>(w + (size_t)(b * (X::KQE + 1)) * 64, G, zero16());
+            acc = mfma_block<1>(w + (size_t)(b * (X::KQE + 1) + X::KQE) * 64, ein, acc);
+            float rr[16];
+            acc_bias(acc, bias + b * 32 + half * 16, rr);
+            if (ok) {
+                store16(A.e + r * X::De + b * 32 + half * 16, rr);
+                store16(A.ehid + r * A.d.KEH + b * 32 + half * 16, rr);
+            }
+        }
+        if (ok && half == 0) A.eflag[r] = adj2d | (adjsp << 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// node side
+template <int D>
+__global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
+    using X = Dim<D>;
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int strip = blockIdx.x / 3, piece = blockIdx.x % 3;
+    const LaneNode L = lane_node(A, strip, j);
+    if (piece == 0) {
+        float4 p = reinterpret_cast<const float4*>(A.pos_in)[L.v];
+        if (A.layer > 0) {
+            const int parts = A.pd.strip_parts[strip];
+            for (int q = 0; q < parts; ++q) {
+                const float4 dp = reinterpret_cast<const float4*>(A.dpos)[(size_t)L.v * A.pd.max_parts + q];
+                p.x += dp.x; p.y += dp.y; p.z += dp.z;
+            }
+        }
+        if (half == 0) reinterpret_cast<float4*>(A.pos_out)[L.v] = p;
+    }
+    const float* mr = mod_row(A, L.b) + A.mod_base;
+    float hx[X::HD];
+    load_nat<X::ND>(A.h + (size_t)L.v * D, half, hx);
+    layer_norm<X::HD>(hx);
+    modulate<X::ND>(hx, mr, mr + D, half);
+    const WSrc ws = make_wsrc(A.W, lane);
+    const unsigned woff = (unsigned)(A.wb[piece == 0 ? JB_WQ : (piece == 1 ? JB_WK : JB_WV)] * 4);
+    const float* bias = A.W + A.wb[piece == 0 ? JB_BQ : (piece == 1 ? JB_BK : JB_BV)];
+    float* outp = piece == 0 ? A.q : (piece == 1 ? A.k : A.v);
+    const int nb = piece == 2 ? X::ND : NHEAD_BLOCKS;
+    WPipe<PG> wp;
+    wpipe_prime(wp, ws, woff);
+#pragma unroll 1
+    for (int b = 0; b < nb; ++b) {
+        const unsigned cur = woff + (unsigned)b * X::KQD * 1024;
+        const unsigned nxt = b + 1 < nb ? cur + X::KQD * 1024 : woff;
+        float bb[16], r[16];
+        load16(bias + b * 32 + half * 16, bb);
+        f32x16 acc = mfma_block_p<X::KQD>(wp, ws, cur, nxt, hx, zero16());
+#pragma unroll
+        for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
+        store16T(outp, nb, L.v, half, b, r);
+    }
+}
+
+template <int D, int R>
+__global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
+    using X = Dim<D>;
+    constexpr int NPASS = X::ND > 8 ? 2 : 1, NOB = X::ND / NPASS;        // ff2 output blocks per pass
+    constexpr int NCH = R * D / 64;                                       // hidden chunks of 64 features
+    constexpr int KQ2 = R * D / 8;                                        // quads per ff2 output block
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int strip = blockIdx.x;
+    const LaneNode L = lane_node(A, strip, j);
+    const float* mr = mod_row(A, L.b) + A.mod_base;
+    const float* ng1 = mr + 2 * D, *ns2 = mr + 3 * D, *nc2 = mr + 4 * D, *ng2 = mr + 5 * D;
+    const WSrc ws = make_wsrc(A.W, lane);
+    const unsigned oN2E = (unsigned)(A.wb[JB_N2E_W] * 4), oF1 = (unsigned)(A.wb[JB_FF1_W] * 4), oF2 = (unsigned)(A.wb[JB_FF2_W] * 4);
+    const unsigned oRow = (unsigned)(A.wb[JB_ROW_W] * 4), oCol = (unsigned)(A.wb[JB_COL_W] * 4), oNro = (unsigned)(A.wb[JB_NRO_W] * 4);
+    WPipe<PG> wp;
+    wpipe_prime(wp, ws, oN2E);
+    float hx[X::HD];
+    {   // aggregated attention messages: fixed-order sum of the per-chunk partials
+        const int parts = A.pd.strip_parts[strip];
+        const float* base = A.hhat + (size_t)L.v * A.pd.max_parts * D;
+        load_nat<X::ND>(base, half, hx);
+        for (int q = 1; q < parts; ++q) {
+#pragma unroll
+            for (int b = 0; b < X::ND; ++b) {
+                float t[16];
+                load16(base + (size_t)q * D + b * 32 + half * 16, t);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) hx[b * 16 + s] += t[s];
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < X::NE; ++b) {                                     // node2edge_lin per node
+        const unsigned cur = oN2E + (unsigned)b * X::KQD * 1024;
+        f32x16 acc = mfma_block_p<X::KQD>(wp, ws, cur, b + 1 < X::NE ? cur + X::KQD * 1024 : oF1, hx, zero16());
+        float r[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) r[s] = acc[s];
+        store16T(A.n2e, X::NE, L.v, half, b, r);
+    }
+    {   // x = LN(h + ng1 * hh) * (1 + nc2) + ns2
+        const float* hrow = A.h + (size_t)L.v * D;
+#pragma unroll
+        for (int b = 0; b < X::ND; ++b) {
+            float g[16], h0[16];
+            load16(ng1 + b * 32 + half * 16, g);
+            load16(hrow + b * 32 + half * 16, h0);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) hx[b * 16 + s] = fmaf(g[s], hx[b * 16 + s], h0[s]);
+        }
+        layer_norm<X::HD>(hx);
+        modulate<X::ND>(hx, ns2, nc2, half);
+    }
+    // FFN: hidden R*D in chunks of 64; ff2 accumulates NOB output blocks per pass (the hidden chunk is
+    // recomputed in every pass — cheaper than spilling D/2 accumulators per lane).  hx must stay intact
+    // until the last pass (it is the ff1 input), so finished output blocks go straight to A.h and are
+    // read back (same thread) as the B operand of the projections below.
+    {
+        const float* b1 = A.W + A.wb[JB_FF1_B];
+        const float* b2 = A.W + A.wb[JB_FF2_B];
+        float* hrow = A.h + (size_t)L.v * D;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            f32x16 o[NOB];
+#pragma unroll
+            for (int b = 0; b < NOB; ++b) o[b] = zero16();
+#pragma unroll 1
+            for (int c = 0; c < NCH; ++c) {
+                float hid[32];
+#pragma unroll
+                for (int b2i = 0; b2i < 2; ++b2i) {
+                    const unsigned cur = oF1 + (unsigned)(c * 2 + b2i) * X::KQD * 1024;
+                    const unsigned nxt = b2i == 0 ? cur + X::KQD * 1024 : oF2 + (unsigned)((ps * NOB) * KQ2 + c * 8) * 1024;
+                    float bb[16];
+                    load16(b1 + (c * 2 + b2i) * 32 + half * 16, bb);
+                    f32x16 acc = mfma_block_p<X::KQD>(wp, ws, cur, nxt, hx, zero16());
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) hid[b2i * 16 + s] = silu_f(acc[s] + bb[s]);
+                }
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) {
+                    const unsigned cur = oF2 + (unsigned)((ps * NOB + ob) * KQ2 + c * 8) * 1024;
+                    const unsigned nxt = ob + 1 < NOB ? oF2 + (unsigned)((ps * NOB + ob + 1) * KQ2 + c * 8) * 1024
+                                                      : (c + 1 < NCH ? oF1 + (unsigned)((c + 1) * 2) * X::KQD * 1024
+                                                                     : (ps + 1 < NPASS ? oF1 : oRow));
+                    o[ob] = mfma_block_p<8>(wp, ws, cur, nxt, hid, o[ob]);
+                }
+            }
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) {
+                const int b = ps * NOB + ob;
+                float bb[16], g[16], r[16];
+                load16(b2 + b * 32 + half * 16, bb);
+                load16(ng2 + b * 32 + half * 16, g);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) r[s] = fmaf(g[s], o[ob][s] + bb[s], hx[b * 16 + s]);
+                store16(hrow + b * 32 + half * 16, r);
+            }
+        }
+        load_nat<X::ND>(hrow, half, hx);                                  // hx = h_out from here on
+    }
+    {   // per-node halves of equi_update.input_lin: W_row h (+ bias), W_col h
+        const float* bin = A.W + A.wb[JB_IN_B];
+#pragma unroll 1
+        for (int b = 0; b < X::ND; ++b) {
+            const unsigned cr = oRow + (unsigned)b * X::KQD * 1024, cc = oCol + (unsigned)b * X::KQD * 1024;
+            float bb[16], r[16];
+            load16(bin + b * 32 + half * 16, bb);
+            f32x16 acc = mfma_block_p<X::KQD>(wp, ws, cr, cc, hx, zero16());
+#pragma unroll
+            for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
+            store16T(A.wrow, X::ND, L.v, half, b, r);
+            acc = mfma_block_p<X::KQD>(wp, ws, cc, b + 1 < X::ND ? cr + X::KQD * 1024 : oNro, hx, zero16());
+#pragma unroll
+            for (int s = 0; s < 16; ++s) r[s] = acc[s];
+            store16T(A.wcol, X::ND, L.v, half, b, r);
+        }
+    }
+    {   // readout node_l(h) -> atom_hids[:, D + l*CNP ...]
+        const float* bias = A.W + A.wb[JB_NRO_B];
+#pragma unroll
+        for (int b = 0; b < X::NRO; ++b) {
+            const unsigned cur = oNro + (unsigned)b * X::KQD * 1024;
+            float bb[16], r[16];
+            load16(bias + b * 32 + half * 16, bb);
+            f32x16 acc = mfma_block_p<X::KQD>(wp, ws, cur, b + 1 < X::NRO ? cur + X::KQD * 1024 : oNro, hx, zero16());
+#pragma unroll
+            for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
+            store16(A.ahid + (size_t)L.v * A.d.KNH + D + A.layer * X::CNP + b * 32 + half * 16, r);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// edge side (directed: rows r = eoff + a*n + c, a = source / row atom, c = target / column atom)
+template <int D>
+__global__ __launch_bounds__(64, 1) void k_edge_scores(KArgs A) {
+    using X = Dim<D>;
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int it = blockIdx.x;
+    const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it];
+    const LaneNode L = lane_node(A, strip, j);
+    const float* mrow = mod_row(A, L.b) + A.mod_base;
+    const float gscale = mrow[X::M_GBF + 0], gshift = mrow[X::M_GBF + 1];
+    const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
+    const WSrc ws = make_wsrc(A.W, lane);
+    const unsigned oEE = (unsigned)(A.wb[JB_EE_W] * 4), oL0 = (unsigned)(A.wb[JB_LE0_W] * 4);
+    WPipe<PG> wp;
+    wpipe_prime(wp, ws, oEE);
+    for (int t = t0; t < t1; ++t) {
+        const bool ok = L.valid && t < L.n;
+        const int tc = ok ? t : 0;
+        const int u = L.noff + tc;
+        const size_t r = (size_t)L.eoff + (size_t)tc * L.n + L.i;      // edge (source a = t) -> (target c = i)
+        const float* es1 = launder(mrow + X::M_EDGE);
+        const float* ec1 = es1 + X::De;
+        const float* cst = launder(A.W);
+        const float* tab = cst + A.wb[JB_GBF];
+        const float* bEE = cst + A.wb[JB_EE_B];
+        TRow qrow = trow(A.q, NHEAD_BLOCKS, L.v, half), krow = trow(A.k, NHEAD_BLOCKS, u, half);
+        qrow.p = launder(qrow.p);
+        const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[u];
+        const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
+        float x[X::HE];
+        {
+            float G[X::HE], e[X::HE];
+            gbf<X::NE>(dx * dx + dy * dy + dz * dz, gscale, gshift, tab, half, G);
+            load_nat<X::NE>(A.e + r * X::De, half, e);
+#pragma unroll
+            for (int b = 0; b < X::NE; ++b) {
+                const unsigned cg = oEE + (unsigned)(b * 2 * X::KQE) * 1024, ce = cg + X::KQE * 1024;
+                float bb[16];
+                load16(bEE + b * 32 + half * 16, bb);
+                f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cg, ce, G, zero16());
+                acc = mfma_block_p<X::KQE>(wp, ws, ce, b + 1 < X::NE ? ce + X::KQE * 1024 : oL0, e, acc);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) x[b * 16 + s] = acc[s] + bb[s];
+            }
+        }
+        layer_norm<X::HE>(x);
+        modulate<X::NE>(x, es1, ec1, half);
+        if (ok) store_nat<X::NE>(A.et + r * X::De, half, x);
+        // lin_edge0 -> tanh -> * q_target * k_source; head g = block g, padded rows are zero in q and k
+        float Sg[NHEAD_BLOCKS];
+        float qn[16], kn[16];
+        load16T(qrow, 0, qn);
+        load16T(krow, 0, kn);
+#pragma unroll
+        for (int g = 0; g < NHEAD_BLOCKS; ++g) {
+            float qq[16], kk[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { qq[s] = qn[s]; kk[s] = kn[s]; }
+            if (g + 1 < NHEAD_BLOCKS) {                    // one block ahead
+                load16T(qrow, g + 1, qn);
+                load16T(krow, g + 1, kn);
+            }
+            const unsigned cur = oL0 + (unsigned)(g * X::KQE) * 1024;
+            f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cur, g + 1 < NHEAD_BLOCKS ? cur + X::KQE * 1024 : oEE, x, zero16());
+            float s_ = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) s_ = fmaf(tanh_f(acc[s]) * qq[s], kk[s], s_);
+            Sg[g] = s_;
+        }
+        const int fl = A.eflag[r];
+#pragma unroll
+        for (int g = 0; g < NHEAD_BLOCKS; ++g) Sg[g] = pair_sum(Sg[g]) * X::INV_SQRT_C;   // / sqrt(out_channels = D / H), layers.py:167
+        float Sout[8];                                  // slot b of this half = head 2b + half (0, 1 = adjacency heads)
+        Sout[0] = half == 0 ? ((fl & 1) ? 1.f : -1e10f) : ((fl & 2) ? 1.f : -1e10f);
+#pragma unroll
+        for (int b = 1; b < 8; ++b) Sout[b] = half == 0 ? Sg[2 * (b - 1)] : Sg[2 * (b - 1) + 1];
+        if (ok) {
+            float4* sp = reinterpret_cast<float4*>(A.S + r * 16 + half * 8);
+            sp[0] = make_float4(Sout[0], Sout[1], Sout[2], Sout[3]);
+            sp[1] = make_float4(Sout[4], Sout[5], Sout[6], Sout[7]);
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64, 1) void k_edge_msgs(KArgs A) {
+    using X = Dim<D>;
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int it = blockIdx.x;
+    const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it], part = A.pd.item_part[it];
+    const LaneNode L = lane_node(A, strip, j);
+    // softmax statistics of all 16 heads of this lane's target; stored slot (g & 1) * 8 + (g >> 1) = head g
+    float mx[16], inv[16];
+    load16(A.stats + (size_t)L.v * 32, mx);
+    load16(A.stats + (size_t)L.v * 32 + 16, inv);
+    const WSrc ws = make_wsrc(A.W, lane);
+    const unsigned oL1 = (unsigned)(A.wb[JB_LE1_W] * 4);
+    WPipe<PG> wp;
+    wpipe_prime(wp, ws, oL1);
+    float macc[X::HD];
+#pragma unroll
+    for (int s = 0; s < X::HD; ++s) macc[s] = 0.f;
+    for (int t = t0; t < t1; ++t) {
+        const bool ok = L.valid && t < L.n && t != L.i;
+        const int tc = (L.valid && t < L.n) ? t : 0;
+        const int u = L.noff + tc;
+        const size_t r = (size_t)L.eoff + (size_t)tc * L.n + L.i;
+        float x[X::HE];
+        load_nat<X::NE>(A.et + r * X::De, half, x);
+        float al[16];                                   // al[g] = attention weight of head g
+        {
+            float sv[16];
+            load16(A.S + r * 16, sv);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int sl = (g & 1) * 8 + (g >> 1);
+                al[g] = ok ? fast_exp(sv[sl] - mx[sl]) * inv[sl] : 0.f;
+            }
+        }
+        const TRow vrow = trow(A.v, X::ND, u, half);
+        float vnext[16];
+        load16T(vrow, 0, vnext);
+#pragma unroll
+        for (int b = 0; b < X::ND; ++b) {
+            float vv[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) vv[s] = vnext[s];
+            if (b + 1 < X::ND) load16T(vrow, b + 1, vnext);
+            const unsigned cur = oL1 + (unsigned)(b * X::KQE) * 1024;
+            f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cur, b + 1 < X::ND ? cur + X::KQE * 1024 : oL1, x, zero16());
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                // feature b*32 + half*16 + s belongs to head feature / C
+                const float a = half ? al[(b * 32 + 16 + s) / X::C] : al[(b * 32 + s) / X::C];
+                macc[b * 16 + s] = fmaf(tanh_f(acc[s]) * vv[s], a, macc[b * 16 + s]);
+            }
+        }
+    }
+    store_nat<X::ND>(A.hhat + ((size_t)L.v * A.pd.max_parts + part) * D, half, macc);
+}
+
+template <int D, int R>
+__global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
+    using X = Dim<D>;
+    constexpr int NCH = R * X::De / 64;                   // edge FFN hidden chunks of 64
+    constexpr int KQ4 = R * X::De / 8;                    // quads per ff4 output block
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int it = blockIdx.x;
+    const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it], part = A.pd.item_part[it];
+    const LaneNode L = lane_node(A, strip, j);
+    const float* mrow = mod_row(A, L.b) + A.mod_base;
+    const float* eg1 = mrow + X::M_EDGE + 2 * X::De;      // edge chunks: es1, ec1, eg1, es2, ec2, eg2
+    const float* qsh = mrow + X::M_EQUI;                  // equi_update.time_mlp: (shift, scale)
+    const float gscale = mrow[X::M_GBF + 0], gshift = mrow[X::M_GBF + 1];
+    const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
+    const float cscale = A.W[A.wb[JB_CSCALE]];
+    const WSrc ws = make_wsrc(A.W, lane);
+    const unsigned o3 = (unsigned)(A.wb[JB_FF3_W] * 4), o4 = (unsigned)(A.wb[JB_FF4_W] * 4);
+    const unsigned oro = (unsigned)(A.wb[JB_ERO_W] * 4), oi = (unsigned)(A.wb[JB_INE_W] * 4), o0 = (unsigned)(A.wb[JB_C0_W] * 4);
+    WPipe<PG> wp;
+    wpipe_prime(wp, ws, o3);
+    float dax = 0.f, day = 0.f, daz = 0.f;
+    for (int t = t0; t < t1; ++t) {
+        const bool inr = L.valid && t < L.n;
+        const bool ok = inr && t != L.i;
+        const int tc = inr ? t : 0;
+        const int u = L.noff + tc;
+        const size_t r = (size_t)L.eoff + (size_t)L.i * L.n + tc;
+        const float* eg1_ = launder(eg1);
+        const float* es2_ = eg1_ + X::De, *ec2_ = es2_ + X::De, *eg2_ = ec2_ + X::De;
+        const float* qsh_ = launder(qsh);
+        const float* qsc_ = qsh_ + D;
+        const float* cst = launder(A.W);
+        const float* n2bias_ = cst + A.wb[JB_N2E_B], *b3_ = cst + A.wb[JB_FF3_B], *b4_ = cst + A.wb[JB_FF4_B];
+        const float* b0_ = cst + A.wb[JB_C0_B], *w2_ = cst + A.wb[JB_C2_W], *tab_ = cst + A.wb[JB_GBF];
+        const float* bro_ = cst + A.wb[JB_ERO_B];
+        TRow wrow = trow(A.wrow, X::ND, L.v, half);
+        wrow.p = launder(wrow.p);
+        const TRow wcol = trow(A.wcol, X::ND, u, half);
+        const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[u];
+        const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        float G[X::HE];
+        gbf<X::NE>(d2, gscale, gshift, tab_, half, G);
+        // ---- edge residual + LN2 + modulate ----
+        float en[X::HE];
+        {
+            const TRow ra = trow(A.n2e, X::NE, L.v, half), rc = trow(A.n2e, X::NE, u, half);
+#pragma unroll
+            for (int b = 0; b < X::NE; ++b) {
+                float e[16], ta[16], tc2[16], g[16], bb[16];
+                load16(A.e + r * X::De + b * 32 + half * 16, e);
+                load16T(ra, b, ta);
+                load16T(rc, b, tc2);
+                load16(eg1_ + b * 32 + half * 16, g);
+                load16(n2bias_ + b * 32 + half * 16, bb);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) en[b * 16 + s] = fmaf(g[s], ta[s] + tc2[s] + bb[s], e[s]);
+            }
+        }
+        layer_norm<X::HE>(en);
+        modulate<X::NE>(en, es2_, ec2_, half);
+        // ---- edge FFN ----
+        {
+            f32x16 o[X::NE];
+#pragma unroll
+            for (int b = 0; b < X::NE; ++b) o[b] = zero16();
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                float hid[32];
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    const unsigned wcur = o3 + (unsigned)(c * 2 + b2) * X::KQE * 1024;
+                    const unsigned wnx = b2 == 0 ? wcur + X::KQE * 1024 : o4 + (unsigned)(c * 8) * 1024;
+                    float bb[16];
+                    load16(b3_ + (c * 2 + b2) * 32 + half * 16, bb);
+                    f32x16 acc = mfma_block_p<X::KQE>(wp, ws, wcur, wnx, en, zero16());
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(acc[s] + bb[s]);
+                }
+#pragma unroll
+                for (int ob = 0; ob < X::NE; ++ob) {
+                    const unsigned wcur = o4 + (unsigned)(ob * KQ4 + c * 8) * 1024;
+                    const unsigned wnx = ob + 1 < X::NE ? o4 + (unsigned)((ob + 1) * KQ4 + c * 8) * 1024
+                                                        : (c + 1 < NCH ? o3 + (unsigned)((c + 1) * 2) * X::KQE * 1024 : oro);
+                    o[ob] = mfma_block_p<8>(wp, ws, wcur, wnx, hid, o[ob]);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < X::NE; ++b) {
+                float ob4[16], og2[16];
+                load16(b4_ + b * 32 + half * 16, ob4);
+                load16(eg2_ + b * 32 + half * 16, og2);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) en[b * 16 + s] = fmaf(og2[s], o[b][s] + ob4[s], en[b * 16 + s]);
+            }
+        }
+        if (inr) store_nat<X::NE>(A.e + r * X::De, half, en);
+        // ---- readout edge_l(e) -> edge_hids[:, De + l*CEP ...] ----
+        {
+            float bb[16];
+            load16(bro_ + half * 16, bb);
+            f32x16 acc = mfma_block_p<X::KQE>(wp, ws, oro, oi, en, zero16());
+            float rr[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) rr[s] = acc[s] + bb[s];
+            if (inr && (half == 0 || X::CEP == 32)) store16(A.ehid + r * A.d.KEH + X::De + A.layer * X::CEP + half * 16, rr);
+        }
+        // ---- equivariant update: u = W_e e + W_d G + (W_row h_a + b) + W_col h_c ----
+        float uu[X::HD];
+#pragma unroll
+        for (int b = 0; b < X::ND; ++b) {
+            const unsigned we = oi + (unsigned)(b * 2 * X::KQE) * 1024, wg_ = we + X::KQE * 1024;
+            float a1[16], a2[16];
+            load16T(wrow, b, a1);
+            load16T(wcol, b, a2);
+            f32x16 acc = mfma_block_p<X::KQE>(wp, ws, we, wg_, en, zero16());
+            acc = mfma_block_p<X::KQE>(wp, ws, wg_, b + 1 < X::ND ? wg_ + X::KQE * 1024 : o0, G, acc);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) uu[b * 16 + s] = acc[s] + a1[s] + a2[s];
+        }
+        layer_norm<X::HD>(uu);
+        modulate<X::ND>(uu, qsh_, qsc_, half);
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll 1
+        for (int b = 0; b < X::ND; ++b) {
+            const unsigned wcur = o0 + (unsigned)b * X::KQD * 1024;
+            const unsigned wnx = b + 1 < X::ND ? wcur + X::KQD * 1024 : o3;
+            float bb[16], k0[16], k1[16], k2[16];
+            load16(b0_ + b * 32 + half * 16, bb);
+            load16(w2_ + b * 32 + half * 16, k0);
+            load16(w2_ + D + b * 32 + half * 16, k1);
+            load16(w2_ + 2 * D + b * 32 + half * 16, k2);
+            f32x16 acc = mfma_block_p<X::KQD>(wp, ws, wcur, wnx, uu, zero16());
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float ys = silu_f(acc[s] + bb[s]);
+                c0 = fmaf(ys, k0[s], c0);
+                c1 = fmaf(ys, k1[s], c1);
+                c2 = fmaf(ys, k2[s], c2);
+            }
+        }
+        c0 = tanh_f(pair_sum(c0));
+        c1 = tanh_f(pair_sum(c1));
+        c2 = tanh_f(pair_sum(c2));
+        const int fl = A.eflag[r];
+        const float iota = (c0 + ((fl & 1) ? c1 : 0.f) + ((fl & 2) ? c2 : 0.f)) * (1.f / 3.f);
+        const float nrm = fmaxf(sqrtf(d2), 1e-8f);
+        const float f = ok ? cscale * iota / nrm : 0.f;
+        dax = fmaf(dx, f, dax);
+        day = fmaf(dy, f, day);
+        daz = fmaf(dz, f, daz);
+    }
+    if (half == 0)
+        reinterpret_cast<float4*>(A.dpos)[(size_t)L.v * A.pd.max_parts + part] = make_float4(dax, day, daz, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// heads
+template <int D>
+__global__ __launch_bounds__(64, 1) void k_node_head(KArgs A) {
+    using X = Dim<D>;
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int v = blockIdx.x * 32 + j;
+    const int KNH = A.d.KNH;
+    f32x16 o[X::ND];
+#pragma unroll
+    for (int b = 0; b < X::ND; ++b) o[b] = zero16();
+    {
+        const float4* w = wq(A, A.wg[JW_NH1_W], lane);
+        const int kq = KNH / 8;
+#pragma unroll 1
+        for (int c = 0; c < KNH / 64; ++c) {
+            float x[32];
+            load_nat<2>(A.ahid + (size_t)v * KNH + c * 64, half, x);
+#pragma unroll
+            for (int ob = 0; ob < X::ND; ++ob) o[ob] = mfma_block<8>(w + ((size_t)ob * kq + c * 8) * 64, x, o[ob]);
+        }
+    }
+    float a1[X::HD];
+    {
+        const float* bias = A.W + A.wg[JW_NH1_B];
+#pragma unroll
+        for (int b = 0; b < X::ND; ++b) {
+            float r[16];
+            acc_bias(o[b], bias + b * 32 + half * 16, r);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) a1[b * 16 + s] = silu_f(r[s]);
+        }
+    }
+    float a2[X::HD / 2];
+    {
+        const float4* w = wq(A, A.wg[JW_NH2_W], lane);
+        const float* bias = A.W + A.wg[JW_NH2_B];
+#pragma unroll
+        for (int b = 0; b < X::ND / 2; ++b) {
+            f32x16 acc = mfma_block<X::KQD>(w + (size_t)b * X::KQD * 64, a1, zero16());
+            float r[16];
+            acc_bias(acc, bias + b * 32 + half * 16, r);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) a2[b * 16 + s] = silu_f(r[s]);
+        }
+    }
+    {
+        f32x16 acc = mfma_block<X::KQD / 2>(wq(A, A.wg[JW_NH3_W], lane), a2, zero16());
+        float r[16];
+        acc_bias(acc, A.W + A.wg[JW_NH3_B] + half * 16, r);
+        store16(A.apred + (size_t)v * 32 + half * 16, r);
+    }
+}
+
+template <int D, int NBK>     // NBK = KEH / 32
+__global__ __launch_bounds__(64, 1) void k_edge_head(KArgs A) {
+    using X = Dim<D>;
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const size_t r = (size_t)blockIdx.x * 32 + j;
+    float x[NBK * 16];
+    load_nat<NBK>(A.ehid + r * (NBK * 32), half, x);
+    float a1[X::De];                                       // [exist De | type De] hidden, half of it per half-lane
+    {
+        const float4* w = wq(A, A.wg[JW_EH1_W], lane);
+        const float* bias = A.W + A.wg[JW_EH1_B];
+#pragma unroll
+        for (int b = 0; b < 2 * X::NE; ++b) {
+            f32x16 acc = mfma_block<NBK * 4>(w + (size_t)b * (NBK * 4) * 64, x, zero16());
+            float rr[16];
+            acc_bias(acc, bias + b * 32 + half * 16, rr);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) a1[b * 16 + s] = silu_f(rr[s]);
+        }
+    }
+    float a2[X::De / 2];
+    {
+        const float4* w = wq(A, A.wg[JW_EH2_W], lane);
+        const float* bias = A.W + A.wg[JW_EH2_B];
+#pragma unroll
+        for (int b = 0; b < X::NE; ++b) {
+            f32x16 acc = mfma_block<X::De / 4>(w + (size_t)b * (X::De / 4) * 64, a1, zero16());
+            float rr[16];
+            acc_bias(acc, bias + b * 32 + half * 16, rr);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) a2[b * 16 + s] = silu_f(rr[s]);
+        }
+    }
+    {
+        f32x16 acc = mfma_block<X::De / 8>(wq(A, A.wg[JW_EH3_W], lane), a2, zero16());
+        float rr[16];
+        acc_bias(acc, A.W + A.wg[JW_EH3_B] + half * 16, rr);
+        if (half == 0 && r < (size_t)A.pd.rows)
+            reinterpret_cast<float4*>(A.epred)[r] = make_float4(rr[0], rr[1], rr[2], rr[3]);
+    }
+}
+
+}  // namespace wide
+}  // namespace jd

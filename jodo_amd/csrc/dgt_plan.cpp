@@ -39,8 +39,9 @@ static void permute(std::vector<int32_t>& a, const std::vector<int>& ord) {
 }
 
 int dgt_dims_from_cfg(const jodo_cfg* c, DgtDims* d) {
-    if (c->nf != 256)
-        return jodo_set_error(JODO_ERR_UNSUPPORTED, "nf=%d: only nf=256 kernels are built (nf=384 is the next tier)", c->nf);
+    if (c->nf != 256 && c->nf != 384)
+        return jodo_set_error(JODO_ERR_UNSUPPORTED, "nf=%d: kernels are built for nf=256 and nf=384", c->nf);
+    if (c->layout != 0 && c->layout != 1) return jodo_set_error(JODO_ERR_ARG, "layout=%d (0 or 1)", c->layout);
     if (c->n_heads != 16 || c->n_extra != 2)
         return jodo_set_error(JODO_ERR_UNSUPPORTED, "n_heads=%d n_extra_heads=%d: kernels are built for 16/2", c->n_heads, c->n_extra);
     if (c->mlp_ratio != 2 && c->mlp_ratio != 4)
@@ -52,11 +53,12 @@ int dgt_dims_from_cfg(const jodo_cfg* c, DgtDims* d) {
     d->D = c->nf; d->De = c->nf / 4; d->T = c->nf * 4; d->L = c->n_layers; d->H = c->n_heads; d->XH = c->n_extra;
     d->SH = d->H - d->XH; d->C = d->D / d->H; d->SC = (d->H * d->C) / d->SH; d->r = c->mlp_ratio;
     d->nd = c->in_node_dim; d->ch = c->edge_ch; d->cond_ch = c->cond_ch;
+    d->wide = (c->nf != 256 || c->layout == 1) ? 1 : 0;
     int tail = d->SC - 16;
-    d->QKP = (d->SH / 2 + (tail + 1) / 2) * 32;
+    d->QKP = d->wide ? d->SH * 32 : (d->SH / 2 + (tail + 1) / 2) * 32;      // wide: one head per 32-row block
     d->ndp = (2 * d->nd + 7) / 8 * 8;
     d->einp = (2 * d->ch + 7) / 8 * 8;
-    d->cnp = 64; d->cep = 16;
+    d->cnp = d->D / 4; d->cep = (d->D / 16 + 15) / 16 * 16;               // 64 / 16 at nf 256, 96 / 32 at nf 384
     if ((2 * d->D) / d->L > d->cnp || (2 * d->De) / d->L > d->cep)
         return jodo_set_error(JODO_ERR_UNSUPPORTED, "n_layers=%d gives readout widths beyond the padded slots", d->L);
     d->KNH = d->D + d->L * d->cnp; d->KEH = d->De + d->L * d->cep;
@@ -90,7 +92,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     if (max_chunk <= 0) max_chunk = 8;
     if (pair_chunk <= 0) pair_chunk = 1;     // measured best on MI355X (QM9 B=2500: 26.7 ms/step vs 27.7 at 2)
     if (spair_chunk <= 0) spair_chunk = pair_chunk;   // sweep on MI355X: 1 and 4 tie, 6 is 35 % slower
-    p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->prof_enabled = 0; p->force_directed = 0; p->dbg_timing = nullptr;
+    p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->prof_enabled = 0; p->force_directed = p->dims.wide; p->dbg_timing = nullptr;
 
     // molecules by descending size (stable): neighbouring lanes share n, big work first
     std::vector<int> order(B);

@@ -15,6 +15,7 @@ struct DgtDims {
     int MB;         // modulation floats per block
     int64_t Mtot;   // modulation floats per molecule
     float cutoff, edge_th;
+    int wide;       // 1 = width-generic kernel set (dgt_kernels_wide.h) and its weight layout
 };
 
 // device views into the descriptor buffer (all int32)

@@ -120,14 +120,17 @@ class _DGTBase(nn.Module):
         D, De, L = m.nf, m.nf // 4, m.n_layers
         T = D * 4
         cond_ch = int(m.cond_ch) if self.conditional else 0
-        self.dims = ModelDims(D, L, m.n_heads, m.n_extra_heads, m.mlp_ratio, in_node_dim, m.edge_ch, cond_ch)
-        if D != 256 or m.n_heads != 16 or m.n_extra_heads != 2 or m.mlp_ratio not in (2, 4):
-            raise NotImplementedError("HIP kernels are built for nf=256, n_heads=16, n_extra_heads=2, mlp_ratio in {2,4} "
-                                      "(got nf=%d heads=%d/%d ratio=%d); nf=384 is the next tier" %
+        if D not in (256, 384) or m.n_heads != 16 or m.n_extra_heads != 2 or m.mlp_ratio not in (2, 4):
+            raise NotImplementedError("HIP kernels are built for nf in {256, 384}, n_heads=16, n_extra_heads=2, "
+                                      "mlp_ratio in {2,4} (got nf=%d heads=%d/%d ratio=%d)" %
                                       (D, m.n_heads, m.n_extra_heads, m.mlp_ratio))
+        # kernel_layout (not a reference key): 'wide' runs the width-generic kernel set at nf=256 too (tests)
+        wide = getattr(m, 'kernel_layout', 'auto') == 'wide'
+        self.dims = ModelDims(D, L, m.n_heads, m.n_extra_heads, m.mlp_ratio, in_node_dim, m.edge_ch, cond_ch, wide=wide)
         if self.dims.cn > self.dims.cnp or self.dims.ce > self.dims.cep or L % 2:
-            raise NotImplementedError("n_layers=%d: per-block readout widths (%d, %d) exceed the padded slots (64, 16) "
-                                      "or n_layers is odd; supported: even n_layers >= 8" % (L, self.dims.cn, self.dims.ce))
+            raise NotImplementedError("n_layers=%d: per-block readout widths (%d, %d) exceed the padded slots (%d, %d) "
+                                      "or n_layers is odd; supported: even n_layers >= 8" %
+                                      (L, self.dims.cn, self.dims.ce, self.dims.cnp, self.dims.cep))
         self.edge_th = float(m.edge_quan_th)
         self.spatial_cut_off = float(m.spatial_cut_off)
         self.n_layers = L
@@ -162,13 +165,13 @@ class _DGTBase(nn.Module):
         _fields_ = [('nf', ctypes.c_int32), ('n_layers', ctypes.c_int32), ('n_heads', ctypes.c_int32),
                     ('n_extra', ctypes.c_int32), ('mlp_ratio', ctypes.c_int32), ('in_node_dim', ctypes.c_int32),
                     ('edge_ch', ctypes.c_int32), ('cond_ch', ctypes.c_int32),
-                    ('spatial_cut_off', ctypes.c_float), ('edge_quan_th', ctypes.c_float)]
+                    ('spatial_cut_off', ctypes.c_float), ('edge_quan_th', ctypes.c_float), ('layout', ctypes.c_int32)]
 
     def _cfg(self):
         if self._cfg_struct is None:
             d = self.dims
             self._cfg_struct = self._Cfg(d.D, d.L, d.H, d.XH, d.r, d.nd, d.ch, d.cond_ch, self.spatial_cut_off,
-                                         self.edge_th)
+                                         self.edge_th, 1 if d.wide else 0)
         return self._cfg_struct
 
     # -- weights -----------------------------------------------------------------------------

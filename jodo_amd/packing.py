@@ -95,6 +95,21 @@ def qk_out_map(sub_heads, sub_ch):
     return m
 
 
+def qk_out_map_wide(sub_heads, sub_ch):
+    """Width-generic arrangement (csrc/dgt_kernels_wide.h): head g owns the 32-row block g in natural
+    order, rows >= SC are zero padding — the per-head reduction is 16 in-lane terms + one exchange for
+    any SC <= 32 (SC = 27 at nf = 384)."""
+    assert sub_ch <= 32
+    m = np.full((sub_heads, 2, 16), -1, dtype=np.int64)
+    for g in range(sub_heads):
+        for h in (0, 1):
+            for s in range(16):
+                c = h * 16 + s
+                if c < sub_ch:
+                    m[g, h, s] = g * sub_ch + c
+    return m
+
+
 def out_row_of_lane(i):
     """MFMA output row i (0..31) of a block -> (half, register)."""
     return (i >> 2) & 1, (i & 3) + 4 * (i >> 3)

@@ -31,9 +31,11 @@ OUT = os.path.join(ROOT, 'tests', 'golden')
 HEAD_GAIN = 30.0      # scale the heads' last layers so that argmax / threshold decodes are not degenerate
 
 
-def build_reference_model(ref, cfg_name, seed, head_gain=1.0):
+def build_reference_model(ref, cfg_name, seed, head_gain=1.0, nf=None):
     cfg = reference_config(cfg_name)
     cfg.device = torch.device('cpu')
+    if nf is not None:
+        cfg.model.nf = nf                                         # README.md:168 `--config.model.nf 384`
     model = ref.models.utils._MODELS[cfg.model.name](cfg).eval()
     deterministic_init_(model, seed=seed)
     if head_gain != 1.0:
@@ -52,8 +54,8 @@ def masks(n_nodes):
     return nm.unsqueeze(2), em.reshape(-1, 1)
 
 
-def forward_fixture(ref, cfg_name, n_nodes, seed, fname):
-    cfg, model = build_reference_model(ref, cfg_name, seed)
+def forward_fixture(ref, cfg_name, n_nodes, seed, fname, nf=None):
+    cfg, model = build_reference_model(ref, cfg_name, seed, nf=nf)
     hp = O.Hyper.from_config(cfg)
     g = torch.Generator().manual_seed(seed + 100)
     B, N = len(n_nodes), max(n_nodes)
@@ -77,7 +79,7 @@ def forward_fixture(ref, cfg_name, n_nodes, seed, fname):
             err = max((d[0] - want[0]).abs().max().item(), (d[1] - want[1]).abs().max().item())
             assert err < 1e-5, "dense oracle vs reference: %g" % err
     np.savez_compressed(os.path.join(OUT, fname), cfg_name=cfg_name, seed=seed, n_nodes=np.array(n_nodes),
-                        xh=xh.numpy(), edge_x=ex.numpy(), noise_level=nl.numpy(),
+                        nf=int(cfg.model.nf), xh=xh.numpy(), edge_x=ex.numpy(), noise_level=nl.numpy(),
                         context=ctx.numpy() if ctx is not None else np.zeros(0, np.float32),
                         out1_x=r1[0].numpy(), out1_e=r1[1].numpy(), out2_x=r2[0].numpy(), out2_e=r2[1].numpy())
     print(fname, 'ok; |out| =', r2[0].abs().max().item(), r2[1].abs().max().item())
@@ -183,6 +185,7 @@ def main():
     forward_fixture(ref, 'vpsde_qm9_uncond_jodo', [3, 5, 9, 12, 17, 29], 11, 'fwd_qm9.npz')
     forward_fixture(ref, 'vpsde_geom_uncond_jodo', [5, 23, 44, 61], 12, 'fwd_geom.npz')
     forward_fixture(ref, 'vpsde_qm9_cond_jodo', [4, 9, 18, 18, 27], 13, 'fwd_cond.npz')
+    forward_fixture(ref, 'vpsde_geom_uncond_jodo', [5, 23, 44], 14, 'fwd_geom384.npz', nf=384)    # BASELINE config 4 width
     ancestral_fixture(ref, 'traj_qm9_anc5.npz')
     dpm_fixture(ref, 'traj_cond_dpm4.npz')
 

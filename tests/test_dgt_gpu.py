@@ -33,10 +33,17 @@ def run(model, xh, ex, nl, nm, em, cx=None, cex=None, ctx=None):
     return out[0].cpu(), out[1].cpu()
 
 
-@pytest.mark.parametrize("fname", ["fwd_qm9.npz", "fwd_geom.npz", "fwd_cond.npz"])
-def test_hip_matches_reference_fixture(fname):
+# layout 'wide' = the width-generic kernel set (csrc/dgt_kernels_wide.h); it is the only set at nf = 384 and
+# is pinned at nf = 256 against the same reference fixtures as the tuned kernels
+@pytest.mark.parametrize("fname,layout", [("fwd_qm9.npz", "auto"), ("fwd_geom.npz", "auto"), ("fwd_cond.npz", "auto"),
+                                          ("fwd_geom384.npz", "auto"),
+                                          ("fwd_qm9.npz", "wide"), ("fwd_geom.npz", "wide"), ("fwd_cond.npz", "wide")])
+def test_hip_matches_reference_fixture(fname, layout):
     fx = load_fixture(fname)
-    cfg = make_config(str(fx['cfg_name']))
+    over = dict(kernel_layout=layout)
+    if 'nf' in fx:
+        over['nf'] = int(fx['nf'])
+    cfg = make_config(str(fx['cfg_name']), **over)
     model = make_model(cfg, int(fx['seed']), DEV)
     hp = O.Hyper.from_config(cfg)
     nm, em = masks(fx['n_nodes'].tolist())
@@ -51,14 +58,18 @@ def test_hip_matches_reference_fixture(fname):
     assert model.last_flags.cpu().tolist()[0] == 0          # NaN guard did not fire
 
 
-@pytest.mark.parametrize("cfg_name,n_nodes,gain,chunk", [
-    ('vpsde_qm9_uncond_jodo', [29, 1, 2, 18, 18, 7, 23], 1.0, 0),
-    ('vpsde_qm9_uncond_jodo', [5] * 40 + [19] * 30, 1.5, 3),      # multi-strip, odd chunking, larger activations
-    ('vpsde_geom_uncond_jodo', [70, 33, 12], 1.5, 16),
-    ('vpsde_qm9_cond_jodo', [9, 9, 14], 1.0, 5),
+@pytest.mark.parametrize("cfg_name,n_nodes,gain,chunk,over", [
+    ('vpsde_qm9_uncond_jodo', [29, 1, 2, 18, 18, 7, 23], 1.0, 0, {}),
+    ('vpsde_qm9_uncond_jodo', [5] * 40 + [19] * 30, 1.5, 3, {}),      # multi-strip, odd chunking, larger activations
+    ('vpsde_geom_uncond_jodo', [70, 33, 12], 1.5, 16, {}),
+    ('vpsde_qm9_cond_jodo', [9, 9, 14], 1.0, 5, {}),
+    ('vpsde_geom_uncond_jodo', [70, 33, 12, 1, 2], 1.5, 0, dict(nf=384)),               # BASELINE config 4 width
+    ('vpsde_geom_uncond_jodo', [19] * 25 + [6] * 30, 1.0, 5, dict(nf=384, n_layers=8, mlp_ratio=2)),
+    ('vpsde_qm9_cond_jodo', [9, 9, 14], 1.0, 5, dict(nf=384)),
+    ('vpsde_qm9_uncond_jodo', [29, 1, 2, 18, 18, 7, 23], 1.5, 3, dict(kernel_layout='wide')),
 ])
-def test_hip_matches_oracle(cfg_name, n_nodes, gain, chunk):
-    cfg = make_config(cfg_name)
+def test_hip_matches_oracle(cfg_name, n_nodes, gain, chunk, over):
+    cfg = make_config(cfg_name, **over)
     model = make_model(cfg, 5, DEV, gain=gain, coord_scale=0.05)
     model.max_chunk = chunk
     hp = O.Hyper.from_config(cfg)

@@ -36,7 +36,7 @@ def test_create_model_exposes_dataparallel_keys():
 
 
 def test_unsupported_settings_fail_loudly():
-    for key, val in (('dist_gbf', False), ('cond_time', False), ('pred_data', False), ('nf', 384), ('n_layers', 4)):
+    for key, val in (('dist_gbf', False), ('cond_time', False), ('pred_data', False), ('nf', 512), ('n_layers', 4)):
         cfg = configs.get('vpsde_qm9_uncond_jodo')
         cfg.model[key] = val
         with pytest.raises(NotImplementedError):

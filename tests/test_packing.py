@@ -41,7 +41,7 @@ class _Cfg(ctypes.Structure):
     _fields_ = [('nf', ctypes.c_int32), ('n_layers', ctypes.c_int32), ('n_heads', ctypes.c_int32),
                 ('n_extra', ctypes.c_int32), ('mlp_ratio', ctypes.c_int32), ('in_node_dim', ctypes.c_int32),
                 ('edge_ch', ctypes.c_int32), ('cond_ch', ctypes.c_int32),
-                ('spatial_cut_off', ctypes.c_float), ('edge_quan_th', ctypes.c_float)]
+                ('spatial_cut_off', ctypes.c_float), ('edge_quan_th', ctypes.c_float), ('layout', ctypes.c_int32)]
 
 
 def _plan(n_nodes, N=None, cfg=None, chunk=0):
@@ -70,8 +70,13 @@ def test_plan_statistics_and_errors():
     assert rc < 0 and b'n_nodes' in lib2.jodo_last_error()
     _, rc, _ = _plan([3, 40], N=29)
     assert rc < 0
-    _, rc, _ = _plan([5, 6], cfg=_Cfg(384, 10, 16, 2, 4, 17, 3, 0, 3.0, 0.0))
-    assert rc < 0 and b'nf=384' in capi.lib().jodo_last_error()
+    _, rc, _ = _plan([5, 6], cfg=_Cfg(512, 10, 16, 2, 4, 17, 3, 0, 3.0, 0.0))
+    assert rc < 0 and b'nf=512' in capi.lib().jodo_last_error()
+    lib3, rc, h3 = _plan([5, 6], cfg=_Cfg(384, 10, 16, 2, 4, 17, 3, 0, 3.0, 0.0))     # BASELINE config 4 width
+    assert rc == 0
+    lib3.jodo_plan_mod_len.restype = ctypes.c_int64
+    assert lib3.jodo_plan_mod_len(h3) == ModelDims(384, 10, 16, 2, 4, 17, 3).Mtot
+    lib3.jodo_plan_destroy(h3)
 
 
 def test_small_and_qk_maps_are_bijections():
@@ -82,3 +87,12 @@ def test_small_and_qk_maps_are_bijections():
     assert sorted(m[m >= 0].tolist()) == list(range(12))
     d = ModelDims(256, 10, 16, 2, 4, 17, 3)
     assert (d.KNH, d.KEH, d.QKP, d.ndp) == (896, 224, 256, 40)
+    for sc in (18, 27):
+        m = P.qk_out_map_wide(14, sc)
+        assert m.shape == (14, 2, 16)
+        flat = m.reshape(-1)
+        assert sorted(flat[flat >= 0].tolist()) == list(range(14 * sc))
+        assert all(set((m[g][m[g] >= 0] // sc).tolist()) == {g} for g in range(14))    # head g lives in block g
+    w = ModelDims(384, 10, 16, 2, 4, 17, 3)
+    assert w.wide and (w.De, w.T, w.SC, w.C, w.QKP, w.cnp, w.cep, w.KNH, w.KEH) == (96, 1536, 27, 24, 448, 96, 32, 1344, 416)
+    assert ModelDims(256, 8, 16, 2, 2, 6, 2, wide=True).QKP == 448 and not ModelDims(256, 8, 16, 2, 2, 6, 2).wide
