@@ -189,17 +189,16 @@ def main():
         elapsed = tt.item()
     step_s = elapsed / args.steps
 
-    # not timed: finish the round's host side once so the whole path is exercised (decode + gather)
+    # not timed: finish the round's host side once so the whole path is exercised (device decode + gather)
+    from jodo_amd import fused
     with torch.no_grad():
-        inv = get_data_inverse_scaler(cfg)
-        pos, one_hot, fc, et = post_process(st['x_mean'], cfg.data.atom_types, cfg.model.include_fc_charge, node_mask,
-                                            inv, st['edge_x_mean'], edge_mask, cfg.data.compress_edge)
+        pos, at, fc, et = fused.decode(cfg, st['x_mean'], st['edge_x_mean'], fused.n_nodes_from_mask(node_mask))
     if world > 1:
         from jodo_amd.dist import gather_molecules
-        gathered = gather_molecules(pos, one_hot.argmax(2), fc[..., 0], et, torch.tensor(n_nodes, device=dev))
+        gathered = gather_molecules(pos, at, fc, et, torch.tensor(n_nodes, device=dev))
         n_total = gathered['n_nodes'].numel() if rank == 0 else 0
     else:
-        n_total = len(mol_process(one_hot, pos, fc, n_nodes, et))
+        n_total = len(fused.mols_from_decoded(pos, at, fc, et, n_nodes))
     nan_fired = model.nan_guard_fired()
 
     if rank == 0:

@@ -134,6 +134,28 @@ enum jodo_prof_class {
 int jodo_profile_enable(jodo_plan* plan, int enable);
 int jodo_profile_read(jodo_plan* plan, float* ms_sum, int32_t* launches);
 
+/* ---- caller-side kernels of the sampling loop ---------------------------
+ * jodo_sampler_step  <- the update of AncestralSampler.sampling, sampling.py:536-589, with the noise
+ *                       construction of models/utils.py:67-99 folded in:
+ *                         mean = c_x * x + c_pred * pred;  next = mean + sigma * eps   (nodes and edges)
+ *                       eps_pos [B,N,3], eps_feat [B,N,node_feats-3], eps_edge [B,edge_ch,N,N] are RAW
+ *                       N(0,1) draws in the reference's shapes and draw order; masking, centre-of-mass
+ *                       removal (positions) and lower-triangle mirroring (edges) happen in the kernel.
+ *                       c_x, c_pred, sigma: posterior coefficients of the step (host scalars).
+ *                       n_nodes_dev: int32[B] atom counts (prefix masks).  All outputs fully written.
+ * jodo_decode        <- post_process sampling.py:53-97 + inverse scaler utils.py:71-105 + the
+ *                       per-molecule slicing inputs of mol_process :12-32: positions [B,N,3] f32,
+ *                       atom type [B,N] u8 (argmax), formal charge [B,N] i8 (round), bond type [B,N,N] u8
+ *                       (compress_edge thresholds, or argmax+1 where any channel > 0.5); zeros on padding. */
+int jodo_sampler_step(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, float c_x, float c_pred,
+                      float sigma, const float* x, const float* edge_x, const float* pred, const float* edge_pred,
+                      const float* eps_pos, const float* eps_feat, const float* eps_edge, float* x_next,
+                      float* edge_next, float* x_mean, float* edge_mean, void* stream);
+int jodo_decode(int B, int N, int atom_types, int include_fc, int edge_ch, int compress_edge, int centered,
+                float pos_norm, float atom_norm, float fc_norm, float edge_norm, const int32_t* n_nodes_dev,
+                const float* xh, const float* edge_x, float* pos_out, uint8_t* atom_type_out, int8_t* fc_out,
+                uint8_t* edge_type_out, void* stream);
+
 const char* jodo_last_error(void);
 
 int jodo_debug_mlp(const float* x, int rows, const float* w1, const float* b1, const float* w2,

@@ -1,0 +1,191 @@
+// Fused caller-side kernels of the sampling loop: HBM-bound elementwise
+// work on the dense API tensors, one pass each instead of ~25 small framework launches per step.
+//
+//   jodo_sampler_step   the ancestral update of AncestralSampler.sampling (sampling.py:536-589):
+//                         mean = c_x * x_t + c_pred * pred          (nodes and edges)
+//                         x_s  = mean + sigma * eps
+//                       with eps built from raw N(0,1) draws exactly as the reference's noise samplers do
+//                       (models/utils.py:67-99): node noise masked, its 3 position channels made
+//                       centre-of-mass free per molecule; edge noise = strict lower triangle of a
+//                       [B,ch,N,N] draw mirrored to the upper triangle, masked, diagonal zero.
+//   jodo_decode         post_process + the per-molecule part of mol_process (sampling.py:53-97, :12-32,
+//                       utils.py:71-105): undo the normalisation, atom type = argmax, formal charge =
+//                       round, bond order by thresholds; compact u8/i8 outputs for ONE device->host copy.
+//
+// Both take the atom counts as a device int32[B] (masks are prefix masks, sampling.py:193-201); all
+// tensors are the reference's dense row-major layouts.  Coalescing: one thread per innermost element,
+// consecutive threads walk the contiguous last dimensions.
+#include <hip/hip_runtime.h>
+#include "../../include/jodo_hip.h"
+#include "jodo_hip_internal.h"
+
+namespace {
+
+// one workgroup per molecule: mean / next state of the node tensor [N, F] (F = 3 + nd)
+__global__ __launch_bounds__(256) void k_step_nodes(int N, int F, const int* __restrict__ n_nodes, float c_x, float c_pred,
+                                                    float sigma, const float* __restrict__ x, const float* __restrict__ pred,
+                                                    const float* __restrict__ eps_pos, const float* __restrict__ eps_feat,
+                                                    float* __restrict__ x_next, float* __restrict__ x_mean) {
+    const int b = blockIdx.x, n = n_nodes[b], nd = F - 3;
+    __shared__ float red[3][256];
+    // centre of mass of the masked position noise: sum over real atoms / n  (remove_mean_with_mask)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float* e = eps_pos + ((size_t)b * N + i) * 3;
+        s0 += e[0]; s1 += e[1]; s2 += e[2];
+    }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+            red[2][threadIdx.x] += red[2][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    const float inv = 1.f / (float)n;
+    const float m[3] = {red[0][0] * inv, red[1][0] * inv, red[2][0] * inv};
+    for (int idx = threadIdx.x; idx < N * F; idx += blockDim.x) {
+        const int i = idx / F, f = idx % F;
+        const size_t g = (size_t)b * N * F + idx;
+        // products rounded separately, then added: the op order of the framework expression c_x*x + c_pred*pred
+        const float mean = __fadd_rn(__fmul_rn(c_x, x[g]), __fmul_rn(c_pred, pred[g]));
+        float e = 0.f;
+        if (i < n) e = f < 3 ? eps_pos[((size_t)b * N + i) * 3 + f] - m[f] : eps_feat[((size_t)b * N + i) * nd + (f - 3)];
+        x_mean[g] = mean;
+        x_next[g] = __fadd_rn(mean, __fmul_rn(sigma, e));
+    }
+}
+
+// one thread per (b, a, c, f) of the edge tensor [B, N, N, ch]; eps_edge is the raw draw [B, ch, N, N]
+__global__ __launch_bounds__(256) void k_step_edges(int B, int N, int ch, const int* __restrict__ n_nodes, float c_x, float c_pred,
+                                                    float sigma, const float* __restrict__ ex, const float* __restrict__ epred,
+                                                    const float* __restrict__ eps, float* __restrict__ e_next,
+                                                    float* __restrict__ e_mean) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t NN = (size_t)N * N, tot = (size_t)B * NN * ch;
+    if (g >= tot) return;
+    const int f = (int)(g % ch);
+    const size_t cell = g / ch;
+    const int c = (int)(cell % N), a = (int)((cell / N) % N), b = (int)(cell / NN);
+    const int n = n_nodes[b];
+    const float mean = __fadd_rn(__fmul_rn(c_x, ex[g]), __fmul_rn(c_pred, epred[g]));
+    float e = 0.f;
+    if (a < n && c < n && a != c) {
+        const int lo = a > c ? a : c, hi = a > c ? c : a;          // strict lower triangle entry (row lo, col hi)
+        e = eps[(((size_t)b * ch + f) * N + lo) * N + hi];
+    }
+    e_mean[g] = mean;
+    e_next[g] = __fadd_rn(mean, __fmul_rn(sigma, e));
+}
+
+struct DecodeArgs {
+    int B, N, atom_types, include_fc, ch, compress_edge, centered;
+    float pos_norm, atom_norm, fc_norm, edge_norm;
+};
+
+// one thread per (b, i): positions, atom type, formal charge
+__global__ __launch_bounds__(256) void k_decode_nodes(DecodeArgs A, const int* __restrict__ n_nodes, const float* __restrict__ xh,
+                                                      float* __restrict__ pos, uint8_t* __restrict__ atom_type,
+                                                      int8_t* __restrict__ fc) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= A.B * A.N) return;
+    const int b = idx / A.N, i = idx % A.N;
+    const int F = 3 + A.atom_types + (A.include_fc ? 1 : 0);
+    const float* r = xh + (size_t)idx * F;
+    const bool real = i < n_nodes[b];
+    float* p = pos + (size_t)idx * 3;
+    for (int k = 0; k < 3; ++k) p[k] = real ? r[k] * A.pos_norm : 0.f;
+    // argmax over the inverse-scaled categories (an increasing affine map: same argmax; first maximum wins)
+    int best = 0;
+    float bv = -INFINITY;
+    for (int k = 0; k < A.atom_types; ++k) {
+        float v = r[3 + k] * A.atom_norm;
+        if (A.centered) v = (v + 1.f) / 2.f;
+        if (!real) v = 0.f;
+        if (v > bv) { bv = v; best = k; }
+    }
+    atom_type[idx] = (uint8_t)best;
+    float q = 0.f;
+    if (A.include_fc && real) q = rintf(r[F - 1] * A.fc_norm);       // torch.round = round-half-to-even
+    fc[idx] = (int8_t)q;
+}
+
+// one thread per (b, a, c): bond type
+__global__ __launch_bounds__(256) void k_decode_edges(DecodeArgs A, const int* __restrict__ n_nodes, const float* __restrict__ ex,
+                                                      uint8_t* __restrict__ edge_type) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t NN = (size_t)A.N * A.N;
+    if (idx >= (size_t)A.B * NN) return;
+    const int b = (int)(idx / NN), a = (int)((idx % NN) / A.N), c = (int)(idx % A.N);
+    const int n = n_nodes[b];
+    const bool real = a < n && c < n && a != c;
+    const float* r = ex + idx * A.ch;
+    float h[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < A.ch && k < 4; ++k) {
+        float v = r[k] * A.edge_norm;
+        if (A.centered) v = (v + 1.f) / 2.f;
+        h[k] = real ? v : 0.f;
+    }
+    int t = 0;
+    if (A.compress_edge) {
+        const bool exist = h[0] >= 0.5f;
+        const float o = h[1] * 3.f;
+        int order = 0;
+        if (o >= 0.5f) order = 1;
+        if (o >= 1.5f) order = 2;
+        if (o >= 2.5f) order = 3;
+        t = exist ? order : 0;
+        if (A.ch == 3 && exist && h[2] >= 0.5f && t == 0) t = 4;
+    } else {
+        bool any = false;
+        int best = 0;
+        float bv = -INFINITY;
+        for (int k = 0; k < A.ch && k < 4; ++k) {
+            any |= h[k] > 0.5f;
+            if (h[k] > bv) { bv = h[k]; best = k; }
+        }
+        t = any ? best + 1 : 0;
+    }
+    edge_type[idx] = (uint8_t)t;
+}
+
+}  // namespace
+
+extern "C" int jodo_sampler_step(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, float c_x, float c_pred,
+                                 float sigma, const float* x, const float* edge_x, const float* pred, const float* edge_pred,
+                                 const float* eps_pos, const float* eps_feat, const float* eps_edge, float* x_next,
+                                 float* edge_next, float* x_mean, float* edge_mean, void* stream) {
+    if (B <= 0 || N <= 0 || node_feats < 4 || edge_ch < 1) return jodo_set_error(JODO_ERR_ARG, "sampler_step: bad shape");
+    if (!n_nodes_dev || !x || !edge_x || !pred || !edge_pred || !eps_pos || !eps_feat || !eps_edge || !x_next || !edge_next ||
+        !x_mean || !edge_mean)
+        return jodo_set_error(JODO_ERR_ARG, "sampler_step: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_step_nodes, dim3(B), dim3(256), 0, st, N, node_feats, n_nodes_dev, c_x, c_pred, sigma, x, pred, eps_pos,
+                       eps_feat, x_next, x_mean);
+    int rc = jodo_check_launch("k_step_nodes");
+    if (rc != JODO_OK) return rc;
+    const size_t tot = (size_t)B * N * N * edge_ch;
+    hipLaunchKernelGGL(k_step_edges, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, N, edge_ch, n_nodes_dev, c_x, c_pred,
+                       sigma, edge_x, edge_pred, eps_edge, edge_next, edge_mean);
+    return jodo_check_launch("k_step_edges");
+}
+
+extern "C" int jodo_decode(int B, int N, int atom_types, int include_fc, int edge_ch, int compress_edge, int centered,
+                           float pos_norm, float atom_norm, float fc_norm, float edge_norm, const int32_t* n_nodes_dev,
+                           const float* xh, const float* edge_x, float* pos_out, uint8_t* atom_type_out, int8_t* fc_out,
+                           uint8_t* edge_type_out, void* stream) {
+    if (B <= 0 || N <= 0 || atom_types < 1 || atom_types > 255 || edge_ch < 1 || edge_ch > 4)
+        return jodo_set_error(JODO_ERR_ARG, "decode: bad shape");
+    if (!n_nodes_dev || !xh || !edge_x || !pos_out || !atom_type_out || !fc_out || !edge_type_out)
+        return jodo_set_error(JODO_ERR_ARG, "decode: null argument");
+    DecodeArgs A{B, N, atom_types, include_fc, edge_ch, compress_edge, centered, pos_norm, atom_norm, fc_norm, edge_norm};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_decode_nodes, dim3((B * N + 255) / 256), dim3(256), 0, st, A, n_nodes_dev, xh, pos_out, atom_type_out, fc_out);
+    int rc = jodo_check_launch("k_decode_nodes");
+    if (rc != JODO_OK) return rc;
+    const size_t tot = (size_t)B * N * N;
+    hipLaunchKernelGGL(k_decode_edges, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, A, n_nodes_dev, edge_x, edge_type_out);
+    return jodo_check_launch("k_decode_edges");
+}

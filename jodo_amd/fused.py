@@ -1,0 +1,96 @@
+"""Python plumbing for the caller-side HIP kernels (csrc/sampler_kernels.hip): the fused ancestral update
+and the fused decode.  Device tensors in, device tensors out; raises (no CPU fallback) on CPU tensors —
+the callers in sampling.py pick the framework path themselves when they run on the CPU (host-logic tests).
+"""
+import ctypes
+
+import torch
+
+from . import capi
+from .utils import _norm_factors
+
+
+def _f32c(t, name):
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise TypeError("%s must be a float32 GPU tensor" % name)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def n_nodes_from_mask(node_mask):
+    """int32 [B] atom counts on the mask's device (masks are prefix masks, sampling.py:193-201)."""
+    B = node_mask.shape[0]
+    return node_mask.reshape(B, -1).sum(1).round().to(torch.int32).contiguous()
+
+
+class StepBuffers:
+    """Ping-pong state buffers of one sampling round (allocated once, reused every step)."""
+
+    def __init__(self, x, edge_x):
+        # explicit row-major buffers: empty_like would inherit the permuted strides of the reference's
+        # edge-noise expression (z.permute(0, 2, 3, 1) * mask), which the kernels do not follow
+        new = lambda t: torch.empty(t.shape, dtype=torch.float32, device=t.device)
+        self.x = [new(x), new(x)]
+        self.e = [new(edge_x), new(edge_x)]
+        self.x_mean = new(x)
+        self.e_mean = new(edge_x)
+        self.cur = 0
+
+
+def sampler_step(bufs, n_nodes_dev, c_x, c_pred, sigma, x, edge_x, pred, edge_pred, eps_pos, eps_feat, eps_edge):
+    """x_mean = c_x x + c_pred pred; x_next = x_mean + sigma * eps (both tensors), eps from RAW normal draws
+    in the reference's shapes (see include/jodo_hip.h).  Returns (x_next, edge_next, x_mean, edge_mean);
+    the returned tensors live in `bufs` and stay valid until the call after next."""
+    B, N, F = x.shape
+    ch = edge_x.shape[-1]
+    x, edge_x = _f32c(x, 'x'), _f32c(edge_x, 'edge_x')
+    pred, edge_pred = _f32c(pred, 'pred'), _f32c(edge_pred, 'edge_pred')
+    eps_pos, eps_feat, eps_edge = _f32c(eps_pos, 'eps_pos'), _f32c(eps_feat, 'eps_feat'), _f32c(eps_edge, 'eps_edge')
+    if eps_pos.shape != (B, N, 3) or eps_feat.shape != (B, N, F - 3) or eps_edge.shape != (B, ch, N, N):
+        raise ValueError("noise draws must have the reference's shapes [B,N,3], [B,N,nd], [B,ch,N,N]")
+    nxt = bufs.cur ^ 1
+    xn, en = bufs.x[nxt], bufs.e[nxt]
+    if xn.data_ptr() == x.data_ptr() or en.data_ptr() == edge_x.data_ptr():
+        raise RuntimeError("sampler_step: output buffer aliases the input state")
+    capi.check(capi.lib().jodo_sampler_step(
+        B, N, F, ch, capi.ptr(n_nodes_dev), ctypes.c_float(float(c_x)), ctypes.c_float(float(c_pred)),
+        ctypes.c_float(float(sigma)), capi.ptr(x), capi.ptr(edge_x), capi.ptr(pred), capi.ptr(edge_pred),
+        capi.ptr(eps_pos), capi.ptr(eps_feat), capi.ptr(eps_edge), capi.ptr(xn), capi.ptr(en),
+        capi.ptr(bufs.x_mean), capi.ptr(bufs.e_mean), capi.current_stream_ptr()), 'jodo_sampler_step')
+    bufs.cur = nxt
+    return xn, en, bufs.x_mean, bufs.e_mean
+
+
+def decode(config, xh, edge_x, n_nodes_dev):
+    """post_process + inverse scaling on the device.  Returns compact device tensors
+    (pos f32 [B,N,3], atom_type u8 [B,N], fc i8 [B,N], edge_type u8 [B,N,N])."""
+    xh, edge_x = _f32c(xh, 'xh'), _f32c(edge_x, 'edge_x')
+    B, N, F = xh.shape
+    atom_types = int(config.data.atom_types)
+    include_fc = int(bool(config.model.include_fc_charge))
+    if F != 3 + atom_types + include_fc:
+        raise ValueError("xh has %d features, config says %d" % (F, 3 + atom_types + include_fc))
+    nf = _norm_factors(config)
+    edge_norm = nf[3] if len(nf) > 3 else 1
+    dev = xh.device
+    pos = torch.empty(B, N, 3, device=dev)
+    at = torch.empty(B, N, dtype=torch.uint8, device=dev)
+    fc = torch.empty(B, N, dtype=torch.int8, device=dev)
+    et = torch.empty(B, N, N, dtype=torch.uint8, device=dev)
+    capi.check(capi.lib().jodo_decode(
+        B, N, atom_types, include_fc, int(edge_x.shape[-1]), int(bool(config.data.compress_edge)),
+        int(bool(config.data.centered)), ctypes.c_float(float(nf[0])), ctypes.c_float(float(nf[1])),
+        ctypes.c_float(float(nf[2])), ctypes.c_float(float(edge_norm)), capi.ptr(n_nodes_dev), capi.ptr(xh),
+        capi.ptr(edge_x), capi.ptr(pos), capi.ptr(at), capi.ptr(fc), capi.ptr(et), capi.current_stream_ptr()),
+        'jodo_decode')
+    return pos, at, fc, et
+
+
+def mols_from_decoded(pos, at, fc, et, n_nodes):
+    """One device->host copy per tensor, then per-molecule views in the reference's tuple format
+    (pos[n,3] f32, atom_type[n] i64, edge_type[n,n] f32, fc[n] i64) — sampling.py:12-32."""
+    pos, at, fc, et = pos.cpu(), at.cpu().long(), fc.cpu().long(), et.cpu().float()
+    mols = []
+    for i, n in enumerate(n_nodes):
+        n = int(n)
+        mols.append((pos[i, :n], at[i, :n], et[i, :n, :n], fc[i, :n]))
+    return mols

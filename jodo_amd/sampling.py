@@ -96,7 +96,7 @@ def build_masks(n_nodes, max_n_nodes, device):
 
 
 def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, inverse_scaler, eps=1e-3,
-                    prop_dist=None, shard=None, return_raw=False):
+                    prop_dist=None, shard=None, return_raw=False, fused_decode=True):
     device = config.device
     steps = config.sampling.steps
     atom_types = config.data.atom_types
@@ -141,10 +141,16 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
                 assert_mean_zero_with_mask(z[:, :, :3], node_mask)
                 edge_z = sample_symmetric_edge_feature_noise(bs, max_n, edge_nf, edge_mask)
                 x_node, x_edge = sampler.sampling(model, z, node_mask, edge_mask, edge_z, context)
-                pos, one_hot, fc, edge_types = post_process(x_node, atom_types, include_fc, node_mask,
-                                                            inverse_scaler, x_edge, edge_mask, compress_edge)
-                assert_mean_zero_with_mask(pos, node_mask)
-                mols += mol_process(one_hot, pos, fc, n_nodes, edge_types)
+                if x_node.is_cuda and fused_decode and getattr(inverse_scaler, 'from_config', False):
+                    # device-side decode: compact u8/i8 results, one device->host copy per tensor
+                    from . import fused
+                    dec = fused.decode(config, x_node, x_edge, fused.n_nodes_from_mask(node_mask))
+                    mols += fused.mols_from_decoded(*dec, n_nodes)
+                else:
+                    pos, one_hot, fc, edge_types = post_process(x_node, atom_types, include_fc, node_mask,
+                                                                inverse_scaler, x_edge, edge_mask, compress_edge)
+                    assert_mean_zero_with_mask(pos, node_mask)
+                    mols += mol_process(one_hot, pos, fc, n_nodes, edge_types)
                 if shard is None or shard[0] == 0:
                     print('Generate {}, Total {}.'.format(len(mols), n_samples))
         if return_raw or shard is not None:
@@ -170,8 +176,11 @@ class AncestralSampler:
     """Ancestral sampling for joint 2-D & 3-D generation; returns the noise-free mean of the last step."""
 
     def __init__(self, noise_scheduler, time_steps, model_pred_data, pred_edge=False, self_cond=False,
-                 cond_process_fn=None, noise_fn=None):
+                 cond_process_fn=None, noise_fn=None, fused=True):
         self.noise_scheduler = noise_scheduler
+        # fused: on GPU tensors the update + noise construction run as one HIP kernel per tensor
+        # (csrc/sampler_kernels.hip) instead of ~25 framework launches; same RNG draws in the same order
+        self.fused = fused
         self.t_array = time_steps
         self.s_array = torch.cat([time_steps[1:], torch.zeros(1, device=time_steps.device)])
         self.model_pred_data = model_pred_data
@@ -212,6 +221,19 @@ class AncestralSampler:
         else:
             pred_t, edge_pred_t = model(vec_t, x, node_mask, edge_mask, edge_x=edge_x, noise_level=noise_level,
                                         context=context)
+        if self.fused and x.is_cuda and self.noise_fn is None and self.model_pred_data:
+            from . import fused
+            if st.get('_bufs') is None:
+                st['_bufs'] = fused.StepBuffers(x, edge_x)
+                st['_n_nodes'] = fused.n_nodes_from_mask(node_mask)
+            N, nd, ch = x.shape[1], x.shape[2] - 3, edge_x.shape[-1]
+            eps_pos = torch.randn((bs, N, 3), device=x.device)          # draw order of models/utils.py:67-99
+            eps_feat = torch.randn((bs, N, nd), device=x.device)
+            eps_edge = torch.randn((bs, ch, N, N), device=x.device)
+            st['x'], st['edge_x'], st['x_mean'], st['edge_x_mean'] = fused.sampler_step(
+                st['_bufs'], st['_n_nodes'], float(c_x), float(c_pred), float(sigma), x, edge_x, pred_t, edge_pred_t,
+                eps_pos, eps_feat, eps_edge)
+            return st
         # the coefficients are scalars shared by the batch (the reference broadcasts them through
         # .repeat(bs) + expand_dims, sampling.py:569-589 — same values, same products)
         if self.model_pred_data:

@@ -39,6 +39,7 @@ def get_data_inverse_scaler(config):
         edge_type = edge_type * edge_mask.reshape(node_mask.size(0), n, n, 1)
         return pos, atom_type, fc_charge, edge_type
 
+    inverse_scale_fn.from_config = True       # lets the sampler use the equivalent device-side decode (fused.decode)
     return inverse_scale_fn
 
 
