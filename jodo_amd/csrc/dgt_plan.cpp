@@ -89,7 +89,27 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     // per-item prologue and the per-workgroup LDS weight staging must be amortised)
     int pair_chunk = (max_chunk >> 16) & 0xff, spair_chunk = (max_chunk >> 24) & 0xff;
     max_chunk &= 0xffff;
-    if (max_chunk <= 0) max_chunk = 8;
+    if (max_chunk <= 0) {
+        // automatic: 8 sources per item amortises the per-item prologue, but a small batch then has fewer
+        // items than the chip has SIMDs (1024) and the attention kernels become latency-bound
+        // (QM9 cond B = 313 on MI355X: k_edge_msgs 1.37 -> 0.52 ms/step going from 8 to 2); shrink the
+        // chunk until there are >= 2 items per SIMD
+        int64_t strip_nmax_sum = 0;                       // sum over strips of the largest molecule in the strip
+        {
+            std::vector<int> sorted(n_nodes, n_nodes + B);
+            std::sort(sorted.begin(), sorted.end(), [](int a, int b) { return a > b; });
+            int64_t v = 0;
+            int strip = -1;
+            for (int m = 0; m < B; ++m) {
+                const int first = (int)(v / 32), last = (int)((v + sorted[m] - 1) / 32);
+                for (int s = std::max(first, strip + 1); s <= last; ++s) strip_nmax_sum += sorted[m];   // sizes descend
+                strip = std::max(strip, last);
+                v += sorted[m];
+            }
+        }
+        max_chunk = 8;
+        while (max_chunk > 2 && strip_nmax_sum / max_chunk < 2048) --max_chunk;
+    }
     if (pair_chunk <= 0) pair_chunk = 1;     // measured best on MI355X (QM9 B=2500: 26.7 ms/step vs 27.7 at 2)
     if (spair_chunk <= 0) spair_chunk = pair_chunk;   // sweep on MI355X: 1 and 4 tie, 6 is 35 % slower
     p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->prof_enabled = 0; p->force_directed = p->dims.wide; p->dbg_timing = nullptr;
