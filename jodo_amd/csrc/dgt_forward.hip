@@ -135,13 +135,20 @@ int forward_wide(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, fl
         A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
         { ProfScope ps(p, st, JODO_PROF_NODE_PRE); LAUNCH((wide::k_node_pre<D>), p->n_strips * 3, 64, A); }
         cur ^= 1;
-        if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_SCORES); LAUNCH((wide::k_edge_scores<D>), p->n_items, 64, A); }
+        if (p->n_items > 0) {
+            ProfScope ps(p, st, JODO_PROF_EDGE_SCORES);            // exactly one of the two does the work (device flag)
+            if (p->n_sitems > 0) LAUNCH((wide::k_edge_scores_sym<D>), p->n_sitems, 64, A);
+            LAUNCH((wide::k_edge_scores<D>), p->n_items, 64, A);
+        }
         { ProfScope ps(p, st, JODO_PROF_SOFTMAX); LAUNCH(k_softmax, (p->Nn + 15) / 16, 256, A); }
         if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_MSGS); LAUNCH((wide::k_edge_msgs<D>), p->n_items, 64, A); }
         { ProfScope ps(p, st, JODO_PROF_NODE_POST);
           if (d.r == 2) LAUNCH((wide::k_node_post<D, 2>), p->n_strips, 64, A); else LAUNCH((wide::k_node_post<D, 4>), p->n_strips, 64, A); }
         if (p->n_items > 0) {
             ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);
+            if (p->n_pitems > 0) {
+                if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2>), p->n_pitems, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4>), p->n_pitems, 64, A);
+            }
             if (d.r == 2) LAUNCH((wide::k_edge_update<D, 2>), p->n_items, 64, A); else LAUNCH((wide::k_edge_update<D, 4>), p->n_items, 64, A);
         }
     }

@@ -11,12 +11,12 @@
 //   * a value block no longer coincides with two attention heads (C = 24), so every lane carries all
 //     16 softmax weights and picks per register;
 //   * the node FFN accumulates its D outputs in passes of <= 8 blocks (register budget at D = 384);
-//   * directed kernels only (FLAG_ASYM is forced): the symmetric pair path is an optimisation of the
-//     nf = 256 set (dgt_kernels_sym.h).
+//   * the pair kernels park the shared part of input_lin in private (scratch) memory instead of LDS.
 // Instantiated for D = 384; D = 256 is instantiated too so that the whole set can be pinned against
 // the tuned kernels and the nf = 256 fixtures (jodo_cfg.layout = 1, tests only).
 #pragma once
 #include "dgt_kernels_common.h"
+#include "dgt_kernels_sym.h"
 
 namespace jd {
 namespace wide {
@@ -152,10 +152,19 @@ __global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
     if (piece == 0) {
         float4 p = reinterpret_cast<const float4*>(A.pos_in)[L.v];
         if (A.layer > 0) {
-            const int parts = A.pd.strip_parts[strip];
-            for (int q = 0; q < parts; ++q) {
-                const float4 dp = reinterpret_cast<const float4*>(A.dpos)[(size_t)L.v * A.pd.max_parts + q];
-                p.x += dp.x; p.y += dp.y; p.z += dp.z;
+            if (A.flags[FLAG_ASYM]) {
+                const int parts = A.pd.strip_parts[strip];
+                for (int q = 0; q < parts; ++q) {
+                    const float4 dp = reinterpret_cast<const float4*>(A.dpos)[(size_t)L.v * A.pd.max_parts + q];
+                    p.x += dp.x; p.y += dp.y; p.z += dp.z;
+                }
+            } else {                                       // pair path: one contribution per edge row (i, c)
+                const float4* row = reinterpret_cast<const float4*>(A.dposE) + (size_t)L.eoff + (size_t)L.i * L.n;
+                for (int c = 0; c < L.n; ++c) {
+                    if (c == L.i) continue;
+                    const float4 dp = row[c];
+                    p.x += dp.x; p.y += dp.y; p.z += dp.z;
+                }
             }
         }
         if (half == 0) reinterpret_cast<float4*>(A.pos_out)[L.v] = p;
@@ -322,6 +331,7 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
 // edge side (directed: rows r = eoff + a*n + c, a = source / row atom, c = target / column atom)
 template <int D>
 __global__ __launch_bounds__(64, 1) void k_edge_scores(KArgs A) {
+    if (!A.flags[FLAG_ASYM]) return;                            // symmetric inputs: k_edge_scores_sym runs instead
     using X = Dim<D>;
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
     const int it = blockIdx.x;
@@ -462,6 +472,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_msgs(KArgs A) {
 
 template <int D, int R>
 __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
+    if (!A.flags[FLAG_ASYM]) return;                            // symmetric inputs: k_edge_update_sym runs instead
     using X = Dim<D>;
     constexpr int NCH = R * X::De / 64;                   // edge FFN hidden chunks of 64
     constexpr int KQ4 = R * X::De / 8;                    // quads per ff4 output block
@@ -614,6 +625,280 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
     }
     if (half == 0)
         reinterpret_cast<float4*>(A.dpos)[(size_t)L.v * A.pd.max_parts + part] = make_float4(dax, day, daz, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pair (symmetric-input) variants, see dgt_kernels_sym.h for the enumeration and the argument why the edge
+// state stays exactly symmetric.  Width-generic differences: weights streamed; the symmetric part S of
+// input_lin (D/2 values per lane) waits for direction 1 in PRIVATE memory (a per-lane array indexed with a
+// run-time block number, i.e. hardware scratch, L1/L2-resident) — at D = 384 four waves' slabs (4 x 48 KiB)
+// no longer fit the CU's 160 KiB LDS.
+template <int D>
+__global__ __launch_bounds__(64, 1) void k_edge_scores_sym(KArgs A) {
+    if (A.flags[FLAG_ASYM]) return;
+    using X = Dim<D>;
+    const int lane = threadIdx.x & 63, jl = lane & 31, half = lane >> 5;
+    const int it = blockIdx.x;
+    const int strip = A.pd.sitem_strip[it], t0 = A.pd.sitem_t0[it], t1 = A.pd.sitem_t1[it];
+    const LaneNode L = lane_node(A, strip, jl);
+    const float* mrow = mod_row(A, L.b) + A.mod_base;
+    const float gscale = mrow[X::M_GBF + 0], gshift = mrow[X::M_GBF + 1];
+    const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
+    const WSrc ws = make_wsrc(A.W, lane);
+    const unsigned oEE = (unsigned)(A.wb[JB_EE_W] * 4), oL0 = (unsigned)(A.wb[JB_LE0_W] * 4);
+    WPipe<PG> wp;
+    wpipe_prime(wp, ws, oEE);
+    for (int t = t0; t < t1; ++t) {
+        const PairLane P = pair_of(L, t + 1);
+        const float* es1 = launder(mrow + X::M_EDGE);
+        const float* ec1 = es1 + X::De;
+        const float* cst = launder(A.W);
+        const float* tab = cst + A.wb[JB_GBF];
+        const float* bEE = cst + A.wb[JB_EE_B];
+        TRow qi = trow(A.q, NHEAD_BLOCKS, L.v, half), ki = trow(A.k, NHEAD_BLOCKS, L.v, half);
+        qi.p = launder(qi.p); ki.p = launder(ki.p);
+        const TRow qj = trow(A.q, NHEAD_BLOCKS, P.u, half), kj = trow(A.k, NHEAD_BLOCKS, P.u, half);
+        const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[P.u];
+        const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
+        float x[X::HE];
+        {
+            float G[X::HE], e[X::HE];
+            gbf<X::NE>(dx * dx + dy * dy + dz * dz, gscale, gshift, tab, half, G);
+            load_nat<X::NE>(A.e + P.rij * X::De, half, e);
+#pragma unroll
+            for (int b = 0; b < X::NE; ++b) {
+                const unsigned cg = oEE + (unsigned)(b * 2 * X::KQE) * 1024, ce = cg + X::KQE * 1024;
+                float bb[16];
+                load16(bEE + b * 32 + half * 16, bb);
+                f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cg, ce, G, zero16());
+                acc = mfma_block_p<X::KQE>(wp, ws, ce, b + 1 < X::NE ? ce + X::KQE * 1024 : oL0, e, acc);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) x[b * 16 + s] = acc[s] + bb[s];
+            }
+        }
+        layer_norm<X::HE>(x);
+        modulate<X::NE>(x, es1, ec1, half);
+        if (P.ok) {
+            store_nat<X::NE>(A.et + P.rij * X::De, half, x);
+            store_nat<X::NE>(A.et + P.rji * X::De, half, x);
+        }
+        // tanh(lin_edge0) once; direction 1 = edge (j -> i): q_i . k_j ; direction 2 = edge (i -> j): q_j . k_i
+        float Sg1[NHEAD_BLOCKS], Sg2[NHEAD_BLOCKS];
+        float qin[16], kin[16], qjn[16], kjn[16];
+        load16T(qi, 0, qin); load16T(ki, 0, kin);
+        load16T(qj, 0, qjn); load16T(kj, 0, kjn);
+#pragma unroll
+        for (int g = 0; g < NHEAD_BLOCKS; ++g) {
+            float a1[16], a2[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { a1[s] = qin[s] * kjn[s]; a2[s] = qjn[s] * kin[s]; }
+            if (g + 1 < NHEAD_BLOCKS) {
+                load16T(qi, g + 1, qin); load16T(ki, g + 1, kin);
+                load16T(qj, g + 1, qjn); load16T(kj, g + 1, kjn);
+            }
+            const unsigned cur = oL0 + (unsigned)(g * X::KQE) * 1024;
+            f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cur, g + 1 < NHEAD_BLOCKS ? cur + X::KQE * 1024 : oEE, x, zero16());
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float tt = tanh_f(acc[s]);
+                s1 = fmaf(tt, a1[s], s1);
+                s2 = fmaf(tt, a2[s], s2);
+            }
+            Sg1[g] = s1; Sg2[g] = s2;
+        }
+        const int f1 = A.eflag[P.rji], f2 = A.eflag[P.rij];
+#pragma unroll
+        for (int g = 0; g < NHEAD_BLOCKS; ++g) {
+            Sg1[g] = pair_sum(Sg1[g]) * X::INV_SQRT_C;
+            Sg2[g] = pair_sum(Sg2[g]) * X::INV_SQRT_C;
+        }
+        float S1[8], S2[8];                                // slot b of this half = head 2b + half
+        S1[0] = half == 0 ? ((f1 & 1) ? 1.f : -1e10f) : ((f1 & 2) ? 1.f : -1e10f);
+        S2[0] = half == 0 ? ((f2 & 1) ? 1.f : -1e10f) : ((f2 & 2) ? 1.f : -1e10f);
+#pragma unroll
+        for (int b = 1; b < 8; ++b) {
+            S1[b] = half == 0 ? Sg1[2 * (b - 1)] : Sg1[2 * (b - 1) + 1];
+            S2[b] = half == 0 ? Sg2[2 * (b - 1)] : Sg2[2 * (b - 1) + 1];
+        }
+        if (P.ok) {
+            float4* sp = reinterpret_cast<float4*>(A.S + P.rji * 16 + half * 8);      // edge (j -> i)
+            sp[0] = make_float4(S1[0], S1[1], S1[2], S1[3]);
+            sp[1] = make_float4(S1[4], S1[5], S1[6], S1[7]);
+            float4* sq = reinterpret_cast<float4*>(A.S + P.rij * 16 + half * 8);      // edge (i -> j)
+            sq[0] = make_float4(S2[0], S2[1], S2[2], S2[3]);
+            sq[1] = make_float4(S2[4], S2[5], S2[6], S2[7]);
+        }
+    }
+}
+
+template <int D, int R>
+__global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
+    if (A.flags[FLAG_ASYM]) return;
+    using X = Dim<D>;
+    constexpr int NCH = R * X::De / 64;
+    constexpr int KQ4 = R * X::De / 8;
+    const int lane = threadIdx.x & 63, jl = lane & 31, half = lane >> 5;
+    const int it = blockIdx.x;
+    const int strip = A.pd.pitem_strip[it], t0 = A.pd.pitem_t0[it], t1 = A.pd.pitem_t1[it];
+    const LaneNode L = lane_node(A, strip, jl);
+    const float* mrow = mod_row(A, L.b) + A.mod_base;
+    const float* eg1 = mrow + X::M_EDGE + 2 * X::De;
+    const float* qsh = mrow + X::M_EQUI;
+    const float gscale = mrow[X::M_GBF + 0], gshift = mrow[X::M_GBF + 1];
+    const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
+    const float cscale = A.W[A.wb[JB_CSCALE]];
+    const WSrc ws = make_wsrc(A.W, lane);
+    const unsigned o3 = (unsigned)(A.wb[JB_FF3_W] * 4), o4 = (unsigned)(A.wb[JB_FF4_W] * 4);
+    const unsigned oro = (unsigned)(A.wb[JB_ERO_W] * 4), oi = (unsigned)(A.wb[JB_INE_W] * 4), o0 = (unsigned)(A.wb[JB_C0_W] * 4);
+    WPipe<PG> wp;
+    wpipe_prime(wp, ws, o3);
+    float park[X::HD];                                      // S, then u of direction 1: private (scratch) memory
+    for (int t = t0; t < t1; ++t) {
+        const PairLane P = pair_of(L, t + 1);
+        const float* eg1_ = launder(eg1);
+        const float* es2_ = eg1_ + X::De, *ec2_ = es2_ + X::De, *eg2_ = ec2_ + X::De;
+        const float* qsh_ = launder(qsh);
+        const float* qsc_ = qsh_ + D;
+        const float* cst = launder(A.W);
+        const float* n2bias_ = cst + A.wb[JB_N2E_B], *b3_ = cst + A.wb[JB_FF3_B], *b4_ = cst + A.wb[JB_FF4_B];
+        const float* b0_ = cst + A.wb[JB_C0_B], *w2_ = cst + A.wb[JB_C2_W], *tab_ = cst + A.wb[JB_GBF];
+        const float* bro_ = cst + A.wb[JB_ERO_B];
+        TRow wrow_i = trow(A.wrow, X::ND, L.v, half), wcol_i = trow(A.wcol, X::ND, L.v, half);
+        wrow_i.p = launder(wrow_i.p); wcol_i.p = launder(wcol_i.p);
+        const TRow wrow_j = trow(A.wrow, X::ND, P.u, half), wcol_j = trow(A.wcol, X::ND, P.u, half);
+        const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[P.u];
+        const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        float G[X::HE];
+        gbf<X::NE>(d2, gscale, gshift, tab_, half, G);
+        // ---- edge residual + LN2 + modulate (symmetric) ----
+        float en[X::HE];
+        {
+            const TRow ra = trow(A.n2e, X::NE, L.v, half), rc = trow(A.n2e, X::NE, P.u, half);
+#pragma unroll
+            for (int b = 0; b < X::NE; ++b) {
+                float e[16], ta[16], tc2[16], g[16], bb[16];
+                load16(A.e + P.rij * X::De + b * 32 + half * 16, e);
+                load16T(ra, b, ta);
+                load16T(rc, b, tc2);
+                load16(eg1_ + b * 32 + half * 16, g);
+                load16(n2bias_ + b * 32 + half * 16, bb);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) en[b * 16 + s] = fmaf(g[s], ta[s] + tc2[s] + bb[s], e[s]);
+            }
+        }
+        layer_norm<X::HE>(en);
+        modulate<X::NE>(en, es2_, ec2_, half);
+        // ---- edge FFN ----
+        {
+            f32x16 o[X::NE];
+#pragma unroll
+            for (int b = 0; b < X::NE; ++b) o[b] = zero16();
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                float hid[32];
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    const unsigned wcur = o3 + (unsigned)(c * 2 + b2) * X::KQE * 1024;
+                    const unsigned wnx = b2 == 0 ? wcur + X::KQE * 1024 : o4 + (unsigned)(c * 8) * 1024;
+                    float bb[16];
+                    load16(b3_ + (c * 2 + b2) * 32 + half * 16, bb);
+                    f32x16 acc = mfma_block_p<X::KQE>(wp, ws, wcur, wnx, en, zero16());
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(acc[s] + bb[s]);
+                }
+#pragma unroll
+                for (int ob = 0; ob < X::NE; ++ob) {
+                    const unsigned wcur = o4 + (unsigned)(ob * KQ4 + c * 8) * 1024;
+                    const unsigned wnx = ob + 1 < X::NE ? o4 + (unsigned)((ob + 1) * KQ4 + c * 8) * 1024
+                                                        : (c + 1 < NCH ? o3 + (unsigned)((c + 1) * 2) * X::KQE * 1024 : oro);
+                    o[ob] = mfma_block_p<8>(wp, ws, wcur, wnx, hid, o[ob]);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < X::NE; ++b) {
+                float ob4[16], og2[16];
+                load16(b4_ + b * 32 + half * 16, ob4);
+                load16(eg2_ + b * 32 + half * 16, og2);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) en[b * 16 + s] = fmaf(og2[s], o[b][s] + ob4[s], en[b * 16 + s]);
+            }
+        }
+        if (P.ok) {
+            store_nat<X::NE>(A.e + P.rij * X::De, half, en);
+            store_nat<X::NE>(A.e + P.rji * X::De, half, en);
+        }
+        // ---- readout ----
+        {
+            float bb[16];
+            load16(bro_ + half * 16, bb);
+            f32x16 acc = mfma_block_p<X::KQE>(wp, ws, oro, oi, en, zero16());
+            float rr[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) rr[s] = acc[s] + bb[s];
+            if (P.ok && (half == 0 || X::CEP == 32)) {
+                store16(A.ehid + P.rij * A.d.KEH + X::De + A.layer * X::CEP + half * 16, rr);
+                store16(A.ehid + P.rji * A.d.KEH + X::De + A.layer * X::CEP + half * 16, rr);
+            }
+        }
+        // ---- S = W_e e + W_d G, shared by both directions: parked in private memory ----
+#pragma unroll
+        for (int b = 0; b < X::ND; ++b) {
+            const unsigned we = oi + (unsigned)(b * 2 * X::KQE) * 1024, wg_ = we + X::KQE * 1024;
+            f32x16 acc = mfma_block_p<X::KQE>(wp, ws, we, wg_, en, zero16());
+            acc = mfma_block_p<X::KQE>(wp, ws, wg_, b + 1 < X::ND ? wg_ + X::KQE * 1024 : o0, G, acc);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) park[b * 16 + s] = acc[s];
+        }
+        // ---- two directed evaluations: u = S + W_row h_a + W_col h_c -> LN -> modulate -> coord_mlp ----
+#pragma unroll 1
+        for (int dir = 0; dir < 2; ++dir) {
+            const TRow& ra = dir == 0 ? wrow_i : wrow_j;
+            const TRow& rc = dir == 0 ? wcol_j : wcol_i;
+            float uu[X::HD];
+#pragma unroll
+            for (int b = 0; b < X::ND; ++b) {
+                float a1[16], a2[16];
+                load16T(ra, b, a1);
+                load16T(rc, b, a2);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) uu[b * 16 + s] = park[b * 16 + s] + (a1[s] + a2[s]);
+            }
+            layer_norm<X::HD>(uu);
+            modulate<X::ND>(uu, qsh_, qsc_, half);
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll 1
+            for (int b = 0; b < X::ND; ++b) {
+                const unsigned wcur = o0 + (unsigned)b * X::KQD * 1024;
+                const unsigned wnx = b + 1 < X::ND ? wcur + X::KQD * 1024 : (dir == 0 ? o0 : o3);
+                float bb[16], k0[16], k1[16], k2[16];
+                load16(b0_ + b * 32 + half * 16, bb);
+                load16(w2_ + b * 32 + half * 16, k0);
+                load16(w2_ + D + b * 32 + half * 16, k1);
+                load16(w2_ + 2 * D + b * 32 + half * 16, k2);
+                f32x16 acc = mfma_block_p<X::KQD>(wp, ws, wcur, wnx, uu, zero16());
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float ys = silu_f(acc[s] + bb[s]);
+                    c0 = fmaf(ys, k0[s], c0);
+                    c1 = fmaf(ys, k1[s], c1);
+                    c2 = fmaf(ys, k2[s], c2);
+                }
+            }
+            c0 = tanh_f(pair_sum(c0));
+            c1 = tanh_f(pair_sum(c1));
+            c2 = tanh_f(pair_sum(c2));
+            const size_t rr = dir == 0 ? P.rij : P.rji;
+            const int fl = A.eflag[rr];
+            const float iota = (c0 + ((fl & 1) ? c1 : 0.f) + ((fl & 2) ? c2 : 0.f)) * (1.f / 3.f);
+            const float nrm = fmaxf(sqrtf(d2), 1e-8f);
+            const float f = cscale * iota / nrm;
+            const float sgn = dir == 0 ? 1.f : -1.f;          // x_a - x_c
+            if (P.ok && half == 0)
+                reinterpret_cast<float4*>(A.dposE)[rr] = make_float4(sgn * dx * f, sgn * dy * f, sgn * dz * f, 0.f);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

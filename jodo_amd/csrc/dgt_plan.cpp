@@ -112,7 +112,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     }
     if (pair_chunk <= 0) pair_chunk = 1;     // measured best on MI355X (QM9 B=2500: 26.7 ms/step vs 27.7 at 2)
     if (spair_chunk <= 0) spair_chunk = pair_chunk;   // sweep on MI355X: 1 and 4 tie, 6 is 35 % slower
-    p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->prof_enabled = 0; p->force_directed = p->dims.wide; p->dbg_timing = nullptr;
+    p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->prof_enabled = 0; p->force_directed = 0; p->dbg_timing = nullptr;
 
     // molecules by descending size (stable): neighbouring lanes share n, big work first
     std::vector<int> order(B);
