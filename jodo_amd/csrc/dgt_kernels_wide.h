@@ -3,8 +3,8 @@
 // score channels, 16 x 24 value channels).  Same strip model, same HBM layouts, same launch sequence;
 // what differs from the tuned nf = 256 set:
 //   * all weights are streamed from L2 through the software-pipelined ring (the K = De projections of
-//     the attention kernels no longer fit in LDS at De = 96), prefetch group of 4 quads (K = 96 gives
-//     12-quad blocks);
+//     the attention kernels no longer fit in LDS at De = 96), prefetch group of 4 quads at D = 384 (K = 96 gives
+//     12-quad blocks), 8 at D = 256;
 //   * score heads use the "one head per 32-row block" arrangement (jodo_amd/packing.py
 //     qk_out_map_wide): SC = 27 has no 16 + 2 split, and padding a head to 32 rows keeps its reduction
 //     in-lane;
@@ -21,7 +21,6 @@
 namespace jd {
 namespace wide {
 
-constexpr int PG = 4;            // weight quads in flight per prefetch group
 constexpr int NHEAD_BLOCKS = 14; // learned score heads, one 32-row block each
 
 template <int D_>
@@ -29,6 +28,7 @@ struct Dim {
     static constexpr int D = D_, De = D_ / 4, ND = D_ / 32, NE = D_ / 128;
     static constexpr int HD = D_ / 2, HE = D_ / 8;                // registers per half-lane: node / edge vector
     static constexpr int KQD = D_ / 8, KQE = D_ / 32;             // weight quads per output block for K = D / K = De
+    static constexpr int PG = (D_ % 256 == 0) ? 8 : 4;             // weight quads in flight per prefetch group (must divide D/32)
     static constexpr int C = D_ / 16;                              // value channels per head
     static constexpr float INV_SQRT_C = D_ == 256 ? 0.25f : (D_ == 384 ? 0.20412414523193150f : 0.f);
     static constexpr int CNP = D_ / 4, NRO = CNP / 32;             // padded node readout width / blocks
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
     const float* bias = A.W + A.wb[piece == 0 ? JB_BQ : (piece == 1 ? JB_BK : JB_BV)];
     float* outp = piece == 0 ? A.q : (piece == 1 ? A.k : A.v);
     const int nb = piece == 2 ? X::ND : NHEAD_BLOCKS;
-    WPipe<PG> wp;
+    WPipe<X::PG> wp;
     wpipe_prime(wp, ws, woff);
 #pragma unroll 1
     for (int b = 0; b < nb; ++b) {
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned oN2E = (unsigned)(A.wb[JB_N2E_W] * 4), oF1 = (unsigned)(A.wb[JB_FF1_W] * 4), oF2 = (unsigned)(A.wb[JB_FF2_W] * 4);
     const unsigned oRow = (unsigned)(A.wb[JB_ROW_W] * 4), oCol = (unsigned)(A.wb[JB_COL_W] * 4), oNro = (unsigned)(A.wb[JB_NRO_W] * 4);
-    WPipe<PG> wp;
+    WPipe<X::PG> wp;
     wpipe_prime(wp, ws, oN2E);
     float hx[X::HD];
     {   // aggregated attention messages: fixed-order sum of the per-chunk partials
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_scores(KArgs A) {
     const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned oEE = (unsigned)(A.wb[JB_EE_W] * 4), oL0 = (unsigned)(A.wb[JB_LE0_W] * 4);
-    WPipe<PG> wp;
+    WPipe<X::PG> wp;
     wpipe_prime(wp, ws, oEE);
     for (int t = t0; t < t1; ++t) {
         const bool ok = L.valid && t < L.n;
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_msgs(KArgs A) {
     load16(A.stats + (size_t)L.v * 32 + 16, inv);
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned oL1 = (unsigned)(A.wb[JB_LE1_W] * 4);
-    WPipe<PG> wp;
+    WPipe<X::PG> wp;
     wpipe_prime(wp, ws, oL1);
     float macc[X::HD];
 #pragma unroll
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned o3 = (unsigned)(A.wb[JB_FF3_W] * 4), o4 = (unsigned)(A.wb[JB_FF4_W] * 4);
     const unsigned oro = (unsigned)(A.wb[JB_ERO_W] * 4), oi = (unsigned)(A.wb[JB_INE_W] * 4), o0 = (unsigned)(A.wb[JB_C0_W] * 4);
-    WPipe<PG> wp;
+    WPipe<X::PG> wp;
     wpipe_prime(wp, ws, o3);
     float dax = 0.f, day = 0.f, daz = 0.f;
     for (int t = t0; t < t1; ++t) {
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_scores_sym(KArgs A) {
     const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned oEE = (unsigned)(A.wb[JB_EE_W] * 4), oL0 = (unsigned)(A.wb[JB_LE0_W] * 4);
-    WPipe<PG> wp;
+    WPipe<X::PG> wp;
     wpipe_prime(wp, ws, oEE);
     for (int t = t0; t < t1; ++t) {
         const PairLane P = pair_of(L, t + 1);
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned o3 = (unsigned)(A.wb[JB_FF3_W] * 4), o4 = (unsigned)(A.wb[JB_FF4_W] * 4);
     const unsigned oro = (unsigned)(A.wb[JB_ERO_W] * 4), oi = (unsigned)(A.wb[JB_INE_W] * 4), o0 = (unsigned)(A.wb[JB_C0_W] * 4);
-    WPipe<PG> wp;
+    WPipe<X::PG> wp;
     wpipe_prime(wp, ws, o3);
     float park[X::HD];                                      // S, then u of direction 1: private (scratch) memory
     for (int t = t0; t < t1; ++t) {
