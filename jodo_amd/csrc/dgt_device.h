@@ -133,6 +133,31 @@ __device__ __forceinline__ void store16T(float* arr, int NB, int node, int half,
     for (int q = 0; q < 4; ++q) p[(b * 4 + q) * 64] = make_float4(x[q * 4 + 0], x[q * 4 + 1], x[q * 4 + 2], x[q * 4 + 3]);
 }
 
+// Buffer-descriptor variant of TRow.  Plain global loads from the (noalias, read-only) node arrays are not
+// held in place by pipeline_fence(): hipcc sinks each one down to its first use and emits load ->
+// s_waitcnt vmcnt(0) -> add, one exposed L2 round trip per 16 bytes (seen in the ISA of the pair-update
+// kernel: 32 serialised round trips per direction).  Buffer-load intrinsics ARE ordered by the fence, so a
+// group of rows can be requested up front and consumed after one wait.
+struct BRow {
+    __amdgpu_buffer_rsrc_t rs;   // descriptor of the whole array (wave-uniform)
+    unsigned voff;               // byte offset of this lane's float4 of (block 0, quad 0)
+};
+__device__ __forceinline__ BRow brow(const float* arr, int NB, int node, int half) {
+    BRow r;
+    r.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(arr), 0, 0x7fffffff, 0x00020000);
+    r.voff = (unsigned)((((size_t)(node >> 5) * NB * 256) + (node & 31) + 32 * half) * 16);
+    return r;
+}
+__device__ __forceinline__ void bload16(const BRow& r, int b, float (&x)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned int __attribute__((ext_vector_type(4))) v =
+            __builtin_amdgcn_raw_buffer_load_b128(r.rs, r.voff, (unsigned)((b * 4 + q) * 1024), 0);
+        x[q * 4 + 0] = __uint_as_float(v.x); x[q * 4 + 1] = __uint_as_float(v.y);
+        x[q * 4 + 2] = __uint_as_float(v.z); x[q * 4 + 3] = __uint_as_float(v.w);
+    }
+}
+
 // ---- one output block of a projection -------------------------------------------------------------
 // w: this lane's float4 of quad 0 of the block (= block base + lane); KQ quads of 4 k-steps;
 // act: KQ*4 activation registers.  acc += W_block * act.
@@ -220,6 +245,20 @@ __device__ __forceinline__ f32x16 mfma_block_p(WPipe<PG>& p, const WSrc& w, unsi
         pipeline_fence();
     }
     return acc;
+}
+
+// 16 consecutive floats of this lane's half (features b*32 + half*16 ..) from the weight blob through the
+// descriptor: unlike load16 these are held in place by pipeline_fence(), so "operands of the epilogue are
+// requested before the MFMA block they follow" is what the hardware actually sees.
+// soff: byte offset of feature 0 of the vector (wave-uniform).
+__device__ __forceinline__ void cload16(const WSrc& w, int half, unsigned soff, float (&x)[16]) {
+    const unsigned hv = (unsigned)half * 64u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w.rs, hv + (unsigned)q * 16u, soff, 0);
+        x[q * 4 + 0] = __uint_as_float(v.x); x[q * 4 + 1] = __uint_as_float(v.y);
+        x[q * 4 + 2] = __uint_as_float(v.z); x[q * 4 + 3] = __uint_as_float(v.w);
+    }
 }
 
 // accumulator (+ bias in slot order) -> registers [16]

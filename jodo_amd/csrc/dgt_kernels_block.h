@@ -191,15 +191,16 @@ __global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_msgs(KArgs A) {
 #pragma unroll
             for (int b2 = 0; b2 < 8; ++b2) al[b2] = ok ? fast_exp(sv[b2] - mx[b2]) * inv[b2] : 0.f;
         }
-        const TRow vrow = trow(A.v, 8, u, half);
+        const BRow vrow = brow(A.v, 8, u, half);     // buffer loads: the fence keeps them ahead of the MFMAs
         float vnext[16];
-        load16T(vrow, 0, vnext);
+        bload16(vrow, 0, vnext);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             float vv[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) vv[s] = vnext[s];
-            if (b < 7) load16T(vrow, b + 1, vnext);   // one block ahead
+            if (b < 7) bload16(vrow, b + 1, vnext);   // one block ahead
+            pipeline_fence();
             f32x16 acc = mfma_block_lds<8>(wL1 + (b * 8) * 64, x, zero16());
 #pragma unroll
             for (int s = 0; s < 16; ++s) macc[b * 16 + s] = fmaf(tanh_f(acc[s]) * vv[s], al[b], macc[b * 16 + s]);

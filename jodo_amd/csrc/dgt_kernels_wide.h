@@ -753,7 +753,8 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
     const unsigned oro = (unsigned)(A.wb[JB_ERO_W] * 4), oi = (unsigned)(A.wb[JB_INE_W] * 4), o0 = (unsigned)(A.wb[JB_C0_W] * 4);
     WPipe<X::PG> wp;
     wpipe_prime(wp, ws, o3);
-    float park[X::HD];                                      // S, then u of direction 1: private (scratch) memory
+    float park[X::HD];                                      // S = shared part of input_lin, kept for both directions
+    PT_INIT
     for (int t = t0; t < t1; ++t) {
         const PairLane P = pair_of(L, t + 1);
         const float* eg1_ = launder(eg1);
@@ -764,9 +765,8 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
         const float* n2bias_ = cst + A.wb[JB_N2E_B], *b3_ = cst + A.wb[JB_FF3_B], *b4_ = cst + A.wb[JB_FF4_B];
         const float* b0_ = cst + A.wb[JB_C0_B], *w2_ = cst + A.wb[JB_C2_W], *tab_ = cst + A.wb[JB_GBF];
         const float* bro_ = cst + A.wb[JB_ERO_B];
-        TRow wrow_i = trow(A.wrow, X::ND, L.v, half), wcol_i = trow(A.wcol, X::ND, L.v, half);
-        wrow_i.p = launder(wrow_i.p); wcol_i.p = launder(wcol_i.p);
-        const TRow wrow_j = trow(A.wrow, X::ND, P.u, half), wcol_j = trow(A.wcol, X::ND, P.u, half);
+        const BRow wrow_i = brow(A.wrow, X::ND, L.v, half), wcol_i = brow(A.wcol, X::ND, L.v, half);
+        const BRow wrow_j = brow(A.wrow, X::ND, P.u, half), wcol_j = brow(A.wcol, X::ND, P.u, half);
         const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[P.u];
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
@@ -790,6 +790,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
         }
         layer_norm<X::HE>(en);
         modulate<X::NE>(en, es2_, ec2_, half);
+        PT(0);
         // ---- edge FFN ----
         {
             f32x16 o[X::NE];
@@ -829,6 +830,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             store_nat<X::NE>(A.e + P.rij * X::De, half, en);
             store_nat<X::NE>(A.e + P.rji * X::De, half, en);
         }
+        PT(1);
         // ---- readout ----
         {
             float bb[16];
@@ -842,7 +844,8 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                 store16(A.ehid + P.rji * A.d.KEH + X::De + A.layer * X::CEP + half * 16, rr);
             }
         }
-        // ---- S = W_e e + W_d G, shared by both directions: parked in private memory ----
+        PT(2);
+        // ---- S = W_e e + W_d G, shared by both directions: parked per lane ----
 #pragma unroll
         for (int b = 0; b < X::ND; ++b) {
             const unsigned we = oi + (unsigned)(b * 2 * X::KQE) * 1024, wg_ = we + X::KQE * 1024;
@@ -851,22 +854,34 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) park[b * 16 + s] = acc[s];
         }
+        PT(3);
         // ---- two directed evaluations: u = S + W_row h_a + W_col h_c -> LN -> modulate -> coord_mlp ----
 #pragma unroll 1
         for (int dir = 0; dir < 2; ++dir) {
-            const TRow& ra = dir == 0 ? wrow_i : wrow_j;
-            const TRow& rc = dir == 0 ? wcol_j : wcol_i;
+            BRow ra = wrow_i, rc = wcol_j;
+            if (dir == 1) { ra.voff = wrow_j.voff; rc.voff = wcol_i.voff; }
             float uu[X::HD];
+            // the per-node rows are requested four blocks at a time (buffer loads, pinned by the fence) and only
+            // then consumed — see BRow in dgt_device.h
 #pragma unroll
-            for (int b = 0; b < X::ND; ++b) {
-                float a1[16], a2[16];
-                load16T(ra, b, a1);
-                load16T(rc, b, a2);
+            for (int g = 0; g < X::ND / 4; ++g) {
+                float a1[64], a2[64];
 #pragma unroll
-                for (int s = 0; s < 16; ++s) uu[b * 16 + s] = park[b * 16 + s] + (a1[s] + a2[s]);
+                for (int k = 0; k < 4; ++k) {
+                    float t1[16], t2[16];
+                    bload16(ra, g * 4 + k, t1);
+                    bload16(rc, g * 4 + k, t2);
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) { a1[k * 16 + s] = t1[s]; a2[k * 16 + s] = t2[s]; }
+                }
+                pipeline_fence();
+#pragma unroll
+                for (int s = 0; s < 64; ++s) uu[g * 64 + s] = park[g * 64 + s] + (a1[s] + a2[s]);
             }
+            PT(6);
             layer_norm<X::HD>(uu);
             modulate<X::ND>(uu, qsh_, qsc_, half);
+            PT(4);
             float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll 1
             for (int b = 0; b < X::ND; ++b) {
@@ -886,6 +901,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                     c2 = fmaf(ys, k2[s], c2);
                 }
             }
+            PT(dir == 0 ? 5 : 7);
             c0 = tanh_f(pair_sum(c0));
             c1 = tanh_f(pair_sum(c1));
             c2 = tanh_f(pair_sum(c2));
@@ -897,8 +913,10 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             const float sgn = dir == 0 ? 1.f : -1.f;          // x_a - x_c
             if (P.ok && half == 0)
                 reinterpret_cast<float4*>(A.dposE)[rr] = make_float4(sgn * dx * f, sgn * dy * f, sgn * dz * f, 0.f);
+            PT(6);
         }
     }
+    PT_FLUSH;
 }
 
 // ------------------------------------------------------------------------------------------------
