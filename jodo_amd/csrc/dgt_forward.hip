@@ -272,12 +272,13 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
         { ProfScope ps(p, st, JODO_PROF_SOFTMAX); LAUNCH(k_softmax, (p->Nn + 15) / 16, 256, A); }
         if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_MSGS); LAUNCH(k_edge_msgs, (p->n_items + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A); }
         { ProfScope ps(p, st, JODO_PROF_NODE_POST);
-          // few strips (small batch): a 4-wave workgroup per strip; otherwise one wave per strip (measured on
-          // MI355X: 4-wave 1.0 vs 1.7 ms/step at 177 strips, but 4.1 vs 3.6 ms/step at 1409 strips)
-          static const char* force = getenv("JODO_NODE_POST");                     // experiment switch: "1" or "4"
-          const bool one_wave = force ? force[0] == '1' : p->n_strips > 512;
-          if (one_wave) { if (d.r == 2) LAUNCH(k_node_post<2>, p->n_strips, 64, A); else LAUNCH(k_node_post<4>, p->n_strips, 64, A); }
-          else { if (d.r == 2) LAUNCH(k_node_post4<2>, p->n_strips, NP4_WAVES * 64, A); else LAUNCH(k_node_post4<4>, p->n_strips, NP4_WAVES * 64, A); } }
+          // waves per strip: 4 for few strips (small batch), else 1 (measured on MI355X: 4-wave 1.0 vs 1.7 ms/step at
+          // 177 strips, but 4.1 vs 3.6 ms/step at 1409 strips)
+          static const char* force = getenv("JODO_NODE_POST");                     // experiment switch: "1", "2" or "4"
+          const int nw = force ? force[0] - '0' : (p->n_strips > 512 ? 1 : 4);
+          if (nw == 1) { if (d.r == 2) LAUNCH(k_node_post<2>, p->n_strips, 64, A); else LAUNCH(k_node_post<4>, p->n_strips, 64, A); }
+          else if (nw == 2) { if (d.r == 2) LAUNCH((k_node_postw<2, 2>), p->n_strips, 128, A); else LAUNCH((k_node_postw<4, 2>), p->n_strips, 128, A); }
+          else { if (d.r == 2) LAUNCH((k_node_postw<2, 4>), p->n_strips, 256, A); else LAUNCH((k_node_postw<4, 4>), p->n_strips, 256, A); } }
         if (p->n_items > 0) {
             ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);
             if (p->n_pitems > 0) {

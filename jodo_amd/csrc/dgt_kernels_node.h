@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Four-wave variant: one workgroup (4 waves = the 4 SIMDs of a CU) per strip.  The waves share the
+// Multi-wave variant: one workgroup of NW = 2 or 4 waves per strip.  The waves share the
 // strip's work — FFN hidden chunks c = w, w + 4, ..; afterwards 4 of the 16 W_row / W_col blocks each —
 // and exchange through LDS once: the partial FFN sums (4 x 32 KiB) are reduced by the wave that owns the
 // output block, which then publishes its two blocks of h' in place of partial 0.  The cheap
@@ -202,29 +202,28 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
 // Why: with one wave per strip a launch has only Nn/32 items (1409 at QM9 B = 2500: 1.4 per SIMD -> two
 // full rounds; 177 at B = 313: 83 % of the chip idle); here an item is ~3.7x shorter and the unit of
 // scheduling is a CU.
-constexpr int NP4_WAVES = 4;
-
-template <int W>   // reduce + publish the two output blocks owned by wave W
-__device__ __forceinline__ void node_post4_reduce(const KArgs& A, const LaneNode& L, int half, int lane, float4* part,
+template <int W, int NW>   // reduce + publish the 8 / NW output blocks owned by wave W
+__device__ __forceinline__ void node_postw_reduce(const KArgs& A, const LaneNode& L, int half, int lane, float4* part,
                                                   const float* ng2, const float (&hx)[128]) {
+    constexpr int NBW = 8 / NW;
     const float* b2 = A.W + A.wb[JB_FF2_B];
 #pragma unroll
-    for (int bb = 0; bb < 2; ++bb) {
-        const int b = 2 * W + bb;
+    for (int bb = 0; bb < NBW; ++bb) {
+        const int b = NBW * W + bb;
         float sum[16], bias[16], g[16], r[16];
         load16(b2 + b * 32 + half * 16, bias);
         load16(ng2 + b * 32 + half * 16, g);
 #pragma unroll
         for (int s = 0; s < 16; ++s) sum[s] = 0.f;
 #pragma unroll
-        for (int w = 0; w < NP4_WAVES; ++w)
+        for (int w = 0; w < NW; ++w)                            // fixed order: bit-deterministic
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 v = part[((w * 8 + b) * 4 + q) * 64 + lane];
                 sum[q * 4 + 0] += v.x; sum[q * 4 + 1] += v.y; sum[q * 4 + 2] += v.z; sum[q * 4 + 3] += v.w;
             }
 #pragma unroll
-        for (int s = 0; s < 16; ++s) r[s] = fmaf(g[s], sum[s] + bias[s], hx[(2 * W + bb) * 16 + s]);
+        for (int s = 0; s < 16; ++s) r[s] = fmaf(g[s], sum[s] + bias[s], hx[(NBW * W + bb) * 16 + s]);
         store16(A.h + (size_t)L.v * 256 + b * 32 + half * 16, r);
 #pragma unroll
         for (int q = 0; q < 4; ++q)       // only this wave ever reads column b of the partials: safe to overwrite
@@ -232,9 +231,9 @@ __device__ __forceinline__ void node_post4_reduce(const KArgs& A, const LaneNode
     }
 }
 
-template <int R>
-__global__ __launch_bounds__(NP4_WAVES * 64, 1) void k_node_post4(KArgs A) {
-    __shared__ float4 part[NP4_WAVES * 8 * 4 * 64];           // [4 waves][8 blocks][4 quads][64 lanes] = 128 KiB
+template <int R, int NW>   // mlp_ratio, waves per strip (2 or 4)
+__global__ __launch_bounds__(NW * 64, 1) void k_node_postw(KArgs A) {
+    __shared__ float4 part[NW * 8 * 4 * 64];                  // [NW waves][8 blocks][4 quads][64 lanes] = NW x 32 KiB
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
     const int strip = blockIdx.x;
     const LaneNode L = lane_node(A, strip, j);
@@ -243,21 +242,25 @@ __global__ __launch_bounds__(NP4_WAVES * 64, 1) void k_node_post4(KArgs A) {
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned oN2E = (unsigned)(A.wb[JB_N2E_W] * 4), oF1 = (unsigned)(A.wb[JB_FF1_W] * 4), oF2 = (unsigned)(A.wb[JB_FF2_W] * 4);
     const unsigned oRow = (unsigned)(A.wb[JB_ROW_W] * 4), oCol = (unsigned)(A.wb[JB_COL_W] * 4), oNro = (unsigned)(A.wb[JB_NRO_W] * 4);
-    constexpr int NCH = R * 4, CPW = NCH / NP4_WAVES;         // hidden chunks of 64, chunks per wave
+    constexpr int NCH = R * 4, CPW = NCH / NW;                // hidden chunks of 64, chunks per wave
     constexpr int KQ2 = R * 256 / 8;
-    // first weight block of this wave's last phase: W_row blocks 0-3 / 4-7 (waves 0, 1), W_col blocks 0-3 / 4-7 (2, 3)
-    const unsigned oLast = (wave < 2 ? oRow : oCol) + (unsigned)((wave & 1) * 4) * 32 * 1024;
+    constexpr int PER = 16 / NW;                              // W_row / W_col blocks per wave in the last phase
+    constexpr int ROW_WAVES = NW / 2;                         // waves 0 .. NW/2-1 take W_row, the others W_col + readout
+    constexpr int NRO_PER = 2 / ROW_WAVES;                    // readout blocks per W_col wave
+    const bool is_row = wave < ROW_WAVES;
+    const int b0 = (wave % ROW_WAVES) * PER;
+    const unsigned oLast = (is_row ? oRow : oCol) + (unsigned)b0 * 32 * 1024;
     const unsigned oFirstFF = oF1 + (unsigned)(wave * 2) * 32 * 1024;
     WPipe<8> wp;
     wpipe_prime(wp, ws, wave < 2 ? oN2E + (unsigned)wave * 32 * 1024 : oFirstFF);
     float hx[128];
-    {   // aggregated messages: each wave sums every 4th partial, then the four sums are combined through LDS
+    {   // aggregated messages: each wave sums every NW-th partial, then the sums are combined through LDS
         // (a small batch is cut into many short source chunks, i.e. many partials: dgt_plan.cpp)
         const int parts = A.pd.strip_parts[strip];
         const float* base = A.hhat + (size_t)L.v * A.pd.max_parts * 256;
 #pragma unroll
         for (int s = 0; s < 128; ++s) hx[s] = 0.f;
-        for (int q = wave; q < parts; q += NP4_WAVES) {
+        for (int q = wave; q < parts; q += NW) {
             float t[128];
             load_nat<8>(base + (size_t)q * 256, half, t);
 #pragma unroll
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(NP4_WAVES * 64, 1) void k_node_post4(KArgs A) {
 #pragma unroll
             for (int s = 0; s < 128; ++s) hx[s] = 0.f;
 #pragma unroll
-            for (int w = 0; w < NP4_WAVES; ++w)               // fixed order: bit-deterministic
+            for (int w = 0; w < NW; ++w)                      // fixed order: bit-deterministic
 #pragma unroll
                 for (int b = 0; b < 8; ++b)
 #pragma unroll
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(NP4_WAVES * 64, 1) void k_node_post4(KArgs A) {
         const float* b1 = A.W + A.wb[JB_FF1_B];
 #pragma unroll 1
         for (int ci = 0; ci < CPW; ++ci) {
-            const int c = wave + NP4_WAVES * ci;
+            const int c = wave + NW * ci;
             float hid[32];
 #pragma unroll
             for (int b2 = 0; b2 < 2; ++b2) {
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(NP4_WAVES * 64, 1) void k_node_post4(KArgs A) {
             for (int ob = 0; ob < 8; ++ob) {
                 const unsigned cur = oF2 + (unsigned)(ob * KQ2 + c * 8) * 1024;
                 const unsigned nxt = ob < 7 ? oF2 + (unsigned)((ob + 1) * KQ2 + c * 8) * 1024
-                                            : (ci + 1 < CPW ? oF1 + (unsigned)((c + NP4_WAVES) * 2) * 32 * 1024 : oLast);
+                                            : (ci + 1 < CPW ? oF1 + (unsigned)((c + NW) * 2) * 32 * 1024 : oLast);
                 o[ob] = mfma_block_p<8>(wp, ws, cur, nxt, hid, o[ob]);
             }
         }
@@ -328,10 +331,10 @@ __global__ __launch_bounds__(NP4_WAVES * 64, 1) void k_node_post4(KArgs A) {
         for (int q = 0; q < 4; ++q)
             part[((wave * 8 + b) * 4 + q) * 64 + lane] = make_float4(o[b][q * 4 + 0], o[b][q * 4 + 1], o[b][q * 4 + 2], o[b][q * 4 + 3]);
     __syncthreads();
-    if (wave == 0) node_post4_reduce<0>(A, L, half, lane, part, ng2, hx);
-    else if (wave == 1) node_post4_reduce<1>(A, L, half, lane, part, ng2, hx);
-    else if (wave == 2) node_post4_reduce<2>(A, L, half, lane, part, ng2, hx);
-    else node_post4_reduce<3>(A, L, half, lane, part, ng2, hx);
+    if (wave == 0) node_postw_reduce<0, NW>(A, L, half, lane, part, ng2, hx);
+    else if (wave == 1) node_postw_reduce<1, NW>(A, L, half, lane, part, ng2, hx);
+    else if (NW > 2 && wave == 2) node_postw_reduce<2 % NW, NW>(A, L, half, lane, part, ng2, hx);
+    else if (NW > 2) node_postw_reduce<3 % NW, NW>(A, L, half, lane, part, ng2, hx);
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < 8; ++b)                               // every wave picks up the full h'
@@ -340,32 +343,35 @@ __global__ __launch_bounds__(NP4_WAVES * 64, 1) void k_node_post4(KArgs A) {
             const float4 v = part[((0 * 8 + b) * 4 + q) * 64 + lane];
             hx[b * 16 + q * 4 + 0] = v.x; hx[b * 16 + q * 4 + 1] = v.y; hx[b * 16 + q * 4 + 2] = v.z; hx[b * 16 + q * 4 + 3] = v.w;
         }
-    {   // 4 of the 16 W_row / W_col blocks; waves 2, 3 then one readout block each
+    {   // this wave's share of the 16 W_row / W_col blocks; the W_col waves then take the readout blocks
         const float* bin = A.W + A.wb[JB_IN_B];
-        const bool is_row = wave < 2;
         float* dst = is_row ? A.wrow : A.wcol;
-        const int b0 = (wave & 1) * 4;
-        const unsigned oAfter = is_row ? oLast : oNro + (unsigned)(wave & 1) * 32 * 1024;
+        const int ro0 = (wave % ROW_WAVES) * NRO_PER;         // first readout block of this (W_col) wave
+        const unsigned oAfter = is_row ? oLast : oNro + (unsigned)ro0 * 32 * 1024;
 #pragma unroll 1
-        for (int bi = 0; bi < 4; ++bi) {
+        for (int bi = 0; bi < PER; ++bi) {
             const int b = b0 + bi;
             const unsigned cur = oLast + (unsigned)bi * 32 * 1024;
             float bb[16], r[16];
             load16(bin + b * 32 + half * 16, bb);
-            f32x16 acc = mfma_block_p<32>(wp, ws, cur, bi < 3 ? cur + 32 * 1024 : oAfter, hx, zero16());
+            f32x16 acc = mfma_block_p<32>(wp, ws, cur, bi + 1 < PER ? cur + 32 * 1024 : oAfter, hx, zero16());
 #pragma unroll
             for (int s = 0; s < 16; ++s) r[s] = acc[s] + (is_row ? bb[s] : 0.f);
             store16T(dst, 8, L.v, half, b, r);
         }
         if (!is_row) {                                        // readout node_l(h') -> atom_hids[:, D + l*64 ...]
-            const int b = wave & 1;
             const float* bias = A.W + A.wb[JB_NRO_B];
-            float bb[16], r[16];
-            load16(bias + b * 32 + half * 16, bb);
-            f32x16 acc = mfma_block_p<32>(wp, ws, oAfter, oAfter, hx, zero16());
+#pragma unroll 1
+            for (int k = 0; k < NRO_PER; ++k) {
+                const int b = ro0 + k;
+                const unsigned cur = oAfter + (unsigned)k * 32 * 1024;
+                float bb[16], r[16];
+                load16(bias + b * 32 + half * 16, bb);
+                f32x16 acc = mfma_block_p<32>(wp, ws, cur, k + 1 < NRO_PER ? cur + 32 * 1024 : cur, hx, zero16());
 #pragma unroll
-            for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
-            store16(A.ahid + (size_t)L.v * A.d.KNH + 256 + A.layer * 64 + b * 32 + half * 16, r);
+                for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
+                store16(A.ahid + (size_t)L.v * A.d.KNH + 256 + A.layer * 64 + b * 32 + half * 16, r);
+            }
         }
     }
 }
