@@ -12,5 +12,6 @@ f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -30 "$f" | cut -c1-220 > $OUT/kernel_stats_top.csv && cat $OUT/kernel_stats_top.csv | cut -c1-160
 find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete
 timeout 600 python bench.py --workload geom --steps 6 --warmup 2 --breakdown --no-cpu-baseline > $OUT/bench_geom.json 2> $OUT/bench_geom.err; cat $OUT/bench_geom.json
+timeout 900 python bench.py --workload geom384 --steps 4 --warmup 2 --breakdown --no-cpu-baseline > $OUT/bench_geom384.json 2> $OUT/bench_geom384.err; cat $OUT/bench_geom384.json
 timeout 600 python bench.py --workload cond --steps 10 --warmup 3 --breakdown --no-cpu-baseline > $OUT/bench_cond.json 2> $OUT/bench_cond.err; cat $OUT/bench_cond.json
 bash tools/gpu_pmc.sh $TAG 2>&1 | tail -60
