@@ -15,6 +15,7 @@ struct KArgs {
     int64_t mod_base;                     // offset of the current block inside a modulation vector
     int layer;
     int force_directed;                   // debug: never take the symmetric pair path
+    int pre_mode;                         // k_node_pre: 0 = also advance the positions, 1 = q/k/v only (k_pos_final did it)
     // workspace
     float *hid1, *temb, *mods, *condh, *condh2;
     float *pos_in, *pos_out, *dpos, *cpos, *feat, *h, *hhat, *q, *k, *v, *n2e, *wrow, *wcol, *ahid, *stats, *apred;

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
     const int strip = blockIdx.x / 3, piece = blockIdx.x % 3;
     const LaneNode L = lane_node(A, strip, j);
     // positions entering this block: previous positions + the contributions of the previous update
-    if (piece == 0) {
+    if (piece == 0 && A.pre_mode == 0) {
         float4 p = reinterpret_cast<const float4*>(A.pos_in)[L.v];
         if (A.layer > 0) {
             if (A.flags[FLAG_ASYM]) {

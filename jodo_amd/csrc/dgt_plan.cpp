@@ -228,6 +228,9 @@ extern "C" void jodo_plan_destroy(jodo_plan* p) {
     if (!p) return;
     for (void* e : p->prof_ev) (void)hipEventDestroy((hipEvent_t)e);
     for (void* e : p->prof_pool) (void)hipEventDestroy((hipEvent_t)e);
+    if (p->aux_stream) { (void)hipStreamSynchronize((hipStream_t)p->aux_stream); (void)hipStreamDestroy((hipStream_t)p->aux_stream); }
+    if (p->ev_fork) (void)hipEventDestroy((hipEvent_t)p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy((hipEvent_t)p->ev_join);
     delete p;
 }
 extern "C" int jodo_profile_enable(jodo_plan* p, int enable) {

@@ -68,6 +68,9 @@ struct jodo_plan {
     void* dbg_timing;                // debug: device buffer of 16 x u64 phase-cycle sums (or null)
     int max_blocks;                  // debug: limit blocks executed (<0 = all)
     int last_pos_buf;                // debug: which pos buffer holds the latest positions
+    void* aux_stream = nullptr;      // helper stream (hipStream_t) for work overlapped with the edge update; created lazily
+    void* ev_fork = nullptr;         // hipEvent_t pair for the fork / join of that stream
+    void* ev_join = nullptr;
 };
 
 int dgt_dims_from_cfg(const jodo_cfg* cfg, DgtDims* d);
