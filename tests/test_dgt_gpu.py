@@ -241,14 +241,16 @@ def test_cpu_tensor_and_grad_are_rejected_loudly():
         model(d(nl), d(xh), d(nm), d(em), edge_x=d(ex), cond_x=None, cond_edge_x=None, noise_level=d(nl))
 
 
-@pytest.mark.parametrize("cfg_name,n_nodes", [
-    ('vpsde_qm9_uncond_jodo', [1, 2, 3, 4, 9, 10, 18, 29, 28]),       # odd/even sizes, n = 1, 2
-    ('vpsde_geom_uncond_jodo', [44, 45, 7]),
+@pytest.mark.parametrize("cfg_name,n_nodes,over", [
+    ('vpsde_qm9_uncond_jodo', [1, 2, 3, 4, 9, 10, 18, 29, 28], {}),       # odd/even sizes, n = 1, 2
+    ('vpsde_geom_uncond_jodo', [44, 45, 7], {}),
+    ('vpsde_geom_uncond_jodo', [44, 45, 7, 1, 2], dict(nf=384)),             # width-generic pair kernels
+    ('vpsde_qm9_uncond_jodo', [1, 2, 3, 4, 9, 10, 18, 29, 28], dict(kernel_layout='wide')),
 ])
-def test_pair_path_equals_directed_path(cfg_name, n_nodes):
+def test_pair_path_equals_directed_path(cfg_name, n_nodes, over):
     """Symmetric inputs take the pair kernels (decided on the device); forcing the directed kernels on the
     same inputs must give the same result (and both match the oracle)."""
-    cfg = make_config(cfg_name)
+    cfg = make_config(cfg_name, **over)
     hp = O.Hyper.from_config(cfg)
     xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=11)
     m_pair = make_model(cfg, 3, DEV, gain=1.5, coord_scale=0.05)
