@@ -328,11 +328,8 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
         if (p->n_items > 0) {
             ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);
             if (p->n_pitems > 0) {
-                // the width-generic pair kernel (S parked per lane, node terms gathered per direction) measured
-                // faster than the LDS-slab variant of dgt_kernels_sym.h: 11.9 vs 12.6 ms/step at QM9 B = 2500
-                static const bool slab = getenv("JODO_UPDATE_SLAB") != nullptr;       // experiment switch
-                if (slab) { if (d.r == 2) LAUNCH(k_edge_update_sym<2>, p->n_pitems, 64, A); else LAUNCH(k_edge_update_sym<4>, p->n_pitems, 64, A); }
-                else { if (d.r == 2) LAUNCH((wide::k_edge_update_sym<256, 2>), p->n_pitems, 64, A); else LAUNCH((wide::k_edge_update_sym<256, 4>), p->n_pitems, 64, A); }
+                // the pair kernel is the width-generic one (S kept per lane, node terms gathered per direction)
+                if (d.r == 2) LAUNCH((wide::k_edge_update_sym<256, 2>), p->n_pitems, 64, A); else LAUNCH((wide::k_edge_update_sym<256, 4>), p->n_pitems, 64, A);
             }
             if (d.r == 2) LAUNCH(k_edge_update<2>, p->n_items, 64, A); else LAUNCH(k_edge_update<4>, p->n_items, 64, A);
         }

@@ -157,235 +157,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_scores_sym(KArgs A) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-template <int R>
-__global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
-    if (A.flags[FLAG_ASYM]) return;
-    const int lane = threadIdx.x & 63, jl = lane & 31, half = lane >> 5;
-    const int it = blockIdx.x;
-    const int strip = A.pd.pitem_strip[it], t0 = A.pd.pitem_t0[it], t1 = A.pd.pitem_t1[it];
-    const LaneNode L = lane_node(A, strip, jl);
-    const float* mrow = mod_row(A, L.b) + A.mod_base;
-    const float* eg1 = mrow + 6 * 256 + 2 * 64;
-    const float* qsh = mrow + 6 * 256 + 6 * 64;
-    const float gscale = mrow[6 * 256 + 6 * 64 + 2 * 256 + 0], gshift = mrow[6 * 256 + 6 * 64 + 2 * 256 + 1];
-    const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
-    const float cscale = A.W[A.wb[JB_CSCALE]];
-    const WSrc ws = make_wsrc(A.W, lane);
-    const unsigned o3 = (unsigned)(A.wb[JB_FF3_W] * 4), o4 = (unsigned)(A.wb[JB_FF4_W] * 4);
-    const unsigned oro = (unsigned)(A.wb[JB_ERO_W] * 4), oi = (unsigned)(A.wb[JB_INE_W] * 4), o0 = (unsigned)(A.wb[JB_C0_W] * 4);
-    constexpr int KQ4 = R * 64 / 8;
-    WPipe<8> wp;
-    wpipe_prime(wp, ws, o3);
-    __shared__ float4 pre1[32 * 64];                           // u of direction 1 (pre-LayerNorm) of this wave, [quad][lane]
-    PT_INIT
-    for (int t = t0; t < t1; ++t) {
-        const PairLane P = pair_of(L, t + 1);
-        const float* eg1_ = launder(eg1);
-        const float* es2_ = eg1_ + 64, *ec2_ = es2_ + 64, *eg2_ = ec2_ + 64;
-        const float* qsh_ = launder(qsh);
-        const float* qsc_ = qsh_ + 256;
-        const float* cst = launder(A.W);
-        const float* n2bias_ = cst + A.wb[JB_N2E_B], *b3_ = cst + A.wb[JB_FF3_B], *b4_ = cst + A.wb[JB_FF4_B];
-        const float* b0_ = cst + A.wb[JB_C0_B], *w2_ = cst + A.wb[JB_C2_W], *tab_ = cst + A.wb[JB_GBF];
-        const float* bro_ = cst + A.wb[JB_ERO_B];
-        TRow wrow_i = trow(A.wrow, 8, L.v, half), wcol_i = trow(A.wcol, 8, L.v, half);
-        wrow_i.p = launder(wrow_i.p); wcol_i.p = launder(wcol_i.p);
-        const TRow wrow_j = trow(A.wrow, 8, P.u, half), wcol_j = trow(A.wcol, 8, P.u, half);
-        const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[P.u];
-        const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
-        const float d2 = dx * dx + dy * dy + dz * dz;
-        float G[32];
-        gbf64(d2, gscale, gshift, tab_, half, G);
-        // ---- edge residual + LN2 + modulate (symmetric) ----
-        float en[32];
-        {
-            float e[32], n2a[32], n2c[32];
-            load_nat<2>(A.e + P.rij * 64, half, e);
-            {
-                const TRow ra = trow(A.n2e, 2, L.v, half), rc = trow(A.n2e, 2, P.u, half);
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    float ta[16], tc2[16];
-                    load16T(ra, b, ta);
-                    load16T(rc, b, tc2);
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) { n2a[b * 16 + s] = ta[s]; n2c[b * 16 + s] = tc2[s]; }
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                float g[16], bb[16];
-                load16(eg1_ + b * 32 + half * 16, g);
-                load16(n2bias_ + b * 32 + half * 16, bb);
-#pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    en[b * 16 + s] = fmaf(g[s], n2a[b * 16 + s] + n2c[b * 16 + s] + bb[s], e[b * 16 + s]);
-            }
-        }
-        layer_norm<32>(en);
-        modulate<2>(en, es2_, ec2_, half);
-        PT(0);
-        // ---- edge FFN ----
-        {
-            f32x16 o[2] = {zero16(), zero16()};
-            float ob4[32], og2[32];
-#pragma unroll
-            for (int c = 0; c < R; ++c) {
-                float hid[32];
-#pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2) {
-                    const unsigned wcur = o3 + (unsigned)(c * 2 + b2) * 8 * 1024;
-                    const unsigned wnx = b2 == 0 ? wcur + 8 * 1024 : o4 + (unsigned)(c * 8) * 1024;
-                    float bb[16];
-                    load16(b3_ + (c * 2 + b2) * 32 + half * 16, bb);
-                    f32x16 acc = mfma_block_p<8>(wp, ws, wcur, wnx, en, zero16());
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(acc[s] + bb[s]);
-                }
-                if (c == R - 1) {
-                    load_nat<2>(b4_, half, ob4);
-                    load_nat<2>(eg2_, half, og2);
-                }
-#pragma unroll
-                for (int ob = 0; ob < 2; ++ob) {
-                    const unsigned wcur = o4 + (unsigned)(ob * KQ4 + c * 8) * 1024;
-                    const unsigned wnx = ob == 0 ? o4 + (unsigned)(KQ4 + c * 8) * 1024
-                                                 : (c + 1 < R ? o3 + (unsigned)((c + 1) * 2) * 8 * 1024 : oro);
-                    o[ob] = mfma_block_p<8>(wp, ws, wcur, wnx, hid, o[ob]);
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    en[b * 16 + s] = fmaf(og2[b * 16 + s], o[b][s] + ob4[b * 16 + s], en[b * 16 + s]);
-        }
-        if (P.ok) {
-            store_nat<2>(A.e + P.rij * 64, half, en);
-            store_nat<2>(A.e + P.rji * 64, half, en);
-        }
-        PT(1);
-        // ---- readout ----
-        {
-            float bb[16];
-            load16(bro_ + half * 16, bb);
-            f32x16 acc = mfma_block_p<8>(wp, ws, oro, oi, en, zero16());
-            float rr[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) rr[s] = acc[s] + bb[s];
-            if (P.ok && half == 0) {
-                store16(A.ehid + P.rij * A.d.KEH + 64 + A.layer * 16, rr);
-                store16(A.ehid + P.rji * A.d.KEH + 64 + A.layer * 16, rr);
-            }
-        }
-        PT(2);
-        // ---- symmetric part of input_lin: S = W_e e + W_d G, shared by both directions.  The per-node terms
-        //      W_row h_a + W_col h_c of BOTH directions are gathered under these MFMAs; as soon as block b of S
-        //      is complete, u(dir 0) = S + (W_row h_i + W_col h_j) replaces the gathered terms in registers and
-        //      u(dir 1) = S + (W_row h_j + W_col h_i) is parked in this wave's LDS slab ----
-        float uu0[128];
-        {
-            f32x16 U[8];
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const unsigned wcur = oi + (unsigned)(b * 16) * 1024;
-                const unsigned wnx = b < 7 ? oi + (unsigned)((b + 1) * 16) * 1024 : oi + 8u * 1024;
-                float a1[16], a2[16];
-                load16T(wrow_i, b, a1);
-                load16T(wcol_j, b, a2);
-                U[b] = mfma_block_p<8>(wp, ws, wcur, wnx, en, zero16());
-#pragma unroll
-                for (int s = 0; s < 16; ++s) uu0[b * 16 + s] = a1[s] + a2[s];
-            }
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const unsigned wcur = oi + (unsigned)(b * 16 + 8) * 1024;
-                const unsigned wnx = b < 7 ? oi + (unsigned)((b + 1) * 16 + 8) * 1024 : o3;
-                U[b] = mfma_block_p<8>(wp, ws, wcur, wnx, G, U[b]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)          // S parked for direction 1 (its per-node terms are added later)
-                    pre1[(b * 4 + q) * 64 + lane] = make_float4(U[b][q * 4 + 0], U[b][q * 4 + 1], U[b][q * 4 + 2], U[b][q * 4 + 3]);
-#pragma unroll
-                for (int s = 0; s < 16; ++s) uu0[b * 16 + s] += U[b][s];
-            }
-        }
-        PT(3);
-        // ---- two directed evaluations of LN -> modulate -> coord_mlp ----
-#pragma unroll
-        for (int dir = 0; dir < 2; ++dir) {
-            float uu[128];
-            if (dir == 0) {
-#pragma unroll
-                for (int s = 0; s < 128; ++s) uu[s] = uu0[s];
-            } else {
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 t = pre1[(b * 4 + q) * 64 + lane];
-                        uu[b * 16 + q * 4 + 0] = t.x;
-                        uu[b * 16 + q * 4 + 1] = t.y;
-                        uu[b * 16 + q * 4 + 2] = t.z;
-                        uu[b * 16 + q * 4 + 3] = t.w;
-                    }
-            }
-            layer_norm<128>(uu);
-            modulate<8>(uu, qsh_, qsc_, half);
-            PT(4);
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-            // coord_mlp.0 runs on its own, deeper weight pipe (16 quads = 4096 MFMA cycles of cover): the
-            // per-node gathers issued in this loop come from HBM/MALL (~2 us) and, because vmcnt retires in
-            // order, would otherwise stall the weight stream once per block
-            WPipe<16> wc;
-            wpipe_prime(wc, ws, o0);
-#pragma unroll 1
-            for (int b = 0; b < 8; ++b) {
-                const unsigned wcur = o0 + (unsigned)b * 32 * 1024;
-                const unsigned wnx = b < 7 ? wcur + 32 * 1024 : o0;
-                float bb[16], k0[16], k1[16], k2[16];
-                load16(b0_ + b * 32 + half * 16, bb);
-                load16(w2_ + b * 32 + half * 16, k0);
-                load16(w2_ + 256 + b * 32 + half * 16, k1);
-                load16(w2_ + 512 + b * 32 + half * 16, k2);
-                float a1[16], a2[16];
-                if (dir == 0) {                          // direction 1's W_row h_j + W_col h_i, hidden under this block
-                    load16T(wrow_j, b, a1);
-                    load16T(wcol_i, b, a2);
-                }
-                f32x16 acc = mfma_block_p<32>(wc, ws, wcur, wnx, uu, zero16());
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const float ys = silu_f(acc[s] + bb[s]);
-                    c0 = fmaf(ys, k0[s], c0);
-                    c1 = fmaf(ys, k1[s], c1);
-                    c2 = fmaf(ys, k2[s], c2);
-                }
-                if (dir == 0) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 t = pre1[(b * 4 + q) * 64 + lane];
-                        pre1[(b * 4 + q) * 64 + lane] = make_float4(t.x + (a1[q * 4 + 0] + a2[q * 4 + 0]), t.y + (a1[q * 4 + 1] + a2[q * 4 + 1]),
-                                                                    t.z + (a1[q * 4 + 2] + a2[q * 4 + 2]), t.w + (a1[q * 4 + 3] + a2[q * 4 + 3]));
-                    }
-                }
-            }
-            PT(dir == 0 ? 5 : 7);
-            c0 = tanh_f(pair_sum(c0));
-            c1 = tanh_f(pair_sum(c1));
-            c2 = tanh_f(pair_sum(c2));
-            const size_t rr = dir == 0 ? P.rij : P.rji;
-            const int fl = A.eflag[rr];
-            const float iota = (c0 + ((fl & 1) ? c1 : 0.f) + ((fl & 2) ? c2 : 0.f)) * (1.f / 3.f);
-            const float nrm = fmaxf(sqrtf(d2), 1e-8f);
-            const float f = cscale * iota / nrm;
-            const float sgn = dir == 0 ? 1.f : -1.f;          // x_a - x_c
-            if (P.ok && half == 0)
-                reinterpret_cast<float4*>(A.dposE)[rr] = make_float4(sgn * dx * f, sgn * dy * f, sgn * dz * f, 0.f);
-            PT(6);
-        }
-    }
-    PT_FLUSH;
-}
+// The pair variant of the update kernel is width-generic: wide::k_edge_update_sym<D, R> in dgt_kernels_wide.h
+// (an earlier nf = 256-only version that parked direction 1 in an LDS slab measured 6 % slower and was removed).
 
 }  // namespace jd

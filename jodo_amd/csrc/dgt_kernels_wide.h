@@ -629,10 +629,10 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
 
 // ------------------------------------------------------------------------------------------------
 // Pair (symmetric-input) variants, see dgt_kernels_sym.h for the enumeration and the argument why the edge
-// state stays exactly symmetric.  Width-generic differences: weights streamed; the symmetric part S of
-// input_lin (D/2 values per lane) waits for direction 1 in PRIVATE memory (a per-lane array indexed with a
-// run-time block number, i.e. hardware scratch, L1/L2-resident) — at D = 384 four waves' slabs (4 x 48 KiB)
-// no longer fit the CU's 160 KiB LDS.
+// state stays exactly symmetric.  Weights are streamed; the symmetric part S of input_lin (D/2 values per
+// lane) is kept in a per-lane array for both directions (registers at D = 256, partly spilled to scratch at
+// D = 384 — four waves' LDS slabs of 48 KiB would not fit the CU's 160 KiB), and each direction requests its
+// per-node rows with buffer loads pinned ahead of their use (BRow, dgt_device.h).
 template <int D>
 __global__ __launch_bounds__(64, 1) void k_edge_scores_sym(KArgs A) {
     if (A.flags[FLAG_ASYM]) return;
