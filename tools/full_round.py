@@ -1,6 +1,6 @@
 """One complete sampling round through the public entry points (get_sampling_fn -> sampler -> fused decode):
 wall time of the whole round incl. decode and the device->host copies ("time one full round").
-Usage: python tools/full_round.py [qm9|geom|cond] [batch] [steps]"""
+Usage: python tools/full_round.py [qm9|geom|cond] [batch] [steps] [ancestral|fast]   (fast = hybrid DPM-solver, steps = NFE)"""
 import os, sys, time, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,6 +17,11 @@ cfg = configs.get(cfg_name)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else {'qm9': 2500, 'geom': 512, 'cond': 313}[which]
 if len(sys.argv) > 3:
     cfg.sampling.steps = int(sys.argv[3])
+if len(sys.argv) > 4:
+    cfg.sampling.method = sys.argv[4]
+    if sys.argv[4] == 'fast':                        # keys the reference's cond config lacks (values of the uncond config, :102-103)
+        cfg.sampling['dpm_solver_method'] = 'singlestep_fixed'
+        cfg.sampling['dpm_solver_order'] = 2
 dev = torch.device('cuda:0')
 cfg.device = dev
 torch.manual_seed(cfg.seed)
@@ -32,6 +37,8 @@ class _Prop:                                           # synthetic property samp
 
 fn = get_sampling_fn(cfg, ns, nodes_dist, B, B, get_data_inverse_scaler(cfg),
                      prop_dist=_Prop() if which == 'cond' else None, return_raw=True)
+if os.environ.get('WARM', '1') == '1':               # first call pays weight packing + first-touch costs
+    fn(model)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 mols = fn(model)
