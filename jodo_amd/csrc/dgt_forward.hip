@@ -204,7 +204,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     A.W = packed_w;
     for (int i = 0; i < JW_GLOBAL_COUNT; ++i) A.wg[i] = woff[i];
     for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = 0;
-    A.mod_base = 0; A.layer = 0; A.force_directed = p->force_directed; A.pre_mode = 0;
+    A.mod_base = 0; A.layer = 0; A.force_directed = p->force_directed; A.pre_mode = 0; A.strip0 = 0;
     fill_ws(A, p, workspace);
     float* posbuf[2] = {ws_ptr<float>(workspace, p->ws.pos0), ws_ptr<float>(workspace, p->ws.pos1)};
     A.pos_in = posbuf[0]; A.pos_out = posbuf[1];
@@ -299,13 +299,25 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
         { ProfScope ps(p, st, JODO_PROF_SOFTMAX); LAUNCH(k_softmax, (p->Nn + 15) / 16, 256, A); }
         if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_MSGS); LAUNCH(k_edge_msgs, (p->n_items + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A); }
         { ProfScope ps(p, st, JODO_PROF_NODE_POST);
-          // waves per strip: 4 for few strips (small batch), else 1 (measured on MI355X: 4-wave 1.0 vs 1.7 ms/step at
-          // 177 strips, but 4.1 vs 3.6 ms/step at 1409 strips)
-          static const char* force = getenv("JODO_NODE_POST");                     // experiment switch: "1", "2" or "4"
-          const int nw = force ? force[0] - '0' : (p->n_strips > 512 ? 1 : 4);
-          if (nw == 1) { if (d.r == 2) LAUNCH(k_node_post<2>, p->n_strips, 64, A); else LAUNCH(k_node_post<4>, p->n_strips, 64, A); }
-          else if (nw == 2) { if (d.r == 2) LAUNCH((k_node_postw<2, 2>), p->n_strips, 128, A); else LAUNCH((k_node_postw<4, 2>), p->n_strips, 128, A); }
-          else { if (d.r == 2) LAUNCH((k_node_postw<2, 4>), p->n_strips, 256, A); else LAUNCH((k_node_postw<4, 4>), p->n_strips, 256, A); } }
+          // One wave per strip for every full round of 1024 strips (one per SIMD); the remainder r — which would
+          // otherwise occupy r SIMDs for a whole item while the rest idle — goes to a second launch in which a
+          // workgroup of 4 (r <= 256) or 2 (r <= 512) waves shares each strip.  Measured on MI355X: 177 strips
+          // 1.7 -> 0.75 ms/step with 4 waves; all 1409 strips with 2 / 4 waves 3.7 / 4.1 vs 3.6 ms/step with 1.
+          static const char* force = getenv("JODO_NODE_POST");                     // experiment switch: "1", "2" or "4" for all strips
+          const int full = force ? (force[0] == '1' ? p->n_strips : 0) : (p->n_strips / 1024) * 1024;
+          const int rem = p->n_strips - full;
+          const int nw = force ? force[0] - '0' : (rem <= 256 ? 4 : (rem <= 512 ? 2 : 1));
+          if (full > 0) {
+              A.strip0 = 0;
+              if (d.r == 2) LAUNCH(k_node_post<2>, full, 64, A); else LAUNCH(k_node_post<4>, full, 64, A);
+          }
+          if (rem > 0) {
+              A.strip0 = full;
+              if (nw == 1) { if (d.r == 2) LAUNCH(k_node_post<2>, rem, 64, A); else LAUNCH(k_node_post<4>, rem, 64, A); }
+              else if (nw == 2) { if (d.r == 2) LAUNCH((k_node_postw<2, 2>), rem, 128, A); else LAUNCH((k_node_postw<4, 2>), rem, 128, A); }
+              else { if (d.r == 2) LAUNCH((k_node_postw<2, 4>), rem, 256, A); else LAUNCH((k_node_postw<4, 4>), rem, 256, A); }
+          }
+          A.strip0 = 0; }
         if (overlap && l + 1 < nblocks) {
             // fork: q/k/v of block l + 1 on the helper stream, concurrently with this block's edge update (whose
             // last partial round of work items leaves most SIMDs idle)

@@ -15,6 +15,7 @@ struct KArgs {
     int64_t mod_base;                     // offset of the current block inside a modulation vector
     int layer;
     int force_directed;                   // debug: never take the symmetric pair path
+    int strip0;                           // k_node_post*: first strip of this launch (a layer's strips may be split over two launches)
     int pre_mode;                         // k_node_pre: 0 = also advance the positions, 1 = q/k/v only (k_pos_final did it)
     // workspace
     float *hid1, *temb, *mods, *condh, *condh2;

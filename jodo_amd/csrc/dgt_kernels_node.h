@@ -96,7 +96,7 @@ __device__ __forceinline__ void node_residual_ln(const KArgs& A, const LaneNode&
 template <int R>   // mlp_ratio
 __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int strip = blockIdx.x;
+    const int strip = blockIdx.x + A.strip0;
     const LaneNode L = lane_node(A, strip, j);
     const float* mr = mod_row(A, L.b) + A.mod_base;
     const float* ng2 = mr + 5 * 256;
@@ -235,7 +235,7 @@ template <int R, int NW>   // mlp_ratio, waves per strip (2 or 4)
 __global__ __launch_bounds__(NW * 64, 1) void k_node_postw(KArgs A) {
     __shared__ float4 part[NW * 8 * 4 * 64];                  // [NW waves][8 blocks][4 quads][64 lanes] = NW x 32 KiB
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
-    const int strip = blockIdx.x;
+    const int strip = blockIdx.x + A.strip0;
     const LaneNode L = lane_node(A, strip, j);
     const float* mr = mod_row(A, L.b) + A.mod_base;
     const float* ng2 = mr + 5 * 256;
