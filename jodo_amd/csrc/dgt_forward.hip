@@ -95,6 +95,26 @@ int launch_edge_head(hipStream_t st, const KArgs& A) {
     return JODO_OK;
 }
 
+// Pair update: every full round of 1024 one-iteration items (one per SIMD) in one launch; the items of the last,
+// sparsely filled round in a second launch with two workgroups per item, one direction each (both recompute the
+// shared trunk: item time x 0.64).  At QM9 B = 2500 a launch has 13 400 items = 13 full rounds + 88.
+template <int D>
+int launch_update_sym(jodo_plan* p, hipStream_t st, KArgs& A) {
+    const DgtDims& d = p->dims;
+    static const bool nosplit = getenv("JODO_NO_DIR_SPLIT") != nullptr;      // experiment switch
+    const int full = (p->n_pitems / 1024) * 1024, rem = p->n_pitems - full;
+    const bool split = !nosplit && rem > 0 && rem <= 512;
+    const int n1 = split ? full : p->n_pitems;
+    A.item0 = 0; A.dir_split = 0;
+    if (n1 > 0) { if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2>), n1, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4>), n1, 64, A); }
+    if (split) {
+        A.item0 = full; A.dir_split = 1;
+        if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2>), 2 * rem, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4>), 2 * rem, 64, A);
+        A.item0 = 0; A.dir_split = 0;
+    }
+    return JODO_OK;
+}
+
 // ---- width-generic kernel set (dgt_kernels_wide.h): everything after the time/modulation prologue ----
 template <int D, int KQ>
 int launch_embed_nodes_w(hipStream_t st, const KArgs& A) {
@@ -147,7 +167,8 @@ int forward_wide(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, fl
         if (p->n_items > 0) {
             ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);
             if (p->n_pitems > 0) {
-                if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2>), p->n_pitems, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4>), p->n_pitems, 64, A);
+                rc = launch_update_sym<D>(p, st, A);
+                if (rc) return rc;
             }
             if (d.r == 2) LAUNCH((wide::k_edge_update<D, 2>), p->n_items, 64, A); else LAUNCH((wide::k_edge_update<D, 4>), p->n_items, 64, A);
         }
@@ -204,7 +225,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     A.W = packed_w;
     for (int i = 0; i < JW_GLOBAL_COUNT; ++i) A.wg[i] = woff[i];
     for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = 0;
-    A.mod_base = 0; A.layer = 0; A.force_directed = p->force_directed; A.pre_mode = 0; A.strip0 = 0;
+    A.mod_base = 0; A.layer = 0; A.force_directed = p->force_directed; A.pre_mode = 0; A.strip0 = 0; A.item0 = 0; A.dir_split = 0;
     fill_ws(A, p, workspace);
     float* posbuf[2] = {ws_ptr<float>(workspace, p->ws.pos0), ws_ptr<float>(workspace, p->ws.pos1)};
     A.pos_in = posbuf[0]; A.pos_out = posbuf[1];
@@ -341,7 +362,8 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
             ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);
             if (p->n_pitems > 0) {
                 // the pair kernel is the width-generic one (S kept per lane, node terms gathered per direction)
-                if (d.r == 2) LAUNCH((wide::k_edge_update_sym<256, 2>), p->n_pitems, 64, A); else LAUNCH((wide::k_edge_update_sym<256, 4>), p->n_pitems, 64, A);
+                rc = launch_update_sym<256>(p, st, A);
+                if (rc) return rc;
             }
             if (d.r == 2) LAUNCH(k_edge_update<2>, p->n_items, 64, A); else LAUNCH(k_edge_update<4>, p->n_items, 64, A);
         }

@@ -16,6 +16,7 @@ struct KArgs {
     int layer;
     int force_directed;                   // debug: never take the symmetric pair path
     int strip0;                           // k_node_post*: first strip of this launch (a layer's strips may be split over two launches)
+    int item0, dir_split;                 // pair update: first item of this launch; 1 = two workgroups per item, one direction each
     int pre_mode;                         // k_node_pre: 0 = also advance the positions, 1 = q/k/v only (k_pos_final did it)
     // workspace
     float *hid1, *temb, *mods, *condh, *condh2;

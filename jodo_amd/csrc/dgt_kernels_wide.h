@@ -739,7 +739,10 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
     constexpr int NCH = R * X::De / 64;
     constexpr int KQ4 = R * X::De / 8;
     const int lane = threadIdx.x & 63, jl = lane & 31, half = lane >> 5;
-    const int it = blockIdx.x;
+    // dir_split: the items of a launch's sparsely filled last round get two workgroups each; both compute the
+    // shared trunk, each evaluates one direction (item time x 0.64) — the trunk's stores come from direction 0
+    const int it = A.item0 + (A.dir_split ? (int)(blockIdx.x >> 1) : (int)blockIdx.x);
+    const int dsel = A.dir_split ? (int)(blockIdx.x & 1) : -1;
     const int strip = A.pd.pitem_strip[it], t0 = A.pd.pitem_t0[it], t1 = A.pd.pitem_t1[it];
     const LaneNode L = lane_node(A, strip, jl);
     const float* mrow = mod_row(A, L.b) + A.mod_base;
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                 for (int s = 0; s < 16; ++s) en[b * 16 + s] = fmaf(og2[s], o[b][s] + ob4[s], en[b * 16 + s]);
             }
         }
-        if (P.ok) {
+        if (P.ok && dsel != 1) {
             store_nat<X::NE>(A.e + P.rij * X::De, half, en);
             store_nat<X::NE>(A.e + P.rji * X::De, half, en);
         }
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             float rr[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) rr[s] = acc[s] + bb[s];
-            if (P.ok && (half == 0 || X::CEP == 32)) {
+            if (P.ok && dsel != 1 && (half == 0 || X::CEP == 32)) {
                 store16(A.ehid + P.rij * A.d.KEH + X::De + A.layer * X::CEP + half * 16, rr);
                 store16(A.ehid + P.rji * A.d.KEH + X::De + A.layer * X::CEP + half * 16, rr);
             }
@@ -858,6 +861,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
         // ---- two directed evaluations: u = S + W_row h_a + W_col h_c -> LN -> modulate -> coord_mlp ----
 #pragma unroll 1
         for (int dir = 0; dir < 2; ++dir) {
+            if (dsel >= 0 && dir != dsel) continue;
             BRow ra = wrow_i, rc = wcol_j;
             if (dir == 1) { ra.voff = wrow_j.voff; rc.voff = wcol_i.voff; }
             float uu[X::HD];
@@ -886,7 +890,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
 #pragma unroll 1
             for (int b = 0; b < X::ND; ++b) {
                 const unsigned wcur = o0 + (unsigned)b * X::KQD * 1024;
-                const unsigned wnx = b + 1 < X::ND ? wcur + X::KQD * 1024 : (dir == 0 ? o0 : o3);
+                const unsigned wnx = b + 1 < X::ND ? wcur + X::KQD * 1024 : ((dir == 0 && dsel < 0) ? o0 : o3);
                 float bb[16], k0[16], k1[16], k2[16];
                 load16(b0_ + b * 32 + half * 16, bb);
                 load16(w2_ + b * 32 + half * 16, k0);
