@@ -931,18 +931,26 @@ __global__ __launch_bounds__(64, 1) void k_node_head(KArgs A) {
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
     const int v = blockIdx.x * 32 + j;
     const int KNH = A.d.KNH;
+    const WSrc ws = make_wsrc(A.W, lane);
+    const unsigned o1 = (unsigned)(A.wg[JW_NH1_W] * 4), o2 = (unsigned)(A.wg[JW_NH2_W] * 4), o3 = (unsigned)(A.wg[JW_NH3_W] * 4);
+    WPipe<4> wp;
+    wpipe_prime(wp, ws, o1);
     f32x16 o[X::ND];
 #pragma unroll
     for (int b = 0; b < X::ND; ++b) o[b] = zero16();
     {
-        const float4* w = wq(A, A.wg[JW_NH1_W], lane);
-        const int kq = KNH / 8;
+        const int kq = KNH / 8, nch = KNH / 64;
 #pragma unroll 1
-        for (int c = 0; c < KNH / 64; ++c) {
+        for (int c = 0; c < nch; ++c) {
             float x[32];
             load_nat<2>(A.ahid + (size_t)v * KNH + c * 64, half, x);
 #pragma unroll
-            for (int ob = 0; ob < X::ND; ++ob) o[ob] = mfma_block<8>(w + ((size_t)ob * kq + c * 8) * 64, x, o[ob]);
+            for (int ob = 0; ob < X::ND; ++ob) {
+                const unsigned cur = o1 + (unsigned)(ob * kq + c * 8) * 1024;
+                const unsigned nxt = ob + 1 < X::ND ? o1 + (unsigned)((ob + 1) * kq + c * 8) * 1024
+                                                    : (c + 1 < nch ? o1 + (unsigned)((c + 1) * 8) * 1024 : o2);
+                o[ob] = mfma_block_p<8>(wp, ws, cur, nxt, x, o[ob]);
+            }
         }
     }
     float a1[X::HD];
@@ -958,11 +966,11 @@ __global__ __launch_bounds__(64, 1) void k_node_head(KArgs A) {
     }
     float a2[X::HD / 2];
     {
-        const float4* w = wq(A, A.wg[JW_NH2_W], lane);
         const float* bias = A.W + A.wg[JW_NH2_B];
 #pragma unroll
         for (int b = 0; b < X::ND / 2; ++b) {
-            f32x16 acc = mfma_block<X::KQD>(w + (size_t)b * X::KQD * 64, a1, zero16());
+            const unsigned cur = o2 + (unsigned)(b * X::KQD) * 1024;
+            f32x16 acc = mfma_block_p<X::KQD>(wp, ws, cur, b + 1 < X::ND / 2 ? cur + X::KQD * 1024 : o3, a1, zero16());
             float r[16];
             acc_bias(acc, bias + b * 32 + half * 16, r);
 #pragma unroll
@@ -970,7 +978,7 @@ __global__ __launch_bounds__(64, 1) void k_node_head(KArgs A) {
         }
     }
     {
-        f32x16 acc = mfma_block<X::KQD / 2>(wq(A, A.wg[JW_NH3_W], lane), a2, zero16());
+        f32x16 acc = mfma_block_p<X::KQD / 2>(wp, ws, o3, o3, a2, zero16());
         float r[16];
         acc_bias(acc, A.W + A.wg[JW_NH3_B] + half * 16, r);
         store16(A.apred + (size_t)v * 32 + half * 16, r);
@@ -982,15 +990,19 @@ __global__ __launch_bounds__(64, 1) void k_edge_head(KArgs A) {
     using X = Dim<D>;
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
     const size_t r = (size_t)blockIdx.x * 32 + j;
+    const WSrc ws = make_wsrc(A.W, lane);
+    const unsigned o1 = (unsigned)(A.wg[JW_EH1_W] * 4), o2 = (unsigned)(A.wg[JW_EH2_W] * 4), o3 = (unsigned)(A.wg[JW_EH3_W] * 4);
+    WPipe<4> wp;
+    wpipe_prime(wp, ws, o1);
     float x[NBK * 16];
     load_nat<NBK>(A.ehid + r * (NBK * 32), half, x);
     float a1[X::De];                                       // [exist De | type De] hidden, half of it per half-lane
     {
-        const float4* w = wq(A, A.wg[JW_EH1_W], lane);
         const float* bias = A.W + A.wg[JW_EH1_B];
 #pragma unroll
         for (int b = 0; b < 2 * X::NE; ++b) {
-            f32x16 acc = mfma_block<NBK * 4>(w + (size_t)b * (NBK * 4) * 64, x, zero16());
+            const unsigned cur = o1 + (unsigned)(b * NBK * 4) * 1024;
+            f32x16 acc = mfma_block_p<NBK * 4>(wp, ws, cur, b + 1 < 2 * X::NE ? cur + (unsigned)(NBK * 4) * 1024 : o2, x, zero16());
             float rr[16];
             acc_bias(acc, bias + b * 32 + half * 16, rr);
 #pragma unroll
@@ -999,11 +1011,11 @@ __global__ __launch_bounds__(64, 1) void k_edge_head(KArgs A) {
     }
     float a2[X::De / 2];
     {
-        const float4* w = wq(A, A.wg[JW_EH2_W], lane);
         const float* bias = A.W + A.wg[JW_EH2_B];
 #pragma unroll
         for (int b = 0; b < X::NE; ++b) {
-            f32x16 acc = mfma_block<X::De / 4>(w + (size_t)b * (X::De / 4) * 64, a1, zero16());
+            const unsigned cur = o2 + (unsigned)(b * (X::De / 4)) * 1024;
+            f32x16 acc = mfma_block_p<X::De / 4>(wp, ws, cur, b + 1 < X::NE ? cur + (unsigned)(X::De / 4) * 1024 : o3, a1, zero16());
             float rr[16];
             acc_bias(acc, bias + b * 32 + half * 16, rr);
 #pragma unroll
@@ -1011,7 +1023,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_head(KArgs A) {
         }
     }
     {
-        f32x16 acc = mfma_block<X::De / 8>(wq(A, A.wg[JW_EH3_W], lane), a2, zero16());
+        f32x16 acc = mfma_block_p<X::De / 8>(wp, ws, o3, o3, a2, zero16());
         float rr[16];
         acc_bias(acc, A.W + A.wg[JW_EH3_B] + half * 16, rr);
         if (half == 0 && r < (size_t)A.pd.rows)
