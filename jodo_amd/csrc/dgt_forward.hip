@@ -314,7 +314,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
         cur ^= 1;                                  // the block's positions are in pos_out now
         if (p->n_items > 0) {
             ProfScope ps(p, st, JODO_PROF_EDGE_SCORES);           // exactly one of the two does the work (device flag)
-            if (p->n_sitems > 0) LAUNCH(k_edge_scores_sym, (p->n_sitems + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A);
+            if (p->n_sitems > 0) LAUNCH(k_edge_scores_sym, (p->n_sitems + SYM_WAVES - 1) / SYM_WAVES, SYM_WAVES * 64, A);
             LAUNCH(k_edge_scores, (p->n_items + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A);
         }
         { ProfScope ps(p, st, JODO_PROF_SOFTMAX); LAUNCH(k_softmax, (p->Nn + 15) / 16, 256, A); }

@@ -22,9 +22,9 @@ namespace jd {
 // 256 B of weights per MFMA at K = 64).
 constexpr int WG_WAVES = 8;
 
-template <int NQ>   // cooperative copy of NQ quads (1 KiB each) global -> LDS
+template <int NQ, int NW = WG_WAVES>   // cooperative copy of NQ quads (1 KiB each) global -> LDS by NW waves
 __device__ __forceinline__ void stage_weights(float4* __restrict__ dst, const float4* __restrict__ src) {
-    for (int i = threadIdx.x; i < NQ * 64; i += WG_WAVES * 64) dst[i] = src[i];
+    for (int i = threadIdx.x; i < NQ * 64; i += NW * 64) dst[i] = src[i];
 }
 
 template <int KQ>

@@ -47,14 +47,35 @@ __device__ __forceinline__ PairLane pair_of(const LaneNode& L, int d) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_scores_sym(KArgs A) {
+constexpr int SYM_WAVES = 4;      // one wave per SIMD with the full register file: no spills, gathers pinned ahead
+
+// LDS weights with the read of quad q + 1 pinned ahead of the MFMAs of quad q: with a single wave per SIMD
+// nothing else hides the ds_read latency (hipcc emits ds_read -> s_waitcnt lgkmcnt(0) -> 4 MFMAs otherwise)
+template <int KQ>
+__device__ __forceinline__ f32x16 mfma_block_lds_p(const float4* wl, const float (&act)[KQ * 4], f32x16 acc) {
+    float4 a = wl[0];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        float4 nx = a;
+        if (q + 1 < KQ) nx = wl[(q + 1) * 64];
+        pipeline_fence();
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, act[4 * q + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, act[4 * q + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, act[4 * q + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, act[4 * q + 3], acc, 0, 0, 0);
+        a = nx;
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(SYM_WAVES * 64, 1) void k_edge_scores_sym(KArgs A) {
     if (A.flags[FLAG_ASYM]) return;
     __shared__ float4 wl[(32 + 64) * 64];                       // edge_emb (2 x 16 quads) | lin_edge0 (8 x 8 quads)
-    stage_weights<32>(wl, reinterpret_cast<const float4*>(A.W + A.wb[JB_EE_W]));
-    stage_weights<64>(wl + 32 * 64, reinterpret_cast<const float4*>(A.W + A.wb[JB_LE0_W]));
+    stage_weights<32, SYM_WAVES>(wl, reinterpret_cast<const float4*>(A.W + A.wb[JB_EE_W]));
+    stage_weights<64, SYM_WAVES>(wl + 32 * 64, reinterpret_cast<const float4*>(A.W + A.wb[JB_LE0_W]));
     __syncthreads();
     const int lane = threadIdx.x & 63, jl = lane & 31, half = lane >> 5;
-    const int it = blockIdx.x * WG_WAVES + (threadIdx.x >> 6);
+    const int it = blockIdx.x * SYM_WAVES + (threadIdx.x >> 6);
     if (it >= A.pd.n_sitems) return;
     const int strip = A.pd.sitem_strip[it], t0 = A.pd.sitem_t0[it], t1 = A.pd.sitem_t1[it];
     const LaneNode L = lane_node(A, strip, jl);
@@ -70,9 +91,8 @@ __global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_scores_sym(KArgs A) {
         const float* cst = launder(A.W);
         const float* tab = cst + A.wb[JB_GBF];
         const float* bEE = cst + A.wb[JB_EE_B];
-        TRow qi = trow(A.q, 8, L.v, half), ki = trow(A.k, 8, L.v, half);
-        qi.p = launder(qi.p); ki.p = launder(ki.p);
-        const TRow qj = trow(A.q, 8, P.u, half), kj = trow(A.k, 8, P.u, half);
+        const BRow qi = brow(A.q, 8, L.v, half), ki = brow(A.k, 8, L.v, half);
+        const BRow qj = brow(A.q, 8, P.u, half), kj = brow(A.k, 8, P.u, half);
         const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[P.u];
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
         float x[32];
@@ -84,8 +104,8 @@ __global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_scores_sym(KArgs A) {
             for (int b = 0; b < 2; ++b) {
                 float bb[16];
                 load16(bEE + b * 32 + half * 16, bb);
-                f32x16 acc = mfma_block_lds<8>(wEE + (b * 16) * 64, G, zero16());
-                acc = mfma_block_lds<8>(wEE + (b * 16 + 8) * 64, e, acc);
+                f32x16 acc = mfma_block_lds_p<8>(wEE + (b * 16) * 64, G, zero16());
+                acc = mfma_block_lds_p<8>(wEE + (b * 16 + 8) * 64, e, acc);
 #pragma unroll
                 for (int s = 0; s < 16; ++s) x[b * 16 + s] = acc[s] + bb[s];
             }
@@ -99,16 +119,17 @@ __global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_scores_sym(KArgs A) {
         // tanh(lin_edge0) once; direction 1 = edge (j -> i): q_i . k_j ; direction 2 = edge (i -> j): q_j . k_i
         float m1[7], m2[7];
         float qin[16], kin[16], qjn[16], kjn[16];
-        load16T(qi, 0, qin); load16T(ki, 0, kin);
-        load16T(qj, 0, qjn); load16T(kj, 0, kjn);
+        bload16(qi, 0, qin); bload16(ki, 0, kin);
+        bload16(qj, 0, qjn); bload16(kj, 0, kjn);
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
             float a1[16], a2[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) { a1[s] = qin[s] * kjn[s]; a2[s] = qjn[s] * kin[s]; }
-            load16T(qi, b + 1, qin); load16T(ki, b + 1, kin);
-            load16T(qj, b + 1, qjn); load16T(kj, b + 1, kjn);
-            f32x16 acc = mfma_block_lds<8>(wL0 + (b * 8) * 64, x, zero16());
+            bload16(qi, b + 1, qin); bload16(ki, b + 1, kin);
+            bload16(qj, b + 1, qjn); bload16(kj, b + 1, kjn);
+            pipeline_fence();
+            f32x16 acc = mfma_block_lds_p<8>(wL0 + (b * 8) * 64, x, zero16());
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
@@ -121,7 +142,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_scores_sym(KArgs A) {
         }
         float tl1[14], tl2[14];
         {
-            f32x16 acc = mfma_block_lds<8>(wL0 + (7 * 8) * 64, x, zero16());
+            f32x16 acc = mfma_block_lds_p<8>(wL0 + (7 * 8) * 64, x, zero16());
 #pragma unroll
             for (int g = 0; g < 14; ++g) {
                 const float tt = tanh_f(acc[g]);

@@ -111,7 +111,8 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         while (max_chunk > 2 && strip_nmax_sum / max_chunk < 2048) --max_chunk;
     }
     if (pair_chunk <= 0) pair_chunk = 1;     // measured best on MI355X (QM9 B=2500: 26.7 ms/step vs 27.7 at 2)
-    if (spair_chunk <= 0) spair_chunk = pair_chunk;   // sweep on MI355X: 1 and 4 tie, 6 is 35 % slower
+    const bool spair_auto = spair_chunk <= 0;
+    if (spair_chunk <= 0) spair_chunk = 2;   // 4-wave workgroups stage 96 KiB of weights: 2 offsets per item (sweep: 1 -> 2.97, 2 -> 2.71, 3 -> 2.85 ms/step)
     p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->prof_enabled = 0; p->force_directed = 0; p->dbg_timing = nullptr;
 
     // molecules by descending size (stable): neighbouring lanes share n, big work first
@@ -176,6 +177,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         permute(pi_strip, ord); permute(pi_t0, ord); permute(pi_t1, ord);
     }
     std::vector<int32_t> si_strip, si_t0, si_t1;
+    if (spair_auto && (int64_t)p->n_pitems / 2 < 2048) spair_chunk = 1;      // small batch: keep >= 2 items per SIMD
     for (int s = 0; s < p->n_strips; ++s) {
         int nmax = 0;
         for (int j = 0; j < 32; ++j) nmax = std::max(nmax, (int)node_n[s * 32 + j]);
@@ -187,8 +189,8 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         for (int q = 0; q < parts; ++q) { si_strip.push_back(s); si_t0.push_back(q * chunk); si_t1.push_back(std::min(dmax, (q + 1) * chunk)); }
     }
     p->n_sitems = (int)si_strip.size();
-    {   // eight pair-scores items per workgroup
-        const std::vector<int> ord = xcd_order(si_strip, 8);
+    {   // four pair-scores items per workgroup
+        const std::vector<int> ord = xcd_order(si_strip, 4);
         permute(si_strip, ord); permute(si_t0, ord); permute(si_t1, ord);
     }
 
