@@ -655,9 +655,8 @@ __global__ __launch_bounds__(64, 1) void k_edge_scores_sym(KArgs A) {
         const float* cst = launder(A.W);
         const float* tab = cst + A.wb[JB_GBF];
         const float* bEE = cst + A.wb[JB_EE_B];
-        TRow qi = trow(A.q, NHEAD_BLOCKS, L.v, half), ki = trow(A.k, NHEAD_BLOCKS, L.v, half);
-        qi.p = launder(qi.p); ki.p = launder(ki.p);
-        const TRow qj = trow(A.q, NHEAD_BLOCKS, P.u, half), kj = trow(A.k, NHEAD_BLOCKS, P.u, half);
+        const BRow qi = brow(A.q, NHEAD_BLOCKS, L.v, half), ki = brow(A.k, NHEAD_BLOCKS, L.v, half);
+        const BRow qj = brow(A.q, NHEAD_BLOCKS, P.u, half), kj = brow(A.k, NHEAD_BLOCKS, P.u, half);
         const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[P.u];
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
         float x[X::HE];
@@ -685,16 +684,16 @@ __global__ __launch_bounds__(64, 1) void k_edge_scores_sym(KArgs A) {
         // tanh(lin_edge0) once; direction 1 = edge (j -> i): q_i . k_j ; direction 2 = edge (i -> j): q_j . k_i
         float Sg1[NHEAD_BLOCKS], Sg2[NHEAD_BLOCKS];
         float qin[16], kin[16], qjn[16], kjn[16];
-        load16T(qi, 0, qin); load16T(ki, 0, kin);
-        load16T(qj, 0, qjn); load16T(kj, 0, kjn);
+        bload16(qi, 0, qin); bload16(ki, 0, kin);
+        bload16(qj, 0, qjn); bload16(kj, 0, kjn);
 #pragma unroll
         for (int g = 0; g < NHEAD_BLOCKS; ++g) {
             float a1[16], a2[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) { a1[s] = qin[s] * kjn[s]; a2[s] = qjn[s] * kin[s]; }
             if (g + 1 < NHEAD_BLOCKS) {
-                load16T(qi, g + 1, qin); load16T(ki, g + 1, kin);
-                load16T(qj, g + 1, qjn); load16T(kj, g + 1, kjn);
+                bload16(qi, g + 1, qin); bload16(ki, g + 1, kin);
+                bload16(qj, g + 1, qjn); bload16(kj, g + 1, kjn);
             }
             const unsigned cur = oL0 + (unsigned)(g * X::KQE) * 1024;
             f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cur, g + 1 < NHEAD_BLOCKS ? cur + X::KQE * 1024 : oEE, x, zero16());
