@@ -151,6 +151,17 @@ int jodo_sampler_step(int B, int N, int node_feats, int edge_ch, const int32_t* 
                       float sigma, const float* x, const float* edge_x, const float* pred, const float* edge_pred,
                       const float* eps_pos, const float* eps_feat, const float* eps_edge, float* x_next,
                       float* edge_next, float* x_mean, float* edge_mean, void* stream);
+/* Graph-replayable form of the same update: the per-step scalars come from a device table
+ * coef_tab_dev [steps][4] = (c_x, c_pred, sigma, noise_level) at row *step_dev, so ONE captured hipGraph of a
+ * sampling step (jodo_step_begin -> jodo_dgt_forward -> noise draws -> jodo_sampler_step_tab -> jodo_step_end)
+ * serves every step.  jodo_step_begin writes noise_level[b] = tab[*step][3] for the forward; jodo_step_end
+ * increments *step_dev. */
+int jodo_sampler_step_tab(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, const float* coef_tab_dev,
+                          const int32_t* step_dev, const float* x, const float* edge_x, const float* pred,
+                          const float* edge_pred, const float* eps_pos, const float* eps_feat, const float* eps_edge,
+                          float* x_next, float* edge_next, float* x_mean, float* edge_mean, void* stream);
+int jodo_step_begin(int B, const float* coef_tab_dev, const int32_t* step_dev, float* noise_level_out, void* stream);
+int jodo_step_end(int32_t* step_dev, void* stream);
 int jodo_decode(int B, int N, int atom_types, int include_fc, int edge_ch, int compress_edge, int centered,
                 float pos_norm, float atom_norm, float fc_norm, float edge_norm, const int32_t* n_nodes_dev,
                 const float* xh, const float* edge_x, float* pos_out, uint8_t* atom_type_out, int8_t* fc_out,

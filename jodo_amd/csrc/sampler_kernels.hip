@@ -22,11 +22,15 @@
 namespace {
 
 // one workgroup per molecule: mean / next state of the node tensor [N, F] (F = 3 + nd)
+// coef (optional): device table [steps][4] = (c_x, c_pred, sigma, noise_level), row *step — lets a captured
+// HIP graph of one sampling step be replayed for every step (host scalars would be baked into the graph)
 __global__ __launch_bounds__(256) void k_step_nodes(int N, int F, const int* __restrict__ n_nodes, float c_x, float c_pred,
-                                                    float sigma, const float* __restrict__ x, const float* __restrict__ pred,
+                                                    float sigma, const float* __restrict__ coef, const int* __restrict__ step,
+                                                    const float* __restrict__ x, const float* __restrict__ pred,
                                                     const float* __restrict__ eps_pos, const float* __restrict__ eps_feat,
                                                     float* __restrict__ x_next, float* __restrict__ x_mean) {
     const int b = blockIdx.x, n = n_nodes[b], nd = F - 3;
+    if (coef) { const float* c = coef + 4 * (size_t)(*step); c_x = c[0]; c_pred = c[1]; sigma = c[2]; }
     __shared__ float red[3][256];
     // centre of mass of the masked position noise: sum over real atoms / n  (remove_mean_with_mask)
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -60,12 +64,14 @@ __global__ __launch_bounds__(256) void k_step_nodes(int N, int F, const int* __r
 
 // one thread per (b, a, c, f) of the edge tensor [B, N, N, ch]; eps_edge is the raw draw [B, ch, N, N]
 __global__ __launch_bounds__(256) void k_step_edges(int B, int N, int ch, const int* __restrict__ n_nodes, float c_x, float c_pred,
-                                                    float sigma, const float* __restrict__ ex, const float* __restrict__ epred,
+                                                    float sigma, const float* __restrict__ coef, const int* __restrict__ step,
+                                                    const float* __restrict__ ex, const float* __restrict__ epred,
                                                     const float* __restrict__ eps, float* __restrict__ e_next,
                                                     float* __restrict__ e_mean) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t NN = (size_t)N * N, tot = (size_t)B * NN * ch;
     if (g >= tot) return;
+    if (coef) { const float* c = coef + 4 * (size_t)(*step); c_x = c[0]; c_pred = c[1]; sigma = c[2]; }
     const int f = (int)(g % ch);
     const size_t cell = g / ch;
     const int c = (int)(cell % N), a = (int)((cell / N) % N), b = (int)(cell / NN);
@@ -153,23 +159,60 @@ __global__ __launch_bounds__(256) void k_decode_edges(DecodeArgs A, const int* _
 
 }  // namespace
 
-extern "C" int jodo_sampler_step(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, float c_x, float c_pred,
-                                 float sigma, const float* x, const float* edge_x, const float* pred, const float* edge_pred,
-                                 const float* eps_pos, const float* eps_feat, const float* eps_edge, float* x_next,
-                                 float* edge_next, float* x_mean, float* edge_mean, void* stream) {
+namespace {
+__global__ void k_step_begin(int B, const float* __restrict__ coef, const int* __restrict__ step, float* __restrict__ noise_level) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) noise_level[b] = coef[4 * (size_t)(*step) + 3];
+}
+__global__ void k_step_end(int* step) { *step += 1; }
+
+int sampler_step_launch(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, float c_x, float c_pred, float sigma,
+                        const float* coef, const int32_t* step, const float* x, const float* edge_x, const float* pred,
+                        const float* edge_pred, const float* eps_pos, const float* eps_feat, const float* eps_edge, float* x_next,
+                        float* edge_next, float* x_mean, float* edge_mean, void* stream) {
     if (B <= 0 || N <= 0 || node_feats < 4 || edge_ch < 1) return jodo_set_error(JODO_ERR_ARG, "sampler_step: bad shape");
     if (!n_nodes_dev || !x || !edge_x || !pred || !edge_pred || !eps_pos || !eps_feat || !eps_edge || !x_next || !edge_next ||
         !x_mean || !edge_mean)
         return jodo_set_error(JODO_ERR_ARG, "sampler_step: null argument");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_step_nodes, dim3(B), dim3(256), 0, st, N, node_feats, n_nodes_dev, c_x, c_pred, sigma, x, pred, eps_pos,
-                       eps_feat, x_next, x_mean);
+    hipLaunchKernelGGL(k_step_nodes, dim3(B), dim3(256), 0, st, N, node_feats, n_nodes_dev, c_x, c_pred, sigma, coef, step, x, pred,
+                       eps_pos, eps_feat, x_next, x_mean);
     int rc = jodo_check_launch("k_step_nodes");
     if (rc != JODO_OK) return rc;
     const size_t tot = (size_t)B * N * N * edge_ch;
     hipLaunchKernelGGL(k_step_edges, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, N, edge_ch, n_nodes_dev, c_x, c_pred,
-                       sigma, edge_x, edge_pred, eps_edge, edge_next, edge_mean);
+                       sigma, coef, step, edge_x, edge_pred, eps_edge, edge_next, edge_mean);
     return jodo_check_launch("k_step_edges");
+}
+}  // namespace
+
+extern "C" int jodo_sampler_step(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, float c_x, float c_pred,
+                                 float sigma, const float* x, const float* edge_x, const float* pred, const float* edge_pred,
+                                 const float* eps_pos, const float* eps_feat, const float* eps_edge, float* x_next,
+                                 float* edge_next, float* x_mean, float* edge_mean, void* stream) {
+    return sampler_step_launch(B, N, node_feats, edge_ch, n_nodes_dev, c_x, c_pred, sigma, nullptr, nullptr, x, edge_x, pred, edge_pred,
+                               eps_pos, eps_feat, eps_edge, x_next, edge_next, x_mean, edge_mean, stream);
+}
+
+extern "C" int jodo_sampler_step_tab(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, const float* coef_tab_dev,
+                                     const int32_t* step_dev, const float* x, const float* edge_x, const float* pred,
+                                     const float* edge_pred, const float* eps_pos, const float* eps_feat, const float* eps_edge,
+                                     float* x_next, float* edge_next, float* x_mean, float* edge_mean, void* stream) {
+    if (!coef_tab_dev || !step_dev) return jodo_set_error(JODO_ERR_ARG, "sampler_step_tab: null table");
+    return sampler_step_launch(B, N, node_feats, edge_ch, n_nodes_dev, 0.f, 0.f, 0.f, coef_tab_dev, step_dev, x, edge_x, pred, edge_pred,
+                               eps_pos, eps_feat, eps_edge, x_next, edge_next, x_mean, edge_mean, stream);
+}
+
+extern "C" int jodo_step_begin(int B, const float* coef_tab_dev, const int32_t* step_dev, float* noise_level_out, void* stream) {
+    if (B <= 0 || !coef_tab_dev || !step_dev || !noise_level_out) return jodo_set_error(JODO_ERR_ARG, "step_begin: bad argument");
+    hipLaunchKernelGGL(k_step_begin, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, coef_tab_dev, step_dev, noise_level_out);
+    return jodo_check_launch("k_step_begin");
+}
+
+extern "C" int jodo_step_end(int32_t* step_dev, void* stream) {
+    if (!step_dev) return jodo_set_error(JODO_ERR_ARG, "step_end: null");
+    hipLaunchKernelGGL(k_step_end, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+    return jodo_check_launch("k_step_end");
 }
 
 extern "C" int jodo_decode(int B, int N, int atom_types, int include_fc, int edge_ch, int compress_edge, int centered,

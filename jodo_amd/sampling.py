@@ -11,7 +11,8 @@ Additions that do not change the reference behaviour:
   * `noise_fn` hook on the samplers: parity tests replay recorded noise instead of drawing it;
   * `shard=(rank, world)` on `get_sampling_fn`: each process samples a contiguous slice of every
     round's batch (jodo_amd/dist.py gathers the results) — replaces nn.DataParallel;
-  * masks are built vectorised rather than with a Python loop over the batch (:195-196).
+  * masks are built vectorised rather than with a Python loop over the batch (:195-196);
+  * `hip_graph=True` on `get_sampling_fn`: the ancestral loop replays one captured HIP graph per step.
 The 2-D-only sampler (`AncestralSampler_2D`) is out of scope.
 """
 import random
@@ -96,7 +97,7 @@ def build_masks(n_nodes, max_n_nodes, device):
 
 
 def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, inverse_scaler, eps=1e-3,
-                    prop_dist=None, shard=None, return_raw=False, fused_decode=True):
+                    prop_dist=None, shard=None, return_raw=False, fused_decode=True, hip_graph=False):
     device = config.device
     steps = config.sampling.steps
     atom_types = config.data.atom_types
@@ -140,7 +141,12 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
                 z = sample_combined_position_feature_noise(bs, max_n, node_nf, node_mask)
                 assert_mean_zero_with_mask(z[:, :, :3], node_mask)
                 edge_z = sample_symmetric_edge_feature_noise(bs, max_n, edge_nf, edge_mask)
-                x_node, x_edge = sampler.sampling(model, z, node_mask, edge_mask, edge_z, context)
+                if hip_graph and z.is_cuda and isinstance(sampler, AncestralSampler):
+                    # one captured HIP graph per round, replayed for every step (jodo_amd/graphed.py)
+                    from .graphed import GraphedAncestralRound
+                    x_node, x_edge = GraphedAncestralRound(sampler, model, node_mask, edge_mask, context).run(z, edge_z)
+                else:
+                    x_node, x_edge = sampler.sampling(model, z, node_mask, edge_mask, edge_z, context)
                 if x_node.is_cuda and fused_decode and getattr(inverse_scaler, 'from_config', False):
                     # device-side decode: compact u8/i8 results, one device->host copy per tensor
                     from . import fused

@@ -339,3 +339,51 @@ def test_fused_decode_equals_post_process(cfg_name):
         assert g_[1].dtype == torch.int64 and g_[3].dtype == torch.int64
     with pytest.raises(TypeError):
         fused.decode(cfg, xh.cpu(), ex, fused.n_nodes_from_mask(nm))
+
+
+def test_graph_replayed_sampling_round():
+    """HIP-graph replay of the ancestral loop: every replayed step must (a) have evaluated the score network on
+    the state the previous step produced and (b) apply the reference update to its own recorded noise draws."""
+    from jodo_amd.diffusion import NoiseScheduleVP
+    from jodo_amd.graphed import GraphedAncestralRound
+    from jodo_amd.sampling import AncestralSampler, posterior_coefficients
+    from jodo_amd.models.utils import sample_combined_position_feature_noise, sample_symmetric_edge_feature_noise
+    from jodo_amd.utils import get_self_cond_fn
+    cfg = make_config('vpsde_qm9_uncond_jodo')
+    hp = O.Hyper.from_config(cfg)
+    n_nodes = [9, 1, 29, 17, 2, 12]
+    nm, em = masks(n_nodes, DEV)
+    B, N = len(n_nodes), max(n_nodes)
+    model = make_model(cfg, 4, DEV, head_gain=10.0)
+    ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
+    ts = torch.linspace(ns.T, 1e-3, 7)
+    smp = AncestralSampler(ns, ts, True, True, True, get_self_cond_fn(cfg))
+    torch.manual_seed(5)
+    z = sample_combined_position_feature_noise(B, N, hp.in_node_dim, nm)
+    ez = sample_symmetric_edge_feature_noise(B, N, hp.edge_ch, em)
+    rnd = GraphedAncestralRound(smp, model, nm, em, record=True)
+    with torch.no_grad():
+        x_mean, e_mean = rnd.run(z, ez)
+    torch.cuda.synchronize()
+    assert [h['step'] for h in rnd.history] == list(range(1, len(ts)))           # steps 1..6 ran exactly once each
+    prev_pred = None
+    for h in rnd.history:
+        i = h['step']
+        c_x, c_pred, sigma, alpha_t, sigma_t, _, _ = posterior_coefficients(ns, ts[i], smp.s_array[i])
+        zx = h['eps_pos'] * nm
+        zx = zx - zx.sum(1, keepdim=True) / nm.sum(1, keepdim=True) * nm
+        eps_n = torch.cat([zx, h['eps_feat'] * nm], 2)
+        ze = torch.tril(h['eps_edge'], -1)
+        ze = (ze + ze.transpose(-1, -2)).permute(0, 2, 3, 1) * em.reshape(B, N, N, 1)
+        want_mean, want_emean = float(c_x) * h['x_prev'] + float(c_pred) * h['pred_keep'], float(c_x) * h['e_prev'] + float(c_pred) * h['epred_keep']
+        assert (h['x_mean'] - want_mean).abs().max().item() < 2e-6 and (h['e_mean'] - want_emean).abs().max().item() < 2e-6
+        assert (h['x'] - (want_mean + float(sigma) * eps_n)).abs().max().item() < 2e-6
+        assert (h['e'] - (want_emean + float(sigma) * ze)).abs().max().item() < 2e-6
+        if prev_pred is not None:                                  # (a): same forward, eagerly, on the recorded inputs
+            nl = torch.full((B,), float(torch.log(alpha_t ** 2 / sigma_t ** 2)), device=DEV)
+            with torch.no_grad():
+                px, pe = model(nl, h['x_prev'], nm, em, edge_x=h['e_prev'], noise_level=nl, cond_x=prev_pred[0], cond_edge_x=prev_pred[1])
+            assert torch.equal(px, h['pred_keep']) and torch.equal(pe, h['epred_keep'])
+            assert torch.equal(h['x_prev'], prev_state[0]) and torch.equal(h['e_prev'], prev_state[1])
+        prev_pred, prev_state = (h['pred_keep'], h['epred_keep']), (h['x'], h['e'])
+    assert torch.equal(x_mean, rnd.history[-1]['x_mean']) and not bool(torch.isnan(x_mean).any())

@@ -36,7 +36,8 @@ class _Prop:                                           # synthetic property samp
 
 
 fn = get_sampling_fn(cfg, ns, nodes_dist, B, B, get_data_inverse_scaler(cfg),
-                     prop_dist=_Prop() if which == 'cond' else None, return_raw=True)
+                     prop_dist=_Prop() if which == 'cond' else None, return_raw=True,
+                     hip_graph=os.environ.get('HIP_GRAPH', '0') == '1')
 if os.environ.get('WARM', '1') == '1':               # first call pays weight packing + first-touch costs
     fn(model)
 torch.cuda.synchronize()
@@ -45,6 +46,6 @@ mols = fn(model)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(json.dumps({'workload': which, 'batch': B, 'steps': int(cfg.sampling.steps), 'method': cfg.sampling.method,
-                  'round_seconds': dt, 'molecules': len(mols), 'molecules_per_s': len(mols) / dt,
+                  'round_seconds': dt, 'molecules': len(mols), 'molecules_per_s': len(mols) / dt, 'hip_graph': os.environ.get('HIP_GRAPH', '0') == '1',
                   'ms_per_step': dt / int(cfg.sampling.steps) * 1e3, 'nan_guard': bool(model.nan_guard_fired()),
                   'first_molecule_atoms': int(mols[0][0].shape[0])}))
