@@ -211,18 +211,21 @@ def main():
         # the roofline leg needs.
         from jodo_amd.graphed import GraphedAncestralRound
         capi.check(L.jodo_profile_enable(plan['handle'], 0), 'profile_enable')
-        with torch.no_grad():
-            rnd = GraphedAncestralRound(sampler, model, node_mask, edge_mask, context)
-            rnd.prepare(z, edge_z)
-            for _ in range(3):
-                rnd.replay()
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            for _ in range(args.steps):
-                rnd.replay()
-            torch.cuda.synchronize()
-            tg = (time.perf_counter() - tg) / args.steps
-        graph_info = {'ms_per_step': tg * 1e3, 'value': B / (SAMPLING_STEPS * tg), 'unit': 'molecules/s'}
+        try:
+            with torch.no_grad():
+                rnd = GraphedAncestralRound(sampler, model, node_mask, edge_mask, context)
+                rnd.prepare(z, edge_z)
+                for _ in range(3):
+                    rnd.replay()
+                torch.cuda.synchronize()
+                tg = time.perf_counter()
+                for _ in range(args.steps):
+                    rnd.replay()
+                torch.cuda.synchronize()
+                tg = (time.perf_counter() - tg) / args.steps
+            graph_info = {'ms_per_step': tg * 1e3, 'value': B / (SAMPLING_STEPS * tg), 'unit': 'molecules/s'}
+        except Exception as exc:                      # the extra must never take the headline down with it
+            graph_info = {'error': repr(exc)}
         capi.check(L.jodo_profile_enable(plan['handle'], 1), 'profile_enable')
     ms = (ctypes.c_float * 8)()
     cnt = (ctypes.c_int32 * 8)()
