@@ -10,7 +10,6 @@
 //     in-lane;
 //   * a value block no longer coincides with two attention heads (C = 24), so every lane carries all
 //     16 softmax weights and picks per register;
-//   * the node FFN accumulates its D outputs in passes of <= 8 blocks (register budget at D = 384);
 //   * the pair kernels park the shared part of input_lin in private (scratch) memory instead of LDS.
 // Instantiated for D = 384; D = 256 is instantiated too so that the whole set can be pinned against
 // the tuned kernels and the nf = 256 fixtures (jodo_cfg.layout = 1, tests only).
@@ -197,7 +196,8 @@ __global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
 template <int D, int R>
 __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
     using X = Dim<D>;
-    constexpr int NPASS = X::ND > 8 ? 2 : 1, NOB = X::ND / NPASS;        // ff2 output blocks per pass
+    constexpr int NPASS = 1, NOB = X::ND / NPASS;        // ff2 output blocks per pass (one pass fits at D = 384: 192 inputs in
+                                                          // VGPRs + 192 accumulators in AGPRs, no spills; two passes cost 27 % more MFMAs)
     constexpr int NCH = R * D / 64;                                       // hidden chunks of 64 features
     constexpr int KQ2 = R * D / 8;                                        // quads per ff2 output block
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
