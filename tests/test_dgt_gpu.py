@@ -387,3 +387,37 @@ def test_graph_replayed_sampling_round():
             assert torch.equal(h['x_prev'], prev_state[0]) and torch.equal(h['e_prev'], prev_state[1])
         prev_pred, prev_state = (h['pred_keep'], h['epred_keep']), (h['x'], h['e'])
     assert torch.equal(x_mean, rnd.history[-1]['x_mean']) and not bool(torch.isnan(x_mean).any())
+
+
+@pytest.mark.parametrize("cfg_name,info,B,over", [
+    ('vpsde_qm9_uncond_jodo', 'qm9_with_h', 230, {}),        # ~130 strips (4-wave node_post), pair items just above one round
+    ('vpsde_qm9_uncond_jodo', 'qm9_with_h', 700, {}),        # ~395 strips (2-wave node_post), 3 full rounds + split remainder
+    ('vpsde_geom_uncond_jodo', 'geom_with_h_1', 60, dict(nf=384)),
+])
+def test_medium_batches_cross_the_decomposition_boundaries(cfg_name, info, B, over):
+    """Batch sizes chosen so that the launches mix their variants (full rounds + cooperative / direction-split
+    remainders, automatic chunk sizes): the pair path must equal the directed path, and the first molecules must
+    equal the same molecules evaluated alone (batch independence)."""
+    from jodo_amd.models import load_dataset_info, get_node_dist
+    cfg = make_config(cfg_name, **over)
+    hp = O.Hyper.from_config(cfg)
+    torch.manual_seed(B)
+    n_nodes = get_node_dist(load_dataset_info(info)).sample(B).tolist()
+    xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=B)
+    nl[:] = 0.3
+    m_pair = make_model(cfg, 6, DEV, gain=1.2, coord_scale=0.05)
+    m_dir = make_model(cfg, 6, DEV, gain=1.2, coord_scale=0.05)
+    m_dir.force_directed = True
+    a = run(m_pair, xh, ex, nl, nm, em)
+    b = run(m_dir, xh, ex, nl, nm, em)
+    assert m_pair.last_flags.cpu().tolist()[4] == 0 and m_dir.last_flags.cpu().tolist()[4] == 1
+    close(a[0], b[0], atol=2e-5)
+    close(a[1], b[1], atol=2e-5)
+    assert torch.isfinite(a[0]).all() and torch.equal(a[1], a[1].transpose(1, 2))
+    k = 12
+    sub = n_nodes[:k]
+    Ns = max(sub)
+    nm2, em2 = masks(sub)
+    c = run(m_pair, xh[:k, :Ns], ex[:k, :Ns, :Ns], nl[:k], nm2, em2)
+    close(c[0], a[0][:k, :Ns], atol=2e-5)
+    close(c[1], a[1][:k, :Ns, :Ns], atol=2e-5)
