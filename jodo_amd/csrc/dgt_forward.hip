@@ -318,7 +318,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
             LAUNCH(k_edge_scores, (p->n_items + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A);
         }
         { ProfScope ps(p, st, JODO_PROF_SOFTMAX); LAUNCH(k_softmax, (p->Nn + 15) / 16, 256, A); }
-        if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_MSGS); LAUNCH(k_edge_msgs, (p->n_items + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A); }
+        if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_MSGS); LAUNCH(k_edge_msgs, (p->n_items + MSG_WAVES - 1) / MSG_WAVES, MSG_WAVES * 64, A); }
         { ProfScope ps(p, st, JODO_PROF_NODE_POST);
           // One wave per strip for every full round of 1024 strips (one per SIMD); the remainder r — which would
           // otherwise occupy r SIMDs for a whole item while the rest idle — goes to a second launch in which a

@@ -154,12 +154,14 @@ __global__ void k_softmax(KArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_WAVES * 64, 2) void k_edge_msgs(KArgs A) {
+constexpr int MSG_WAVES = 4;      // two 4-wave workgroups per CU (2 x 64 KiB LDS): finer scheduling grain than one of 8
+
+__global__ __launch_bounds__(MSG_WAVES * 64, 2) void k_edge_msgs(KArgs A) {
     __shared__ float4 wl[64 * 64];                              // lin_edge1 (8 x 8 quads)
-    stage_weights<64>(wl, reinterpret_cast<const float4*>(A.W + A.wb[JB_LE1_W]));
+    stage_weights<64, MSG_WAVES>(wl, reinterpret_cast<const float4*>(A.W + A.wb[JB_LE1_W]));
     __syncthreads();
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int it = blockIdx.x * WG_WAVES + (threadIdx.x >> 6);
+    const int it = blockIdx.x * MSG_WAVES + (threadIdx.x >> 6);
     if (it >= A.pd.n_items) return;
     const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it], part = A.pd.item_part[it];
     const LaneNode L = lane_node(A, strip, j);
