@@ -59,7 +59,13 @@ __device__ __forceinline__ void pipeline_fence() {
 }
 
 // sum of a per-half partial over the two half-lanes of an item
-__device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32); }
+// gfx950: v_permlane32_swap exchanges the upper half of one register with the lower half of another in the
+// VALU (x' = [x.lo, y.lo], y' = [x.hi, y.hi]); with x = y = v the two results are v.lo and v.hi broadcast to
+// both halves.  Replaces a ds_bpermute (LDS round trip) per reduction.
+__device__ __forceinline__ float pair_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 // ---- register <-> memory in natural-half slot order -----------------------------------------------
 // row points at feature 0 of this lane's item; NB = number of 32-feature blocks.
