@@ -154,8 +154,8 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         }
     }
     p->n_items = (int)it_strip.size(); p->max_parts = max_parts;
-    {   // directed items are consumed 8 per workgroup by the attention kernels
-        const std::vector<int> ord = xcd_order(it_strip, 8);
+    {   // directed items are consumed 4 per workgroup by the message kernel (8 by the directed scores kernel)
+        const std::vector<int> ord = xcd_order(it_strip, 4);
         permute(it_strip, ord); permute(it_t0, ord); permute(it_t1, ord); permute(it_part, ord);
     }
     // pair work items for the symmetric path: lane i meets partner (i + d) mod n for d = 1 .. floor(n/2)
