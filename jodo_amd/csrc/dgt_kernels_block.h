@@ -142,12 +142,14 @@ __global__ void k_softmax(KArgs A) {
     const int n = A.pd.node_n[v], i = A.pd.node_i[v];
     const float* Sr = A.S + ((size_t)A.pd.node_eoff[v] + i) * 16 + slot;   // rows (t, i), stride n
     const size_t st = (size_t)n * 16;
-    float m = -INFINITY;
-    for (int t = 0; t < n; ++t)
-        if (t != i) m = fmaxf(m, Sr[t * st]);
-    float sum = 0.f;
-    for (int t = 0; t < n; ++t)
-        if (t != i) sum += __expf(Sr[t * st] - m);
+    // one pass (running maximum with rescaled sum): S is read once instead of twice
+    float m = -INFINITY, sum = 0.f;
+    for (int t = 0; t < n; ++t) {
+        if (t == i) continue;
+        const float v = Sr[t * st];
+        if (v > m) { sum = sum * __expf(m - v) + 1.f; m = v; }
+        else sum += __expf(v - m);
+    }
     if (n <= 1) { m = 0.f; sum = 0.f; }
     A.stats[(size_t)v * 32 + slot] = m;
     A.stats[(size_t)v * 32 + 16 + slot] = n > 1 ? 1.f / (sum + 1e-16f) : 0.f;
