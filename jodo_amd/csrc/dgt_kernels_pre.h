@@ -196,7 +196,13 @@ __global__ __launch_bounds__(64) void k_embed_edges(KArgs A) {
     const float gscale = mr[0], gshift = mr[1];
     const float4 pc = reinterpret_cast<const float4*>(A.cpos)[L.v];
     const float* tab = A.W + A.wg[JW_GBF_TOP];
-    const float4* w = wq(A, A.wg[JW_EDGE_EMB_W], lane);
+    // the whole weight set of this projection is 18 quads: held in registers for all rows of the item
+    float4 wreg[18];
+    {
+        const float4* w = wq(A, A.wg[JW_EDGE_EMB_W], lane);
+#pragma unroll
+        for (int q = 0; q < 18; ++q) wreg[q] = w[(size_t)q * 64];
+    }
     const float* bias = A.W + A.wg[JW_EDGE_EMB_B];
     for (int t = t0; t < t1; ++t) {
         const bool ok = L.valid && t < L.n;
@@ -229,8 +235,22 @@ __global__ __launch_bounds__(64) void k_embed_edges(KArgs A) {
         }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            f32x16 acc = mfma_block<8>(w + (size_t)(b * 9) * 64, G, zero16());
-            acc = mfma_block<1>(w + (size_t)(b * 9 + 8) * 64, ein, acc);
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 a = wreg[b * 9 + q];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, G[4 * q + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, G[4 * q + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, G[4 * q + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, G[4 * q + 3], acc, 0, 0, 0);
+            }
+            {
+                const float4 a = wreg[b * 9 + 8];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, ein[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, ein[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, ein[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, ein[3], acc, 0, 0, 0);
+            }
             float rr[16];
             acc_bias(acc, bias + b * 32 + half * 16, rr);
             if (ok) {
