@@ -186,24 +186,24 @@ def main():
             elapsed = time.perf_counter() - t0
         st = dict(x_mean=rnd.x_mean, edge_x_mean=rnd.e_mean)
     else:
-      with torch.no_grad():
-        st = sampler.init_state(z, edge_z)
-        for i in range(args.warmup):
-            st = sampler.step(model, i, st, node_mask, edge_mask, context)
-        plan = model._last_plan
-        capi.check(L.jodo_profile_enable(plan['handle'], 1), 'profile_enable')
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.warmup, args.warmup + args.steps):
-            st = sampler.step(model, i, st, node_mask, edge_mask, context)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        with torch.no_grad():
+            st = sampler.init_state(z, edge_z)
+            for i in range(args.warmup):
+                st = sampler.step(model, i, st, node_mask, edge_mask, context)
+            plan = model._last_plan
+            capi.check(L.jodo_profile_enable(plan['handle'], 1), 'profile_enable')
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.warmup, args.warmup + args.steps):
+                st = sampler.step(model, i, st, node_mask, edge_mask, context)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
     graph_info = None
     if not args.graph and world == 1:
         # extra, reported beside the headline: the same step replayed as ONE captured HIP graph (no per-step

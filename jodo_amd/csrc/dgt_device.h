@@ -253,20 +253,6 @@ __device__ __forceinline__ f32x16 mfma_block_p(WPipe<PG>& p, const WSrc& w, unsi
     return acc;
 }
 
-// 16 consecutive floats of this lane's half (features b*32 + half*16 ..) from the weight blob through the
-// descriptor: unlike load16 these are held in place by pipeline_fence(), so "operands of the epilogue are
-// requested before the MFMA block they follow" is what the hardware actually sees.
-// soff: byte offset of feature 0 of the vector (wave-uniform).
-__device__ __forceinline__ void cload16(const WSrc& w, int half, unsigned soff, float (&x)[16]) {
-    const unsigned hv = (unsigned)half * 64u;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w.rs, hv + (unsigned)q * 16u, soff, 0);
-        x[q * 4 + 0] = __uint_as_float(v.x); x[q * 4 + 1] = __uint_as_float(v.y);
-        x[q * 4 + 2] = __uint_as_float(v.z); x[q * 4 + 3] = __uint_as_float(v.w);
-    }
-}
-
 // accumulator (+ bias in slot order) -> registers [16]
 __device__ __forceinline__ void acc_bias(const f32x16& acc, const float* __restrict__ bias16, float (&r)[16]) {
     float b[16];

@@ -15,8 +15,6 @@ the random stream differs from an eager run (graph-captured generators advance t
 replay), which is why parity tests compare each replayed step against the framework formula on the step's
 own recorded draws rather than against an eager trajectory.
 """
-import ctypes
-
 import torch
 
 from . import capi, fused
