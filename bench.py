@@ -271,6 +271,9 @@ def main():
                        'parallelism': 'batch shard x%d, no data-path collective' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'k_edge_update', 'achieved': achieved / 1e12, 'peak': PEAK_FP32_MFMA / 1e12,
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA, 'traffic': None,
+                         'note': 'one launch = the pair-update work of one block: up to two dispatches of the same kernel '
+                                 '(full rounds of work items + direction-split remainder) inside one HIP-event bracket; '
+                                 'rocprofv3 lists the dispatches separately (their durations add up to avg_launch_ms)',
                          'avg_launch_ms': upd_ms, 'launches': upd_n, 'alg_flops_per_launch': flops_launch,
                          'whole_step_TFLOPs': total_flops / step_s / 1e12,
                          'whole_step_frac': total_flops / step_s / PEAK_FP32_MFMA},
