@@ -2,6 +2,7 @@
 // the strip model / packed-weight chain the production kernels use.  Exposed through the C ABI as
 // jodo_debug_mlp so tests can validate the MFMA lane maps and the packer on real hardware.
 #include "dgt_device.h"
+#include "../../include/jodo_hip.h"
 #include "jodo_hip_internal.h"
 
 using namespace jd;
@@ -45,4 +46,49 @@ extern "C" int jodo_debug_mlp(const float* x, int rows, const float* w1, const f
     hipLaunchKernelGGL(k_debug_mlp, dim3((rows + 31) / 32), dim3(64), 0, (hipStream_t)stream, x, rows,
                        (const float4*)w1, b1, (const float4*)w2, b2, y);
     return jodo_check_launch("k_debug_mlp");
+}
+
+// fp32 matrix-pipe microbenchmark: every wave runs `iters` rounds of 8 independent v_mfma_f32_32x32x2_f32 chains
+// (or one dependent chain, which is what a projection block is) on register operands — no memory traffic.  Gives
+// the ceiling the roofline fractions are measured against on the actual box (spec: 157.3 TFLOP/s).
+template <int CHAINS>
+__global__ __launch_bounds__(64, 1) void k_mfma_peak(int iters, float* __restrict__ sink) {
+    f32x16 acc[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) acc[c] = zero16();
+    float a = 1.0f + threadIdx.x * 1e-6f, b = 0.5f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 8 / CHAINS; ++r)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) s += acc[c][0];
+    if (s == 123.456f) sink[0] = s;             // keeps the chains alive
+}
+
+// waves_per_simd x 1024 waves; returns TFLOP/s of `chains` in {1, 8} (dependent chain / 8 independent chains).
+// Synchronises: a measurement helper for bench.py / DESIGN.md, not part of the data path.
+extern "C" int jodo_debug_mfma_peak(int iters, int chains, float* sink_dev, float* tflops_out) {
+    if (iters <= 0 || !sink_dev || !tflops_out || (chains != 1 && chains != 8)) return jodo_set_error(JODO_ERR_ARG, "mfma_peak: bad argument");
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return jodo_set_error(JODO_ERR_LAUNCH, "mfma_peak: events");
+    const int waves = 1024 * 4;
+    for (int rep = 0; rep < 2; ++rep) {          // first repetition warms up clocks / code
+        (void)hipEventRecord(e0, 0);
+        if (chains == 1) hipLaunchKernelGGL(k_mfma_peak<1>, dim3(waves), dim3(64), 0, 0, iters, sink_dev);
+        else hipLaunchKernelGGL(k_mfma_peak<8>, dim3(waves), dim3(64), 0, 0, iters, sink_dev);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+    }
+    int rc = jodo_check_launch("k_mfma_peak");
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc != JODO_OK) return rc;
+    const double flops = (double)waves * iters * 8.0 * 4096.0;
+    *tflops_out = (float)(flops / (ms * 1e-3) / 1e12);
+    return JODO_OK;
 }

@@ -1,0 +1,11 @@
+"""Measured fp32-MFMA ceiling of the box (jodo_debug_mfma_peak): 8 independent chains and 1 dependent chain per wave."""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from jodo_amd import capi
+L = capi.lib()
+sink = torch.zeros(4, device='cuda')
+for chains in (8, 1):
+    out = ctypes.c_float()
+    capi.check(L.jodo_debug_mfma_peak(20000, chains, capi.ptr(sink), ctypes.byref(out)), 'mfma_peak')
+    print('chains', chains, 'TFLOP/s %.1f' % out.value)
