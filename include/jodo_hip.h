@@ -171,8 +171,8 @@ const char* jodo_last_error(void);
 
 /* measurement helper (synchronises, default stream): fp32 MFMA throughput of the box in TFLOP/s from a
  * register-only kernel; chains = 8 independent accumulator chains per wave (pipe ceiling) or 1 dependent chain
- * (what one projection block is).  sink_dev: any device float. */
-int jodo_debug_mfma_peak(int iters, int chains, float* sink_dev, float* tflops_out);
+ * (what one projection block is); waves_per_simd x 1024 waves are launched.  sink_dev: any device float. */
+int jodo_debug_mfma_peak(int iters, int chains, int waves_per_simd, float* sink_dev, float* tflops_out);
 
 int jodo_debug_mlp(const float* x, int rows, const float* w1, const float* b1, const float* w2,
                    const float* b2, float* y, void* stream);

@@ -69,13 +69,14 @@ __global__ __launch_bounds__(64, 1) void k_mfma_peak(int iters, float* __restric
     if (s == 123.456f) sink[0] = s;             // keeps the chains alive
 }
 
-// waves_per_simd x 1024 waves; returns TFLOP/s of `chains` in {1, 8} (dependent chain / 8 independent chains).
+// 1024 x waves_per_simd waves; returns TFLOP/s of `chains` in {1, 8} (dependent chain / 8 independent chains).
 // Synchronises: a measurement helper for bench.py / DESIGN.md, not part of the data path.
-extern "C" int jodo_debug_mfma_peak(int iters, int chains, float* sink_dev, float* tflops_out) {
+extern "C" int jodo_debug_mfma_peak(int iters, int chains, int waves_per_simd, float* sink_dev, float* tflops_out) {
     if (iters <= 0 || !sink_dev || !tflops_out || (chains != 1 && chains != 8)) return jodo_set_error(JODO_ERR_ARG, "mfma_peak: bad argument");
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return jodo_set_error(JODO_ERR_LAUNCH, "mfma_peak: events");
-    const int waves = 1024 * 4;
+    if (waves_per_simd < 1 || waves_per_simd > 8) return jodo_set_error(JODO_ERR_ARG, "mfma_peak: waves_per_simd");
+    const int waves = 1024 * waves_per_simd;
     for (int rep = 0; rep < 2; ++rep) {          // first repetition warms up clocks / code
         (void)hipEventRecord(e0, 0);
         if (chains == 1) hipLaunchKernelGGL(k_mfma_peak<1>, dim3(waves), dim3(64), 0, 0, iters, sink_dev);

@@ -6,6 +6,7 @@ from jodo_amd import capi
 L = capi.lib()
 sink = torch.zeros(4, device='cuda')
 for chains in (8, 1):
-    out = ctypes.c_float()
-    capi.check(L.jodo_debug_mfma_peak(20000, chains, capi.ptr(sink), ctypes.byref(out)), 'mfma_peak')
-    print('chains', chains, 'TFLOP/s %.1f' % out.value)
+    for wps in (4, 1):
+        out = ctypes.c_float()
+        capi.check(L.jodo_debug_mfma_peak(20000, chains, wps, capi.ptr(sink), ctypes.byref(out)), 'mfma_peak')
+        print('chains', chains, 'waves/SIMD', wps, 'TFLOP/s %.1f' % out.value)
