@@ -174,6 +174,11 @@ const char* jodo_last_error(void);
  * (what one projection block is); waves_per_simd x 1024 waves are launched.  sink_dev: any device float. */
 int jodo_debug_mfma_peak(int iters, int chains, int waves_per_simd, float* sink_dev, float* tflops_out);
 
+/* same, one dependent chain per wave (waves_per_simd x 1024 waves) with nv independent v_fma (and nt transcendentals)
+ * issued after every MFMA: tells whether vector work hides under the matrix pipe.  (nv, nt) in
+ * {(0,0),(4,0),(8,0),(12,0),(16,0),(4,1),(4,2)}. */
+int jodo_debug_mfma_valu(int iters, int nv, int nt, int waves_per_simd, float* sink_dev, float* tflops_out);
+
 int jodo_debug_mlp(const float* x, int rows, const float* w1, const float* b1, const float* w2,
                    const float* b2, float* y, void* stream);
 

@@ -93,3 +93,57 @@ extern "C" int jodo_debug_mfma_peak(int iters, int chains, int waves_per_simd, f
     *tflops_out = (float)(flops / (ms * 1e-3) / 1e12);
     return JODO_OK;
 }
+
+// Does VALU work issued between the MFMAs of a dependent chain hide under them?  NV independent v_fma per MFMA
+// (and optionally one transcendental) in the same wave; returns the MFMA-only TFLOP/s.
+template <int NV, int NT>
+__global__ __launch_bounds__(64, 1) void k_mfma_valu(int iters, float* __restrict__ sink) {
+    f32x16 acc = zero16();
+    float a = 1.0f + threadIdx.x * 1e-6f, b = 0.5f;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = 0.001f * (threadIdx.x + i);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[(r * NV + k) & 15] = fmaf(v[(r * NV + k) & 15], 1.0001f, 0.5f);
+#pragma unroll
+            for (int k = 0; k < NT; ++k) v[(r + k) & 15] = __builtin_amdgcn_exp2f(v[(r + k) & 15] * 0.001f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = acc[0];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+    if (s == 123.456f) sink[0] = s;
+}
+
+extern "C" int jodo_debug_mfma_valu(int iters, int nv, int nt, int waves_per_simd, float* sink_dev, float* tflops_out) {
+    if (iters <= 0 || !sink_dev || !tflops_out) return jodo_set_error(JODO_ERR_ARG, "mfma_valu: bad argument");
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return jodo_set_error(JODO_ERR_LAUNCH, "mfma_valu: events");
+    if (waves_per_simd < 1 || waves_per_simd > 8) return jodo_set_error(JODO_ERR_ARG, "mfma_valu: waves_per_simd");
+    const int waves = 1024 * waves_per_simd;
+    for (int rep = 0; rep < 2; ++rep) {
+        (void)hipEventRecord(e0, 0);
+        if (nv == 0 && nt == 0) hipLaunchKernelGGL((k_mfma_valu<0, 0>), dim3(waves), dim3(64), 0, 0, iters, sink_dev);
+        else if (nv == 4 && nt == 0) hipLaunchKernelGGL((k_mfma_valu<4, 0>), dim3(waves), dim3(64), 0, 0, iters, sink_dev);
+        else if (nv == 8 && nt == 0) hipLaunchKernelGGL((k_mfma_valu<8, 0>), dim3(waves), dim3(64), 0, 0, iters, sink_dev);
+        else if (nv == 12 && nt == 0) hipLaunchKernelGGL((k_mfma_valu<12, 0>), dim3(waves), dim3(64), 0, 0, iters, sink_dev);
+        else if (nv == 16 && nt == 0) hipLaunchKernelGGL((k_mfma_valu<16, 0>), dim3(waves), dim3(64), 0, 0, iters, sink_dev);
+        else if (nv == 4 && nt == 1) hipLaunchKernelGGL((k_mfma_valu<4, 1>), dim3(waves), dim3(64), 0, 0, iters, sink_dev);
+        else if (nv == 4 && nt == 2) hipLaunchKernelGGL((k_mfma_valu<4, 2>), dim3(waves), dim3(64), 0, 0, iters, sink_dev);
+        else { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return jodo_set_error(JODO_ERR_ARG, "mfma_valu: unsupported (nv, nt)"); }
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+    }
+    int rc = jodo_check_launch("k_mfma_valu");
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc != JODO_OK) return rc;
+    *tflops_out = (float)((double)waves * iters * 8.0 * 4096.0 / (ms * 1e-3) / 1e12);
+    return JODO_OK;
+}
