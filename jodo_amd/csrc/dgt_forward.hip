@@ -225,7 +225,8 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     A.W = packed_w;
     for (int i = 0; i < JW_GLOBAL_COUNT; ++i) A.wg[i] = woff[i];
     for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = 0;
-    A.mod_base = 0; A.layer = 0; A.force_directed = p->force_directed; A.pre_mode = 0; A.strip0 = 0; A.item0 = 0; A.dir_split = 0;
+    A.mod_base = 0; A.layer = 0; A.force_directed = p->force_directed; A.pre_mode = 0; A.strip0 = 0; A.item0 = 0; A.dir_split = 0; A.fuse_next = 0; A.mod_base_next = 0;
+    for (int i = 0; i < 6; ++i) A.wbn[i] = 0;
     fill_ws(A, p, workspace);
     float* posbuf[2] = {ws_ptr<float>(workspace, p->ws.pos0), ws_ptr<float>(workspace, p->ws.pos1)};
     A.pos_in = posbuf[0]; A.pos_out = posbuf[1];
@@ -284,6 +285,12 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     // kernels share the SIMDs) and needs a library-owned stream.
     static const bool overlap_env = getenv("JODO_OVERLAP") != nullptr;
     bool overlap = overlap_env && nblocks > 1;
+    // With at least one strip per SIMD, k_node_post of block l also produces block l + 1's q / k / v (it holds h' in
+    // registers): drops a launch with its own latency-bound prologue and partial last round (QM9 B = 2500, 1409
+    // strips: 23.31 -> 23.18 ms/step).  With fewer strips the separate kernel's 3x finer items fill the chip better
+    // (GEOM B = 512, 710 strips: fused 35.1 vs 34.6 ms/step), so it stays separate there.
+    static const bool fuse_env = getenv("JODO_NO_FUSE_PRE") == nullptr;
+    const bool fuse_pre = fuse_env && !overlap && nblocks > 1 && p->n_strips >= 1024;
     if (overlap && !p->aux_stream) {
         hipStream_t sx; hipEvent_t e1, e2;
         if (hipStreamCreateWithFlags(&sx, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess ||
@@ -297,17 +304,19 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
         A.mod_base = 32 + (int64_t)l * d.MB;
         for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + i];
         A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
-        if (!overlap) {
+        if (!overlap && !fuse_pre) {
             A.pre_mode = 0;
             ProfScope ps(p, st, JODO_PROF_NODE_PRE); LAUNCH(k_node_pre, p->n_strips * 3, 64, A);
         } else {
-            // positions entering the block (needs the previous update); the q/k/v projections of this block were
-            // enqueued on the helper stream right after the previous block's k_node_post (they only need h)
+            // positions entering the block (needs the previous update).  The q/k/v projections of this block were
+            // produced by the previous block's k_node_post (fused, default) or enqueued on the helper stream right
+            // after it (JODO_OVERLAP): they only need h
+            ProfScope ps(p, st, JODO_PROF_NODE_PRE);
             LAUNCH(k_pos_final, (p->Nn_pad + 255) / 256, 256, A);
             if (l == 0) {
                 A.pre_mode = 1;
-                ProfScope ps(p, st, JODO_PROF_NODE_PRE); LAUNCH(k_node_pre, p->n_strips * 3, 64, A);
-            } else if (hipStreamWaitEvent(st, (hipEvent_t)p->ev_join, 0) != hipSuccess) {
+                LAUNCH(k_node_pre, p->n_strips * 3, 64, A);
+            } else if (overlap && hipStreamWaitEvent(st, (hipEvent_t)p->ev_join, 0) != hipSuccess) {
                 return jodo_set_error(JODO_ERR_LAUNCH, "stream join failed");
             }
         }
@@ -324,6 +333,12 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
           // otherwise occupy r SIMDs for a whole item while the rest idle — goes to a second launch in which a
           // workgroup of 4 (r <= 256) or 2 (r <= 512) waves shares each strip.  Measured on MI355X: 177 strips
           // 1.7 -> 0.75 ms/step with 4 waves; all 1409 strips with 2 / 4 waves 3.7 / 4.1 vs 3.6 ms/step with 1.
+          A.fuse_next = (fuse_pre && l + 1 < nblocks) ? 1 : 0;
+          if (A.fuse_next) {
+              static const int slots[6] = {JB_WQ, JB_BQ, JB_WK, JB_BK, JB_WV, JB_BV};
+              for (int i = 0; i < 6; ++i) A.wbn[i] = woff[JW_GLOBAL_COUNT + (l + 1) * JB_BLOCK_COUNT + slots[i]];
+              A.mod_base_next = 32 + (int64_t)(l + 1) * d.MB;
+          }
           static const char* force = getenv("JODO_NODE_POST");                     // experiment switch: "1", "2" or "4" for all strips
           const int full = force ? (force[0] == '1' ? p->n_strips : 0) : (p->n_strips / 1024) * 1024;
           const int rem = p->n_strips - full;

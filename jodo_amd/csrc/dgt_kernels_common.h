@@ -17,6 +17,11 @@ struct KArgs {
     int force_directed;                   // debug: never take the symmetric pair path
     int strip0;                           // k_node_post*: first strip of this launch (a layer's strips may be split over two launches)
     int item0, dir_split;                 // pair update: first item of this launch; 1 = two workgroups per item, one direction each
+    // k_node_post*: when fuse_next != 0 the kernel also produces the NEXT block's q / k / v (LN1 + modulate of the
+    // h it has just computed), with the next block's weights (wbn = its WQ, BQ, WK, BK, WV, BV slots) and modulation
+    int fuse_next;
+    int64_t wbn[6];
+    int64_t mod_base_next;
     int pre_mode;                         // k_node_pre: 0 = also advance the positions, 1 = q/k/v only (k_pos_final did it)
     // workspace
     float *hid1, *temb, *mods, *condh, *condh2;

@@ -90,6 +90,34 @@ __device__ __forceinline__ void node_residual_ln(const KArgs& A, const LaneNode&
     modulate<8>(x, ns2, nc2, half);
 }
 
+// ---- the next block's k_node_pre work, fused behind k_node_post (which holds h' in registers) -------
+// x: h' in, LN1(h') * (1 + nc1) + ns1 of the NEXT block out
+__device__ __forceinline__ void node_next_ln(const KArgs& A, const LaneNode& L, int half, float (&x)[128]) {
+    const float* mr = mod_row(A, L.b) + A.mod_base_next;
+    layer_norm<128>(x);
+    modulate<8>(x, mr, mr + 256, half);
+}
+// output blocks [g0, g1) of the concatenated projection q (0-7) | k (8-15) | v (16-23); the weight ring must
+// already hold the first quads of block g0 (the caller chained its previous block to it)
+__device__ __forceinline__ void node_next_qkv(const KArgs& A, const LaneNode& L, int half, const float (&x)[128], const WSrc& ws,
+                                              WPipe<8>& wp, int g0, int g1) {
+#pragma unroll 1
+    for (int g = g0; g < g1; ++g) {
+        const int piece = g >> 3, b = g & 7;
+        const unsigned cur = (unsigned)(A.wbn[2 * piece] * 4) + (unsigned)b * 32 * 1024;
+        const int gn = g + 1 < g1 ? g + 1 : g0;
+        const unsigned nxt = (unsigned)(A.wbn[2 * (gn >> 3)] * 4) + (unsigned)(gn & 7) * 32 * 1024;
+        const float* bias = A.W + A.wbn[2 * piece + 1];
+        float* outp = piece == 0 ? A.q : (piece == 1 ? A.k : A.v);
+        float bb[16], r[16];
+        load16(bias + b * 32 + half * 16, bb);
+        f32x16 acc = mfma_block_p<32>(wp, ws, cur, nxt, x, zero16());
+#pragma unroll
+        for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
+        store16T(outp, 8, L.v, half, b, r);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // One item per strip.  (Splitting this kernel into (strip, piece) items was measured slower: every item
 // pays the same latency-bound prologue — partial-sum reduction, LayerNorm — which is 20-50 % of a piece.)
@@ -185,11 +213,15 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
             const unsigned cur = oNro + (unsigned)b * 32 * 1024;
             float bb[16], r[16];
             load16(bias + b * 32 + half * 16, bb);
-            f32x16 acc = mfma_block_p<32>(wp, ws, cur, b == 0 ? cur + 32 * 1024 : oNro, hx, zero16());
+            f32x16 acc = mfma_block_p<32>(wp, ws, cur, b == 0 ? cur + 32 * 1024 : (A.fuse_next ? (unsigned)(A.wbn[0] * 4) : oNro), hx, zero16());
 #pragma unroll
             for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
             store16(A.ahid + (size_t)L.v * A.d.KNH + 256 + A.layer * 64 + b * 32 + half * 16, r);
         }
+    }
+    if (A.fuse_next) {                                        // next block's LN1 + modulate + q / k / v, h' still in registers
+        node_next_ln(A, L, half, hx);
+        node_next_qkv(A, L, half, hx, ws, wp, 0, 24);
     }
 }
 
@@ -348,13 +380,16 @@ __global__ __launch_bounds__(NW * 64, 1) void k_node_postw(KArgs A) {
         float* dst = is_row ? A.wrow : A.wcol;
         const int ro0 = (wave % ROW_WAVES) * NRO_PER;         // first readout block of this (W_col) wave
         const unsigned oAfter = is_row ? oLast : oNro + (unsigned)ro0 * 32 * 1024;
+        // first q / k / v block of this wave when the next block's projections are fused in (24 blocks over NW waves)
+        const int g0 = wave * (24 / NW);
+        const unsigned oNextQ = A.fuse_next ? (unsigned)(A.wbn[2 * (g0 >> 3)] * 4) + (unsigned)(g0 & 7) * 32 * 1024 : oLast;
 #pragma unroll 1
         for (int bi = 0; bi < PER; ++bi) {
             const int b = b0 + bi;
             const unsigned cur = oLast + (unsigned)bi * 32 * 1024;
             float bb[16], r[16];
             load16(bin + b * 32 + half * 16, bb);
-            f32x16 acc = mfma_block_p<32>(wp, ws, cur, bi + 1 < PER ? cur + 32 * 1024 : oAfter, hx, zero16());
+            f32x16 acc = mfma_block_p<32>(wp, ws, cur, bi + 1 < PER ? cur + 32 * 1024 : (is_row ? oNextQ : oAfter), hx, zero16());
 #pragma unroll
             for (int s = 0; s < 16; ++s) r[s] = acc[s] + (is_row ? bb[s] : 0.f);
             store16T(dst, 8, L.v, half, b, r);
@@ -367,11 +402,15 @@ __global__ __launch_bounds__(NW * 64, 1) void k_node_postw(KArgs A) {
                 const unsigned cur = oAfter + (unsigned)k * 32 * 1024;
                 float bb[16], r[16];
                 load16(bias + b * 32 + half * 16, bb);
-                f32x16 acc = mfma_block_p<32>(wp, ws, cur, k + 1 < NRO_PER ? cur + 32 * 1024 : cur, hx, zero16());
+                f32x16 acc = mfma_block_p<32>(wp, ws, cur, k + 1 < NRO_PER ? cur + 32 * 1024 : oNextQ, hx, zero16());
 #pragma unroll
                 for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
                 store16(A.ahid + (size_t)L.v * A.d.KNH + 256 + A.layer * 64 + b * 32 + half * 16, r);
             }
+        }
+        if (A.fuse_next) {                                    // next block's q / k / v: 24 / NW blocks per wave
+            node_next_ln(A, L, half, hx);
+            node_next_qkv(A, L, half, hx, ws, wp, g0, g0 + 24 / NW);
         }
     }
 }
