@@ -167,15 +167,9 @@ __global__ __launch_bounds__(MSG_WAVES * 64, 2) void k_edge_msgs(KArgs A) {
     if (it >= A.pd.n_items) return;
     const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it], part = A.pd.item_part[it];
     const LaneNode L = lane_node(A, strip, j);
-    float mx[8], inv[8];
-    {
-        const float4* sp = reinterpret_cast<const float4*>(A.stats + (size_t)L.v * 32 + half * 8);
-        const float4 a = sp[0], b = sp[1];
-        mx[0] = a.x; mx[1] = a.y; mx[2] = a.z; mx[3] = a.w; mx[4] = b.x; mx[5] = b.y; mx[6] = b.z; mx[7] = b.w;
-        const float4* ip = reinterpret_cast<const float4*>(A.stats + (size_t)L.v * 32 + 16 + half * 8);
-        const float4 c = ip[0], d = ip[1];
-        inv[0] = c.x; inv[1] = c.y; inv[2] = c.z; inv[3] = c.w; inv[4] = d.x; inv[5] = d.y; inv[6] = d.z; inv[7] = d.w;
-    }
+    // softmax statistics of this lane's target are re-read (L1 hits) every iteration instead of living in 16
+    // registers: keeps the kernel free of scratch spills at 2 waves per SIMD
+    const float4* stp = launder(reinterpret_cast<const float4*>(A.stats + (size_t)L.v * 32 + half * 8));
     const float4* wL1 = wl + lane;
     float macc[128];
 #pragma unroll
@@ -192,6 +186,9 @@ __global__ __launch_bounds__(MSG_WAVES * 64, 2) void k_edge_msgs(KArgs A) {
             const float4* sp = reinterpret_cast<const float4*>(A.S + r * 16 + half * 8);
             const float4 a = sp[0], b = sp[1];
             const float sv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            const float4 m0 = stp[0], m1 = stp[1], i0 = stp[4], i1 = stp[5];
+            const float mx[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+            const float inv[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
 #pragma unroll
             for (int b2 = 0; b2 < 8; ++b2) al[b2] = ok ? fast_exp(sv[b2] - mx[b2]) * inv[b2] : 0.f;
         }
