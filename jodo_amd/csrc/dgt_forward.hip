@@ -67,7 +67,8 @@ struct ProfScope {
         if (!p->prof_pool.empty()) { hipEvent_t e = (hipEvent_t)p->prof_pool.back(); p->prof_pool.pop_back(); return e; }
         hipEvent_t e; (void)hipEventCreate(&e); return e;
     }
-    ProfScope(jodo_plan* p_, hipStream_t st_, int cls_) : p(p_), st(st_), cls(cls_), on(p_->prof_enabled != 0) {
+    ProfScope(jodo_plan* p_, hipStream_t st_, int cls_)
+        : p(p_), st(st_), cls(cls_), on(p_->prof_enabled == 1 || (p_->prof_enabled == 2 && cls_ == JODO_PROF_EDGE_UPDATE)) {
         if (on) { hipEvent_t e = get(p); (void)hipEventRecord(e, st); p->prof_ev.push_back(e); }
     }
     ~ProfScope() {

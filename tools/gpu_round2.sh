@@ -4,8 +4,10 @@ TAG=${1:-rXX}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 900 python bench.py --steps 10 --warmup 3 --breakdown > $OUT/bench.json 2> $OUT/bench.err
+timeout 900 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 tail -2 $OUT/bench.err; cat $OUT/bench.json
+# per-kernel-class table: every class bracketed with HIP events (adds ~0.4 ms/step of event packets)
+timeout 900 python bench.py --steps 10 --warmup 3 --breakdown --no-cpu-baseline > $OUT/bench_breakdown.json 2> $OUT/bench_breakdown.err; cat $OUT/bench_breakdown.json
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o trace -- \
     python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err )
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
