@@ -17,9 +17,10 @@ namespace jd {
 // ------------------------------------------------------------------------------------------------
 // LDS-resident weights: the two edge-attention kernels use small projections (K = 64) whose whole
 // weight set fits in LDS (scores: edge_emb 32 KiB + lin_edge0 64 KiB; msgs: lin_edge1 64 KiB).  A
-// workgroup of 8 waves (8 work items) loads it once; every iteration then reads its A operands with
-// conflict-free ds_read_b128 instead of streaming them from L2 (which was the L1-bandwidth limiter:
-// 256 B of weights per MFMA at K = 64).
+// workgroup (8 waves for the directed scores kernel, 4 for the message and the pair scores kernels: a
+// workgroup holds its CU slots until its slowest wave is done, so smaller is better once staging is
+// amortised) loads it once; every iteration then reads its A operands with conflict-free ds_read_b128
+// instead of streaming them from L2 (which was the L1-bandwidth limiter: 256 B of weights per MFMA at K = 64).
 constexpr int WG_WAVES = 8;
 
 template <int NQ, int NW = WG_WAVES>   // cooperative copy of NQ quads (1 KiB each) global -> LDS by NW waves

@@ -2,8 +2,11 @@
 //   k_node_pre    LN1 + modulate + q / k / v projections                      (layers.py:147-149)
 //   k_node_post   node2edge_lin per node, gated residual + LN2 + FFN, W_row h' / W_col h' (halves of
 //                 equi_update.input_lin), readout
+//   k_node_postw  the same with a workgroup of 2 or 4 waves per strip (few strips / remainder strips)
 // There are only Nn/32 node strips (1409 at QM9 B = 2500 — fewer than two per SIMD); k_node_pre is cut
-// into independent (strip, piece) items (q / k / v), which measured faster; k_node_post is not (see there).
+// into independent (strip, piece) items (q / k / v), which measured faster.  k_node_post keeps one item per strip
+// for every full round of 1024 strips and hands the remainder to k_node_postw; with >= 1024 strips it also
+// produces the next block's q / k / v (node_next_*), see the launcher in dgt_forward.hip.
 #pragma once
 #include "dgt_kernels_common.h"
 
