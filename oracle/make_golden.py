@@ -11,8 +11,20 @@ cond_DGT_concat with `jodo_amd.models.init_utils.deterministic_init_` (weights a
   traj_cond_dpm4.npz                           4-NFE hybrid DPM-solver trajectory on the conditional
                                                model (BASELINE config 5 path), recorded position noise
 
+  fwd_geom_big.npz / fwd_geom384_big.npz      GEOM molecules at the top of the size range, n = 181 (the dataset
+                                               maximum, datasets/datasets_config.py:58), 140, 100 — node strips
+                                               spanning 4-6 work-item parts, circulant pair walks of 90 offsets
+  blocks_qm9.npz / blocks_geom.npz             the reference's own per-block tensors (h, edge_attr, pos after every
+                                               e_block, models/mol_gnn.py:562-568) captured with forward hooks
+  traj_qm9_anc50.npz                           50-step ancestral trajectory; besides the replayable noise it records
+                                               every step's input state and the reference's prediction (teacher forcing)
+  traj_cond_dpm_multi8.npz / _single3.npz / _single1.npz
+                                               hybrid DPM-solver: 2nd-order multistep (8 NFE), single-step order 3
+                                               (6 NFE) and order 1 (3 NFE)
+
 While doing so it asserts the oracle restatement (oracle/dgt_oracle.py) against the reference:
-faithful == reference bit-for-bit, dense within 1e-5.  Run:  python oracle/make_golden.py
+faithful == reference bit-for-bit, dense within 1e-5.
+Run:  python oracle/make_golden.py [fixture-name-prefix ...]     (no argument = all)
 """
 import os
 import sys
@@ -141,12 +153,114 @@ def ancestral_fixture(ref, fname, steps=5, n_nodes=(9, 5, 17, 12), seed=21):
           'atom types', np.unique(one_hot.argmax(2).numpy()), 'bond types', np.unique(et.numpy()))
 
 
-def dpm_fixture(ref, fname, nfe=4, n_nodes=(9, 5, 17, 12), seed=31):
+def blocks_fixture(ref, cfg_name, n_nodes, seed, fname):
+    """The reference's own tensors after every e_block (mol_gnn.py:562-568): h [Nn,D], edge_attr [E,De] (sparse,
+    row-major (b,i,j) order of dense_to_sparse), pos after remove_mean_with_mask — for a self-conditioned call."""
+    cfg, model = build_reference_model(ref, cfg_name, seed)
+    hp = O.Hyper.from_config(cfg)
+    g = torch.Generator().manual_seed(seed + 100)
+    B, N = len(n_nodes), max(n_nodes)
+    nm, em = masks(n_nodes)
+    xh = torch.randn(B, N, 3 + hp.in_node_dim, generator=g) * nm
+    xh[:, :, :3] = xh[:, :, :3] - xh[:, :, :3].sum(1, keepdim=True) / nm.sum(1, keepdim=True) * nm
+    ex = torch.randn(B, N, N, hp.edge_ch, generator=g)
+    ex = (torch.tril(ex.permute(0, 3, 1, 2), -1) + torch.tril(ex.permute(0, 3, 1, 2), -1).transpose(-1, -2)).permute(0, 2, 3, 1)
+    ex = ex * em.reshape(B, N, N, 1)
+    nl = torch.randn(B, generator=g) * 2.0
+    rec = []
+    hooks = [model._modules['e_block_%d' % i].register_forward_hook(lambda m, a, out: rec.append([t.detach().clone() for t in out]))
+             for i in range(hp.n_layers)]
+    with torch.no_grad():
+        r1 = model(torch.ones(B), xh, nm, em, edge_x=ex, noise_level=nl, cond_x=None, cond_edge_x=None, context=None)
+        del rec[:]
+        r2 = model(torch.ones(B), xh, nm, em, edge_x=ex, noise_level=nl, cond_x=r1[0], cond_edge_x=r1[1], context=None)
+    for h_ in hooks:
+        h_.remove()
+    assert len(rec) == hp.n_layers
+    hs = torch.stack([r[0] for r in rec]).reshape(hp.n_layers, B, N, -1)
+    es = torch.stack([r[1] for r in rec])                                   # [L, E, De]
+    ps = torch.stack([ref.models.utils.remove_mean_with_mask(r[2].reshape(B, N, 3), nm) for r in rec])
+    # the dense oracle's intermediates against the reference's own
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        _, _, inter = O.forward_dense(sd, hp, xh, nm, em, ex, r1[0], r1[1], nl, None, return_intermediates=True)
+    eoff = 0
+    for b, n in enumerate(n_nodes):
+        for l in range(hp.n_layers):
+            blk = inter[b][l]
+            assert (blk['h'] - hs[l, b, :n]).abs().max() < 2e-5
+            assert (blk['pos'] - ps[l, b, :n]).abs().max() < 2e-5
+            offd = ~torch.eye(n, dtype=torch.bool)
+            assert (blk['e'][offd] - es[l, eoff:eoff + n * (n - 1)]).abs().max() < 2e-5
+        eoff += n * (n - 1)
+    np.savez_compressed(os.path.join(OUT, fname), cfg_name=cfg_name, seed=seed, n_nodes=np.array(n_nodes),
+                        xh=xh.numpy(), edge_x=ex.numpy(), noise_level=nl.numpy(), out1_x=r1[0].numpy(), out1_e=r1[1].numpy(),
+                        out2_x=r2[0].numpy(), out2_e=r2[1].numpy(), h=hs.numpy(), e=es.numpy(), pos=ps.numpy())
+    print(fname, 'ok; blocks', hp.n_layers, 'E', es.shape[1])
+
+
+def ancestral_tf_fixture(ref, fname, steps=50, n_nodes=(9, 5, 17, 12), seed=23):
+    """Long ancestral trajectory (K = 50, the upper end of SURVEY.md §8c's K-step range) with, per step, the
+    input state and the reference model's prediction, so a kernel can be teacher-forced along it."""
+    cfg, model = build_reference_model(ref, 'vpsde_qm9_uncond_jodo', seed, head_gain=HEAD_GAIN)
+    cfg.sampling.steps = steps
+    S = ref.sampling
+    ns = ref.diffusion.noise_schedule.NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0,
+                                                      continuous_beta_1=cfg.sde.continuous_beta_1)
+    sampler = S.AncestralSampler(ns, torch.linspace(ns.T, 1e-3, steps), cfg.model.pred_data, cfg.pred_edge,
+                                 cfg.model.self_cond, ref.utils.get_self_cond_fn(cfg))
+    n_nodes = list(n_nodes)
+    B, N = len(n_nodes), max(n_nodes)
+    nm, em = masks(n_nodes)
+    torch.manual_seed(seed)
+    node_nf = cfg.data.atom_types + int(cfg.model.include_fc_charge)
+    z = S.sample_combined_position_feature_noise(B, N, node_nf, nm)
+    ez = S.sample_symmetric_edge_feature_noise(B, N, cfg.model.edge_ch, em)
+    rec_node, rec_edge, rec_in, rec_out = [], [], [], []
+    orig_n, orig_e = S.sample_combined_position_feature_noise, S.sample_symmetric_edge_feature_noise
+
+    def rn(*a, **k):
+        v = orig_n(*a, **k)
+        rec_node.append(v.clone())
+        return v
+
+    def re_(*a, **k):
+        v = orig_e(*a, **k)
+        rec_edge.append(v.clone())
+        return v
+
+    def model_rec(t, x, node_mask, edge_mask, **kw):
+        out = model(t, x, node_mask, edge_mask, **kw)
+        rec_in.append((x.clone(), kw['edge_x'].clone(), kw['noise_level'].clone()))
+        rec_out.append((out[0].clone(), out[1].clone()))
+        return out
+
+    S.sample_combined_position_feature_noise, S.sample_symmetric_edge_feature_noise = rn, re_
+    try:
+        with torch.no_grad():
+            x_mean, e_mean = sampler.sampling(model_rec, z, nm, em, ez, None)
+    finally:
+        S.sample_combined_position_feature_noise, S.sample_symmetric_edge_feature_noise = orig_n, orig_e
+    inv = ref.utils.get_data_inverse_scaler(cfg)
+    pos, one_hot, fc, et = S.post_process(x_mean.clone(), cfg.data.atom_types, cfg.model.include_fc_charge, nm, inv,
+                                          e_mean.clone(), em, cfg.data.compress_edge)
+    np.savez_compressed(os.path.join(OUT, fname), seed=seed, steps=steps, head_gain=HEAD_GAIN, n_nodes=np.array(n_nodes),
+                        z=z.numpy(), edge_z=ez.numpy(), node_noise=torch.stack(rec_node).numpy(),
+                        edge_noise=torch.stack(rec_edge).numpy(), x_mean=x_mean.numpy(), edge_x_mean=e_mean.numpy(),
+                        pos=pos.numpy(), atom_type=one_hot.argmax(2).numpy(), fc=fc.numpy(), edge_type=et.numpy(),
+                        step_x=torch.stack([r[0] for r in rec_in]).numpy(), step_edge_x=torch.stack([r[1] for r in rec_in]).numpy(),
+                        step_noise_level=torch.stack([r[2] for r in rec_in]).numpy(),
+                        step_pred=torch.stack([r[0] for r in rec_out]).numpy(),
+                        step_edge_pred=torch.stack([r[1] for r in rec_out]).numpy())
+    print(fname, 'ok; steps', len(rec_in), 'atom types', np.unique(one_hot.argmax(2).numpy()), 'bond types', np.unique(et.numpy()))
+
+
+def dpm_fixture(ref, fname, nfe=4, n_nodes=(9, 5, 17, 12), seed=31, method='singlestep_fixed', order=2):
     cfg, model = build_reference_model(ref, 'vpsde_qm9_cond_jodo', seed, head_gain=HEAD_GAIN)
     cfg.sampling.steps = nfe
     cfg.sampling.method = 'fast'
-    cfg.sampling.dpm_solver_method = 'singlestep_fixed'       # keys the cond config lacks
-    cfg.sampling.dpm_solver_order = 2
+    cfg.sampling.dpm_solver_method = method                   # keys the cond config lacks (SURVEY.md §0)
+    cfg.sampling.dpm_solver_order = order
     M = ref.mix_dpm_solver
     S = ref.sampling
     ns = ref.diffusion.noise_schedule.NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0,
@@ -174,7 +288,7 @@ def dpm_fixture(ref, fname, nfe=4, n_nodes=(9, 5, 17, 12), seed=31):
     finally:
         M.sample_center_gravity_zero_gaussian_with_mask = orig
     np.savez_compressed(os.path.join(OUT, fname), seed=seed, nfe=nfe, head_gain=HEAD_GAIN, n_nodes=np.array(n_nodes),
-                        z=z.numpy(), edge_z=ez.numpy(), context=ctx.numpy(), pos_noise=torch.stack(rec).numpy(),
+                        method=method, order=order, z=z.numpy(), edge_z=ez.numpy(), context=ctx.numpy(), pos_noise=torch.stack(rec).numpy(),
                         x=x.numpy(), edge_x=ex.numpy())
     print(fname, 'ok; noise draws', len(rec))
 
@@ -182,12 +296,26 @@ def dpm_fixture(ref, fname, nfe=4, n_nodes=(9, 5, 17, 12), seed=31):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
-    forward_fixture(ref, 'vpsde_qm9_uncond_jodo', [3, 5, 9, 12, 17, 29], 11, 'fwd_qm9.npz')
-    forward_fixture(ref, 'vpsde_geom_uncond_jodo', [5, 23, 44, 61], 12, 'fwd_geom.npz')
-    forward_fixture(ref, 'vpsde_qm9_cond_jodo', [4, 9, 18, 18, 27], 13, 'fwd_cond.npz')
-    forward_fixture(ref, 'vpsde_geom_uncond_jodo', [5, 23, 44], 14, 'fwd_geom384.npz', nf=384)    # BASELINE config 4 width
-    ancestral_fixture(ref, 'traj_qm9_anc5.npz')
-    dpm_fixture(ref, 'traj_cond_dpm4.npz')
+    jobs = [
+        ('fwd_qm9.npz', lambda f: forward_fixture(ref, 'vpsde_qm9_uncond_jodo', [3, 5, 9, 12, 17, 29], 11, f)),
+        ('fwd_geom.npz', lambda f: forward_fixture(ref, 'vpsde_geom_uncond_jodo', [5, 23, 44, 61], 12, f)),
+        ('fwd_cond.npz', lambda f: forward_fixture(ref, 'vpsde_qm9_cond_jodo', [4, 9, 18, 18, 27], 13, f)),
+        ('fwd_geom384.npz', lambda f: forward_fixture(ref, 'vpsde_geom_uncond_jodo', [5, 23, 44], 14, f, nf=384)),   # BASELINE config 4 width
+        ('fwd_geom_big.npz', lambda f: forward_fixture(ref, 'vpsde_geom_uncond_jodo', [100, 181, 140], 15, f)),      # dataset maximum n = 181
+        ('fwd_geom384_big.npz', lambda f: forward_fixture(ref, 'vpsde_geom_uncond_jodo', [140, 100, 181], 16, f, nf=384)),
+        ('blocks_qm9.npz', lambda f: blocks_fixture(ref, 'vpsde_qm9_uncond_jodo', [3, 9, 17, 29], 17, f)),
+        ('blocks_geom.npz', lambda f: blocks_fixture(ref, 'vpsde_geom_uncond_jodo', [12, 33], 18, f)),
+        ('traj_qm9_anc5.npz', lambda f: ancestral_fixture(ref, f)),
+        ('traj_qm9_anc50.npz', lambda f: ancestral_tf_fixture(ref, f)),
+        ('traj_cond_dpm4.npz', lambda f: dpm_fixture(ref, f)),
+        ('traj_cond_dpm_multi8.npz', lambda f: dpm_fixture(ref, f, nfe=8, seed=32, method='multistep', order=2)),
+        ('traj_cond_dpm_single3.npz', lambda f: dpm_fixture(ref, f, nfe=6, seed=33, method='singlestep_fixed', order=3)),
+        ('traj_cond_dpm_single1.npz', lambda f: dpm_fixture(ref, f, nfe=3, seed=34, method='singlestep_fixed', order=1)),
+    ]
+    want = sys.argv[1:]
+    for fname, job in jobs:
+        if not want or any(fname.startswith(w) for w in want):
+            job(fname)
 
 
 if __name__ == '__main__':

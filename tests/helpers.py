@@ -73,6 +73,35 @@ class OracleModel:
                            kw.get('cond_edge_x'), kw['noise_level'], context)
 
 
+def reference_blocks_dense(fx, l):
+    """Per molecule (original batch order): the reference's tensors after block l from a blocks_*.npz fixture as
+    (h [n,D], e [n,n,De] dense with a zero diagonal, pos [n,3]); the fixture stores the edge state sparse in the
+    (b, i, j) row-major order of dense_to_sparse (mol_gnn.py:512-514)."""
+    n_nodes = fx['n_nodes'].tolist()
+    out, eoff = [], 0
+    for b, n in enumerate(n_nodes):
+        offd = ~torch.eye(n, dtype=torch.bool)
+        e = torch.zeros(n, n, fx['e'].shape[-1])
+        e[offd] = torch.from_numpy(fx['e'][l, eoff:eoff + n * (n - 1)])
+        eoff += n * (n - 1)
+        out.append((torch.from_numpy(fx['h'][l, b, :n]), e, torch.from_numpy(fx['pos'][l, b, :n])))
+    return out
+
+
+def debug_fetch(model, what, count):
+    """jodo_debug_fetch (include/jodo_hip.h) of the plan used by the model's last call -> CPU tensor."""
+    import ctypes
+    from jodo_amd import capi
+    plan = model._last_plan
+    dst = torch.empty(count, device=plan['ws'].device)
+    cnt = ctypes.c_int64()
+    capi.check(capi.lib().jodo_debug_fetch(plan['handle'], capi.ptr(plan['ws']), what, capi.ptr(dst), ctypes.byref(cnt),
+                                           capi.current_stream_ptr()), 'jodo_debug_fetch')
+    torch.cuda.synchronize()
+    assert cnt.value <= count
+    return dst[:cnt.value].cpu()
+
+
 def max_err(a, b):
     return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
 

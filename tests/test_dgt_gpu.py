@@ -11,7 +11,8 @@ import torch
 
 from oracle import dgt_oracle as O
 
-from helpers import (check_decodes, load_fixture, make_config, make_model, masks, random_inputs, state_dict_cpu)
+from helpers import (check_decodes, debug_fetch, load_fixture, make_config, make_model, masks, random_inputs,
+                     reference_blocks_dense, state_dict_cpu)
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -37,6 +38,10 @@ def run(model, xh, ex, nl, nm, em, cx=None, cex=None, ctx=None):
 # is pinned at nf = 256 against the same reference fixtures as the tuned kernels
 @pytest.mark.parametrize("fname,layout", [("fwd_qm9.npz", "auto"), ("fwd_geom.npz", "auto"), ("fwd_cond.npz", "auto"),
                                           ("fwd_geom384.npz", "auto"),
+                                          # n = 181 (GEOM maximum), 140, 100: strips spanning many work-item parts,
+                                          # circulant pair walks of up to 90 offsets
+                                          ("fwd_geom_big.npz", "auto"), ("fwd_geom_big.npz", "wide"),
+                                          ("fwd_geom384_big.npz", "auto"),
                                           ("fwd_qm9.npz", "wide"), ("fwd_geom.npz", "wide"), ("fwd_cond.npz", "wide")])
 def test_hip_matches_reference_fixture(fname, layout):
     fx = load_fixture(fname)
@@ -185,15 +190,17 @@ def test_ancestral_trajectory_with_hip_model():
     check_decodes(cfg, fx, x_mean, e_mean, nm, em)
 
 
-def test_dpm_solver_trajectory_with_hip_model():
+@pytest.mark.parametrize("fname", ['traj_cond_dpm4.npz', 'traj_cond_dpm_multi8.npz', 'traj_cond_dpm_single3.npz',
+                                   'traj_cond_dpm_single1.npz'])
+def test_dpm_solver_trajectory_with_hip_model(fname):
     from jodo_amd.diffusion import NoiseScheduleVP
     from jodo_amd.mix_dpm_solver import DPM_Solver_hybrid
-    fx = load_fixture('traj_cond_dpm4.npz')
+    fx = load_fixture(fname)
     cfg = make_config('vpsde_qm9_cond_jodo')
     cfg.sampling.steps = int(fx['nfe'])
     cfg.sampling.method = 'fast'
-    cfg.sampling.dpm_solver_method = 'singlestep_fixed'
-    cfg.sampling.dpm_solver_order = 2
+    cfg.sampling.dpm_solver_method = str(fx['method']) if 'method' in fx else 'singlestep_fixed'
+    cfg.sampling.dpm_solver_order = int(fx['order']) if 'order' in fx else 2
     model = make_model(cfg, int(fx['seed']), DEV, head_gain=float(fx['head_gain']))
     nm, em = masks(fx['n_nodes'].tolist(), DEV)
     pn = torch.from_numpy(fx['pos_noise']).to(DEV)
@@ -202,6 +209,141 @@ def test_dpm_solver_trajectory_with_hip_model():
                             torch.from_numpy(fx['context']).to(DEV))
     close(x, torch.from_numpy(fx['x']), atol=1e-3, rtol=0)
     close(ex, torch.from_numpy(fx['edge_x']), atol=1e-3, rtol=0)
+
+
+def test_ancestral_50_steps_free_running_and_teacher_forced():
+    """K = 50: (a) free-running with the recorded noise, end state within the K-step tolerance and decodes
+    bit-exact above margin; (b) teacher-forced: every one of the reference's 50 recorded step inputs through the
+    kernels, against the reference's recorded prediction at the single-forward tolerance."""
+    from jodo_amd.diffusion import NoiseScheduleVP
+    from jodo_amd.sampling import AncestralSampler
+    from jodo_amd.utils import get_self_cond_fn
+    fx = load_fixture('traj_qm9_anc50.npz')
+    cfg = make_config('vpsde_qm9_uncond_jodo')
+    model = make_model(cfg, int(fx['seed']), DEV, head_gain=float(fx['head_gain']))
+    nm, em = masks(fx['n_nodes'].tolist(), DEV)
+    ns = NoiseScheduleVP(cfg.sde.schedule)
+    steps = int(fx['steps'])
+    noise = {'node': torch.from_numpy(fx['node_noise']).to(DEV), 'edge': torch.from_numpy(fx['edge_noise']).to(DEV)}
+    sampler = AncestralSampler(ns, torch.linspace(ns.T, 1e-3, steps), True, True, True,
+                               get_self_cond_fn(cfg), noise_fn=lambda i, kind, like: noise[kind][i])
+    with torch.no_grad():
+        x_mean, e_mean = sampler.sampling(model, torch.from_numpy(fx['z']).to(DEV), nm, em,
+                                          torch.from_numpy(fx['edge_z']).to(DEV), None)
+    close(x_mean, torch.from_numpy(fx['x_mean']), atol=1e-3, rtol=0)
+    close(e_mean, torch.from_numpy(fx['edge_x_mean']), atol=1e-3, rtol=0)
+    check_decodes(cfg, fx, x_mean, e_mean, nm, em)
+    t = lambda k, i: torch.from_numpy(fx[k][i]).to(DEV)
+    worst = 0.0
+    with torch.no_grad():
+        for i in range(steps):
+            cx = None if i == 0 else t('step_pred', i - 1)
+            cex = None if i == 0 else t('step_edge_pred', i - 1)
+            nl = t('step_noise_level', i)
+            px, pe = model(nl, t('step_x', i), nm, em, edge_x=t('step_edge_x', i), cond_x=cx, cond_edge_x=cex, noise_level=nl)
+            close(px, t('step_pred', i), atol=5e-5)          # head_gain 30 amplifies the output error accordingly
+            close(pe, t('step_edge_pred', i), atol=5e-5)
+            worst = max(worst, (px - t('step_pred', i)).abs().max().item(), (pe - t('step_edge_pred', i)).abs().max().item())
+    print("teacher-forced worst |err| over 50 steps: %.2e" % worst)
+
+
+@pytest.mark.parametrize("fname,layout", [("blocks_qm9.npz", "auto"), ("blocks_qm9.npz", "wide"), ("blocks_geom.npz", "auto"),
+                                          ("blocks_geom.npz", "wide")])
+def test_per_block_intermediates(fname, layout):
+    """h, edge state and positions after EVERY block against the reference's own per-block tensors
+    (models/mol_gnn.py:562-568, captured by oracle/make_golden.py) at the per-block tolerance atol 1e-4
+    (SURVEY.md §8c): an error that cancels by the last block or hides behind the small gain of the output heads
+    would show here.  jodo_debug_set_max_blocks stops the forward after l + 1 blocks, jodo_debug_fetch copies the
+    packed internal arrays out (molecules in descending-size order, dense n x n edge tiles)."""
+    from jodo_amd import capi
+    fx = load_fixture(fname)
+    cfg = make_config(str(fx['cfg_name']), kernel_layout=layout)
+    model = make_model(cfg, int(fx['seed']), DEV)
+    hp = O.Hyper.from_config(cfg)
+    n_nodes = fx['n_nodes'].tolist()
+    nm, em = masks(n_nodes, DEV)
+    t = lambda k: torch.from_numpy(fx[k]).to(DEV)
+    args = (t('noise_level'), t('xh'), nm, em)
+    kw = dict(edge_x=t('edge_x'), cond_x=t('out1_x'), cond_edge_x=t('out1_e'), noise_level=t('noise_level'))
+    with torch.no_grad():
+        o = model(*args, **kw)
+    close(o[0], t('out2_x'))
+    close(o[1], t('out2_e'))
+    order = sorted(range(len(n_nodes)), key=lambda b: -n_nodes[b])           # the plan's order: descending n, stable
+    Nn, rows, D, De = sum(n_nodes), sum(n * n for n in n_nodes), hp.nf, hp.de
+    handle = model._last_plan['handle']
+    worst = dict(h=0.0, e=0.0, pos=0.0)
+    try:
+        for l in range(hp.n_layers):
+            capi.check(capi.lib().jodo_debug_set_max_blocks(handle, l + 1), 'set_max_blocks')
+            with torch.no_grad():
+                model(*args, **kw)
+            assert model._last_plan['handle'] is handle                         # same plan (same mask tensors)
+            h = debug_fetch(model, 0, Nn * D).reshape(Nn, D)
+            e = debug_fetch(model, 1, rows * De).reshape(rows, De)
+            pos = debug_fetch(model, 2, Nn * 4).reshape(Nn, 4)[:, :3]
+            ref = reference_blocks_dense(fx, l)
+            no, eo = 0, 0
+            for b in order:
+                n = n_nodes[b]
+                rh, re, rp = ref[b]
+                offd = ~torch.eye(n, dtype=torch.bool)
+                gp = pos[no:no + n] - pos[no:no + n].mean(0, keepdim=True)      # the kernels centre once, at the end
+                ge = e[eo:eo + n * n].reshape(n, n, De)
+                for name, got, want in (('h', h[no:no + n], rh), ('e', ge[offd], re[offd]), ('pos', gp, rp)):
+                    err = (got - want).abs().max().item() if want.numel() else 0.0
+                    worst[name] = max(worst[name], err)
+                    assert err < 1e-4, "block %d molecule %d %s: %.3e" % (l, b, name, err)
+                no += n
+                eo += n * n
+    finally:
+        capi.check(capi.lib().jodo_debug_set_max_blocks(handle, -1), 'set_max_blocks')
+    print("per-block worst |err|:", worst)
+
+
+@pytest.mark.parametrize("cfg_name,info,B,over", [
+    ('vpsde_qm9_uncond_jodo', 'qm9_with_h', 2500, {}),                     # BASELINE configs[1]
+    ('vpsde_geom_uncond_jodo', 'geom_with_h_1', 512, {}),                  # BASELINE configs[2]
+    ('vpsde_geom_uncond_jodo', 'geom_with_h_1', 1250, dict(nf=384)),       # per-GPU share of BASELINE configs[3]
+])
+def test_full_size_batches_match_oracle_on_sampled_molecules(cfg_name, info, B, over):
+    """The batch sizes the bench numbers are quoted on: a first-step and a self-conditioned evaluation of the FULL
+    batch by the kernels; 64 whole molecules spread over the size range (always including the largest and the
+    smallest) are then re-evaluated by the dense oracle as a sub-batch (cheap; outputs are batch-independent,
+    SURVEY.md §4) and compared at the single-forward tolerance."""
+    from jodo_amd.models import load_dataset_info, get_node_dist
+    cfg = make_config(cfg_name, **over)
+    model = make_model(cfg, 8, DEV)
+    hp = O.Hyper.from_config(cfg)
+    sd = state_dict_cpu(model)
+    torch.manual_seed(42)
+    n_nodes = get_node_dist(load_dataset_info(info)).sample(B).tolist()
+    xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=7)
+    xh[:, :, :3] -= xh[:, :, :3].sum(1, keepdim=True) / nm.sum(1, keepdim=True) * nm
+    nl[:] = 0.5                                                              # sampling: one noise level per batch
+    x1, e1 = run(model, xh, ex, nl, nm, em)
+    assert model.last_flags.cpu().tolist()[:5] == [0, 1, 1, 0, 0]            # first step, shared time row, pair path
+    x2, e2 = run(model, xh, ex, nl, nm, em, x1, e1)
+    assert model.last_flags.cpu().tolist()[:5] == [0, 0, 1, 1, 0]
+    N = max(n_nodes)
+    for x, e in ((x1, e1), (x2, e2)):
+        assert torch.isfinite(x).all() and torch.isfinite(e).all()
+        assert torch.equal(e, e.transpose(1, 2))
+        assert (x * (1 - nm)).abs().max() == 0 and (e * (1 - em.reshape(B, N, N, 1))).abs().max() == 0
+    by_size = sorted(range(B), key=lambda b: (n_nodes[b], b))
+    sub = sorted(set(by_size[int(round(i * (B - 1) / 63.0))] for i in range(64)))
+    sn = [n_nodes[b] for b in sub]
+    Ns = max(sn)
+    assert max(sn) == max(n_nodes) and min(sn) == min(n_nodes) and len(sub) >= 60
+    nms, ems = masks(sn)
+    cut = lambda a, k: a[sub][:, :Ns] if k == 1 else a[sub][:, :Ns, :Ns]
+    with torch.no_grad():
+        r1 = O.forward_dense(sd, hp, cut(xh, 1), nms, ems, cut(ex, 2), None, None, nl[sub])
+        r2 = O.forward_dense(sd, hp, cut(xh, 1), nms, ems, cut(ex, 2), cut(x1, 1), cut(e1, 2), nl[sub])
+    close(cut(x1, 1), r1[0], atol=3e-5)
+    close(cut(e1, 2), r1[1], atol=3e-5)
+    close(cut(x2, 1), r2[0], atol=3e-5)
+    close(cut(e2, 2), r2[1], atol=3e-5)
 
 
 def test_full_size_batch_properties():

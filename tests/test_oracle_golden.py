@@ -56,14 +56,18 @@ def test_ancestral_sampler_reproduces_reference_trajectory():
     check_decodes(cfg, fx, x_mean, e_mean, nm, em)
 
 
-def test_dpm_solver_reproduces_reference_trajectory():
-    fx = load_fixture('traj_cond_dpm4.npz')
+# hybrid DPM-solver (mix_dpm_solver.py): single-step order 2 (BASELINE config 5), 2nd-order multistep (:230-265 and
+# the warm-up / history shifting of :340-372), single-step order 3 (:150-227) and order 1 (:61-93)
+@pytest.mark.parametrize("fname", ['traj_cond_dpm4.npz', 'traj_cond_dpm_multi8.npz', 'traj_cond_dpm_single3.npz',
+                                   'traj_cond_dpm_single1.npz'])
+def test_dpm_solver_reproduces_reference_trajectory(fname):
+    fx = load_fixture(fname)
     cfg = make_config('vpsde_qm9_cond_jodo')
     cfg.device = 'cpu'
     cfg.sampling.steps = int(fx['nfe'])
     cfg.sampling.method = 'fast'
-    cfg.sampling.dpm_solver_method = 'singlestep_fixed'
-    cfg.sampling.dpm_solver_order = 2
+    cfg.sampling.dpm_solver_method = str(fx['method']) if 'method' in fx else 'singlestep_fixed'
+    cfg.sampling.dpm_solver_order = int(fx['order']) if 'order' in fx else 2
     model = make_model(cfg, int(fx['seed']), head_gain=float(fx['head_gain']))
     om = OracleModel(state_dict_cpu(model), O.Hyper.from_config(cfg), faithful=True)
     nm, em = masks(fx['n_nodes'].tolist())
@@ -73,6 +77,83 @@ def test_dpm_solver_reproduces_reference_trajectory():
                             torch.from_numpy(fx['context']))
     assert (x - torch.from_numpy(fx['x'])).abs().max() < 1e-3   # K-step trajectory tolerance
     assert (ex - torch.from_numpy(fx['edge_x'])).abs().max() < 1e-3   # K-step trajectory tolerance
+
+
+def test_ancestral_sampler_50_steps_and_teacher_forced_oracle():
+    """K = 50 (upper end of SURVEY.md §8c's K-step range): the host sampler + faithful oracle reproduce the
+    reference's trajectory, and the dense oracle reproduces every recorded per-step prediction from the recorded
+    per-step inputs (teacher forcing; the tolerance of a single forward)."""
+    fx = load_fixture('traj_qm9_anc50.npz')
+    cfg = make_config('vpsde_qm9_uncond_jodo')
+    cfg.device = 'cpu'
+    model = make_model(cfg, int(fx['seed']), head_gain=float(fx['head_gain']))
+    hp = O.Hyper.from_config(cfg)
+    sd = state_dict_cpu(model)
+    nm, em = masks(fx['n_nodes'].tolist())
+    ns = _schedule(cfg)
+    steps = int(fx['steps'])
+    assert steps == 50 and fx['step_x'].shape[0] == 50
+    noise = {'node': torch.from_numpy(fx['node_noise']), 'edge': torch.from_numpy(fx['edge_noise'])}
+    sampler = AncestralSampler(ns, torch.linspace(ns.T, 1e-3, steps), True, True, True, get_self_cond_fn(cfg),
+                               noise_fn=lambda i, kind, like: noise[kind][i])
+    x_mean, e_mean = sampler.sampling(OracleModel(sd, hp, faithful=True), torch.from_numpy(fx['z']), nm, em,
+                                      torch.from_numpy(fx['edge_z']), None)
+    assert (x_mean - torch.from_numpy(fx['x_mean'])).abs().max() < 1e-3      # K-step trajectory tolerance
+    assert (e_mean - torch.from_numpy(fx['edge_x_mean'])).abs().max() < 1e-3
+    check_decodes(cfg, fx, x_mean, e_mean, nm, em)
+    t = lambda k, i: torch.from_numpy(fx[k][i])
+    with torch.no_grad():
+        for i in (0, 1, 7, 24, 49):
+            cx = None if i == 0 else t('step_pred', i - 1)
+            cex = None if i == 0 else t('step_edge_pred', i - 1)
+            d = O.forward_dense(sd, hp, t('step_x', i), nm, em, t('step_edge_x', i), cx, cex, t('step_noise_level', i))
+            assert (d[0] - t('step_pred', i)).abs().max() < 2e-5
+            assert (d[1] - t('step_edge_pred', i)).abs().max() < 5e-5
+
+
+@pytest.mark.parametrize("fname", ['blocks_qm9.npz', 'blocks_geom.npz'])
+def test_oracle_intermediates_match_reference_blocks(fname):
+    """The reference's own h / edge_attr / pos after every block (mol_gnn.py:562-568) against the dense oracle's
+    per-block intermediates — the same tensors the -m gpu test fetches from the kernels."""
+    from helpers import reference_blocks_dense
+    fx = load_fixture(fname)
+    cfg = make_config(str(fx['cfg_name']))
+    sd = state_dict_cpu(make_model(cfg, int(fx['seed'])))
+    hp = O.Hyper.from_config(cfg)
+    n_nodes = fx['n_nodes'].tolist()
+    nm, em = masks(n_nodes)
+    t = lambda k: torch.from_numpy(fx[k])
+    with torch.no_grad():
+        ox, oe, inter = O.forward_dense(sd, hp, t('xh'), nm, em, t('edge_x'), t('out1_x'), t('out1_e'), t('noise_level'),
+                                        None, return_intermediates=True)
+    assert (ox - t('out2_x')).abs().max() < 1e-5 and (oe - t('out2_e')).abs().max() < 1e-5
+    for l in range(hp.n_layers):
+        for b, (h, e, pos) in enumerate(reference_blocks_dense(fx, l)):
+            n = n_nodes[b]
+            offd = ~torch.eye(n, dtype=torch.bool)
+            assert (inter[b][l]['h'] - h).abs().max() < 1e-4                     # per-block tolerance (SURVEY.md §8c)
+            assert (inter[b][l]['e'][offd] - e[offd]).abs().max() < 1e-4
+            assert (inter[b][l]['pos'] - pos).abs().max() < 1e-4
+
+
+def test_large_molecule_fixture_against_dense_oracle():
+    """n = 100 molecule of the GEOM size-range fixture, evaluated alone by the dense oracle (batch independence,
+    SURVEY.md §4) — the n = 181 / 140 molecules were checked when the fixture was generated (oracle/make_golden.py
+    asserts dense == reference < 1e-5 on the whole batch) and are checked against the kernels in -m gpu."""
+    fx = load_fixture('fwd_geom_big.npz')
+    cfg = make_config(str(fx['cfg_name']))
+    sd = state_dict_cpu(make_model(cfg, int(fx['seed'])))
+    hp = O.Hyper.from_config(cfg)
+    n_nodes = fx['n_nodes'].tolist()
+    assert max(n_nodes) == 181
+    b = n_nodes.index(100)
+    nm, em = masks([100])
+    t = lambda k: torch.from_numpy(fx[k])
+    with torch.no_grad():
+        d = O.forward_dense(sd, hp, t('xh')[b:b + 1, :100], nm, em, t('edge_x')[b:b + 1, :100, :100],
+                            t('out1_x')[b:b + 1, :100], t('out1_e')[b:b + 1, :100, :100], t('noise_level')[b:b + 1])
+    assert (d[0] - t('out2_x')[b:b + 1, :100]).abs().max() < 2e-5
+    assert (d[1] - t('out2_e')[b:b + 1, :100, :100]).abs().max() < 2e-5
 
 
 def test_dense_and_faithful_agree_with_edge_cases():
