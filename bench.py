@@ -15,9 +15,18 @@ path; RCCL is only used for the timing reduction and the final gather of generat
 The JSON line also carries
   roofline      fp32-MFMA roofline of the dominant kernel (k_edge_update), timed live with HIP events
                 on the launch stream (jodo_profile_* in the C ABI); algorithmic FLOPs per launch =
-                directed edges x per-edge FLOPs of that kernel
-  cpu_baseline  oracle/dgt_oracle.py forward_faithful (op-for-op port of the reference's sparse
-                formulation) timed on the host cores on a bounded sample (rank 0, N = 1 only)
+                directed edges x per-edge FLOPs of that kernel.  `traffic` = HBM bytes per
+                launch of that kernel from the committed PMC passes of this same command
+                (profiles/*_pmc_traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE /
+                WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md), `hbm` = the same for the
+                three edge kernels with GB/s against the 8 TB/s peak; null when no committed pass matches
+                this workload
+  steady_state  >= 100 timed steps (when --steps is smaller) — the per-step figure SURVEY.md §8d asks for
+  full_round    one complete 1000-step round through the public entry points (get_sampling_fn -> sampler
+                -> device decode -> host tuples), wall clock: the end-to-end molecules/s, not extrapolated
+  cpu_baseline  BASELINE config 1 in full (QM9, batch 64, 50 ancestral steps) with the port of the
+                reference's CPU path (our host sampler + oracle.forward_faithful) on the box's host cores
+                (rank 0, N = 1 only); calibration of the port against the real reference: BASELINE.md §3
 """
 import argparse
 import ctypes
@@ -56,47 +65,128 @@ def edge_update_flops_per_edge(hp):
             + 12 * De + 8 * D)             # LN2/modulate on e, LN/modulate on u
 
 
-def cpu_baseline(seed=42):
-    """Bounded CPU sample: QM9 model, B = 64 (BASELINE config 1 shape), a few denoise-step forwards of the
-    faithful port, extrapolated to molecules/s of a 1000-step round."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(seed=42, steps=50, batch=64):
+    """BASELINE config 1 in full: vpsde_qm9_uncond_jodo, batch 64, 50 ancestral steps on the host CPU with the
+    port of the reference's path (jodo_amd's host sampler driving oracle.forward_faithful, the op-for-op mirror of
+    the reference's sparse formulation; the reference itself cannot travel to the GPU box).  Same procedure as
+    oracle/calibrate_cpu.py, which times it against the real reference in the build container.
+
+    Threads: torch CPU scatter code does not always scale to a big box's core count, so two forwards are probed with
+    os.cpu_count() threads and with 32; the 50-step run uses the faster setting and `cores` reports it (both probe
+    timings are in the record)."""
     from jodo_amd import configs
+    from jodo_amd.diffusion import NoiseScheduleVP
     from jodo_amd.models import get_model_class, deterministic_init_, load_dataset_info, get_node_dist
-    from jodo_amd.sampling import build_masks
+    from jodo_amd.models.utils import sample_combined_position_feature_noise, sample_symmetric_edge_feature_noise
+    from jodo_amd.sampling import AncestralSampler, build_masks
+    from jodo_amd.utils import get_self_cond_fn
     from oracle import dgt_oracle as O
     cfg = configs.get('vpsde_qm9_uncond_jodo')
     model = deterministic_init_(get_model_class('DGT_concat')(cfg), seed=seed)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     hp = O.Hyper.from_config(cfg)
     torch.manual_seed(seed)
-    n_nodes = get_node_dist(load_dataset_info('qm9_with_h')).sample(64).tolist()
-    B, N = 64, max(n_nodes)
+    n_nodes = get_node_dist(load_dataset_info('qm9_with_h')).sample(batch).tolist()
+    N = max(n_nodes)
     nm, em = build_masks(n_nodes, N, 'cpu')
-    xh = torch.randn(B, N, 9) * nm
-    ex = torch.randn(B, N, N, 2)
-    ex = (ex + ex.transpose(1, 2)) * em.reshape(B, N, N, 1)
-    nl = torch.full((B,), 0.5)
-    # scatter-heavy torch CPU code stops scaling (and can collapse) far below the box's core count:
-    # use at most 32 threads and report that number as `cores`
-    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 32)))
+    z = sample_combined_position_feature_noise(batch, N, 6, nm)
+    ez = sample_symmetric_edge_feature_noise(batch, N, 2, em)
+
+    class Port:
+        def __call__(self, t, xh, node_mask, edge_mask, context=None, **kw):
+            return O.forward_faithful(sd, hp, xh, node_mask, edge_mask, kw['edge_x'], kw.get('cond_x'), kw.get('cond_edge_x'),
+                                      kw['noise_level'], context)
+
+    ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
+    smp = AncestralSampler(ns, torch.linspace(ns.T, 1e-3, steps), True, True, True, get_self_cond_fn(cfg))
+    ncpu = os.cpu_count() or 1
+    probes = {}
     with torch.no_grad():
-        c = O.forward_faithful(sd, hp, xh, nm, em, ex, None, None, nl)        # warm-up + self-cond input
+        for th in sorted({ncpu, min(ncpu, 32)}, reverse=True):
+            torch.set_num_threads(th)
+            st = smp.step(Port(), 0, smp.init_state(z, ez), nm, em)            # warm-up (first step, cond = None)
+            t0 = time.perf_counter()
+            for i in (1, 2):
+                st = smp.step(Port(), i, st, nm, em)
+            probes[th] = (time.perf_counter() - t0) / 2
+        threads = min(probes, key=probes.get)
+        torch.set_num_threads(threads)
         t0 = time.perf_counter()
-        n_steps = 0
-        while n_steps < 1 or (time.perf_counter() - t0 < 15.0 and n_steps < 20):
-            c = O.forward_faithful(sd, hp, xh, nm, em, ex, c[0], c[1], nl)
-            n_steps += 1
-        dt = (time.perf_counter() - t0) / n_steps
-    return dict(value=B / (SAMPLING_STEPS * dt), unit='molecules/s', cores=torch.get_num_threads(), kind='port',
-                sample='%d self-conditioned denoise-step forwards of oracle.forward_faithful at B=64 '
-                       '(BASELINE config 1 shape), %.3f s/step, extrapolated x1000 steps' % (n_steps, dt),
-                ms_per_step=dt * 1e3)
+        x_mean, e_mean = smp.sampling(Port(), z, nm, em, ez, None)
+        wall = time.perf_counter() - t0
+    assert bool(torch.isfinite(x_mean).all())
+    return dict(value=batch / (wall * SAMPLING_STEPS / steps), unit='molecules/s', cores=threads, kind='port',
+                sample='BASELINE config 1 in full: QM9 uncond, batch %d, %d ancestral steps, %.1f s wall (%.3f s/step); value = '
+                       'molecules/s of a 1000-step round = batch / (wall x %d) (per-step cost is step-independent)'
+                       % (batch, steps, wall, wall / steps, SAMPLING_STEPS // steps),
+                config1_wall_s=wall, config1_molecules_per_s=batch / wall, ms_per_step=wall / steps * 1e3,
+                cpu=cpu_model(), cpu_count=ncpu,
+                thread_probe_s_per_step={str(k): round(v, 4) for k, v in probes.items()},
+                calibration='port vs the real reference on this config: see BASELINE.md §3 (build container, 8 threads)')
+
+
+class _SyntheticContext:
+    """Stand-in for cond_gen's DistributionProperty (needs the dataset): context ~ N(0,1) [B, cond_ch]."""
+
+    def __init__(self, cond_ch):
+        self.cond_ch = cond_ch
+
+    def sample_batch(self, n_nodes):
+        return torch.randn(len(n_nodes), self.cond_ch)
+
+
+def load_pmc_traffic(workload, batch, upd_ms):
+    """HBM bytes per launch from the newest committed PMC summary of this workload (profiles/*_pmc_traffic.json,
+    tools/pmc_traffic.py: separate --pmc FETCH_SIZE and WRITE_SIZE passes of `python bench.py`, FETCH_SIZE x2 per
+    the gfx950 note in MI355X_MICROARCH.md, per dispatch).  Returns (traffic_bytes_of_the_dominant_launch, table) or
+    (None, None).  Counters cannot be collected from inside the process being profiled, hence the committed pass."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get('workload') == workload and int(d.get('batch', -1)) == int(batch):
+            best = (f, d)
+    if best is None:
+        return None, None
+    f, d = best
+    table = {}
+    dominant = 0.0
+    for name, k in d['kernels'].items():
+        bytes_launch = k['fetch_bytes_x2_per_block'] + k['write_bytes_per_block']
+        row = {'hbm_bytes_per_launch': bytes_launch, 'fetch_bytes_x2': k['fetch_bytes_x2_per_block'],
+               'write_bytes': k['write_bytes_per_block'], 'algorithmic_bytes': k.get('algorithmic_bytes_per_block'),
+               'dispatches_per_launch': k.get('dispatches_per_block')}
+        ms_ = upd_ms if (name == 'edge_update' and upd_ms > 0) else k.get('avg_ms_per_block')
+        if ms_:
+            row['GBps'] = bytes_launch / (ms_ * 1e-3) / 1e9
+            row['frac_of_8TBps'] = row['GBps'] / 8000.0
+            row['ms_per_launch'] = ms_
+        table[name] = row
+        if name == 'edge_update':
+            dominant = bytes_launch
+    table['source'] = os.path.relpath(f, ROOT)
+    table['command'] = d.get('command')
+    return (dominant or None), table
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='qm9', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--max-chunk', type=int, default=0)
@@ -105,6 +195,8 @@ def main():
     ap.add_argument('--layout', default='auto', choices=['auto', 'wide'], help="'wide': width-generic kernels at nf=256")
     ap.add_argument('--graph', action='store_true', help='replay one captured HIP graph per step (jodo_amd/graphed.py)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-full-round', action='store_true', help='skip the end-to-end 1000-step round (N = 1 only leg)')
+    ap.add_argument('--full-round', action='store_true', help='run the end-to-end round for workloads other than qm9 too')
     ap.add_argument('--breakdown', action='store_true',
                     help='time every kernel class with HIP events (costs ~0.5 ms/step of event packets; default: only the '
                          'dominant pair-update class, which the roofline object needs) and print the table to stderr')
@@ -229,6 +321,18 @@ def main():
         except Exception as exc:                      # the extra must never take the headline down with it
             graph_info = {'error': repr(exc)}
         capi.check(L.jodo_profile_enable(plan['handle'], 1 if args.breakdown else 2), 'profile_enable')
+    # ---- >= 100 steady-state steps when the timed region above was shorter -----------------------
+    steady = None
+    if not args.graph and world == 1 and args.steps < 100:
+        with torch.no_grad():
+            torch.cuda.synchronize()
+            ts0 = time.perf_counter()
+            for i in range(args.warmup + args.steps, args.warmup + args.steps + 100):
+                st = sampler.step(model, i, st, node_mask, edge_mask, context)
+            torch.cuda.synchronize()
+            steady = {'steps': 100, 'ms_per_step': (time.perf_counter() - ts0) * 10.0}
+        steady['value'] = B / (SAMPLING_STEPS * steady['ms_per_step'] * 1e-3)
+        steady['unit'] = 'molecules/s'
     ms = (ctypes.c_float * 8)()
     cnt = (ctypes.c_int32 * 8)()
     capi.check(L.jodo_profile_read(plan['handle'], ms, cnt), 'profile_read')
@@ -251,6 +355,29 @@ def main():
         n_total = len(fused.mols_from_decoded(pos, at, fc, et, n_nodes))
     nan_fired = model.nan_guard_fired()
 
+    # ---- one complete round through the public entry points, wall clock (N = 1) -----------------------------------
+    full_round = None
+    if world == 1 and not args.no_full_round and (args.workload == 'qm9' or args.full_round):
+        from jodo_amd.sampling import get_sampling_fn
+        full_round = {}
+        for mode, hg in (('eager', False), ('hip_graph', True)):
+            try:
+                torch.manual_seed(cfg.seed)
+                fn = get_sampling_fn(cfg, ns, get_node_dist(load_dataset_info(wl['info'])), B, B, get_data_inverse_scaler(cfg),
+                                     prop_dist=_SyntheticContext(hp.cond_ch) if hp.cond_ch else None, return_raw=True, hip_graph=hg)
+                torch.cuda.synchronize()
+                tr = time.perf_counter()
+                mols = fn(model)
+                torch.cuda.synchronize()
+                tr = time.perf_counter() - tr
+                full_round[mode] = {'round_seconds': tr, 'molecules': len(mols), 'value': len(mols) / tr, 'unit': 'molecules/s',
+                                    'ms_per_step_incl_everything': tr / int(cfg.sampling.steps) * 1e3,
+                                    'steps': int(cfg.sampling.steps)}
+            except Exception as exc:                  # an extra leg must never take the headline down with it
+                full_round[mode] = {'error': repr(exc)}
+        full_round['note'] = ('get_sampling_fn -> sampler -> device decode -> host tuples, one call: atom-count draw, masks, '
+                              'initial noise, plan creation, %d denoise steps, decode and device->host copies all inside the '
+                              'clock (weights already packed)' % int(cfg.sampling.steps))
     if rank == 0:
         E = sum(n * (n - 1) for n in n_nodes)
         flops_launch = E * edge_update_flops_per_edge(hp)
@@ -258,7 +385,11 @@ def main():
         per_class = {names[c]: (ms[c] / max(cnt[c], 1), cnt[c]) for c in range(8)}
         upd_ms, upd_n = per_class['edge_update']
         achieved = flops_launch / (upd_ms * 1e-3) if upd_ms > 0 else 0.0
-        total_flops = O.algorithmic_flops(hp, n_nodes)['total']
+        flags_now = model.last_flags.cpu().tolist()
+        # sampling shares one noise level per batch and the kernels then evaluate the time-modulation GEMVs once
+        # (uniform_t flag set on the device): count them once, not once per molecule
+        total_flops = O.algorithmic_flops(hp, n_nodes, shared_time=bool(flags_now[2]) and not hp.cond_ch)['total']
+        traffic, hbm = load_pmc_traffic(args.workload, B, upd_ms)
         out = {
             'metric': 'molecules/sec (1000-step ancestral)',
             'value': B * world / (SAMPLING_STEPS * step_s),
@@ -272,7 +403,7 @@ def main():
                        'weights': 'deterministic random init (trained checkpoints are external downloads)',
                        'parallelism': 'batch shard x%d, no data-path collective' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'k_edge_update', 'achieved': achieved / 1e12, 'peak': PEAK_FP32_MFMA / 1e12,
-                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA, 'traffic': None,
+                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA, 'traffic': traffic, 'hbm': hbm,
                          'note': 'one launch = the pair-update work of one block: up to two dispatches of the same kernel '
                                  '(full rounds of work items + direction-split remainder) inside one HIP-event bracket; '
                                  'rocprofv3 lists the dispatches separately (their durations add up to avg_launch_ms)',
@@ -282,9 +413,10 @@ def main():
             # per-class totals per step; classes other than edge_update are only timed with --breakdown
             'kernel_ms': {k: round(v[0] * (v[1] / args.steps), 4) for k, v in per_class.items() if v[1] > 0},
             'hip_graph_replay': graph_info,
+            'steady_state': steady,
+            'full_round': full_round,
             'molecules_decoded': n_total, 'nan_guard': bool(nan_fired),
-            'device_flags': dict(zip(('nan', 'first_step', 'uniform_t', 'cond_nonzero', 'asymmetric_edges'),
-                                     model.last_flags.cpu().tolist()[:5])),
+            'device_flags': dict(zip(('nan', 'first_step', 'uniform_t', 'cond_nonzero', 'asymmetric_edges'), flags_now[:5])),
         }
         if args.breakdown:
             print(json.dumps(per_class), file=sys.stderr)

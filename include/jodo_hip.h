@@ -100,7 +100,8 @@ int jodo_plan_stats(const jodo_plan* plan, int64_t* out6);
  *   noise_level [B]; context [B,cond_ch] or NULL
  *   out_xh [B,N,3+nd], out_edge [B,N,N,ch] (fully written, zeros on padding)
  *   flags_dev: int32[8] device scratch; after the call [0] = NaN guard fired (mol_gnn.py:587-589),
- *              [1] = first-step branch taken (:544), [2] = all molecules shared one noise level,
+ *              [1] reserved (0), [2] = all molecules shared one noise level, [3] = the self-conditioning positions
+ *              were not all equal (0 => the batch-global first-step branch of :544 was taken),
  *              [4] = edge inputs were not symmetric (directed kernels used)
  *   workspace: jodo_plan_workspace_bytes() bytes of device scratch
  *   dbg: optional device buffer for intermediates (tests) or NULL */

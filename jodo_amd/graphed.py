@@ -51,6 +51,13 @@ class GraphedAncestralRound:
         capi.check(L.jodo_step_begin(B, capi.ptr(self.tab), capi.ptr(self.step), capi.ptr(self.nl), st), 'jodo_step_begin')
         pred, epred = self.model(self.nl, self.x, self.node_mask, self.edge_mask, edge_x=self.e, noise_level=self.nl,
                                  cond_x=self.cx, cond_edge_x=self.cex, context=self.context)
+        if self.record:
+            self.pred_keep.copy_(pred); self.epred_keep.copy_(epred)
+            self.x_prev.copy_(self.x); self.e_prev.copy_(self.e)
+        # self-conditioning post-process BEFORE the update, as the eager sampler and the reference do
+        # (sampling.py:553-571): 'clamp' clamps the atom / charge channels of pred in place, and the update uses them
+        cxn, cexn = self.sampler.cond_process_fn(pred, epred)
+        self.cx.copy_(cxn); self.cex.copy_(cexn)
         self.eps_pos.normal_()                     # draw order of models/utils.py:67-99: positions, features, edges
         self.eps_feat.normal_()
         self.eps_edge.normal_()
@@ -59,11 +66,6 @@ class GraphedAncestralRound:
                                            capi.ptr(self.eps_pos), capi.ptr(self.eps_feat), capi.ptr(self.eps_edge),
                                            capi.ptr(self.x_next), capi.ptr(self.e_next), capi.ptr(self.x_mean),
                                            capi.ptr(self.e_mean), st), 'jodo_sampler_step_tab')
-        if self.record:
-            self.pred_keep.copy_(pred); self.epred_keep.copy_(epred)
-            self.x_prev.copy_(self.x); self.e_prev.copy_(self.e)
-        cxn, cexn = self.sampler.cond_process_fn(pred, epred)
-        self.cx.copy_(cxn); self.cex.copy_(cexn)
         self.x.copy_(self.x_next); self.e.copy_(self.e_next)
         capi.check(L.jodo_step_end(capi.ptr(self.step), st), 'jodo_step_end')
 

@@ -372,8 +372,10 @@ def forward_dense(p, hp, xh, node_mask, edge_mask, edge_x, cond_x=None, cond_edg
 # ----------------------------------------------------------------------------------------------
 # algorithmic work model — used by bench.py for roofline.achieved
 # ----------------------------------------------------------------------------------------------
-def algorithmic_flops(hp, n_nodes):
-    """FLOPs (multiply-add = 2) of one forward for molecules with the given atom counts."""
+def algorithmic_flops(hp, n_nodes, shared_time=False):
+    """FLOPs (multiply-add = 2) of one forward for molecules with the given atom counts.  shared_time: every
+    molecule has the same noise level and there is no per-molecule context (unconditional sampling), so the time
+    embedding and the per-block modulation GEMVs are needed once per batch, not once per molecule."""
     D, De, T, L, r = hp.nf, hp.de, hp.tdim, hp.n_layers, hp.mlp_ratio
     QK = hp.sub_heads * hp.sub_ch
     XH = hp.n_extra_heads
@@ -386,7 +388,7 @@ def algorithmic_flops(hp, n_nodes):
     n = torch.as_tensor(n_nodes, dtype=torch.float64)
     E = float((n * (n - 1)).sum())
     Nn = float(n.sum())
-    B = float(n.numel())
+    B = 1.0 if shared_time else float(n.numel())
     nd, ch = hp.in_node_dim, hp.edge_ch
     catn = ((2 * D) // L) * L + D
     cate = ((2 * De) // L) * L + De
