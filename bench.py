@@ -81,9 +81,10 @@ def cpu_baseline(seed=42, steps=50, batch=64):
     the reference's sparse formulation; the reference itself cannot travel to the GPU box).  Same procedure as
     oracle/calibrate_cpu.py, which times it against the real reference in the build container.
 
-    Threads: torch CPU scatter code does not always scale to a big box's core count, so two forwards are probed with
-    os.cpu_count() threads and with 32; the 50-step run uses the faster setting and `cores` reports it (both probe
-    timings are in the record)."""
+    Threads: min(os.cpu_count(), 32), reported as `cores`.  torch's CPU scatter / index code does not scale to a
+    big box's core count — measured on the GPU box of round 2 (EPYC 9575F, 256 hardware threads): 0.96 s per step
+    with 32 threads, 162.9 s per step with 256 (oversubscribed OpenMP barriers) — so the baseline runs where the
+    reference's own torch code would run best, and says so."""
     from jodo_amd import configs
     from jodo_amd.diffusion import NoiseScheduleVP
     from jodo_amd.models import get_model_class, deterministic_init_, load_dataset_info, get_node_dist
@@ -110,17 +111,9 @@ def cpu_baseline(seed=42, steps=50, batch=64):
     ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
     smp = AncestralSampler(ns, torch.linspace(ns.T, 1e-3, steps), True, True, True, get_self_cond_fn(cfg))
     ncpu = os.cpu_count() or 1
-    probes = {}
+    threads = max(1, min(ncpu, 32))
+    torch.set_num_threads(threads)
     with torch.no_grad():
-        for th in sorted({ncpu, min(ncpu, 32)}, reverse=True):
-            torch.set_num_threads(th)
-            st = smp.step(Port(), 0, smp.init_state(z, ez), nm, em)            # warm-up (first step, cond = None)
-            t0 = time.perf_counter()
-            for i in (1, 2):
-                st = smp.step(Port(), i, st, nm, em)
-            probes[th] = (time.perf_counter() - t0) / 2
-        threads = min(probes, key=probes.get)
-        torch.set_num_threads(threads)
         t0 = time.perf_counter()
         x_mean, e_mean = smp.sampling(Port(), z, nm, em, ez, None)
         wall = time.perf_counter() - t0
@@ -131,7 +124,8 @@ def cpu_baseline(seed=42, steps=50, batch=64):
                        % (batch, steps, wall, wall / steps, SAMPLING_STEPS // steps),
                 config1_wall_s=wall, config1_molecules_per_s=batch / wall, ms_per_step=wall / steps * 1e3,
                 cpu=cpu_model(), cpu_count=ncpu,
-                thread_probe_s_per_step={str(k): round(v, 4) for k, v in probes.items()},
+                threads_note='min(cpu_count, 32): with all 256 hardware threads of the round-2 box the same port ran 170x slower '
+                             '(162.9 vs 0.96 s/step, profiles/r02_bench_qm9.json of commit "bench: config-1 CPU baseline")',
                 calibration='port vs the real reference on this config: see BASELINE.md §3 (build container, 8 threads)')
 
 

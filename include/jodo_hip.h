@@ -102,13 +102,26 @@ int jodo_plan_stats(const jodo_plan* plan, int64_t* out6);
  *   flags_dev: int32[8] device scratch; after the call [0] = NaN guard fired (mol_gnn.py:587-589),
  *              [1] reserved (0), [2] = all molecules shared one noise level, [3] = the self-conditioning positions
  *              were not all equal (0 => the batch-global first-step branch of :544 was taken),
- *              [4] = edge inputs were not symmetric (directed kernels used)
+ *              [4] = edge inputs were not symmetric (directed kernels used), [5] = STICKY count of calls in which
+ *              the NaN guard fired (only ever incremented by the library; the caller clears it when it reads it)
  *   workspace: jodo_plan_workspace_bytes() bytes of device scratch
  *   dbg: optional device buffer for intermediates (tests) or NULL */
 int jodo_dgt_forward(jodo_plan* plan, const void* desc_dev, const float* packed_w, const int64_t* woff,
                      int n_woff, const float* xh, const float* edge_x, const float* cond_x,
                      const float* cond_edge_x, const float* noise_level, const float* context,
                      float* out_xh, float* out_edge, int32_t* flags_dev, void* workspace, void* stream);
+
+/* Work-decomposition options of a plan (defaults are the measured-best settings).  These replace the
+ * environment switches of round 1: the library reads no environment variables. */
+enum jodo_plan_option {
+    JODO_OPT_FUSE_NEXT_QKV = 0,   /* 1 (default): with >= 1024 node strips k_node_post of block l also produces block l + 1's
+                                     q / k / v; 0: always a separate k_node_pre launch */
+    JODO_OPT_DIR_SPLIT = 1,       /* 1 (default): pair-update items of a launch's sparsely filled last round get two workgroups,
+                                     one per direction; 0: one workgroup per item */
+    JODO_OPT_NODE_POST_WAVES = 2, /* 0 (default): automatic; 1 / 2 / 4: waves per strip for every strip of k_node_post */
+    JODO_OPT_COUNT
+};
+int jodo_plan_set_option(jodo_plan* plan, int option, int value);
 
 /* debug: copy an internal per-block intermediate out of the workspace after a forward.
  * what: 0 = h [Nn,D], 1 = e [rows,De], 2 = pos [Nn,4] (raw, not centred), 3 = hhat [Nn,D] of the last

@@ -8,7 +8,8 @@
 #include "dgt_kernels_post.h"
 #include "dgt_kernels_wide.h"
 #include "jodo_hip_internal.h"
-#include <cstdlib>
+#include <memory>
+#include <utility>
 
 using namespace jd;
 
@@ -45,6 +46,7 @@ void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
     A.stats = ws_ptr<float>(ws, w.stats); A.apred = ws_ptr<float>(ws, w.apred);
     A.eflag = ws_ptr<int>(ws, w.eflag); A.e = ws_ptr<float>(ws, w.e); A.et = ws_ptr<float>(ws, w.et);
     A.S = ws_ptr<float>(ws, w.S); A.ehid = ws_ptr<float>(ws, w.ehid); A.epred = ws_ptr<float>(ws, w.epred);
+    A.e_out = ws_ptr<float>(ws, w.e2);
     A.dposE = ws_ptr<float>(ws, w.dposE);
 }
 
@@ -102,9 +104,8 @@ int launch_edge_head(hipStream_t st, const KArgs& A) {
 template <int D>
 int launch_update_sym(jodo_plan* p, hipStream_t st, KArgs& A) {
     const DgtDims& d = p->dims;
-    static const bool nosplit = getenv("JODO_NO_DIR_SPLIT") != nullptr;      // experiment switch
     const int full = (p->n_pitems / 1024) * 1024, rem = p->n_pitems - full;
-    const bool split = !nosplit && rem > 0 && rem <= 512;
+    const bool split = p->opt[JODO_OPT_DIR_SPLIT] != 0 && rem > 0 && rem <= 512;
     const int n1 = split ? full : p->n_pitems;
     A.item0 = 0; A.dir_split = 0;
     if (n1 > 0) { if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2>), n1, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4>), n1, 64, A); }
@@ -129,7 +130,7 @@ int launch_edge_head_w(hipStream_t st, const KArgs& A) {
 }
 
 template <int D>
-int forward_wide(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, float* const posbuf[2], ProfScope* pro) {
+int forward_wide(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, float* const posbuf[2], std::unique_ptr<ProfScope>& pro) {
     const DgtDims& d = p->dims;
     int rc = JODO_OK;
     LAUNCH(k_pack_nodes, (p->Nn_pad + 255) / 256, 256, A);
@@ -146,7 +147,7 @@ int forward_wide(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, fl
     }
     if (rc) return rc;
     if (p->n_items > 0) LAUNCH((wide::k_embed_edges<D>), p->n_items, 64, A);
-    delete pro;
+    pro.reset();
     const int nblocks = (p->max_blocks >= 0 && p->max_blocks < d.L) ? p->max_blocks : d.L;
     int cur = 0;
     for (int l = 0; l < nblocks; ++l) {
@@ -172,6 +173,8 @@ int forward_wide(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, fl
                 if (rc) return rc;
             }
             if (d.r == 2) LAUNCH((wide::k_edge_update<D, 2>), p->n_items, 64, A); else LAUNCH((wide::k_edge_update<D, 4>), p->n_items, 64, A);
+            std::swap(A.e, A.e_out);               // the state the next block reads is the one just written
+            p->last_e_buf ^= 1;
         }
     }
     ProfScope epi(p, st, JODO_PROF_EPILOGUE);
@@ -239,7 +242,8 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     int rc;
 
     // ---- time embedding -> modulation vectors ----
-    ProfScope* pro = new ProfScope(p, st, JODO_PROF_PROLOGUE);
+    p->last_e_buf = 0;
+    std::unique_ptr<ProfScope> pro(new ProfScope(p, st, JODO_PROF_PROLOGUE));      // ends after the embeddings; released on every return path
     LAUNCH(k_flags_init, 1, 256, A);
     { const size_t tot = (size_t)p->B * p->N * p->N; LAUNCH(k_check_sym, (unsigned)((tot + 255) / 256), 256, A); }
     LAUNCH(k_time1, p->B, 256, A);
@@ -276,49 +280,31 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     if (rc) return rc;
     if (p->n_items > 0) LAUNCH(k_embed_edges, p->n_items, 64, A);
 
-    delete pro;
+    pro.reset();
     // ---- DGT blocks ----
     const int nblocks = (p->max_blocks >= 0 && p->max_blocks < d.L) ? p->max_blocks : d.L;
-    // optional overlap (JODO_OVERLAP=1): the next block's q/k/v projections run on a helper stream beside the edge
-    // update (fork/join with events inside this call; nothing is synchronised with the host).  Measured on
-    // MI355X: QM9 B = 2500 24.46 -> 24.05 ms/step, GEOM B = 512 36.17 -> 36.01, QM9 cond B = 313 5.19 -> 5.29.
-    // Off by default: it is worth < 2 %, blurs the per-kernel timings the roofline accounting relies on (two
-    // kernels share the SIMDs) and needs a library-owned stream.
-    static const bool overlap_env = getenv("JODO_OVERLAP") != nullptr;
-    bool overlap = overlap_env && nblocks > 1;
     // With at least one strip per SIMD, k_node_post of block l also produces block l + 1's q / k / v (it holds h' in
     // registers): drops a launch with its own latency-bound prologue and partial last round (QM9 B = 2500, 1409
     // strips: 23.31 -> 23.18 ms/step).  With fewer strips the separate kernel's 3x finer items fill the chip better
     // (GEOM B = 512, 710 strips: fused 35.1 vs 34.6 ms/step), so it stays separate there.
-    static const bool fuse_env = getenv("JODO_NO_FUSE_PRE") == nullptr;
-    const bool fuse_pre = fuse_env && !overlap && nblocks > 1 && p->n_strips >= 1024;
-    if (overlap && !p->aux_stream) {
-        hipStream_t sx; hipEvent_t e1, e2;
-        if (hipStreamCreateWithFlags(&sx, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess)
-            return jodo_set_error(JODO_ERR_LAUNCH, "could not create the helper stream");
-        p->aux_stream = sx; p->ev_fork = e1; p->ev_join = e2;
-    }
+    const bool fuse_pre = p->opt[JODO_OPT_FUSE_NEXT_QKV] != 0 && nblocks > 1 && p->n_strips >= 1024;
     int cur = 0;                                   // posbuf[cur] holds the positions entering the block
     for (int l = 0; l < nblocks; ++l) {
         A.layer = l;
         A.mod_base = 32 + (int64_t)l * d.MB;
         for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + i];
         A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
-        if (!overlap && !fuse_pre) {
+        if (!fuse_pre) {
             A.pre_mode = 0;
             ProfScope ps(p, st, JODO_PROF_NODE_PRE); LAUNCH(k_node_pre, p->n_strips * 3, 64, A);
         } else {
             // positions entering the block (needs the previous update).  The q/k/v projections of this block were
-            // produced by the previous block's k_node_post (fused, default) or enqueued on the helper stream right
-            // after it (JODO_OVERLAP): they only need h
+            // produced by the previous block's k_node_post: they only need h
             ProfScope ps(p, st, JODO_PROF_NODE_PRE);
             LAUNCH(k_pos_final, (p->Nn_pad + 255) / 256, 256, A);
             if (l == 0) {
                 A.pre_mode = 1;
                 LAUNCH(k_node_pre, p->n_strips * 3, 64, A);
-            } else if (overlap && hipStreamWaitEvent(st, (hipEvent_t)p->ev_join, 0) != hipSuccess) {
-                return jodo_set_error(JODO_ERR_LAUNCH, "stream join failed");
             }
         }
         cur ^= 1;                                  // the block's positions are in pos_out now
@@ -340,10 +326,10 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
               for (int i = 0; i < 6; ++i) A.wbn[i] = woff[JW_GLOBAL_COUNT + (l + 1) * JB_BLOCK_COUNT + slots[i]];
               A.mod_base_next = 32 + (int64_t)(l + 1) * d.MB;
           }
-          static const char* force = getenv("JODO_NODE_POST");                     // experiment switch: "1", "2" or "4" for all strips
-          const int full = force ? (force[0] == '1' ? p->n_strips : 0) : (p->n_strips / 1024) * 1024;
+          const int force = p->opt[JODO_OPT_NODE_POST_WAVES];                      // 0 = automatic
+          const int full = force ? (force == 1 ? p->n_strips : 0) : (p->n_strips / 1024) * 1024;
           const int rem = p->n_strips - full;
-          const int nw = force ? force[0] - '0' : (rem <= 256 ? 4 : (rem <= 512 ? 2 : 1));
+          const int nw = force ? force : (rem <= 256 ? 4 : (rem <= 512 ? 2 : 1));
           if (full > 0) {
               A.strip0 = 0;
               if (d.r == 2) LAUNCH(k_node_post<2>, full, 64, A); else LAUNCH(k_node_post<4>, full, 64, A);
@@ -355,25 +341,6 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
               else { if (d.r == 2) LAUNCH((k_node_postw<2, 4>), rem, 256, A); else LAUNCH((k_node_postw<4, 4>), rem, 256, A); }
           }
           A.strip0 = 0; }
-        if (overlap && l + 1 < nblocks) {
-            // fork: q/k/v of block l + 1 on the helper stream, concurrently with this block's edge update (whose
-            // last partial round of work items leaves most SIMDs idle)
-            KArgs A2 = A;
-            A2.layer = l + 1;
-            A2.mod_base = 32 + (int64_t)(l + 1) * d.MB;
-            for (int i = 0; i < JB_BLOCK_COUNT; ++i) A2.wb[i] = woff[JW_GLOBAL_COUNT + (l + 1) * JB_BLOCK_COUNT + i];
-            A2.pre_mode = 1;
-            hipStream_t sx = (hipStream_t)p->aux_stream;
-            if (hipEventRecord((hipEvent_t)p->ev_fork, st) != hipSuccess || hipStreamWaitEvent(sx, (hipEvent_t)p->ev_fork, 0) != hipSuccess)
-                return jodo_set_error(JODO_ERR_LAUNCH, "stream fork failed");
-            {
-                ProfScope ps(p, sx, JODO_PROF_NODE_PRE);
-                hipLaunchKernelGGL(k_node_pre, dim3(p->n_strips * 3), dim3(64), 0, sx, A2);
-                int rc_ = jodo_check_launch("k_node_pre (helper stream)");
-                if (rc_ != JODO_OK) return rc_;
-            }
-            if (hipEventRecord((hipEvent_t)p->ev_join, sx) != hipSuccess) return jodo_set_error(JODO_ERR_LAUNCH, "stream join record failed");
-        }
         if (p->n_items > 0) {
             ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);
             if (p->n_pitems > 0) {
@@ -382,6 +349,8 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
                 if (rc) return rc;
             }
             if (d.r == 2) LAUNCH(k_edge_update<2>, p->n_items, 64, A); else LAUNCH(k_edge_update<4>, p->n_items, 64, A);
+            std::swap(A.e, A.e_out);               // the state the next block reads is the one just written
+            p->last_e_buf ^= 1;
         }
     }
     // ---- heads + outputs ----
@@ -418,7 +387,7 @@ extern "C" int jodo_debug_fetch(jodo_plan* p, const void* workspace, int what, f
     int64_t n = 0;
     switch (what) {
         case 0: src = ws + p->ws.h; n = (int64_t)p->Nn * p->dims.D; break;
-        case 1: src = ws + p->ws.e; n = p->rows * p->dims.De; break;
+        case 1: src = ws + (p->last_e_buf ? p->ws.e2 : p->ws.e); n = p->rows * p->dims.De; break;
         case 2: src = ws + (p->last_pos_buf ? p->ws.pos1 : p->ws.pos0); n = (int64_t)p->Nn * 4; break;
         case 3: src = ws + p->ws.hhat; n = (int64_t)p->Nn * p->max_parts * p->dims.D; break;
         case 4: src = ws + p->ws.S; n = p->rows * 16; break;

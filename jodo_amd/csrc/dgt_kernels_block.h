@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
                 for (int s = 0; s < 16; ++s)
                     en[b * 16 + s] = fmaf(og2[b * 16 + s], o[b][s] + ob4[b * 16 + s], en[b * 16 + s]);
         }
-        if (inr) store_nat<2>(A.e + r * 64, half, en);
+        if (inr) store_nat<2>(A.e_out + r * 64, half, en);
         // ---- readout edge_l(e) -> edge_hids[:, De + l*16 ...] (valid outputs live in half 0) ----
         {
             float bb[16];

@@ -4,7 +4,7 @@
 #include "dgt_plan.h"
 
 // flags_dev layout (int32[8])
-enum { FLAG_NAN = 0, FLAG_FIRST = 1, FLAG_UNIFORM_T = 2, FLAG_COND_NONZERO = 3, FLAG_ASYM = 4 };
+enum { FLAG_NAN = 0, FLAG_FIRST = 1, FLAG_UNIFORM_T = 2, FLAG_COND_NONZERO = 3, FLAG_ASYM = 4, FLAG_NAN_COUNT = 5 };
 
 struct KArgs {
     PlanDev pd;
@@ -28,6 +28,8 @@ struct KArgs {
     float *pos_in, *pos_out, *dpos, *cpos, *feat, *h, *hhat, *q, *k, *v, *n2e, *wrow, *wcol, *ahid, *stats, *apred;
     int* eflag;
     float *e, *et, *S, *ehid, *epred, *dposE;
+    float* e_out;                         // edge state written by the update kernels (ping-pong with e: never in place,
+                                          // two workgroups of a direction-split item read the same input rows)
     int* flags;
     unsigned long long* dbgt;             // debug: per-phase cycle sums (builds with -DJODO_PHASE_TIMING only)
     // API tensors

@@ -144,6 +144,9 @@ __global__ __launch_bounds__(64) void k_edge_head(KArgs A) {
 __global__ void k_finalize_nodes(KArgs A) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;    // (b, i)
     if (idx >= A.pd.B * A.pd.N) return;
+    // sticky count of evaluations in which the NaN guard fired: never reset by the library, read-and-cleared by the
+    // caller once per sampling round (the reference prints its warning per forward, mol_gnn.py:588)
+    if (idx == 0 && A.flags[FLAG_NAN] != 0) A.flags[FLAG_NAN_COUNT] += 1;
     const int b = idx / A.pd.N, i = idx % A.pd.N;
     const int n = A.pd.orig_n[b], nd = A.d.nd;
     float* o = A.out_xh + (size_t)idx * (3 + nd);

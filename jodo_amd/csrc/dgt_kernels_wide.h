@@ -567,7 +567,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
                 for (int s = 0; s < 16; ++s) en[b * 16 + s] = fmaf(og2[s], o[b][s] + ob4[s], en[b * 16 + s]);
             }
         }
-        if (inr) store_nat<X::NE>(A.e + r * X::De, half, en);
+        if (inr) store_nat<X::NE>(A.e_out + r * X::De, half, en);
         // ---- readout edge_l(e) -> edge_hids[:, De + l*CEP ...] ----
         {
             float bb[16];
@@ -829,8 +829,8 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             }
         }
         if (P.ok && dsel != 1) {
-            store_nat<X::NE>(A.e + P.rij * X::De, half, en);
-            store_nat<X::NE>(A.e + P.rji * X::De, half, en);
+            store_nat<X::NE>(A.e_out + P.rij * X::De, half, en);
+            store_nat<X::NE>(A.e_out + P.rji * X::De, half, en);
         }
         PT(1);
         // ---- readout ----

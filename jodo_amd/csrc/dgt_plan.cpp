@@ -113,7 +113,9 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     if (pair_chunk <= 0) pair_chunk = 1;     // measured best on MI355X (QM9 B=2500: 26.7 ms/step vs 27.7 at 2)
     const bool spair_auto = spair_chunk <= 0;
     if (spair_chunk <= 0) spair_chunk = 2;   // 4-wave workgroups stage 96 KiB of weights: 2 offsets per item (sweep: 1 -> 2.97, 2 -> 2.71, 3 -> 2.85 ms/step)
-    p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->prof_enabled = 0; p->force_directed = 0; p->dbg_timing = nullptr;
+    p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->last_e_buf = 0;
+    p->opt[JODO_OPT_FUSE_NEXT_QKV] = 1; p->opt[JODO_OPT_DIR_SPLIT] = 1; p->opt[JODO_OPT_NODE_POST_WAVES] = 0;
+    p->prof_enabled = 0; p->force_directed = 0; p->dbg_timing = nullptr;
 
     // molecules by descending size (stable): neighbouring lanes share n, big work first
     std::vector<int> order(B);
@@ -219,7 +221,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     w.q = take(NP * d.QKP * f); w.k = take(NP * d.QKP * f); w.v = take(NP * d.D * f); w.n2e = take(NP * d.De * f);
     w.wrow = take(NP * d.D * f); w.wcol = take(NP * d.D * f); w.ahid = take(NP * d.KNH * f); w.stats = take(NP * 32 * f);
     w.apred = take(NP * 32 * f);
-    w.eflag = take(R * sizeof(int32_t)); w.e = take(R * d.De * f); w.et = take(R * d.De * f); w.S = take(R * 16 * f);
+    w.eflag = take(R * sizeof(int32_t)); w.e = take(R * d.De * f); w.e2 = take(R * d.De * f); w.et = take(R * d.De * f); w.S = take(R * 16 * f);
     w.ehid = take(R * d.KEH * f); w.epred = take(R * 4 * f); w.dposE = take(R * 4 * f);
     w.total = o;
     *out = p;
@@ -230,9 +232,6 @@ extern "C" void jodo_plan_destroy(jodo_plan* p) {
     if (!p) return;
     for (void* e : p->prof_ev) (void)hipEventDestroy((hipEvent_t)e);
     for (void* e : p->prof_pool) (void)hipEventDestroy((hipEvent_t)e);
-    if (p->aux_stream) { (void)hipStreamSynchronize((hipStream_t)p->aux_stream); (void)hipStreamDestroy((hipStream_t)p->aux_stream); }
-    if (p->ev_fork) (void)hipEventDestroy((hipEvent_t)p->ev_fork);
-    if (p->ev_join) (void)hipEventDestroy((hipEvent_t)p->ev_join);
     delete p;
 }
 extern "C" int jodo_profile_enable(jodo_plan* p, int enable) {
@@ -279,6 +278,14 @@ extern "C" int jodo_debug_set_timing_buffer(jodo_plan* p, void* dev16xu64) {
 extern "C" int jodo_debug_set_force_directed(jodo_plan* p, int on) {
     if (!p) return jodo_set_error(JODO_ERR_ARG, "null plan");
     p->force_directed = on;
+    return JODO_OK;
+}
+extern "C" int jodo_plan_set_option(jodo_plan* p, int option, int value) {
+    if (!p) return jodo_set_error(JODO_ERR_ARG, "null plan");
+    if (option < 0 || option >= JODO_OPT_COUNT) return jodo_set_error(JODO_ERR_ARG, "plan_set_option: unknown option %d", option);
+    if (option == JODO_OPT_NODE_POST_WAVES && value != 0 && value != 1 && value != 2 && value != 4)
+        return jodo_set_error(JODO_ERR_ARG, "plan_set_option: node-post waves per strip must be 0 (auto), 1, 2 or 4");
+    p->opt[option] = value;
     return JODO_OK;
 }
 extern "C" int jodo_debug_set_max_blocks(jodo_plan* p, int mb) {

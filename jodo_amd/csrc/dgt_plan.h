@@ -46,7 +46,7 @@ struct PlanDev {
 struct WsLayout {   // byte offsets into the workspace
     size_t hid1, temb, mods, condh, condh2;
     size_t pos0, pos1, dpos, cpos, feat, h, hhat, q, k, v, n2e, wrow, wcol, ahid, stats, apred;
-    size_t eflag, e, et, S, ehid, epred, dposE;
+    size_t eflag, e, e2, et, S, ehid, epred, dposE;
     size_t total;
 };
 
@@ -68,9 +68,8 @@ struct jodo_plan {
     void* dbg_timing;                // debug: device buffer of 16 x u64 phase-cycle sums (or null)
     int max_blocks;                  // debug: limit blocks executed (<0 = all)
     int last_pos_buf;                // debug: which pos buffer holds the latest positions
-    void* aux_stream = nullptr;      // helper stream (hipStream_t) for work overlapped with the edge update; created lazily
-    void* ev_fork = nullptr;         // hipEvent_t pair for the fork / join of that stream
-    void* ev_join = nullptr;
+    int last_e_buf;                  // debug: which edge-state buffer holds the latest state
+    int opt[JODO_OPT_COUNT];         // jodo_plan_set_option values
 };
 
 int dgt_dims_from_cfg(const jodo_cfg* cfg, DgtDims* d);

@@ -20,6 +20,20 @@ def shard_range(n_items, rank, world):
     return min(rank * per, n_items), min((rank + 1) * per, n_items)
 
 
+def assign_lpt(n_nodes, world):
+    """Longest-processing-time assignment of molecules to ranks by their edge work n^2: molecules in
+    descending n^2 go to the currently least-loaded rank.  Returns `world` ascending index lists (deterministic: ties
+    broken by index and rank)."""
+    order = sorted(range(len(n_nodes)), key=lambda i: (-int(n_nodes[i]) ** 2, i))
+    load = [0] * world
+    out = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], len(out[k]), k))
+        out[r].append(i)
+        load[r] += int(n_nodes[i]) ** 2
+    return [sorted(o) for o in out]
+
+
 def _pad_to(t, shape):
     out = torch.zeros(shape, dtype=t.dtype, device=t.device)
     out[tuple(slice(0, s) for s in t.shape)] = t
@@ -55,3 +69,36 @@ def unpack_molecules(g):
     n = g['n_nodes'].cpu().tolist()
     pos, at, ch, bd = g['pos'].cpu(), g['atom_type'].cpu().long(), g['charge'].cpu().long(), g['bond'].cpu().float()
     return [(pos[i, :k], at[i, :k], bd[i, :k, :k], ch[i, :k]) for i, k in enumerate(n)]
+
+
+def gather_sampled(mols, indices, device=None, group=None):
+    """End-of-sampling collective for `get_sampling_fn(shard=...)`: every rank passes its list of molecule tuples
+    (pos[n,3], atom_type[n], edge_type[n,n], fc[n]) and their global indices (`sampling_fn.last_indices`); returns, on
+    every rank, the full list in global order — the list an unsharded run would have produced.  One all_gather per
+    tensor (RCCL over xGMI on the GPU box when `device` is the rank's GPU; gloo on CPU)."""
+    device = device or 'cpu'
+    B = len(mols)
+    N = max([int(m[0].shape[0]) for m in mols], default=1)
+    pos = torch.zeros(B, N, 3)
+    at = torch.zeros(B, N, dtype=torch.uint8)
+    ch = torch.zeros(B, N, dtype=torch.int8)
+    bd = torch.zeros(B, N, N, dtype=torch.uint8)
+    n = torch.zeros(B, dtype=torch.int32)
+    for k, m in enumerate(mols):
+        nk = int(m[0].shape[0])
+        n[k] = nk
+        pos[k, :nk], at[k, :nk], bd[k, :nk, :nk], ch[k, :nk] = m[0], m[1].to(torch.uint8), m[2].to(torch.uint8), m[3].to(torch.int8)
+    g = gather_molecules(pos.to(device), at.to(device), ch.to(device), bd.to(device), n.to(device), group=group)
+    world = dist.get_world_size(group)
+    cnt = torch.tensor([B], dtype=torch.int64, device=device)
+    cnts = [torch.empty_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    Bm = max(int(c) for c in cnts)
+    idx = torch.full((max(Bm, 1),), -1, dtype=torch.int64, device=device)
+    idx[:B] = torch.as_tensor(list(indices), dtype=torch.int64, device=device)
+    idxs = [torch.empty_like(idx) for _ in range(world)]
+    dist.all_gather(idxs, idx, group=group)
+    order = torch.cat([i[:int(c)] for i, c in zip(idxs, cnts)]).cpu()
+    out = unpack_molecules(g)
+    assert len(out) == order.numel()
+    return [out[k] for k in torch.argsort(order).tolist()]

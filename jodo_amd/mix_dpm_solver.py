@@ -33,6 +33,12 @@ class DPM_Solver_hybrid:
         assert config.model.pred_data, "Not support in current version."
         assert config.model.self_cond, "Not support in current version."
 
+    def noise_draws_per_round(self):
+        """Position-noise draws of one `sampling` call: every update draws once except the last."""
+        if self.method == 'singlestep_fixed':
+            return (self.steps // self.order) * self.order - 1
+        return self.steps - 1
+
     @staticmethod
     def get_time_steps(skip_type, t_T, t_0, N, device):
         if skip_type != 'time_uniform':

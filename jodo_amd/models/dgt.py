@@ -157,6 +157,7 @@ class _DGTBase(nn.Module):
         self._packed = None           # (version_key, blob_dev, woff_host ctypes array)
         self._plans = {}              # plan cache keyed by the mask tensor identity
         self._cfg_struct = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed_weights())
         self.last_flags = None        # device int32[8] of the last call (NaN guard etc.)
         self.warn_nan = True
 
@@ -176,6 +177,10 @@ class _DGTBase(nn.Module):
 
     # -- weights -----------------------------------------------------------------------------
     def _weights(self, device):
+        # cheap key checked on every call: tensor versions (bumped by optimizer steps, load_state_dict, p.copy_) and
+        # storage addresses (model.to(...)).  In-place writes through `.data` (the reference's EMA copy_to / restore,
+        # models/ema.py:44-66) bump neither: a content fingerprint is compared whenever a new plan is built (once per
+        # sampling round, _plan below), and invalidate_packed_weights() forces a re-pack explicitly.
         key = (str(device),) + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
         if self._packed is None or self._packed[0] != key:
             sd = {k: v.detach().float().cpu() for k, v in self.state_dict().items()}
@@ -183,7 +188,19 @@ class _DGTBase(nn.Module):
             blob_dev = torch.from_numpy(blob).to(device)
             woff_c = (ctypes.c_int64 * len(woff))(*woff.tolist())
             self._packed = (key, blob_dev, woff_c, len(woff))
+            self._packed_fingerprint = self._fingerprint()
         return self._packed
+
+    def _fingerprint(self):
+        """Content fingerprint of all parameters: one fused norm launch + one reduction, one host sync."""
+        ps = [p.detach() for p in self.parameters()]
+        norms = torch._foreach_norm(ps)
+        w = torch.arange(1, len(norms) + 1, device=norms[0].device, dtype=torch.float64)
+        return float((torch.stack([n.double() for n in norms]) * (1.0 + 1e-3 * w)).sum().item())
+
+    def _recheck_weights(self):
+        if self._packed is not None and self._fingerprint() != getattr(self, '_packed_fingerprint', None):
+            self._packed = None
 
     # -- plans ---------------------------------------------------------------------------------
     def _plan(self, node_mask, edge_mask, device, validate=True):
@@ -193,6 +210,7 @@ class _DGTBase(nn.Module):
         plan = self._plans.get(key)
         if plan is not None and plan['mask'] is node_mask and plan['mask_version'] == node_mask._version:
             return plan
+        self._recheck_weights()                          # new batch (= new sampling round): catch `.data` weight updates
         B, N = node_mask.shape[0], node_mask.shape[1]
         nm = node_mask.reshape(B, N)
         n_nodes = nm.sum(1).round().to(torch.int32)
@@ -218,6 +236,8 @@ class _DGTBase(nn.Module):
         ws = torch.zeros(L.jodo_plan_workspace_bytes(handle), dtype=torch.uint8, device=device)
         if getattr(self, 'force_directed', False):       # tests: never use the symmetric pair kernels
             capi.check(L.jodo_debug_set_force_directed(handle, 1), 'jodo_debug_set_force_directed')
+        for opt, val in getattr(self, 'plan_options', {}).items():     # {jodo_plan_option: value}, experiments only
+            capi.check(L.jodo_plan_set_option(handle, int(opt), int(val)), 'jodo_plan_set_option')
         capi.check(L.jodo_plan_upload(handle, capi.ptr(desc), capi.current_stream_ptr()), 'jodo_plan_upload')
         torch.cuda.current_stream().synchronize()        # host staging buffer lives in the plan; be safe
         plan = dict(handle=handle, desc=desc, ws=ws, n_nodes=n_host, B=B, N=N, mask=node_mask,
@@ -270,6 +290,21 @@ class _DGTBase(nn.Module):
         self.last_flags = plan['flags']
         self._last_plan = plan
         return out_x, out_e
+
+    def take_nan_count(self):
+        """Number of evaluations since the last call in which the NaN guard fired (sticky device counter, flags[5] of
+        every cached plan); one host sync, so call it once per sampling round, not per step."""
+        total = 0
+        for plan in self._plans.values():
+            total += int(plan['flags'][5].item())
+            plan['flags'][5] = 0
+        return total
+
+    def invalidate_packed_weights(self):
+        """Drop the packed kernel weights; the next forward re-packs from the current parameters.  Needed after
+        in-place updates that do not bump tensor versions (`param.data.copy_(...)`, e.g. the reference's
+        ExponentialMovingAverage.copy_to / restore, models/ema.py:44-66)."""
+        self._packed = None
 
     def nan_guard_fired(self):
         """Lazy read of the device NaN-guard flag of the last call (the reference prints a warning and

@@ -96,8 +96,58 @@ def build_masks(n_nodes, max_n_nodes, device):
     return node_mask.unsqueeze(2).to(device), edge_mask.view(bs * max_n_nodes * max_n_nodes, 1).to(device)
 
 
+class _ParityNoise:
+    """Noise of the UNSHARDED batch replayed on every rank (shard_mode='parity'): each draw is made on the CPU with
+    the full round's shapes, in the reference's draw order (sampling.py:204-209 initial noise, :576 / :588 per step,
+    mix_dpm_solver.py:56 positions), then cut down to this rank's molecules [lo:hi] and its own padded width.  Every
+    rank consumes the global CPU generator identically, so the slices are a partition of ONE draw and a world-size-N
+    run reproduces the world-size-1 run molecule for molecule."""
+
+    def __init__(self, n_nodes_round, lo, hi, node_nf, edge_nf, device):
+        self.bs, self.N = len(n_nodes_round), int(max(n_nodes_round))
+        self.lo, self.hi = lo, hi
+        self.Nl = int(max(n_nodes_round[lo:hi])) if hi > lo else 0
+        self.node_nf, self.edge_nf, self.device = node_nf, edge_nf, device
+        self.nm, self.em = build_masks(n_nodes_round, self.N, 'cpu')
+
+    def _cut(self, t, dims):
+        if self.hi == self.lo:
+            return None
+        t = t[self.lo:self.hi, :self.Nl] if dims == 1 else t[self.lo:self.hi, :self.Nl, :self.Nl]
+        return t.contiguous().to(self.device)
+
+    def node(self):
+        return self._cut(sample_combined_position_feature_noise(self.bs, self.N, self.node_nf, self.nm), 1)
+
+    def edge(self):
+        return self._cut(sample_symmetric_edge_feature_noise(self.bs, self.N, self.edge_nf, self.em), 2)
+
+    def pos(self):
+        from .models.utils import sample_center_gravity_zero_gaussian_with_mask
+        return self._cut(sample_center_gravity_zero_gaussian_with_mask((self.bs, self.N, 3), 'cpu', self.nm), 1)
+
+    def __call__(self, step, kind, like):             # noise_fn hook of AncestralSampler / DPM_Solver_hybrid
+        return {'node': self.node, 'edge': self.edge, 'pos': self.pos}[kind]()
+
+
 def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, inverse_scaler, eps=1e-3,
-                    prop_dist=None, shard=None, return_raw=False, fused_decode=True, hip_graph=False):
+                    prop_dist=None, shard=None, return_raw=False, fused_decode=True, hip_graph=False,
+                    shard_mode='perf', shard_assign='contiguous', seed=None):
+    """sampling.py:148-232.  Without `shard` this is the reference's procedure, RNG use included.
+
+    shard=(rank, world) — one process per GPU (replaces nn.DataParallel).  Seeding contract: every rank passes the SAME
+    `seed` (default config.seed).  The atom counts of all rounds and the conditioning context are drawn once from
+    `torch.manual_seed(seed)` on every rank (identical lists, no communication).  Then
+      shard_mode='perf'   the rounds * batch_size molecules are dealt to the ranks FIRST (contiguous slices, or
+                          shard_assign='lpt': greedy longest-processing-time by n^2 for balance) and each rank cuts its
+                          share into rounds of up to batch_size (BASELINE config 5: 10 000 molecules on 8 GPUs = one round
+                          of 1250 per GPU, not four rounds of 313); all noise comes from `seed + 1 + rank`, so no two
+                          ranks share a noise stream;
+      shard_mode='parity' every round of the unsharded run is split across the ranks and the unsharded run's noise is
+                          replayed (_ParityNoise): the gathered result equals the world-size-1 run.  Slow (full-batch CPU
+                          draws per step) — for tests.
+    Returns this rank's molecules; `sampling_fn.last_indices` holds their indices in the global order (rounds *
+    batch_size molecules, as the unsharded run generates them) for the caller's gather (jodo_amd/dist.py)."""
     device = config.device
     steps = config.sampling.steps
     atom_types = config.data.atom_types
@@ -108,6 +158,10 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
     compress_edge = config.data.compress_edge
     if config.only_2D or not pred_edge:
         raise NotImplementedError("only the 3-D + edge (vpsde_edge) sampling path is in scope")
+    if shard_mode not in ('perf', 'parity') or shard_assign not in ('contiguous', 'lpt'):
+        raise ValueError("shard_mode in {'perf','parity'}, shard_assign in {'contiguous','lpt'}")
+    if shard is not None and not (0 <= shard[0] < shard[1]):
+        raise ValueError("shard=(rank, world) with 0 <= rank < world")
 
     rounds = int(np.ceil(n_samples / batch_size))
     if config.sampling.method == 'ancestral':
@@ -122,49 +176,117 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
     else:
         raise ValueError('Invalid sampling method!')
 
+    def one_round(model, n_nodes, context, noise=None):
+        """n_nodes molecules (this process's share of a round) -> list of decoded molecule tuples."""
+        bs = len(n_nodes)
+        max_n = int(max(n_nodes))
+        node_mask, edge_mask = build_masks(n_nodes, max_n, device)
+        if noise is None:
+            z = sample_combined_position_feature_noise(bs, max_n, node_nf, node_mask)
+            edge_z = sample_symmetric_edge_feature_noise(bs, max_n, edge_nf, edge_mask)
+        else:
+            z, edge_z = noise.node(), noise.edge()
+        assert_mean_zero_with_mask(z[:, :, :3], node_mask)
+        sampler.noise_fn = noise
+        try:
+            if hip_graph and noise is None and z.is_cuda and isinstance(sampler, AncestralSampler):
+                # one captured HIP graph per round, replayed for every step (jodo_amd/graphed.py)
+                from .graphed import GraphedAncestralRound
+                x_node, x_edge = GraphedAncestralRound(sampler, model, node_mask, edge_mask, context).run(z, edge_z)
+            else:
+                x_node, x_edge = sampler.sampling(model, z, node_mask, edge_mask, edge_z, context)
+        finally:
+            sampler.noise_fn = None
+        _warn_nan(model)
+        if x_node.is_cuda and fused_decode and getattr(inverse_scaler, 'from_config', False):
+            # device-side decode: compact u8/i8 results, one device->host copy per tensor
+            from . import fused
+            dec = fused.decode(config, x_node, x_edge, fused.n_nodes_from_mask(node_mask))
+            return fused.mols_from_decoded(*dec, n_nodes)
+        pos, one_hot, fc, edge_types = post_process(x_node, atom_types, include_fc, node_mask, inverse_scaler, x_edge,
+                                                    edge_mask, compress_edge)
+        assert_mean_zero_with_mask(pos, node_mask)
+        return mol_process(one_hot, pos, fc, n_nodes, edge_types)
+
     def sampling_fn(model):
         model.eval()
         mols = []
+        total = rounds * batch_size
         with torch.no_grad():
-            n_nodes_all = nodes_dist.sample(rounds * batch_size)
-            for r in range(rounds):
-                n_nodes = n_nodes_all[r * batch_size:(r + 1) * batch_size]
-                if shard is not None:                      # contiguous slice of this round's batch
-                    rank, world = shard
-                    per = (len(n_nodes) + world - 1) // world
-                    n_nodes = n_nodes[rank * per:(rank + 1) * per]
-                bs = len(n_nodes)
-                max_n = int(max(n_nodes))
-                context = prop_dist.sample_batch(n_nodes).to(device) if prop_dist is not None else None
-                node_mask, edge_mask = build_masks(n_nodes, max_n, device)
-
-                z = sample_combined_position_feature_noise(bs, max_n, node_nf, node_mask)
-                assert_mean_zero_with_mask(z[:, :, :3], node_mask)
-                edge_z = sample_symmetric_edge_feature_noise(bs, max_n, edge_nf, edge_mask)
-                if hip_graph and z.is_cuda and isinstance(sampler, AncestralSampler):
-                    # one captured HIP graph per round, replayed for every step (jodo_amd/graphed.py)
-                    from .graphed import GraphedAncestralRound
-                    x_node, x_edge = GraphedAncestralRound(sampler, model, node_mask, edge_mask, context).run(z, edge_z)
-                else:
-                    x_node, x_edge = sampler.sampling(model, z, node_mask, edge_mask, edge_z, context)
-                if x_node.is_cuda and fused_decode and getattr(inverse_scaler, 'from_config', False):
-                    # device-side decode: compact u8/i8 results, one device->host copy per tensor
-                    from . import fused
-                    dec = fused.decode(config, x_node, x_edge, fused.n_nodes_from_mask(node_mask))
-                    mols += fused.mols_from_decoded(*dec, n_nodes)
-                else:
-                    pos, one_hot, fc, edge_types = post_process(x_node, atom_types, include_fc, node_mask,
-                                                                inverse_scaler, x_edge, edge_mask, compress_edge)
-                    assert_mean_zero_with_mask(pos, node_mask)
-                    mols += mol_process(one_hot, pos, fc, n_nodes, edge_types)
-                if shard is None or shard[0] == 0:
+            if shard is None:                                  # the reference's procedure
+                n_nodes_all = nodes_dist.sample(total)
+                for r in range(rounds):
+                    n_nodes = n_nodes_all[r * batch_size:(r + 1) * batch_size]
+                    context = prop_dist.sample_batch(n_nodes).to(device) if prop_dist is not None else None
+                    mols += one_round(model, n_nodes, context)
                     print('Generate {}, Total {}.'.format(len(mols), n_samples))
-        if return_raw or shard is not None:
-            return mols                                    # caller gathers / shuffles
-        random.shuffle(mols)
-        return mols[:n_samples]
+                sampling_fn.last_indices = list(range(total))
+                if return_raw:
+                    return mols
+                random.shuffle(mols)
+                return mols[:n_samples]
 
+            rank, world = shard
+            base = int(config.seed if seed is None else seed)
+            torch.manual_seed(base)                            # identical on every rank
+            n_nodes_all = nodes_dist.sample(total)
+            if shard_mode == 'perf':
+                context_all = prop_dist.sample_batch(n_nodes_all) if prop_dist is not None else None
+                from .dist import assign_lpt, shard_range
+                if shard_assign == 'lpt':
+                    mine = assign_lpt(n_nodes_all.tolist(), world)[rank]
+                else:
+                    lo, hi = shard_range(total, rank, world)
+                    mine = list(range(lo, hi))
+                torch.manual_seed(base + 1 + rank)             # this rank's own noise stream (CPU and device generators)
+                for r0 in range(0, len(mine), batch_size):
+                    idx = torch.as_tensor(mine[r0:r0 + batch_size], dtype=torch.long)
+                    context = context_all[idx].to(device) if context_all is not None else None
+                    mols += one_round(model, n_nodes_all[idx], context)
+                    if rank == 0:
+                        print('Generate {} on rank 0, Total {}.'.format(len(mols), n_samples))
+                sampling_fn.last_indices = list(mine)
+            else:                                              # parity: replay the unsharded run's draws
+                from .dist import shard_range
+                indices = []
+                for r in range(rounds):
+                    n_nodes = n_nodes_all[r * batch_size:(r + 1) * batch_size]
+                    context = prop_dist.sample_batch(n_nodes) if prop_dist is not None else None
+                    lo, hi = shard_range(len(n_nodes), rank, world)
+                    noise = _ParityNoise(n_nodes.tolist(), lo, hi, node_nf, edge_nf, device)
+                    if hi == lo:                               # nothing of this round is ours: stay in step with the stream
+                        _consume_round_noise(noise, sampler, steps)
+                        continue
+                    ctx = context[lo:hi].to(device) if context is not None else None
+                    mols += one_round(model, n_nodes[lo:hi], ctx, noise)
+                    indices += list(range(r * batch_size + lo, r * batch_size + hi))
+                sampling_fn.last_indices = indices
+        return mols                                            # caller gathers / shuffles
+
+    sampling_fn.last_indices = None
     return sampling_fn
+
+
+def _consume_round_noise(noise, sampler, steps):
+    """Advance the CPU generator by exactly the draws one round makes (a rank whose slice of a round is empty)."""
+    noise.node(); noise.edge()
+    if isinstance(sampler, AncestralSampler):
+        for _ in range(steps):
+            noise.node(); noise.edge()
+    else:
+        for _ in range(sampler.noise_draws_per_round()):
+            noise.pos()
+
+
+def _warn_nan(model):
+    """The reference prints 'Warning: detected nan, resetting output to zero.' in every forward that hits the guard
+    (mol_gnn.py:587-589).  The kernels keep a sticky device counter instead of a host sync per step; it is read once
+    per round here (one .item())."""
+    take = getattr(model, 'take_nan_count', None) or getattr(getattr(model, 'module', None), 'take_nan_count', None)
+    if take is not None:
+        n = take()
+        if n:
+            print('Warning: detected nan in %d score-network evaluation(s) of this round, position outputs were reset to zero.' % n)
 
 
 def posterior_coefficients(ns, t, s):

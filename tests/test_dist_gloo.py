@@ -58,6 +58,117 @@ def test_shard_and_gather_world2():
     assert res == [(0, True), (1, True)]
 
 
+# ---- sharded sampling through get_sampling_fn: RNG contract, parity mode, LPT ------------------
+def _sampling_setup(method, steps):
+    from helpers import OracleModel, make_config, make_model, state_dict_cpu
+    from jodo_amd.diffusion import NoiseScheduleVP
+    from jodo_amd.models import load_dataset_info, get_node_dist
+    from jodo_amd.utils import get_data_inverse_scaler
+    from oracle import dgt_oracle as O
+    cfg = make_config('vpsde_qm9_uncond_jodo')
+    cfg.device = 'cpu'
+    cfg.sampling.steps = steps
+    cfg.sampling.method = method
+    cfg.sampling['dpm_solver_method'] = 'singlestep_fixed'
+    cfg.sampling['dpm_solver_order'] = 2
+    model = OracleModel(state_dict_cpu(make_model(cfg, 5, head_gain=30.0)), O.Hyper.from_config(cfg))
+    ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
+    return cfg, model, ns, get_node_dist(load_dataset_info('qm9_with_h')), get_data_inverse_scaler(cfg)
+
+
+def _sample_worker(rank, world, port, method, steps, mode, assign, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from jodo_amd.dist import gather_sampled
+    from jodo_amd.sampling import get_sampling_fn
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg, model, ns, nodes_dist, inv = _sampling_setup(method, steps)
+    torch.manual_seed(1234 + rank)                       # whatever the process did before must not matter
+    fn = get_sampling_fn(cfg, ns, nodes_dist, 5, 9, inv, shard=(rank, world), shard_mode=mode, shard_assign=assign, seed=77)
+    mols = fn(model)
+    full = gather_sampled(mols, fn.last_indices)
+    q.put((rank, fn.last_indices, [tuple(t.numpy().copy() for t in m) for m in full]))      # by value (no shared-memory handles)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_world2(method, steps, mode, assign='contiguous'):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, method, steps, mode, assign, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    return [(r, idx, [tuple(torch.from_numpy(a) for a in m) for m in mols]) for r, idx, mols in res]
+
+
+def _same(a, b):
+    return len(a) == len(b) and all(all(torch.equal(x, y) for x, y in zip(m, w)) for m, w in zip(a, b))
+
+
+def test_sharded_sampling_parity_mode_reproduces_the_unsharded_run():
+    """world 2, shard_mode='parity': the gathered molecules equal the world-size-1 run bit for bit — ancestral
+    (BASELINE configs 1-4 path) and hybrid DPM-solver (config 5 path); 9 samples in rounds of 5, so the second
+    round is ragged and the ranks hold 3 + 2 molecules of it."""
+    from jodo_amd.sampling import get_sampling_fn
+    threads = torch.get_num_threads()
+    torch.set_num_threads(2)                  # as the workers: CPU GEMM blocking (hence low bits) depends on the thread count
+    try:
+        _parity_body(get_sampling_fn)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def _parity_body(get_sampling_fn):
+    for method, steps in (('ancestral', 3), ('fast', 4)):
+        cfg, model, ns, nodes_dist, inv = _sampling_setup(method, steps)
+        torch.manual_seed(77)
+        want = get_sampling_fn(cfg, ns, nodes_dist, 5, 9, inv, return_raw=True)(model)       # the reference's procedure
+        one = get_sampling_fn(cfg, ns, nodes_dist, 5, 9, inv, shard=(0, 1), shard_mode='parity', seed=77)
+        got1 = one(model)
+        assert one.last_indices == list(range(10)) and _same(got1, want)
+        res = _run_world2(method, steps, 'parity')
+        assert sorted(res[0][1] + res[1][1]) == list(range(10)) and not set(res[0][1]) & set(res[1][1])
+        assert res[0][1] == [0, 1, 2, 5, 6, 7]                  # contiguous slice of every round
+        for _, _, full in res:
+            assert _same(full, want)
+        assert len({int(m[0].shape[0]) for m in want}) > 1      # not a degenerate batch
+
+
+def test_sharded_sampling_perf_mode_rng_contract_and_lpt():
+    """shard_mode='perf': molecules are dealt to the ranks before rounds are cut, atom counts come from the shared
+    seed (identical on all ranks whatever their prior RNG state), noise from seed + 1 + rank (no two ranks share a
+    stream), LPT balances the n^2 work."""
+    from jodo_amd.dist import assign_lpt
+    res = _run_world2('ancestral', 2, 'perf')
+    assert res[0][1] == list(range(0, 5)) and res[1][1] == list(range(5, 10))
+    assert _same(res[0][2], res[1][2])                          # both ranks hold the same gathered list
+    full = res[0][2]
+    cfg, model, ns, nodes_dist, inv = _sampling_setup('ancestral', 2)
+    torch.manual_seed(77)
+    n_all = nodes_dist.sample(10).tolist()
+    assert [int(m[0].shape[0]) for m in full] == n_all          # shared-seed atom counts, global order restored
+    # same-size molecules on different ranks must not be duplicates of each other (independent noise streams)
+    pos = {}
+    for i, m in enumerate(full):
+        for j, w in pos.get(int(m[0].shape[0]), []):
+            assert not torch.allclose(m[0], w, atol=1e-3)
+        pos.setdefault(int(m[0].shape[0]), []).append((i, m[0]))
+    lpt = _run_world2('ancestral', 2, 'perf', 'lpt')
+    assert sorted(lpt[0][1] + lpt[1][1]) == list(range(10))
+    assert [int(m[0].shape[0]) for m in lpt[0][2]] == n_all
+    a = assign_lpt(n_all, 2)
+    assert a == [lpt[0][1], lpt[1][1]]
+    load = [sum(n_all[i] ** 2 for i in part) for part in a]
+    assert abs(load[0] - load[1]) <= max(n_all) ** 2            # LPT bound: loads differ by at most one job
+
+
 def test_shard_range_covers_everything():
     for n, w in ((10, 4), (7, 2), (2500, 8), (3, 8)):
         spans = [shard_range(n, r, w) for r in range(w)]
