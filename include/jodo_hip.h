@@ -51,8 +51,8 @@ typedef struct {
 } jodo_cfg;
 
 /* Slots of the weight-offset table handed to jodo_dgt_forward (offsets in floats into the packed
- * weight blob produced by jodo_amd/packing_model.py; the Python packer and this enum are kept in
- * lock-step by tests/test_packing.py). */
+ * weight blob produced by jodo_dgt_pack_weights; tests/test_packing.py keeps this enum, the C packer and the
+ * independent Python packer jodo_amd/packing_model.py in lock-step, blob for blob). */
 enum jodo_wslot_global {
     JW_TIME_FREQ = 0, JW_TIME_W1, JW_TIME_B1, JW_TIME_W3, JW_TIME_B3,
     JW_COND_W0, JW_COND_B0, JW_COND_W2, JW_COND_B2, JW_COND_LIN_W, JW_COND_LIN_B,
@@ -72,6 +72,30 @@ enum jodo_wslot_block {
 };
 /* table length = JW_GLOBAL_COUNT + n_layers * JB_BLOCK_COUNT; block l slot s lives at
  * JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + s */
+
+/* ---- weights --------------------------------------------------------------------------------------------------
+ * jodo_dgt_pack_weights  <- the parameter container of DGT_concat / Cond_DGT_concat: the 351 (QM9) / 431 (GEOM L = 10) /
+ *                           357 (conditional) tensors of its state_dict, names and shapes as registered by the
+ *                           constructors models/mol_gnn.py:414-489 and :601-684 (a leading "module." — checkpoints
+ *                           saved through nn.DataParallel, utils.py:23-30 — is accepted and ignored).
+ * A host with nothing but a C FFI hands over the named fp32 tensors (HOST pointers, contiguous, PyTorch [out, in]
+ * layout) and receives the packed blob in MFMA A-operand order plus the offset table jodo_dgt_forward takes.
+ *   jodo_dgt_packed_size        number of floats of the blob and of offset-table slots for this configuration
+ *   jodo_dgt_pack_weights_host  pack into caller-owned host memory (no device work at all)
+ *   jodo_dgt_pack_weights       pack and upload into caller-owned DEVICE memory; this load-time call synchronises
+ *                               `stream` before returning (its staging buffer lives only for the call)
+ * A missing or mis-sized parameter is an error (JODO_ERR_ARG, the name is in jodo_last_error()). */
+typedef struct {
+    const char* name;       /* state_dict key, e.g. "e_block_3.attn_mpnn.lin_edge0.weight" */
+    const float* data;      /* host pointer, contiguous fp32 */
+    const int64_t* shape;
+    int32_t ndim;
+} jodo_tensor;
+int jodo_dgt_packed_size(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, size_t* n_floats, int* n_woff);
+int jodo_dgt_pack_weights_host(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, float* packed_host,
+                               size_t cap_floats, int64_t* woff_out, int n_woff);
+int jodo_dgt_pack_weights(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, void* packed_dev,
+                          size_t cap_floats, int64_t* woff_out, int n_woff, void* stream);
 
 typedef struct jodo_plan jodo_plan;
 

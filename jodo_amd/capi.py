@@ -44,3 +44,38 @@ def ptr(t):
 def current_stream_ptr():
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class JodoTensor(ctypes.Structure):             # jodo_tensor (include/jodo_hip.h)
+    _fields_ = [('name', ctypes.c_char_p), ('data', ctypes.c_void_p), ('shape', ctypes.POINTER(ctypes.c_int64)),
+                ('ndim', ctypes.c_int32)]
+
+
+def pack_weights(cfg_struct, state_dict, device=None):
+    """state_dict (reference key names; values on any device) -> (blob, woff ctypes int64 array, n_woff) through the
+    C packer jodo_dgt_pack_weights[_host].  device=None: blob is a CPU torch tensor; otherwise it is packed straight
+    into a device tensor (one host->device copy of the blob inside the call)."""
+    import numpy as np
+    import torch
+    L = lib()
+    keep, arr = [], (JodoTensor * len(state_dict))()
+    for i, (k, v) in enumerate(state_dict.items()):
+        t = np.ascontiguousarray(v.detach().float().cpu().numpy())
+        shp = (ctypes.c_int64 * max(t.ndim, 1))(*t.shape)
+        name = k.encode()
+        keep.append((t, shp, name))
+        arr[i] = JodoTensor(name, t.ctypes.data_as(ctypes.c_void_p), shp, t.ndim)
+    n_floats, n_woff = ctypes.c_size_t(), ctypes.c_int()
+    check(L.jodo_dgt_packed_size(ctypes.byref(cfg_struct), arr, len(keep), ctypes.byref(n_floats), ctypes.byref(n_woff)),
+          'jodo_dgt_packed_size')
+    woff = (ctypes.c_int64 * n_woff.value)()
+    if device is None:
+        blob = torch.empty(n_floats.value, dtype=torch.float32)
+        check(L.jodo_dgt_pack_weights_host(ctypes.byref(cfg_struct), arr, len(keep), ctypes.c_void_p(blob.data_ptr()),
+                                           ctypes.c_size_t(n_floats.value), woff, n_woff.value), 'jodo_dgt_pack_weights_host')
+    else:
+        blob = torch.empty(n_floats.value, dtype=torch.float32, device=device)
+        check(L.jodo_dgt_pack_weights(ctypes.byref(cfg_struct), arr, len(keep), ctypes.c_void_p(blob.data_ptr()),
+                                      ctypes.c_size_t(n_floats.value), woff, n_woff.value, current_stream_ptr()),
+              'jodo_dgt_pack_weights')
+    return blob, woff, n_woff.value

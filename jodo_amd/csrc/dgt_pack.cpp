@@ -1,0 +1,347 @@
+// jodo_dgt_pack_weights: the reference's state_dict (parameter names and shapes of DGT_concat / Cond_DGT_concat,
+// /root/reference/models/mol_gnn.py:414-489, :601-684) -> the single fp32 blob + offset table jodo_dgt_forward reads.
+//
+// Every dense projection runs on v_mfma_f32_32x32x2_f32 in the transposed orientation
+//     D[out_feature, item] += W[out_feature, k] * X[k, item]
+// with the weights as A operand: lane l supplies W[row(l & 31)][k-slot l >> 5].  A packed projection is
+// float [n_out_blocks][ksteps / 4][64 lanes][4] (one 16-byte load per lane feeds four MFMAs).  Which matrix row /
+// column a (block, lane, k-step) reads is given by two index maps:
+//     in_map  [ksteps][2]      input column of k-step R for half-lane h   (-1 = zero)
+//     out_map [blocks][2][16]  output row held by register s of half h    (-1 = zero)
+// "natural" maps put feature (R / 16) * 32 + h * 16 + R % 16 in register R of half h, so that memory stays in natural
+// order and the accumulator of one projection is the B operand of the next.  Host-only code; no device work except
+// the final upload in jodo_dgt_pack_weights.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "dgt_plan.h"
+#include "jodo_hip_internal.h"
+
+namespace {
+
+typedef std::vector<int64_t> IMap;      // in_map  [ksteps][2] flattened
+typedef std::vector<int64_t> OMap;      // out_map [nb][2][16] flattened
+
+IMap nat_in(int n, int64_t base = 0) {
+    IMap m((size_t)n);                   // n/2 k-steps x 2
+    for (int R = 0; R < n / 2; ++R)
+        for (int h = 0; h < 2; ++h) m[(size_t)R * 2 + h] = base + (R / 16) * 32 + h * 16 + (R % 16);
+    return m;
+}
+OMap nat_out(int n, int n_valid = -1) {
+    OMap m((size_t)n);
+    for (int b = 0; b < n / 32; ++b)
+        for (int h = 0; h < 2; ++h)
+            for (int s = 0; s < 16; ++s) {
+                const int64_t f = b * 32 + h * 16 + s;
+                m[((size_t)b * 2 + h) * 16 + s] = (n_valid >= 0 && f >= n_valid) ? -1 : f;
+            }
+    return m;
+}
+// short feature group (n <= 32, padded to a multiple of 8): half h, register s holds feature h * (npad / 2) + s
+IMap small_in(int n, int64_t base = 0) {
+    const int npad = (n + 7) / 8 * 8, half = npad / 2;
+    IMap m((size_t)npad, -1);
+    for (int h = 0; h < 2; ++h)
+        for (int s = 0; s < half; ++s) {
+            const int f = h * half + s;
+            if (f < n) m[(size_t)s * 2 + h] = base + f;
+        }
+    return m;
+}
+IMap cat(const IMap& a, const IMap& b) { IMap o(a); o.insert(o.end(), b.begin(), b.end()); return o; }
+// tuned nf = 256 arrangement of the SH x SC score features (reduction per head stays register-local):
+// blocks 0 .. SH/2-1: half h of block b = channels 0..15 of head 2b + h; tail channel c of head g in block SH/2 + c/2,
+// half c % 2, register g
+OMap qk_out(int SH, int SC) {
+    const int tail = SC - 16, nb = SH / 2 + (tail + 1) / 2;
+    OMap m((size_t)nb * 32, -1);
+    for (int b = 0; b < SH / 2; ++b)
+        for (int h = 0; h < 2; ++h)
+            for (int s = 0; s < 16; ++s) m[((size_t)b * 2 + h) * 16 + s] = (int64_t)(2 * b + h) * SC + s;
+    for (int c = 0; c < tail; ++c)
+        for (int g = 0; g < SH; ++g) m[((size_t)(SH / 2 + c / 2) * 2 + (c % 2)) * 16 + g] = (int64_t)g * SC + 16 + c;
+    return m;
+}
+// width-generic arrangement: head g owns block g in natural order, rows >= SC are padding
+OMap qk_out_wide(int SH, int SC) {
+    OMap m((size_t)SH * 32, -1);
+    for (int g = 0; g < SH; ++g)
+        for (int h = 0; h < 2; ++h)
+            for (int s = 0; s < 16; ++s)
+                if (h * 16 + s < SC) m[((size_t)g * 2 + h) * 16 + s] = (int64_t)g * SC + h * 16 + s;
+    return m;
+}
+// first layer of a head MLP: padded activation layout [base | L x pad] -> true column base + l * cnt + c
+IMap hid_in(int base, int L, int cnt, int pad) {
+    const int width = base + L * pad;
+    std::vector<int64_t> col((size_t)width, -1);
+    for (int i = 0; i < base; ++i) col[i] = i;
+    for (int l = 0; l < L; ++l)
+        for (int c = 0; c < cnt; ++c) col[base + l * pad + c] = base + l * cnt + c;
+    IMap nat = nat_in(width);
+    for (auto& v : nat) v = col[(size_t)v];
+    return nat;
+}
+
+struct Packer {
+    std::vector<float> blob;
+    std::vector<int64_t> offs;        // in put() order
+    void put(const float* src, size_t n) {
+        offs.push_back((int64_t)blob.size());
+        blob.insert(blob.end(), src, src + n);
+        blob.resize((blob.size() + 63) / 64 * 64, 0.f);     // every slot 256-byte aligned
+    }
+    void put(const std::vector<float>& v) { put(v.data(), v.size()); }
+    void put_zero1() { const float z = 0.f; put(&z, 1); }
+    // W [n_out][ld] row-major
+    void put_proj(const float* W, int64_t ld, const IMap& in, const OMap& out) {
+        const size_t ksteps = in.size() / 2, nb = out.size() / 32;
+        std::vector<float> p(nb * ksteps * 64);
+        for (size_t b = 0; b < nb; ++b)
+            for (size_t kq = 0; kq < ksteps / 4; ++kq)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, kh = lane >> 5, oh = (i >> 2) & 1, os = (i & 3) + 4 * (i >> 3);
+                    const int64_t row = out[(b * 2 + oh) * 16 + os];
+                    for (int c = 0; c < 4; ++c) {
+                        const int64_t col = in[(kq * 4 + c) * 2 + kh];
+                        p[((b * (ksteps / 4) + kq) * 64 + lane) * 4 + c] = (row < 0 || col < 0) ? 0.f : W[row * ld + col];
+                    }
+                }
+        put(p);
+    }
+    void put_vec(const float* v, const OMap& out) {
+        std::vector<float> p(out.size());
+        for (size_t i = 0; i < out.size(); ++i) p[i] = out[i] < 0 ? 0.f : v[out[i]];
+        put(p);
+    }
+};
+
+struct Lookup {
+    std::unordered_map<std::string, const jodo_tensor*> m;
+    std::string missing;
+    const float* get(const std::string& name, int64_t numel) {
+        auto it = m.find(name);
+        if (it == m.end()) { if (missing.empty()) missing = name; return nullptr; }
+        int64_t n = 1;
+        for (int i = 0; i < it->second->ndim; ++i) n *= it->second->shape[i];
+        if (n != numel) { if (missing.empty()) missing = name + " (wrong size)"; return nullptr; }
+        return it->second->data;
+    }
+};
+
+std::vector<float> gbf_table(Lookup& lk, const std::string& prefix, int De) {
+    // [3][De]: mu, 1 / sigma, 1 / (sqrt(2 * 3.14159) * sigma), sigma = |w| + 1e-5 (layers.py:291-295, :328-334);
+    // entry 0 of each row belongs to feature x' itself
+    std::vector<float> tab((size_t)3 * De, 0.f);
+    const float* mu = lk.get(prefix + ".means.weight", De - 1);
+    const float* sd = lk.get(prefix + ".stds.weight", De - 1);
+    if (!mu || !sd) return tab;
+    const double a = std::pow(2 * 3.14159, 0.5);
+    for (int k = 1; k < De; ++k) {
+        const double sg = std::fabs((double)sd[k - 1]) + 1e-5;
+        tab[k] = mu[k - 1];
+        tab[De + k] = (float)(1.0 / sg);
+        tab[2 * De + k] = (float)(1.0 / (a * sg));
+    }
+    tab[De] = 1.f;
+    return tab;
+}
+
+int pack(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, Packer& P, std::vector<int64_t>& woff) {
+    DgtDims d;
+    int rc = dgt_dims_from_cfg(cfg, &d);
+    if (rc != JODO_OK) return rc;
+    const int D = d.D, De = d.De, T = d.T, L = d.L, nd = d.nd, ch = d.ch, r = d.r;
+    const int cn = (2 * D) / L, ce = (2 * De) / L;
+    Lookup lk;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (!tensors[i].name || !tensors[i].data) return jodo_set_error(JODO_ERR_ARG, "pack_weights: tensor %d has a null field", i);
+        std::string nm(tensors[i].name);
+        if (nm.rfind("module.", 0) == 0) nm = nm.substr(7);          // DataParallel-saved checkpoints (utils.py:23-30)
+        lk.m[nm] = &tensors[i];
+    }
+    auto W = [&](const std::string& k, int64_t numel) { return lk.get(k, numel); };
+    const std::vector<float> dummy((size_t)std::max<int64_t>(d.Mtot, (int64_t)T * 17), 0.f);
+    auto S = [&](const float* p) { return p ? p : dummy.data(); };        // keep going after a miss; reported at the end
+
+    // ---- time embedding ----
+    P.put(S(W("time_mlp.0.weights", 8)), 8);
+    P.put(S(W("time_mlp.1.weight", (int64_t)T * 17)), (size_t)T * 17);
+    P.put(S(W("time_mlp.1.bias", T)), T);
+    if (const float* w = W("time_mlp.3.weight", (int64_t)T * T)) P.put_proj(w, T, nat_in(T), nat_out(T)); else P.put_zero1();
+    P.put(S(W("time_mlp.3.bias", T)), T);
+    if (d.cond_ch > 0) {
+        P.put(S(W("cond_mlp.0.weight", D)), D);
+        P.put(S(W("cond_mlp.0.bias", D)), D);
+        if (const float* w = W("cond_mlp.2.weight", (int64_t)D * D)) P.put_proj(w, D, nat_in(D), nat_out(D)); else P.put_zero1();
+        P.put(S(W("cond_mlp.2.bias", D)), D);
+        const int kc = d.cond_ch * D;
+        if (kc % 64) return jodo_set_error(JODO_ERR_UNSUPPORTED, "cond_ch * nf = %d is not a multiple of 64", kc);
+        if (const float* w = W("cond_lin.weight", (int64_t)T * kc)) P.put_proj(w, kc, nat_in(kc), nat_out(T)); else P.put_zero1();
+        P.put(S(W("cond_lin.bias", T)), T);
+    } else {
+        for (int i = 0; i < 6; ++i) P.put_zero1();
+    }
+    // ---- all time-modulation linears fused into one [Mtot, T] projection ----
+    {
+        std::vector<float> Wm((size_t)d.Mtot * T, 0.f), bm((size_t)d.Mtot, 0.f);
+        auto rows = [&](int64_t o, const std::string& base, int n) {
+            const float* w = W(base + ".weight", (int64_t)n * T);
+            const float* b = W(base + ".bias", n);
+            if (w) std::memcpy(&Wm[(size_t)o * T], w, sizeof(float) * (size_t)n * T);
+            if (b) std::memcpy(&bm[(size_t)o], b, sizeof(float) * (size_t)n);
+        };
+        rows(0, "dist_layer.time_mlp.1", 2);
+        for (int l = 0; l < L; ++l) {
+            const std::string b = "e_block_" + std::to_string(l);
+            int64_t o = 32 + (int64_t)l * d.MB;
+            rows(o, b + ".node_time_mlp.1", 6 * D); o += 6 * D;
+            rows(o, b + ".edge_time_mlp.1", 6 * De); o += 6 * De;
+            rows(o, b + ".equi_update.time_mlp.1", 2 * D); o += 2 * D;
+            rows(o, b + ".dist_layer.time_mlp.1", 2);
+        }
+        P.put_proj(Wm.data(), T, nat_in(T), nat_out((int)d.Mtot));
+        P.put(bm);
+    }
+    // ---- embeddings ----
+    if (const float* w = W("node_emb.weight", (int64_t)D * 2 * nd)) P.put_proj(w, 2 * nd, small_in(2 * nd), nat_out(D)); else P.put_zero1();
+    P.put(S(W("node_emb.bias", D)), D);
+    if (const float* w = W("edge_emb.weight", (int64_t)De * (2 * ch + De)))
+        P.put_proj(w, 2 * ch + De, cat(nat_in(De, 2 * ch), small_in(2 * ch)), nat_out(De));      // [G0 ; raw edge inputs]
+    else P.put_zero1();
+    P.put(S(W("edge_emb.bias", De)), De);
+    P.put(gbf_table(lk, "dist_layer", De));
+    // ---- heads ----
+    const int catn = D + L * cn, cate = De + L * ce, h2 = De / 2;
+    if (const float* w = W("node_pred_mlp.0.weight", (int64_t)D * catn)) P.put_proj(w, catn, hid_in(D, L, cn, d.cnp), nat_out(D)); else P.put_zero1();
+    P.put(S(W("node_pred_mlp.0.bias", D)), D);
+    if (const float* w = W("node_pred_mlp.2.weight", (int64_t)(D / 2) * D)) P.put_proj(w, D, nat_in(D), nat_out(D / 2)); else P.put_zero1();
+    P.put(S(W("node_pred_mlp.2.bias", D / 2)), D / 2);
+    {
+        const OMap om = nat_out(32, nd);
+        if (const float* w = W("node_pred_mlp.4.weight", (int64_t)nd * (D / 2))) P.put_proj(w, D / 2, nat_in(D / 2), om); else P.put_zero1();
+        P.put_vec(S(W("node_pred_mlp.4.bias", nd)), om);
+    }
+    {   // exist | type heads side by side
+        const float* w1a = W("edge_exist_mlp.0.weight", (int64_t)De * cate), *w1b = W("edge_type_mlp.0.weight", (int64_t)De * cate);
+        std::vector<float> W1((size_t)2 * De * cate, 0.f), b1((size_t)2 * De, 0.f);
+        if (w1a) std::memcpy(W1.data(), w1a, sizeof(float) * (size_t)De * cate);
+        if (w1b) std::memcpy(W1.data() + (size_t)De * cate, w1b, sizeof(float) * (size_t)De * cate);
+        P.put_proj(W1.data(), cate, hid_in(De, L, ce, d.cep), nat_out(2 * De));
+        if (const float* b = W("edge_exist_mlp.0.bias", De)) std::memcpy(b1.data(), b, sizeof(float) * De);
+        if (const float* b = W("edge_type_mlp.0.bias", De)) std::memcpy(b1.data() + De, b, sizeof(float) * De);
+        P.put(b1);
+        std::vector<float> W2((size_t)2 * h2 * 2 * De, 0.f), b2((size_t)2 * h2, 0.f);
+        const float* w2a = W("edge_exist_mlp.2.weight", (int64_t)h2 * De), *w2b = W("edge_type_mlp.2.weight", (int64_t)h2 * De);
+        for (int i = 0; i < h2; ++i)
+            for (int k = 0; k < De; ++k) {
+                if (w2a) W2[(size_t)i * 2 * De + k] = w2a[(size_t)i * De + k];
+                if (w2b) W2[(size_t)(h2 + i) * 2 * De + De + k] = w2b[(size_t)i * De + k];
+            }
+        P.put_proj(W2.data(), 2 * De, nat_in(2 * De), nat_out(2 * h2));
+        if (const float* b = W("edge_exist_mlp.2.bias", h2)) std::memcpy(b2.data(), b, sizeof(float) * h2);
+        if (const float* b = W("edge_type_mlp.2.bias", h2)) std::memcpy(b2.data() + h2, b, sizeof(float) * h2);
+        P.put(b2);
+        std::vector<float> W3((size_t)ch * 2 * h2, 0.f), b3((size_t)ch, 0.f);
+        const float* w3a = W("edge_exist_mlp.4.weight", h2), *w3b = W("edge_type_mlp.4.weight", (int64_t)(ch - 1) * h2);
+        for (int k = 0; k < h2; ++k) {
+            if (w3a) W3[k] = w3a[k];
+            for (int c = 1; c < ch; ++c)
+                if (w3b) W3[(size_t)c * 2 * h2 + h2 + k] = w3b[(size_t)(c - 1) * h2 + k];
+        }
+        const OMap om3 = nat_out(32, ch);
+        P.put_proj(W3.data(), 2 * h2, nat_in(2 * h2), om3);
+        if (const float* b = W("edge_exist_mlp.4.bias", 1)) b3[0] = b[0];
+        if (const float* b = W("edge_type_mlp.4.bias", ch - 1)) for (int c = 1; c < ch; ++c) b3[c] = b[c - 1];
+        P.put_vec(b3.data(), om3);
+    }
+    if ((int)P.offs.size() != JW_GLOBAL_COUNT) return jodo_set_error(JODO_ERR_ARG, "pack_weights: internal slot count %d", (int)P.offs.size());
+    // ---- blocks ----
+    const OMap qk = d.wide ? qk_out_wide(d.SH, d.SC) : qk_out(d.SH, d.SC);
+    if ((int)qk.size() != d.QKP) return jodo_set_error(JODO_ERR_ARG, "pack_weights: q/k map width %d != %d", (int)qk.size(), d.QKP);
+    const int QK = d.SH * d.SC, KIN = 2 * D + 2 * De;
+    for (int l = 0; l < L; ++l) {
+        const std::string b = "e_block_" + std::to_string(l), a = b + ".attn_mpnn";
+        auto proj = [&](const std::string& key, int64_t n_out, int64_t ld, const IMap& in, const OMap& out) {
+            if (const float* w = W(key, n_out * ld)) P.put_proj(w, ld, in, out); else P.put_zero1();
+        };
+        proj(a + ".lin_query.weight", QK, D, nat_in(D), qk);  P.put_vec(S(W(a + ".lin_query.bias", QK)), qk);
+        proj(a + ".lin_key.weight", QK, D, nat_in(D), qk);    P.put_vec(S(W(a + ".lin_key.bias", QK)), qk);
+        proj(a + ".lin_value.weight", D, D, nat_in(D), nat_out(D)); P.put(S(W(a + ".lin_value.bias", D)), D);
+        proj(b + ".edge_emb.weight", De, 2 * De, cat(nat_in(De), nat_in(De, De)), nat_out(De)); P.put(S(W(b + ".edge_emb.bias", De)), De);
+        proj(a + ".lin_edge0.weight", QK, De, nat_in(De), qk);
+        proj(a + ".lin_edge1.weight", D, De, nat_in(De), nat_out(D));
+        proj(b + ".node2edge_lin.weight", De, D, nat_in(D), nat_out(De)); P.put(S(W(b + ".node2edge_lin.bias", De)), De);
+        proj(b + ".ff_linear1.weight", (int64_t)r * D, D, nat_in(D), nat_out(r * D)); P.put(S(W(b + ".ff_linear1.bias", r * D)), (size_t)r * D);
+        proj(b + ".ff_linear2.weight", D, (int64_t)r * D, nat_in(r * D), nat_out(D)); P.put(S(W(b + ".ff_linear2.bias", D)), D);
+        proj(b + ".ff_linear3.weight", (int64_t)r * De, De, nat_in(De), nat_out(r * De)); P.put(S(W(b + ".ff_linear3.bias", r * De)), (size_t)r * De);
+        proj(b + ".ff_linear4.weight", De, (int64_t)r * De, nat_in(r * De), nat_out(De)); P.put(S(W(b + ".ff_linear4.bias", De)), De);
+        // input_lin [D, 2D + De + De] = h_row | h_col | e | G: the kernels feed [e ; G] per edge and apply the h halves per node
+        proj(b + ".equi_update.input_lin.weight", D, KIN, cat(nat_in(De, 2 * D), nat_in(De, 2 * D + De)), nat_out(D));
+        proj(b + ".equi_update.input_lin.weight", D, KIN, nat_in(D, 0), nat_out(D));
+        proj(b + ".equi_update.input_lin.weight", D, KIN, nat_in(D, D), nat_out(D));
+        P.put(S(W(b + ".equi_update.input_lin.bias", D)), D);
+        proj(b + ".equi_update.coord_mlp.0.weight", D, D, nat_in(D), nat_out(D)); P.put(S(W(b + ".equi_update.coord_mlp.0.bias", D)), D);
+        P.put(S(W(b + ".equi_update.coord_mlp.2.weight", (int64_t)3 * D)), (size_t)3 * D);
+        P.put(S(W(b + ".equi_update.coord_norm.scale", 1)), 1);
+        const OMap omn = nat_out(d.cnp, cn), ome = nat_out(32, ce);
+        proj("node_" + std::to_string(l) + ".weight", cn, D, nat_in(D), omn); P.put_vec(S(W("node_" + std::to_string(l) + ".bias", cn)), omn);
+        proj("edge_" + std::to_string(l) + ".weight", ce, De, nat_in(De), ome); P.put_vec(S(W("edge_" + std::to_string(l) + ".bias", ce)), ome);
+        P.put(gbf_table(lk, b + ".dist_layer", De));
+    }
+    if (!lk.missing.empty()) return jodo_set_error(JODO_ERR_ARG, "pack_weights: parameter '%s' missing from the tensor list", lk.missing.c_str());
+    if ((int)P.offs.size() != JW_GLOBAL_COUNT + L * JB_BLOCK_COUNT)
+        return jodo_set_error(JODO_ERR_ARG, "pack_weights: internal slot count %d", (int)P.offs.size());
+    woff = P.offs;
+    return JODO_OK;
+}
+
+}  // namespace
+
+extern "C" int jodo_dgt_packed_size(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, size_t* n_floats, int* n_woff) {
+    if (!cfg || !tensors || !n_floats || !n_woff) return jodo_set_error(JODO_ERR_ARG, "packed_size: null argument");
+    Packer P;
+    std::vector<int64_t> woff;
+    const int rc = pack(cfg, tensors, n_tensors, P, woff);
+    if (rc != JODO_OK) return rc;
+    *n_floats = P.blob.size();
+    *n_woff = (int)woff.size();
+    return JODO_OK;
+}
+
+extern "C" int jodo_dgt_pack_weights_host(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, float* packed_host,
+                                          size_t cap_floats, int64_t* woff_out, int n_woff) {
+    if (!cfg || !tensors || !packed_host || !woff_out) return jodo_set_error(JODO_ERR_ARG, "pack_weights: null argument");
+    Packer P;
+    std::vector<int64_t> woff;
+    const int rc = pack(cfg, tensors, n_tensors, P, woff);
+    if (rc != JODO_OK) return rc;
+    if (P.blob.size() > cap_floats || (int)woff.size() != n_woff)
+        return jodo_set_error(JODO_ERR_ARG, "pack_weights: buffer holds %zu floats / %d slots, need %zu / %d", cap_floats, n_woff,
+                              P.blob.size(), (int)woff.size());
+    std::memcpy(packed_host, P.blob.data(), sizeof(float) * P.blob.size());
+    std::memcpy(woff_out, woff.data(), sizeof(int64_t) * woff.size());
+    return JODO_OK;
+}
+
+extern "C" int jodo_dgt_pack_weights(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, void* packed_dev,
+                                     size_t cap_floats, int64_t* woff_out, int n_woff, void* stream) {
+    if (!cfg || !tensors || !packed_dev || !woff_out) return jodo_set_error(JODO_ERR_ARG, "pack_weights: null argument");
+    Packer P;
+    std::vector<int64_t> woff;
+    const int rc = pack(cfg, tensors, n_tensors, P, woff);
+    if (rc != JODO_OK) return rc;
+    if (P.blob.size() > cap_floats || (int)woff.size() != n_woff)
+        return jodo_set_error(JODO_ERR_ARG, "pack_weights: buffer holds %zu floats / %d slots, need %zu / %d", cap_floats, n_woff,
+                              P.blob.size(), (int)woff.size());
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(packed_dev, P.blob.data(), sizeof(float) * P.blob.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);       // the staging memory belongs to this call
+    if (e != hipSuccess) return jodo_set_error(JODO_ERR_LAUNCH, "pack_weights: %s", hipGetErrorString(e));
+    std::memcpy(woff_out, woff.data(), sizeof(int64_t) * woff.size());
+    return JODO_OK;
+}

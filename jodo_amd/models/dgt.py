@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from .. import capi
-from ..packing_model import ModelDims, pack_model
+from ..packing_model import ModelDims
 from . import utils
 
 
@@ -183,11 +183,10 @@ class _DGTBase(nn.Module):
         # sampling round, _plan below), and invalidate_packed_weights() forces a re-pack explicitly.
         key = (str(device),) + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
         if self._packed is None or self._packed[0] != key:
-            sd = {k: v.detach().float().cpu() for k, v in self.state_dict().items()}
-            blob, woff = pack_model(sd, self.dims)
-            blob_dev = torch.from_numpy(blob).to(device)
-            woff_c = (ctypes.c_int64 * len(woff))(*woff.tolist())
-            self._packed = (key, blob_dev, woff_c, len(woff))
+            # C-side packer (csrc/dgt_pack.cpp, jodo_dgt_pack_weights): the state_dict goes through the C ABI as named
+            # fp32 tensors; jodo_amd/packing_model.py is an independent Python packer kept for tests (blob equality)
+            blob_dev, woff_c, n_woff = capi.pack_weights(self._cfg(), self.state_dict(), device)
+            self._packed = (key, blob_dev, woff_c, n_woff)
             self._packed_fingerprint = self._fingerprint()
         return self._packed
 

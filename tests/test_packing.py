@@ -96,3 +96,28 @@ def test_small_and_qk_maps_are_bijections():
     w = ModelDims(384, 10, 16, 2, 4, 17, 3)
     assert w.wide and (w.De, w.T, w.SC, w.C, w.QKP, w.cnp, w.cep, w.KNH, w.KEH) == (96, 1536, 27, 24, 448, 96, 32, 1344, 416)
     assert ModelDims(256, 8, 16, 2, 2, 6, 2, wide=True).QKP == 448 and not ModelDims(256, 8, 16, 2, 2, 6, 2).wide
+
+
+@pytest.mark.parametrize("cfg_name,over", [('vpsde_qm9_uncond_jodo', {}), ('vpsde_qm9_uncond_jodo', dict(kernel_layout='wide')),
+                                           ('vpsde_geom_uncond_jodo', {}), ('vpsde_geom_uncond_jodo', dict(nf=384)),
+                                           ('vpsde_qm9_cond_jodo', {})])
+def test_c_packer_equals_python_packer(cfg_name, over):
+    """jodo_dgt_pack_weights_host (csrc/dgt_pack.cpp) against the independent Python packer: same blob bit for bit,
+    same offset table — for the tuned and the width-generic layouts, the GEOM widths and the conditional model; a
+    'module.'-prefixed state_dict (DataParallel checkpoints) packs identically; a missing tensor is a named error."""
+    import torch
+    from helpers import make_config, make_model
+    from jodo_amd.packing_model import pack_model
+    cfg = make_config(cfg_name, **over)
+    model = make_model(cfg, 3)
+    sd = model.state_dict()
+    blob_py, woff_py = pack_model({k: v.detach().float().cpu() for k, v in sd.items()}, model.dims)
+    blob_c, woff_c, n = capi.pack_weights(model._cfg(), sd)
+    assert n == len(woff_py) and list(woff_c) == woff_py.tolist()
+    assert blob_c.numel() == blob_py.size and np.array_equal(blob_c.numpy().view(np.uint32), blob_py.view(np.uint32))
+    blob_m, woff_m, _ = capi.pack_weights(model._cfg(), {'module.' + k: v for k, v in sd.items()})
+    assert torch.equal(blob_m, blob_c) and list(woff_m) == list(woff_c)
+    bad = dict(sd)
+    del bad['e_block_1.attn_mpnn.lin_edge0.weight']
+    with pytest.raises(capi.JodoHipError, match='lin_edge0'):
+        capi.pack_weights(model._cfg(), bad)
