@@ -375,7 +375,7 @@ def main():
     if rank == 0:
         E = sum(n * (n - 1) for n in n_nodes)
         flops_launch = E * edge_update_flops_per_edge(hp)
-        names = ['prologue', 'node_pre', 'edge_scores', 'softmax', 'edge_msgs', 'node_post', 'edge_update', 'epilogue']
+        names = ['prologue', 'node_pre', 'edge_attn', 'softmax', 'edge_msgs', 'node_post', 'edge_update', 'epilogue']   # edge_attn: fused attention (nf 256); pair scores kernel on the width-generic path
         per_class = {names[c]: (ms[c] / max(cnt[c], 1), cnt[c]) for c in range(8)}
         upd_ms, upd_n = per_class['edge_update']
         achieved = flops_launch / (upd_ms * 1e-3) if upd_ms > 0 else 0.0

@@ -201,6 +201,27 @@ int jodo_sampler_step_tab(int B, int N, int node_feats, int edge_ch, const int32
                           float* x_next, float* edge_next, float* x_mean, float* edge_mean, void* stream);
 int jodo_step_begin(int B, const float* coef_tab_dev, const int32_t* step_dev, float* noise_level_out, void* stream);
 int jodo_step_end(int32_t* step_dev, void* stream);
+/* jodo_dpm_update  <- one update of the hybrid DPM-Solver++ sampler, mix_dpm_solver.py: positions take the ancestral step
+ *                     of :44-59 (pos_out = cx * x_pos + cp * PP + sigma * eps, eps_pos [B,N,3] RAW N(0,1) draws: masking and
+ *                     centre-of-mass removal happen in the kernel; sigma = 0 for the last update of a round, :56), every other
+ *                     channel of the node tensor and the whole edge tensor take the data-prediction update of :61-265
+ *                         out = a * base - b * P - c * (c2 * (DA - DB))
+ *                     which covers first order (c = 0, :84-85), single-step second order (:124-125, :137-146: P = DB =
+ *                     prediction at the start, DA = prediction at s1), third order (:199-219, c < 0) and second-order
+ *                     multistep (:253-260: P = DA = newest prediction, DB = the one before, c2 = 1 / r0).  PP = the
+ *                     prediction whose position channels drive the ancestral step.  Tensors: node [B,N,3+nd], edge
+ *                     [B,N,N,ch]; e* = the edge counterparts.  Coefficients {cx, cp, sigma, a, b, c, c2, noise_level}: either 8
+ *                     host floats, or row *step_dev of a device table (row stride tab_stride floats, first column tab_col) so
+ *                     that a captured hipGraph of an outer step replays for every step.
+ * jodo_step_begin_at  noise_level[b] = table[*step][tab_col + 7]  (the graph-replayable counterpart of the per-evaluation
+ *                     noise level, mix_dpm_solver.py:118,131) */
+int jodo_dpm_update(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, const float* coef8_host,
+                    const float* coef_tab_dev, const int32_t* step_dev, int tab_stride, int tab_col, const float* x_pos,
+                    const float* x_base, const float* edge_base, const float* P, const float* eP, const float* DA, const float* eDA,
+                    const float* DB, const float* eDB, const float* PP, const float* eps_pos, float* x_out, float* edge_out,
+                    void* stream);
+int jodo_step_begin_at(int B, const float* coef_tab_dev, const int32_t* step_dev, int tab_stride, int tab_col,
+                       float* noise_level_out, void* stream);
 int jodo_decode(int B, int N, int atom_types, int include_fc, int edge_ch, int compress_edge, int centered,
                 float pos_norm, float atom_norm, float fc_norm, float edge_norm, const int32_t* n_nodes_dev,
                 const float* xh, const float* edge_x, float* pos_out, uint8_t* atom_type_out, int8_t* fc_out,

@@ -27,6 +27,10 @@ PlanDev make_plan_dev(const jodo_plan* p, const void* desc_dev) {
     d.n_pitems = p->n_pitems;
     d.sitem_strip = base + p->off_sitem_strip; d.sitem_t0 = base + p->off_sitem_t0; d.sitem_t1 = base + p->off_sitem_t1;
     d.n_sitems = p->n_sitems;
+    d.ag_node = base + p->off_ag_node; d.ai_group = base + p->off_ai_group; d.ai_t0 = base + p->off_ai_t0; d.ai_t1 = base + p->off_ai_t1;
+    d.ai_part = base + p->off_ai_part; d.ad_group = base + p->off_ad_group; d.ad_t0 = base + p->off_ad_t0; d.ad_t1 = base + p->off_ad_t1;
+    d.ad_part = base + p->off_ad_part; d.ad_big = base + p->off_ad_big; d.anode_parts = base + p->off_anode_parts;
+    d.n_agroups = p->n_agroups; d.n_aitems = p->n_aitems; d.n_aditems = p->n_aditems; d.amax_parts = p->amax_parts;
     d.Nn = p->Nn; d.Nn_pad = p->Nn_pad; d.n_strips = p->n_strips; d.n_items = p->n_items; d.B = p->B; d.N = p->N;
     d.max_parts = p->max_parts; d.rows = p->rows;
     return d;
@@ -40,7 +44,7 @@ void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
     A.hid1 = ws_ptr<float>(ws, w.hid1); A.temb = ws_ptr<float>(ws, w.temb); A.mods = ws_ptr<float>(ws, w.mods);
     A.condh = ws_ptr<float>(ws, w.condh); A.condh2 = ws_ptr<float>(ws, w.condh2);
     A.dpos = ws_ptr<float>(ws, w.dpos); A.cpos = ws_ptr<float>(ws, w.cpos); A.feat = ws_ptr<float>(ws, w.feat);
-    A.h = ws_ptr<float>(ws, w.h); A.hhat = ws_ptr<float>(ws, w.hhat); A.q = ws_ptr<float>(ws, w.q);
+    A.h = ws_ptr<float>(ws, w.h); A.hhat = ws_ptr<float>(ws, w.hhat); A.astat = ws_ptr<float>(ws, w.astat); A.q = ws_ptr<float>(ws, w.q);
     A.k = ws_ptr<float>(ws, w.k); A.v = ws_ptr<float>(ws, w.v); A.n2e = ws_ptr<float>(ws, w.n2e);
     A.wrow = ws_ptr<float>(ws, w.wrow); A.wcol = ws_ptr<float>(ws, w.wcol); A.ahid = ws_ptr<float>(ws, w.ahid);
     A.stats = ws_ptr<float>(ws, w.stats); A.apred = ws_ptr<float>(ws, w.apred);
@@ -308,13 +312,13 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
             }
         }
         cur ^= 1;                                  // the block's positions are in pos_out now
-        if (p->n_items > 0) {
-            ProfScope ps(p, st, JODO_PROF_EDGE_SCORES);           // exactly one of the two does the work (device flag)
-            if (p->n_sitems > 0) LAUNCH(k_edge_scores_sym, (p->n_sitems + SYM_WAVES - 1) / SYM_WAVES, SYM_WAVES * 64, A);
-            LAUNCH(k_edge_scores, (p->n_items + WG_WAVES - 1) / WG_WAVES, WG_WAVES * 64, A);
+        {
+            // fused attention edge phase (dgt_kernels_attn.h): pair-mode items do the work for symmetric inputs, directed-mode
+            // items for asymmetric inputs and for molecules larger than a group (device flag; the other launch exits at once)
+            ProfScope ps(p, st, JODO_PROF_EDGE_SCORES);
+            if (p->n_aitems > 0) LAUNCH(k_edge_attn<true>, p->n_aitems, ATT_WAVES * 64, A);
+            if (p->n_aditems > 0) LAUNCH(k_edge_attn<false>, p->n_aditems, ATT_WAVES * 64, A);
         }
-        { ProfScope ps(p, st, JODO_PROF_SOFTMAX); LAUNCH(k_softmax, (p->Nn + 15) / 16, 256, A); }
-        if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_MSGS); LAUNCH(k_edge_msgs, (p->n_items + MSG_WAVES - 1) / MSG_WAVES, MSG_WAVES * 64, A); }
         { ProfScope ps(p, st, JODO_PROF_NODE_POST);
           // One wave per strip for every full round of 1024 strips (one per SIMD); the remainder r — which would
           // otherwise occupy r SIMDs for a whole item while the rest idle — goes to a second launch in which a

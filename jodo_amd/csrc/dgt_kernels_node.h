@@ -8,7 +8,7 @@
 // for every full round of 1024 strips and hands the remainder to k_node_postw; with >= 1024 strips it also
 // produces the next block's q / k / v (node_next_*), see the launcher in dgt_forward.hip.
 #pragma once
-#include "dgt_kernels_common.h"
+#include "dgt_kernels_attn.h"
 
 namespace jd {
 
@@ -63,18 +63,12 @@ __global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
     }
 }
 
-// hh = aggregated attention messages: sum of the per-chunk partials, built slice by slice (16 registers
-// of temporaries) so that the prologue does not blow the register budget
-__device__ __forceinline__ void node_load_hh(const KArgs& A, const LaneNode& L, int strip, int half, float (&hh)[128]) {
-    const int parts = A.pd.strip_parts[strip];
-    const float* base = A.hhat + (size_t)L.v * A.pd.max_parts * 256;
-    load_nat<8>(base, half, hh);                              // part 0 always exists
-    for (int q = 1; q < parts; ++q) {                         // 32 independent 16-byte loads per trip
-        float t[128];
-        load_nat<8>(base + (size_t)q * 256, half, t);
-#pragma unroll
-        for (int s = 0; s < 128; ++s) hh[s] += t[s];
-    }
+// hh = aggregated attention messages: flash-style merge of the per-item partials of the fused attention kernel
+// (attn_merge, dgt_kernels_attn.h), fixed order
+__device__ __forceinline__ void node_load_hh(const KArgs& A, const LaneNode& L, int half, float (&hh)[128]) {
+    float M[8], Ls[8];
+    attn_merge(A, L.v, half, 0, 1, hh, M, Ls);
+    attn_normalise(hh, Ls);
 }
 
 // in place: x = LN(h + ng1 * x) * (1 + nc2) + ns2   (x holds hh on entry, the FFN input on exit)
@@ -137,7 +131,7 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
     WPipe<8> wp;
     wpipe_prime(wp, ws, oN2E);
     float hx[128];                                            // first the messages, then (in place) the FFN input
-    node_load_hh(A, L, strip, half, hx);
+    node_load_hh(A, L, half, hx);
     // node2edge_lin applied per node (bias added on the edge side)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -289,41 +283,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_node_postw(KArgs A) {
     WPipe<8> wp;
     wpipe_prime(wp, ws, wave < 2 ? oN2E + (unsigned)wave * 32 * 1024 : oFirstFF);
     float hx[128];
-    {   // aggregated messages: each wave sums every NW-th partial, then the sums are combined through LDS
-        // (a small batch is cut into many short source chunks, i.e. many partials: dgt_plan.cpp)
-        const int parts = A.pd.strip_parts[strip];
-        const float* base = A.hhat + (size_t)L.v * A.pd.max_parts * 256;
-#pragma unroll
-        for (int s = 0; s < 128; ++s) hx[s] = 0.f;
-        for (int q = wave; q < parts; q += NW) {
-            float t[128];
-            load_nat<8>(base + (size_t)q * 256, half, t);
-#pragma unroll
-            for (int s = 0; s < 128; ++s) hx[s] += t[s];
-        }
-        if (parts > 1) {                                      // wave-uniform and workgroup-uniform
-#pragma unroll
-            for (int b = 0; b < 8; ++b)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    part[((wave * 8 + b) * 4 + q) * 64 + lane] = make_float4(hx[b * 16 + q * 4 + 0], hx[b * 16 + q * 4 + 1], hx[b * 16 + q * 4 + 2], hx[b * 16 + q * 4 + 3]);
-            __syncthreads();
-#pragma unroll
-            for (int s = 0; s < 128; ++s) hx[s] = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w)                      // fixed order: bit-deterministic
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 v = part[((w * 8 + b) * 4 + q) * 64 + lane];
-                        hx[b * 16 + q * 4 + 0] += v.x; hx[b * 16 + q * 4 + 1] += v.y; hx[b * 16 + q * 4 + 2] += v.z; hx[b * 16 + q * 4 + 3] += v.w;
-                    }
-            __syncthreads();
-        } else if (wave != 0) {                               // single partial: everybody reads it
-            load_nat<8>(base, half, hx);
-        }
-    }
+    node_load_hh(A, L, half, hx);                             // every wave merges the (few, L2-resident) partials itself
     if (wave < 2) {                                           // node2edge_lin: one block each on waves 0 and 1
         f32x16 acc = mfma_block_p<32>(wp, ws, oN2E + (unsigned)wave * 32 * 1024, oFirstFF, hx, zero16());
         float r[16];

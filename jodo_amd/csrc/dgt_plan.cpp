@@ -196,6 +196,77 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         permute(si_strip, ord); permute(si_t0, ord); permute(si_t1, ord);
     }
 
+    // ---- fused attention kernel: groups of whole molecules (<= 128 lanes), items = (group, range of pair offsets) ----
+    // A pair (i, j) is evaluated once, by lane i; what it contributes to target j is handed to j's lane through LDS,
+    // so both atoms of a pair must sit in the same 4-wave workgroup: a group holds whole molecules only.  Molecules
+    // come in descending size; a group takes them in that order while they fit and then fills its gap with the
+    // largest remaining molecules that still fit (lanes of a smaller molecule idle during the larger offsets, which
+    // is better than idling throughout).  A molecule larger than a group (n > 128, GEOM's tail) gets groups of
+    // consecutive atoms of its own and is walked in directed form (every lane visits all its sources, no hand-over).
+    std::vector<int32_t> ag_node, ai_group, ai_t0, ai_t1, ai_part, ad_group, ad_t0, ad_t1, ad_part, ad_big, anode_parts(p->Nn_pad, 0);
+    int amax_parts = 1;
+    {
+        constexpr int G = 128;
+        int achunk = spair_auto ? 0 : spair_chunk;
+        std::vector<int> mol_n(B), mol_noff(B);
+        for (int m = 0; m < B; ++m) { mol_n[m] = n_nodes[order[m]]; mol_noff[m] = orig_noff[order[m]]; }
+        std::vector<char> used(B, 0);
+        std::vector<int> g_nmax, g_big;
+        int head = 0;
+        while (head < B) {
+            if (used[head]) { ++head; continue; }
+            if (mol_n[head] > G) {                              // spans several groups
+                for (int o = 0; o < mol_n[head]; o += G) {
+                    for (int k = 0; k < G; ++k) ag_node.push_back(o + k < mol_n[head] ? mol_noff[head] + o + k : -1);
+                    g_nmax.push_back(mol_n[head]); g_big.push_back(1);
+                }
+                used[head++] = 1;
+                continue;
+            }
+            int fill = 0, nmax = mol_n[head];
+            std::vector<int32_t> lanes;
+            for (int m = head; m < B && fill < G; ++m) {        // sizes descend: the first unused one that fits is the largest
+                if (used[m] || mol_n[m] > G - fill) continue;
+                for (int k = 0; k < mol_n[m]; ++k) lanes.push_back(mol_noff[m] + k);
+                fill += mol_n[m]; used[m] = 1;
+            }
+            lanes.resize(G, -1);
+            ag_node.insert(ag_node.end(), lanes.begin(), lanes.end());
+            g_nmax.push_back(nmax); g_big.push_back(0);
+        }
+        const int ng = (int)g_nmax.size();
+        p->n_agroups = ng;
+        if (achunk <= 0) {                                      // automatic: coarse items amortise the per-item partial
+            int64_t iters = 0;                                  // (1 KiB per atom), fine items fill 256 CUs evenly
+            for (int g = 0; g < ng; ++g) iters += std::max(1, g_nmax[g] / 2);
+            achunk = 3;
+            while (achunk > 1 && iters / achunk < 2 * 256) --achunk;
+        }
+        struct It { int g, t0, t1, part, big; };
+        std::vector<It> pit, dit;
+        for (int g = 0; g < ng; ++g) {
+            const int nmax = g_nmax[g], dmax = nmax / 2;
+            int parts;
+            if (g_big[g]) parts = std::max(1, (nmax + 2 * achunk - 1) / (2 * achunk));
+            else parts = std::max(1, (dmax + achunk - 1) / achunk);
+            amax_parts = std::max(amax_parts, parts);
+            const int cp = dmax > 0 ? (dmax + parts - 1) / parts : 0, cd = (nmax + parts - 1) / parts;
+            for (int q = 0; q < parts; ++q) {
+                if (!g_big[g]) pit.push_back({g, std::min(dmax, q * cp), std::min(dmax, (q + 1) * cp), q, 0});
+                dit.push_back({g, std::min(nmax, q * cd), std::min(nmax, (q + 1) * cd), q, g_big[g]});
+            }
+            for (int k = 0; k < G; ++k) { const int v = ag_node[(size_t)g * G + k]; if (v >= 0) anode_parts[v] = parts; }
+        }
+        // longest items first (the tail of the launch is then filled with short ones); stable, so neighbours in the
+        // queue stay neighbours in memory
+        auto lpt = [](const It& a, const It& b) { return (a.t1 - a.t0) > (b.t1 - b.t0); };
+        std::stable_sort(pit.begin(), pit.end(), lpt);
+        std::stable_sort(dit.begin(), dit.end(), lpt);
+        for (const It& it : pit) { ai_group.push_back(it.g); ai_t0.push_back(it.t0); ai_t1.push_back(it.t1); ai_part.push_back(it.part); }
+        for (const It& it : dit) { ad_group.push_back(it.g); ad_t0.push_back(it.t0); ad_t1.push_back(it.t1); ad_part.push_back(it.part); ad_big.push_back(it.big); }
+        p->n_aitems = (int)pit.size(); p->n_aditems = (int)dit.size(); p->amax_parts = amax_parts;
+    }
+
     auto put = [&](const std::vector<int32_t>& a, size_t* off) {
         *off = p->desc.size();
         p->desc.insert(p->desc.end(), a.begin(), a.end());
@@ -207,6 +278,9 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     put(it_strip, &p->off_item_strip); put(it_t0, &p->off_item_t0); put(it_t1, &p->off_item_t1); put(it_part, &p->off_item_part); put(strip_parts, &p->off_strip_parts);
     put(pi_strip, &p->off_pitem_strip); put(pi_t0, &p->off_pitem_t0); put(pi_t1, &p->off_pitem_t1);
     put(si_strip, &p->off_sitem_strip); put(si_t0, &p->off_sitem_t0); put(si_t1, &p->off_sitem_t1);
+    put(ag_node, &p->off_ag_node); put(ai_group, &p->off_ai_group); put(ai_t0, &p->off_ai_t0); put(ai_t1, &p->off_ai_t1); put(ai_part, &p->off_ai_part);
+    put(ad_group, &p->off_ad_group); put(ad_t0, &p->off_ad_t0); put(ad_t1, &p->off_ad_t1); put(ad_part, &p->off_ad_part); put(ad_big, &p->off_ad_big);
+    put(anode_parts, &p->off_anode_parts);
 
     // workspace layout
     const DgtDims& d = p->dims;
@@ -217,7 +291,8 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     w.hid1 = take(Bp * d.T * f); w.temb = take(Bp * d.T * f); w.mods = take(Bp * (size_t)d.Mtot * f);
     w.condh = take(Bp * (size_t)std::max(1, d.cond_ch) * d.D * f); w.condh2 = take(Bp * (size_t)std::max(1, d.cond_ch) * d.D * f);
     w.pos0 = take(NP * 4 * f); w.pos1 = take(NP * 4 * f); w.dpos = take(NP * max_parts * 4 * f); w.cpos = take(NP * 4 * f);
-    w.feat = take(NP * d.ndp * f); w.h = take(NP * d.D * f); w.hhat = take(NP * max_parts * d.D * f);
+    w.feat = take(NP * d.ndp * f); w.h = take(NP * d.D * f); w.hhat = take(NP * std::max(max_parts, amax_parts) * d.D * f);
+    w.astat = take(NP * amax_parts * 32 * f);
     w.q = take(NP * d.QKP * f); w.k = take(NP * d.QKP * f); w.v = take(NP * d.D * f); w.n2e = take(NP * d.De * f);
     w.wrow = take(NP * d.D * f); w.wcol = take(NP * d.D * f); w.ahid = take(NP * d.KNH * f); w.stats = take(NP * 32 * f);
     w.apred = take(NP * 32 * f);

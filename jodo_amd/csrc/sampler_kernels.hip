@@ -215,6 +215,123 @@ extern "C" int jodo_step_end(int32_t* step_dev, void* stream) {
     return jodo_check_launch("k_step_end");
 }
 
+// ---- hybrid DPM-Solver++ update (mix_dpm_solver.py:44-59 positions, :61-265 atom / charge / bond channels) ----------
+//   positions   pos_out = cx * pos + cp * pos_pred + sigma * eps          (ancestral; eps: masked, centre-of-mass free)
+//   the rest    out     = a * base - b * P - c * (c2 * (DA - DB))         (data-prediction DPM-Solver++; c = 0: first order)
+// coefficients: {cx, cp, sigma, a, b, c, c2, noise_level} by value, or row (*step) * stride + col of a device table
+// (captured HIP graphs).  Products are rounded one by one in the order of the framework expressions.
+namespace {
+struct DpmCoef { float cx, cp, sigma, a, b, c, c2, nl; };
+
+__device__ __forceinline__ DpmCoef dpm_coef(DpmCoef k, const float* tab, const int* step, int stride, int col) {
+    if (tab) {
+        const float* r = tab + (size_t)(*step) * stride + col;
+        k.cx = r[0]; k.cp = r[1]; k.sigma = r[2]; k.a = r[3]; k.b = r[4]; k.c = r[5]; k.c2 = r[6]; k.nl = r[7];
+    }
+    return k;
+}
+__device__ __forceinline__ float dpm_value(const DpmCoef& k, float base, float p, float da, float db) {
+    float v = __fsub_rn(__fmul_rn(k.a, base), __fmul_rn(k.b, p));
+    if (k.c != 0.f) {
+        float d = __fsub_rn(da, db);
+        if (k.c2 != 1.f) d = __fmul_rn(k.c2, d);
+        v = __fsub_rn(v, __fmul_rn(k.c, d));
+    }
+    return v;
+}
+
+// one workgroup per molecule, node tensor [N, F]
+__global__ __launch_bounds__(256) void k_dpm_nodes(int N, int F, const int* __restrict__ n_nodes, DpmCoef k, const float* __restrict__ tab,
+                                                   const int* __restrict__ step, int stride, int col, const float* __restrict__ x_pos,
+                                                   const float* __restrict__ x_base, const float* __restrict__ P,
+                                                   const float* __restrict__ DA, const float* __restrict__ DB,
+                                                   const float* __restrict__ PP, const float* __restrict__ eps_pos,
+                                                   float* __restrict__ out) {
+    const int b = blockIdx.x, n = n_nodes[b];
+    k = dpm_coef(k, tab, step, stride, col);
+    __shared__ float red[3][256];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (k.sigma != 0.f)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const float* e = eps_pos + ((size_t)b * N + i) * 3;
+            s0 += e[0]; s1 += e[1]; s2 += e[2];
+        }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+            red[2][threadIdx.x] += red[2][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    const float inv = 1.f / (float)n;
+    const float m[3] = {red[0][0] * inv, red[1][0] * inv, red[2][0] * inv};
+    for (int idx = threadIdx.x; idx < N * F; idx += blockDim.x) {
+        const int i = idx / F, f = idx % F;
+        const size_t g = (size_t)b * N * F + idx;
+        float v;
+        if (f < 3) {
+            v = __fadd_rn(__fmul_rn(k.cx, x_pos[g]), __fmul_rn(k.cp, PP[g]));
+            if (k.sigma != 0.f) {                               // last update of a round: no noise (last_step)
+                const float e = i < n ? eps_pos[((size_t)b * N + i) * 3 + f] - m[f] : 0.f;
+                v = __fadd_rn(v, __fmul_rn(k.sigma, e));
+            }
+        } else {
+            v = dpm_value(k, x_base[g], P[g], DA[g], DB[g]);
+        }
+        out[g] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dpm_edges(size_t tot, DpmCoef k, const float* __restrict__ tab, const int* __restrict__ step,
+                                                   int stride, int col, const float* __restrict__ base, const float* __restrict__ P,
+                                                   const float* __restrict__ DA, const float* __restrict__ DB, float* __restrict__ out) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= tot) return;
+    k = dpm_coef(k, tab, step, stride, col);
+    out[g] = dpm_value(k, base[g], P[g], DA[g], DB[g]);
+}
+
+__global__ void k_step_begin_at(int B, const float* __restrict__ tab, const int* __restrict__ step, int stride, int col,
+                                float* __restrict__ noise_level) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) noise_level[b] = tab[(size_t)(*step) * stride + col + 7];
+}
+}  // namespace
+
+extern "C" int jodo_dpm_update(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, const float* coef8_host,
+                               const float* coef_tab_dev, const int32_t* step_dev, int tab_stride, int tab_col, const float* x_pos,
+                               const float* x_base, const float* edge_base, const float* P, const float* eP, const float* DA,
+                               const float* eDA, const float* DB, const float* eDB, const float* PP, const float* eps_pos,
+                               float* x_out, float* edge_out, void* stream) {
+    if (B <= 0 || N <= 0 || node_feats < 4 || edge_ch < 1) return jodo_set_error(JODO_ERR_ARG, "dpm_update: bad shape");
+    if (!n_nodes_dev || !x_pos || !x_base || !edge_base || !P || !eP || !DA || !eDA || !DB || !eDB || !PP || !eps_pos || !x_out || !edge_out)
+        return jodo_set_error(JODO_ERR_ARG, "dpm_update: null argument");
+    if ((coef8_host == nullptr) == (coef_tab_dev == nullptr) || (coef_tab_dev && !step_dev))
+        return jodo_set_error(JODO_ERR_ARG, "dpm_update: pass either host coefficients or a device table + step counter");
+    DpmCoef k{0, 0, 0, 0, 0, 0, 1, 0};
+    if (coef8_host) k = DpmCoef{coef8_host[0], coef8_host[1], coef8_host[2], coef8_host[3], coef8_host[4], coef8_host[5], coef8_host[6], coef8_host[7]};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_dpm_nodes, dim3(B), dim3(256), 0, st, N, node_feats, n_nodes_dev, k, coef_tab_dev, step_dev, tab_stride, tab_col,
+                       x_pos, x_base, P, DA, DB, PP, eps_pos, x_out);
+    int rc = jodo_check_launch("k_dpm_nodes");
+    if (rc != JODO_OK) return rc;
+    const size_t tot = (size_t)B * N * N * edge_ch;
+    hipLaunchKernelGGL(k_dpm_edges, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tot, k, coef_tab_dev, step_dev, tab_stride,
+                       tab_col, edge_base, eP, eDA, eDB, edge_out);
+    return jodo_check_launch("k_dpm_edges");
+}
+
+extern "C" int jodo_step_begin_at(int B, const float* coef_tab_dev, const int32_t* step_dev, int tab_stride, int tab_col,
+                                  float* noise_level_out, void* stream) {
+    if (B <= 0 || !coef_tab_dev || !step_dev || !noise_level_out) return jodo_set_error(JODO_ERR_ARG, "step_begin_at: bad argument");
+    hipLaunchKernelGGL(k_step_begin_at, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, coef_tab_dev, step_dev, tab_stride,
+                       tab_col, noise_level_out);
+    return jodo_check_launch("k_step_begin_at");
+}
+
 extern "C" int jodo_decode(int B, int N, int atom_types, int include_fc, int edge_ch, int compress_edge, int centered,
                            float pos_norm, float atom_norm, float fc_norm, float edge_norm, const int32_t* n_nodes_dev,
                            const float* xh, const float* edge_x, float* pos_out, uint8_t* atom_type_out, int8_t* fc_out,

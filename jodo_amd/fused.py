@@ -94,3 +94,45 @@ def mols_from_decoded(pos, at, fc, et, n_nodes):
         n = int(n)
         mols.append((pos[i, :n], at[i, :n], et[i, :n, :n], fc[i, :n]))
     return mols
+
+
+class _DpmBuffers:
+    """Output buffers of the fused solver updates: a small ring, so that an update never writes a tensor that the
+    solver still holds (state at the start of the outer step, intermediate states, the previous output)."""
+
+    def __init__(self, x, edge_x, depth=4):
+        new = lambda t: torch.empty(t.shape, dtype=torch.float32, device=t.device)
+        self.x = [new(x) for _ in range(depth)]
+        self.e = [new(edge_x) for _ in range(depth)]
+        self.eps = torch.empty(x.shape[0], x.shape[1], 3, dtype=torch.float32, device=x.device)
+        self.cur = 0
+
+
+def dpm_update(solver, coef, x_pos, x_base, edge_base, P, DA, DB, PP, node_mask):
+    """jodo_dpm_update (include/jodo_hip.h): coef = [cx, cp, sigma, a, b, c, c2, 0]; P / DA / DB / PP are
+    (node prediction, edge prediction) pairs.  Draws the position noise (raw N(0,1) [B,N,3], the reference's shape and
+    draw, mix_dpm_solver.py:56) unless sigma == 0 (last update of a round).  Returns (x_out, edge_out)."""
+    B, N, F = x_base.shape
+    ch = edge_base.shape[-1]
+    bufs = getattr(solver, '_dpm_bufs', None)
+    if bufs is None or bufs.x[0].shape != x_base.shape or bufs.x[0].device != x_base.device:
+        bufs = solver._dpm_bufs = _DpmBuffers(x_base, edge_base)
+        solver._dpm_n_nodes = n_nodes_from_mask(node_mask)
+    live = {t.data_ptr() for t in (x_pos, x_base, edge_base, P[0], P[1], DA[0], DA[1], DB[0], DB[1], PP[0])}
+    for _ in range(len(bufs.x)):
+        bufs.cur = (bufs.cur + 1) % len(bufs.x)
+        if bufs.x[bufs.cur].data_ptr() not in live and bufs.e[bufs.cur].data_ptr() not in live:
+            break
+    else:
+        raise RuntimeError("dpm_update: no free output buffer")
+    xo, eo = bufs.x[bufs.cur], bufs.e[bufs.cur]
+    if coef[2] != 0.0:
+        bufs.eps.normal_()
+    c8 = (ctypes.c_float * 8)(*coef)
+    f = lambda t, n: _f32c(t, n)
+    capi.check(capi.lib().jodo_dpm_update(
+        B, N, F, ch, capi.ptr(solver._dpm_n_nodes), c8, None, None, 0, 0, capi.ptr(f(x_pos, 'x_pos')), capi.ptr(f(x_base, 'x_base')),
+        capi.ptr(f(edge_base, 'edge_base')), capi.ptr(f(P[0], 'P')), capi.ptr(f(P[1], 'eP')), capi.ptr(f(DA[0], 'DA')),
+        capi.ptr(f(DA[1], 'eDA')), capi.ptr(f(DB[0], 'DB')), capi.ptr(f(DB[1], 'eDB')), capi.ptr(f(PP[0], 'PP')),
+        capi.ptr(bufs.eps), capi.ptr(xo), capi.ptr(eo), capi.current_stream_ptr()), 'jodo_dpm_update')
+    return xo, eo

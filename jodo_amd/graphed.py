@@ -126,3 +126,101 @@ class GraphedAncestralRound:
         while self.done < self.steps:
             self.replay()
         return self.last
+
+
+class GraphedDPMRound:
+    """HIP-graph replay of the hybrid DPM-solver loop (BASELINE config 5: single-step, order 2, `steps` = NFE): ONE outer
+    step — two score-network evaluations, two position-noise draws, two fused solver updates (jodo_dpm_update), state
+    hand-over — is captured once and replayed for the remaining outer steps.  All per-step scalars sit in a device table
+    [K][16] (two rows of jodo_dpm_update coefficients incl. the evaluation's noise level) indexed by a device step
+    counter.  The first outer step (no self-conditioning input yet) and one warm-up step run eagerly.  Semantics:
+    DPM_Solver_hybrid.sampling, mix_dpm_solver.py:304-376, with singlestep_dpm_solver_second_update :96-149."""
+
+    def __init__(self, solver, model, node_mask, edge_mask, context=None):
+        if solver.method != 'singlestep_fixed' or solver.order != 2:
+            raise NotImplementedError("graph replay covers the single-step second-order solver (BASELINE config 5)")
+        if solver.noise_fn is not None:
+            raise ValueError("noise_fn replay and graph capture are mutually exclusive")
+        self.solver, self.model = solver, model
+        self.node_mask, self.edge_mask, self.context = node_mask, edge_mask, context
+        ns = solver.noise_schedule
+        K = solver.steps // 2
+        outer = solver.get_time_steps('time_uniform', ns.T, 1. / ns.total_N, K, 'cpu')
+        tab = torch.zeros(K, 16, dtype=torch.float32)
+        for k in range(K):
+            ts, te = outer[k], outer[k + 1]
+            inner = solver.get_time_steps('time_uniform', ts.item(), te.item(), 2, 'cpu')
+            lam = ns.marginal_lambda(inner)
+            r1 = (lam[1] - lam[0]) / (lam[-1] - lam[0])
+            c = solver.second_order_coefficients(ts, te, r1)
+            cx1, cp1, sg1 = solver.position_coefficients(ts, c['s1'])
+            cx2, cp2, sg2 = solver.position_coefficients(c['s1'], te)
+            tab[k, 0:8] = torch.tensor([float(cx1), float(cp1), float(sg1), float(c['a1']), float(c['b1']), 0.0, 1.0,
+                                        float(ns.get_noiseLevel(ts))])
+            tab[k, 8:16] = torch.tensor([float(cx2), float(cp2), 0.0 if k == K - 1 else float(sg2), float(c['a2']), float(c['b2']),
+                                         float(c['c2']), 1.0, float(ns.get_noiseLevel(c['s1']))])
+        self.K, self.tab_host, self.graph = K, tab, None
+
+    def _outer_step(self):
+        L = capi.lib()
+        B, N, F = self.x.shape
+        ch = self.e.shape[-1]
+        st = capi.current_stream_ptr()
+        up = lambda col, x_pos, P, DA, DB, PP, xo, eo: capi.check(L.jodo_dpm_update(
+            B, N, F, ch, capi.ptr(self.n_nodes), None, capi.ptr(self.tab), capi.ptr(self.step), 16, col, capi.ptr(x_pos),
+            capi.ptr(self.x), capi.ptr(self.e), capi.ptr(P[0]), capi.ptr(P[1]), capi.ptr(DA[0]), capi.ptr(DA[1]), capi.ptr(DB[0]),
+            capi.ptr(DB[1]), capi.ptr(PP[0]), capi.ptr(self.eps), capi.ptr(xo), capi.ptr(eo), st), 'jodo_dpm_update')
+        capi.check(L.jodo_step_begin_at(B, capi.ptr(self.tab), capi.ptr(self.step), 16, 0, capi.ptr(self.nl), st), 'jodo_step_begin_at')
+        p0 = self.model(self.nl, self.x, self.node_mask, self.edge_mask, edge_x=self.e, noise_level=self.nl, cond_x=self.cx,
+                        cond_edge_x=self.cex, context=self.context)
+        self.cx.copy_(p0[0]); self.cex.copy_(p0[1])            # self-conditioning input of the next evaluation (:296-302)
+        c0 = (self.cx, self.cex)
+        self.eps.normal_()
+        up(0, self.x, c0, c0, c0, c0, self.x1, self.e1)
+        capi.check(L.jodo_step_begin_at(B, capi.ptr(self.tab), capi.ptr(self.step), 16, 8, capi.ptr(self.nl), st), 'jodo_step_begin_at')
+        p1 = self.model(self.nl, self.x1, self.node_mask, self.edge_mask, edge_x=self.e1, noise_level=self.nl, cond_x=self.cx,
+                        cond_edge_x=self.cex, context=self.context)
+        self.eps.normal_()
+        up(8, self.x1, c0, p1, c0, p1, self.x2, self.e2)
+        self.cx.copy_(p1[0]); self.cex.copy_(p1[1])
+        self.x.copy_(self.x2); self.e.copy_(self.e2)
+        capi.check(L.jodo_step_end(capi.ptr(self.step), st), 'jodo_step_end')
+
+    def run(self, x, edge_x):
+        """Returns (x, edge_x) at t_end like DPM_Solver_hybrid.sampling."""
+        sv, dev = self.solver, x.device
+        ns = sv.noise_schedule
+        sv.cond_x = sv.cond_edge_x = None
+        sv._noise_calls = 0
+        model_fn = sv.get_model_fn(self.model)
+        outer = sv.get_time_steps('time_uniform', ns.T, 1. / ns.total_N, self.K, 'cpu')
+        inner = sv.get_time_steps('time_uniform', outer[0].item(), outer[1].item(), 2, 'cpu')
+        lam = ns.marginal_lambda(inner)
+        r1 = (lam[1] - lam[0]) / (lam[-1] - lam[0])
+        x, edge_x = sv.singlestep_dpm_solver_update(model_fn, x, self.node_mask, self.edge_mask, edge_x, self.context, outer[0],
+                                                    outer[1], self.K == 1, order=2, r1=r1)      # outer step 0: eager, cond = None
+        if self.K > 1:
+            new = lambda t: torch.empty(t.shape, dtype=torch.float32, device=dev)
+            self.x, self.e = x.contiguous().clone(), edge_x.contiguous().clone()
+            self.cx, self.cex = sv.cond_x.contiguous().clone(), sv.cond_edge_x.contiguous().clone()
+            self.x1, self.e1, self.x2, self.e2 = new(self.x), new(self.e), new(self.x), new(self.e)
+            self.eps = torch.empty(self.x.shape[0], self.x.shape[1], 3, device=dev)
+            self.nl = torch.empty(self.x.shape[0], device=dev)
+            self.tab = self.tab_host.to(dev)
+            self.step = torch.ones(1, dtype=torch.int32, device=dev)
+            self.n_nodes = fused.n_nodes_from_mask(self.node_mask)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._outer_step()                               # outer step 1: eager warm-up on the static buffers
+            torch.cuda.current_stream().wait_stream(side)
+            if self.K > 2:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self._outer_step()
+                for _ in range(self.K - 2):                # capture records, it does not run: K - 2 outer steps are left
+                    self.graph.replay()
+            x, edge_x = self.x.clone(), self.e.clone()
+        from .models.utils import assert_mean_zero_with_mask
+        assert_mean_zero_with_mask(x[:, :, :3], self.node_mask)
+        return x, edge_x

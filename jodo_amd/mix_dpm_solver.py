@@ -21,7 +21,7 @@ def merge_x(pos, feat):
 
 
 class DPM_Solver_hybrid:
-    def __init__(self, noise_schedule, config, noise_fn=None):
+    def __init__(self, noise_schedule, config, noise_fn=None, fused=True):
         self.noise_schedule = noise_schedule
         self.cond_x = None
         self.cond_edge_x = None
@@ -30,6 +30,7 @@ class DPM_Solver_hybrid:
         self.method = config.sampling.dpm_solver_method
         self.noise_fn = noise_fn          # optional replay hook: noise_fn(call_index, 'pos', like) -> tensor
         self._noise_calls = 0
+        self.fused = fused                # GPU tensors: one fused kernel per tensor and update (jodo_dpm_update)
         assert config.model.pred_data, "Not support in current version."
         assert config.model.self_cond, "Not support in current version."
 
@@ -46,14 +47,19 @@ class DPM_Solver_hybrid:
         return torch.linspace(t_T, t_0, N + 1).to(device)
 
     # -- positions: one ancestral step t_start -> t_end --------------------------------------
-    def ancestral_position_update(self, position_x, position_pred, node_mask, t_start, t_end, last_step=False):
+    def position_coefficients(self, t_start, t_end):
+        """(c_x, c_pred, sigma) of the ancestral position step (:44-59)."""
         ns = self.noise_schedule
         alpha_t, sigma_t = ns.marginal_prob(t_start)
         alpha_s, sigma_s = ns.marginal_prob(t_end)
         a_ts = alpha_t / alpha_s
         var_ts = sigma_t ** 2 - a_ts ** 2 * sigma_s ** 2
         sigma = torch.sqrt(var_ts) * sigma_s / sigma_t
-        position = (a_ts * sigma_s ** 2 / sigma_t ** 2) * position_x + (alpha_s * var_ts / sigma_t ** 2) * position_pred
+        return a_ts * sigma_s ** 2 / sigma_t ** 2, alpha_s * var_ts / sigma_t ** 2, sigma
+
+    def ancestral_position_update(self, position_x, position_pred, node_mask, t_start, t_end, last_step=False):
+        c_x, c_pred, sigma = self.position_coefficients(t_start, t_end)
+        position = c_x * position_x + c_pred * position_pred
         if not last_step:
             if self.noise_fn is not None:
                 eps = self.noise_fn(self._noise_calls, 'pos', position_x)
@@ -62,6 +68,34 @@ class DPM_Solver_hybrid:
             self._noise_calls += 1
             position = position + sigma * eps
         return position
+
+    def _update(self, x_pos, x_base, edge_base, P, DA, DB, PP, node_mask, t_from, t_to, last_step, a, b, c=None, c2=None):
+        """One solver update of the whole state:
+            positions   ancestral step t_from -> t_to driven by the position channels of PP           (:44-59)
+            the rest    a * base - b * P - c * (c2 * (DA - DB))     (node feature channels and the edge tensor)
+        P / DA / DB / PP are (node prediction, edge prediction) pairs.  On GPU tensors (and when no noise is being
+        replayed) this is ONE fused kernel per tensor (jodo_dpm_update, csrc/sampler_kernels.hip) instead of ~25
+        framework launches; the op order of the products is the same in both paths."""
+        if self.fused and x_base.is_cuda and self.noise_fn is None:
+            from . import fused
+            c_x, c_pred, sigma = self.position_coefficients(t_from, t_to)
+            coef = [float(c_x), float(c_pred), 0.0 if last_step else float(sigma), float(a), float(b),
+                    0.0 if c is None else float(c), 1.0 if c2 is None else float(c2), 0.0]
+            if not last_step:
+                self._noise_calls += 1
+            return fused.dpm_update(self, coef, x_pos, x_base, edge_base, P, DA, DB, PP, node_mask)
+        pos_base, atom_base = split_x(x_base)
+        _, atom_p = split_x(P[0])
+        atom = a * atom_base - b * atom_p
+        edge = a * edge_base - b * P[1]
+        if c is not None:
+            d_atom, d_edge = split_x(DA[0])[1] - split_x(DB[0])[1], DA[1] - DB[1]
+            if c2 is not None:
+                d_atom, d_edge = c2 * d_atom, c2 * d_edge
+            atom = atom - c * d_atom
+            edge = edge - c * d_edge
+        pos = self.ancestral_position_update(split_x(x_pos)[0], split_x(PP[0])[0], node_mask, t_from, t_to, last_step)
+        return merge_x(pos, atom), edge
 
     def _predict(self, model_fn, x, node_mask, edge_mask, edge_x, context, t):
         bs = x.size(0)
@@ -77,19 +111,14 @@ class DPM_Solver_hybrid:
         sigma_start, sigma_end = ns.marginal_std(t_start), ns.marginal_std(t_end)
         alpha_end = torch.exp(ns.marginal_log_mean_coeff(t_end))
         phi_1 = torch.expm1(-h)
-        pos0, atom0 = split_x(x)
         if pred_start is None and edge_pred_start is None:
             pred_start, edge_pred_start = self._predict(model_fn, x, node_mask, edge_mask, edge_x, context, t_start)
-        pos_pred0, atom_pred0 = split_x(pred_start)
-        atom_end = sigma_end / sigma_start * atom0 - alpha_end * phi_1 * atom_pred0
-        edge_end = sigma_end / sigma_start * edge_x - alpha_end * phi_1 * edge_pred_start
-        pos_end = self.ancestral_position_update(pos0, pos_pred0, node_mask, t_start, t_end, last_step)
-        return merge_x(pos_end, atom_end), edge_end
+        p0 = (pred_start, edge_pred_start)
+        return self._update(x, x, edge_x, p0, p0, p0, p0, node_mask, t_start, t_end, last_step,
+                            sigma_end / sigma_start, alpha_end * phi_1)
 
     # -- order 2, single step ------------------------------------------------------------------
-    def singlestep_dpm_solver_second_update(self, model_fn, x, node_mask, edge_mask, edge_x, context,
-                                            t_start, t_end, last_step, r1=0.5):
-        r1 = 0.5 if r1 is None else r1
+    def second_order_coefficients(self, t_start, t_end, r1):
         ns = self.noise_schedule
         lam0, lam1 = ns.marginal_lambda(t_start), ns.marginal_lambda(t_end)
         h = lam1 - lam0
@@ -99,23 +128,18 @@ class DPM_Solver_hybrid:
         alpha_end = torch.exp(ns.marginal_log_mean_coeff(t_end))
         phi_11 = torch.expm1(-r1 * h)
         phi_1 = torch.expm1(-h)
-        pos0, atom0 = split_x(x)
+        return dict(s1=s1, a1=sigma_s1 / sigma_start, b1=alpha_s1 * phi_11, a2=sigma_end / sigma_start, b2=alpha_end * phi_1,
+                    c2=(0.5 / r1) * (alpha_end * phi_1))
 
-        pred0, edge_pred0 = self._predict(model_fn, x, node_mask, edge_mask, edge_x, context, t_start)
-        pos_pred0, atom_pred0 = split_x(pred0)
-        atom_s1 = (sigma_s1 / sigma_start) * atom0 - (alpha_s1 * phi_11) * atom_pred0
-        edge_s1 = (sigma_s1 / sigma_start) * edge_x - (alpha_s1 * phi_11) * edge_pred0
-        pos_s1 = self.ancestral_position_update(pos0, pos_pred0, node_mask, t_start, s1)
-        x_s1 = merge_x(pos_s1, atom_s1)
-
-        pred1, edge_pred1 = self._predict(model_fn, x_s1, node_mask, edge_mask, edge_s1, context, s1)
-        pos_pred1, atom_pred1 = split_x(pred1)
-        atom_end = ((sigma_end / sigma_start) * atom0 - (alpha_end * phi_1) * atom_pred0
-                    - (0.5 / r1) * (alpha_end * phi_1) * (atom_pred1 - atom_pred0))
-        edge_end = ((sigma_end / sigma_start) * edge_x - (alpha_end * phi_1) * edge_pred0
-                    - (0.5 / r1) * (alpha_end * phi_1) * (edge_pred1 - edge_pred0))
-        pos_end = self.ancestral_position_update(pos_s1, pos_pred1, node_mask, s1, t_end, last_step)
-        return merge_x(pos_end, atom_end), edge_end
+    def singlestep_dpm_solver_second_update(self, model_fn, x, node_mask, edge_mask, edge_x, context,
+                                            t_start, t_end, last_step, r1=0.5):
+        r1 = 0.5 if r1 is None else r1
+        k = self.second_order_coefficients(t_start, t_end, r1)
+        s1 = k['s1']
+        p0 = self._predict(model_fn, x, node_mask, edge_mask, edge_x, context, t_start)
+        x_s1, edge_s1 = self._update(x, x, edge_x, p0, p0, p0, p0, node_mask, t_start, s1, False, k['a1'], k['b1'])
+        p1 = self._predict(model_fn, x_s1, node_mask, edge_mask, edge_s1, context, s1)
+        return self._update(x_s1, x, edge_x, p0, p1, p0, p1, node_mask, s1, t_end, last_step, k['a2'], k['b2'], k['c2'])
 
     # -- order 3, single step ------------------------------------------------------------------
     def singlestep_dpm_solver_third_update(self, model_fn, x, node_mask, edge_mask, edge_x, context,
@@ -137,41 +161,22 @@ class DPM_Solver_hybrid:
         phi_1 = torch.expm1(-h)
         phi_22 = torch.expm1(-r2 * h) / (r2 * h) + 1.
         phi_2 = phi_1 / h + 1.
-        pos0, atom0 = split_x(x)
-
-        pred0, edge_pred0 = self._predict(model_fn, x, node_mask, edge_mask, edge_x, context, t_start)
-        pos_pred0, atom_pred0 = split_x(pred0)
-        atom_s1 = (sigma_s1 / sigma_start) * atom0 - (alpha_s1 * phi_11) * atom_pred0
-        edge_s1 = (sigma_s1 / sigma_start) * edge_x - (alpha_s1 * phi_11) * edge_pred0
-        pos_s1 = self.ancestral_position_update(pos0, pos_pred0, node_mask, t_start, s1)
-        x_s1 = merge_x(pos_s1, atom_s1)
-
-        pred1, edge_pred1 = self._predict(model_fn, x_s1, node_mask, edge_mask, edge_s1, context, s1)
-        pos_pred1, atom_pred1 = split_x(pred1)
-        atom_s2 = ((sigma_s2 / sigma_start) * atom0 - (alpha_s2 * phi_12) * atom_pred0
-                   + r2 / r1 * (alpha_s2 * phi_22) * (atom_pred1 - atom_pred0))
-        edge_s2 = ((sigma_s2 / sigma_start) * edge_x - (alpha_s2 * phi_12) * edge_pred0
-                   + r2 / r1 * (alpha_s2 * phi_22) * (edge_pred1 - edge_pred0))
-        pos_s2 = self.ancestral_position_update(pos_s1, pos_pred1, node_mask, s1, s2)
-        x_s2 = merge_x(pos_s2, atom_s2)
-
-        pred2, edge_pred2 = self._predict(model_fn, x_s2, node_mask, edge_mask, edge_s2, context, s2)
-        pos_pred2, atom_pred2 = split_x(pred2)
-        atom_end = ((sigma_end / sigma_start) * atom0 - (alpha_end * phi_1) * atom_pred0
-                    + (1. / r2) * (alpha_end * phi_2) * (atom_pred2 - atom_pred0))
-        edge_end = ((sigma_end / sigma_start) * edge_x - (alpha_end * phi_1) * edge_pred0
-                    + (1. / r2) * (alpha_end * phi_2) * (edge_pred2 - edge_pred0))
-        pos_end = self.ancestral_position_update(pos_s2, pos_pred2, node_mask, s2, t_end, last_step)
-        return merge_x(pos_end, atom_end), edge_end
+        p0 = self._predict(model_fn, x, node_mask, edge_mask, edge_x, context, t_start)
+        x_s1, edge_s1 = self._update(x, x, edge_x, p0, p0, p0, p0, node_mask, t_start, s1, False,
+                                     sigma_s1 / sigma_start, alpha_s1 * phi_11)
+        p1 = self._predict(model_fn, x_s1, node_mask, edge_mask, edge_s1, context, s1)
+        # the reference ADDS the difference terms here (:199-202, :216-219): c is the negated coefficient
+        x_s2, edge_s2 = self._update(x_s1, x, edge_x, p0, p1, p0, p1, node_mask, s1, s2, False,
+                                     sigma_s2 / sigma_start, alpha_s2 * phi_12, -(r2 / r1 * (alpha_s2 * phi_22)))
+        p2 = self._predict(model_fn, x_s2, node_mask, edge_mask, edge_s2, context, s2)
+        return self._update(x_s2, x, edge_x, p0, p2, p0, p2, node_mask, s2, t_end, last_step,
+                            sigma_end / sigma_start, alpha_end * phi_1, -((1. / r2) * (alpha_end * phi_2)))
 
     # -- order 2, multistep --------------------------------------------------------------------
     def multistep_dpm_solver_second_update(self, model_fn, x, node_mask, edge_mask, edge_x, context,
                                            model_prev_list, t_prev_list, t, last_step):
         ns = self.noise_schedule
-        (pred_m1, edge_pred_m1), (pred_m0, edge_pred_m0) = model_prev_list[-2], model_prev_list[-1]
-        _, atom_pred_m1 = split_x(pred_m1)
-        pos_pred_m0, atom_pred_m0 = split_x(pred_m0)
-        pos_m0, atom_m0 = split_x(x)
+        p_m1, p_m0 = model_prev_list[-2], model_prev_list[-1]
         t_m1, t_m0 = t_prev_list[-2], t_prev_list[-1]
         lam_m1, lam_m0, lam_t = ns.marginal_lambda(t_m1), ns.marginal_lambda(t_m0), ns.marginal_lambda(t)
         sigma_m0, sigma_t = ns.marginal_std(t_m0), ns.marginal_std(t)
@@ -180,12 +185,8 @@ class DPM_Solver_hybrid:
         h = lam_t - lam_m0
         r0 = h_0 / h
         phi_1 = torch.expm1(-h)
-        d_atom = (1. / r0) * (atom_pred_m0 - atom_pred_m1)
-        d_edge = (1. / r0) * (edge_pred_m0 - edge_pred_m1)
-        atom_t = (sigma_t / sigma_m0) * atom_m0 - (alpha_t * phi_1) * atom_pred_m0 - 0.5 * (alpha_t * phi_1) * d_atom
-        edge_t = (sigma_t / sigma_m0) * edge_x - (alpha_t * phi_1) * edge_pred_m0 - 0.5 * (alpha_t * phi_1) * d_edge
-        pos_t = self.ancestral_position_update(pos_m0, pos_pred_m0, node_mask, t_prev_list[-1], t, last_step)
-        return merge_x(pos_t, atom_t), edge_t
+        return self._update(x, x, edge_x, p_m0, p_m0, p_m1, p_m0, node_mask, t_prev_list[-1], t, last_step,
+                            sigma_t / sigma_m0, alpha_t * phi_1, 0.5 * (alpha_t * phi_1), 1. / r0)
 
     def singlestep_dpm_solver_update(self, model_fn, x, node_mask, edge_mask, edge_x, context, t_start, t_end,
                                      last_step, order, r1=None, r2=None):
@@ -271,4 +272,6 @@ class DPM_Solver_hybrid:
             raise ValueError("Get wrong method {}".format(self.method))
 
         assert_mean_zero_with_mask(x[:, :, :3], node_mask)
+        if self.fused and x.is_cuda and self.noise_fn is None:
+            x, edge_x = x.clone(), edge_x.clone()        # the fused updates write into buffers the solver reuses
         return x, edge_x

@@ -193,6 +193,10 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
                 # one captured HIP graph per round, replayed for every step (jodo_amd/graphed.py)
                 from .graphed import GraphedAncestralRound
                 x_node, x_edge = GraphedAncestralRound(sampler, model, node_mask, edge_mask, context).run(z, edge_z)
+            elif (hip_graph and noise is None and z.is_cuda and isinstance(sampler, DPM_Solver_hybrid)
+                  and sampler.method == 'singlestep_fixed' and sampler.order == 2):
+                from .graphed import GraphedDPMRound
+                x_node, x_edge = GraphedDPMRound(sampler, model, node_mask, edge_mask, context).run(z, edge_z)
             else:
                 x_node, x_edge = sampler.sampling(model, z, node_mask, edge_mask, edge_z, context)
         finally:

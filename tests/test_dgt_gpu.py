@@ -455,6 +455,80 @@ def test_fused_sampler_step_equals_framework_step(cfg_name, n_nodes):
     assert float((xa * (1 - nm)).abs().max()) == 0.0                             # padding stays exactly zero
 
 
+@pytest.mark.parametrize("method,order,nfe", [('singlestep_fixed', 2, 6), ('singlestep_fixed', 3, 6), ('singlestep_fixed', 1, 3),
+                                              ('multistep', 2, 5)])
+def test_fused_dpm_update_equals_framework_update(method, order, nfe):
+    """Hybrid DPM-solver: the fused update kernel (jodo_dpm_update) against the op-by-op framework update on the same
+    seed (same position-noise draws), for every solver variant of mix_dpm_solver.py:61-265."""
+    from jodo_amd.diffusion import NoiseScheduleVP
+    from jodo_amd.mix_dpm_solver import DPM_Solver_hybrid
+    from jodo_amd.models.utils import sample_combined_position_feature_noise, sample_symmetric_edge_feature_noise
+    cfg = make_config('vpsde_qm9_uncond_jodo')
+    cfg.sampling.steps, cfg.sampling.method = nfe, 'fast'
+    cfg.sampling['dpm_solver_method'], cfg.sampling['dpm_solver_order'] = method, order
+    hp = O.Hyper.from_config(cfg)
+    n_nodes = [9, 1, 29, 17, 2]
+    nm, em = masks(n_nodes, DEV)
+    B, N = len(n_nodes), max(n_nodes)
+    ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
+
+    class Fake(torch.nn.Module):                       # deterministic stand-in for the score network
+        def forward(self, t, x, node_mask, edge_mask, edge_x=None, noise_level=None, cond_x=None, cond_edge_x=None, context=None):
+            e = torch.tanh(edge_x * 0.7 + 0.1 * noise_level.reshape(-1, 1, 1, 1))
+            out = torch.tanh(x * 0.5 + 0.2) * node_mask
+            if cond_x is not None:
+                out = out + 0.1 * cond_x
+            pos = out[:, :, :3] - out[:, :, :3].sum(1, keepdim=True) / node_mask.sum(1, keepdim=True) * node_mask
+            return torch.cat([pos, out[:, :, 3:]], 2), (e + e.transpose(1, 2)) * edge_mask.reshape(edge_x.shape[0], edge_x.shape[1], edge_x.shape[2], 1)
+
+    outs = []
+    for fused_on in (False, True):
+        torch.manual_seed(321)
+        z = sample_combined_position_feature_noise(B, N, hp.in_node_dim, nm)
+        ez = sample_symmetric_edge_feature_noise(B, N, hp.edge_ch, em)
+        solver = DPM_Solver_hybrid(ns, cfg, fused=fused_on)
+        outs.append(solver.sampling(Fake(), z, nm, em, ez, None))
+        assert solver._noise_calls == solver.noise_draws_per_round()
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() < 2e-6
+    assert float((outs[1][0] * (1 - nm)).abs().max()) == 0.0                     # padding stays exactly zero
+
+
+def test_graph_replayed_dpm_round_equals_eager_solver():
+    """BASELINE config 5 path (conditional model, single-step order 2): the captured outer step replayed K - 2 times
+    against the eager solver.  Position noise is switched off on both sides (sigma columns of the table zeroed / a
+    zero noise_fn), which makes the two runs comparable sample for sample."""
+    from jodo_amd.diffusion import NoiseScheduleVP
+    from jodo_amd.graphed import GraphedDPMRound
+    from jodo_amd.mix_dpm_solver import DPM_Solver_hybrid
+    from jodo_amd.models.utils import sample_combined_position_feature_noise, sample_symmetric_edge_feature_noise
+    cfg = make_config('vpsde_qm9_cond_jodo')
+    cfg.sampling.steps, cfg.sampling.method = 10, 'fast'
+    cfg.sampling['dpm_solver_method'], cfg.sampling['dpm_solver_order'] = 'singlestep_fixed', 2
+    hp = O.Hyper.from_config(cfg)
+    n_nodes = [9, 1, 27, 17, 2, 12]
+    nm, em = masks(n_nodes, DEV)
+    B, N = len(n_nodes), max(n_nodes)
+    model = make_model(cfg, 4, DEV, head_gain=10.0)
+    ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
+    torch.manual_seed(5)
+    z = sample_combined_position_feature_noise(B, N, hp.in_node_dim, nm)
+    ez = sample_symmetric_edge_feature_noise(B, N, hp.edge_ch, em)
+    ctx = torch.randn(B, 1, device=DEV)
+    eager = DPM_Solver_hybrid(ns, cfg, noise_fn=lambda i, kind, like: torch.zeros_like(like))
+    want = eager.sampling(model, z, nm, em, ez, ctx)
+    rnd = GraphedDPMRound(DPM_Solver_hybrid(ns, cfg), model, nm, em, ctx)
+    rnd.tab_host[:, 2] = 0.0
+    rnd.tab_host[:, 10] = 0.0
+    rnd.solver.position_coefficients = (lambda f: (lambda a, b: f(a, b)[:2] + (torch.zeros(()),)))(rnd.solver.position_coefficients)
+    with torch.no_grad():
+        got = rnd.run(z, ez)
+    torch.cuda.synchronize()
+    assert rnd.K == 5 and int(rnd.step.item()) == 5                # outer steps 0 (eager), 1 (warm-up), 2-4 (replays)
+    close(got[0], want[0], atol=2e-4, rtol=0)
+    close(got[1], want[1], atol=2e-4, rtol=0)
+
+
 @pytest.mark.parametrize("cfg_name", ['vpsde_qm9_uncond_jodo', 'vpsde_geom_uncond_jodo'])
 def test_fused_decode_equals_post_process(cfg_name):
     from jodo_amd import fused
