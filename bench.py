@@ -292,13 +292,17 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
+    # HIP-event timings of exactly the timed region above
+    ms = (ctypes.c_float * 8)()
+    cnt = (ctypes.c_int32 * 8)()
+    capi.check(L.jodo_profile_read(plan['handle'], ms, cnt), 'profile_read')
+    capi.check(L.jodo_profile_enable(plan['handle'], 0), 'profile_enable')
     graph_info = None
     if not args.graph and world == 1:
         # extra, reported beside the headline: the same step replayed as ONE captured HIP graph (no per-step
         # Python / launch overhead).  The headline stays the eager loop, whose kernels carry the HIP-event brackets
         # the roofline leg needs.
         from jodo_amd.graphed import GraphedAncestralRound
-        capi.check(L.jodo_profile_enable(plan['handle'], 0), 'profile_enable')
         try:
             with torch.no_grad():
                 rnd = GraphedAncestralRound(sampler, model, node_mask, edge_mask, context)
@@ -314,7 +318,6 @@ def main():
             graph_info = {'ms_per_step': tg * 1e3, 'value': B / (SAMPLING_STEPS * tg), 'unit': 'molecules/s'}
         except Exception as exc:                      # the extra must never take the headline down with it
             graph_info = {'error': repr(exc)}
-        capi.check(L.jodo_profile_enable(plan['handle'], 1 if args.breakdown else 2), 'profile_enable')
     # ---- >= 100 steady-state steps when the timed region above was shorter -----------------------
     steady = None
     if not args.graph and world == 1 and args.steps < 100:
@@ -327,10 +330,6 @@ def main():
             steady = {'steps': 100, 'ms_per_step': (time.perf_counter() - ts0) * 10.0}
         steady['value'] = B / (SAMPLING_STEPS * steady['ms_per_step'] * 1e-3)
         steady['unit'] = 'molecules/s'
-    ms = (ctypes.c_float * 8)()
-    cnt = (ctypes.c_int32 * 8)()
-    capi.check(L.jodo_profile_read(plan['handle'], ms, cnt), 'profile_read')
-    capi.check(L.jodo_profile_enable(plan['handle'], 0), 'profile_enable')
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

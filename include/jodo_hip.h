@@ -167,7 +167,7 @@ int jodo_debug_set_timing_buffer(jodo_plan* plan, void* dev16xu64);
  * dominant class JODO_PROF_EDGE_UPDATE (what the roofline leg needs; ~0.1 ms); jodo_profile_read synchronises those events and returns, per class, the summed
  * milliseconds and launch counts since the last read (arrays of JODO_PROF_COUNT), then resets. */
 enum jodo_prof_class {
-    JODO_PROF_PROLOGUE = 0, JODO_PROF_NODE_PRE, JODO_PROF_EDGE_SCORES, JODO_PROF_SOFTMAX, JODO_PROF_EDGE_MSGS,
+    JODO_PROF_PROLOGUE = 0, JODO_PROF_NODE_PRE, JODO_PROF_EDGE_ATTN, JODO_PROF_RESERVED3, JODO_PROF_RESERVED4,
     JODO_PROF_NODE_POST, JODO_PROF_EDGE_UPDATE, JODO_PROF_EPILOGUE, JODO_PROF_COUNT
 };
 int jodo_profile_enable(jodo_plan* plan, int enable);

@@ -293,25 +293,4 @@ __device__ __forceinline__ void modulate(float (&x)[NB * 16], const float* __res
     }
 }
 
-// ---- Gaussian basis of a squared distance (CondGaussianLayer) ---------------------------------------
-// tab: [3][64] = mu, 1/sigma, 1/(sqrt(2*3.14159)*sigma); entry 0 of each row unused (feature 0 = x').
-// Half h produces features b*32 + h*16 + s, b = 0,1.
-__device__ __forceinline__ void gbf64(float d2, float scale, float shift, const float* __restrict__ tab,
-                                      int half, float (&g)[32]) {
-    const float x = fmaf(d2, scale + 1.f, shift);
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        float mu[16], is[16], cf[16];
-        load16(tab + b * 32 + half * 16, mu);
-        load16(tab + 64 + b * 32 + half * 16, is);
-        load16(tab + 128 + b * 32 + half * 16, cf);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float z = (x - mu[s]) * is[s];
-            g[b * 16 + s] = fast_exp(-0.5f * z * z) * cf[s];
-        }
-    }
-    if (half == 0) g[0] = x;
-}
-
 }  // namespace jd

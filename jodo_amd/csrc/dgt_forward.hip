@@ -3,8 +3,6 @@
 // synchronisation, no allocation.
 #include "dgt_kernels_pre.h"
 #include "dgt_kernels_node.h"
-#include "dgt_kernels_block.h"
-#include "dgt_kernels_sym.h"
 #include "dgt_kernels_post.h"
 #include "dgt_kernels_wide.h"
 #include "jodo_hip_internal.h"
@@ -25,8 +23,6 @@ PlanDev make_plan_dev(const jodo_plan* p, const void* desc_dev) {
     d.item_part = base + p->off_item_part; d.strip_parts = base + p->off_strip_parts;
     d.pitem_strip = base + p->off_pitem_strip; d.pitem_t0 = base + p->off_pitem_t0; d.pitem_t1 = base + p->off_pitem_t1;
     d.n_pitems = p->n_pitems;
-    d.sitem_strip = base + p->off_sitem_strip; d.sitem_t0 = base + p->off_sitem_t0; d.sitem_t1 = base + p->off_sitem_t1;
-    d.n_sitems = p->n_sitems;
     d.ag_node = base + p->off_ag_node; d.ai_group = base + p->off_ai_group; d.ai_t0 = base + p->off_ai_t0; d.ai_t1 = base + p->off_ai_t1;
     d.ai_part = base + p->off_ai_part; d.ad_group = base + p->off_ad_group; d.ad_t0 = base + p->off_ad_t0; d.ad_t1 = base + p->off_ad_t1;
     d.ad_part = base + p->off_ad_part; d.ad_big = base + p->off_ad_big; d.anode_parts = base + p->off_anode_parts;
@@ -47,9 +43,9 @@ void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
     A.h = ws_ptr<float>(ws, w.h); A.hhat = ws_ptr<float>(ws, w.hhat); A.astat = ws_ptr<float>(ws, w.astat); A.q = ws_ptr<float>(ws, w.q);
     A.k = ws_ptr<float>(ws, w.k); A.v = ws_ptr<float>(ws, w.v); A.n2e = ws_ptr<float>(ws, w.n2e);
     A.wrow = ws_ptr<float>(ws, w.wrow); A.wcol = ws_ptr<float>(ws, w.wcol); A.ahid = ws_ptr<float>(ws, w.ahid);
-    A.stats = ws_ptr<float>(ws, w.stats); A.apred = ws_ptr<float>(ws, w.apred);
-    A.eflag = ws_ptr<int>(ws, w.eflag); A.e = ws_ptr<float>(ws, w.e); A.et = ws_ptr<float>(ws, w.et);
-    A.S = ws_ptr<float>(ws, w.S); A.ehid = ws_ptr<float>(ws, w.ehid); A.epred = ws_ptr<float>(ws, w.epred);
+    A.apred = ws_ptr<float>(ws, w.apred);
+    A.eflag = ws_ptr<int>(ws, w.eflag); A.e = ws_ptr<float>(ws, w.e);
+    A.ehid = ws_ptr<float>(ws, w.ehid); A.epred = ws_ptr<float>(ws, w.epred);
     A.e_out = ws_ptr<float>(ws, w.e2);
     A.dposE = ws_ptr<float>(ws, w.dposE);
 }
@@ -90,18 +86,6 @@ struct ProfScope {
         if (rc_ != JODO_OK) return rc_;                                 \
     } while (0)
 
-template <int KQ>
-int launch_embed_nodes(hipStream_t st, const KArgs& A) {
-    LAUNCH(k_embed_nodes<KQ>, A.pd.n_strips, 64, A);
-    return JODO_OK;
-}
-
-template <int NBK>
-int launch_edge_head(hipStream_t st, const KArgs& A) {
-    LAUNCH(k_edge_head<NBK>, (unsigned)((A.pd.rows + 31) / 32), 64, A);
-    return JODO_OK;
-}
-
 // Pair update: every full round of 1024 one-iteration items (one per SIMD) in one launch; the items of the last,
 // sparsely filled round in a second launch with two workgroups per item, one direction each (both recompute the
 // shared trunk: item time x 0.64).  At QM9 B = 2500 a launch has 13 400 items = 13 full rounds + 88.
@@ -121,57 +105,121 @@ int launch_update_sym(jodo_plan* p, hipStream_t st, KArgs& A) {
     return JODO_OK;
 }
 
-// ---- width-generic kernel set (dgt_kernels_wide.h): everything after the time/modulation prologue ----
 template <int D, int KQ>
-int launch_embed_nodes_w(hipStream_t st, const KArgs& A) {
+int launch_embed_nodes(hipStream_t st, const KArgs& A) {
     LAUNCH((wide::k_embed_nodes<D, KQ>), A.pd.n_strips, 64, A);
     return JODO_OK;
 }
 template <int D, int NBK>
-int launch_edge_head_w(hipStream_t st, const KArgs& A) {
+int launch_edge_head(hipStream_t st, const KArgs& A) {
     LAUNCH((wide::k_edge_head<D, NBK>), (unsigned)((A.pd.rows + 31) / 32), 64, A);
     return JODO_OK;
 }
 
-template <int D>
-int forward_wide(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, float* const posbuf[2], std::unique_ptr<ProfScope>& pro) {
+// nf = 256 node kernels (dgt_kernels_node.h): k_node_post with one wave per strip for every full round of 1024 strips (one
+// per SIMD); the remainder r — which would otherwise occupy r SIMDs for a whole item while the rest idle — goes to a second
+// launch in which a workgroup of 4 (r <= 256) or 2 (r <= 512) waves shares each strip.  Measured on MI355X: 177 strips
+// 1.7 -> 0.75 ms/step with 4 waves; all 1409 strips with 2 / 4 waves 3.7 / 4.1 vs 3.6 ms/step with 1.
+int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A) {
+    const DgtDims& d = p->dims;
+    const int force = p->opt[JODO_OPT_NODE_POST_WAVES];                      // 0 = automatic
+    const int full = force ? (force == 1 ? p->n_strips : 0) : (p->n_strips / 1024) * 1024;
+    const int rem = p->n_strips - full;
+    const int nw = force ? force : (rem <= 256 ? 4 : (rem <= 512 ? 2 : 1));
+    if (full > 0) {
+        A.strip0 = 0;
+        if (d.r == 2) LAUNCH(k_node_post<2>, full, 64, A); else LAUNCH(k_node_post<4>, full, 64, A);
+    }
+    if (rem > 0) {
+        A.strip0 = full;
+        if (nw == 1) { if (d.r == 2) LAUNCH(k_node_post<2>, rem, 64, A); else LAUNCH(k_node_post<4>, rem, 64, A); }
+        else if (nw == 2) { if (d.r == 2) LAUNCH((k_node_postw<2, 2>), rem, 128, A); else LAUNCH((k_node_postw<4, 2>), rem, 128, A); }
+        else { if (d.r == 2) LAUNCH((k_node_postw<2, 4>), rem, 256, A); else LAUNCH((k_node_postw<4, 4>), rem, 256, A); }
+    }
+    A.strip0 = 0;
+    return JODO_OK;
+}
+
+// Everything after the time / modulation prologue.  One kernel set for every width (dgt_kernels_wide.h, dgt_kernels_attn.h);
+// TUNED (nf = 256 with the 8-block q / k arrangement) swaps in the nf = 256 node kernels of dgt_kernels_node.h and the
+// LDS-resident-weight variant of the attention kernel.
+template <int D, bool TUNED>
+int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, float* const posbuf[2], std::unique_ptr<ProfScope>& pro) {
     const DgtDims& d = p->dims;
     int rc = JODO_OK;
+    // ---- pack inputs, embeddings ----
     LAUNCH(k_pack_nodes, (p->Nn_pad + 255) / 256, 256, A);
     switch (d.ndp / 8) {
-        case 1: rc = launch_embed_nodes_w<D, 1>(st, A); break;
-        case 2: rc = launch_embed_nodes_w<D, 2>(st, A); break;
-        case 3: rc = launch_embed_nodes_w<D, 3>(st, A); break;
-        case 4: rc = launch_embed_nodes_w<D, 4>(st, A); break;
-        case 5: rc = launch_embed_nodes_w<D, 5>(st, A); break;
-        case 6: rc = launch_embed_nodes_w<D, 6>(st, A); break;
-        case 7: rc = launch_embed_nodes_w<D, 7>(st, A); break;
-        case 8: rc = launch_embed_nodes_w<D, 8>(st, A); break;
+        case 1: rc = launch_embed_nodes<D, 1>(st, A); break;
+        case 2: rc = launch_embed_nodes<D, 2>(st, A); break;
+        case 3: rc = launch_embed_nodes<D, 3>(st, A); break;
+        case 4: rc = launch_embed_nodes<D, 4>(st, A); break;
+        case 5: rc = launch_embed_nodes<D, 5>(st, A); break;
+        case 6: rc = launch_embed_nodes<D, 6>(st, A); break;
+        case 7: rc = launch_embed_nodes<D, 7>(st, A); break;
+        case 8: rc = launch_embed_nodes<D, 8>(st, A); break;
         default: return jodo_set_error(JODO_ERR_UNSUPPORTED, "node input width %d", d.ndp);
     }
     if (rc) return rc;
     if (p->n_items > 0) LAUNCH((wide::k_embed_edges<D>), p->n_items, 64, A);
     pro.reset();
+    // ---- DGT blocks ----
     const int nblocks = (p->max_blocks >= 0 && p->max_blocks < d.L) ? p->max_blocks : d.L;
-    int cur = 0;
+    // With at least one strip per SIMD, k_node_post of block l also produces block l + 1's q / k / v (it holds h' in
+    // registers): drops a launch with its own latency-bound prologue and partial last round (QM9 B = 2500, 1409
+    // strips: 23.31 -> 23.18 ms/step).  With fewer strips the separate kernel's 3x finer items fill the chip better
+    // (GEOM B = 512, 710 strips: fused 35.1 vs 34.6 ms/step), so it stays separate there.
+    const bool fuse_pre = TUNED && p->opt[JODO_OPT_FUSE_NEXT_QKV] != 0 && nblocks > 1 && p->n_strips >= 1024;
+    int cur = 0;                                   // posbuf[cur] holds the positions entering the block
     for (int l = 0; l < nblocks; ++l) {
         A.layer = l;
         A.mod_base = 32 + (int64_t)l * d.MB;
         for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + i];
         A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
-        { ProfScope ps(p, st, JODO_PROF_NODE_PRE); LAUNCH((wide::k_node_pre<D>), p->n_strips * 3, 64, A); }
-        cur ^= 1;
-        if (p->n_items > 0) {
-            ProfScope ps(p, st, JODO_PROF_EDGE_SCORES);            // exactly one of the two does the work (device flag)
-            if (p->n_sitems > 0) LAUNCH((wide::k_edge_scores_sym<D>), p->n_sitems, 64, A);
-            LAUNCH((wide::k_edge_scores<D>), p->n_items, 64, A);
+        {
+            ProfScope ps(p, st, JODO_PROF_NODE_PRE);
+            if constexpr (TUNED) {
+                if (!fuse_pre) {
+                    A.pre_mode = 0;
+                    LAUNCH(k_node_pre, p->n_strips * 3, 64, A);
+                } else {
+                    // positions entering the block (needs the previous update); the q/k/v projections of this block were
+                    // produced by the previous block's k_node_post: they only need h
+                    LAUNCH(k_pos_final, (p->Nn_pad + 255) / 256, 256, A);
+                    if (l == 0) {
+                        A.pre_mode = 1;
+                        LAUNCH(k_node_pre, p->n_strips * 3, 64, A);
+                    }
+                }
+            } else {
+                LAUNCH((wide::k_node_pre<D>), p->n_strips * 3, 64, A);
+            }
         }
-        { ProfScope ps(p, st, JODO_PROF_SOFTMAX); LAUNCH(k_softmax, (p->Nn + 15) / 16, 256, A); }
-        if (p->n_items > 0) { ProfScope ps(p, st, JODO_PROF_EDGE_MSGS); LAUNCH((wide::k_edge_msgs<D>), p->n_items, 64, A); }
-        { ProfScope ps(p, st, JODO_PROF_NODE_POST);
-          if (d.r == 2) LAUNCH((wide::k_node_post<D, 2>), p->n_strips, 64, A); else LAUNCH((wide::k_node_post<D, 4>), p->n_strips, 64, A); }
+        cur ^= 1;                                  // the block's positions are in pos_out now
+        {
+            // fused attention edge phase (dgt_kernels_attn.h): pair-mode items do the work for symmetric inputs, directed-mode
+            // items for asymmetric inputs and for molecules larger than a group (device flag; the other launch exits at once)
+            ProfScope ps(p, st, JODO_PROF_EDGE_ATTN);
+            if (p->n_aitems > 0) LAUNCH((k_edge_attn<D, !TUNED, true>), p->n_aitems, ATT_WAVES * 64, A);
+            if (p->n_aditems > 0) LAUNCH((k_edge_attn<D, !TUNED, false>), p->n_aditems, ATT_WAVES * 64, A);
+        }
+        {
+            ProfScope ps(p, st, JODO_PROF_NODE_POST);
+            if constexpr (TUNED) {
+                A.fuse_next = (fuse_pre && l + 1 < nblocks) ? 1 : 0;
+                if (A.fuse_next) {
+                    static const int slots[6] = {JB_WQ, JB_BQ, JB_WK, JB_BK, JB_WV, JB_BV};
+                    for (int i = 0; i < 6; ++i) A.wbn[i] = woff[JW_GLOBAL_COUNT + (l + 1) * JB_BLOCK_COUNT + slots[i]];
+                    A.mod_base_next = 32 + (int64_t)(l + 1) * d.MB;
+                }
+                rc = launch_node_post_256(p, st, A);
+                if (rc) return rc;
+            } else {
+                if (d.r == 2) LAUNCH((wide::k_node_post<D, 2>), p->n_strips, 64, A); else LAUNCH((wide::k_node_post<D, 4>), p->n_strips, 64, A);
+            }
+        }
         if (p->n_items > 0) {
-            ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);
+            ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);          // exactly one of the two does the work (device flag)
             if (p->n_pitems > 0) {
                 rc = launch_update_sym<D>(p, st, A);
                 if (rc) return rc;
@@ -181,23 +229,24 @@ int forward_wide(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, fl
             p->last_e_buf ^= 1;
         }
     }
+    // ---- heads + outputs ----
     ProfScope epi(p, st, JODO_PROF_EPILOGUE);
     A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
-    A.layer = nblocks;
+    A.layer = nblocks;                             // k_pos_final adds the last block's partial updates if any ran
     LAUNCH(k_pos_final, (p->Nn_pad + 255) / 256, 256, A);
     p->last_pos_buf = cur ^ 1;
     LAUNCH((wide::k_node_head<D>), p->n_strips, 64, A);
     switch (d.KEH / 32) {
-        case 5: rc = launch_edge_head_w<D, 5>(st, A); break;
-        case 6: rc = launch_edge_head_w<D, 6>(st, A); break;
-        case 7: rc = launch_edge_head_w<D, 7>(st, A); break;
-        case 8: rc = launch_edge_head_w<D, 8>(st, A); break;
-        case 9: rc = launch_edge_head_w<D, 9>(st, A); break;
-        case 10: rc = launch_edge_head_w<D, 10>(st, A); break;
-        case 11: rc = launch_edge_head_w<D, 11>(st, A); break;
-        case 12: rc = launch_edge_head_w<D, 12>(st, A); break;
-        case 13: rc = launch_edge_head_w<D, 13>(st, A); break;
-        case 15: rc = launch_edge_head_w<D, 15>(st, A); break;
+        case 5: rc = launch_edge_head<D, 5>(st, A); break;
+        case 6: rc = launch_edge_head<D, 6>(st, A); break;
+        case 7: rc = launch_edge_head<D, 7>(st, A); break;
+        case 8: rc = launch_edge_head<D, 8>(st, A); break;
+        case 9: rc = launch_edge_head<D, 9>(st, A); break;
+        case 10: rc = launch_edge_head<D, 10>(st, A); break;
+        case 11: rc = launch_edge_head<D, 11>(st, A); break;
+        case 12: rc = launch_edge_head<D, 12>(st, A); break;
+        case 13: rc = launch_edge_head<D, 13>(st, A); break;
+        case 15: rc = launch_edge_head<D, 15>(st, A); break;
         default: return jodo_set_error(JODO_ERR_UNSUPPORTED, "edge head width %d", d.KEH);
     }
     if (rc) return rc;
@@ -266,122 +315,8 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     rc = rowgemm(st, A.temb, d.T, A.mods, d.Mtot, W + A.wg[JW_MOD_W], W + A.wg[JW_MOD_B], p->B, d.T, (int)(d.Mtot / 32), 1, 0,
                  uflag);
     if (rc) return rc;
-    if (d.wide) return d.D == 256 ? forward_wide<256>(p, st, A, woff, posbuf, pro) : forward_wide<384>(p, st, A, woff, posbuf, pro);
-
-    // ---- pack inputs, embeddings ----
-    LAUNCH(k_pack_nodes, (p->Nn_pad + 255) / 256, 256, A);
-    switch (d.ndp / 8) {
-        case 1: rc = launch_embed_nodes<1>(st, A); break;
-        case 2: rc = launch_embed_nodes<2>(st, A); break;
-        case 3: rc = launch_embed_nodes<3>(st, A); break;
-        case 4: rc = launch_embed_nodes<4>(st, A); break;
-        case 5: rc = launch_embed_nodes<5>(st, A); break;
-        case 6: rc = launch_embed_nodes<6>(st, A); break;
-        case 7: rc = launch_embed_nodes<7>(st, A); break;
-        case 8: rc = launch_embed_nodes<8>(st, A); break;
-        default: return jodo_set_error(JODO_ERR_UNSUPPORTED, "node input width %d", d.ndp);
-    }
-    if (rc) return rc;
-    if (p->n_items > 0) LAUNCH(k_embed_edges, p->n_items, 64, A);
-
-    pro.reset();
-    // ---- DGT blocks ----
-    const int nblocks = (p->max_blocks >= 0 && p->max_blocks < d.L) ? p->max_blocks : d.L;
-    // With at least one strip per SIMD, k_node_post of block l also produces block l + 1's q / k / v (it holds h' in
-    // registers): drops a launch with its own latency-bound prologue and partial last round (QM9 B = 2500, 1409
-    // strips: 23.31 -> 23.18 ms/step).  With fewer strips the separate kernel's 3x finer items fill the chip better
-    // (GEOM B = 512, 710 strips: fused 35.1 vs 34.6 ms/step), so it stays separate there.
-    const bool fuse_pre = p->opt[JODO_OPT_FUSE_NEXT_QKV] != 0 && nblocks > 1 && p->n_strips >= 1024;
-    int cur = 0;                                   // posbuf[cur] holds the positions entering the block
-    for (int l = 0; l < nblocks; ++l) {
-        A.layer = l;
-        A.mod_base = 32 + (int64_t)l * d.MB;
-        for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + i];
-        A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
-        if (!fuse_pre) {
-            A.pre_mode = 0;
-            ProfScope ps(p, st, JODO_PROF_NODE_PRE); LAUNCH(k_node_pre, p->n_strips * 3, 64, A);
-        } else {
-            // positions entering the block (needs the previous update).  The q/k/v projections of this block were
-            // produced by the previous block's k_node_post: they only need h
-            ProfScope ps(p, st, JODO_PROF_NODE_PRE);
-            LAUNCH(k_pos_final, (p->Nn_pad + 255) / 256, 256, A);
-            if (l == 0) {
-                A.pre_mode = 1;
-                LAUNCH(k_node_pre, p->n_strips * 3, 64, A);
-            }
-        }
-        cur ^= 1;                                  // the block's positions are in pos_out now
-        {
-            // fused attention edge phase (dgt_kernels_attn.h): pair-mode items do the work for symmetric inputs, directed-mode
-            // items for asymmetric inputs and for molecules larger than a group (device flag; the other launch exits at once)
-            ProfScope ps(p, st, JODO_PROF_EDGE_SCORES);
-            if (p->n_aitems > 0) LAUNCH(k_edge_attn<true>, p->n_aitems, ATT_WAVES * 64, A);
-            if (p->n_aditems > 0) LAUNCH(k_edge_attn<false>, p->n_aditems, ATT_WAVES * 64, A);
-        }
-        { ProfScope ps(p, st, JODO_PROF_NODE_POST);
-          // One wave per strip for every full round of 1024 strips (one per SIMD); the remainder r — which would
-          // otherwise occupy r SIMDs for a whole item while the rest idle — goes to a second launch in which a
-          // workgroup of 4 (r <= 256) or 2 (r <= 512) waves shares each strip.  Measured on MI355X: 177 strips
-          // 1.7 -> 0.75 ms/step with 4 waves; all 1409 strips with 2 / 4 waves 3.7 / 4.1 vs 3.6 ms/step with 1.
-          A.fuse_next = (fuse_pre && l + 1 < nblocks) ? 1 : 0;
-          if (A.fuse_next) {
-              static const int slots[6] = {JB_WQ, JB_BQ, JB_WK, JB_BK, JB_WV, JB_BV};
-              for (int i = 0; i < 6; ++i) A.wbn[i] = woff[JW_GLOBAL_COUNT + (l + 1) * JB_BLOCK_COUNT + slots[i]];
-              A.mod_base_next = 32 + (int64_t)(l + 1) * d.MB;
-          }
-          const int force = p->opt[JODO_OPT_NODE_POST_WAVES];                      // 0 = automatic
-          const int full = force ? (force == 1 ? p->n_strips : 0) : (p->n_strips / 1024) * 1024;
-          const int rem = p->n_strips - full;
-          const int nw = force ? force : (rem <= 256 ? 4 : (rem <= 512 ? 2 : 1));
-          if (full > 0) {
-              A.strip0 = 0;
-              if (d.r == 2) LAUNCH(k_node_post<2>, full, 64, A); else LAUNCH(k_node_post<4>, full, 64, A);
-          }
-          if (rem > 0) {
-              A.strip0 = full;
-              if (nw == 1) { if (d.r == 2) LAUNCH(k_node_post<2>, rem, 64, A); else LAUNCH(k_node_post<4>, rem, 64, A); }
-              else if (nw == 2) { if (d.r == 2) LAUNCH((k_node_postw<2, 2>), rem, 128, A); else LAUNCH((k_node_postw<4, 2>), rem, 128, A); }
-              else { if (d.r == 2) LAUNCH((k_node_postw<2, 4>), rem, 256, A); else LAUNCH((k_node_postw<4, 4>), rem, 256, A); }
-          }
-          A.strip0 = 0; }
-        if (p->n_items > 0) {
-            ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);
-            if (p->n_pitems > 0) {
-                // the pair kernel is the width-generic one (S kept per lane, node terms gathered per direction)
-                rc = launch_update_sym<256>(p, st, A);
-                if (rc) return rc;
-            }
-            if (d.r == 2) LAUNCH(k_edge_update<2>, p->n_items, 64, A); else LAUNCH(k_edge_update<4>, p->n_items, 64, A);
-            std::swap(A.e, A.e_out);               // the state the next block reads is the one just written
-            p->last_e_buf ^= 1;
-        }
-    }
-    // ---- heads + outputs ----
-    ProfScope epi(p, st, JODO_PROF_EPILOGUE);
-    A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
-    A.layer = nblocks;                             // k_pos_final adds the last block's partial updates if any ran
-    LAUNCH(k_pos_final, (p->Nn_pad + 255) / 256, 256, A);
-    p->last_pos_buf = cur ^ 1;
-    LAUNCH(k_node_head, p->n_strips, 64, A);
-    switch (d.KEH / 32) {
-        case 3: rc = launch_edge_head<3>(st, A); break;
-        case 4: rc = launch_edge_head<4>(st, A); break;
-        case 5: rc = launch_edge_head<5>(st, A); break;
-        case 6: rc = launch_edge_head<6>(st, A); break;
-        case 7: rc = launch_edge_head<7>(st, A); break;
-        case 8: rc = launch_edge_head<8>(st, A); break;
-        case 9: rc = launch_edge_head<9>(st, A); break;
-        case 10: rc = launch_edge_head<10>(st, A); break;
-        default: return jodo_set_error(JODO_ERR_UNSUPPORTED, "edge head width %d", d.KEH);
-    }
-    if (rc) return rc;
-    LAUNCH(k_finalize_nodes, (p->B * p->N + 255) / 256, 256, A);
-    {
-        const size_t tot = (size_t)p->B * p->N * p->N;
-        LAUNCH(k_finalize_edges, (unsigned)((tot + 255) / 256), 256, A);
-    }
-    return JODO_OK;
+    if (!d.wide) return forward_blocks<256, true>(p, st, A, woff, posbuf, pro);
+    return d.D == 256 ? forward_blocks<256, false>(p, st, A, woff, posbuf, pro) : forward_blocks<384, false>(p, st, A, woff, posbuf, pro);
 }
 
 extern "C" int jodo_debug_fetch(jodo_plan* p, const void* workspace, int what, float* dst, int64_t* count, void* stream) {
@@ -393,11 +328,9 @@ extern "C" int jodo_debug_fetch(jodo_plan* p, const void* workspace, int what, f
         case 0: src = ws + p->ws.h; n = (int64_t)p->Nn * p->dims.D; break;
         case 1: src = ws + (p->last_e_buf ? p->ws.e2 : p->ws.e); n = p->rows * p->dims.De; break;
         case 2: src = ws + (p->last_pos_buf ? p->ws.pos1 : p->ws.pos0); n = (int64_t)p->Nn * 4; break;
-        case 3: src = ws + p->ws.hhat; n = (int64_t)p->Nn * p->max_parts * p->dims.D; break;
-        case 4: src = ws + p->ws.S; n = p->rows * 16; break;
+        case 3: src = ws + p->ws.hhat; n = (int64_t)p->Nn * p->amax_parts * p->dims.D; break;
         case 5: src = ws + p->ws.mods; n = p->dims.Mtot; break;
         case 6: src = ws + p->ws.q; n = (int64_t)p->Nn * p->dims.QKP; break;
-        case 7: src = ws + p->ws.et; n = p->rows * p->dims.De; break;
         default: return jodo_set_error(JODO_ERR_ARG, "debug_fetch: unknown selector %d", what);
     }
     hipError_t e = hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);

@@ -8,22 +8,24 @@
 //
 // in ONE kernel: nothing per-edge is written to HBM (round 1 stored et and the scores — 480 MB per block at QM9
 // B = 2500 — and read them back twice, k_edge_scores_sym -> k_softmax -> k_edge_msgs).  The softmax is carried
-// flash-style: every lane owns one target atom and keeps a running (max, sum, 128 message accumulators) for each of
-// its 8 heads; k_node_post merges the partials of the items that shared a target.
+// flash-style: every lane owns one target atom and keeps a running (max, sum) per head and D/2 message accumulators;
+// k_node_post merges the partials of the items that shared a target (attn_merge below).
 //
 // Pair mode (symmetric edge inputs, i.e. sampling).  The edge state is exactly symmetric, so lane i evaluates the pair
-// {i, j = (i + d) mod n} once (circulant walk d = 1 .. n/2, dgt_kernels_sym.h).  Target i's new source is j, computed
-// in place.  Target j's new source is i: its score and its unweighted message v_i * T1 are handed to j's lane through
-// LDS — the sender writes its own slot, the receiver reads the slot of lane (i - d) mod n.  That needs both atoms of a
-// pair in one workgroup, hence the plan's groups: whole molecules, up to 128 lanes, one 4-wave workgroup
-// (dgt_plan.cpp).  Nine workgroup barriers per offset (one for the scores, one per 32-feature message block, double
-// buffered); all waves of an item run the same offsets, so the barriers are cheap.
+// {i, j = (i + d) mod n} once (circulant walk d = 1 .. n/2, pair_of() in dgt_kernels_sym.h).  Target i's new source is
+// j, computed in place.  Target j's new source is i: its scores and its unweighted message v_i * T1 are handed to j's
+// lane through LDS — the sender writes its own slot, the receiver reads the slot of lane (i - d) mod n.  That needs both
+// atoms of a pair in one workgroup, hence the plan's groups: whole molecules, up to 128 lanes, one 4-wave workgroup
+// (dgt_plan.cpp).  One workgroup barrier for the scores and one per 32-feature message block (double buffered); all
+// waves of an item run the same offsets.
 //
 // Directed mode (asymmetric caller inputs; molecules larger than a group): lane = target, the wave visits every
 // source itself — no hand-over, no barriers, twice the matrix work per edge.
 //
-// Weights: edge_emb + lin_edge0 (96 KiB) live in LDS for the whole item, lin_edge1 (64 KiB) streams from L2 through
-// the software-pipelined ring (dgt_device.h).  40 KiB of LDS carry the hand-over buffers.
+// template <D, WQK>: node width and q / k arrangement.  WQK = false (nf = 256 only): the tuned 8-block arrangement
+// (jodo_amd/packing.py qk_out_map), edge_emb + lin_edge0 (96 KiB) resident in LDS, lin_edge1 streamed from L2 through
+// the software-pipelined ring; WQK = true: one 32-row block per head (qk_out_map_wide; the only option at nf = 384,
+// SC = 27), all weights streamed.  40 KiB of LDS carry the hand-over buffers.
 #pragma once
 #include "dgt_kernels_sym.h"
 
@@ -33,29 +35,111 @@ constexpr int ATT_WAVES = 4;
 constexpr int ATT_LANES = 128;
 constexpr float ATT_NEG = -3.0e38f;                    // "no source yet": exp(ATT_NEG - m) == 0 for every real m
 
-struct AttnLane {                                      // softmax + message state of one target atom (this half's 8 heads)
-    float m[8], l[8];
-    float acc[128];
+template <int D_, bool WQK_>
+struct AttnT {
+    static constexpr int D = D_, De = D_ / 4, NE = D_ / 128, HE = D_ / 8, ND = D_ / 32, HD = D_ / 2, C = D_ / 16;
+    static constexpr bool WQK = WQK_;
+    static constexpr bool LDSW = !WQK_;                            // edge_emb + lin_edge0 resident in LDS
+    static constexpr int NQB = WQK_ ? 14 : 8;                      // 32-row blocks of q / k / lin_edge0
+    static constexpr int KQE = D_ / 32;                            // weight quads per output block for K = De
+    static constexpr int PG = (D_ % 256 == 0) ? 8 : 4;             // quads in flight (must divide KQE)
+    static constexpr bool PH = (D_ / 16 == 16) && !(D_ > 256);     // C = 16: a half-lane's registers belong to heads 2b + half only, so it
+    static constexpr int NS = PH ? 8 : 16;                         // tracks 8 heads (slot k = head 2k + half) instead of all 16
+    static constexpr bool LDSS = D_ > 256;                         // running softmax state in LDS (registers are short at nf = 384:
+                                                                   // D/2 accumulators + D/8 inputs per lane; LDS is free, no resident weights)
+    static constexpr float INV_SQRT_C = D_ == 256 ? 0.25f : (D_ == 384 ? 0.20412414523193150f : 0.f);
+    static constexpr int M_EDGE = 6 * D_, M_GBF = 6 * D_ + 6 * (D_ / 4) + 2 * D_;
+    static_assert(!LDSW || D_ == 256, "LDS-resident weights are sized for nf = 256");
+    static_assert(C % 8 == 0, "message blocks are split at register 8 between two heads");
 };
 
-// scores of one pair for both directions from T0 = tanh(lin_edge0 x): S1 = edge (j -> i), S2 = edge (i -> j), in the
-// slot order of this half (slot 0 = adjacency head `half`, slot b = learned head 2(b-1) + half)
-__device__ __forceinline__ void attn_scores(const float4* wL0, const float (&x)[32], const BRow& qi, const BRow& ki,
-                                            const BRow& qj, const BRow& kj, int half, int f1, int f2, bool both,
-                                            float (&S1)[8], float (&S2)[8]) {
-    float m1[7], m2[7];
-    float qin[16], kin[16], qjn[16], kjn[16];
-    bload16(qi, 0, qin); bload16(kj, 0, kjn);
-    if (both) { bload16(qj, 0, qjn); bload16(ki, 0, kin); }
+// Gaussian basis (CondGaussianLayer, layers.py:291-295, :328-334) for De = 32 * NB features
+template <int NB>
+__device__ __forceinline__ void gbf_n(float d2, float scale, float shift, const float* __restrict__ tab, int half, float (&g)[NB * 16]) {
+    constexpr int De = NB * 32;
+    const float x = fmaf(d2, scale + 1.f, shift);
 #pragma unroll
-    for (int b = 0; b < 7; ++b) {
+    for (int b = 0; b < NB; ++b) {
+        float mu[16], is[16], cf[16];
+        load16(tab + b * 32 + half * 16, mu);
+        load16(tab + De + b * 32 + half * 16, is);
+        load16(tab + 2 * De + b * 32 + half * 16, cf);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float z = (x - mu[s]) * is[s];
+            g[b * 16 + s] = fast_exp(-0.5f * z * z) * cf[s];
+        }
+    }
+    if (half == 0) g[0] = x;
+}
+
+// weight source of one kernel instance: LDS image (tuned) or the streamed ring (wide)
+template <typename X>
+struct AttnW {
+    const float4* wEE;      // LDS: edge_emb, lin_edge0 (this lane's float4 of quad 0)
+    const float4* wL0;
+    WSrc ws;
+    unsigned oEE, oL0, oL1;
+    WPipe<X::PG> wp;
+};
+
+// one K = De output block; `cur` / `nxt` are byte offsets for the streamed case, `wl` the LDS block for the resident case
+template <typename X, bool LDS>
+__device__ __forceinline__ f32x16 attn_block(AttnW<X>& w, const float4* wl, unsigned cur, unsigned nxt, const float (&act)[X::HE], f32x16 acc) {
+    if constexpr (LDS) return mfma_block_lds_p<X::KQE>(wl, act, acc);
+    else return mfma_block_p<X::KQE>(w.wp, w.ws, cur, nxt, act, acc);
+}
+
+// et of an edge row from its state e and squared length d2 (GBF -> edge_emb -> LN1 -> modulate)
+template <typename X>
+__device__ __forceinline__ void attn_edge_input(const KArgs& A, AttnW<X>& w, const float* erow, float d2, float gscale, float gshift,
+                                                const float* mrow, int half, float (&x)[X::HE]) {
+    const float* es1 = launder(mrow + X::M_EDGE);
+    const float* ec1 = es1 + X::De;
+    const float* cst = launder(A.W);
+    const float* tab = cst + A.wb[JB_GBF];
+    const float* bEE = cst + A.wb[JB_EE_B];
+    float G[X::HE], e[X::HE];
+    gbf_n<X::NE>(d2, gscale, gshift, tab, half, G);
+    load_nat<X::NE>(erow, half, e);
+#pragma unroll
+    for (int b = 0; b < X::NE; ++b) {
+        const unsigned cg = w.oEE + (unsigned)(b * 2 * X::KQE) * 1024, ce = cg + X::KQE * 1024;
+        float bb[16];
+        load16(bEE + b * 32 + half * 16, bb);
+        f32x16 acc = attn_block<X, X::LDSW>(w, w.wEE + (b * 2 * X::KQE) * 64, cg, ce, G, zero16());
+        acc = attn_block<X, X::LDSW>(w, w.wEE + ((b * 2 + 1) * X::KQE) * 64, ce, b + 1 < X::NE ? ce + X::KQE * 1024 : w.oL0, e, acc);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) x[b * 16 + s] = acc[s] + bb[s];
+    }
+    layer_norm<X::HE>(x);
+    modulate<X::NE>(x, es1, ec1, half);
+}
+
+// scores of one pair for both directions from T0 = tanh(lin_edge0 x): S1 = edge (j -> i), S2 = edge (i -> j); all 16
+// heads in every lane (heads 0, 1 = adjacency heads from the edge flags f1 / f2, 2.. = learned)
+template <typename X, bool BOTH>
+__device__ __forceinline__ void attn_scores(AttnW<X>& w, const float (&x)[X::HE], const BRow& qi, const BRow& ki, const BRow& qj,
+                                            const BRow& kj, int half, int f1, int f2, float (&S1)[16], float (&S2)[16]) {
+    constexpr int NM = X::WQK ? 14 : 7;                 // blocks reduced per head / per head pair
+    float m1[X::WQK ? 1 : 7], m2[X::WQK ? 1 : 7];
+    float qin[16], kin[16], qjn[16], kjn[16];
+    S1[0] = (f1 & 1) ? 1.f : -1e10f; S1[1] = (f1 & 2) ? 1.f : -1e10f;           // extra heads, 0 -> -1e10 (layers.py:170-174)
+    S2[0] = (f2 & 1) ? 1.f : -1e10f; S2[1] = (f2 & 2) ? 1.f : -1e10f;
+    bload16(qi, 0, qin); bload16(kj, 0, kjn);
+    if (BOTH) { bload16(qj, 0, qjn); bload16(ki, 0, kin); }
+#pragma unroll
+    for (int b = 0; b < NM; ++b) {
         float a1[16], a2[16];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) { a1[s] = qin[s] * kjn[s]; a2[s] = both ? qjn[s] * kin[s] : 0.f; }
-        bload16(qi, b + 1, qin); bload16(kj, b + 1, kjn);
-        if (both) { bload16(qj, b + 1, qjn); bload16(ki, b + 1, kin); }
+        for (int s = 0; s < 16; ++s) { a1[s] = qin[s] * kjn[s]; a2[s] = BOTH ? qjn[s] * kin[s] : 0.f; }
+        if (b + 1 < X::NQB) {
+            bload16(qi, b + 1, qin); bload16(kj, b + 1, kjn);
+            if (BOTH) { bload16(qj, b + 1, qjn); bload16(ki, b + 1, kin); }
+        }
         pipeline_fence();
-        f32x16 acc = mfma_block_lds_p<8>(wL0 + (b * 8) * 64, x, zero16());
+        const unsigned cur = w.oL0 + (unsigned)(b * X::KQE) * 1024;
+        f32x16 acc = attn_block<X, X::LDSW>(w, w.wL0 + (b * X::KQE) * 64, cur, b + 1 < X::NQB ? cur + X::KQE * 1024 : w.oL1, x, zero16());
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -63,73 +147,65 @@ __device__ __forceinline__ void attn_scores(const float4* wL0, const float (&x)[
             s1 = fmaf(tt, a1[s], s1);
             s2 = fmaf(tt, a2[s], s2);
         }
-        m1[b] = s1; m2[b] = s2;
+        if constexpr (X::WQK) {                        // head g = block g (padded rows are zero in q and k)
+            S1[2 + b] = pair_sum(s1) * X::INV_SQRT_C;                          // / sqrt(out_channels = D / H), layers.py:167
+            S2[2 + b] = BOTH ? pair_sum(s2) * X::INV_SQRT_C : 0.f;
+        } else {
+            m1[b] = s1; m2[b] = s2;
+        }
         pipeline_fence();
     }
-    float tl1[14], tl2[14];
-    {
-        f32x16 acc = mfma_block_lds_p<8>(wL0 + (7 * 8) * 64, x, zero16());
+    if constexpr (!X::WQK) {                           // tuned: half h of block b = head 2b + h (channels 0..15); tail block:
+        float tl1[14], tl2[14];                        // register g of half h = head g, channel 16 + h
+        f32x16 acc = attn_block<X, X::LDSW>(w, w.wL0 + (7 * X::KQE) * 64, 0, 0, x, zero16());
 #pragma unroll
         for (int g = 0; g < 14; ++g) {
             const float tt = tanh_f(acc[g]);
             tl1[g] = tt * qin[g] * kjn[g];
-            tl2[g] = both ? tt * qjn[g] * kin[g] : 0.f;
+            tl2[g] = BOTH ? tt * qjn[g] * kin[g] : 0.f;
         }
-    }
-    float Sg1[14], Sg2[14];
 #pragma unroll
-    for (int g = 0; g < 14; ++g) {
-        const float o1 = ((g & 1) == half) ? m1[g >> 1] : 0.f;
-        const float o2 = ((g & 1) == half) ? m2[g >> 1] : 0.f;
-        Sg1[g] = pair_sum(o1 + tl1[g]) * 0.25f;                                // / sqrt(out_channels = 16), layers.py:167
-        Sg2[g] = both ? pair_sum(o2 + tl2[g]) * 0.25f : 0.f;
-    }
-    S1[0] = half == 0 ? ((f1 & 1) ? 1.f : -1e10f) : ((f1 & 2) ? 1.f : -1e10f);   // extra heads, 0 -> -1e10 (layers.py:170-174)
-    S2[0] = half == 0 ? ((f2 & 1) ? 1.f : -1e10f) : ((f2 & 2) ? 1.f : -1e10f);
-#pragma unroll
-    for (int b = 1; b < 8; ++b) {
-        S1[b] = half == 0 ? Sg1[2 * (b - 1)] : Sg1[2 * (b - 1) + 1];
-        S2[b] = half == 0 ? Sg2[2 * (b - 1)] : Sg2[2 * (b - 1) + 1];
+        for (int g = 0; g < 14; ++g) {
+            const float o1 = ((g & 1) == half) ? m1[g >> 1] : 0.f;
+            const float o2 = ((g & 1) == half) ? m2[g >> 1] : 0.f;
+            S1[2 + g] = pair_sum(o1 + tl1[g]) * X::INV_SQRT_C;
+            S2[2 + g] = BOTH ? pair_sum(o2 + tl2[g]) * X::INV_SQRT_C : 0.f;
+        }
     }
 }
 
-// et of an edge row from its state e and squared length d2 (GBF -> edge_emb -> LN1 -> modulate)
-__device__ __forceinline__ void attn_edge_input(const KArgs& A, const float4* wEE, const float* erow, float d2, float gscale,
-                                                float gshift, const float* mrow, int half, float (&x)[32]) {
-    const float* es1 = launder(mrow + 6 * 256);
-    const float* ec1 = es1 + 64;
-    const float* cst = launder(A.W);
-    const float* tab = cst + A.wb[JB_GBF];
-    const float* bEE = cst + A.wb[JB_EE_B];
-    float G[32], e[32];
-    gbf64(d2, gscale, gshift, tab, half, G);
-    load_nat<2>(erow, half, e);
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        float bb[16];
-        load16(bEE + b * 32 + half * 16, bb);
-        f32x16 acc = mfma_block_lds_p<8>(wEE + (b * 16) * 64, G, zero16());
-        acc = mfma_block_lds_p<8>(wEE + (b * 16 + 8) * 64, e, acc);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) x[b * 16 + s] = acc[s] + bb[s];
-    }
-    layer_norm<32>(x);
-    modulate<2>(x, es1, ec1, half);
+// the two heads a 16-register group of message block b belongs to: registers 0-7 -> lo, 8-15 -> hi (C is a multiple of 8)
+template <typename X>
+__device__ __forceinline__ void attn_pick(const float (&v)[16], int b, int half, float& lo, float& hi) {
+    lo = half ? v[(b * 32 + 16) / X::C] : v[(b * 32) / X::C];
+    hi = half ? v[(b * 32 + 24) / X::C] : v[(b * 32 + 8) / X::C];
+}
+
+// the same from a per-thread LDS column (element h at col[h * 256])
+template <typename X>
+__device__ __forceinline__ void attn_pick_lds(const float* col, int b, int half, float& lo, float& hi) {
+    lo = col[(half ? (b * 32 + 16) / X::C : (b * 32) / X::C) * 256];
+    hi = col[(half ? (b * 32 + 24) / X::C : (b * 32 + 8) / X::C) * 256];
 }
 
 // PAIR = true: pair-mode items (ai_*), exits when the inputs are asymmetric; PAIR = false: directed-mode items (ad_*),
 // runs when the inputs are asymmetric or the item belongs to a molecule that spans several groups
-template <bool PAIR>
+template <int D, bool WQK, bool PAIR>
 __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
+    using X = AttnT<D, WQK>;
     const int it = blockIdx.x;
     const bool asym = A.flags[FLAG_ASYM] != 0;
     if (PAIR ? asym : !(asym || A.pd.ad_big[it])) return;
-    __shared__ float4 wl[(32 + 64) * 64];               // edge_emb (2 x 16 quads) | lin_edge0 (8 x 8 quads)
-    __shared__ float4 sx[PAIR ? 2 * 256 : 1];           // scores handed to the partner: [quad][half * 128 + lane]
-    __shared__ float4 ux[PAIR ? 2 * 4 * 256 : 1];       // unweighted messages of one 32-feature block, double buffered
-    stage_weights<32, ATT_WAVES>(wl, reinterpret_cast<const float4*>(A.W + A.wb[JB_EE_W]));
-    stage_weights<64, ATT_WAVES>(wl + 32 * 64, reinterpret_cast<const float4*>(A.W + A.wb[JB_LE0_W]));
-    __syncthreads();
+    __shared__ float4 wl[X::LDSW ? (32 + 64) * 64 : 1];  // edge_emb (2 x 16 quads) | lin_edge0 (8 x 8 quads)
+    __shared__ float4 sx[PAIR ? 2 * 256 : 1];            // scores handed to the partner: [quad][half * 128 + lane], heads 8h .. 8h + 7
+    __shared__ float4 ux[PAIR ? 2 * 4 * 256 : 1];        // unweighted messages of one 32-feature block, double buffered
+    __shared__ float stt[X::LDSS ? 5 * 16 * 256 : 1];    // per thread: running max, sum | rescale, p(own source), p(handed-over source)
+    float* const stc = stt + threadIdx.x;                // element (k, h) of this thread at stc[(k * 16 + h) * 256]
+    if constexpr (X::LDSW) {
+        stage_weights<32, ATT_WAVES>(wl, reinterpret_cast<const float4*>(A.W + A.wb[JB_EE_W]));
+        stage_weights<64, ATT_WAVES>(wl + 32 * 64, reinterpret_cast<const float4*>(A.W + A.wb[JB_LE0_W]));
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
     const int ln = wave * 32 + (lane & 31);             // lane of the group
     const int grp = PAIR ? A.pd.ai_group[it] : A.pd.ad_group[it];
@@ -143,24 +219,28 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
     L.noff = A.pd.node_noff[L.v]; L.eoff = A.pd.node_eoff[L.v];
     const int lbase = ln - L.i;                         // group lane of atom 0 of this lane's molecule (pair mode)
     const float* mrow = mod_row(A, L.b) + A.mod_base;
-    const float gscale = mrow[6 * 256 + 6 * 64 + 2 * 256 + 0], gshift = mrow[6 * 256 + 6 * 64 + 2 * 256 + 1];
+    const float gscale = mrow[X::M_GBF + 0], gshift = mrow[X::M_GBF + 1];
     const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
-    const float4* wEE = wl + lane;
-    const float4* wL0 = wl + 32 * 64 + lane;
-    const WSrc ws = make_wsrc(A.W, lane);
-    const unsigned oL1 = (unsigned)(A.wb[JB_LE1_W] * 4);
-    WPipe<8> wp;
-    wpipe_prime(wp, ws, oL1);
-    AttnLane st;
+    AttnW<X> w;
+    w.wEE = wl + lane;
+    w.wL0 = wl + (X::LDSW ? 32 * 64 : 0) + lane;
+    w.ws = make_wsrc(A.W, lane);
+    w.oEE = (unsigned)(A.wb[JB_EE_W] * 4); w.oL0 = (unsigned)(A.wb[JB_LE0_W] * 4); w.oL1 = (unsigned)(A.wb[JB_LE1_W] * 4);
+    wpipe_prime(w.wp, w.ws, X::LDSW ? w.oL1 : w.oEE);
+    float sm[X::LDSS ? 1 : X::NS], sl[X::LDSS ? 1 : X::NS];   // running max / sum of this target (X::NS head slots)
+    float macc[X::HD];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) { st.m[b] = ATT_NEG; st.l[b] = 0.f; }
+    for (int h = 0; h < X::NS; ++h) {
+        if constexpr (X::LDSS) { stc[h * 256] = ATT_NEG; stc[(16 + h) * 256] = 0.f; }
+        else { sm[h] = ATT_NEG; sl[h] = 0.f; }
+    }
 #pragma unroll
-    for (int s = 0; s < 128; ++s) st.acc[s] = 0.f;
+    for (int s = 0; s < X::HD; ++s) macc[s] = 0.f;
     const int slot = half * ATT_LANES + ln;             // this lane's slot in the hand-over buffers
     for (int t = t0; t < t1; ++t) {
         // ---- who is the source ----
         bool ok, rok = false;
-        int u, rslot = slot;
+        int u, rln = ln;
         size_t r_in, r_out = 0;                         // edge rows: (source -> this target), (this atom -> partner)
         if (PAIR) {
             const PairLane P = pair_of(L, t + 1);
@@ -169,7 +249,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
             int rr = L.i - d;
             if (rr < 0) rr += L.n;
             rok = L.valid && L.n > 1 && (2 * d < L.n || (2 * d == L.n && 2 * rr < L.n));   // did lane (i - d) evaluate {i - d, i}?
-            rslot = half * ATT_LANES + (rok ? lbase + rr : ln);
+            rln = rok ? lbase + rr : ln;
         } else {
             const bool inr = L.valid && t < L.n;
             ok = inr && t != L.i;
@@ -179,51 +259,82 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
         }
         const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[u];
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
-        float x[32];
+        float x[X::HE];
         // pair mode reads row (i, j) like the other pair kernels (the state is symmetric); directed mode the true row
-        attn_edge_input(A, wEE, A.e + (PAIR ? r_out : r_in) * 64, dx * dx + dy * dy + dz * dz, gscale, gshift, mrow, half, x);
+        attn_edge_input<X>(A, w, A.e + (PAIR ? r_out : r_in) * X::De, dx * dx + dy * dy + dz * dz, gscale, gshift, mrow, half, x);
         // ---- scores ----
-        const BRow qi = brow(A.q, 8, L.v, half), ki = brow(A.k, 8, L.v, half);
-        const BRow qj = brow(A.q, 8, u, half), kj = brow(A.k, 8, u, half);
-        float S1[8], S2[8];
-        attn_scores(wL0, x, qi, ki, qj, kj, half, A.eflag[r_in], PAIR ? A.eflag[r_out] : 0, PAIR, S1, S2);
-        float R[8];
+        const BRow qi = brow(A.q, X::NQB, L.v, half), ki = brow(A.k, X::NQB, L.v, half);
+        const BRow qj = brow(A.q, X::NQB, u, half), kj = brow(A.k, X::NQB, u, half);
+        float Sa[X::NS], R[X::LDSS ? 1 : X::NS];           // scores of the own source / of the handed-over source per head slot
+        {
+            float S1[16], S2[16];
+            attn_scores<X, PAIR>(w, x, qi, ki, qj, kj, half, A.eflag[r_in], PAIR ? A.eflag[r_out] : 0, S1, S2);
+            float Sb[X::NS];
+#pragma unroll
+            for (int k = 0; k < X::NS; ++k) {
+                Sa[k] = X::PH ? (half ? S1[2 * k + 1] : S1[2 * k]) : S1[k];
+                Sb[k] = X::PH ? (half ? S2[2 * k + 1] : S2[2 * k]) : S2[k];
+            }
+            if (PAIR) {                                 // PH: a half hands its 8 slots to the same half of the partner; otherwise half h
+                if constexpr (X::PH) {                  // hands over heads 8h .. 8h + 7 and the receiver reads both halves
+                    sx[slot] = make_float4(Sb[0], Sb[1], Sb[2], Sb[3]);
+                    sx[256 + slot] = make_float4(Sb[4], Sb[5], Sb[6], Sb[7]);
+                } else {
+                    sx[slot] = half ? make_float4(Sb[8], Sb[9], Sb[10], Sb[11]) : make_float4(Sb[0], Sb[1], Sb[2], Sb[3]);
+                    sx[256 + slot] = half ? make_float4(Sb[12], Sb[13], Sb[14], Sb[15]) : make_float4(Sb[4], Sb[5], Sb[6], Sb[7]);
+                }
+            }
+        }
         if (PAIR) {
-            sx[slot] = make_float4(S2[0], S2[1], S2[2], S2[3]);
-            sx[256 + slot] = make_float4(S2[4], S2[5], S2[6], S2[7]);
             __syncthreads();
-            const float4 a = sx[rslot], b = sx[256 + rslot];
-            R[0] = a.x; R[1] = a.y; R[2] = a.z; R[3] = a.w; R[4] = b.x; R[5] = b.y; R[6] = b.z; R[7] = b.w;
+            if constexpr (X::PH) {
+                const float4 a = sx[half * ATT_LANES + rln], b = sx[256 + half * ATT_LANES + rln];
+                R[0] = a.x; R[1] = a.y; R[2] = a.z; R[3] = a.w; R[4] = b.x; R[5] = b.y; R[6] = b.z; R[7] = b.w;
+            } else if constexpr (!X::LDSS) {
+                const float4 a = sx[rln], b = sx[256 + rln], c = sx[ATT_LANES + rln], e = sx[256 + ATT_LANES + rln];
+                R[0] = a.x; R[1] = a.y; R[2] = a.z; R[3] = a.w; R[4] = b.x; R[5] = b.y; R[6] = b.z; R[7] = b.w;
+                R[8] = c.x; R[9] = c.y; R[10] = c.z; R[11] = c.w; R[12] = e.x; R[13] = e.y; R[14] = e.z; R[15] = e.w;
+            }
         }
         // ---- running softmax of this target: up to two new sources ----
-        float sc[8], p1[8], p2[8];
+        float sc[X::LDSS ? 1 : X::NS], p1[X::LDSS ? 1 : X::NS], p2[X::LDSS ? 1 : X::NS];
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            float mn = st.m[b];
-            if (ok) mn = fmaxf(mn, S1[b]);
-            if (PAIR && rok) mn = fmaxf(mn, R[b]);
-            sc[b] = fast_exp(st.m[b] - mn);
-            p1[b] = ok ? fast_exp(S1[b] - mn) : 0.f;
-            p2[b] = (PAIR && rok) ? fast_exp(R[b] - mn) : 0.f;
-            st.l[b] = fmaf(st.l[b], sc[b], p1[b] + p2[b]);
-            st.m[b] = mn;
+        for (int h = 0; h < X::NS; ++h) {
+            const float m0 = X::LDSS ? stc[h * 256] : sm[h];
+            // head h of the partner's hand-over: quad (h & 7) / 4 of half-slot h / 8, component h & 3
+            const float rh = !PAIR ? 0.f : (X::LDSS ? reinterpret_cast<const float*>(sx + ((h & 7) / 4) * 256 + (h / 8) * ATT_LANES + rln)[h & 3] : R[h]);
+            float mn = m0;
+            if (ok) mn = fmaxf(mn, Sa[h]);
+            if (PAIR && rok) mn = fmaxf(mn, rh);
+            const float c_ = fast_exp(m0 - mn);
+            const float a_ = ok ? fast_exp(Sa[h] - mn) : 0.f;
+            const float b_ = (PAIR && rok) ? fast_exp(rh - mn) : 0.f;
+            if constexpr (X::LDSS) {
+                stc[h * 256] = mn;
+                stc[(16 + h) * 256] = fmaf(stc[(16 + h) * 256], c_, a_ + b_);
+                stc[(32 + h) * 256] = c_; stc[(48 + h) * 256] = a_; stc[(64 + h) * 256] = b_;
+            } else {
+                sl[h] = fmaf(sl[h], c_, a_ + b_);
+                sm[h] = mn; sc[h] = c_; p1[h] = a_; p2[h] = b_;
+            }
         }
         // ---- messages: T1 = tanh(lin_edge1 x) once; own direction v_j * T1, partner's direction v_i * T1 ----
-        const BRow vj = brow(A.v, 8, u, half), vi = brow(A.v, 8, L.v, half);
+        const BRow vj = brow(A.v, X::ND, u, half), vi = brow(A.v, X::ND, L.v, half);
+        const int rslot = half * ATT_LANES + rln;
         float vjn[16], vin[16];
         bload16(vj, 0, vjn);
         if (PAIR) bload16(vi, 0, vin);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < X::ND; ++b) {
             float vv[16], vo[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) { vv[s] = vjn[s]; vo[s] = PAIR ? vin[s] : 0.f; }
-            if (b < 7) {
+            if (b + 1 < X::ND) {
                 bload16(vj, b + 1, vjn);
                 if (PAIR) bload16(vi, b + 1, vin);
             }
-            const unsigned cur = oL1 + (unsigned)(b * 8) * 1024;
-            f32x16 acc = mfma_block_p<8>(wp, ws, cur, b < 7 ? cur + 8 * 1024 : oL1, x, zero16());
+            const unsigned cur = w.oL1 + (unsigned)(b * X::KQE) * 1024;
+            f32x16 acc = mfma_block_p<X::KQE>(w.wp, w.ws, cur, b + 1 < X::ND ? cur + X::KQE * 1024 : (X::LDSW ? w.oL1 : w.oEE), x, zero16());
             float T[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) T[s] = tanh_f(acc[s]);
@@ -237,71 +348,95 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
                 __syncthreads();
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 w = ub[q * 256 + rslot];
-                    um[q * 4 + 0] = w.x; um[q * 4 + 1] = w.y; um[q * 4 + 2] = w.z; um[q * 4 + 3] = w.w;
+                    const float4 r4 = ub[q * 256 + rslot];
+                    um[q * 4 + 0] = r4.x; um[q * 4 + 1] = r4.y; um[q * 4 + 2] = r4.z; um[q * 4 + 3] = r4.w;
                 }
+            }
+            float sc_lo, sc_hi, p1_lo, p1_hi, p2_lo = 0.f, p2_hi = 0.f;
+            if constexpr (X::LDSS) {
+                attn_pick_lds<X>(stc + 32 * 256, b, half, sc_lo, sc_hi);
+                attn_pick_lds<X>(stc + 48 * 256, b, half, p1_lo, p1_hi);
+                if (PAIR) attn_pick_lds<X>(stc + 64 * 256, b, half, p2_lo, p2_hi);
+            } else if constexpr (X::PH) {               // block b = head 2b + half = slot b
+                sc_lo = sc_hi = sc[b]; p1_lo = p1_hi = p1[b];
+                if (PAIR) p2_lo = p2_hi = p2[b];
+            } else {
+                attn_pick<X>(sc, b, half, sc_lo, sc_hi);
+                attn_pick<X>(p1, b, half, p1_lo, p1_hi);
+                if (PAIR) attn_pick<X>(p2, b, half, p2_lo, p2_hi);
             }
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                float a = fmaf(st.acc[b * 16 + s], sc[b], p1[b] * (T[s] * vv[s]));
-                if (PAIR) a = fmaf(p2[b], um[s], a);
-                st.acc[b * 16 + s] = a;
+                float a = fmaf(macc[b * 16 + s], s < 8 ? sc_lo : sc_hi, (s < 8 ? p1_lo : p1_hi) * (T[s] * vv[s]));
+                if (PAIR) a = fmaf(s < 8 ? p2_lo : p2_hi, um[s], a);
+                macc[b * 16 + s] = a;
             }
         }
     }
     // ---- partial of this item: unnormalised sums + (max, sum) per head ----
     if (L.valid) {
-        store_nat<8>(A.hhat + ((size_t)L.v * A.pd.amax_parts + part) * 256, half, st.acc);
-        float4* sp = reinterpret_cast<float4*>(A.astat + ((size_t)L.v * A.pd.amax_parts + part) * 32 + half * 16);
-        sp[0] = make_float4(st.m[0], st.m[1], st.m[2], st.m[3]);
-        sp[1] = make_float4(st.m[4], st.m[5], st.m[6], st.m[7]);
-        sp[2] = make_float4(st.l[0], st.l[1], st.l[2], st.l[3]);
-        sp[3] = make_float4(st.l[4], st.l[5], st.l[6], st.l[7]);
+        store_nat<X::ND>(A.hhat + ((size_t)L.v * A.pd.amax_parts + part) * D, half, macc);
+        float* sp = A.astat + ((size_t)L.v * A.pd.amax_parts + part) * 32;       // [16 maxima | 16 sums], head-indexed
+        if constexpr (X::PH) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { sp[2 * k + half] = sm[k]; sp[16 + 2 * k + half] = sl[k]; }
+        } else {
+            float fin[16];                              // half 0 stores the maxima, half 1 the sums (both halves hold both)
+#pragma unroll
+            for (int h = 0; h < 16; ++h) {
+                if constexpr (X::LDSS) fin[h] = stc[((half ? 16 : 0) + h) * 256];
+                else fin[h] = half ? sl[h] : sm[h];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                reinterpret_cast<float4*>(sp)[(half ? 4 : 0) + q] = make_float4(fin[q * 4 + 0], fin[q * 4 + 1], fin[q * 4 + 2], fin[q * 4 + 3]);
+        }
     }
 }
 
 // merge the attention partials of a node (k_node_post*): hhat = sum_p acc_p e^{m_p - M} / (sum_p l_p e^{m_p - M} + 1e-16),
-// fixed order.  hh: this half-lane's 128 message features (block b = head 2b + half).
-__device__ __forceinline__ void attn_merge(const KArgs& A, int v, int half, int p0, int pstep, float (&hh)[128], float (&M)[8],
-                                           float (&Ls)[8]) {
+// fixed order.  hh: this half-lane's D / 2 message features.  (layers.py:178: PyG softmax = e / (sum + 1e-16))
+template <int D>
+__device__ __forceinline__ void attn_merge(const KArgs& A, int v, int half, float (&hh)[D / 2]) {
+    using X = AttnT<D, true>;
     const int parts = A.pd.anode_parts[v];
-    const float* sbase = A.astat + (size_t)v * A.pd.amax_parts * 32 + half * 16;
-    const float* hbase = A.hhat + (size_t)v * A.pd.amax_parts * 256;
+    const float* sbase = A.astat + (size_t)v * A.pd.amax_parts * 32;
+    const float* hbase = A.hhat + (size_t)v * A.pd.amax_parts * D;
+    float M[16], Ls[16];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) { M[b] = ATT_NEG; Ls[b] = 0.f; }
-    for (int q = p0; q < parts; q += pstep) {
-        float m[8];
-        const float4* sp = reinterpret_cast<const float4*>(sbase + (size_t)q * 32);
-        const float4 a = sp[0], c = sp[1];
-        m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = c.x; m[5] = c.y; m[6] = c.z; m[7] = c.w;
+    for (int h = 0; h < 16; ++h) { M[h] = ATT_NEG; Ls[h] = 0.f; }
+    for (int q = 0; q < parts; ++q) {
+        float m[16];
+        load16(sbase + (size_t)q * 32, m);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) M[b] = fmaxf(M[b], m[b]);
+        for (int h = 0; h < 16; ++h) M[h] = fmaxf(M[h], m[h]);
     }
 #pragma unroll
-    for (int s = 0; s < 128; ++s) hh[s] = 0.f;
-    for (int q = p0; q < parts; q += pstep) {
-        const float4* sp = reinterpret_cast<const float4*>(sbase + (size_t)q * 32);
-        const float4 a = sp[0], c = sp[1], la = sp[2], lc = sp[3];
-        const float m[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-        const float l[8] = {la.x, la.y, la.z, la.w, lc.x, lc.y, lc.z, lc.w};
-        float w[8];
+    for (int s = 0; s < D / 2; ++s) hh[s] = 0.f;
+    for (int q = 0; q < parts; ++q) {
+        float m[16], l[16], wq[16];
+        load16(sbase + (size_t)q * 32, m);
+        load16(sbase + (size_t)q * 32 + 16, l);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) { w[b] = fast_exp(m[b] - M[b]); Ls[b] = fmaf(l[b], w[b], Ls[b]); }
+        for (int h = 0; h < 16; ++h) { wq[h] = fast_exp(m[h] - M[h]); Ls[h] = fmaf(l[h], wq[h], Ls[h]); }
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            float t[16];
-            load16(hbase + (size_t)q * 256 + b * 32 + half * 16, t);
+        for (int b = 0; b < X::ND; ++b) {
+            float t[16], lo, hi;
+            load16(hbase + (size_t)q * D + b * 32 + half * 16, t);
+            attn_pick<X>(wq, b, half, lo, hi);
 #pragma unroll
-            for (int s = 0; s < 16; ++s) hh[b * 16 + s] = fmaf(t[s], w[b], hh[b * 16 + s]);
+            for (int s = 0; s < 16; ++s) hh[b * 16 + s] = fmaf(t[s], s < 8 ? lo : hi, hh[b * 16 + s]);
         }
     }
-}
-__device__ __forceinline__ void attn_normalise(float (&hh)[128], const float (&Ls)[8]) {
+    float inv[16];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        const float inv = 1.f / (Ls[b] + 1e-16f);              // layers.py:178 (PyG softmax: e / (sum + 1e-16))
+    for (int h = 0; h < 16; ++h) inv[h] = 1.f / (Ls[h] + 1e-16f);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) hh[b * 16 + s] *= inv;
+    for (int b = 0; b < X::ND; ++b) {
+        float lo, hi;
+        attn_pick<X>(inv, b, half, lo, hi);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) hh[b * 16 + s] *= s < 8 ? lo : hi;
     }
 }
 

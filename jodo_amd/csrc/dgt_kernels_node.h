@@ -66,9 +66,7 @@ __global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
 // hh = aggregated attention messages: flash-style merge of the per-item partials of the fused attention kernel
 // (attn_merge, dgt_kernels_attn.h), fixed order
 __device__ __forceinline__ void node_load_hh(const KArgs& A, const LaneNode& L, int half, float (&hh)[128]) {
-    float M[8], Ls[8];
-    attn_merge(A, L.v, half, 0, 1, hh, M, Ls);
-    attn_normalise(hh, Ls);
+    attn_merge<256>(A, L.v, half, hh);
 }
 
 // in place: x = LN(h + ng1 * x) * (1 + nc2) + ns2   (x holds hh on entry, the FFN input on exit)

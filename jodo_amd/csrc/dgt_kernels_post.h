@@ -1,4 +1,4 @@
-// Epilogue kernels: prediction heads, NaN guard, centre-of-mass removal, dense symmetrised output.
+// Epilogue kernels (prediction heads: dgt_kernels_wide.h): NaN guard, centre-of-mass removal, dense symmetrised output.
 // Reference: DGT_concat.forward models/mol_gnn.py:571-594, to_dense_edge_attr models/utils.py:129-137,
 // remove_mean_with_mask models/utils.py:38-45.
 #pragma once
@@ -32,112 +32,6 @@ __global__ void k_pos_final(KArgs A) {
         if (isnan(p.x) || isnan(p.y) || isnan(p.z)) atomicOr(&A.flags[FLAG_NAN], 1);
     }
     reinterpret_cast<float4*>(A.pos_out)[v] = p;
-}
-
-// node head: [h0 ; node_0(h) ; ... ] (KNH) -> 256 -> SiLU -> 128 -> SiLU -> nd
-__global__ __launch_bounds__(64, 1) void k_node_head(KArgs A) {
-    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int v = blockIdx.x * 32 + j;
-    const int KNH = A.d.KNH;
-    const WSrc ws = make_wsrc(A.W, lane);
-    const unsigned o1 = (unsigned)(A.wg[JW_NH1_W] * 4), o2 = (unsigned)(A.wg[JW_NH2_W] * 4), o3 = (unsigned)(A.wg[JW_NH3_W] * 4);
-    WPipe<8> wp;
-    wpipe_prime(wp, ws, o1);
-    f32x16 o[8];
-#pragma unroll
-    for (int b = 0; b < 8; ++b) o[b] = zero16();
-    {
-        const int kq = KNH / 8, nch = KNH / 64;
-#pragma unroll 1
-        for (int c = 0; c < nch; ++c) {
-            float x[32];
-            load_nat<2>(A.ahid + (size_t)v * KNH + c * 64, half, x);
-#pragma unroll
-            for (int ob = 0; ob < 8; ++ob) {
-                const unsigned cur = o1 + (unsigned)(ob * kq + c * 8) * 1024;
-                const unsigned nxt = ob < 7 ? o1 + (unsigned)((ob + 1) * kq + c * 8) * 1024
-                                            : (c + 1 < nch ? o1 + (unsigned)((c + 1) * 8) * 1024 : o2);
-                o[ob] = mfma_block_p<8>(wp, ws, cur, nxt, x, o[ob]);
-            }
-        }
-    }
-    float a1[128];
-    {
-        const float* bias = A.W + A.wg[JW_NH1_B];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            float r[16];
-            acc_bias(o[b], bias + b * 32 + half * 16, r);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) a1[b * 16 + s] = silu_f(r[s]);
-        }
-    }
-    float a2[64];
-    {
-        const float* bias = A.W + A.wg[JW_NH2_B];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const unsigned cur = o2 + (unsigned)(b * 32) * 1024;
-            f32x16 acc = mfma_block_p<32>(wp, ws, cur, b < 3 ? cur + 32 * 1024 : o3, a1, zero16());
-            float r[16];
-            acc_bias(acc, bias + b * 32 + half * 16, r);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) a2[b * 16 + s] = silu_f(r[s]);
-        }
-    }
-    {
-        f32x16 acc = mfma_block_p<16>(wp, ws, o3, o3, a2, zero16());
-        float r[16];
-        acc_bias(acc, A.W + A.wg[JW_NH3_B] + half * 16, r);
-        store16(A.apred + (size_t)v * 32 + half * 16, r);
-    }
-}
-
-// edge heads on dense rows: [e0 ; edge_0(e) ; ...] (KEH) -> [exist 64 | type 64] -> SiLU
-//   -> block-diagonal [32 | 32] -> SiLU -> block-diagonal [1 | ch-1]
-template <int NBK>     // KEH / 32
-__global__ __launch_bounds__(64) void k_edge_head(KArgs A) {
-    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const size_t r = (size_t)blockIdx.x * 32 + j;             // workspace rows are padded by 32
-    const WSrc ws = make_wsrc(A.W, lane);
-    const unsigned o1 = (unsigned)(A.wg[JW_EH1_W] * 4), o2 = (unsigned)(A.wg[JW_EH2_W] * 4), o3 = (unsigned)(A.wg[JW_EH3_W] * 4);
-    WPipe<4> wp;                                              // NBK * 4 quads per block: any NBK divides
-    wpipe_prime(wp, ws, o1);
-    float x[NBK * 16];
-    load_nat<NBK>(A.ehid + r * (NBK * 32), half, x);
-    float a1[64];
-    {
-        const float* bias = A.W + A.wg[JW_EH1_B];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const unsigned cur = o1 + (unsigned)(b * NBK * 4) * 1024;
-            f32x16 acc = mfma_block_p<NBK * 4>(wp, ws, cur, b < 3 ? cur + (unsigned)(NBK * 4) * 1024 : o2, x, zero16());
-            float rr[16];
-            acc_bias(acc, bias + b * 32 + half * 16, rr);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) a1[b * 16 + s] = silu_f(rr[s]);
-        }
-    }
-    float a2[32];
-    {
-        const float* bias = A.W + A.wg[JW_EH2_B];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const unsigned cur = o2 + (unsigned)(b * 16) * 1024;
-            f32x16 acc = mfma_block_p<16>(wp, ws, cur, b < 1 ? cur + 16 * 1024 : o3, a1, zero16());
-            float rr[16];
-            acc_bias(acc, bias + b * 32 + half * 16, rr);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) a2[b * 16 + s] = silu_f(rr[s]);
-        }
-    }
-    {
-        f32x16 acc = mfma_block_p<8>(wp, ws, o3, o3, a2, zero16());
-        float rr[16];
-        acc_bias(acc, A.W + A.wg[JW_EH3_B] + half * 16, rr);
-        if (half == 0 && r < (size_t)A.pd.rows)
-            reinterpret_cast<float4*>(A.epred)[r] = make_float4(rr[0], rr[1], rr[2], rr[3]);
-    }
 }
 
 // dense outputs: out_xh [B,N,3+nd], out_edge [B,N,N,ch]; zeros on padding; edges symmetrised

@@ -1,4 +1,4 @@
-// Prologue kernels: time embedding / modulation vectors, input packing, node and edge embeddings.
+// Prologue kernels: time embedding / modulation vectors, input packing (node / edge embeddings: dgt_kernels_wide.h).
 // Reference: DGT_concat.forward models/mol_gnn.py:509-557, time_mlp :481-489 + layers.py:283-288,
 // Cond_DGT_concat context path :728-734.
 #pragma once
@@ -158,108 +158,6 @@ __global__ void k_pack_nodes(KArgs A) {
     }
     reinterpret_cast<float4*>(A.pos_in)[v] = p;
     reinterpret_cast<float4*>(A.cpos)[v] = cp;
-}
-
-// h0 = node_emb([feat ; cond_feat]);  KQ = ndp / 8 quads
-template <int KQ>
-__global__ __launch_bounds__(64) void k_embed_nodes(KArgs A) {
-    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int v = blockIdx.x * 32 + j;
-    float x[KQ * 4];
-    const float4* src = reinterpret_cast<const float4*>(A.feat + (size_t)v * (KQ * 8) + half * (KQ * 4));
-#pragma unroll
-    for (int q = 0; q < KQ; ++q) {
-        const float4 t = src[q];
-        x[q * 4 + 0] = t.x; x[q * 4 + 1] = t.y; x[q * 4 + 2] = t.z; x[q * 4 + 3] = t.w;
-    }
-    const float4* w = wq(A, A.wg[JW_NODE_EMB_W], lane);
-    const float* bias = A.W + A.wg[JW_NODE_EMB_B];
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        f32x16 acc = mfma_block<KQ>(w + (size_t)b * KQ * 64, x, zero16());
-        float r[16];
-        acc_bias(acc, bias + b * 32 + half * 16, r);
-        store16(A.h + (size_t)v * 256 + b * 32 + half * 16, r);
-        store16(A.ahid + (size_t)v * A.d.KNH + b * 32 + half * 16, r);
-    }
-}
-
-// e0 = edge_emb([edge_x ; cond_edge_x ; G0]) per dense edge row; also adjacency flags
-__global__ __launch_bounds__(64) void k_embed_edges(KArgs A) {
-    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int it = blockIdx.x;
-    const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it];
-    const LaneNode L = lane_node(A, strip, j);
-    const int ch = A.d.ch;
-    const bool first = A.flags[FLAG_COND_NONZERO] == 0;
-    const float* mr = mod_row(A, L.b);
-    const float gscale = mr[0], gshift = mr[1];
-    const float4 pc = reinterpret_cast<const float4*>(A.cpos)[L.v];
-    const float* tab = A.W + A.wg[JW_GBF_TOP];
-    // the whole weight set of this projection is 18 quads: held in registers for all rows of the item
-    float4 wreg[18];
-    {
-        const float4* w = wq(A, A.wg[JW_EDGE_EMB_W], lane);
-#pragma unroll
-        for (int q = 0; q < 18; ++q) wreg[q] = w[(size_t)q * 64];
-    }
-    const float* bias = A.W + A.wg[JW_EDGE_EMB_B];
-    for (int t = t0; t < t1; ++t) {
-        const bool ok = L.valid && t < L.n;
-        const int tc = ok ? t : 0;
-        const int u = L.noff + tc;
-        const size_t r = (size_t)L.eoff + (size_t)L.i * L.n + tc;
-        const float4 pu = reinterpret_cast<const float4*>(A.cpos)[u];
-        const float dx = pc.x - pu.x, dy = pc.y - pu.y, dz = pc.z - pu.z;
-        const float d2c = dx * dx + dy * dy + dz * dz;
-        // raw inputs of this edge: features f = half*4 + s of [edge_x(ch) ; cond_edge_x(ch)]
-        const size_t din = (((size_t)L.b * A.pd.N + L.i) * A.pd.N + tc) * ch;
-        float ein[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int f = half * 4 + s;
-            float val = 0.f;
-            if (f < ch) val = A.edge_x[din + f];
-            else if (f < 2 * ch && A.cond_edge_x) val = A.cond_edge_x[din + (f - ch)];
-            ein[s] = val;
-        }
-        int adj2d = 1;
-        if (A.cond_edge_x) adj2d = A.cond_edge_x[din] >= A.d.edge_th ? 1 : 0;
-        const int adjsp = d2c <= A.d.cutoff ? 1 : 0;
-        float G[32];
-        if (first) {
-#pragma unroll
-            for (int s = 0; s < 32; ++s) G[s] = 0.f;
-        } else {
-            gbf64(d2c, gscale, gshift, tab, half, G);
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            f32x16 acc = zero16();
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 a = wreg[b * 9 + q];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, G[4 * q + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, G[4 * q + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, G[4 * q + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, G[4 * q + 3], acc, 0, 0, 0);
-            }
-            {
-                const float4 a = wreg[b * 9 + 8];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, ein[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, ein[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, ein[2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, ein[3], acc, 0, 0, 0);
-            }
-            float rr[16];
-            acc_bias(acc, bias + b * 32 + half * 16, rr);
-            if (ok) {
-                store16(A.e + r * 64 + b * 32 + half * 16, rr);
-                store16(A.ehid + r * A.d.KEH + b * 32 + half * 16, rr);
-            }
-        }
-        if (ok && half == 0) A.eflag[r] = adj2d | (adjsp << 1);
-    }
 }
 
 }  // namespace jd

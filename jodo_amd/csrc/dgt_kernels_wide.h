@@ -7,15 +7,13 @@
 //     12-quad blocks), 8 at D = 256;
 //   * score heads use the "one head per 32-row block" arrangement (jodo_amd/packing.py
 //     qk_out_map_wide): SC = 27 has no 16 + 2 split, and padding a head to 32 rows keeps its reduction
-//     in-lane;
-//   * a value block no longer coincides with two attention heads (C = 24), so every lane carries all
-//     16 softmax weights and picks per register;
+//     in-lane (the attention edge phase itself is the width-generic k_edge_attn, dgt_kernels_attn.h);
 //   * the pair kernels park the shared part of input_lin in private (scratch) memory instead of LDS.
 // Instantiated for D = 384; D = 256 is instantiated too so that the whole set can be pinned against
 // the tuned kernels and the nf = 256 fixtures (jodo_cfg.layout = 1, tests only).
 #pragma once
 #include "dgt_kernels_common.h"
-#include "dgt_kernels_sym.h"
+#include "dgt_kernels_attn.h"
 
 namespace jd {
 namespace wide {
@@ -35,26 +33,6 @@ struct Dim {
     // modulation slice of one block: node 6 x D | edge 6 x De | equi (shift, scale) 2 x D | gbf (scale, shift)
     static constexpr int M_EDGE = 6 * D_, M_EQUI = 6 * D_ + 6 * (D_ / 4), M_GBF = 6 * D_ + 6 * (D_ / 4) + 2 * D_;
 };
-
-template <int NB>
-__device__ __forceinline__ void gbf(float d2, float scale, float shift, const float* __restrict__ tab, int half,
-                                    float (&g)[NB * 16]) {
-    constexpr int De = NB * 32;
-    const float x = fmaf(d2, scale + 1.f, shift);
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        float mu[16], is[16], cf[16];
-        load16(tab + b * 32 + half * 16, mu);
-        load16(tab + De + b * 32 + half * 16, is);
-        load16(tab + 2 * De + b * 32 + half * 16, cf);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float z = (x - mu[s]) * is[s];
-            g[b * 16 + s] = fast_exp(-0.5f * z * z) * cf[s];
-        }
-    }
-    if (half == 0) g[0] = x;
-}
 
 // ------------------------------------------------------------------------------------------------
 // prologue
@@ -123,7 +101,7 @@ __global__ __launch_bounds__(64) void k_embed_edges(KArgs A) {
 #pragma unroll
             for (int s = 0; s < X::HE; ++s) G[s] = 0.f;
         } else {
-            gbf<X::NE>(d2c, gscale, gshift, tab, half, G);
+            gbf_n<X::NE>(d2c, gscale, gshift, tab, half, G);
         }
 #pragma unroll
         for (int b = 0; b < X::NE; ++b) {
@@ -211,20 +189,7 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
     WPipe<X::PG> wp;
     wpipe_prime(wp, ws, oN2E);
     float hx[X::HD];
-    {   // aggregated attention messages: fixed-order sum of the per-chunk partials
-        const int parts = A.pd.strip_parts[strip];
-        const float* base = A.hhat + (size_t)L.v * A.pd.max_parts * D;
-        load_nat<X::ND>(base, half, hx);
-        for (int q = 1; q < parts; ++q) {
-#pragma unroll
-            for (int b = 0; b < X::ND; ++b) {
-                float t[16];
-                load16(base + (size_t)q * D + b * 32 + half * 16, t);
-#pragma unroll
-                for (int s = 0; s < 16; ++s) hx[b * 16 + s] += t[s];
-            }
-        }
-    }
+    attn_merge<D>(A, L.v, half, hx);                                      // aggregated attention messages (dgt_kernels_attn.h)
 #pragma unroll
     for (int b = 0; b < X::NE; ++b) {                                     // node2edge_lin per node
         const unsigned cur = oN2E + (unsigned)b * X::KQD * 1024;
@@ -329,147 +294,6 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
 
 // ------------------------------------------------------------------------------------------------
 // edge side (directed: rows r = eoff + a*n + c, a = source / row atom, c = target / column atom)
-template <int D>
-__global__ __launch_bounds__(64, 1) void k_edge_scores(KArgs A) {
-    if (!A.flags[FLAG_ASYM]) return;                            // symmetric inputs: k_edge_scores_sym runs instead
-    using X = Dim<D>;
-    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int it = blockIdx.x;
-    const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it];
-    const LaneNode L = lane_node(A, strip, j);
-    const float* mrow = mod_row(A, L.b) + A.mod_base;
-    const float gscale = mrow[X::M_GBF + 0], gshift = mrow[X::M_GBF + 1];
-    const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
-    const WSrc ws = make_wsrc(A.W, lane);
-    const unsigned oEE = (unsigned)(A.wb[JB_EE_W] * 4), oL0 = (unsigned)(A.wb[JB_LE0_W] * 4);
-    WPipe<X::PG> wp;
-    wpipe_prime(wp, ws, oEE);
-    for (int t = t0; t < t1; ++t) {
-        const bool ok = L.valid && t < L.n;
-        const int tc = ok ? t : 0;
-        const int u = L.noff + tc;
-        const size_t r = (size_t)L.eoff + (size_t)tc * L.n + L.i;      // edge (source a = t) -> (target c = i)
-        const float* es1 = launder(mrow + X::M_EDGE);
-        const float* ec1 = es1 + X::De;
-        const float* cst = launder(A.W);
-        const float* tab = cst + A.wb[JB_GBF];
-        const float* bEE = cst + A.wb[JB_EE_B];
-        TRow qrow = trow(A.q, NHEAD_BLOCKS, L.v, half), krow = trow(A.k, NHEAD_BLOCKS, u, half);
-        qrow.p = launder(qrow.p);
-        const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[u];
-        const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
-        float x[X::HE];
-        {
-            float G[X::HE], e[X::HE];
-            gbf<X::NE>(dx * dx + dy * dy + dz * dz, gscale, gshift, tab, half, G);
-            load_nat<X::NE>(A.e + r * X::De, half, e);
-#pragma unroll
-            for (int b = 0; b < X::NE; ++b) {
-                const unsigned cg = oEE + (unsigned)(b * 2 * X::KQE) * 1024, ce = cg + X::KQE * 1024;
-                float bb[16];
-                load16(bEE + b * 32 + half * 16, bb);
-                f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cg, ce, G, zero16());
-                acc = mfma_block_p<X::KQE>(wp, ws, ce, b + 1 < X::NE ? ce + X::KQE * 1024 : oL0, e, acc);
-#pragma unroll
-                for (int s = 0; s < 16; ++s) x[b * 16 + s] = acc[s] + bb[s];
-            }
-        }
-        layer_norm<X::HE>(x);
-        modulate<X::NE>(x, es1, ec1, half);
-        if (ok) store_nat<X::NE>(A.et + r * X::De, half, x);
-        // lin_edge0 -> tanh -> * q_target * k_source; head g = block g, padded rows are zero in q and k
-        float Sg[NHEAD_BLOCKS];
-        float qn[16], kn[16];
-        load16T(qrow, 0, qn);
-        load16T(krow, 0, kn);
-#pragma unroll
-        for (int g = 0; g < NHEAD_BLOCKS; ++g) {
-            float qq[16], kk[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) { qq[s] = qn[s]; kk[s] = kn[s]; }
-            if (g + 1 < NHEAD_BLOCKS) {                    // one block ahead
-                load16T(qrow, g + 1, qn);
-                load16T(krow, g + 1, kn);
-            }
-            const unsigned cur = oL0 + (unsigned)(g * X::KQE) * 1024;
-            f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cur, g + 1 < NHEAD_BLOCKS ? cur + X::KQE * 1024 : oEE, x, zero16());
-            float s_ = 0.f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) s_ = fmaf(tanh_f(acc[s]) * qq[s], kk[s], s_);
-            Sg[g] = s_;
-        }
-        const int fl = A.eflag[r];
-#pragma unroll
-        for (int g = 0; g < NHEAD_BLOCKS; ++g) Sg[g] = pair_sum(Sg[g]) * X::INV_SQRT_C;   // / sqrt(out_channels = D / H), layers.py:167
-        float Sout[8];                                  // slot b of this half = head 2b + half (0, 1 = adjacency heads)
-        Sout[0] = half == 0 ? ((fl & 1) ? 1.f : -1e10f) : ((fl & 2) ? 1.f : -1e10f);
-#pragma unroll
-        for (int b = 1; b < 8; ++b) Sout[b] = half == 0 ? Sg[2 * (b - 1)] : Sg[2 * (b - 1) + 1];
-        if (ok) {
-            float4* sp = reinterpret_cast<float4*>(A.S + r * 16 + half * 8);
-            sp[0] = make_float4(Sout[0], Sout[1], Sout[2], Sout[3]);
-            sp[1] = make_float4(Sout[4], Sout[5], Sout[6], Sout[7]);
-        }
-    }
-}
-
-template <int D>
-__global__ __launch_bounds__(64, 1) void k_edge_msgs(KArgs A) {
-    using X = Dim<D>;
-    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int it = blockIdx.x;
-    const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it], part = A.pd.item_part[it];
-    const LaneNode L = lane_node(A, strip, j);
-    // softmax statistics of all 16 heads of this lane's target; stored slot (g & 1) * 8 + (g >> 1) = head g
-    float mx[16], inv[16];
-    load16(A.stats + (size_t)L.v * 32, mx);
-    load16(A.stats + (size_t)L.v * 32 + 16, inv);
-    const WSrc ws = make_wsrc(A.W, lane);
-    const unsigned oL1 = (unsigned)(A.wb[JB_LE1_W] * 4);
-    WPipe<X::PG> wp;
-    wpipe_prime(wp, ws, oL1);
-    float macc[X::HD];
-#pragma unroll
-    for (int s = 0; s < X::HD; ++s) macc[s] = 0.f;
-    for (int t = t0; t < t1; ++t) {
-        const bool ok = L.valid && t < L.n && t != L.i;
-        const int tc = (L.valid && t < L.n) ? t : 0;
-        const int u = L.noff + tc;
-        const size_t r = (size_t)L.eoff + (size_t)tc * L.n + L.i;
-        float x[X::HE];
-        load_nat<X::NE>(A.et + r * X::De, half, x);
-        float al[16];                                   // al[g] = attention weight of head g
-        {
-            float sv[16];
-            load16(A.S + r * 16, sv);
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int sl = (g & 1) * 8 + (g >> 1);
-                al[g] = ok ? fast_exp(sv[sl] - mx[sl]) * inv[sl] : 0.f;
-            }
-        }
-        const TRow vrow = trow(A.v, X::ND, u, half);
-        float vnext[16];
-        load16T(vrow, 0, vnext);
-#pragma unroll
-        for (int b = 0; b < X::ND; ++b) {
-            float vv[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) vv[s] = vnext[s];
-            if (b + 1 < X::ND) load16T(vrow, b + 1, vnext);
-            const unsigned cur = oL1 + (unsigned)(b * X::KQE) * 1024;
-            f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cur, b + 1 < X::ND ? cur + X::KQE * 1024 : oL1, x, zero16());
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                // feature b*32 + half*16 + s belongs to head feature / C
-                const float a = half ? al[(b * 32 + 16 + s) / X::C] : al[(b * 32 + s) / X::C];
-                macc[b * 16 + s] = fmaf(tanh_f(acc[s]) * vv[s], a, macc[b * 16 + s]);
-            }
-        }
-    }
-    store_nat<X::ND>(A.hhat + ((size_t)L.v * A.pd.max_parts + part) * D, half, macc);
-}
-
 template <int D, int R>
 __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
     if (!A.flags[FLAG_ASYM]) return;                            // symmetric inputs: k_edge_update_sym runs instead
@@ -513,7 +337,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
         float G[X::HE];
-        gbf<X::NE>(d2, gscale, gshift, tab_, half, G);
+        gbf_n<X::NE>(d2, gscale, gshift, tab_, half, G);
         // ---- edge residual + LN2 + modulate ----
         float en[X::HE];
         {
@@ -633,104 +457,6 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
 // lane) is kept in a per-lane array for both directions (registers at D = 256, partly spilled to scratch at
 // D = 384 — four waves' LDS slabs of 48 KiB would not fit the CU's 160 KiB), and each direction requests its
 // per-node rows with buffer loads pinned ahead of their use (BRow, dgt_device.h).
-template <int D>
-__global__ __launch_bounds__(64, 1) void k_edge_scores_sym(KArgs A) {
-    if (A.flags[FLAG_ASYM]) return;
-    using X = Dim<D>;
-    const int lane = threadIdx.x & 63, jl = lane & 31, half = lane >> 5;
-    const int it = blockIdx.x;
-    const int strip = A.pd.sitem_strip[it], t0 = A.pd.sitem_t0[it], t1 = A.pd.sitem_t1[it];
-    const LaneNode L = lane_node(A, strip, jl);
-    const float* mrow = mod_row(A, L.b) + A.mod_base;
-    const float gscale = mrow[X::M_GBF + 0], gshift = mrow[X::M_GBF + 1];
-    const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
-    const WSrc ws = make_wsrc(A.W, lane);
-    const unsigned oEE = (unsigned)(A.wb[JB_EE_W] * 4), oL0 = (unsigned)(A.wb[JB_LE0_W] * 4);
-    WPipe<X::PG> wp;
-    wpipe_prime(wp, ws, oEE);
-    for (int t = t0; t < t1; ++t) {
-        const PairLane P = pair_of(L, t + 1);
-        const float* es1 = launder(mrow + X::M_EDGE);
-        const float* ec1 = es1 + X::De;
-        const float* cst = launder(A.W);
-        const float* tab = cst + A.wb[JB_GBF];
-        const float* bEE = cst + A.wb[JB_EE_B];
-        const BRow qi = brow(A.q, NHEAD_BLOCKS, L.v, half), ki = brow(A.k, NHEAD_BLOCKS, L.v, half);
-        const BRow qj = brow(A.q, NHEAD_BLOCKS, P.u, half), kj = brow(A.k, NHEAD_BLOCKS, P.u, half);
-        const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[P.u];
-        const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
-        float x[X::HE];
-        {
-            float G[X::HE], e[X::HE];
-            gbf<X::NE>(dx * dx + dy * dy + dz * dz, gscale, gshift, tab, half, G);
-            load_nat<X::NE>(A.e + P.rij * X::De, half, e);
-#pragma unroll
-            for (int b = 0; b < X::NE; ++b) {
-                const unsigned cg = oEE + (unsigned)(b * 2 * X::KQE) * 1024, ce = cg + X::KQE * 1024;
-                float bb[16];
-                load16(bEE + b * 32 + half * 16, bb);
-                f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cg, ce, G, zero16());
-                acc = mfma_block_p<X::KQE>(wp, ws, ce, b + 1 < X::NE ? ce + X::KQE * 1024 : oL0, e, acc);
-#pragma unroll
-                for (int s = 0; s < 16; ++s) x[b * 16 + s] = acc[s] + bb[s];
-            }
-        }
-        layer_norm<X::HE>(x);
-        modulate<X::NE>(x, es1, ec1, half);
-        if (P.ok) {
-            store_nat<X::NE>(A.et + P.rij * X::De, half, x);
-            store_nat<X::NE>(A.et + P.rji * X::De, half, x);
-        }
-        // tanh(lin_edge0) once; direction 1 = edge (j -> i): q_i . k_j ; direction 2 = edge (i -> j): q_j . k_i
-        float Sg1[NHEAD_BLOCKS], Sg2[NHEAD_BLOCKS];
-        float qin[16], kin[16], qjn[16], kjn[16];
-        bload16(qi, 0, qin); bload16(ki, 0, kin);
-        bload16(qj, 0, qjn); bload16(kj, 0, kjn);
-#pragma unroll
-        for (int g = 0; g < NHEAD_BLOCKS; ++g) {
-            float a1[16], a2[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) { a1[s] = qin[s] * kjn[s]; a2[s] = qjn[s] * kin[s]; }
-            if (g + 1 < NHEAD_BLOCKS) {
-                bload16(qi, g + 1, qin); bload16(ki, g + 1, kin);
-                bload16(qj, g + 1, qjn); bload16(kj, g + 1, kjn);
-            }
-            const unsigned cur = oL0 + (unsigned)(g * X::KQE) * 1024;
-            f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cur, g + 1 < NHEAD_BLOCKS ? cur + X::KQE * 1024 : oEE, x, zero16());
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float tt = tanh_f(acc[s]);
-                s1 = fmaf(tt, a1[s], s1);
-                s2 = fmaf(tt, a2[s], s2);
-            }
-            Sg1[g] = s1; Sg2[g] = s2;
-        }
-        const int f1 = A.eflag[P.rji], f2 = A.eflag[P.rij];
-#pragma unroll
-        for (int g = 0; g < NHEAD_BLOCKS; ++g) {
-            Sg1[g] = pair_sum(Sg1[g]) * X::INV_SQRT_C;
-            Sg2[g] = pair_sum(Sg2[g]) * X::INV_SQRT_C;
-        }
-        float S1[8], S2[8];                                // slot b of this half = head 2b + half
-        S1[0] = half == 0 ? ((f1 & 1) ? 1.f : -1e10f) : ((f1 & 2) ? 1.f : -1e10f);
-        S2[0] = half == 0 ? ((f2 & 1) ? 1.f : -1e10f) : ((f2 & 2) ? 1.f : -1e10f);
-#pragma unroll
-        for (int b = 1; b < 8; ++b) {
-            S1[b] = half == 0 ? Sg1[2 * (b - 1)] : Sg1[2 * (b - 1) + 1];
-            S2[b] = half == 0 ? Sg2[2 * (b - 1)] : Sg2[2 * (b - 1) + 1];
-        }
-        if (P.ok) {
-            float4* sp = reinterpret_cast<float4*>(A.S + P.rji * 16 + half * 8);      // edge (j -> i)
-            sp[0] = make_float4(S1[0], S1[1], S1[2], S1[3]);
-            sp[1] = make_float4(S1[4], S1[5], S1[6], S1[7]);
-            float4* sq = reinterpret_cast<float4*>(A.S + P.rij * 16 + half * 8);      // edge (i -> j)
-            sq[0] = make_float4(S2[0], S2[1], S2[2], S2[3]);
-            sq[1] = make_float4(S2[4], S2[5], S2[6], S2[7]);
-        }
-    }
-}
-
 template <int D, int R>
 __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
     if (A.flags[FLAG_ASYM]) return;
@@ -773,7 +499,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
         float G[X::HE];
-        gbf<X::NE>(d2, gscale, gshift, tab_, half, G);
+        gbf_n<X::NE>(d2, gscale, gshift, tab_, half, G);
         // ---- edge residual + LN2 + modulate (symmetric) ----
         float en[X::HE];
         {

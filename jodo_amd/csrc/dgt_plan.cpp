@@ -178,24 +178,6 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         const std::vector<int> ord = xcd_order(pi_strip, 1);
         permute(pi_strip, ord); permute(pi_t0, ord); permute(pi_t1, ord);
     }
-    std::vector<int32_t> si_strip, si_t0, si_t1;
-    if (spair_auto && (int64_t)p->n_pitems / 2 < 2048) spair_chunk = 1;      // small batch: keep >= 2 items per SIMD
-    for (int s = 0; s < p->n_strips; ++s) {
-        int nmax = 0;
-        for (int j = 0; j < 32; ++j) nmax = std::max(nmax, (int)node_n[s * 32 + j]);
-        const int dmax = nmax / 2;
-        if (dmax == 0) continue;
-        int parts = (dmax + spair_chunk - 1) / spair_chunk;
-        int chunk = (dmax + parts - 1) / parts;
-        parts = (dmax + chunk - 1) / chunk;
-        for (int q = 0; q < parts; ++q) { si_strip.push_back(s); si_t0.push_back(q * chunk); si_t1.push_back(std::min(dmax, (q + 1) * chunk)); }
-    }
-    p->n_sitems = (int)si_strip.size();
-    {   // four pair-scores items per workgroup
-        const std::vector<int> ord = xcd_order(si_strip, 4);
-        permute(si_strip, ord); permute(si_t0, ord); permute(si_t1, ord);
-    }
-
     // ---- fused attention kernel: groups of whole molecules (<= 128 lanes), items = (group, range of pair offsets) ----
     // A pair (i, j) is evaluated once, by lane i; what it contributes to target j is handed to j's lane through LDS,
     // so both atoms of a pair must sit in the same 4-wave workgroup: a group holds whole molecules only.  Molecules
@@ -239,8 +221,8 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         if (achunk <= 0) {                                      // automatic: coarse items amortise the per-item partial
             int64_t iters = 0;                                  // (1 KiB per atom), fine items fill 256 CUs evenly
             for (int g = 0; g < ng; ++g) iters += std::max(1, g_nmax[g] / 2);
-            achunk = 3;
-            while (achunk > 1 && iters / achunk < 2 * 256) --achunk;
+            achunk = 6;                                         // measured at QM9 B = 2500: 1 -> 5.45, 3 -> 4.42, 6 -> 4.05, 8 -> 4.25,
+            while (achunk > 1 && iters / achunk < 2 * 256) --achunk;   // 15 -> 4.67 ms/step for the kernel (k_node_post follows the part count)
         }
         struct It { int g, t0, t1, part, big; };
         std::vector<It> pit, dit;
@@ -277,7 +259,6 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     put(orig_n, &p->off_orig_n); put(orig_noff, &p->off_orig_noff); put(orig_eoff, &p->off_orig_eoff);
     put(it_strip, &p->off_item_strip); put(it_t0, &p->off_item_t0); put(it_t1, &p->off_item_t1); put(it_part, &p->off_item_part); put(strip_parts, &p->off_strip_parts);
     put(pi_strip, &p->off_pitem_strip); put(pi_t0, &p->off_pitem_t0); put(pi_t1, &p->off_pitem_t1);
-    put(si_strip, &p->off_sitem_strip); put(si_t0, &p->off_sitem_t0); put(si_t1, &p->off_sitem_t1);
     put(ag_node, &p->off_ag_node); put(ai_group, &p->off_ai_group); put(ai_t0, &p->off_ai_t0); put(ai_t1, &p->off_ai_t1); put(ai_part, &p->off_ai_part);
     put(ad_group, &p->off_ad_group); put(ad_t0, &p->off_ad_t0); put(ad_t1, &p->off_ad_t1); put(ad_part, &p->off_ad_part); put(ad_big, &p->off_ad_big);
     put(anode_parts, &p->off_anode_parts);
@@ -291,12 +272,12 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     w.hid1 = take(Bp * d.T * f); w.temb = take(Bp * d.T * f); w.mods = take(Bp * (size_t)d.Mtot * f);
     w.condh = take(Bp * (size_t)std::max(1, d.cond_ch) * d.D * f); w.condh2 = take(Bp * (size_t)std::max(1, d.cond_ch) * d.D * f);
     w.pos0 = take(NP * 4 * f); w.pos1 = take(NP * 4 * f); w.dpos = take(NP * max_parts * 4 * f); w.cpos = take(NP * 4 * f);
-    w.feat = take(NP * d.ndp * f); w.h = take(NP * d.D * f); w.hhat = take(NP * std::max(max_parts, amax_parts) * d.D * f);
+    w.feat = take(NP * d.ndp * f); w.h = take(NP * d.D * f); w.hhat = take(NP * amax_parts * d.D * f);
     w.astat = take(NP * amax_parts * 32 * f);
     w.q = take(NP * d.QKP * f); w.k = take(NP * d.QKP * f); w.v = take(NP * d.D * f); w.n2e = take(NP * d.De * f);
-    w.wrow = take(NP * d.D * f); w.wcol = take(NP * d.D * f); w.ahid = take(NP * d.KNH * f); w.stats = take(NP * 32 * f);
+    w.wrow = take(NP * d.D * f); w.wcol = take(NP * d.D * f); w.ahid = take(NP * d.KNH * f);
     w.apred = take(NP * 32 * f);
-    w.eflag = take(R * sizeof(int32_t)); w.e = take(R * d.De * f); w.e2 = take(R * d.De * f); w.et = take(R * d.De * f); w.S = take(R * 16 * f);
+    w.eflag = take(R * sizeof(int32_t)); w.e = take(R * d.De * f); w.e2 = take(R * d.De * f);
     w.ehid = take(R * d.KEH * f); w.epred = take(R * 4 * f); w.dposE = take(R * 4 * f);
     w.total = o;
     *out = p;

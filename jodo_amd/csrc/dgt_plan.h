@@ -36,9 +36,6 @@ struct PlanDev {
     const int* pitem_strip; // pair work items (symmetric path): strip, [d0, d1) over circulant offsets d = t + 1
     const int* pitem_t0;
     const int* pitem_t1;
-    const int* sitem_strip; // pair work items of the scores kernel (coarser chunks)
-    const int* sitem_t0;
-    const int* sitem_t1;
     // fused attention kernel (k_edge_attn): groups of whole molecules, up to 128 lanes each, one 4-wave workgroup per item
     const int* ag_node;     // [n_agroups][128] packed node of lane ln (-1 = idle lane)
     const int* ai_group;    // pair-mode items: group, offsets d = t + 1 for t in [t0, t1), partial index
@@ -52,27 +49,27 @@ struct PlanDev {
     const int* ad_big;      // 1 = group of a molecule that spans several groups: directed mode even for symmetric inputs
     const int* anode_parts; // [Nn_pad] number of attention partials of a node
     int n_agroups, n_aitems, n_aditems, amax_parts;
-    int Nn, Nn_pad, n_strips, n_items, n_pitems, n_sitems, B, N, max_parts;
+    int Nn, Nn_pad, n_strips, n_items, n_pitems, B, N, max_parts;
     int64_t rows;
 };
 
 struct WsLayout {   // byte offsets into the workspace
     size_t hid1, temb, mods, condh, condh2;
-    size_t pos0, pos1, dpos, cpos, feat, h, hhat, astat, q, k, v, n2e, wrow, wcol, ahid, stats, apred;
-    size_t eflag, e, e2, et, S, ehid, epred, dposE;
+    size_t pos0, pos1, dpos, cpos, feat, h, hhat, astat, q, k, v, n2e, wrow, wcol, ahid, apred;
+    size_t eflag, e, e2, ehid, epred, dposE;
     size_t total;
 };
 
 struct jodo_plan {
     jodo_cfg cfg;
     DgtDims dims;
-    int B, N, Nn, Nn_pad, n_strips, n_items, n_pitems, n_sitems, max_parts;
+    int B, N, Nn, Nn_pad, n_strips, n_items, n_pitems, max_parts;
     int n_agroups, n_aitems, n_aditems, amax_parts;
     size_t off_ag_node, off_ai_group, off_ai_t0, off_ai_t1, off_ai_part, off_ad_group, off_ad_t0, off_ad_t1, off_ad_part, off_ad_big, off_anode_parts;
     int64_t rows, dir_edges;
     std::vector<int32_t> desc;       // concatenated descriptor tables
     size_t off_node_b, off_node_i, off_node_n, off_node_noff, off_node_eoff, off_orig_n, off_orig_noff,
-        off_orig_eoff, off_item_strip, off_item_t0, off_item_t1, off_item_part, off_strip_parts, off_pitem_strip, off_pitem_t0, off_pitem_t1, off_sitem_strip, off_sitem_t0, off_sitem_t1;   // in int32 elements
+        off_orig_eoff, off_item_strip, off_item_t0, off_item_t1, off_item_part, off_strip_parts, off_pitem_strip, off_pitem_t0, off_pitem_t1;   // in int32 elements
     WsLayout ws;
     // profiling (jodo_profile_*): pairs of events per launch class, recorded on the launch stream
     int prof_enabled;

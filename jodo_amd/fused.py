@@ -129,10 +129,12 @@ def dpm_update(solver, coef, x_pos, x_base, edge_base, P, DA, DB, PP, node_mask)
     if coef[2] != 0.0:
         bufs.eps.normal_()
     c8 = (ctypes.c_float * 8)(*coef)
-    f = lambda t, n: _f32c(t, n)
+    # contiguous fp32 views are bound to names until the launch is enqueued: a temporary freed earlier could be handed
+    # out again by the caching allocator for the next temporary and be overwritten before the kernel reads it
+    t = [_f32c(v, n) for v, n in ((x_pos, 'x_pos'), (x_base, 'x_base'), (edge_base, 'edge_base'), (P[0], 'P'), (P[1], 'eP'),
+                                  (DA[0], 'DA'), (DA[1], 'eDA'), (DB[0], 'DB'), (DB[1], 'eDB'), (PP[0], 'PP'))]
     capi.check(capi.lib().jodo_dpm_update(
-        B, N, F, ch, capi.ptr(solver._dpm_n_nodes), c8, None, None, 0, 0, capi.ptr(f(x_pos, 'x_pos')), capi.ptr(f(x_base, 'x_base')),
-        capi.ptr(f(edge_base, 'edge_base')), capi.ptr(f(P[0], 'P')), capi.ptr(f(P[1], 'eP')), capi.ptr(f(DA[0], 'DA')),
-        capi.ptr(f(DA[1], 'eDA')), capi.ptr(f(DB[0], 'DB')), capi.ptr(f(DB[1], 'eDB')), capi.ptr(f(PP[0], 'PP')),
+        B, N, F, ch, capi.ptr(solver._dpm_n_nodes), c8, None, None, 0, 0, *[capi.ptr(v) for v in t],
         capi.ptr(bufs.eps), capi.ptr(xo), capi.ptr(eo), capi.current_stream_ptr()), 'jodo_dpm_update')
+    del t
     return xo, eo
