@@ -188,6 +188,7 @@ def main():
     ap.add_argument('--spair-chunk', type=int, default=0)
     ap.add_argument('--layout', default='auto', choices=['auto', 'wide'], help="'wide': width-generic kernels at nf=256")
     ap.add_argument('--graph', action='store_true', help='replay one captured HIP graph per step (jodo_amd/graphed.py)')
+    ap.add_argument('--plan-opt', action='append', default=[], help='jodo_plan_option=value (experiments), e.g. 3=0')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-full-round', action='store_true', help='skip the end-to-end 1000-step round (N = 1 only leg)')
     ap.add_argument('--full-round', action='store_true', help='run the end-to-end round for workloads other than qm9 too')
@@ -233,6 +234,7 @@ def main():
     model.max_chunk = args.max_chunk
     model.pair_chunk = args.pair_chunk
     model.spair_chunk = args.spair_chunk
+    model.plan_options = {int(o.split('=')[0]): int(o.split('=')[1]) for o in args.plan_opt}
     model.force_directed = bool(int(os.environ.get("JODO_FORCE_DIRECTED", "0")))   # debug: skip the symmetric pair kernels
 
     # synthetic inputs: atom counts from the training histogram (seed 42 + rank), reference noise shapes

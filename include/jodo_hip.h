@@ -36,8 +36,9 @@ extern "C" {
 
 /* Model hyper-parameters (config.model.* / config.data.* of the reference's configs). */
 typedef struct {
-    int32_t nf;          /* D: node hidden width (256 tuned kernels; 384 width-generic set) */
-    int32_t n_layers;    /* L                                                   */
+    int32_t nf;          /* D: node hidden width: 256 or 384 (README.md:168 `--config.model.nf 384`) */
+    int32_t n_layers;    /* L: the per-block readouts 2D // L and 2De // L must fit their padded slots D/4 and
+                            16 (nf 256) / 32 (nf 384), i.e. L >= 8; the Python module additionally asks for even L */
     int32_t n_heads;     /* H (16)                                              */
     int32_t n_extra;     /* XH: adjacency heads (2)                             */
     int32_t mlp_ratio;   /* r                                                   */
@@ -46,8 +47,9 @@ typedef struct {
     int32_t cond_ch;     /* 0 = DGT_concat, >0 = cond_DGT_concat                */
     float spatial_cut_off;
     float edge_quan_th;
-    int32_t layout;      /* 0 = automatic (nf 256: tuned kernel set, otherwise the width-generic set);
-                            1 = width-generic kernel set and weight layout even for nf 256 (tests)  */
+    int32_t layout;      /* q / k / lin_edge0 arrangement: 0 = automatic (nf 256: 8 blocks, two heads per block + tail block,
+                            with the nf-256 node kernels and LDS-resident attention weights; otherwise one 32-row block per
+                            head); 1 = one block per head even at nf 256 (tests: runs the width-generic instantiations) */
 } jodo_cfg;
 
 /* Slots of the weight-offset table handed to jodo_dgt_forward (offsets in floats into the packed
@@ -102,8 +104,10 @@ typedef struct jodo_plan jodo_plan;
 /* Build the execution plan for a batch: B molecules with n_nodes[b] atoms (host array), padded
  * width N of the dense API tensors.  Molecules are ordered by size internally; masks are implied
  * (prefix masks, diagonal excluded), which is what the reference's samplers produce
- * (sampling.py:193-201).  max_chunk: low 16 bits = sources per directed edge work item, high 16 bits =
- * offsets per pair work item of the symmetric path (0 = defaults 8 / 2). */
+ * (sampling.py:193-201).  max_chunk packs three work-item sizes (0 in a field = automatic): bits 0-15 sources per
+ * directed edge work item (embeddings, directed update; default 8), bits 16-23 pair offsets per item of the pair update
+ * kernel (default 1), bits 24-31 pair offsets per item of the fused attention kernel (default 6, fewer for batches that
+ * would not fill the chip). */
 int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes_host, int max_chunk,
                      jodo_plan** out);
 void jodo_plan_destroy(jodo_plan* plan);
@@ -143,13 +147,14 @@ enum jodo_plan_option {
     JODO_OPT_DIR_SPLIT = 1,       /* 1 (default): pair-update items of a launch's sparsely filled last round get two workgroups,
                                      one per direction; 0: one workgroup per item */
     JODO_OPT_NODE_POST_WAVES = 2, /* 0 (default): automatic; 1 / 2 / 4: waves per strip for every strip of k_node_post */
+    JODO_OPT_ATTN_VARIANT = 3,    /* nf 256 pair attention kernel, weight residency / hand-over granularity: 0, 1, 2 (dgt_kernels_attn.h) */
     JODO_OPT_COUNT
 };
 int jodo_plan_set_option(jodo_plan* plan, int option, int value);
 
 /* debug: copy an internal per-block intermediate out of the workspace after a forward.
- * what: 0 = h [Nn,D], 1 = e [rows,De], 2 = pos [Nn,4] (raw, not centred), 3 = hhat [Nn,D] of the last
- * block run.  dst must hold the full array; returns element count via *count. */
+ * what: 0 = h [Nn,D], 1 = e [rows,De], 2 = pos [Nn,4] (raw, not centred), 3 = the attention partials
+ * [Nn, parts, D] (unnormalised) of the last block run, 5 = the modulation row, 6 = q.  dst must hold the full array; returns element count via *count. */
 int jodo_debug_fetch(jodo_plan* plan, const void* workspace, int what, float* dst_dev, int64_t* count,
                      void* stream);
 /* limit the number of DGT blocks executed by jodo_dgt_forward (tests; <0 = all) */

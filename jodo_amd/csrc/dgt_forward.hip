@@ -200,7 +200,13 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
             // fused attention edge phase (dgt_kernels_attn.h): pair-mode items do the work for symmetric inputs, directed-mode
             // items for asymmetric inputs and for molecules larger than a group (device flag; the other launch exits at once)
             ProfScope ps(p, st, JODO_PROF_EDGE_ATTN);
-            if (p->n_aitems > 0) LAUNCH((k_edge_attn<D, !TUNED, true>), p->n_aitems, ATT_WAVES * 64, A);
+            if (p->n_aitems > 0) {
+                const int var = TUNED ? p->opt[JODO_OPT_ATTN_VARIANT] : 0;
+                if (var == 1) LAUNCH((k_edge_attn<D, !TUNED, true, TUNED ? 1 : 0>), p->n_aitems, ATT_WAVES * 64, A);
+                else if (var == 2) LAUNCH((k_edge_attn<D, !TUNED, true, TUNED ? 2 : 0>), p->n_aitems, ATT_WAVES * 64, A);
+                else if (var == 3) LAUNCH((k_edge_attn<D, !TUNED, true, TUNED ? 3 : 0>), p->n_aitems, ATT_WAVES * 64, A);
+                else LAUNCH((k_edge_attn<D, !TUNED, true, 0>), p->n_aitems, ATT_WAVES * 64, A);
+            }
             if (p->n_aditems > 0) LAUNCH((k_edge_attn<D, !TUNED, false>), p->n_aditems, ATT_WAVES * 64, A);
         }
         {

@@ -35,21 +35,31 @@ constexpr int ATT_WAVES = 4;
 constexpr int ATT_LANES = 128;
 constexpr float ATT_NEG = -3.0e38f;                    // "no source yet": exp(ATT_NEG - m) == 0 for every real m
 
-template <int D_, bool WQK_>
+template <int D_, bool WQK_, int VAR_ = 0>
 struct AttnT {
     static constexpr int D = D_, De = D_ / 4, NE = D_ / 128, HE = D_ / 8, ND = D_ / 32, HD = D_ / 2, C = D_ / 16;
     static constexpr bool WQK = WQK_;
-    static constexpr bool LDSW = !WQK_;                            // edge_emb + lin_edge0 resident in LDS
+    // weight residency / hand-over granularity (nf = 256, tuned arrangement only; the others stream everything):
+    //   VAR 0: edge_emb + lin_edge0 in LDS (96 KiB), messages handed over block by block (double buffered, a barrier each)
+    //   VAR 1: lin_edge0 in LDS (64 KiB), edge_emb streamed, messages handed over four blocks at a time (64 KiB)
+    //   VAR 2: everything streamed, all message blocks handed over at once (128 KiB)
+    //   VAR 3: edge_emb + the seven main blocks of lin_edge0 in LDS (88 KiB), its tail block streamed, four blocks per
+    //          hand-over (64 KiB): exactly the 160 KiB of a CU
+    static constexpr bool LDS_EE = !WQK_ && (VAR_ == 0 || VAR_ == 3);
+    static constexpr bool LDS_L0 = !WQK_ && VAR_ != 2;
+    static constexpr bool LDS_TAIL = LDS_L0 && VAR_ != 3;          // tail block of lin_edge0 (tuned arrangement) resident too
+    static constexpr int PHB = WQK_ ? 1 : (VAR_ == 0 ? 1 : (VAR_ == 2 ? D_ / 32 : 4));   // message blocks per hand-over phase
     static constexpr int NQB = WQK_ ? 14 : 8;                      // 32-row blocks of q / k / lin_edge0
     static constexpr int KQE = D_ / 32;                            // weight quads per output block for K = De
     static constexpr int PG = (D_ % 256 == 0) ? 8 : 4;             // quads in flight (must divide KQE)
     static constexpr bool PH = (D_ / 16 == 16) && !(D_ > 256);     // C = 16: a half-lane's registers belong to heads 2b + half only, so it
     static constexpr int NS = PH ? 8 : 16;                         // tracks 8 heads (slot k = head 2k + half) instead of all 16
+    static constexpr bool PREF = !(D_ > 256);                      // request the next source's edge row one iteration ahead (D/8 registers)
     static constexpr bool LDSS = D_ > 256;                         // running softmax state in LDS (registers are short at nf = 384:
                                                                    // D/2 accumulators + D/8 inputs per lane; LDS is free, no resident weights)
     static constexpr float INV_SQRT_C = D_ == 256 ? 0.25f : (D_ == 384 ? 0.20412414523193150f : 0.f);
     static constexpr int M_EDGE = 6 * D_, M_GBF = 6 * D_ + 6 * (D_ / 4) + 2 * D_;
-    static_assert(!LDSW || D_ == 256, "LDS-resident weights are sized for nf = 256");
+    static_assert(!(LDS_EE || LDS_L0) || D_ == 256, "LDS-resident weights are sized for nf = 256");
     static_assert(C % 8 == 0, "message blocks are split at register 8 between two heads");
 };
 
@@ -92,23 +102,22 @@ __device__ __forceinline__ f32x16 attn_block(AttnW<X>& w, const float4* wl, unsi
 
 // et of an edge row from its state e and squared length d2 (GBF -> edge_emb -> LN1 -> modulate)
 template <typename X>
-__device__ __forceinline__ void attn_edge_input(const KArgs& A, AttnW<X>& w, const float* erow, float d2, float gscale, float gshift,
+__device__ __forceinline__ void attn_edge_input(const KArgs& A, AttnW<X>& w, const float (&e)[X::HE], float d2, float gscale, float gshift,
                                                 const float* mrow, int half, float (&x)[X::HE]) {
     const float* es1 = launder(mrow + X::M_EDGE);
     const float* ec1 = es1 + X::De;
     const float* cst = launder(A.W);
     const float* tab = cst + A.wb[JB_GBF];
     const float* bEE = cst + A.wb[JB_EE_B];
-    float G[X::HE], e[X::HE];
+    float G[X::HE];
     gbf_n<X::NE>(d2, gscale, gshift, tab, half, G);
-    load_nat<X::NE>(erow, half, e);
 #pragma unroll
     for (int b = 0; b < X::NE; ++b) {
         const unsigned cg = w.oEE + (unsigned)(b * 2 * X::KQE) * 1024, ce = cg + X::KQE * 1024;
         float bb[16];
         load16(bEE + b * 32 + half * 16, bb);
-        f32x16 acc = attn_block<X, X::LDSW>(w, w.wEE + (b * 2 * X::KQE) * 64, cg, ce, G, zero16());
-        acc = attn_block<X, X::LDSW>(w, w.wEE + ((b * 2 + 1) * X::KQE) * 64, ce, b + 1 < X::NE ? ce + X::KQE * 1024 : w.oL0, e, acc);
+        f32x16 acc = attn_block<X, X::LDS_EE>(w, w.wEE + (b * 2 * X::KQE) * 64, cg, ce, G, zero16());
+        acc = attn_block<X, X::LDS_EE>(w, w.wEE + ((b * 2 + 1) * X::KQE) * 64, ce, b + 1 < X::NE ? ce + X::KQE * 1024 : (X::LDS_L0 ? w.oL1 : w.oL0), e, acc);
 #pragma unroll
         for (int s = 0; s < 16; ++s) x[b * 16 + s] = acc[s] + bb[s];
     }
@@ -139,7 +148,7 @@ __device__ __forceinline__ void attn_scores(AttnW<X>& w, const float (&x)[X::HE]
         }
         pipeline_fence();
         const unsigned cur = w.oL0 + (unsigned)(b * X::KQE) * 1024;
-        f32x16 acc = attn_block<X, X::LDSW>(w, w.wL0 + (b * X::KQE) * 64, cur, b + 1 < X::NQB ? cur + X::KQE * 1024 : w.oL1, x, zero16());
+        f32x16 acc = attn_block<X, X::LDS_L0>(w, w.wL0 + (b * X::KQE) * 64, cur, b + 1 < X::NQB ? cur + X::KQE * 1024 : w.oL1, x, zero16());
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -157,7 +166,7 @@ __device__ __forceinline__ void attn_scores(AttnW<X>& w, const float (&x)[X::HE]
     }
     if constexpr (!X::WQK) {                           // tuned: half h of block b = head 2b + h (channels 0..15); tail block:
         float tl1[14], tl2[14];                        // register g of half h = head g, channel 16 + h
-        f32x16 acc = attn_block<X, X::LDSW>(w, w.wL0 + (7 * X::KQE) * 64, 0, 0, x, zero16());
+        f32x16 acc = attn_block<X, X::LDS_TAIL>(w, w.wL0 + (7 * X::KQE) * 64, w.oL0 + (unsigned)(7 * X::KQE) * 1024, w.oL1, x, zero16());
 #pragma unroll
         for (int g = 0; g < 14; ++g) {
             const float tt = tanh_f(acc[g]);
@@ -190,22 +199,21 @@ __device__ __forceinline__ void attn_pick_lds(const float* col, int b, int half,
 
 // PAIR = true: pair-mode items (ai_*), exits when the inputs are asymmetric; PAIR = false: directed-mode items (ad_*),
 // runs when the inputs are asymmetric or the item belongs to a molecule that spans several groups
-template <int D, bool WQK, bool PAIR>
+template <int D, bool WQK, bool PAIR, int VAR = 0>
 __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
-    using X = AttnT<D, WQK>;
+    using X = AttnT<D, WQK, VAR>;
+    constexpr bool PREF = X::PREF;
     const int it = blockIdx.x;
     const bool asym = A.flags[FLAG_ASYM] != 0;
     if (PAIR ? asym : !(asym || A.pd.ad_big[it])) return;
-    __shared__ float4 wl[X::LDSW ? (32 + 64) * 64 : 1];  // edge_emb (2 x 16 quads) | lin_edge0 (8 x 8 quads)
+    __shared__ float4 wl[(X::LDS_EE ? 32 * 64 : 0) + (X::LDS_L0 ? (X::LDS_TAIL ? 64 : 56) * 64 : 0) + (X::LDS_EE && !X::LDS_TAIL ? 0 : 1)];   // edge_emb (2 x 16 quads) | lin_edge0 (8 x 8 quads)
     __shared__ float4 sx[PAIR ? 2 * 256 : 1];            // scores handed to the partner: [quad][half * 128 + lane], heads 8h .. 8h + 7
-    __shared__ float4 ux[PAIR ? 2 * 4 * 256 : 1];        // unweighted messages of one 32-feature block, double buffered
+    __shared__ float4 ux[PAIR ? (X::PHB == 1 ? 2 : X::PHB) * 4 * 256 : 1];   // unweighted messages: one block double buffered, or a phase of PHB blocks
     __shared__ float stt[X::LDSS ? 5 * 16 * 256 : 1];    // per thread: running max, sum | rescale, p(own source), p(handed-over source)
     float* const stc = stt + threadIdx.x;                // element (k, h) of this thread at stc[(k * 16 + h) * 256]
-    if constexpr (X::LDSW) {
-        stage_weights<32, ATT_WAVES>(wl, reinterpret_cast<const float4*>(A.W + A.wb[JB_EE_W]));
-        stage_weights<64, ATT_WAVES>(wl + 32 * 64, reinterpret_cast<const float4*>(A.W + A.wb[JB_LE0_W]));
-        __syncthreads();
-    }
+    if constexpr (X::LDS_EE) stage_weights<32, ATT_WAVES>(wl, reinterpret_cast<const float4*>(A.W + A.wb[JB_EE_W]));
+    if constexpr (X::LDS_L0) stage_weights<(X::LDS_TAIL ? 64 : 56), ATT_WAVES>(wl + (X::LDS_EE ? 32 * 64 : 0), reinterpret_cast<const float4*>(A.W + A.wb[JB_LE0_W]));
+    if constexpr (X::LDS_EE || X::LDS_L0) __syncthreads();
     const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
     const int ln = wave * 32 + (lane & 31);             // lane of the group
     const int grp = PAIR ? A.pd.ai_group[it] : A.pd.ad_group[it];
@@ -223,10 +231,12 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
     const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
     AttnW<X> w;
     w.wEE = wl + lane;
-    w.wL0 = wl + (X::LDSW ? 32 * 64 : 0) + lane;
+    w.wL0 = wl + (X::LDS_EE ? 32 * 64 : 0) + lane;
     w.ws = make_wsrc(A.W, lane);
     w.oEE = (unsigned)(A.wb[JB_EE_W] * 4); w.oL0 = (unsigned)(A.wb[JB_LE0_W] * 4); w.oL1 = (unsigned)(A.wb[JB_LE1_W] * 4);
-    wpipe_prime(w.wp, w.ws, X::LDSW ? w.oL1 : w.oEE);
+    // first block of the streamed ring of one iteration
+    const unsigned ring0 = !X::LDS_EE ? w.oEE : ((X::LDS_L0 && !X::LDS_TAIL) ? w.oL0 + (unsigned)(7 * X::KQE) * 1024 : w.oL1);
+    wpipe_prime(w.wp, w.ws, ring0);
     float sm[X::LDSS ? 1 : X::NS], sl[X::LDSS ? 1 : X::NS];   // running max / sum of this target (X::NS head slots)
     float macc[X::HD];
 #pragma unroll
@@ -237,38 +247,64 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
 #pragma unroll
     for (int s = 0; s < X::HD; ++s) macc[s] = 0.f;
     const int slot = half * ATT_LANES + ln;             // this lane's slot in the hand-over buffers
-    for (int t = t0; t < t1; ++t) {
-        // ---- who is the source ----
-        bool ok, rok = false;
-        int u, rln = ln;
-        size_t r_in, r_out = 0;                         // edge rows: (source -> this target), (this atom -> partner)
+    // the source of iteration t (pair mode: partner (i + t + 1) mod n and the lane that hands its result over)
+    struct Src { bool ok, rok; int u, rln; size_t r_in, r_out; };
+    auto source = [&](int t) {
+        Src S;
+        S.rok = false; S.rln = ln; S.r_out = 0;
         if (PAIR) {
             const PairLane P = pair_of(L, t + 1);
-            ok = P.ok; u = P.u; r_in = P.rji; r_out = P.rij;
+            S.ok = P.ok; S.u = P.u; S.r_in = P.rji; S.r_out = P.rij;
             const int d = t + 1;
             int rr = L.i - d;
             if (rr < 0) rr += L.n;
-            rok = L.valid && L.n > 1 && (2 * d < L.n || (2 * d == L.n && 2 * rr < L.n));   // did lane (i - d) evaluate {i - d, i}?
-            rln = rok ? lbase + rr : ln;
+            S.rok = L.valid && L.n > 1 && (2 * d < L.n || (2 * d == L.n && 2 * rr < L.n));   // did lane (i - d) evaluate {i - d, i}?
+            S.rln = S.rok ? lbase + rr : ln;
         } else {
             const bool inr = L.valid && t < L.n;
-            ok = inr && t != L.i;
+            S.ok = inr && t != L.i;
             const int tc = inr ? t : 0;
-            u = L.noff + tc;
-            r_in = (size_t)L.eoff + (size_t)tc * L.n + L.i;            // edge (source a = t) -> (target c = i)
+            S.u = L.noff + tc;
+            S.r_in = (size_t)L.eoff + (size_t)tc * L.n + L.i;          // edge (source a = t) -> (target c = i)
         }
-        const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[u];
+        return S;
+    };
+    // Per-source inputs that come straight from HBM (the edge row is read once per block by exactly one lane) are
+    // requested one iteration ahead: the row of iteration t + 1 is in flight while iteration t computes.
+    // pair mode reads row (i, j) like the other pair kernels (the state is symmetric); directed mode the true row
+    Src cur = source(t0 < t1 ? t0 : 0);
+    float e[X::HE];
+    float4 pu = make_float4(0.f, 0.f, 0.f, 0.f);
+    int f1 = 0, f2 = 0;
+    auto request = [&]() {
+        load_nat<X::NE>(A.e + (PAIR ? cur.r_out : cur.r_in) * X::De, half, e);
+        pu = reinterpret_cast<const float4*>(A.pos_out)[cur.u];
+        f1 = A.eflag[cur.r_in];
+        if (PAIR) f2 = A.eflag[cur.r_out];
+    };
+    if constexpr (PREF) request();
+    for (int t = t0; t < t1; ++t) {
+        if constexpr (!PREF) {                         // registers are short: request at the point of use
+            cur = source(t);
+            request();
+        }
+        const bool ok = cur.ok, rok = cur.rok;
+        const int u = cur.u, rln = cur.rln;
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
+        const int fl1 = f1, fl2 = f2;
         float x[X::HE];
-        // pair mode reads row (i, j) like the other pair kernels (the state is symmetric); directed mode the true row
-        attn_edge_input<X>(A, w, A.e + (PAIR ? r_out : r_in) * X::De, dx * dx + dy * dy + dz * dz, gscale, gshift, mrow, half, x);
+        attn_edge_input<X>(A, w, e, dx * dx + dy * dy + dz * dz, gscale, gshift, mrow, half, x);
+        if constexpr (PREF) {
+            cur = source(t + 1 < t1 ? t + 1 : t);      // next source: its row, position and flags are requested now
+            request();
+        }
         // ---- scores ----
         const BRow qi = brow(A.q, X::NQB, L.v, half), ki = brow(A.k, X::NQB, L.v, half);
         const BRow qj = brow(A.q, X::NQB, u, half), kj = brow(A.k, X::NQB, u, half);
         float Sa[X::NS], R[X::LDSS ? 1 : X::NS];           // scores of the own source / of the handed-over source per head slot
         {
             float S1[16], S2[16];
-            attn_scores<X, PAIR>(w, x, qi, ki, qj, kj, half, A.eflag[r_in], PAIR ? A.eflag[r_out] : 0, S1, S2);
+            attn_scores<X, PAIR>(w, x, qi, ki, qj, kj, half, fl1, fl2, S1, S2);
             float Sb[X::NS];
 #pragma unroll
             for (int k = 0; k < X::NS; ++k) {
@@ -333,25 +369,12 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
                 bload16(vj, b + 1, vjn);
                 if (PAIR) bload16(vi, b + 1, vin);
             }
+            if (PAIR && X::PHB > 1 && b > 0 && b % X::PHB == 0) __syncthreads();      // the previous phase has been read everywhere
             const unsigned cur = w.oL1 + (unsigned)(b * X::KQE) * 1024;
-            f32x16 acc = mfma_block_p<X::KQE>(w.wp, w.ws, cur, b + 1 < X::ND ? cur + X::KQE * 1024 : (X::LDSW ? w.oL1 : w.oEE), x, zero16());
+            f32x16 acc = mfma_block_p<X::KQE>(w.wp, w.ws, cur, b + 1 < X::ND ? cur + X::KQE * 1024 : ring0, x, zero16());
             float T[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) T[s] = tanh_f(acc[s]);
-            float um[16];
-            if (PAIR) {
-                float4* ub = ux + (b & 1) * 4 * 256;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    ub[q * 256 + slot] = make_float4(T[q * 4 + 0] * vo[q * 4 + 0], T[q * 4 + 1] * vo[q * 4 + 1],
-                                                     T[q * 4 + 2] * vo[q * 4 + 2], T[q * 4 + 3] * vo[q * 4 + 3]);
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 r4 = ub[q * 256 + rslot];
-                    um[q * 4 + 0] = r4.x; um[q * 4 + 1] = r4.y; um[q * 4 + 2] = r4.z; um[q * 4 + 3] = r4.w;
-                }
-            }
             float sc_lo, sc_hi, p1_lo, p1_hi, p2_lo = 0.f, p2_hi = 0.f;
             if constexpr (X::LDSS) {
                 attn_pick_lds<X>(stc + 32 * 256, b, half, sc_lo, sc_hi);
@@ -365,11 +388,36 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
                 attn_pick<X>(p1, b, half, p1_lo, p1_hi);
                 if (PAIR) attn_pick<X>(p2, b, half, p2_lo, p2_hi);
             }
+            if (PAIR) {                                 // this atom's unweighted message for the partner's accumulator
+                float4* ub = ux + (X::PHB == 1 ? (b & 1) : (b % X::PHB)) * 4 * 256;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                float a = fmaf(macc[b * 16 + s], s < 8 ? sc_lo : sc_hi, (s < 8 ? p1_lo : p1_hi) * (T[s] * vv[s]));
-                if (PAIR) a = fmaf(s < 8 ? p2_lo : p2_hi, um[s], a);
-                macc[b * 16 + s] = a;
+                for (int q = 0; q < 4; ++q)
+                    ub[q * 256 + slot] = make_float4(T[q * 4 + 0] * vo[q * 4 + 0], T[q * 4 + 1] * vo[q * 4 + 1],
+                                                     T[q * 4 + 2] * vo[q * 4 + 2], T[q * 4 + 3] * vo[q * 4 + 3]);
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s)                // own source
+                macc[b * 16 + s] = fmaf(macc[b * 16 + s], s < 8 ? sc_lo : sc_hi, (s < 8 ? p1_lo : p1_hi) * (T[s] * vv[s]));
+            if (PAIR && (b + 1) % X::PHB == 0) {        // end of a hand-over phase: the partners' messages of its blocks
+                __syncthreads();
+#pragma unroll
+                for (int bb = b + 1 - X::PHB; bb <= b; ++bb) {
+                    const float4* ub = ux + (X::PHB == 1 ? (bb & 1) : (bb % X::PHB)) * 4 * 256;
+                    float q_lo = p2_lo, q_hi = p2_hi;
+                    if constexpr (X::PHB > 1) {
+                        if constexpr (X::PH) { q_lo = q_hi = p2[bb]; }
+                        else if constexpr (X::LDSS) attn_pick_lds<X>(stc + 64 * 256, bb, half, q_lo, q_hi);
+                        else attn_pick<X>(p2, bb, half, q_lo, q_hi);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 r4 = ub[q * 256 + rslot];
+                        macc[bb * 16 + q * 4 + 0] = fmaf(q * 4 + 0 < 8 ? q_lo : q_hi, r4.x, macc[bb * 16 + q * 4 + 0]);
+                        macc[bb * 16 + q * 4 + 1] = fmaf(q * 4 + 1 < 8 ? q_lo : q_hi, r4.y, macc[bb * 16 + q * 4 + 1]);
+                        macc[bb * 16 + q * 4 + 2] = fmaf(q * 4 + 2 < 8 ? q_lo : q_hi, r4.z, macc[bb * 16 + q * 4 + 2]);
+                        macc[bb * 16 + q * 4 + 3] = fmaf(q * 4 + 3 < 8 ? q_lo : q_hi, r4.w, macc[bb * 16 + q * 4 + 3]);
+                    }
+                }
             }
         }
     }

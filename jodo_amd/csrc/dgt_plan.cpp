@@ -82,11 +82,10 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
             delete p;
             return jodo_set_error(JODO_ERR_ARG, "plan_create: n_nodes[%d]=%d outside [1,%d]", b, n_nodes[b], N);
         }
-    // low 16 bits: sources per directed work item (default 8); high 16 bits: pair offsets per pair work
-    // item (default 2: the pair kernels write per-edge results, so small items cost nothing downstream)
-    // bits 16-23: pair offsets per item of the pair UPDATE kernel (default 1: long iterations, balance
-    // matters most); bits 24-31: the same for the pair SCORES kernel (default 4: short iterations, the
-    // per-item prologue and the per-workgroup LDS weight staging must be amortised)
+    // bits 0-15: sources per directed work item (default 8); bits 16-23: pair offsets per item of the pair UPDATE
+    // kernel (default 1: long iterations, balance matters most); bits 24-31: pair offsets per item of the fused
+    // attention kernel (default 6: its per-item cost — 96 KiB of weights staged into LDS, 1 KiB of partial per atom —
+    // must be amortised, see below)
     int pair_chunk = (max_chunk >> 16) & 0xff, spair_chunk = (max_chunk >> 24) & 0xff;
     max_chunk &= 0xffff;
     if (max_chunk <= 0) {
@@ -112,9 +111,8 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     }
     if (pair_chunk <= 0) pair_chunk = 1;     // measured best on MI355X (QM9 B=2500: 26.7 ms/step vs 27.7 at 2)
     const bool spair_auto = spair_chunk <= 0;
-    if (spair_chunk <= 0) spair_chunk = 2;   // 4-wave workgroups stage 96 KiB of weights: 2 offsets per item (sweep: 1 -> 2.97, 2 -> 2.71, 3 -> 2.85 ms/step)
     p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->last_e_buf = 0;
-    p->opt[JODO_OPT_FUSE_NEXT_QKV] = 1; p->opt[JODO_OPT_DIR_SPLIT] = 1; p->opt[JODO_OPT_NODE_POST_WAVES] = 0;
+    p->opt[JODO_OPT_FUSE_NEXT_QKV] = 1; p->opt[JODO_OPT_DIR_SPLIT] = 1; p->opt[JODO_OPT_NODE_POST_WAVES] = 0; p->opt[JODO_OPT_ATTN_VARIANT] = 0;
     p->prof_enabled = 0; p->force_directed = 0; p->dbg_timing = nullptr;
 
     // molecules by descending size (stable): neighbouring lanes share n, big work first

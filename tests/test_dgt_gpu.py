@@ -90,6 +90,29 @@ def test_hip_matches_oracle(cfg_name, n_nodes, gain, chunk, over):
         close(got[1], want[1], atol=5e-5)
 
 
+def test_attention_kernel_variants_agree():
+    """The nf = 256 pair attention kernel exists in four weight-residency / hand-over variants (JODO_OPT_ATTN_VARIANT,
+    dgt_kernels_attn.h): same arithmetic in the same order, so bit-equal outputs, and all match the oracle."""
+    cfg = make_config('vpsde_qm9_uncond_jodo')
+    hp = O.Hyper.from_config(cfg)
+    n_nodes = [29, 1, 2, 18, 18, 7, 23, 12, 12, 9] * 4
+    xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=31)
+    outs = []
+    for var in (0, 1, 2, 3):
+        model = make_model(cfg, 5, DEV, gain=1.5, coord_scale=0.05)
+        model.plan_options = {3: var}
+        o1 = run(model, xh, ex, nl, nm, em)
+        outs.append(run(model, xh, ex, nl, nm, em, o1[0], o1[1]))
+    sd = state_dict_cpu(model)
+    with torch.no_grad():
+        r1 = O.forward_dense(sd, hp, xh, nm, em, ex, None, None, nl)
+        r2 = O.forward_dense(sd, hp, xh, nm, em, ex, r1[0], r1[1], nl)
+    close(outs[0][0], r2[0], atol=5e-5)
+    close(outs[0][1], r2[1], atol=5e-5)
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+
+
 def test_uniform_and_per_molecule_noise_levels_agree():
     cfg = make_config('vpsde_qm9_uncond_jodo')
     model = make_model(cfg, 9, DEV)
