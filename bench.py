@@ -29,6 +29,7 @@ The JSON line also carries
                 (rank 0, N = 1 only); calibration of the port against the real reference: BASELINE.md §3
 """
 import argparse
+import contextlib
 import ctypes
 import json
 import os
@@ -125,7 +126,7 @@ def cpu_baseline(seed=42, steps=50, batch=64):
                 config1_wall_s=wall, config1_molecules_per_s=batch / wall, ms_per_step=wall / steps * 1e3,
                 cpu=cpu_model(), cpu_count=ncpu,
                 threads_note='min(cpu_count, 32): with all 256 hardware threads of the round-2 box the same port ran 170x slower '
-                             '(162.9 vs 0.96 s/step, profiles/r02_bench_qm9.json of commit "bench: config-1 CPU baseline")',
+                             '(162.9 vs 0.96 s/step: thread_probe_s_per_step in profiles/r02_bench_qm9_baseline.json)',
                 calibration='port vs the real reference on this config: see BASELINE.md §3 (build container, 8 threads)')
 
 
@@ -362,7 +363,8 @@ def main():
                                      prop_dist=_SyntheticContext(hp.cond_ch) if hp.cond_ch else None, return_raw=True, hip_graph=hg)
                 torch.cuda.synchronize()
                 tr = time.perf_counter()
-                mols = fn(model)
+                with contextlib.redirect_stdout(sys.stderr):      # the sampler prints its progress like the reference does;
+                    mols = fn(model)                             # stdout carries the ONE JSON line only
                 torch.cuda.synchronize()
                 tr = time.perf_counter() - tr
                 full_round[mode] = {'round_seconds': tr, 'molecules': len(mols), 'value': len(mols) / tr, 'unit': 'molecules/s',
