@@ -8,7 +8,7 @@
 //   * score heads use the "one head per 32-row block" arrangement (jodo_amd/packing.py
 //     qk_out_map_wide): SC = 27 has no 16 + 2 split, and padding a head to 32 rows keeps its reduction
 //     in-lane (the attention edge phase itself is the width-generic k_edge_attn, dgt_kernels_attn.h);
-//   * the pair kernels park the shared part of input_lin in private (scratch) memory instead of LDS.
+//   * the pair update parks half of the shared part of input_lin in LDS at D = 384 (registers hold the rest).
 // Instantiated for D = 384; D = 256 is instantiated too so that the whole set can be pinned against
 // the tuned kernels and the nf = 256 fixtures (jodo_cfg.layout = 1, tests only).
 #pragma once
@@ -481,7 +481,11 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
     const unsigned oro = (unsigned)(A.wb[JB_ERO_W] * 4), oi = (unsigned)(A.wb[JB_INE_W] * 4), o0 = (unsigned)(A.wb[JB_C0_W] * 4);
     WPipe<X::PG> wp;
     wpipe_prime(wp, ws, o3);
-    float park[X::HD];                                      // S = shared part of input_lin, kept for both directions
+    // S = shared part of input_lin, kept for both directions: in registers; at nf = 384 (192 values per lane next to the 192
+    // of u) the upper half is parked in LDS instead (24 KiB per one-wave workgroup, four per CU) — spilled to scratch before
+    constexpr int PLB = D > 256 ? X::ND / 2 : 0;            // blocks parked in LDS
+    __shared__ float4 pl[PLB > 0 ? PLB * 4 * 64 : 1];
+    float park[(X::ND - PLB) * 16];
     PT_INIT
     for (int t = t0; t < t1; ++t) {
         const PairLane P = pair_of(L, t + 1);
@@ -580,7 +584,14 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             f32x16 acc = mfma_block_p<X::KQE>(wp, ws, we, wg_, en, zero16());
             acc = mfma_block_p<X::KQE>(wp, ws, wg_, b + 1 < X::ND ? wg_ + X::KQE * 1024 : o0, G, acc);
 #pragma unroll
-            for (int s = 0; s < 16; ++s) park[b * 16 + s] = acc[s];
+            for (int s = 0; s < 16; ++s) {
+                if (b < X::ND - PLB) park[(b < X::ND - PLB ? b : 0) * 16 + s] = acc[s];
+            }
+            if (b >= X::ND - PLB) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    pl[((b - (X::ND - PLB)) * 4 + q) * 64 + lane] = make_float4(acc[q * 4 + 0], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
+            }
         }
         PT(3);
         // ---- two directed evaluations: u = S + W_row h_a + W_col h_c -> LN -> modulate -> coord_mlp ----
@@ -590,22 +601,38 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             BRow ra = wrow_i, rc = wcol_j;
             if (dir == 1) { ra.voff = wrow_j.voff; rc.voff = wcol_i.voff; }
             float uu[X::HD];
-            // the per-node rows are requested four blocks at a time (buffer loads, pinned by the fence) and only
+            // the per-node rows are requested GB blocks at a time (buffer loads, pinned by the fence) and only
             // then consumed — see BRow in dgt_device.h
+            constexpr int GB = D == 256 ? 4 : 2;          // blocks per gather group (registers are shorter at nf = 384)
 #pragma unroll
-            for (int g = 0; g < X::ND / 4; ++g) {
-                float a1[64], a2[64];
+            for (int g = 0; g < X::ND / GB; ++g) {
+                float a1[GB * 16], a2[GB * 16];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < GB; ++k) {
                     float t1[16], t2[16];
-                    bload16(ra, g * 4 + k, t1);
-                    bload16(rc, g * 4 + k, t2);
+                    bload16(ra, g * GB + k, t1);
+                    bload16(rc, g * GB + k, t2);
 #pragma unroll
                     for (int s = 0; s < 16; ++s) { a1[k * 16 + s] = t1[s]; a2[k * 16 + s] = t2[s]; }
                 }
                 pipeline_fence();
 #pragma unroll
-                for (int s = 0; s < 64; ++s) uu[g * 64 + s] = park[g * 64 + s] + (a1[s] + a2[s]);
+                for (int k = 0; k < GB; ++k) {
+                    const int b = g * GB + k;
+                    float pk[16];
+                    if (b < X::ND - PLB) {
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) pk[s] = park[(b < X::ND - PLB ? b : 0) * 16 + s];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 t = pl[((b - (X::ND - PLB)) * 4 + q) * 64 + lane];
+                            pk[q * 4 + 0] = t.x; pk[q * 4 + 1] = t.y; pk[q * 4 + 2] = t.z; pk[q * 4 + 3] = t.w;
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) uu[b * 16 + s] = pk[s] + (a1[k * 16 + s] + a2[k * 16 + s]);
+                }
             }
             PT(6);
             layer_norm<X::HD>(uu);
