@@ -49,8 +49,10 @@ WORKLOADS = {
                  name='GEOM-Drugs uncond JODO medium (nf=256 L=10), 1000-step ancestral, batch 512 per GPU'),
     'geom384': dict(cfg='vpsde_geom_uncond_jodo', info='geom_with_h_1', batch=1250, nf=384,
                     name='GEOM-Drugs uncond JODO large (nf=384 L=10), 1000-step ancestral, batch 1250 per GPU'),
-    'cond': dict(cfg='vpsde_qm9_cond_jodo', info='qm9_second_half', batch=313,
-                 name='QM9 cond JODO (cond_DGT_concat), ancestral steps, batch 313 per GPU'),
+    # BASELINE configs[4]: 10 000 molecules over 8 GPUs.  get_sampling_fn(shard=...) deals the molecules to the ranks before
+    # cutting rounds, so a GPU runs ONE round of 1250 (round 1 ran four rounds of 313: --batch 313 reproduces that)
+    'cond': dict(cfg='vpsde_qm9_cond_jodo', info='qm9_second_half', batch=1250,
+                 name='QM9 cond JODO (cond_DGT_concat), ancestral steps, batch 1250 per GPU'),
 }
 PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 SAMPLING_STEPS = 1000
