@@ -42,7 +42,8 @@ void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
     A.dpos = ws_ptr<float>(ws, w.dpos); A.cpos = ws_ptr<float>(ws, w.cpos); A.feat = ws_ptr<float>(ws, w.feat);
     A.h = ws_ptr<float>(ws, w.h); A.hhat = ws_ptr<float>(ws, w.hhat); A.astat = ws_ptr<float>(ws, w.astat); A.q = ws_ptr<float>(ws, w.q);
     A.k = ws_ptr<float>(ws, w.k); A.v = ws_ptr<float>(ws, w.v); A.n2e = ws_ptr<float>(ws, w.n2e);
-    A.wrow = ws_ptr<float>(ws, w.wrow); A.wcol = ws_ptr<float>(ws, w.wcol); A.ahid = ws_ptr<float>(ws, w.ahid);
+    A.wrow = ws_ptr<float>(ws, w.wrow); A.wcol = ws_ptr<float>(ws, w.wcol); A.ua = ws_ptr<float>(ws, w.ua); A.ub = ws_ptr<float>(ws, w.ub);
+    A.rmean = ws_ptr<float>(ws, w.rmean); A.ahid = ws_ptr<float>(ws, w.ahid);
     A.apred = ws_ptr<float>(ws, w.apred);
     A.eflag = ws_ptr<int>(ws, w.eflag); A.e = ws_ptr<float>(ws, w.e);
     A.ehid = ws_ptr<float>(ws, w.ehid); A.epred = ws_ptr<float>(ws, w.epred);
@@ -93,7 +94,8 @@ template <int D>
 int launch_update_sym(jodo_plan* p, hipStream_t st, KArgs& A) {
     const DgtDims& d = p->dims;
     const int full = (p->n_pitems / 1024) * 1024, rem = p->n_pitems - full;
-    const bool split = p->opt[JODO_OPT_DIR_SPLIT] != 0 && rem > 0 && rem <= 512;
+    // (nf = 256: the directions share coord_mlp.0 and their tails are short vector work — nothing to split)
+    const bool split = D != 256 && p->opt[JODO_OPT_DIR_SPLIT] != 0 && rem > 0 && rem <= 512;
     const int n1 = split ? full : p->n_pitems;
     A.item0 = 0; A.dir_split = 0;
     if (n1 > 0) { if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2>), n1, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4>), n1, 64, A); }
@@ -223,6 +225,8 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
             } else {
                 if (d.r == 2) LAUNCH((wide::k_node_post<D, 2>), p->n_strips, 64, A); else LAUNCH((wide::k_node_post<D, 4>), p->n_strips, 64, A);
             }
+            // per-node part of coord_mlp.0 pushed through the LayerNorm (pair update at nf = 256, dgt_kernels_wide.h)
+            if (D == 256 && p->n_pitems > 0) LAUNCH((wide::k_node_ab<D>), p->n_strips * 2, 64, A);
         }
         if (p->n_items > 0) {
             ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);          // exactly one of the two does the work (device flag)

@@ -25,7 +25,7 @@ struct KArgs {
     int pre_mode;                         // k_node_pre: 0 = also advance the positions, 1 = q/k/v only (k_pos_final did it)
     // workspace
     float *hid1, *temb, *mods, *condh, *condh2;
-    float *pos_in, *pos_out, *dpos, *cpos, *feat, *h, *hhat, *astat, *q, *k, *v, *n2e, *wrow, *wcol, *ahid, *apred;
+    float *pos_in, *pos_out, *dpos, *cpos, *feat, *h, *hhat, *astat, *q, *k, *v, *n2e, *wrow, *wcol, *ua, *ub, *rmean, *ahid, *apred;
     int* eflag;
     float *e, *ehid, *epred, *dposE;
     float* e_out;                         // edge state written by the update kernels (ping-pong with e: never in place,

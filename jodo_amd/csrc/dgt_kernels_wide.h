@@ -32,6 +32,7 @@ struct Dim {
     static constexpr int CEP = (D_ / 16 + 15) / 16 * 16;           // padded edge readout width (16 or 32)
     // modulation slice of one block: node 6 x D | edge 6 x De | equi (shift, scale) 2 x D | gbf (scale, shift)
     static constexpr int M_EDGE = 6 * D_, M_EQUI = 6 * D_ + 6 * (D_ / 4), M_GBF = 6 * D_ + 6 * (D_ / 4) + 2 * D_;
+    static constexpr int M_WG = M_GBF + 32, M_BS = M_WG + D_;      // coord_mlp.0 pushed through the LayerNorm: W0 (1 + sc) | W0 sh + b0
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -292,6 +293,45 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
     }
 }
 
+// coord_mlp.0 pushed through the LayerNorm of equi_update, per-node part (see k_edge_update_sym): piece 0: A = W0 (R (1 + sc)),
+// R = W_row h + b (A.wrow); piece 1: B = W0 (C (1 + sc)), C = W_col h (A.wcol); also the feature means of R and C, which
+// add up to the LayerNorm mean of a directed edge.  One (strip, piece) item per wave: 2 x n_strips items.
+template <int D>
+__global__ __launch_bounds__(64, 1) void k_node_ab(KArgs A) {
+    using X = Dim<D>;
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int strip = blockIdx.x >> 1, piece = blockIdx.x & 1;
+    const LaneNode L = lane_node(A, strip, j);
+    const float* qsc = mod_row(A, L.b) + A.mod_base + X::M_EQUI + D;       // equi_update.time_mlp: (shift, scale)
+    const TRow src = trow(piece == 0 ? A.wrow : A.wcol, X::ND, L.v, half);
+    float x[X::HD];
+    float sum = 0.f;
+#pragma unroll
+    for (int b = 0; b < X::ND; ++b) {
+        float t[16], g[16];
+        load16T(src, b, t);
+        load16(qsc + b * 32 + half * 16, g);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { sum += t[s]; x[b * 16 + s] = t[s] * (1.f + g[s]); }
+    }
+    const float mean = pair_sum(sum) * (1.f / D);
+    if (half == 0) A.rmean[(size_t)L.v * 2 + piece] = mean;
+    const WSrc ws = make_wsrc(A.W, lane);
+    const unsigned o0 = (unsigned)(A.wb[JB_C0_W] * 4);
+    WPipe<X::PG> wp;
+    wpipe_prime(wp, ws, o0);
+    float* dst = piece == 0 ? A.ua : A.ub;
+#pragma unroll 1
+    for (int b = 0; b < X::ND; ++b) {
+        const unsigned cur = o0 + (unsigned)b * X::KQD * 1024;
+        f32x16 acc = mfma_block_p<X::KQD>(wp, ws, cur, b + 1 < X::ND ? cur + X::KQD * 1024 : o0, x, zero16());
+        float r[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) r[s] = acc[s];
+        store16T(dst, X::ND, L.v, half, b, r);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // edge side (directed: rows r = eoff + a*n + c, a = source / row atom, c = target / column atom)
 template <int D, int R>
@@ -483,9 +523,10 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
     wpipe_prime(wp, ws, o3);
     // S = shared part of input_lin, kept for both directions: in registers; at nf = 384 (192 values per lane next to the 192
     // of u) the upper half is parked in LDS instead (24 KiB per one-wave workgroup, four per CU) — spilled to scratch before
+    constexpr bool HOIST = D == 256;                        // coord_mlp.0 once per pair (below); nf = 384 keeps one per direction
     constexpr int PLB = D > 256 ? X::ND / 2 : 0;            // blocks parked in LDS
     __shared__ float4 pl[PLB > 0 ? PLB * 4 * 64 : 1];
-    float park[(X::ND - PLB) * 16];
+    float park[HOIST ? 1 : (X::ND - PLB) * 16];
     PT_INIT
     for (int t = t0; t < t1; ++t) {
         const PairLane P = pair_of(L, t + 1);
@@ -577,99 +618,214 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             }
         }
         PT(2);
-        // ---- S = W_e e + W_d G, shared by both directions: parked per lane ----
+        if constexpr (HOIST) {
+            // ---- coord_mlp.0 pushed through the LayerNorm: ONE D x D projection per pair instead of one per direction ----
+            // u = LN(pre) (1 + sc) + sh with pre = S + R_a + C_c (R = W_row h + b, C = W_col h) is affine in pre once its
+            // mean / rstd are known:  y = coord_mlp.0(u) = [Z + A_a + B_c - mean * wg] * rstd + bs  with
+            //   Z = W0 (S (1 + sc))                  computed here, once per pair
+            //   A_a = W0 (R_a (1 + sc)), B_c = ...   per node, k_node_ab
+            //   wg = W0 (1 + sc), bs = W0 sh + b0    per molecule, rows of the modulation table (dgt_pack.cpp)
+            // What remains per direction is vector work: the LayerNorm statistics of pre and the SiLU / coord_mlp.2 tail.
+            // The statistics pass rides on the S projection and the tail pass on the Z projection, block by block: the
+            // per-node rows they gather are requested one block ahead and arrive behind 4k / 8k cycles of MFMAs.  The mean
+            // of pre is meanS + mean(R_a) + mean(C_c); only meanS is unknown while S is being produced, so the variance is
+            // accumulated around m0 = mean(R_a) + mean(C_c) and corrected: var = E[(pre - m0)^2] - meanS^2 (meanS is the
+            // mean of a bias-free projection of a normalised vector: small against the spread, no cancellation).
+            unsigned opq = 0;                                    // own rows do not depend on the pair offset: without an opaque
+            asm volatile("" : "+v"(opq));                        // offset LICM hoists and spills them
+            BRow ua_i = brow(A.ua, X::ND, L.v, half), ub_i = brow(A.ub, X::ND, L.v, half);
+            const BRow ua_j = brow(A.ua, X::ND, P.u, half), ub_j = brow(A.ub, X::ND, P.u, half);
+            BRow own_r = wrow_i, own_c = wcol_i;
+            ua_i.voff += opq; ub_i.voff += opq; own_r.voff += opq; own_c.voff += opq;
+            const float m00 = A.rmean[(size_t)L.v * 2] + A.rmean[(size_t)P.u * 2 + 1];          // direction 0: a = i, c = j
+            const float m01 = A.rmean[(size_t)P.u * 2] + A.rmean[(size_t)L.v * 2 + 1];          // direction 1: a = j, c = i
+            float sg[X::HD];
+            float ssum = 0.f, q0 = 0.f, q1 = 0.f;
+            float n0[16], n1[16], n2[16], n3[16];
+            bload16(own_r, 0, n0); bload16(wcol_j, 0, n1); bload16(wrow_j, 0, n2); bload16(own_c, 0, n3);
 #pragma unroll
-        for (int b = 0; b < X::ND; ++b) {
-            const unsigned we = oi + (unsigned)(b * 2 * X::KQE) * 1024, wg_ = we + X::KQE * 1024;
-            f32x16 acc = mfma_block_p<X::KQE>(wp, ws, we, wg_, en, zero16());
-            acc = mfma_block_p<X::KQE>(wp, ws, wg_, b + 1 < X::ND ? wg_ + X::KQE * 1024 : o0, G, acc);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                if (b < X::ND - PLB) park[(b < X::ND - PLB ? b : 0) * 16 + s] = acc[s];
-            }
-            if (b >= X::ND - PLB) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    pl[((b - (X::ND - PLB)) * 4 + q) * 64 + lane] = make_float4(acc[q * 4 + 0], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
-            }
-        }
-        PT(3);
-        // ---- two directed evaluations: u = S + W_row h_a + W_col h_c -> LN -> modulate -> coord_mlp ----
-#pragma unroll 1
-        for (int dir = 0; dir < 2; ++dir) {
-            if (dsel >= 0 && dir != dsel) continue;
-            BRow ra = wrow_i, rc = wcol_j;
-            if (dir == 1) { ra.voff = wrow_j.voff; rc.voff = wcol_i.voff; }
-            float uu[X::HD];
-            // the per-node rows are requested GB blocks at a time (buffer loads, pinned by the fence) and only
-            // then consumed — see BRow in dgt_device.h
-            constexpr int GB = D == 256 ? 4 : 2;          // blocks per gather group (registers are shorter at nf = 384)
-#pragma unroll
-            for (int g = 0; g < X::ND / GB; ++g) {
-                float a1[GB * 16], a2[GB * 16];
-#pragma unroll
-                for (int k = 0; k < GB; ++k) {
-                    float t1[16], t2[16];
-                    bload16(ra, g * GB + k, t1);
-                    bload16(rc, g * GB + k, t2);
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) { a1[k * 16 + s] = t1[s]; a2[k * 16 + s] = t2[s]; }
-                }
-                pipeline_fence();
-#pragma unroll
-                for (int k = 0; k < GB; ++k) {
-                    const int b = g * GB + k;
-                    float pk[16];
-                    if (b < X::ND - PLB) {
-#pragma unroll
-                        for (int s = 0; s < 16; ++s) pk[s] = park[(b < X::ND - PLB ? b : 0) * 16 + s];
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float4 t = pl[((b - (X::ND - PLB)) * 4 + q) * 64 + lane];
-                            pk[q * 4 + 0] = t.x; pk[q * 4 + 1] = t.y; pk[q * 4 + 2] = t.z; pk[q * 4 + 3] = t.w;
-                        }
-                    }
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) uu[b * 16 + s] = pk[s] + (a1[k * 16 + s] + a2[k * 16 + s]);
-                }
-            }
-            PT(6);
-            layer_norm<X::HD>(uu);
-            modulate<X::ND>(uu, qsh_, qsc_, half);
-            PT(4);
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-#pragma unroll 1
             for (int b = 0; b < X::ND; ++b) {
-                const unsigned wcur = o0 + (unsigned)b * X::KQD * 1024;
-                const unsigned wnx = b + 1 < X::ND ? wcur + X::KQD * 1024 : ((dir == 0 && dsel < 0) ? o0 : o3);
-                float bb[16], k0[16], k1[16], k2[16];
-                load16(b0_ + b * 32 + half * 16, bb);
-                load16(w2_ + b * 32 + half * 16, k0);
-                load16(w2_ + D + b * 32 + half * 16, k1);
-                load16(w2_ + 2 * D + b * 32 + half * 16, k2);
-                f32x16 acc = mfma_block_p<X::KQD>(wp, ws, wcur, wnx, uu, zero16());
+                const unsigned we = oi + (unsigned)(b * 2 * X::KQE) * 1024, wg_ = we + X::KQE * 1024;
+                float g[16], t0[16], t1[16];
+                load16(qsc_ + b * 32 + half * 16, g);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) { t0[s] = (n0[s] + n1[s]) - m00; t1[s] = (n2[s] + n3[s]) - m01; }
+                if (b + 1 < X::ND) { bload16(own_r, b + 1, n0); bload16(wcol_j, b + 1, n1); bload16(wrow_j, b + 1, n2); bload16(own_c, b + 1, n3); }
+                else { bload16(ua_i, 0, n0); bload16(ub_j, 0, n1); bload16(ua_j, 0, n2); bload16(ub_i, 0, n3); }    // first block of the tail
+                f32x16 acc = mfma_block_p<X::KQE>(wp, ws, we, wg_, en, zero16());
+                acc = mfma_block_p<X::KQE>(wp, ws, wg_, b + 1 < X::ND ? wg_ + X::KQE * 1024 : o0, G, acc);
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
-                    const float ys = silu_f(acc[s] + bb[s]);
-                    c0 = fmaf(ys, k0[s], c0);
-                    c1 = fmaf(ys, k1[s], c1);
-                    c2 = fmaf(ys, k2[s], c2);
+                    const float sv = acc[s];
+                    ssum += sv;
+                    sg[b * 16 + s] = sv * (1.f + g[s]);
+                    const float d0 = sv + t0[s], d1 = sv + t1[s];
+                    q0 = fmaf(d0, d0, q0);
+                    q1 = fmaf(d1, d1, q1);
                 }
             }
-            PT(dir == 0 ? 5 : 7);
-            c0 = tanh_f(pair_sum(c0));
-            c1 = tanh_f(pair_sum(c1));
-            c2 = tanh_f(pair_sum(c2));
-            const size_t rr = dir == 0 ? P.rij : P.rji;
-            const int fl = A.eflag[rr];
-            const float iota = (c0 + ((fl & 1) ? c1 : 0.f) + ((fl & 2) ? c2 : 0.f)) * (1.f / 3.f);
+            const float meanS = pair_sum(ssum) * (1.f / D);
+            const float rstd0 = __builtin_amdgcn_rsqf(fmaxf(pair_sum(q0) * (1.f / D) - meanS * meanS, 0.f) + 1e-6f);
+            const float rstd1 = __builtin_amdgcn_rsqf(fmaxf(pair_sum(q1) * (1.f / D) - meanS * meanS, 0.f) + 1e-6f);
+            const float mr0 = (meanS + m00) * rstd0, mr1 = (meanS + m01) * rstd1;
+            PT(3);
+            const float* wg_v = launder(mrow + X::M_WG);
+            const float* bs_v = wg_v + D;
+            float c00 = 0.f, c01 = 0.f, c02 = 0.f, c10 = 0.f, c11 = 0.f, c12 = 0.f;
+#pragma unroll 1
+            for (int b = 0; b < X::ND; ++b) {
+                float t0[16], t1[16], wgb[16], bsb[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) { t0[s] = n0[s] + n1[s]; t1[s] = n2[s] + n3[s]; }
+                {                                                // next block's rows (the last iteration re-requests its own)
+                    const int bn = b + 1 < X::ND ? b + 1 : b;
+                    bload16(ua_i, bn, n0); bload16(ub_j, bn, n1); bload16(ua_j, bn, n2); bload16(ub_i, bn, n3);
+                }
+                load16(wg_v + b * 32 + half * 16, wgb);
+                load16(bs_v + b * 32 + half * 16, bsb);
+                const unsigned wcur = o0 + (unsigned)b * X::KQD * 1024;
+                f32x16 z = mfma_block_p<X::KQD>(wp, ws, wcur, b + 1 < X::ND ? wcur + X::KQD * 1024 : o3, sg, zero16());
+                // vector tail of this block, one direction after the other and eight registers at a time (fences keep the
+                // compiler from evaluating all 32 SiLUs at once: their temporaries would not fit the 256 arch VGPRs)
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {
+                    float k0[8], k1[8], k2[8], ca[8];
+                    auto ld8 = [&](const float* p8, float (&r)[8]) {
+                        const float4 a = reinterpret_cast<const float4*>(p8)[0], c = reinterpret_cast<const float4*>(p8)[1];
+                        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = c.x; r[5] = c.y; r[6] = c.z; r[7] = c.w;
+                    };
+                    const int fo = b * 32 + half * 16 + hq * 8;
+                    ld8(w2_ + fo, k0); ld8(w2_ + D + fo, k1); ld8(w2_ + 2 * D + fo, k2);
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) ca[s] = fmaf(-mr0, wgb[hq * 8 + s], bsb[hq * 8 + s]);
+                    pipeline_fence();
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        const float ys0 = silu_f(fmaf(z[hq * 8 + s] + t0[hq * 8 + s], rstd0, ca[s]));
+                        c00 = fmaf(ys0, k0[s], c00); c01 = fmaf(ys0, k1[s], c01); c02 = fmaf(ys0, k2[s], c02);
+                    }
+                    pipeline_fence();
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) ca[s] = fmaf(-mr1, wgb[hq * 8 + s], bsb[hq * 8 + s]);
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        const float ys1 = silu_f(fmaf(z[hq * 8 + s] + t1[hq * 8 + s], rstd1, ca[s]));
+                        c10 = fmaf(ys1, k0[s], c10); c11 = fmaf(ys1, k1[s], c11); c12 = fmaf(ys1, k2[s], c12);
+                    }
+                    pipeline_fence();
+                }
+            }
+            PT(5);
             const float nrm = fmaxf(sqrtf(d2), 1e-8f);
-            const float f = cscale * iota / nrm;
-            const float sgn = dir == 0 ? 1.f : -1.f;          // x_a - x_c
-            if (P.ok && half == 0)
-                reinterpret_cast<float4*>(A.dposE)[rr] = make_float4(sgn * dx * f, sgn * dy * f, sgn * dz * f, 0.f);
+#pragma unroll
+            for (int dir = 0; dir < 2; ++dir) {
+                const float c0 = tanh_f(pair_sum(dir == 0 ? c00 : c10));
+                const float c1 = tanh_f(pair_sum(dir == 0 ? c01 : c11));
+                const float c2 = tanh_f(pair_sum(dir == 0 ? c02 : c12));
+                const size_t rr = dir == 0 ? P.rij : P.rji;
+                const int fl = A.eflag[rr];
+                const float iota = (c0 + ((fl & 1) ? c1 : 0.f) + ((fl & 2) ? c2 : 0.f)) * (1.f / 3.f);
+                const float f = cscale * iota / nrm;
+                const float sgn = dir == 0 ? 1.f : -1.f;          // x_a - x_c
+                if (P.ok && half == 0)
+                    reinterpret_cast<float4*>(A.dposE)[rr] = make_float4(sgn * dx * f, sgn * dy * f, sgn * dz * f, 0.f);
+            }
             PT(6);
+        } else {
+            // ---- S = W_e e + W_d G, shared by both directions: parked per lane ----
+    #pragma unroll
+            for (int b = 0; b < X::ND; ++b) {
+                const unsigned we = oi + (unsigned)(b * 2 * X::KQE) * 1024, wg_ = we + X::KQE * 1024;
+                f32x16 acc = mfma_block_p<X::KQE>(wp, ws, we, wg_, en, zero16());
+                acc = mfma_block_p<X::KQE>(wp, ws, wg_, b + 1 < X::ND ? wg_ + X::KQE * 1024 : o0, G, acc);
+    #pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    if (b < X::ND - PLB) park[(b < X::ND - PLB ? b : 0) * 16 + s] = acc[s];
+                }
+                if (b >= X::ND - PLB) {
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        pl[((b - (X::ND - PLB)) * 4 + q) * 64 + lane] = make_float4(acc[q * 4 + 0], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
+                }
+            }
+            PT(3);
+            // ---- two directed evaluations: u = S + W_row h_a + W_col h_c -> LN -> modulate -> coord_mlp ----
+    #pragma unroll 1
+            for (int dir = 0; dir < 2; ++dir) {
+                if (dsel >= 0 && dir != dsel) continue;
+                BRow ra = wrow_i, rc = wcol_j;
+                if (dir == 1) { ra.voff = wrow_j.voff; rc.voff = wcol_i.voff; }
+                float uu[X::HD];
+                // the per-node rows are requested GB blocks at a time (buffer loads, pinned by the fence) and only
+                // then consumed — see BRow in dgt_device.h
+                constexpr int GB = D == 256 ? 4 : 2;          // blocks per gather group (registers are shorter at nf = 384)
+    #pragma unroll
+                for (int g = 0; g < X::ND / GB; ++g) {
+                    float a1[GB * 16], a2[GB * 16];
+    #pragma unroll
+                    for (int k = 0; k < GB; ++k) {
+                        float t1[16], t2[16];
+                        bload16(ra, g * GB + k, t1);
+                        bload16(rc, g * GB + k, t2);
+    #pragma unroll
+                        for (int s = 0; s < 16; ++s) { a1[k * 16 + s] = t1[s]; a2[k * 16 + s] = t2[s]; }
+                    }
+                    pipeline_fence();
+    #pragma unroll
+                    for (int k = 0; k < GB; ++k) {
+                        const int b = g * GB + k;
+                        float pk[16];
+                        if (b < X::ND - PLB) {
+    #pragma unroll
+                            for (int s = 0; s < 16; ++s) pk[s] = park[(b < X::ND - PLB ? b : 0) * 16 + s];
+                        } else {
+    #pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 t = pl[((b - (X::ND - PLB)) * 4 + q) * 64 + lane];
+                                pk[q * 4 + 0] = t.x; pk[q * 4 + 1] = t.y; pk[q * 4 + 2] = t.z; pk[q * 4 + 3] = t.w;
+                            }
+                        }
+    #pragma unroll
+                        for (int s = 0; s < 16; ++s) uu[b * 16 + s] = pk[s] + (a1[k * 16 + s] + a2[k * 16 + s]);
+                    }
+                }
+                PT(6);
+                layer_norm<X::HD>(uu);
+                modulate<X::ND>(uu, qsh_, qsc_, half);
+                PT(4);
+                float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    #pragma unroll 1
+                for (int b = 0; b < X::ND; ++b) {
+                    const unsigned wcur = o0 + (unsigned)b * X::KQD * 1024;
+                    const unsigned wnx = b + 1 < X::ND ? wcur + X::KQD * 1024 : ((dir == 0 && dsel < 0) ? o0 : o3);
+                    float bb[16], k0[16], k1[16], k2[16];
+                    load16(b0_ + b * 32 + half * 16, bb);
+                    load16(w2_ + b * 32 + half * 16, k0);
+                    load16(w2_ + D + b * 32 + half * 16, k1);
+                    load16(w2_ + 2 * D + b * 32 + half * 16, k2);
+                    f32x16 acc = mfma_block_p<X::KQD>(wp, ws, wcur, wnx, uu, zero16());
+    #pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        const float ys = silu_f(acc[s] + bb[s]);
+                        c0 = fmaf(ys, k0[s], c0);
+                        c1 = fmaf(ys, k1[s], c1);
+                        c2 = fmaf(ys, k2[s], c2);
+                    }
+                }
+                PT(dir == 0 ? 5 : 7);
+                c0 = tanh_f(pair_sum(c0));
+                c1 = tanh_f(pair_sum(c1));
+                c2 = tanh_f(pair_sum(c2));
+                const size_t rr = dir == 0 ? P.rij : P.rji;
+                const int fl = A.eflag[rr];
+                const float iota = (c0 + ((fl & 1) ? c1 : 0.f) + ((fl & 2) ? c2 : 0.f)) * (1.f / 3.f);
+                const float nrm = fmaxf(sqrtf(d2), 1e-8f);
+                const float f = cscale * iota / nrm;
+                const float sgn = dir == 0 ? 1.f : -1.f;          // x_a - x_c
+                if (P.ok && half == 0)
+                    reinterpret_cast<float4*>(A.dposE)[rr] = make_float4(sgn * dx * f, sgn * dy * f, sgn * dz * f, 0.f);
+                PT(6);
+            }
         }
     }
     PT_FLUSH;

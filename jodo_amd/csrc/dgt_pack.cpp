@@ -202,7 +202,33 @@ int pack(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, Packer&
             rows(o, b + ".node_time_mlp.1", 6 * D); o += 6 * D;
             rows(o, b + ".edge_time_mlp.1", 6 * De); o += 6 * De;
             rows(o, b + ".equi_update.time_mlp.1", 2 * D); o += 2 * D;
-            rows(o, b + ".dist_layer.time_mlp.1", 2);
+            rows(o, b + ".dist_layer.time_mlp.1", 2); o += 32;
+            // coord_mlp.0 pushed through the LayerNorm of equi_update (pair update kernel): W0 (1 + scale) and W0 shift + b0
+            // are affine in SiLU(time_emb) like every other modulation output; composed in double, k ascending
+            const float* W0 = W(b + ".equi_update.coord_mlp.0.weight", (int64_t)D * D);
+            const float* b0 = W(b + ".equi_update.coord_mlp.0.bias", D);
+            const float* Wt = W(b + ".equi_update.time_mlp.1.weight", (int64_t)2 * D * T);      // rows: shift [D] | scale [D]
+            const float* bt = W(b + ".equi_update.time_mlp.1.bias", 2 * D);
+            if (W0 && b0 && Wt && bt) {
+                std::vector<double> acc((size_t)T);
+                for (int part = 0; part < 2; ++part) {               // 0: scale rows -> W0 (1 + sc); 1: shift rows -> W0 sh + b0
+                    const float* Wsrc = Wt + (size_t)(part == 0 ? D : 0) * T;
+                    const float* bsrc = bt + (part == 0 ? D : 0);
+                    for (int i = 0; i < D; ++i) {
+                        std::fill(acc.begin(), acc.end(), 0.0);
+                        double bacc = 0.0;
+                        for (int k = 0; k < D; ++k) {
+                            const double wk = W0[(size_t)i * D + k];
+                            const float* row = Wsrc + (size_t)k * T;
+                            for (int t = 0; t < T; ++t) acc[t] += wk * (double)row[t];
+                            bacc += wk * ((part == 0 ? 1.0 : 0.0) + (double)bsrc[k]);
+                        }
+                        float* dst = &Wm[(size_t)(o + (int64_t)part * D + i) * T];
+                        for (int t = 0; t < T; ++t) dst[t] = (float)acc[t];
+                        bm[(size_t)(o + (int64_t)part * D + i)] = (float)(bacc + (part == 1 ? (double)b0[i] : 0.0));
+                    }
+                }
+            }
         }
         P.put_proj(Wm.data(), T, nat_in(T), nat_out((int)d.Mtot));
         P.put(bm);

@@ -63,7 +63,7 @@ int dgt_dims_from_cfg(const jodo_cfg* c, DgtDims* d) {
         return jodo_set_error(JODO_ERR_UNSUPPORTED, "n_layers=%d gives readout widths beyond the padded slots", d->L);
     d->KNH = d->D + d->L * d->cnp; d->KEH = d->De + d->L * d->cep;
     if (d->KEH % 32 != 0) return jodo_set_error(JODO_ERR_UNSUPPORTED, "edge head width %d not a multiple of 32", d->KEH);
-    d->MB = 6 * d->D + 6 * d->De + 2 * d->D + 32;
+    d->MB = 6 * d->D + 6 * d->De + 2 * d->D + 32 + 2 * d->D;     // node | edge | equi (shift, scale) | gbf | W0 (1 + scale) | W0 shift + b0
     d->Mtot = 32 + (int64_t)d->L * d->MB;
     d->cutoff = c->spatial_cut_off; d->edge_th = c->edge_quan_th;
     return JODO_OK;
@@ -273,7 +273,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     w.feat = take(NP * d.ndp * f); w.h = take(NP * d.D * f); w.hhat = take(NP * amax_parts * d.D * f);
     w.astat = take(NP * amax_parts * 32 * f);
     w.q = take(NP * d.QKP * f); w.k = take(NP * d.QKP * f); w.v = take(NP * d.D * f); w.n2e = take(NP * d.De * f);
-    w.wrow = take(NP * d.D * f); w.wcol = take(NP * d.D * f); w.ahid = take(NP * d.KNH * f);
+    w.wrow = take(NP * d.D * f); w.wcol = take(NP * d.D * f); w.ua = take(NP * d.D * f); w.ub = take(NP * d.D * f); w.rmean = take(NP * 2 * f); w.ahid = take(NP * d.KNH * f);
     w.apred = take(NP * 32 * f);
     w.eflag = take(R * sizeof(int32_t)); w.e = take(R * d.De * f); w.e2 = take(R * d.De * f);
     w.ehid = take(R * d.KEH * f); w.epred = take(R * 4 * f); w.dposE = take(R * 4 * f);

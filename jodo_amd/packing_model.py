@@ -44,7 +44,9 @@ class ModelDims:
         self.cn, self.ce = (2 * nf) // n_layers, (2 * self.De) // n_layers
         self.cnp, self.cep = nf // 4, (nf // 16 + 15) // 16 * 16          # 64 / 16 at nf 256, 96 / 32 at nf 384
         self.KNH, self.KEH = nf + n_layers * self.cnp, self.De + n_layers * self.cep
-        self.MB = 6 * nf + 6 * self.De + 2 * nf + 32
+        # modulation slice of a block: node 6D | edge 6De | equi (shift, scale) 2D | gbf 2 (+30 pad) | coord_mlp.0 pushed
+        # through the LayerNorm of equi_update: W0 (1 + scale) [D] | W0 shift + b0 [D]  (csrc/dgt_kernels_wide.h, pair update)
+        self.MB = 6 * nf + 6 * self.De + 2 * nf + 32 + 2 * nf
         self.Mtot = 32 + n_layers * self.MB
 
 
@@ -133,6 +135,16 @@ def pack_model(sd, dims):
         Wm[o:o + 2 * D] = w(b + '.equi_update.time_mlp.1.weight'); bm[o:o + 2 * D] = w(b + '.equi_update.time_mlp.1.bias')
         o += 2 * D
         Wm[o:o + 2] = w(b + '.dist_layer.time_mlp.1.weight'); bm[o:o + 2] = w(b + '.dist_layer.time_mlp.1.bias')
+        o += 32
+        # y = coord_mlp.0(LN(pre) (1 + sc) + sh) = [W0 (pre (1 + sc)) - mean W0 (1 + sc)] rstd + (W0 sh + b0): the two
+        # per-molecule vectors are affine in SiLU(time_emb) like every other modulation output -> two more row groups
+        W0 = w(b + '.equi_update.coord_mlp.0.weight').astype(np.float64)
+        Wt = w(b + '.equi_update.time_mlp.1.weight').astype(np.float64)          # rows: shift [D] | scale [D]
+        bt = w(b + '.equi_update.time_mlp.1.bias').astype(np.float64)
+        Wm[o:o + D] = (W0 @ Wt[D:2 * D]).astype(np.float32); bm[o:o + D] = (W0 @ (1.0 + bt[D:2 * D])).astype(np.float32)
+        o += D
+        Wm[o:o + D] = (W0 @ Wt[0:D]).astype(np.float32)
+        bm[o:o + D] = (W0 @ bt[0:D] + w(b + '.equi_update.coord_mlp.0.bias').astype(np.float64)).astype(np.float32)
     put('MOD_W', P.pack_projection(Wm, nat(T), nout(d.Mtot)))
     put('MOD_B', bm)
 
