@@ -253,6 +253,37 @@ __device__ __forceinline__ f32x16 mfma_block_p(WPipe<PG>& p, const WSrc& w, unsi
     return acc;
 }
 
+// Same with the NEXT block living in another buffer (wn): the prefetch of its first group goes through that descriptor.
+template <int KQ, int PG>
+__device__ __forceinline__ f32x16 mfma_block_p2(WPipe<PG>& p, const WSrc& w, unsigned cur_off, const WSrc& wn, unsigned next_off,
+                                                const float (&act)[KQ * 4], f32x16 acc) {
+    static_assert(KQ % PG == 0, "block length must be a multiple of the prefetch group");
+#pragma unroll
+    for (int g = 0; g < KQ / PG; ++g) {
+        float4 cur[PG];
+#pragma unroll
+        for (int i = 0; i < PG; ++i) cur[i] = p.q[i];
+        if (g + 1 < KQ / PG) {
+#pragma unroll
+            for (int i = 0; i < PG; ++i) p.q[i] = wload(w, cur_off, (g + 1) * PG + i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PG; ++i) p.q[i] = wload(wn, next_off, i);
+        }
+        pipeline_fence();
+#pragma unroll
+        for (int i = 0; i < PG; ++i) {
+            const int k = (g * PG + i) * 4;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i].x, act[k + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i].y, act[k + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i].z, act[k + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i].w, act[k + 3], acc, 0, 0, 0);
+        }
+        pipeline_fence();
+    }
+    return acc;
+}
+
 // accumulator (+ bias in slot order) -> registers [16]
 __device__ __forceinline__ void acc_bias(const f32x16& acc, const float* __restrict__ bias16, float (&r)[16]) {
     float b[16];

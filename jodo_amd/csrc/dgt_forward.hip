@@ -43,7 +43,7 @@ void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
     A.h = ws_ptr<float>(ws, w.h); A.hhat = ws_ptr<float>(ws, w.hhat); A.astat = ws_ptr<float>(ws, w.astat); A.q = ws_ptr<float>(ws, w.q);
     A.k = ws_ptr<float>(ws, w.k); A.v = ws_ptr<float>(ws, w.v); A.n2e = ws_ptr<float>(ws, w.n2e);
     A.wrow = ws_ptr<float>(ws, w.wrow); A.wcol = ws_ptr<float>(ws, w.wcol); A.ua = ws_ptr<float>(ws, w.ua); A.ub = ws_ptr<float>(ws, w.ub);
-    A.rmean = ws_ptr<float>(ws, w.rmean); A.ahid = ws_ptr<float>(ws, w.ahid);
+    A.rmean = ws_ptr<float>(ws, w.rmean); A.mfold = ws_ptr<float>(ws, w.mfold); A.ahid = ws_ptr<float>(ws, w.ahid);
     A.apred = ws_ptr<float>(ws, w.apred);
     A.eflag = ws_ptr<int>(ws, w.eflag); A.e = ws_ptr<float>(ws, w.e);
     A.ehid = ws_ptr<float>(ws, w.ehid); A.epred = ws_ptr<float>(ws, w.epred);
@@ -99,6 +99,9 @@ int launch_update_sym(jodo_plan* p, hipStream_t st, KArgs& A) {
     const int n1 = split ? full : p->n_pitems;
     A.item0 = 0; A.dir_split = 0;
     if (n1 > 0) { if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2>), n1, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4>), n1, 64, A); }
+    if constexpr (D == 256) {      // shared modulation row (device flag): the variant with the folded coord_mlp.0 does the work
+        if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2, true>), n1, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4, true>), n1, 64, A);
+    }
     if (split) {
         A.item0 = full; A.dir_split = 1;
         if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2>), 2 * rem, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4>), 2 * rem, 64, A);
@@ -164,6 +167,15 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
     }
     if (rc) return rc;
     if (p->n_items > 0) LAUNCH((wide::k_embed_edges<D>), p->n_items, 64, A);
+    if (D == 256 && p->n_pitems > 0) {             // folded coord_mlp.0 of every block (pair update, shared modulation row)
+        if (d.L > 16) return jodo_set_error(JODO_ERR_UNSUPPORTED, "more than 16 blocks");
+        FoldOffs F;
+        for (int l = 0; l < 16; ++l) {
+            F.c0[l] = l < d.L ? woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + JB_C0_W] : 0;
+            F.ine[l] = l < d.L ? woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + JB_INE_W] : 0;
+        }
+        LAUNCH((wide::k_fold_coord<D>), d.L * (D / 32) * (d.De / 4), 64, A, F);
+    }
     pro.reset();
     // ---- DGT blocks ----
     const int nblocks = (p->max_blocks >= 0 && p->max_blocks < d.L) ? p->max_blocks : d.L;

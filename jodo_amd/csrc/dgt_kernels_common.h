@@ -25,7 +25,7 @@ struct KArgs {
     int pre_mode;                         // k_node_pre: 0 = also advance the positions, 1 = q/k/v only (k_pos_final did it)
     // workspace
     float *hid1, *temb, *mods, *condh, *condh2;
-    float *pos_in, *pos_out, *dpos, *cpos, *feat, *h, *hhat, *astat, *q, *k, *v, *n2e, *wrow, *wcol, *ua, *ub, *rmean, *ahid, *apred;
+    float *pos_in, *pos_out, *dpos, *cpos, *feat, *h, *hhat, *astat, *q, *k, *v, *n2e, *wrow, *wcol, *ua, *ub, *rmean, *mfold, *ahid, *apred;
     int* eflag;
     float *e, *ehid, *epred, *dposE;
     float* e_out;                         // edge state written by the update kernels (ping-pong with e: never in place,
@@ -36,6 +36,9 @@ struct KArgs {
     const float *xh, *edge_x, *cond_x, *cond_edge_x, *noise, *context;
     float *out_xh, *out_edge;
 };
+
+// k_fold_coord: per-layer slot offsets of coord_mlp.0 and of the [e ; G] part of input_lin (one launch covers every block)
+struct FoldOffs { int64_t c0[16], ine[16]; };
 
 namespace jd {
 

@@ -332,6 +332,41 @@ __global__ __launch_bounds__(64, 1) void k_node_ab(KArgs A) {
     }
 }
 
+// M_l = coord_mlp.0 diag(1 + sc_l) input_lin[:, e ; G] for every block l, in the streaming layout of input_lin's [e ; G]
+// part (pack_projection: [out block][quad][lane] float4) — valid when all molecules share one modulation row (device flag
+// UNIFORM_T), which is how sampling runs an unconditional model.  Both factors are read in their packed layouts: row o of
+// coord_mlp.0 sits at lane (s & 3) + 4 h + 8 (s >> 2) of block o / 32 (o % 32 = 16 h + s), its column j at register
+// m = 16 (j / 32) + j % 16 of half (j % 32) / 16.  One float4 of M per thread, sums in double; 2 x 134 MFLOP per forward.
+template <int D>
+__global__ __launch_bounds__(64) void k_fold_coord(KArgs A, FoldOffs F) {
+    if (!A.flags[FLAG_UNIFORM_T]) return;
+    using X = Dim<D>;
+    constexpr int KQI = 2 * X::KQE, PER_L = X::ND * KQI;
+    const int l = blockIdx.x / PER_L, r = blockIdx.x % PER_L, nb = r / KQI, q = r % KQI;
+    const int lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const float* sc = A.mods + 32 + (size_t)l * A.d.MB + X::M_EQUI + D;
+    const float4* c0 = reinterpret_cast<const float4*>(A.W + F.c0[l]) + (size_t)nb * X::KQD * 64;
+    const float4* ine = reinterpret_cast<const float4*>(A.W + F.ine[l]);
+    double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+#pragma unroll 2
+    for (int qj = 0; qj < X::KQD; ++qj) {
+#pragma unroll
+        for (int khj = 0; khj < 2; ++khj) {
+            const float4 w = c0[qj * 64 + i + 32 * khj];
+            const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj) {
+                const int m = 4 * qj + cj, j = (m >> 4) * 32 + khj * 16 + (m & 15);
+                const int s_ = j & 15, h_ = (j >> 4) & 1, ij = (s_ & 3) + 4 * h_ + 8 * (s_ >> 2);
+                const float4 v = ine[((size_t)(j >> 5) * KQI + q) * 64 + ij + 32 * kh];
+                const double f = (double)wv[cj] * (1.0 + (double)sc[j]);
+                a0 += f * v.x; a1 += f * v.y; a2 += f * v.z; a3 += f * v.w;
+            }
+        }
+    }
+    reinterpret_cast<float4*>(A.mfold)[((size_t)l * PER_L + r) * 64 + lane] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+}
+
 // ------------------------------------------------------------------------------------------------
 // edge side (directed: rows r = eoff + a*n + c, a = source / row atom, c = target / column atom)
 template <int D, int R>
@@ -497,9 +532,14 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
 // lane) is kept in a per-lane array for both directions (registers at D = 256, partly spilled to scratch at
 // D = 384 — four waves' LDS slabs of 48 KiB would not fit the CU's 160 KiB), and each direction requests its
 // per-node rows with buffer loads pinned ahead of their use (BRow, dgt_device.h).
-template <int D, int R>
+template <int D, int R, bool FOLD = false>
 __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
     if (A.flags[FLAG_ASYM]) return;
+    // FOLD (nf = 256 only): every molecule shares one modulation row (unconditional sampling, one noise level per batch),
+    // so coord_mlp.0 (1 + sc) input_lin[e ; G] is ONE D x 2De matrix per block (k_fold_coord) — see the hoist below.
+    // Both variants are launched; the device flag picks the one that works.
+    if (D == 256 && (A.flags[FLAG_UNIFORM_T] != 0) != FOLD) return;
+    static_assert(!FOLD || D == 256, "the folded projection rides on the hoisted coord_mlp.0");
     using X = Dim<D>;
     constexpr int NCH = R * X::De / 64;
     constexpr int KQ4 = R * X::De / 8;
@@ -639,7 +679,8 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             ua_i.voff += opq; ub_i.voff += opq; own_r.voff += opq; own_c.voff += opq;
             const float m00 = A.rmean[(size_t)L.v * 2] + A.rmean[(size_t)P.u * 2 + 1];          // direction 0: a = i, c = j
             const float m01 = A.rmean[(size_t)P.u * 2] + A.rmean[(size_t)L.v * 2 + 1];          // direction 1: a = j, c = i
-            float sg[X::HD];
+            float sg[FOLD ? 1 : X::HD];
+            const WSrc wm = make_wsrc(A.mfold + (size_t)A.layer * D * 2 * X::De, lane);      // FOLD: W0 (1 + sc) W_in[e ; G]
             float ssum = 0.f, q0 = 0.f, q1 = 0.f;
             float n0[16], n1[16], n2[16], n3[16];
             bload16(own_r, 0, n0); bload16(wcol_j, 0, n1); bload16(wrow_j, 0, n2); bload16(own_c, 0, n3);
@@ -647,18 +688,19 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             for (int b = 0; b < X::ND; ++b) {
                 const unsigned we = oi + (unsigned)(b * 2 * X::KQE) * 1024, wg_ = we + X::KQE * 1024;
                 float g[16], t0[16], t1[16];
-                load16(qsc_ + b * 32 + half * 16, g);
+                if constexpr (!FOLD) load16(qsc_ + b * 32 + half * 16, g);
 #pragma unroll
                 for (int s = 0; s < 16; ++s) { t0[s] = (n0[s] + n1[s]) - m00; t1[s] = (n2[s] + n3[s]) - m01; }
                 if (b + 1 < X::ND) { bload16(own_r, b + 1, n0); bload16(wcol_j, b + 1, n1); bload16(wrow_j, b + 1, n2); bload16(own_c, b + 1, n3); }
                 else { bload16(ua_i, 0, n0); bload16(ub_j, 0, n1); bload16(ua_j, 0, n2); bload16(ub_i, 0, n3); }    // first block of the tail
                 f32x16 acc = mfma_block_p<X::KQE>(wp, ws, we, wg_, en, zero16());
-                acc = mfma_block_p<X::KQE>(wp, ws, wg_, b + 1 < X::ND ? wg_ + X::KQE * 1024 : o0, G, acc);
+                if (FOLD && b + 1 == X::ND) acc = mfma_block_p2<X::KQE>(wp, ws, wg_, wm, 0u, G, acc);
+                else acc = mfma_block_p<X::KQE>(wp, ws, wg_, b + 1 < X::ND ? wg_ + X::KQE * 1024 : o0, G, acc);
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const float sv = acc[s];
                     ssum += sv;
-                    sg[b * 16 + s] = sv * (1.f + g[s]);
+                    if constexpr (!FOLD) sg[b * 16 + s] = sv * (1.f + g[s]);
                     const float d0 = sv + t0[s], d1 = sv + t1[s];
                     q0 = fmaf(d0, d0, q0);
                     q1 = fmaf(d1, d1, q1);
@@ -683,8 +725,18 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                 }
                 load16(wg_v + b * 32 + half * 16, wgb);
                 load16(bs_v + b * 32 + half * 16, bsb);
-                const unsigned wcur = o0 + (unsigned)b * X::KQD * 1024;
-                f32x16 z = mfma_block_p<X::KQD>(wp, ws, wcur, b + 1 < X::ND ? wcur + X::KQD * 1024 : o3, sg, zero16());
+                f32x16 z;
+                if constexpr (FOLD) {                            // Z = M [e ; G]: K = 2 De instead of D, and no S to keep
+                    const unsigned mcur = (unsigned)b * 2 * X::KQE * 1024;
+                    WSrc wn = wm;
+                    unsigned noff = mcur + 2 * X::KQE * 1024;
+                    if (b + 1 == X::ND) { wn = ws; noff = o3; }
+                    z = mfma_block_p<X::KQE>(wp, wm, mcur, mcur + X::KQE * 1024, en, zero16());
+                    z = mfma_block_p2<X::KQE>(wp, wm, mcur + X::KQE * 1024, wn, noff, G, z);
+                } else {
+                    const unsigned wcur = o0 + (unsigned)b * X::KQD * 1024;
+                    z = mfma_block_p<X::KQD>(wp, ws, wcur, b + 1 < X::ND ? wcur + X::KQD * 1024 : o3, sg, zero16());
+                }
                 // vector tail of this block, one direction after the other and eight registers at a time (fences keep the
                 // compiler from evaluating all 32 SiLUs at once: their temporaries would not fit the 256 arch VGPRs)
 #pragma unroll
