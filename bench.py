@@ -68,6 +68,18 @@ def edge_update_flops_per_edge(hp):
             + 12 * De + 8 * D)             # LN2/modulate on e, LN/modulate on u
 
 
+def edge_update_executed_flops_per_pair(hp, uniform):
+    """MFMA FLOPs k_edge_update_sym issues per undirected pair (both directions of an edge): the trunk (edge FFN, readout,
+    shared part S of input_lin) once per pair; coord_mlp.0 once per direction at nf != 256, once per pair at nf = 256
+    (pushed through the LayerNorm), and with K = 2 De instead of D when every molecule shares one modulation row
+    (folded with input_lin by k_fold_coord).  The per-node parts live in k_node_ab (node_post class)."""
+    D, De, r = hp.nf, hp.de, hp.mlp_ratio
+    trunk = 2 * 2 * De * r * De + 2 * De * 32 + 2 * (2 * De) * D
+    if D != 256:
+        return trunk + 2 * (2 * D * D)
+    return trunk + (2 * (2 * De) * D if uniform else 2 * D * D)
+
+
 def cpu_model():
     try:
         for line in open('/proc/cpuinfo'):
@@ -385,6 +397,7 @@ def main():
         upd_ms, upd_n = per_class['edge_update']
         achieved = flops_launch / (upd_ms * 1e-3) if upd_ms > 0 else 0.0
         flags_now = model.last_flags.cpu().tolist()
+        exec_launch = (E // 2) * edge_update_executed_flops_per_pair(hp, bool(flags_now[2]))
         # sampling shares one noise level per batch and the kernels then evaluate the time-modulation GEMVs once
         # (uniform_t flag set on the device): count them once, not once per molecule
         total_flops = O.algorithmic_flops(hp, n_nodes, shared_time=bool(flags_now[2]) and not hp.cond_ch)['total']
@@ -403,10 +416,16 @@ def main():
                        'parallelism': 'batch shard x%d, no data-path collective' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'k_edge_update', 'achieved': achieved / 1e12, 'peak': PEAK_FP32_MFMA / 1e12,
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA, 'traffic': traffic, 'hbm': hbm,
-                         'note': 'one launch = the pair-update work of one block: up to two dispatches of the same kernel '
-                                 '(full rounds of work items + direction-split remainder) inside one HIP-event bracket; '
-                                 'rocprofv3 lists the dispatches separately (their durations add up to avg_launch_ms)',
+                         'note': 'achieved = ALGORITHMIC flops of the reference formulation (SURVEY.md 8d share of F_edge x '
+                                 'directed edges) / launch time.  The kernel issues fewer multiply-adds than that (pair symmetry, '
+                                 'coord_mlp.0 pushed through the LayerNorm and folded with input_lin), so frac can exceed 1; '
+                                 'mfma_util = the MFMA flops actually issued / launch time / peak is the hardware utilisation.  '
+                                 'One launch = the pair-update work of one block: the dispatches of k_edge_update_sym (variants '
+                                 'that exit on a device flag included) inside one HIP-event bracket; rocprofv3 lists them '
+                                 'separately (their durations add up to avg_launch_ms)',
                          'avg_launch_ms': upd_ms, 'launches': upd_n, 'alg_flops_per_launch': flops_launch,
+                         'executed_mfma_flops_per_launch': exec_launch,
+                         'mfma_util': (exec_launch / (upd_ms * 1e-3) / PEAK_FP32_MFMA) if upd_ms > 0 else 0.0,
                          'whole_step_TFLOPs': total_flops / step_s / 1e12,
                          'whole_step_frac': total_flops / step_s / PEAK_FP32_MFMA},
             # per-class totals per step; classes other than edge_update are only timed with --breakdown

@@ -99,9 +99,8 @@ int launch_update_sym(jodo_plan* p, hipStream_t st, KArgs& A) {
     const int n1 = split ? full : p->n_pitems;
     A.item0 = 0; A.dir_split = 0;
     if (n1 > 0) { if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2>), n1, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4>), n1, 64, A); }
-    if constexpr (D == 256) {      // shared modulation row (device flag): the variant with the folded coord_mlp.0 does the work
-        if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2, true>), n1, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4, true>), n1, 64, A);
-    }
+    // shared modulation row (device flag): the variant with the folded coord_mlp.0 does the work instead (never split)
+    if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2, true>), p->n_pitems, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4, true>), p->n_pitems, 64, A);
     if (split) {
         A.item0 = full; A.dir_split = 1;
         if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2>), 2 * rem, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4>), 2 * rem, 64, A);
@@ -167,7 +166,7 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
     }
     if (rc) return rc;
     if (p->n_items > 0) LAUNCH((wide::k_embed_edges<D>), p->n_items, 64, A);
-    if (D == 256 && p->n_pitems > 0) {             // folded coord_mlp.0 of every block (pair update, shared modulation row)
+    if (p->n_pitems > 0) {                         // folded coord_mlp.0 of every block (pair update, shared modulation row)
         if (d.L > 16) return jodo_set_error(JODO_ERR_UNSUPPORTED, "more than 16 blocks");
         FoldOffs F;
         for (int l = 0; l < 16; ++l) {
@@ -238,7 +237,7 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
                 if (d.r == 2) LAUNCH((wide::k_node_post<D, 2>), p->n_strips, 64, A); else LAUNCH((wide::k_node_post<D, 4>), p->n_strips, 64, A);
             }
             // per-node part of coord_mlp.0 pushed through the LayerNorm (pair update at nf = 256, dgt_kernels_wide.h)
-            if (D == 256 && p->n_pitems > 0) LAUNCH((wide::k_node_ab<D>), p->n_strips * 2, 64, A);
+            if (p->n_pitems > 0) LAUNCH((wide::k_node_ab<D>), p->n_strips * 2, 64, A);
         }
         if (p->n_items > 0) {
             ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);          // exactly one of the two does the work (device flag)

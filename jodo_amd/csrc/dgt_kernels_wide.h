@@ -298,6 +298,7 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
 // add up to the LayerNorm mean of a directed edge.  One (strip, piece) item per wave: 2 x n_strips items.
 template <int D>
 __global__ __launch_bounds__(64, 1) void k_node_ab(KArgs A) {
+    if (D != 256 && !A.flags[FLAG_UNIFORM_T]) return;       // nf = 384 pushes coord_mlp.0 through only with a shared modulation row
     using X = Dim<D>;
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
     const int strip = blockIdx.x >> 1, piece = blockIdx.x & 1;
@@ -535,11 +536,10 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
 template <int D, int R, bool FOLD = false>
 __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
     if (A.flags[FLAG_ASYM]) return;
-    // FOLD (nf = 256 only): every molecule shares one modulation row (unconditional sampling, one noise level per batch),
-    // so coord_mlp.0 (1 + sc) input_lin[e ; G] is ONE D x 2De matrix per block (k_fold_coord) — see the hoist below.
+    // FOLD: every molecule shares one modulation row (unconditional sampling, one noise level per batch), so
+    // coord_mlp.0 (1 + sc) input_lin[e ; G] is ONE D x 2De matrix per block (k_fold_coord) — see the hoist below.
     // Both variants are launched; the device flag picks the one that works.
-    if (D == 256 && (A.flags[FLAG_UNIFORM_T] != 0) != FOLD) return;
-    static_assert(!FOLD || D == 256, "the folded projection rides on the hoisted coord_mlp.0");
+    if ((A.flags[FLAG_UNIFORM_T] != 0) != FOLD) return;
     using X = Dim<D>;
     constexpr int NCH = R * X::De / 64;
     constexpr int KQ4 = R * X::De / 8;
@@ -563,7 +563,8 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
     wpipe_prime(wp, ws, o3);
     // S = shared part of input_lin, kept for both directions: in registers; at nf = 384 (192 values per lane next to the 192
     // of u) the upper half is parked in LDS instead (24 KiB per one-wave workgroup, four per CU) — spilled to scratch before
-    constexpr bool HOIST = D == 256;                        // coord_mlp.0 once per pair (below); nf = 384 keeps one per direction
+    constexpr bool HOIST = D == 256 || FOLD;                // coord_mlp.0 once per pair (below); nf = 384 without a shared
+                                                            // modulation row keeps one per direction (S (1 + sc) does not fit)
     constexpr int PLB = D > 256 ? X::ND / 2 : 0;            // blocks parked in LDS
     __shared__ float4 pl[PLB > 0 ? PLB * 4 * 64 : 1];
     float park[HOIST ? 1 : (X::ND - PLB) * 16];

@@ -113,17 +113,20 @@ def test_attention_kernel_variants_agree():
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
 
 
-@pytest.mark.parametrize("cfg_name,n_nodes,gain", [
-    ('vpsde_qm9_uncond_jodo', [6, 11, 20, 29, 1, 2], 1.0),
-    ('vpsde_qm9_uncond_jodo', [5] * 40 + [19] * 30, 1.5),
-    ('vpsde_geom_uncond_jodo', [70, 33, 12], 1.5),
+@pytest.mark.parametrize("cfg_name,n_nodes,gain,over", [
+    ('vpsde_qm9_uncond_jodo', [6, 11, 20, 29, 1, 2], 1.0, {}),
+    ('vpsde_qm9_uncond_jodo', [5] * 40 + [19] * 30, 1.5, {}),
+    ('vpsde_geom_uncond_jodo', [70, 33, 12], 1.5, {}),
+    ('vpsde_geom_uncond_jodo', [70, 33, 12, 1, 2], 1.5, dict(nf=384)),                  # BASELINE config 4 width
+    ('vpsde_geom_uncond_jodo', [19] * 25 + [6] * 30, 1.0, dict(nf=384, n_layers=8, mlp_ratio=2)),
+    ('vpsde_qm9_uncond_jodo', [29, 1, 2, 18, 18, 7, 23], 1.5, dict(kernel_layout='wide')),
 ])
-def test_uniform_and_per_molecule_noise_levels_agree(cfg_name, n_nodes, gain):
+def test_uniform_and_per_molecule_noise_levels_agree(cfg_name, n_nodes, gain, over):
     """One noise level for the whole batch (how every sampler calls an unconditional model) takes the shared-row path:
     modulation GEMVs once per batch and, at nf = 256, the pair update with coord_mlp.0 (1 + sc) input_lin folded into one
     matrix per block (k_fold_coord).  Different arithmetic from the per-molecule path, so both are held to the oracle and
-    to each other within the forward tolerance."""
-    cfg = make_config(cfg_name)
+    to each other within the forward tolerance.  At nf = 384 only the shared-row path pushes coord_mlp.0 through."""
+    cfg = make_config(cfg_name, **over)
     model = make_model(cfg, 9, DEV, gain=gain, coord_scale=0.05)
     hp = O.Hyper.from_config(cfg)
     sd = state_dict_cpu(model)
