@@ -70,14 +70,14 @@ def edge_update_flops_per_edge(hp):
 
 def edge_update_executed_flops_per_pair(hp, uniform):
     """MFMA FLOPs k_edge_update_sym issues per undirected pair (both directions of an edge): the trunk (edge FFN, readout,
-    shared part S of input_lin) once per pair; coord_mlp.0 once per direction at nf != 256, once per pair at nf = 256
-    (pushed through the LayerNorm), and with K = 2 De instead of D when every molecule shares one modulation row
-    (folded with input_lin by k_fold_coord).  The per-node parts live in k_node_ab (node_post class)."""
+    shared part S of input_lin) once per pair; coord_mlp.0 with K = 2 De once per pair when every molecule shares one
+    modulation row (pushed through the LayerNorm and folded with input_lin by k_fold_coord), otherwise once per pair at
+    nf = 256 (pushed through only) and once per direction at other widths.  The per-node parts live in k_node_ab (node_post class)."""
     D, De, r = hp.nf, hp.de, hp.mlp_ratio
     trunk = 2 * 2 * De * r * De + 2 * De * 32 + 2 * (2 * De) * D
-    if D != 256:
-        return trunk + 2 * (2 * D * D)
-    return trunk + (2 * (2 * De) * D if uniform else 2 * D * D)
+    if uniform:
+        return trunk + 2 * (2 * De) * D
+    return trunk + (2 * D * D if D == 256 else 2 * (2 * D * D))
 
 
 def cpu_model():
