@@ -254,9 +254,13 @@ __device__ __forceinline__ f32x16 mfma_block_p(WPipe<PG>& p, const WSrc& w, unsi
 }
 
 // Same with the NEXT block living in another buffer (wn): the prefetch of its first group goes through that descriptor.
-template <int KQ, int PG>
+// `after` is called right after that last prefetch has been issued: the place for loads that are consumed much later
+// (per-node row gathers).  Loads return in order, so a slow gather issued BEFORE a weight prefetch delays the wait for
+// those weights; issued after it, it delays nothing until its own consumer.
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int KQ, int PG, typename After = NoHook>
 __device__ __forceinline__ f32x16 mfma_block_p2(WPipe<PG>& p, const WSrc& w, unsigned cur_off, const WSrc& wn, unsigned next_off,
-                                                const float (&act)[KQ * 4], f32x16 acc) {
+                                                const float (&act)[KQ * 4], f32x16 acc, After&& after = NoHook()) {
     static_assert(KQ % PG == 0, "block length must be a multiple of the prefetch group");
 #pragma unroll
     for (int g = 0; g < KQ / PG; ++g) {
@@ -269,6 +273,7 @@ __device__ __forceinline__ f32x16 mfma_block_p2(WPipe<PG>& p, const WSrc& w, uns
         } else {
 #pragma unroll
             for (int i = 0; i < PG; ++i) p.q[i] = wload(wn, next_off, i);
+            after();
         }
         pipeline_fence();
 #pragma unroll

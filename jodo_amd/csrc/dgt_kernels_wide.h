@@ -692,11 +692,17 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                 if constexpr (!FOLD) load16(qsc_ + b * 32 + half * 16, g);
 #pragma unroll
                 for (int s = 0; s < 16; ++s) { t0[s] = (n0[s] + n1[s]) - m00; t1[s] = (n2[s] + n3[s]) - m01; }
-                if (b + 1 < X::ND) { bload16(own_r, b + 1, n0); bload16(wcol_j, b + 1, n1); bload16(wrow_j, b + 1, n2); bload16(own_c, b + 1, n3); }
-                else { bload16(ua_i, 0, n0); bload16(ub_j, 0, n1); bload16(ua_j, 0, n2); bload16(ub_i, 0, n3); }    // first block of the tail
+                // the next block's rows are requested behind the last weight prefetch of this block (see mfma_block_p2)
+                auto next_rows = [&]() {
+                    if (b + 1 < X::ND) { bload16(own_r, b + 1, n0); bload16(wcol_j, b + 1, n1); bload16(wrow_j, b + 1, n2); bload16(own_c, b + 1, n3); }
+                    else { bload16(ua_i, 0, n0); bload16(ub_j, 0, n1); bload16(ua_j, 0, n2); bload16(ub_i, 0, n3); }    // first block of the tail
+                };
+                // (a second weight pipe — each part of a block prefetching its own part of the next block, two groups of
+                // cover — measured no gain: the blocks are bound by instruction issue, not by the wait for L2)
                 f32x16 acc = mfma_block_p<X::KQE>(wp, ws, we, wg_, en, zero16());
-                if (FOLD && b + 1 == X::ND) acc = mfma_block_p2<X::KQE>(wp, ws, wg_, wm, 0u, G, acc);
-                else acc = mfma_block_p<X::KQE>(wp, ws, wg_, b + 1 < X::ND ? wg_ + X::KQE * 1024 : o0, G, acc);
+                if (FOLD && b + 1 == X::ND) acc = mfma_block_p2<X::KQE>(wp, ws, wg_, wm, 0u, G, acc, next_rows);
+                else acc = mfma_block_p2<X::KQE>(wp, ws, wg_, ws, b + 1 < X::ND ? wg_ + X::KQE * 1024 : o0, G, acc, next_rows);
+                PT(3);
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const float sv = acc[s];
@@ -706,12 +712,13 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                     q0 = fmaf(d0, d0, q0);
                     q1 = fmaf(d1, d1, q1);
                 }
+                PT(4);
             }
             const float meanS = pair_sum(ssum) * (1.f / D);
             const float rstd0 = __builtin_amdgcn_rsqf(fmaxf(pair_sum(q0) * (1.f / D) - meanS * meanS, 0.f) + 1e-6f);
             const float rstd1 = __builtin_amdgcn_rsqf(fmaxf(pair_sum(q1) * (1.f / D) - meanS * meanS, 0.f) + 1e-6f);
             const float mr0 = (meanS + m00) * rstd0, mr1 = (meanS + m01) * rstd1;
-            PT(3);
+            PT(4);
             const float* wg_v = launder(mrow + X::M_WG);
             const float* bs_v = wg_v + D;
             float c00 = 0.f, c01 = 0.f, c02 = 0.f, c10 = 0.f, c11 = 0.f, c12 = 0.f;
@@ -720,10 +727,10 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                 float t0[16], t1[16], wgb[16], bsb[16];
 #pragma unroll
                 for (int s = 0; s < 16; ++s) { t0[s] = n0[s] + n1[s]; t1[s] = n2[s] + n3[s]; }
-                {                                                // next block's rows (the last iteration re-requests its own)
-                    const int bn = b + 1 < X::ND ? b + 1 : b;
+                auto next_rows = [&]() {                         // next block's rows (the last iteration re-requests its own),
+                    const int bn = b + 1 < X::ND ? b + 1 : b;    // behind the last weight prefetch of this block
                     bload16(ua_i, bn, n0); bload16(ub_j, bn, n1); bload16(ua_j, bn, n2); bload16(ub_i, bn, n3);
-                }
+                };
                 load16(wg_v + b * 32 + half * 16, wgb);
                 load16(bs_v + b * 32 + half * 16, bsb);
                 f32x16 z;
@@ -733,11 +740,12 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                     unsigned noff = mcur + 2 * X::KQE * 1024;
                     if (b + 1 == X::ND) { wn = ws; noff = o3; }
                     z = mfma_block_p<X::KQE>(wp, wm, mcur, mcur + X::KQE * 1024, en, zero16());
-                    z = mfma_block_p2<X::KQE>(wp, wm, mcur + X::KQE * 1024, wn, noff, G, z);
+                    z = mfma_block_p2<X::KQE>(wp, wm, mcur + X::KQE * 1024, wn, noff, G, z, next_rows);
                 } else {
                     const unsigned wcur = o0 + (unsigned)b * X::KQD * 1024;
-                    z = mfma_block_p<X::KQD>(wp, ws, wcur, b + 1 < X::ND ? wcur + X::KQD * 1024 : o3, sg, zero16());
+                    z = mfma_block_p2<X::KQD>(wp, ws, wcur, ws, b + 1 < X::ND ? wcur + X::KQD * 1024 : o3, sg, zero16(), next_rows);
                 }
+                PT(5);
                 // vector tail of this block, one direction after the other and eight registers at a time (fences keep the
                 // compiler from evaluating all 32 SiLUs at once: their temporaries would not fit the 256 arch VGPRs)
 #pragma unroll
@@ -767,8 +775,9 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                     }
                     pipeline_fence();
                 }
+                PT(7);
             }
-            PT(5);
+            PT(7);
             const float nrm = fmaxf(sqrtf(d2), 1e-8f);
 #pragma unroll
             for (int dir = 0; dir < 2; ++dir) {

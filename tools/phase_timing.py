@@ -25,7 +25,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
 b = buf.cpu().tolist()
 n = max(b[15], 1)
-names = ['0 top + LN(en)', '1 FFN', '2 readout', '3 input_lin S (+ park)', '4 LN statistics, both directions', '5 coord_mlp.0 once (Z)', '6 tail direction 0', '7 tail direction 1 (+ item end)']   # nf = 256 (hoisted) kernel
+names = ['0 top + LN(en)', '1 FFN', '2 readout', '3 input_lin S: MFMA blocks', '4 LN statistics riding on S', '5 folded coord_mlp.0 (Z): MFMA blocks', '6 item end', '7 SiLU / coord_mlp.2 tails riding on Z']   # hoisted kernel
 tot = sum(b[:8])
 print('instrumented waves (x8 blocks):', n, ' total cycles/wave-item: %.0f' % (tot / n))
 for i in range(8):
