@@ -94,10 +94,12 @@ struct AttnW {
 };
 
 // one K = De output block; `cur` / `nxt` are byte offsets for the streamed case, `wl` the LDS block for the resident case
-template <typename X, bool LDS>
-__device__ __forceinline__ f32x16 attn_block(AttnW<X>& w, const float4* wl, unsigned cur, unsigned nxt, const float (&act)[X::HE], f32x16 acc) {
-    if constexpr (LDS) return mfma_block_lds_p<X::KQE>(wl, act, acc);
-    else return mfma_block_p<X::KQE>(w.wp, w.ws, cur, nxt, act, acc);
+// `after`: row gathers for the next block — behind the weight prefetch in the streamed case (mfma_block_p2 in dgt_device.h)
+template <typename X, bool LDS, typename After = NoHook>
+__device__ __forceinline__ f32x16 attn_block(AttnW<X>& w, const float4* wl, unsigned cur, unsigned nxt, const float (&act)[X::HE], f32x16 acc,
+                                             After&& after = NoHook()) {
+    if constexpr (LDS) { after(); return mfma_block_lds_p<X::KQE>(wl, act, acc); }
+    else return mfma_block_p2<X::KQE>(w.wp, w.ws, cur, w.ws, nxt, act, acc, after);
 }
 
 // et of an edge row from its state e and squared length d2 (GBF -> edge_emb -> LN1 -> modulate)
@@ -142,13 +144,15 @@ __device__ __forceinline__ void attn_scores(AttnW<X>& w, const float (&x)[X::HE]
         float a1[16], a2[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) { a1[s] = qin[s] * kjn[s]; a2[s] = BOTH ? qjn[s] * kin[s] : 0.f; }
-        if (b + 1 < X::NQB) {
-            bload16(qi, b + 1, qin); bload16(kj, b + 1, kjn);
-            if (BOTH) { bload16(qj, b + 1, qjn); bload16(ki, b + 1, kin); }
-        }
-        pipeline_fence();
+        auto next_rows = [&]() {
+            if (b + 1 < X::NQB) {
+                bload16(qi, b + 1, qin); bload16(kj, b + 1, kjn);
+                if (BOTH) { bload16(qj, b + 1, qjn); bload16(ki, b + 1, kin); }
+            }
+        };
+        if constexpr (X::LDS_L0) pipeline_fence();
         const unsigned cur = w.oL0 + (unsigned)(b * X::KQE) * 1024;
-        f32x16 acc = attn_block<X, X::LDS_L0>(w, w.wL0 + (b * X::KQE) * 64, cur, b + 1 < X::NQB ? cur + X::KQE * 1024 : w.oL1, x, zero16());
+        f32x16 acc = attn_block<X, X::LDS_L0>(w, w.wL0 + (b * X::KQE) * 64, cur, b + 1 < X::NQB ? cur + X::KQE * 1024 : w.oL1, x, zero16(), next_rows);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -365,13 +369,18 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
             float vv[16], vo[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) { vv[s] = vjn[s]; vo[s] = PAIR ? vin[s] : 0.f; }
-            if (b + 1 < X::ND) {
-                bload16(vj, b + 1, vjn);
-                if (PAIR) bload16(vi, b + 1, vin);
-            }
+            // the next block's v rows are requested BEHIND the weight prefetch of the next block (loads return in order: a
+            // gather ahead of the prefetch would have to land before the next block's MFMAs may start, behind it only
+            // before their epilogue)
+            auto next_rows = [&]() {
+                if (b + 1 < X::ND) {
+                    bload16(vj, b + 1, vjn);
+                    if (PAIR) bload16(vi, b + 1, vin);
+                }
+            };
             if (PAIR && X::PHB > 1 && b > 0 && b % X::PHB == 0) __syncthreads();      // the previous phase has been read everywhere
             const unsigned cur = w.oL1 + (unsigned)(b * X::KQE) * 1024;
-            f32x16 acc = mfma_block_p<X::KQE>(w.wp, w.ws, cur, b + 1 < X::ND ? cur + X::KQE * 1024 : ring0, x, zero16());
+            f32x16 acc = mfma_block_p2<X::KQE>(w.wp, w.ws, cur, w.ws, b + 1 < X::ND ? cur + X::KQE * 1024 : ring0, x, zero16(), next_rows);
             float T[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) T[s] = tanh_f(acc[s]);
