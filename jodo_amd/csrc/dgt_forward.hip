@@ -321,7 +321,9 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     LAUNCH(k_flags_init, 1, 256, A);
     { const size_t tot = (size_t)p->B * p->N * p->N; LAUNCH(k_check_sym, (unsigned)((tot + 255) / 256), 256, A); }
     LAUNCH(k_time1, p->B, 256, A);
-    const int* uflag = flags_dev + FLAG_UNIFORM_T;
+    // a conditional model never shares the modulation row (k_flags_init): no flag, and rowgemm then reuses each activation
+    // chunk for four output blocks instead of one
+    const int* uflag = d.cond_ch > 0 ? nullptr : flags_dev + FLAG_UNIFORM_T;
     rc = rowgemm(st, A.hid1, d.T, A.temb, d.T, W + A.wg[JW_TIME_W3], W + A.wg[JW_TIME_B3], p->B, d.T, d.T / 32, 0, 0, uflag);
     if (rc) return rc;
     if (d.cond_ch > 0) {
