@@ -129,16 +129,22 @@ __device__ __forceinline__ void attn_edge_input(const KArgs& A, AttnW<X>& w, con
 
 // scores of one pair for both directions from T0 = tanh(lin_edge0 x): S1 = edge (j -> i), S2 = edge (i -> j); all 16
 // heads in every lane (heads 0, 1 = adjacency heads from the edge flags f1 / f2, 2.. = learned)
-template <typename X, bool BOTH>
-__device__ __forceinline__ void attn_scores(AttnW<X>& w, const float (&x)[X::HE], const BRow& qi, const BRow& ki, const BRow& qj,
-                                            const BRow& kj, int half, int f1, int f2, float (&S1)[16], float (&S2)[16]) {
-    constexpr int NM = X::WQK ? 14 : 7;                 // blocks reduced per head / per head pair
-    float m1[X::WQK ? 1 : 7], m2[X::WQK ? 1 : 7];
-    float qin[16], kin[16], qjn[16], kjn[16];
-    S1[0] = (f1 & 1) ? 1.f : -1e10f; S1[1] = (f1 & 2) ? 1.f : -1e10f;           // extra heads, 0 -> -1e10 (layers.py:170-174)
-    S2[0] = (f2 & 1) ? 1.f : -1e10f; S2[1] = (f2 & 2) ? 1.f : -1e10f;
+// first q / k rows of a pair (block 0): requested by the caller ahead of the edge-input projections where registers allow
+template <bool BOTH>
+__device__ __forceinline__ void attn_first_rows(const BRow& qi, const BRow& ki, const BRow& qj, const BRow& kj,
+                                                float (&qin)[16], float (&kin)[16], float (&qjn)[16], float (&kjn)[16]) {
     bload16(qi, 0, qin); bload16(kj, 0, kjn);
     if (BOTH) { bload16(qj, 0, qjn); bload16(ki, 0, kin); }
+}
+
+template <typename X, bool BOTH>
+__device__ __forceinline__ void attn_scores(AttnW<X>& w, const float (&x)[X::HE], const BRow& qi, const BRow& ki, const BRow& qj,
+                                            const BRow& kj, int half, int f1, int f2, float (&S1)[16], float (&S2)[16],
+                                            float (&qin)[16], float (&kin)[16], float (&qjn)[16], float (&kjn)[16]) {
+    constexpr int NM = X::WQK ? 14 : 7;                 // blocks reduced per head / per head pair
+    float m1[X::WQK ? 1 : 7], m2[X::WQK ? 1 : 7];
+    S1[0] = (f1 & 1) ? 1.f : -1e10f; S1[1] = (f1 & 2) ? 1.f : -1e10f;           // extra heads, 0 -> -1e10 (layers.py:170-174)
+    S2[0] = (f2 & 1) ? 1.f : -1e10f; S2[1] = (f2 & 2) ? 1.f : -1e10f;
 #pragma unroll
     for (int b = 0; b < NM; ++b) {
         float a1[16], a2[16];
@@ -297,18 +303,23 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
         const int fl1 = f1, fl2 = f2;
         float x[X::HE];
+        // the first q / k rows of the pair travel behind the edge-input projections (8k cycles) where registers allow
+        const BRow qi = brow(A.q, X::NQB, L.v, half), ki = brow(A.k, X::NQB, L.v, half);
+        const BRow qj = brow(A.q, X::NQB, u, half), kj = brow(A.k, X::NQB, u, half);
+        float qin[16], kin[16], qjn[16], kjn[16];
+        if constexpr (PREF) attn_first_rows<PAIR>(qi, ki, qj, kj, qin, kin, qjn, kjn);
         attn_edge_input<X>(A, w, e, dx * dx + dy * dy + dz * dz, gscale, gshift, mrow, half, x);
         if constexpr (PREF) {
             cur = source(t + 1 < t1 ? t + 1 : t);      // next source: its row, position and flags are requested now
             request();
+        } else {
+            attn_first_rows<PAIR>(qi, ki, qj, kj, qin, kin, qjn, kjn);
         }
         // ---- scores ----
-        const BRow qi = brow(A.q, X::NQB, L.v, half), ki = brow(A.k, X::NQB, L.v, half);
-        const BRow qj = brow(A.q, X::NQB, u, half), kj = brow(A.k, X::NQB, u, half);
         float Sa[X::NS], R[X::LDSS ? 1 : X::NS];           // scores of the own source / of the handed-over source per head slot
         {
             float S1[16], S2[16];
-            attn_scores<X, PAIR>(w, x, qi, ki, qj, kj, half, fl1, fl2, S1, S2);
+            attn_scores<X, PAIR>(w, x, qi, ki, qj, kj, half, fl1, fl2, S1, S2, qin, kin, qjn, kjn);
             float Sb[X::NS];
 #pragma unroll
             for (int k = 0; k < X::NS; ++k) {
@@ -324,6 +335,13 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
                     sx[256 + slot] = half ? make_float4(Sb[12], Sb[13], Sb[14], Sb[15]) : make_float4(Sb[4], Sb[5], Sb[6], Sb[7]);
                 }
             }
+        }
+        // first v rows: requested ahead of the hand-over barrier and the softmax update (where registers allow)
+        const BRow vj = brow(A.v, X::ND, u, half), vi = brow(A.v, X::ND, L.v, half);
+        float vjn[16], vin[16];
+        if constexpr (PREF) {
+            bload16(vj, 0, vjn);
+            if (PAIR) bload16(vi, 0, vin);
         }
         if (PAIR) {
             __syncthreads();
@@ -359,11 +377,11 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
             }
         }
         // ---- messages: T1 = tanh(lin_edge1 x) once; own direction v_j * T1, partner's direction v_i * T1 ----
-        const BRow vj = brow(A.v, X::ND, u, half), vi = brow(A.v, X::ND, L.v, half);
         const int rslot = half * ATT_LANES + rln;
-        float vjn[16], vin[16];
-        bload16(vj, 0, vjn);
-        if (PAIR) bload16(vi, 0, vin);
+        if constexpr (!PREF) {
+            bload16(vj, 0, vjn);
+            if (PAIR) bload16(vi, 0, vin);
+        }
 #pragma unroll
         for (int b = 0; b < X::ND; ++b) {
             float vv[16], vo[16];
