@@ -29,6 +29,17 @@
 #pragma once
 #include "dgt_kernels_sym.h"
 
+// per-phase cycle sums of the attention kernel (debug builds with -DJODO_PHASE_TIMING_ATTN; tools/phase_timing.py attn)
+#ifdef JODO_PHASE_TIMING_ATTN
+#define APT_INIT unsigned long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_last = __builtin_readcyclecounter();
+#define APT(ph) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_readcyclecounter(); pt_acc[ph] += n_ - pt_last; pt_last = n_; } while (0)
+#define APT_FLUSH do { if (A.dbgt && (threadIdx.x & 63) == 0 && (blockIdx.x % 61) == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&A.dbgt[i_], pt_acc[i_]); atomicAdd(&A.dbgt[15], (unsigned long long)(t1 - t0)); } } while (0)
+#else
+#define APT_INIT
+#define APT(ph)
+#define APT_FLUSH
+#endif
+
 namespace jd {
 
 constexpr int ATT_WAVES = 4;
@@ -293,6 +304,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
         if (PAIR) f2 = A.eflag[cur.r_out];
     };
     if constexpr (PREF) request();
+    APT_INIT
+    APT(0);
     for (int t = t0; t < t1; ++t) {
         if constexpr (!PREF) {                         // registers are short: request at the point of use
             cur = source(t);
@@ -309,6 +322,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
         float qin[16], kin[16], qjn[16], kjn[16];
         if constexpr (PREF) attn_first_rows<PAIR>(qi, ki, qj, kj, qin, kin, qjn, kjn);
         attn_edge_input<X>(A, w, e, dx * dx + dy * dy + dz * dz, gscale, gshift, mrow, half, x);
+        APT(1);
         if constexpr (PREF) {
             cur = source(t + 1 < t1 ? t + 1 : t);      // next source: its row, position and flags are requested now
             request();
@@ -336,6 +350,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
                 }
             }
         }
+        APT(2);
         // first v rows: requested ahead of the hand-over barrier and the softmax update (where registers allow)
         const BRow vj = brow(A.v, X::ND, u, half), vi = brow(A.v, X::ND, L.v, half);
         float vjn[16], vin[16];
@@ -354,6 +369,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
                 R[8] = c.x; R[9] = c.y; R[10] = c.z; R[11] = c.w; R[12] = e.x; R[13] = e.y; R[14] = e.z; R[15] = e.w;
             }
         }
+        APT(3);
         // ---- running softmax of this target: up to two new sources ----
         float sc[X::LDSS ? 1 : X::NS], p1[X::LDSS ? 1 : X::NS], p2[X::LDSS ? 1 : X::NS];
 #pragma unroll
@@ -376,6 +392,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
                 sm[h] = mn; sc[h] = c_; p1[h] = a_; p2[h] = b_;
             }
         }
+        APT(4);
         // ---- messages: T1 = tanh(lin_edge1 x) once; own direction v_j * T1, partner's direction v_i * T1 ----
         const int rslot = half * ATT_LANES + rln;
         if constexpr (!PREF) {
@@ -448,6 +465,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
             }
         }
     }
+    APT(5);
     // ---- partial of this item: unnormalised sums + (max, sum) per head ----
     if (L.valid) {
         store_nat<X::ND>(A.hhat + ((size_t)L.v * A.pd.amax_parts + part) * D, half, macc);
@@ -467,6 +485,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
                 reinterpret_cast<float4*>(sp)[(half ? 4 : 0) + q] = make_float4(fin[q * 4 + 0], fin[q * 4 + 1], fin[q * 4 + 2], fin[q * 4 + 3]);
         }
     }
+    APT(6);
+    APT_FLUSH;
 }
 
 // merge the attention partials of a node (k_node_post*): hhat = sum_p acc_p e^{m_p - M} / (sum_p l_p e^{m_p - M} + 1e-16),

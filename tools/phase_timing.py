@@ -26,6 +26,8 @@ with torch.no_grad():
 b = buf.cpu().tolist()
 n = max(b[15], 1)
 names = ['0 top + LN(en)', '1 FFN', '2 readout', '3 input_lin S: MFMA blocks', '4 LN statistics riding on S', '5 folded coord_mlp.0 (Z): MFMA blocks', '6 item end', '7 SiLU / coord_mlp.2 tails riding on Z']   # hoisted kernel
+if len(sys.argv) > 1 and sys.argv[1] == 'attn':      # build with -DJODO_PHASE_TIMING_ATTN; counts are per pair offset
+    names = ['0 item prologue (weights to LDS, own rows)', '1 edge input: GBF, edge_emb, LN', '2 scores: lin_edge0, tanh, q.k', '3 hand-over barrier + read', '4 softmax update', '5 messages: lin_edge1, tanh, v, hand-over', '6 item epilogue (partials out)', '7 -']
 tot = sum(b[:8])
 print('instrumented waves (x8 blocks):', n, ' total cycles/wave-item: %.0f' % (tot / n))
 for i in range(8):
