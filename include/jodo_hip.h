@@ -146,7 +146,8 @@ enum jodo_plan_option {
                                      q / k / v; 0: always a separate k_node_pre launch */
     JODO_OPT_DIR_SPLIT = 1,       /* 1 (default): pair-update items of a launch's sparsely filled last round get two workgroups,
                                      one per direction; 0: one workgroup per item */
-    JODO_OPT_NODE_POST_WAVES = 2, /* 0 (default): automatic; 1 / 2 / 4: waves per strip for every strip of k_node_post */
+    JODO_OPT_NODE_POST_WAVES = 2, /* 0 (default): automatic; 1 / 2 / 4: waves per strip for every strip of k_node_post;
+                                   * 12 / 14: automatic split, 2 / 4 waves per strip of the remainder launch */
     JODO_OPT_ATTN_VARIANT = 3,    /* nf 256 pair attention kernel, weight residency / hand-over granularity: 0, 1, 2 (dgt_kernels_attn.h) */
     JODO_OPT_COUNT
 };

@@ -127,9 +127,10 @@ int launch_edge_head(hipStream_t st, const KArgs& A) {
 int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A) {
     const DgtDims& d = p->dims;
     const int force = p->opt[JODO_OPT_NODE_POST_WAVES];                      // 0 = automatic
-    const int full = force ? (force == 1 ? p->n_strips : 0) : (p->n_strips / 1024) * 1024;
+    const bool rem_only = force >= 10;                                       // 12 / 14: automatic split, 2 / 4 waves for the remainder
+    const int full = (force && !rem_only) ? (force == 1 ? p->n_strips : 0) : (p->n_strips / 1024) * 1024;
     const int rem = p->n_strips - full;
-    const int nw = force ? force : (rem <= 256 ? 4 : (rem <= 512 ? 2 : 1));
+    const int nw = rem_only ? force - 10 : (force ? force : (rem <= 256 ? 4 : (rem <= 512 ? 2 : 1)));
     if (full > 0) {
         A.strip0 = 0;
         if (d.r == 2) LAUNCH(k_node_post<2>, full, 64, A); else LAUNCH(k_node_post<4>, full, 64, A);

@@ -337,7 +337,7 @@ extern "C" int jodo_debug_set_force_directed(jodo_plan* p, int on) {
 extern "C" int jodo_plan_set_option(jodo_plan* p, int option, int value) {
     if (!p) return jodo_set_error(JODO_ERR_ARG, "null plan");
     if (option < 0 || option >= JODO_OPT_COUNT) return jodo_set_error(JODO_ERR_ARG, "plan_set_option: unknown option %d", option);
-    if (option == JODO_OPT_NODE_POST_WAVES && value != 0 && value != 1 && value != 2 && value != 4)
+    if (option == JODO_OPT_NODE_POST_WAVES && value != 0 && value != 1 && value != 2 && value != 4 && value != 12 && value != 14)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: node-post waves per strip must be 0 (auto), 1, 2 or 4");
     p->opt[option] = value;
     return JODO_OK;
