@@ -29,6 +29,7 @@ PlanDev make_plan_dev(const jodo_plan* p, const void* desc_dev) {
     d.n_agroups = p->n_agroups; d.n_aitems = p->n_aitems; d.n_aditems = p->n_aditems; d.amax_parts = p->amax_parts;
     d.Nn = p->Nn; d.Nn_pad = p->Nn_pad; d.n_strips = p->n_strips; d.n_items = p->n_items; d.B = p->B; d.N = p->N;
     d.max_parts = p->max_parts; d.rows = p->rows;
+    d.ut_rows = base + p->off_ut_rows; d.n_ut_pad = p->n_ut_pad;
     return d;
 }
 
@@ -114,9 +115,11 @@ int launch_embed_nodes(hipStream_t st, const KArgs& A) {
     LAUNCH((wide::k_embed_nodes<D, KQ>), A.pd.n_strips, 64, A);
     return JODO_OK;
 }
+// symmetric inputs (device flag): one evaluation per unordered pair, written to both rows; otherwise every dense row
 template <int D, int NBK>
 int launch_edge_head(hipStream_t st, const KArgs& A) {
-    LAUNCH((wide::k_edge_head<D, NBK>), (unsigned)((A.pd.rows + 31) / 32), 64, A);
+    if (A.pd.n_ut_pad > 0) LAUNCH((wide::k_edge_head<D, NBK, true>), (unsigned)(A.pd.n_ut_pad / 32), 64, A);
+    LAUNCH((wide::k_edge_head<D, NBK, false>), (unsigned)((A.pd.rows + 31) / 32), 64, A);
     return JODO_OK;
 }
 

@@ -955,11 +955,15 @@ __global__ __launch_bounds__(64, 1) void k_node_head(KArgs A) {
     }
 }
 
-template <int D, int NBK>     // NBK = KEH / 32
+// SYM: the edge state and the readouts of (a, c) and (c, a) are bit-identical for symmetric inputs, so the head runs once per
+// unordered pair (plan list ut_rows) and writes both rows; the directed form covers asymmetric inputs (device flag).
+template <int D, int NBK, bool SYM>     // NBK = KEH / 32
 __global__ __launch_bounds__(64, 1) void k_edge_head(KArgs A) {
+    if ((A.flags[FLAG_ASYM] != 0) == SYM) return;
     using X = Dim<D>;
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const size_t r = (size_t)blockIdx.x * 32 + j;
+    const int ur = SYM ? A.pd.ut_rows[((size_t)blockIdx.x * 32 + j) * 2] : 0, um = SYM ? A.pd.ut_rows[((size_t)blockIdx.x * 32 + j) * 2 + 1] : 0;
+    const size_t r = SYM ? (size_t)(ur < 0 ? 0 : ur) : (size_t)blockIdx.x * 32 + j;
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned o1 = (unsigned)(A.wg[JW_EH1_W] * 4), o2 = (unsigned)(A.wg[JW_EH2_W] * 4), o3 = (unsigned)(A.wg[JW_EH3_W] * 4);
     WPipe<4> wp;
@@ -996,8 +1000,14 @@ __global__ __launch_bounds__(64, 1) void k_edge_head(KArgs A) {
         f32x16 acc = mfma_block_p<X::De / 8>(wp, ws, o3, o3, a2, zero16());
         float rr[16];
         acc_bias(acc, A.W + A.wg[JW_EH3_B] + half * 16, rr);
-        if (half == 0 && r < (size_t)A.pd.rows)
+        if (SYM) {
+            if (half == 0 && ur >= 0) {
+                reinterpret_cast<float4*>(A.epred)[ur] = make_float4(rr[0], rr[1], rr[2], rr[3]);
+                reinterpret_cast<float4*>(A.epred)[um] = make_float4(rr[0], rr[1], rr[2], rr[3]);
+            }
+        } else if (half == 0 && r < (size_t)A.pd.rows) {
             reinterpret_cast<float4*>(A.epred)[r] = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        }
     }
 }
 

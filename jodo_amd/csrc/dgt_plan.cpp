@@ -260,6 +260,18 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     put(ag_node, &p->off_ag_node); put(ai_group, &p->off_ai_group); put(ai_t0, &p->off_ai_t0); put(ai_t1, &p->off_ai_t1); put(ai_part, &p->off_ai_part);
     put(ad_group, &p->off_ad_group); put(ad_t0, &p->off_ad_t0); put(ad_t1, &p->off_ad_t1); put(ad_part, &p->off_ad_part); put(ad_big, &p->off_ad_big);
     put(anode_parts, &p->off_anode_parts);
+    {   // upper-triangle rows of every molecule's dense edge tile + their mirrors: the edge head evaluates a symmetric pair once
+        std::vector<int32_t> ut;
+        for (int b = 0; b < B; ++b) {
+            const int n = orig_n[b];
+            const int64_t e0 = orig_eoff[b];
+            for (int a = 0; a < n; ++a)
+                for (int c = a + 1; c < n; ++c) { ut.push_back((int32_t)(e0 + (int64_t)a * n + c)); ut.push_back((int32_t)(e0 + (int64_t)c * n + a)); }
+        }
+        while ((ut.size() / 2) % 32) { ut.push_back(-1); ut.push_back(-1); }
+        p->n_ut_pad = (int)(ut.size() / 2);
+        put(ut, &p->off_ut_rows);
+    }
 
     // workspace layout
     const DgtDims& d = p->dims;

@@ -48,6 +48,8 @@ struct PlanDev {
     const int* ad_part;
     const int* ad_big;      // 1 = group of a molecule that spans several groups: directed mode even for symmetric inputs
     const int* anode_parts; // [Nn_pad] number of attention partials of a node
+    const int* ut_rows;     // [n_ut_pad][2] dense edge row (a, c) with a < c and its mirror (c, a); -1 = padding (edge head, symmetric inputs)
+    int n_ut_pad;
     int n_agroups, n_aitems, n_aditems, amax_parts;
     int Nn, Nn_pad, n_strips, n_items, n_pitems, B, N, max_parts;
     int64_t rows;
@@ -64,8 +66,8 @@ struct jodo_plan {
     jodo_cfg cfg;
     DgtDims dims;
     int B, N, Nn, Nn_pad, n_strips, n_items, n_pitems, max_parts;
-    int n_agroups, n_aitems, n_aditems, amax_parts;
-    size_t off_ag_node, off_ai_group, off_ai_t0, off_ai_t1, off_ai_part, off_ad_group, off_ad_t0, off_ad_t1, off_ad_part, off_ad_big, off_anode_parts;
+    int n_agroups, n_aitems, n_aditems, amax_parts, n_ut_pad;
+    size_t off_ag_node, off_ai_group, off_ai_t0, off_ai_t1, off_ai_part, off_ad_group, off_ad_t0, off_ad_t1, off_ad_part, off_ad_big, off_anode_parts, off_ut_rows;
     int64_t rows, dir_edges;
     std::vector<int32_t> desc;       // concatenated descriptor tables
     size_t off_node_b, off_node_i, off_node_n, off_node_noff, off_node_eoff, off_orig_n, off_orig_noff,
