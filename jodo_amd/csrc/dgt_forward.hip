@@ -90,7 +90,7 @@ struct ProfScope {
 
 // Pair update: every full round of 1024 one-iteration items (one per SIMD) in one launch; the items of the last,
 // sparsely filled round in a second launch with two workgroups per item, one direction each (both recompute the
-// shared trunk: item time x 0.64).  At QM9 B = 2500 a launch has 13 400 items = 13 full rounds + 88.
+// shared trunk: item time x 0.64).  At QM9 B = 2500 a launch has 12 666 items = 12 full rounds + 378.
 template <int D>
 int launch_update_sym(jodo_plan* p, hipStream_t st, KArgs& A) {
     const DgtDims& d = p->dims;
