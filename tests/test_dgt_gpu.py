@@ -348,15 +348,14 @@ def test_per_block_intermediates(fname, layout):
 
 @pytest.mark.parametrize("cfg_name,info,B,over,n_sub", [
     ('vpsde_qm9_uncond_jodo', 'qm9_with_h', 2500, {}, 64),                     # BASELINE configs[1]
-    ('vpsde_geom_uncond_jodo', 'geom_with_h_1', 512, {}, 24),                  # BASELINE configs[2]
-    ('vpsde_geom_uncond_jodo', 'geom_with_h_1', 1250, dict(nf=384), 24),       # per-GPU share of BASELINE configs[3]
+    ('vpsde_geom_uncond_jodo', 'geom_with_h_1', 512, {}, 64),                  # BASELINE configs[2]
+    ('vpsde_geom_uncond_jodo', 'geom_with_h_1', 1250, dict(nf=384), 64),       # per-GPU share of BASELINE configs[3]
 ])
 def test_full_size_batches_match_oracle_on_sampled_molecules(cfg_name, info, B, over, n_sub):
     """The batch sizes the bench numbers are quoted on: a first-step and a self-conditioned evaluation of the FULL
     batch by the kernels; n_sub whole molecules spread over the size range (always including the largest and the
     smallest) are then re-evaluated by the dense oracle as a sub-batch (outputs are batch-independent,
-    SURVEY.md §4; the GEOM sub-batches are padded to 181 atoms, hence fewer of them) and compared at the
-    single-forward tolerance."""
+    SURVEY.md §4) and compared at the single-forward tolerance."""
     from jodo_amd.models import load_dataset_info, get_node_dist
     cfg = make_config(cfg_name, **over)
     model = make_model(cfg, 8, DEV)
