@@ -65,11 +65,11 @@ def test_hip_matches_reference_fixture(fname, layout):
 
 @pytest.mark.parametrize("cfg_name,n_nodes,gain,chunk,over", [
     ('vpsde_qm9_uncond_jodo', [29, 1, 2, 18, 18, 7, 23], 1.0, 0, {}),
-    ('vpsde_qm9_uncond_jodo', [5] * 40 + [19] * 30, 1.5, 3, {}),      # multi-strip, odd chunking, larger activations
+    ('vpsde_qm9_uncond_jodo', [5] * 20 + [19] * 14, 1.5, 3, {}),      # multi-strip, odd chunking, larger activations
     ('vpsde_geom_uncond_jodo', [70, 33, 12], 1.5, 16, {}),
     ('vpsde_qm9_cond_jodo', [9, 9, 14], 1.0, 5, {}),
     ('vpsde_geom_uncond_jodo', [70, 33, 12, 1, 2], 1.5, 0, dict(nf=384)),               # BASELINE config 4 width
-    ('vpsde_geom_uncond_jodo', [19] * 25 + [6] * 30, 1.0, 5, dict(nf=384, n_layers=8, mlp_ratio=2)),
+    ('vpsde_geom_uncond_jodo', [19] * 10 + [6] * 12, 1.0, 5, dict(nf=384, n_layers=8, mlp_ratio=2)),
     ('vpsde_qm9_cond_jodo', [9, 9, 14], 1.0, 5, dict(nf=384)),
     ('vpsde_qm9_uncond_jodo', [29, 1, 2, 18, 18, 7, 23], 1.5, 3, dict(kernel_layout='wide')),
 ])
@@ -378,19 +378,24 @@ def test_full_size_batches_match_oracle_on_sampled_molecules(cfg_name, info, B, 
         assert torch.equal(e, e.transpose(1, 2))
         assert (x * (1 - nm)).abs().max() == 0 and (e * (1 - em.reshape(B, N, N, 1))).abs().max() == 0
     by_size = sorted(range(B), key=lambda b: (n_nodes[b], b))
-    sub = sorted(set(by_size[int(round(i * (B - 1) / (n_sub - 1.0)))] for i in range(n_sub)))
+    sub = sorted(set(by_size[int(round(i * (B - 1) / (n_sub - 1.0)))] for i in range(n_sub)), key=lambda b: (n_nodes[b], b))
     sn = [n_nodes[b] for b in sub]
-    Ns = max(sn)
     assert max(sn) == max(n_nodes) and min(sn) == min(n_nodes) and len(sub) >= n_sub - 4
-    nms, ems = masks(sn)
-    cut = lambda a, k: a[sub][:, :Ns] if k == 1 else a[sub][:, :Ns, :Ns]
-    with torch.no_grad():
-        r1 = O.forward_dense(sd, hp, cut(xh, 1), nms, ems, cut(ex, 2), None, None, nl[sub])
-        r2 = O.forward_dense(sd, hp, cut(xh, 1), nms, ems, cut(ex, 2), cut(x1, 1), cut(e1, 2), nl[sub])
-    close(cut(x1, 1), r1[0], atol=3e-5)
-    close(cut(e1, 2), r1[1], atol=3e-5)
-    close(cut(x2, 1), r2[0], atol=3e-5)
-    close(cut(e2, 2), r2[1], atol=3e-5)
+    # the oracle takes them in four size-sorted chunks: a dense sub-batch is padded to its largest molecule (181 atoms at
+    # GEOM), and outputs do not depend on the batch
+    for lo in range(0, len(sub), 16):
+        part = sub[lo:lo + 16]
+        pn = [n_nodes[b] for b in part]
+        Ns = max(pn)
+        nms, ems = masks(pn)
+        cut = lambda a, k: a[part][:, :Ns] if k == 1 else a[part][:, :Ns, :Ns]
+        with torch.no_grad():
+            r1 = O.forward_dense(sd, hp, cut(xh, 1), nms, ems, cut(ex, 2), None, None, nl[part])
+            r2 = O.forward_dense(sd, hp, cut(xh, 1), nms, ems, cut(ex, 2), cut(x1, 1), cut(e1, 2), nl[part])
+        close(cut(x1, 1), r1[0], atol=3e-5)
+        close(cut(e1, 2), r1[1], atol=3e-5)
+        close(cut(x2, 1), r2[0], atol=3e-5)
+        close(cut(e2, 2), r2[1], atol=3e-5)
 
 
 def test_full_size_batch_properties():
