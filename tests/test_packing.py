@@ -128,3 +128,38 @@ def test_c_packer_equals_python_packer(cfg_name, over):
     del bad['e_block_1.attn_mpnn.lin_edge0.weight']
     with pytest.raises(capi.JodoHipError, match='lin_edge0'):
         capi.pack_weights(model._cfg(), bad)
+
+
+@pytest.mark.parametrize("D", [256, 384])
+def test_fold_kernel_addressing(D):
+    """k_fold_coord (csrc/dgt_kernels_wide.h) reads coord_mlp.0 and the [e ; G] part of input_lin in their PACKED layouts
+    and writes M = W0 diag(1 + sc) W_in[e ; G] in the streaming layout of input_lin.  Its index arithmetic, restated in
+    numpy over the Python packer's blobs, must give exactly pack_projection(M)."""
+    rng = np.random.default_rng(D)
+    De, KQD, KQE, ND = D // 4, D // 8, D // 32, D // 32
+    KQI = 2 * KQE
+    W0 = rng.standard_normal((D, D)).astype(np.float32)
+    Win = rng.standard_normal((D, 2 * De)).astype(np.float32)
+    sc = (0.3 * rng.standard_normal(D)).astype(np.float32)
+    nat, nout = P.natural_in_map, P.natural_out_map
+    c0 = P.pack_projection(W0, nat(D), nout(D))                                       # [ND, KQD, 64, 4]
+    ine = P.pack_projection(Win, P.concat_in_maps(nat(De), nat(De) + De), nout(D))    # [ND, KQI, 64, 4]
+    assert c0.shape == (ND, KQD, 64, 4) and ine.shape == (ND, KQI, 64, 4)
+    out = np.zeros((ND, KQI, 64, 4), np.float64)
+    lane = np.arange(64)
+    i, kh = lane & 31, lane >> 5
+    for nb in range(ND):
+        for qj in range(KQD):
+            for khj in range(2):
+                w = c0[nb, qj, i + 32 * khj, :].astype(np.float64)                    # [64 lanes, 4]: 4 columns j of row o(lane)
+                for cj in range(4):
+                    m = 4 * qj + cj
+                    j = (m >> 4) * 32 + khj * 16 + (m & 15)
+                    s_, h_ = j & 15, (j >> 4) & 1
+                    ij = (s_ & 3) + 4 * h_ + 8 * (s_ >> 2)
+                    f = w[:, cj] * (1.0 + float(sc[j]))                              # [64]
+                    v = ine[j >> 5][:, ij + 32 * kh, :].astype(np.float64)           # [KQI, 64, 4]
+                    out[nb] += f[None, :, None] * v
+    M = (W0.astype(np.float64) * (1.0 + sc.astype(np.float64))[None, :]) @ Win.astype(np.float64)
+    want = P.pack_projection(M.astype(np.float32), P.concat_in_maps(nat(De), nat(De) + De), nout(D))
+    assert np.allclose(out, want, rtol=1e-5, atol=1e-5)
