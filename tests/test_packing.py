@@ -163,3 +163,29 @@ def test_fold_kernel_addressing(D):
     M = (W0.astype(np.float64) * (1.0 + sc.astype(np.float64))[None, :]) @ Win.astype(np.float64)
     want = P.pack_projection(M.astype(np.float32), P.concat_in_maps(nat(De), nat(De) + De), nout(D))
     assert np.allclose(out, want, rtol=1e-5, atol=1e-5)
+
+
+def test_coord_mlp0_through_the_layer_norm_algebra():
+    """The rewrite behind the hoisted pair update, in float64: with pre = S + R + C,
+    W0 [LN(pre) (1 + sc) + sh] + b0  ==  [Z + A + B - mean * wg] * rstd + bs   where Z = W0 (S (1 + sc)), A = W0 (R (1 + sc)),
+    B = W0 (C (1 + sc)), wg = W0 (1 + sc), bs = W0 sh + b0, mean = mean(S) + mean(R) + mean(C), and the variance accumulated
+    around m0 = mean(R) + mean(C) and corrected by mean(S)^2 — the kernel's one-pass form — equals the biased variance."""
+    rng = np.random.default_rng(7)
+    D = 256
+    W0, b0 = rng.standard_normal((D, D)) / 16, rng.standard_normal(D)
+    S, R, C = rng.standard_normal(D), rng.standard_normal(D) + 0.7, rng.standard_normal(D) - 0.3
+    sc, sh = 0.3 * rng.standard_normal(D), rng.standard_normal(D)
+    pre = S + R + C
+    ln = (pre - pre.mean()) / np.sqrt(pre.var() + 1e-6)
+    want = W0 @ (ln * (1 + sc) + sh) + b0
+    m0, mS = R.mean() + C.mean(), S.mean()
+    var = ((S + R + C - m0) ** 2).mean() - mS * mS
+    assert abs(var - pre.var()) < 1e-12
+    rstd, mean = 1.0 / np.sqrt(var + 1e-6), mS + m0
+    Z, A, B = W0 @ (S * (1 + sc)), W0 @ (R * (1 + sc)), W0 @ (C * (1 + sc))
+    wg, bs = W0 @ (1 + sc), W0 @ sh + b0
+    got = (Z + A + B - mean * wg) * rstd + bs
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+    # shared modulation row: Z through the folded matrix M = W0 diag(1 + sc) W_in
+    Win, x = rng.standard_normal((D, 128)) / 11, rng.standard_normal(128)
+    assert np.allclose((W0 * (1 + sc)[None, :]) @ Win @ x, W0 @ ((Win @ x) * (1 + sc)), rtol=1e-12, atol=1e-12)
