@@ -8,14 +8,22 @@ per-step cost is independent of the step index, so K timed steps measure it dire
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload qm9|geom|geom384|cond]
 
-N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; one
-process per GPU, every rank samples its own B molecules (weak scaling), no collective on the data
-path; RCCL is only used for the timing reduction and the final gather of generated molecules.
+N > 1: one process per GPU.  `python bench.py --gpus N` launches the ranks itself (it re-executes under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`); started by a launcher
+(RANK / WORLD_SIZE in the environment) it runs as that rank.  Every rank samples its own B molecules (weak
+scaling), no collective on the data path; RCCL carries the timing reduction and the final gather of the
+generated molecules (`sharded_round`: one complete round through get_sampling_fn(shard=(rank, world)) +
+dist.gather_sampled, wall clock, with the number of ranks whose molecules arrived).
 
 The JSON line also carries
-  roofline      fp32-MFMA roofline of the dominant kernel (k_edge_update), timed live with HIP events
-                on the launch stream (jodo_profile_* in the C ABI); algorithmic FLOPs per launch =
-                directed edges x per-edge FLOPs of that kernel.  `traffic` = HBM bytes per
+  roofline      fp32-MFMA roofline of the dominant kernel (k_edge_update_sym), timed live with HIP events
+                on the launch stream (jodo_profile_* in the C ABI).  `achieved` / `frac` price the work the
+                kernel EXECUTES: the MFMA flops of one launch from the plan's work-item lists (jodo_plan_work,
+                = SQ_INSTS_MFMA x 4096 of the committed PMC pass) plus the vector flops of its per-direction
+                tails, over the launch time, against the 157.3 TFLOP/s fp32 matrix peak — always <= 1.  The
+                SURVEY.md 8d figure (reference formulation, directed, no symmetry / linearity savings) over the
+                same time is reported as `reference_formulation_ratio` (> 1 means the algorithm does less work
+                than the reference's, not that the hardware exceeds its peak).  `traffic` = HBM bytes per
                 launch of that kernel from the committed PMC passes of this same command
                 (profiles/*_pmc_traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE /
                 WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md), `hbm` = the same for the
@@ -58,26 +66,34 @@ PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 SAMPLING_STEPS = 1000
 
 
-def edge_update_flops_per_edge(hp):
-    """Algorithmic FLOPs per directed edge per launch of k_edge_update (share of SURVEY.md §8d F_edge)."""
-    D, De, L, r = hp.nf, hp.de, hp.n_layers, hp.mlp_ratio
-    return (2 * 2 * De * r * De            # edge FFN
-            + 2 * (2 * De) * D             # input_lin, edge + distance part
-            + 2 * D * D + 2 * D * (1 + hp.n_extra_heads)   # coord_mlp
-            + 2 * De * ((2 * De) // L)     # readout
-            + 12 * De + 8 * D)             # LN2/modulate on e, LN/modulate on u
+def reference_formulation_flops(d, n_nodes, shared_time):
+    """FLOPs (multiply-add = 2) of one forward in the reference's formulation — per DIRECTED edge, no pair
+    symmetry, no LayerNorm hoist / fold (per-edge time MLPs excluded, as 8d does).  d: jodo_amd.models.dims.ModelDims.
+    Returns (total, edge-update share per directed edge)."""
+    D, De, T, L, r, XH = d.D, d.De, d.T, d.L, d.r, d.XH
+    QK = d.SH * d.SC
+    upd = (2 * 2 * De * r * De + 2 * (2 * De) * D + 2 * D * D + 2 * D * (1 + XH) + 2 * De * ((2 * De) // L) + 12 * De + 8 * D)
+    f_edge = (2 * (2 * De) * De + 2 * De * QK + 2 * De * D + 2 * 2 * De * r * De + 2 * (2 * De) * D + 2 * D * D + 2 * D * (1 + XH)
+              + 2 * De * ((2 * De) // L) + (3 * QK + 3 * D) + 8 * (De - 1) + (24 * De + 8 * D))
+    f_node = 2 * D * (2 * QK + D) + 2 * 2 * D * r * D + 2 * D * ((2 * D) // L) + 2 * D * De + 2 * 2 * D * D
+    f_mol = 2 * T * (6 * D + 6 * De + 2 * D + 2)
+    E = float(sum(n * (n - 1) for n in n_nodes))
+    Nn = float(sum(n_nodes))
+    Bm = 1.0 if shared_time else float(len(n_nodes))
+    catn, cate = ((2 * D) // L) * L + D, ((2 * De) // L) * L + De
+    f_pro_edge = 2 * (2 * d.ch + De) * De + 8 * (De - 1)
+    f_head_node = 2 * catn * D + 2 * D * (D // 2) + 2 * (D // 2) * d.nd
+    f_head_edge = 2 * (2 * cate * De + 2 * De * (De // 2)) + 2 * (De // 2) * d.ch
+    total = (L * (E * f_edge + Nn * f_node + Bm * f_mol) + E * (f_pro_edge + f_head_edge) + Nn * (2 * (2 * d.nd) * D + f_head_node)
+             + Bm * (2 * 17 * T + 2 * T * T))
+    return total, upd
 
 
-def edge_update_executed_flops_per_pair(hp, uniform):
-    """MFMA FLOPs k_edge_update_sym issues per undirected pair (both directions of an edge): the trunk (edge FFN, readout,
-    shared part S of input_lin) once per pair; coord_mlp.0 with K = 2 De once per pair when every molecule shares one
-    modulation row (pushed through the LayerNorm and folded with input_lin by k_fold_coord), otherwise once per pair at
-    nf = 256 (pushed through only) and once per direction at other widths.  The per-node parts live in k_node_ab (node_post class)."""
-    D, De, r = hp.nf, hp.de, hp.mlp_ratio
-    trunk = 2 * 2 * De * r * De + 2 * De * 32 + 2 * (2 * De) * D
-    if uniform:
-        return trunk + 2 * (2 * De) * D
-    return trunk + (2 * D * D if D == 256 else 2 * (2 * D * D))
+def edge_update_vector_flops_per_directed_edge(d):
+    """fp32 flops the pair update issues on the VALU per DIRECTED edge besides its MFMAs: LayerNorm statistics of
+    pre = S + R_a + C_c (add, subtract, fma per feature: 4 D), the assembled coord_mlp.0 output + SiLU (7 D), coord_mlp.2's
+    three dot products (6 D) and the shared edge LN2 / modulate / gate work (12 De per pair = 6 De per direction)."""
+    return 17 * d.D + 6 * d.De
 
 
 def cpu_model():
@@ -191,6 +207,13 @@ def load_pmc_traffic(workload, batch, upd_ms):
     return (dominant or None), table
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -203,38 +226,45 @@ def main():
     ap.add_argument('--spair-chunk', type=int, default=0)
     ap.add_argument('--layout', default='auto', choices=['auto', 'wide'], help="'wide': width-generic kernels at nf=256")
     ap.add_argument('--graph', action='store_true', help='replay one captured HIP graph per step (jodo_amd/graphed.py)')
+    ap.add_argument('--torch-noise', action='store_true',
+                    help='per-step noise from three torch.randn launches (the reference RNG stream) instead of in-kernel Philox draws')
     ap.add_argument('--plan-opt', action='append', default=[], help='jodo_plan_option=value (experiments), e.g. 3=0')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-full-round', action='store_true', help='skip the end-to-end 1000-step round (N = 1 only leg)')
+    ap.add_argument('--no-full-round', action='store_true', help='skip the end-to-end 1000-step round')
     ap.add_argument('--full-round', action='store_true', help='run the end-to-end round for workloads other than qm9 too')
     ap.add_argument('--breakdown', action='store_true',
                     help='time every kernel class with HIP events (costs ~0.5 ms/step of event packets; default: only the '
                          'dominant pair-update class, which the roofline object needs) and print the table to stderr')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: become the launcher — one process per GPU over RCCL (same command line per rank)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr',
+               '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execvpe(sys.executable, cmd, env)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
-                             % (args.gpus, args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if torch.cuda.device_count() < world:
+            raise SystemExit("--gpus %d but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl')
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
-    from jodo_amd import configs, capi
+    from jodo_amd import configs, capi, fused
     from jodo_amd.diffusion import NoiseScheduleVP
     from jodo_amd.models import get_model_class, deterministic_init_, load_dataset_info, get_node_dist
-    from jodo_amd.sampling import AncestralSampler, build_masks, post_process, mol_process
+    from jodo_amd.sampling import AncestralSampler, build_masks, get_sampling_fn
     from jodo_amd.models.utils import sample_combined_position_feature_noise, sample_symmetric_edge_feature_noise
     from jodo_amd.utils import get_self_cond_fn, get_data_inverse_scaler
-    from oracle import dgt_oracle as O        # only for the FLOP model and the cpu_baseline leg
 
     wl = WORKLOADS[args.workload]
     cfg = configs.get(wl['cfg'])
@@ -244,8 +274,8 @@ def main():
     if args.layout != 'auto':
         cfg.model['kernel_layout'] = args.layout
     B = args.batch or wl['batch']
-    hp = O.Hyper.from_config(cfg)
     model = deterministic_init_(get_model_class(cfg.model.name)(cfg), seed=cfg.seed).to(dev).eval()
+    dims = model.dims                            # product-side derived sizes (jodo_amd/models/dims.py)
     model.max_chunk = args.max_chunk
     model.pair_chunk = args.pair_chunk
     model.spair_chunk = args.spair_chunk
@@ -254,17 +284,20 @@ def main():
 
     # synthetic inputs: atom counts from the training histogram (seed 42 + rank), reference noise shapes
     torch.manual_seed(cfg.seed + rank)
-    n_nodes = get_node_dist(load_dataset_info(wl['info'])).sample(B).tolist()
+    nodes_dist = get_node_dist(load_dataset_info(wl['info']))
+    n_nodes = nodes_dist.sample(B).tolist()
     N = max(n_nodes)
     node_mask, edge_mask = build_masks(n_nodes, N, dev)
     node_nf = cfg.data.atom_types + int(cfg.model.include_fc_charge)
     z = sample_combined_position_feature_noise(B, N, node_nf, node_mask)
     edge_z = sample_symmetric_edge_feature_noise(B, N, cfg.model.edge_ch, edge_mask)
-    context = torch.randn(B, hp.cond_ch, device=dev) if hp.cond_ch else None
+    context = torch.randn(B, dims.cond_ch, device=dev) if dims.cond_ch else None
     ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0,
                          continuous_beta_1=cfg.sde.continuous_beta_1)
     time_steps = torch.linspace(ns.T, 1e-3, SAMPLING_STEPS)
-    sampler = AncestralSampler(ns, time_steps, True, True, True, get_self_cond_fn(cfg))
+    # per-step noise: drawn inside the fused update kernel (Philox keyed by (seed, rank)) unless --torch-noise
+    new_noise = lambda: None if args.torch_noise else fused.DeviceNoise.for_rank(cfg.seed, rank)
+    sampler = AncestralSampler(ns, time_steps, True, True, True, get_self_cond_fn(cfg), device_noise=new_noise())
 
     L = capi.lib()
     if args.graph:
@@ -314,6 +347,9 @@ def main():
     cnt = (ctypes.c_int32 * 8)()
     capi.check(L.jodo_profile_read(plan['handle'], ms, cnt), 'profile_read')
     capi.check(L.jodo_profile_enable(plan['handle'], 0), 'profile_enable')
+    flags_now = model.last_flags.cpu().tolist()
+    work = (ctypes.c_double * 8)()
+    capi.check(L.jodo_plan_work(plan['handle'], int(flags_now[2]), int(not flags_now[4]), work), 'plan_work')
     graph_info = None
     if not args.graph and world == 1:
         # extra, reported beside the headline: the same step replayed as ONE captured HIP graph (no per-step
@@ -322,6 +358,7 @@ def main():
         from jodo_amd.graphed import GraphedAncestralRound
         try:
             with torch.no_grad():
+                sampler.device_noise = new_noise()
                 rnd = GraphedAncestralRound(sampler, model, node_mask, edge_mask, context)
                 rnd.prepare(z, edge_z)
                 for _ in range(3):
@@ -353,28 +390,22 @@ def main():
         elapsed = tt.item()
     step_s = elapsed / args.steps
 
-    # not timed: finish the round's host side once so the whole path is exercised (device decode + gather)
-    from jodo_amd import fused
+    # not timed: finish the round's host side once so the whole path is exercised (device decode)
     with torch.no_grad():
         pos, at, fc, et = fused.decode(cfg, st['x_mean'], st['edge_x_mean'], fused.n_nodes_from_mask(node_mask))
-    if world > 1:
-        from jodo_amd.dist import gather_molecules
-        gathered = gather_molecules(pos, at, fc, et, torch.tensor(n_nodes, device=dev))
-        n_total = gathered['n_nodes'].numel() if rank == 0 else 0
-    else:
-        n_total = len(fused.mols_from_decoded(pos, at, fc, et, n_nodes))
+    n_total = len(fused.mols_from_decoded(pos, at, fc, et, n_nodes))
     nan_fired = model.nan_guard_fired()
 
-    # ---- one complete round through the public entry points, wall clock (N = 1) -----------------------------------
+    # ---- one complete round through the public entry points, wall clock ---------------------------------------------
+    prop = _SyntheticContext(dims.cond_ch) if dims.cond_ch else None
     full_round = None
     if world == 1 and not args.no_full_round and (args.workload == 'qm9' or args.full_round):
-        from jodo_amd.sampling import get_sampling_fn
         full_round = {}
-        for mode, hg in (('eager', False), ('hip_graph', True)):
+        for mode, hg, dn in (('eager', False, not args.torch_noise), ('eager_torch_randn', False, False)):
             try:
                 torch.manual_seed(cfg.seed)
-                fn = get_sampling_fn(cfg, ns, get_node_dist(load_dataset_info(wl['info'])), B, B, get_data_inverse_scaler(cfg),
-                                     prop_dist=_SyntheticContext(hp.cond_ch) if hp.cond_ch else None, return_raw=True, hip_graph=hg)
+                fn = get_sampling_fn(cfg, ns, nodes_dist, B, B, get_data_inverse_scaler(cfg), prop_dist=prop, return_raw=True,
+                                     hip_graph=hg, device_noise=dn)
                 torch.cuda.synchronize()
                 tr = time.perf_counter()
                 with contextlib.redirect_stdout(sys.stderr):      # the sampler prints its progress like the reference does;
@@ -388,19 +419,51 @@ def main():
                 full_round[mode] = {'error': repr(exc)}
         full_round['note'] = ('get_sampling_fn -> sampler -> device decode -> host tuples, one call: atom-count draw, masks, '
                               'initial noise, plan creation, %d denoise steps, decode and device->host copies all inside the '
-                              'clock (weights already packed)' % int(cfg.sampling.steps))
+                              'clock (weights already packed); eager draws the per-step noise inside the update kernel '
+                              '(Philox), eager_torch_randn with three torch.randn launches per step (the reference RNG stream)'
+                              % int(cfg.sampling.steps))
+    # ---- N > 1: one complete SHARDED round + the RCCL gather of the generated molecules --------------------------------
+    sharded = None
+    if world > 1 and not args.no_full_round:
+        from jodo_amd.dist import gather_sampled
+        try:
+            fn = get_sampling_fn(cfg, ns, nodes_dist, B, B * world, get_data_inverse_scaler(cfg), prop_dist=prop, return_raw=True,
+                                 shard=(rank, world), shard_mode='perf', seed=cfg.seed)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tr = time.perf_counter()
+            with contextlib.redirect_stdout(sys.stderr):
+                mine = fn(model)
+                everyone = gather_sampled(mine, fn.last_indices, device=dev)          # RCCL all_gather of the decoded molecules
+            torch.cuda.synchronize()
+            dist.barrier()
+            tr = time.perf_counter() - tr
+            tt = torch.tensor([tr], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            # which ranks' molecules arrived: every rank reports the size of its share, the gathered list must hold them all
+            share = torch.tensor([len(mine)], device=dev, dtype=torch.int64)
+            shares = [torch.empty_like(share) for _ in range(world)]
+            dist.all_gather(shares, share)
+            sharded = {'round_seconds': tt.item(), 'molecules': len(everyone), 'value': len(everyone) / tt.item(), 'unit': 'molecules/s',
+                       'ranks_seen': sum(1 for s_ in shares if int(s_) > 0), 'molecules_per_rank': [int(s_) for s_ in shares],
+                       'steps': int(cfg.sampling.steps),
+                       'note': 'get_sampling_fn(shard=(rank, world), shard_mode=perf) on every rank + dist.gather_sampled (RCCL '
+                               'all_gather over xGMI), wall clock between two barriers, max over ranks'}
+        except Exception as exc:
+            sharded = {'error': repr(exc)}
     if rank == 0:
         E = sum(n * (n - 1) for n in n_nodes)
-        flops_launch = E * edge_update_flops_per_edge(hp)
-        names = ['prologue', 'node_pre', 'edge_attn', 'softmax', 'edge_msgs', 'node_post', 'edge_update', 'epilogue']   # edge_attn: fused attention (nf 256); pair scores kernel on the width-generic path
+        shared_row = bool(flags_now[2]) and not dims.cond_ch
+        ref_total, ref_upd_edge = reference_formulation_flops(dims, n_nodes, shared_row)
+        names = ['prologue', 'node_pre', 'edge_attn', 'reserved3', 'reserved4', 'node_post', 'edge_update', 'epilogue']
         per_class = {names[c]: (ms[c] / max(cnt[c], 1), cnt[c]) for c in range(8)}
         upd_ms, upd_n = per_class['edge_update']
-        achieved = flops_launch / (upd_ms * 1e-3) if upd_ms > 0 else 0.0
-        flags_now = model.last_flags.cpu().tolist()
-        exec_launch = (E // 2) * edge_update_executed_flops_per_pair(hp, bool(flags_now[2]))
-        # sampling shares one noise level per batch and the kernels then evaluate the time-modulation GEMVs once
-        # (uniform_t flag set on the device): count them once, not once per molecule
-        total_flops = O.algorithmic_flops(hp, n_nodes, shared_time=bool(flags_now[2]) and not hp.cond_ch)['total']
+        nblk = dims.L
+        mfma_launch = work[6] / nblk                              # executed MFMA flops of ONE pair-update launch (one block)
+        valu_launch = E * edge_update_vector_flops_per_directed_edge(dims)
+        exec_launch = mfma_launch + valu_launch
+        achieved = exec_launch / (upd_ms * 1e-3) if upd_ms > 0 else 0.0
+        exec_step = sum(work)                                    # executed MFMA flops of one forward, all kernels
         traffic, hbm = load_pmc_traffic(args.workload, B, upd_ms)
         out = {
             'metric': 'molecules/sec (1000-step ancestral)',
@@ -413,26 +476,34 @@ def main():
             'config': {'workload': wl['name'], 'batch_per_gpu': B, 'sampling_steps': SAMPLING_STEPS,
                        'directed_edges_per_step': E, 'nodes_per_step': sum(n_nodes), 'max_n': N,
                        'weights': 'deterministic random init (trained checkpoints are external downloads)',
+                       'step_noise': 'torch.randn x3 per step' if args.torch_noise else 'in-kernel Philox4x32-10 (jodo_sampler_step_rng)',
                        'parallelism': 'batch shard x%d, no data-path collective' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_edge_update', 'achieved': achieved / 1e12, 'peak': PEAK_FP32_MFMA / 1e12,
+            'roofline': {'bound': 'mfma', 'kernel': 'k_edge_update_sym' if not flags_now[4] else 'k_edge_update',
+                         'achieved': achieved / 1e12, 'peak': PEAK_FP32_MFMA / 1e12,
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA, 'traffic': traffic, 'hbm': hbm,
-                         'note': 'achieved = ALGORITHMIC flops of the reference formulation (SURVEY.md 8d share of F_edge x '
-                                 'directed edges) / launch time.  The kernel issues fewer multiply-adds than that (pair symmetry, '
-                                 'coord_mlp.0 pushed through the LayerNorm and folded with input_lin), so frac can exceed 1; '
-                                 'mfma_util = the MFMA flops actually issued / launch time / peak is the hardware utilisation.  '
-                                 'One launch = the pair-update work of one block: the dispatches of k_edge_update_sym (variants '
-                                 'that exit on a device flag included) inside one HIP-event bracket; rocprofv3 lists them '
-                                 'separately (their durations add up to avg_launch_ms)',
-                         'avg_launch_ms': upd_ms, 'launches': upd_n, 'alg_flops_per_launch': flops_launch,
-                         'executed_mfma_flops_per_launch': exec_launch,
-                         'mfma_util': (exec_launch / (upd_ms * 1e-3) / PEAK_FP32_MFMA) if upd_ms > 0 else 0.0,
-                         'whole_step_TFLOPs': total_flops / step_s / 1e12,
-                         'whole_step_frac': total_flops / step_s / PEAK_FP32_MFMA},
+                         'note': 'achieved = fp32 flops the kernel EXECUTES per launch (MFMA flops from the plan work model '
+                                 'jodo_plan_work = SQ_INSTS_MFMA x 4096 of the committed PMC pass, + the vector flops of its '
+                                 'per-direction tails) / launch time; frac <= 1 by construction.  One launch = the pair-update work '
+                                 'of one block inside one HIP-event bracket on the launch stream.  reference_formulation_ratio = the '
+                                 'SURVEY.md 8d count for the same launch (reference formulation: per directed edge, no pair symmetry, '
+                                 'coord_mlp.0 per edge) / launch time / peak: an algorithmic speed-up figure, > 1 is not a hardware '
+                                 'fraction',
+                         'avg_launch_ms': upd_ms, 'launches': upd_n,
+                         'executed_mfma_flops_per_launch': mfma_launch, 'executed_vector_flops_per_launch': valu_launch,
+                         'mfma_frac': (mfma_launch / (upd_ms * 1e-3) / PEAK_FP32_MFMA) if upd_ms > 0 else 0.0,
+                         'reference_formulation_flops_per_launch': E * ref_upd_edge,
+                         'reference_formulation_ratio': (E * ref_upd_edge / (upd_ms * 1e-3) / PEAK_FP32_MFMA) if upd_ms > 0 else 0.0,
+                         'whole_step_executed_mfma_TFLOP': exec_step / 1e12,
+                         'whole_step_TFLOPs': exec_step / step_s / 1e12,
+                         'whole_step_frac': exec_step / step_s / PEAK_FP32_MFMA,
+                         'whole_step_reference_formulation_ratio': ref_total / step_s / PEAK_FP32_MFMA,
+                         'executed_mfma_flops_per_class': {names[c]: work[c] for c in range(8) if work[c] > 0}},
             # per-class totals per step; classes other than edge_update are only timed with --breakdown
             'kernel_ms': {k: round(v[0] * (v[1] / args.steps), 4) for k, v in per_class.items() if v[1] > 0},
             'hip_graph_replay': graph_info,
             'steady_state': steady,
             'full_round': full_round,
+            'sharded_round': sharded,
             'molecules_decoded': n_total, 'nan_guard': bool(nan_fired),
             'device_flags': dict(zip(('nan', 'first_step', 'uniform_t', 'cond_nonzero', 'asymmetric_edges'), flags_now[:5])),
         }

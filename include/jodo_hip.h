@@ -54,7 +54,7 @@ typedef struct {
 
 /* Slots of the weight-offset table handed to jodo_dgt_forward (offsets in floats into the packed
  * weight blob produced by jodo_dgt_pack_weights; tests/test_packing.py keeps this enum, the C packer and the
- * independent Python packer jodo_amd/packing_model.py in lock-step, blob for blob). */
+ * independent Python packer tests/py_packing_model.py in lock-step, blob for blob). */
 enum jodo_wslot_global {
     JW_TIME_FREQ = 0, JW_TIME_W1, JW_TIME_B1, JW_TIME_W3, JW_TIME_B3,
     JW_COND_W0, JW_COND_B0, JW_COND_W2, JW_COND_B2, JW_COND_LIN_W, JW_COND_LIN_B,
@@ -139,6 +139,13 @@ int jodo_dgt_forward(jodo_plan* plan, const void* desc_dev, const float* packed_
                      const float* cond_edge_x, const float* noise_level, const float* context,
                      float* out_xh, float* out_edge, int32_t* flags_dev, void* workspace, void* stream);
 
+/* Executed-work model of a plan (measurement): fp32 flops that the kernels of ONE jodo_dgt_forward issue on the matrix pipe
+ * (v_mfma_f32_32x32x2_f32 = 4096 flop per instruction), per launch class (enum jodo_prof_class below; array of
+ * JODO_PROF_COUNT doubles), counted from the plan's work-item lists and the kernels' loop structure, padded lanes included.
+ * uniform_t / symmetric = flags [2] / ![4] of the call being priced (they select the kernel variants that do the work).
+ * This is the numerator of bench.py's roofline fraction: work the hardware executes, not the reference formulation's. */
+int jodo_plan_work(const jodo_plan* plan, int uniform_t, int symmetric, double* mfma_flops_per_class);
+
 /* Work-decomposition options of a plan (defaults are the measured-best settings).  These replace the
  * environment switches of round 1: the library reads no environment variables. */
 enum jodo_plan_option {
@@ -148,7 +155,7 @@ enum jodo_plan_option {
                                      one per direction; 0: one workgroup per item */
     JODO_OPT_NODE_POST_WAVES = 2, /* 0 (default): automatic; 1 / 2 / 4: waves per strip for every strip of k_node_post;
                                    * 12 / 14: automatic split, 2 / 4 waves per strip of the remainder launch */
-    JODO_OPT_ATTN_VARIANT = 3,    /* nf 256 pair attention kernel, weight residency / hand-over granularity: 0, 1, 2 (dgt_kernels_attn.h) */
+    JODO_OPT_ATTN_VARIANT = 3,    /* nf 256 pair attention kernel, weight residency / hand-over granularity: 0 (default), 1, 2, 3 (dgt_kernels_attn.h); other values are rejected */
     JODO_OPT_COUNT
 };
 int jodo_plan_set_option(jodo_plan* plan, int option, int value);
@@ -205,6 +212,16 @@ int jodo_sampler_step_tab(int B, int N, int node_feats, int edge_ch, const int32
                           const int32_t* step_dev, const float* x, const float* edge_x, const float* pred,
                           const float* edge_pred, const float* eps_pos, const float* eps_feat, const float* eps_edge,
                           float* x_next, float* edge_next, float* x_mean, float* edge_mean, void* stream);
+/* Device-noise form of the same update ("one jodo_sampler_step kernel with Philox"): the three
+ * normal draws of models/utils.py:67-99 are generated inside the kernel by a counter-based generator (Philox4x32-10 +
+ * Box-Muller) keyed by `seed`, counter = (element, draw index, stream); masking, centre-of-mass removal and lower-triangle
+ * mirroring as above.  draw index = `draw` (host scalars; coef_tab_dev = step_dev = NULL) or `draw` + *step_dev with the
+ * coefficients from row *step_dev of coef_tab_dev (captured hipGraph).  Same distribution as the reference's draws, a
+ * different stream: parity runs keep the replayed-draw form above.  Callers give every rank its own seed. */
+int jodo_sampler_step_rng(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, float c_x, float c_pred,
+                          float sigma, const float* coef_tab_dev, const int32_t* step_dev, uint64_t seed, uint32_t draw,
+                          const float* x, const float* edge_x, const float* pred, const float* edge_pred, float* x_next,
+                          float* edge_next, float* x_mean, float* edge_mean, void* stream);
 int jodo_step_begin(int B, const float* coef_tab_dev, const int32_t* step_dev, float* noise_level_out, void* stream);
 int jodo_step_end(int32_t* step_dev, void* stream);
 /* jodo_dpm_update  <- one update of the hybrid DPM-Solver++ sampler, mix_dpm_solver.py: positions take the ancestral step
@@ -226,6 +243,13 @@ int jodo_dpm_update(int B, int N, int node_feats, int edge_ch, const int32_t* n_
                     const float* x_base, const float* edge_base, const float* P, const float* eP, const float* DA, const float* eDA,
                     const float* DB, const float* eDB, const float* PP, const float* eps_pos, float* x_out, float* edge_out,
                     void* stream);
+/* jodo_dpm_update with the position noise drawn in the kernel (see jodo_sampler_step_rng): draw index = draw (+ *step_dev *
+ * draw_mul with a device table, so that the two updates of a captured outer step use draws 2k and 2k + 1). */
+int jodo_dpm_update_rng(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, const float* coef8_host,
+                        const float* coef_tab_dev, const int32_t* step_dev, int tab_stride, int tab_col, uint64_t seed,
+                        uint32_t draw, uint32_t draw_mul, const float* x_pos, const float* x_base, const float* edge_base,
+                        const float* P, const float* eP, const float* DA, const float* eDA, const float* DB, const float* eDB,
+                        const float* PP, float* x_out, float* edge_out, void* stream);
 int jodo_step_begin_at(int B, const float* coef_tab_dev, const int32_t* step_dev, int tab_stride, int tab_col,
                        float* noise_level_out, void* stream);
 int jodo_decode(int B, int N, int atom_types, int include_fc, int edge_ch, int compress_edge, int centered,

@@ -7,7 +7,7 @@
 //   * dense projections run on v_mfma_f32_32x32x2_f32 in the transposed orientation
 //       D[out_feature, item] += W[out_feature, k] * X[k, item]
 //     with the pre-packed weights as A operand (one 16-byte load per lane feeds 4 MFMAs, see
-//     jodo_amd/packing.py) and the activation registers as B operand.  The accumulator of an output
+//     csrc/dgt_pack.cpp) and the activation registers as B operand.  The accumulator of an output
 //     block *is* the next projection's B operand: chains of projections stay in registers.
 //   * per-item reductions over features (LayerNorm, head scores) are in-lane sums plus one
 //     exchange with lane ^ 32.

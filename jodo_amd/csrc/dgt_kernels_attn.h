@@ -23,7 +23,7 @@
 // source itself — no hand-over, no barriers, twice the matrix work per edge.
 //
 // template <D, WQK>: node width and q / k arrangement.  WQK = false (nf = 256 only): the tuned 8-block arrangement
-// (jodo_amd/packing.py qk_out_map), edge_emb + lin_edge0 (96 KiB) resident in LDS, lin_edge1 streamed from L2 through
+// (csrc/dgt_pack.cpp qk_out_map), edge_emb + lin_edge0 (96 KiB) resident in LDS, lin_edge1 streamed from L2 through
 // the software-pipelined ring; WQK = true: one 32-row block per head (qk_out_map_wide; the only option at nf = 384,
 // SC = 27), all weights streamed.  40 KiB of LDS carry the hand-over buffers.
 #pragma once

@@ -5,7 +5,7 @@
 //   * all weights are streamed from L2 through the software-pipelined ring (the K = De projections of
 //     the attention kernels no longer fit in LDS at De = 96), prefetch group of 4 quads at D = 384 (K = 96 gives
 //     12-quad blocks), 8 at D = 256;
-//   * score heads use the "one head per 32-row block" arrangement (jodo_amd/packing.py
+//   * score heads use the "one head per 32-row block" arrangement (csrc/dgt_pack.cpp
 //     qk_out_map_wide): SC = 27 has no 16 + 2 split, and padding a head to 32 rows keeps its reduction
 //     in-lane (the attention edge phase itself is the width-generic k_edge_attn, dgt_kernels_attn.h);
 //   * the pair update parks half of the shared part of input_lin in LDS at D = 384 (registers hold the rest).

@@ -329,6 +329,65 @@ extern "C" int jodo_plan_stats(const jodo_plan* p, int64_t* o) {
     o[0] = p->Nn; o[1] = p->rows; o[2] = p->dir_edges; o[3] = p->n_strips; o[4] = p->n_items; o[5] = p->max_parts;
     return JODO_OK;
 }
+
+// ---- executed-work model (bench.py's roofline leg) ---------------------------------------------------------
+// fp32 flops the kernels of ONE forward issue on the matrix pipe (v_mfma_f32_32x32x2_f32 = 4096 flop each), per launch class,
+// counted from the plan's own work-item lists and the loop structure of the kernels: out-blocks of 32 x K / 2 k-steps per
+// projection and 32-item wave iteration, padded lanes included — what SQ_INSTS_MFMA x 4096 measures (tools/pmc_work.py checks
+// the two against each other).  uniform_t / symmetric: the device flags of the call (shared modulation row; pair path).
+namespace {
+inline double proj(int out, int K) { return (double)((out + 31) / 32) * (double)((K + 7) / 8 * 4); }   // MFMAs per wave iteration
+}
+extern "C" int jodo_plan_work(const jodo_plan* p, int uniform_t, int symmetric, double* mfma_flops) {
+    if (!p || !mfma_flops) return jodo_set_error(JODO_ERR_ARG, "plan_work: null");
+    const DgtDims& d = p->dims;
+    const bool tuned = !d.wide, sym = symmetric && !p->force_directed && p->n_pitems > 0;
+    const int D = d.D, De = d.De, L = d.L, r = d.r;
+    const int32_t* dsc = p->desc.data();
+    double cls[JODO_PROF_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double strips = p->n_strips;
+    // prologue: time MLP second layer + fused modulation projection (row groups of 32 molecules; one group when the row is
+    // shared), conditional path, embeddings (k_fold_coord is double-precision vector work)
+    const double rowgroups = (uniform_t && d.cond_ch == 0) ? 1.0 : (double)((p->B + 31) / 32);
+    cls[JODO_PROF_PROLOGUE] += rowgroups * (proj(d.T, d.T) + proj((int)d.Mtot, d.T));
+    if (d.cond_ch > 0) cls[JODO_PROF_PROLOGUE] += (double)((p->B * d.cond_ch + 31) / 32) * proj(D, D) + (double)((p->B + 31) / 32) * proj(d.T, d.cond_ch * D);
+    cls[JODO_PROF_PROLOGUE] += strips * proj(D, d.ndp);
+    double dir_iters = 0, pair_iters = 0;                 // wave iterations of the directed / pair item lists
+    for (int i = 0; i < p->n_items; ++i) dir_iters += dsc[p->off_item_t1 + i] - dsc[p->off_item_t0 + i];
+    for (int i = 0; i < p->n_pitems; ++i) pair_iters += dsc[p->off_pitem_t1 + i] - dsc[p->off_pitem_t0 + i];
+    cls[JODO_PROF_PROLOGUE] += dir_iters * proj(De, d.einp + De);                       // k_embed_edges: every dense row
+    // per block
+    const int nqb = tuned ? 8 : d.SH;                                                    // 32-row blocks of q / k / lin_edge0
+    const double qkv = 2.0 * nqb * (D / 2) + proj(D, D);
+    const bool fuse_pre = tuned && p->opt[JODO_OPT_FUSE_NEXT_QKV] != 0 && L > 1 && p->n_strips >= 1024;
+    cls[JODO_PROF_NODE_PRE] += strips * qkv * (fuse_pre ? 1 : L);
+    if (fuse_pre) cls[JODO_PROF_NODE_POST] += strips * qkv * (L - 1);
+    cls[JODO_PROF_NODE_POST] += L * strips * (proj(De, D) + proj(r * D, D) + proj(D, r * D) + 2 * proj(D, D) + proj(d.cnp, D));
+    const bool hoist = sym && (D == 256 || uniform_t);                                  // coord_mlp.0 pushed through the LayerNorm
+    if (p->n_pitems > 0 && (D == 256 || uniform_t)) cls[JODO_PROF_NODE_POST] += L * strips * 2 * proj(D, D);      // k_node_ab
+    // fused attention: pair items (4 waves x offsets) for groups of whole molecules, directed items otherwise
+    const double att_iter = proj(De, 2 * De) + nqb * (double)(De / 2) + proj(D, De);
+    double att_iters = 0;
+    for (int i = 0; i < p->n_aitems; ++i) if (sym) att_iters += 4.0 * (dsc[p->off_ai_t1 + i] - dsc[p->off_ai_t0 + i]);
+    for (int i = 0; i < p->n_aditems; ++i)
+        if (!sym || dsc[p->off_ad_big + i]) att_iters += 4.0 * (dsc[p->off_ad_t1 + i] - dsc[p->off_ad_t0 + i]);
+    cls[JODO_PROF_EDGE_ATTN] += L * att_iters * att_iter;
+    // edge update: trunk (edge FFN, readout, e + distance part S of input_lin) + coord_mlp.0 in its form of the call
+    const double trunk = proj(r * De, De) + proj(De, r * De) + proj(d.cep, De) + proj(D, 2 * De);
+    if (sym) {
+        const double c0 = (uniform_t && d.cond_ch == 0) ? proj(D, 2 * De) : (hoist ? proj(D, D) : 2 * proj(D, D));
+        cls[JODO_PROF_EDGE_UPDATE] += L * pair_iters * (trunk + c0);
+    } else {
+        cls[JODO_PROF_EDGE_UPDATE] += L * dir_iters * (trunk + proj(D, D));
+    }
+    // heads
+    cls[JODO_PROF_EPILOGUE] += strips * (proj(D, d.KNH) + proj(D / 2, D) + proj(d.nd, D / 2));
+    const double eh = 2 * proj(De, d.KEH) + proj(De, 2 * De) + proj(32, De);
+    cls[JODO_PROF_EPILOGUE] += (sym ? (double)(p->n_ut_pad / 32) : (double)((p->rows + 31) / 32)) * eh;
+    for (int c = 0; c < JODO_PROF_COUNT; ++c) mfma_flops[c] = cls[c] * 4096.0;
+    return JODO_OK;
+}
+
 extern "C" int jodo_plan_upload(jodo_plan* p, void* desc_dev, void* stream) {
     if (!p || !desc_dev) return jodo_set_error(JODO_ERR_ARG, "plan_upload: null");
     hipError_t e = hipMemcpyAsync(desc_dev, p->desc.data(), p->desc.size() * sizeof(int32_t), hipMemcpyHostToDevice,
@@ -351,6 +410,10 @@ extern "C" int jodo_plan_set_option(jodo_plan* p, int option, int value) {
     if (option < 0 || option >= JODO_OPT_COUNT) return jodo_set_error(JODO_ERR_ARG, "plan_set_option: unknown option %d", option);
     if (option == JODO_OPT_NODE_POST_WAVES && value != 0 && value != 1 && value != 2 && value != 4 && value != 12 && value != 14)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: node-post waves per strip must be 0 (auto), 1, 2 or 4");
+    if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT) && value != 0 && value != 1)
+        return jodo_set_error(JODO_ERR_ARG, "plan_set_option: option %d is a switch (0 or 1), got %d", option, value);
+    if (option == JODO_OPT_ATTN_VARIANT && (value < 0 || value > 3))
+        return jodo_set_error(JODO_ERR_ARG, "plan_set_option: attention variant must be 0..3, got %d", value);
     p->opt[option] = value;
     return JODO_OK;
 }

@@ -21,6 +21,61 @@
 
 namespace {
 
+// ---- counter-based normal draws (SURVEY.md §8f row 1 "device noise"): Philox4x32-10 (Salmon et al., SC'11) keyed by the
+// caller's 64-bit seed, counter = (element lo, element hi, draw index, stream id); four uniforms -> four normals by
+// Box-Muller.  A value depends only on (seed, draw, stream, element): no generator state, so the same call replays in a
+// captured hipGraph (draw index from a device counter), both triangle halves of the edge noise evaluate the SAME
+// counter (exactly symmetric), and ranks with different seeds never share a stream.  oracle/philox_ref.py restates
+// it in numpy (tests only).
+struct Rng { unsigned long long seed; unsigned draw; unsigned draw_mul; int on; };
+enum { RNG_POS = 0, RNG_FEAT = 1, RNG_EDGE = 2 };
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// four N(0,1) draws of element `elem` of stream `stream` at draw index `draw`
+__device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned draw, unsigned stream, unsigned long long elem,
+                                               float z[4]) {
+    unsigned u[4];
+    philox4x32_10((unsigned)elem, (unsigned)(elem >> 32), draw, stream, (unsigned)seed, (unsigned)(seed >> 32), u);
+    // u1 in (0, 1], u2 in [0, 1): r = sqrt(-2 ln u1), angle = 2 pi u2
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float u1 = ((float)(u[2 * p] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+        const float u2 = (float)(u[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
+        const float r = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincospif(2.0f * u2, &sn, &cs);
+        z[2 * p] = r * cs; z[2 * p + 1] = r * sn;
+    }
+}
+__device__ __forceinline__ unsigned rng_draw(const Rng& g, const int* step) { return g.draw + (step ? (unsigned)(*step) * g.draw_mul : 0u); }
+// raw position draw of atom (b, i): component f in 0..2
+__device__ __forceinline__ void rng_pos3(const Rng& g, unsigned draw, size_t atom, float e[3]) {
+    float z[4];
+    philox_normal4(g.seed, draw, RNG_POS, atom, z);
+    e[0] = z[0]; e[1] = z[1]; e[2] = z[2];
+}
+__device__ __forceinline__ float rng_feat(const Rng& g, unsigned draw, size_t atom, int k) {
+    float z[4];
+    philox_normal4(g.seed, draw, RNG_FEAT, atom * 64 + (size_t)(k >> 2), z);       // up to 256 feature channels per atom
+    return z[k & 3];
+}
+// raw edge draw of the unordered pair (lo > hi) of molecule b, channel f < 4
+__device__ __forceinline__ float rng_edge(const Rng& g, unsigned draw, size_t cell_lower, int f) {
+    float z[4];
+    philox_normal4(g.seed, draw, RNG_EDGE, cell_lower, z);
+    return z[f & 3];
+}
+
 // one workgroup per molecule: mean / next state of the node tensor [N, F] (F = 3 + nd)
 // coef (optional): device table [steps][4] = (c_x, c_pred, sigma, noise_level), row *step — lets a captured
 // HIP graph of one sampling step be replayed for every step (host scalars would be baked into the graph)
@@ -28,15 +83,18 @@ __global__ __launch_bounds__(256) void k_step_nodes(int N, int F, const int* __r
                                                     float sigma, const float* __restrict__ coef, const int* __restrict__ step,
                                                     const float* __restrict__ x, const float* __restrict__ pred,
                                                     const float* __restrict__ eps_pos, const float* __restrict__ eps_feat,
-                                                    float* __restrict__ x_next, float* __restrict__ x_mean) {
+                                                    Rng rng, float* __restrict__ x_next, float* __restrict__ x_mean) {
     const int b = blockIdx.x, n = n_nodes[b], nd = F - 3;
     if (coef) { const float* c = coef + 4 * (size_t)(*step); c_x = c[0]; c_pred = c[1]; sigma = c[2]; }
+    const unsigned draw = rng.on ? rng_draw(rng, coef ? step : nullptr) : 0u;
     __shared__ float red[3][256];
     // centre of mass of the masked position noise: sum over real atoms / n  (remove_mean_with_mask)
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float* e = eps_pos + ((size_t)b * N + i) * 3;
-        s0 += e[0]; s1 += e[1]; s2 += e[2];
+        float ev[3];
+        if (rng.on) rng_pos3(rng, draw, (size_t)b * N + i, ev);
+        else { const float* e = eps_pos + ((size_t)b * N + i) * 3; ev[0] = e[0]; ev[1] = e[1]; ev[2] = e[2]; }
+        s0 += ev[0]; s1 += ev[1]; s2 += ev[2];
     }
     red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
     __syncthreads();
@@ -56,7 +114,12 @@ __global__ __launch_bounds__(256) void k_step_nodes(int N, int F, const int* __r
         // products rounded separately, then added: the op order of the framework expression c_x*x + c_pred*pred
         const float mean = __fadd_rn(__fmul_rn(c_x, x[g]), __fmul_rn(c_pred, pred[g]));
         float e = 0.f;
-        if (i < n) e = f < 3 ? eps_pos[((size_t)b * N + i) * 3 + f] - m[f] : eps_feat[((size_t)b * N + i) * nd + (f - 3)];
+        if (i < n) {
+            if (rng.on) {
+                if (f < 3) { float ev[3]; rng_pos3(rng, draw, (size_t)b * N + i, ev); e = ev[f] - m[f]; }
+                else e = rng_feat(rng, draw, (size_t)b * N + i, f - 3);
+            } else e = f < 3 ? eps_pos[((size_t)b * N + i) * 3 + f] - m[f] : eps_feat[((size_t)b * N + i) * nd + (f - 3)];
+        }
         x_mean[g] = mean;
         x_next[g] = __fadd_rn(mean, __fmul_rn(sigma, e));
     }
@@ -66,7 +129,7 @@ __global__ __launch_bounds__(256) void k_step_nodes(int N, int F, const int* __r
 __global__ __launch_bounds__(256) void k_step_edges(int B, int N, int ch, const int* __restrict__ n_nodes, float c_x, float c_pred,
                                                     float sigma, const float* __restrict__ coef, const int* __restrict__ step,
                                                     const float* __restrict__ ex, const float* __restrict__ epred,
-                                                    const float* __restrict__ eps, float* __restrict__ e_next,
+                                                    const float* __restrict__ eps, Rng rng, float* __restrict__ e_next,
                                                     float* __restrict__ e_mean) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t NN = (size_t)N * N, tot = (size_t)B * NN * ch;
@@ -80,7 +143,8 @@ __global__ __launch_bounds__(256) void k_step_edges(int B, int N, int ch, const 
     float e = 0.f;
     if (a < n && c < n && a != c) {
         const int lo = a > c ? a : c, hi = a > c ? c : a;          // strict lower triangle entry (row lo, col hi)
-        e = eps[(((size_t)b * ch + f) * N + lo) * N + hi];
+        e = rng.on ? rng_edge(rng, rng_draw(rng, coef ? step : nullptr), ((size_t)b * N + lo) * N + hi, f)
+                   : eps[(((size_t)b * ch + f) * N + lo) * N + hi];
     }
     e_mean[g] = mean;
     e_next[g] = __fadd_rn(mean, __fmul_rn(sigma, e));
@@ -167,31 +231,34 @@ __global__ void k_step_begin(int B, const float* __restrict__ coef, const int* _
 __global__ void k_step_end(int* step) { *step += 1; }
 
 int sampler_step_launch(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, float c_x, float c_pred, float sigma,
-                        const float* coef, const int32_t* step, const float* x, const float* edge_x, const float* pred,
+                        const float* coef, const int32_t* step, Rng rng, const float* x, const float* edge_x, const float* pred,
                         const float* edge_pred, const float* eps_pos, const float* eps_feat, const float* eps_edge, float* x_next,
                         float* edge_next, float* x_mean, float* edge_mean, void* stream) {
     if (B <= 0 || N <= 0 || node_feats < 4 || edge_ch < 1) return jodo_set_error(JODO_ERR_ARG, "sampler_step: bad shape");
-    if (!n_nodes_dev || !x || !edge_x || !pred || !edge_pred || !eps_pos || !eps_feat || !eps_edge || !x_next || !edge_next ||
-        !x_mean || !edge_mean)
+    if (!n_nodes_dev || !x || !edge_x || !pred || !edge_pred || !x_next || !edge_next || !x_mean || !edge_mean)
         return jodo_set_error(JODO_ERR_ARG, "sampler_step: null argument");
+    if (!rng.on && (!eps_pos || !eps_feat || !eps_edge)) return jodo_set_error(JODO_ERR_ARG, "sampler_step: null noise draw");
+    if (rng.on && (edge_ch > 4 || node_feats - 3 > 256))
+        return jodo_set_error(JODO_ERR_UNSUPPORTED, "sampler_step_rng: at most 4 edge channels and 256 node feature channels");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_step_nodes, dim3(B), dim3(256), 0, st, N, node_feats, n_nodes_dev, c_x, c_pred, sigma, coef, step, x, pred,
-                       eps_pos, eps_feat, x_next, x_mean);
+                       eps_pos, eps_feat, rng, x_next, x_mean);
     int rc = jodo_check_launch("k_step_nodes");
     if (rc != JODO_OK) return rc;
     const size_t tot = (size_t)B * N * N * edge_ch;
     hipLaunchKernelGGL(k_step_edges, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, N, edge_ch, n_nodes_dev, c_x, c_pred,
-                       sigma, coef, step, edge_x, edge_pred, eps_edge, edge_next, edge_mean);
+                       sigma, coef, step, edge_x, edge_pred, eps_edge, rng, edge_next, edge_mean);
     return jodo_check_launch("k_step_edges");
 }
+const Rng kNoRng{0ull, 0u, 0u, 0};
 }  // namespace
 
 extern "C" int jodo_sampler_step(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, float c_x, float c_pred,
                                  float sigma, const float* x, const float* edge_x, const float* pred, const float* edge_pred,
                                  const float* eps_pos, const float* eps_feat, const float* eps_edge, float* x_next,
                                  float* edge_next, float* x_mean, float* edge_mean, void* stream) {
-    return sampler_step_launch(B, N, node_feats, edge_ch, n_nodes_dev, c_x, c_pred, sigma, nullptr, nullptr, x, edge_x, pred, edge_pred,
-                               eps_pos, eps_feat, eps_edge, x_next, edge_next, x_mean, edge_mean, stream);
+    return sampler_step_launch(B, N, node_feats, edge_ch, n_nodes_dev, c_x, c_pred, sigma, nullptr, nullptr, kNoRng, x, edge_x, pred,
+                               edge_pred, eps_pos, eps_feat, eps_edge, x_next, edge_next, x_mean, edge_mean, stream);
 }
 
 extern "C" int jodo_sampler_step_tab(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, const float* coef_tab_dev,
@@ -199,8 +266,18 @@ extern "C" int jodo_sampler_step_tab(int B, int N, int node_feats, int edge_ch, 
                                      const float* edge_pred, const float* eps_pos, const float* eps_feat, const float* eps_edge,
                                      float* x_next, float* edge_next, float* x_mean, float* edge_mean, void* stream) {
     if (!coef_tab_dev || !step_dev) return jodo_set_error(JODO_ERR_ARG, "sampler_step_tab: null table");
-    return sampler_step_launch(B, N, node_feats, edge_ch, n_nodes_dev, 0.f, 0.f, 0.f, coef_tab_dev, step_dev, x, edge_x, pred, edge_pred,
-                               eps_pos, eps_feat, eps_edge, x_next, edge_next, x_mean, edge_mean, stream);
+    return sampler_step_launch(B, N, node_feats, edge_ch, n_nodes_dev, 0.f, 0.f, 0.f, coef_tab_dev, step_dev, kNoRng, x, edge_x, pred,
+                               edge_pred, eps_pos, eps_feat, eps_edge, x_next, edge_next, x_mean, edge_mean, stream);
+}
+
+extern "C" int jodo_sampler_step_rng(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, float c_x, float c_pred,
+                                     float sigma, const float* coef_tab_dev, const int32_t* step_dev, uint64_t seed, uint32_t draw,
+                                     const float* x, const float* edge_x, const float* pred, const float* edge_pred, float* x_next,
+                                     float* edge_next, float* x_mean, float* edge_mean, void* stream) {
+    if ((coef_tab_dev == nullptr) != (step_dev == nullptr))
+        return jodo_set_error(JODO_ERR_ARG, "sampler_step_rng: pass both the device table and the step counter, or neither");
+    return sampler_step_launch(B, N, node_feats, edge_ch, n_nodes_dev, c_x, c_pred, sigma, coef_tab_dev, step_dev, Rng{seed, draw, 1u, 1},
+                               x, edge_x, pred, edge_pred, nullptr, nullptr, nullptr, x_next, edge_next, x_mean, edge_mean, stream);
 }
 
 extern "C" int jodo_step_begin(int B, const float* coef_tab_dev, const int32_t* step_dev, float* noise_level_out, void* stream) {
@@ -246,15 +323,18 @@ __global__ __launch_bounds__(256) void k_dpm_nodes(int N, int F, const int* __re
                                                    const float* __restrict__ x_base, const float* __restrict__ P,
                                                    const float* __restrict__ DA, const float* __restrict__ DB,
                                                    const float* __restrict__ PP, const float* __restrict__ eps_pos,
-                                                   float* __restrict__ out) {
+                                                   Rng rng, float* __restrict__ out) {
     const int b = blockIdx.x, n = n_nodes[b];
     k = dpm_coef(k, tab, step, stride, col);
+    const unsigned draw = rng.on ? rng_draw(rng, tab ? step : nullptr) : 0u;
     __shared__ float red[3][256];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     if (k.sigma != 0.f)
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const float* e = eps_pos + ((size_t)b * N + i) * 3;
-            s0 += e[0]; s1 += e[1]; s2 += e[2];
+            float ev[3];
+            if (rng.on) rng_pos3(rng, draw, (size_t)b * N + i, ev);
+            else { const float* e = eps_pos + ((size_t)b * N + i) * 3; ev[0] = e[0]; ev[1] = e[1]; ev[2] = e[2]; }
+            s0 += ev[0]; s1 += ev[1]; s2 += ev[2];
         }
     red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
     __syncthreads();
@@ -275,7 +355,11 @@ __global__ __launch_bounds__(256) void k_dpm_nodes(int N, int F, const int* __re
         if (f < 3) {
             v = __fadd_rn(__fmul_rn(k.cx, x_pos[g]), __fmul_rn(k.cp, PP[g]));
             if (k.sigma != 0.f) {                               // last update of a round: no noise (last_step)
-                const float e = i < n ? eps_pos[((size_t)b * N + i) * 3 + f] - m[f] : 0.f;
+                float e = 0.f;
+                if (i < n) {
+                    if (rng.on) { float ev[3]; rng_pos3(rng, draw, (size_t)b * N + i, ev); e = ev[f] - m[f]; }
+                    else e = eps_pos[((size_t)b * N + i) * 3 + f] - m[f];
+                }
                 v = __fadd_rn(v, __fmul_rn(k.sigma, e));
             }
         } else {
@@ -301,27 +385,49 @@ __global__ void k_step_begin_at(int B, const float* __restrict__ tab, const int*
 }
 }  // namespace
 
-extern "C" int jodo_dpm_update(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, const float* coef8_host,
-                               const float* coef_tab_dev, const int32_t* step_dev, int tab_stride, int tab_col, const float* x_pos,
-                               const float* x_base, const float* edge_base, const float* P, const float* eP, const float* DA,
-                               const float* eDA, const float* DB, const float* eDB, const float* PP, const float* eps_pos,
-                               float* x_out, float* edge_out, void* stream) {
+namespace {
+int dpm_update_launch(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, const float* coef8_host,
+                      const float* coef_tab_dev, const int32_t* step_dev, int tab_stride, int tab_col, Rng rng, const float* x_pos,
+                      const float* x_base, const float* edge_base, const float* P, const float* eP, const float* DA, const float* eDA,
+                      const float* DB, const float* eDB, const float* PP, const float* eps_pos, float* x_out, float* edge_out,
+                      void* stream) {
     if (B <= 0 || N <= 0 || node_feats < 4 || edge_ch < 1) return jodo_set_error(JODO_ERR_ARG, "dpm_update: bad shape");
-    if (!n_nodes_dev || !x_pos || !x_base || !edge_base || !P || !eP || !DA || !eDA || !DB || !eDB || !PP || !eps_pos || !x_out || !edge_out)
+    if (!n_nodes_dev || !x_pos || !x_base || !edge_base || !P || !eP || !DA || !eDA || !DB || !eDB || !PP || !x_out || !edge_out)
         return jodo_set_error(JODO_ERR_ARG, "dpm_update: null argument");
+    if (!rng.on && !eps_pos) return jodo_set_error(JODO_ERR_ARG, "dpm_update: null noise draw");
     if ((coef8_host == nullptr) == (coef_tab_dev == nullptr) || (coef_tab_dev && !step_dev))
         return jodo_set_error(JODO_ERR_ARG, "dpm_update: pass either host coefficients or a device table + step counter");
     DpmCoef k{0, 0, 0, 0, 0, 0, 1, 0};
     if (coef8_host) k = DpmCoef{coef8_host[0], coef8_host[1], coef8_host[2], coef8_host[3], coef8_host[4], coef8_host[5], coef8_host[6], coef8_host[7]};
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_dpm_nodes, dim3(B), dim3(256), 0, st, N, node_feats, n_nodes_dev, k, coef_tab_dev, step_dev, tab_stride, tab_col,
-                       x_pos, x_base, P, DA, DB, PP, eps_pos, x_out);
+                       x_pos, x_base, P, DA, DB, PP, eps_pos, rng, x_out);
     int rc = jodo_check_launch("k_dpm_nodes");
     if (rc != JODO_OK) return rc;
     const size_t tot = (size_t)B * N * N * edge_ch;
     hipLaunchKernelGGL(k_dpm_edges, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tot, k, coef_tab_dev, step_dev, tab_stride,
                        tab_col, edge_base, eP, eDA, eDB, edge_out);
     return jodo_check_launch("k_dpm_edges");
+}
+}  // namespace
+
+extern "C" int jodo_dpm_update(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, const float* coef8_host,
+                               const float* coef_tab_dev, const int32_t* step_dev, int tab_stride, int tab_col, const float* x_pos,
+                               const float* x_base, const float* edge_base, const float* P, const float* eP, const float* DA,
+                               const float* eDA, const float* DB, const float* eDB, const float* PP, const float* eps_pos,
+                               float* x_out, float* edge_out, void* stream) {
+    return dpm_update_launch(B, N, node_feats, edge_ch, n_nodes_dev, coef8_host, coef_tab_dev, step_dev, tab_stride, tab_col, kNoRng,
+                             x_pos, x_base, edge_base, P, eP, DA, eDA, DB, eDB, PP, eps_pos, x_out, edge_out, stream);
+}
+
+extern "C" int jodo_dpm_update_rng(int B, int N, int node_feats, int edge_ch, const int32_t* n_nodes_dev, const float* coef8_host,
+                                   const float* coef_tab_dev, const int32_t* step_dev, int tab_stride, int tab_col, uint64_t seed,
+                                   uint32_t draw, uint32_t draw_mul, const float* x_pos, const float* x_base, const float* edge_base,
+                                   const float* P, const float* eP, const float* DA, const float* eDA, const float* DB,
+                                   const float* eDB, const float* PP, float* x_out, float* edge_out, void* stream) {
+    return dpm_update_launch(B, N, node_feats, edge_ch, n_nodes_dev, coef8_host, coef_tab_dev, step_dev, tab_stride, tab_col,
+                             Rng{seed, draw, draw_mul, 1}, x_pos, x_base, edge_base, P, eP, DA, eDA, DB, eDB, PP, nullptr, x_out,
+                             edge_out, stream);
 }
 
 extern "C" int jodo_step_begin_at(int B, const float* coef_tab_dev, const int32_t* step_dev, int tab_stride, int tab_col,

@@ -36,26 +36,60 @@ class StepBuffers:
         self.cur = 0
 
 
-def sampler_step(bufs, n_nodes_dev, c_x, c_pred, sigma, x, edge_x, pred, edge_pred, eps_pos, eps_feat, eps_edge):
+class DeviceNoise:
+    """In-kernel normal draws (jodo_sampler_step_rng / jodo_dpm_update_rng, include/jodo_hip.h): Philox4x32-10 keyed by a
+    64-bit seed; the draw index counts the updates of a round.  `for_rank` derives non-overlapping per-rank keys:
+    the rank sits in the high 32 bits, so rank r of seed s never meets rank r' of seed s'."""
+
+    def __init__(self, seed, draw=0):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.draw = int(draw)
+
+    @classmethod
+    def for_rank(cls, seed, rank=0, round_index=0):
+        return cls(((int(rank) & 0xFFFF) << 48) | ((int(round_index) & 0xFFFF) << 32) | (int(seed) & 0xFFFFFFFF))
+
+    def next_draw(self):
+        d = self.draw
+        self.draw += 1
+        return d
+
+
+def split_replayed_noise(node_noise, edge_noise):
+    """Recorded reference noise (node [B,N,3+nd] masked + CoM-free, edge [B,N,N,ch] symmetric + masked) as the RAW draws the
+    kernels take: masking, centre-of-mass removal and lower-triangle mirroring are idempotent on them."""
+    return (node_noise[:, :, :3].contiguous(), node_noise[:, :, 3:].contiguous(),
+            edge_noise.permute(0, 3, 1, 2).contiguous())
+
+
+def sampler_step(bufs, n_nodes_dev, c_x, c_pred, sigma, x, edge_x, pred, edge_pred, eps_pos=None, eps_feat=None, eps_edge=None,
+                 rng=None):
     """x_mean = c_x x + c_pred pred; x_next = x_mean + sigma * eps (both tensors), eps from RAW normal draws
-    in the reference's shapes (see include/jodo_hip.h).  Returns (x_next, edge_next, x_mean, edge_mean);
-    the returned tensors live in `bufs` and stay valid until the call after next."""
+    in the reference's shapes (see include/jodo_hip.h) or, with rng = DeviceNoise, drawn inside the kernel.
+    Returns (x_next, edge_next, x_mean, edge_mean); the returned tensors live in `bufs` and stay valid until the
+    call after next."""
     B, N, F = x.shape
     ch = edge_x.shape[-1]
     x, edge_x = _f32c(x, 'x'), _f32c(edge_x, 'edge_x')
     pred, edge_pred = _f32c(pred, 'pred'), _f32c(edge_pred, 'edge_pred')
-    eps_pos, eps_feat, eps_edge = _f32c(eps_pos, 'eps_pos'), _f32c(eps_feat, 'eps_feat'), _f32c(eps_edge, 'eps_edge')
-    if eps_pos.shape != (B, N, 3) or eps_feat.shape != (B, N, F - 3) or eps_edge.shape != (B, ch, N, N):
-        raise ValueError("noise draws must have the reference's shapes [B,N,3], [B,N,nd], [B,ch,N,N]")
     nxt = bufs.cur ^ 1
     xn, en = bufs.x[nxt], bufs.e[nxt]
     if xn.data_ptr() == x.data_ptr() or en.data_ptr() == edge_x.data_ptr():
         raise RuntimeError("sampler_step: output buffer aliases the input state")
-    capi.check(capi.lib().jodo_sampler_step(
-        B, N, F, ch, capi.ptr(n_nodes_dev), ctypes.c_float(float(c_x)), ctypes.c_float(float(c_pred)),
-        ctypes.c_float(float(sigma)), capi.ptr(x), capi.ptr(edge_x), capi.ptr(pred), capi.ptr(edge_pred),
-        capi.ptr(eps_pos), capi.ptr(eps_feat), capi.ptr(eps_edge), capi.ptr(xn), capi.ptr(en),
-        capi.ptr(bufs.x_mean), capi.ptr(bufs.e_mean), capi.current_stream_ptr()), 'jodo_sampler_step')
+    cf = lambda v: ctypes.c_float(float(v))
+    if rng is not None:
+        capi.check(capi.lib().jodo_sampler_step_rng(
+            B, N, F, ch, capi.ptr(n_nodes_dev), cf(c_x), cf(c_pred), cf(sigma), None, None, ctypes.c_uint64(rng.seed),
+            ctypes.c_uint32(rng.next_draw()), capi.ptr(x), capi.ptr(edge_x), capi.ptr(pred), capi.ptr(edge_pred), capi.ptr(xn),
+            capi.ptr(en), capi.ptr(bufs.x_mean), capi.ptr(bufs.e_mean), capi.current_stream_ptr()), 'jodo_sampler_step_rng')
+    else:
+        eps_pos, eps_feat, eps_edge = _f32c(eps_pos, 'eps_pos'), _f32c(eps_feat, 'eps_feat'), _f32c(eps_edge, 'eps_edge')
+        if eps_pos.shape != (B, N, 3) or eps_feat.shape != (B, N, F - 3) or eps_edge.shape != (B, ch, N, N):
+            raise ValueError("noise draws must have the reference's shapes [B,N,3], [B,N,nd], [B,ch,N,N]")
+        capi.check(capi.lib().jodo_sampler_step(
+            B, N, F, ch, capi.ptr(n_nodes_dev), cf(c_x), cf(c_pred), cf(sigma), capi.ptr(x), capi.ptr(edge_x), capi.ptr(pred),
+            capi.ptr(edge_pred), capi.ptr(eps_pos), capi.ptr(eps_feat), capi.ptr(eps_edge), capi.ptr(xn), capi.ptr(en),
+            capi.ptr(bufs.x_mean), capi.ptr(bufs.e_mean), capi.current_stream_ptr()), 'jodo_sampler_step')
     bufs.cur = nxt
     return xn, en, bufs.x_mean, bufs.e_mean
 
@@ -108,16 +142,19 @@ class _DpmBuffers:
         self.cur = 0
 
 
-def dpm_update(solver, coef, x_pos, x_base, edge_base, P, DA, DB, PP, node_mask):
+def dpm_update(solver, coef, x_pos, x_base, edge_base, P, DA, DB, PP, n_nodes_dev, eps=None, rng=None):
     """jodo_dpm_update (include/jodo_hip.h): coef = [cx, cp, sigma, a, b, c, c2, 0]; P / DA / DB / PP are
-    (node prediction, edge prediction) pairs.  Draws the position noise (raw N(0,1) [B,N,3], the reference's shape and
-    draw, mix_dpm_solver.py:56) unless sigma == 0 (last update of a round).  Returns (x_out, edge_out)."""
+    (node prediction, edge prediction) pairs; n_nodes_dev = int32 [B] atom counts of THIS round (the solver computes them
+    once per `sampling` call).  Position noise: `eps` (a replayed draw [B,N,3]; masking / CoM removal are idempotent),
+    in-kernel draws with rng = DeviceNoise, otherwise a raw N(0,1) [B,N,3] draw (the reference's shape and draw,
+    mix_dpm_solver.py:56); nothing is drawn when sigma == 0 (last update of a round).  Returns (x_out, edge_out)."""
     B, N, F = x_base.shape
     ch = edge_base.shape[-1]
+    if n_nodes_dev.shape[0] != B or n_nodes_dev.device != x_base.device:
+        raise ValueError("dpm_update: n_nodes_dev does not belong to this batch")
     bufs = getattr(solver, '_dpm_bufs', None)
-    if bufs is None or bufs.x[0].shape != x_base.shape or bufs.x[0].device != x_base.device:
+    if bufs is None or bufs.x[0].shape != x_base.shape or bufs.e[0].shape != edge_base.shape or bufs.x[0].device != x_base.device:
         bufs = solver._dpm_bufs = _DpmBuffers(x_base, edge_base)
-        solver._dpm_n_nodes = n_nodes_from_mask(node_mask)
     live = {t.data_ptr() for t in (x_pos, x_base, edge_base, P[0], P[1], DA[0], DA[1], DB[0], DB[1], PP[0])}
     for _ in range(len(bufs.x)):
         bufs.cur = (bufs.cur + 1) % len(bufs.x)
@@ -126,15 +163,25 @@ def dpm_update(solver, coef, x_pos, x_base, edge_base, P, DA, DB, PP, node_mask)
     else:
         raise RuntimeError("dpm_update: no free output buffer")
     xo, eo = bufs.x[bufs.cur], bufs.e[bufs.cur]
-    if coef[2] != 0.0:
-        bufs.eps.normal_()
+    if rng is None:
+        if eps is not None:
+            bufs.eps.copy_(eps)
+        elif coef[2] != 0.0:
+            bufs.eps.normal_()
     c8 = (ctypes.c_float * 8)(*coef)
     # contiguous fp32 views are bound to names until the launch is enqueued: a temporary freed earlier could be handed
     # out again by the caching allocator for the next temporary and be overwritten before the kernel reads it
     t = [_f32c(v, n) for v, n in ((x_pos, 'x_pos'), (x_base, 'x_base'), (edge_base, 'edge_base'), (P[0], 'P'), (P[1], 'eP'),
                                   (DA[0], 'DA'), (DA[1], 'eDA'), (DB[0], 'DB'), (DB[1], 'eDB'), (PP[0], 'PP'))]
-    capi.check(capi.lib().jodo_dpm_update(
-        B, N, F, ch, capi.ptr(solver._dpm_n_nodes), c8, None, None, 0, 0, *[capi.ptr(v) for v in t],
-        capi.ptr(bufs.eps), capi.ptr(xo), capi.ptr(eo), capi.current_stream_ptr()), 'jodo_dpm_update')
+    if rng is not None:
+        draw = rng.next_draw() if coef[2] != 0.0 else 0
+        capi.check(capi.lib().jodo_dpm_update_rng(
+            B, N, F, ch, capi.ptr(n_nodes_dev), c8, None, None, 0, 0, ctypes.c_uint64(rng.seed), ctypes.c_uint32(draw),
+            ctypes.c_uint32(0), *[capi.ptr(v) for v in t], capi.ptr(xo), capi.ptr(eo), capi.current_stream_ptr()),
+            'jodo_dpm_update_rng')
+    else:
+        capi.check(capi.lib().jodo_dpm_update(
+            B, N, F, ch, capi.ptr(n_nodes_dev), c8, None, None, 0, 0, *[capi.ptr(v) for v in t],
+            capi.ptr(bufs.eps), capi.ptr(xo), capi.ptr(eo), capi.current_stream_ptr()), 'jodo_dpm_update')
     del t
     return xo, eo

@@ -15,6 +15,8 @@ the random stream differs from an eager run (graph-captured generators advance t
 replay), which is why parity tests compare each replayed step against the framework formula on the step's
 own recorded draws rather than against an eager trajectory.
 """
+import ctypes
+
 import torch
 
 from . import capi, fused
@@ -58,14 +60,22 @@ class GraphedAncestralRound:
         # (sampling.py:553-571): 'clamp' clamps the atom / charge channels of pred in place, and the update uses them
         cxn, cexn = self.sampler.cond_process_fn(pred, epred)
         self.cx.copy_(cxn); self.cex.copy_(cexn)
-        self.eps_pos.normal_()                     # draw order of models/utils.py:67-99: positions, features, edges
-        self.eps_feat.normal_()
-        self.eps_edge.normal_()
-        capi.check(L.jodo_sampler_step_tab(B, N, F, ch, capi.ptr(self.n_nodes), capi.ptr(self.tab), capi.ptr(self.step),
-                                           capi.ptr(self.x), capi.ptr(self.e), capi.ptr(pred), capi.ptr(epred),
-                                           capi.ptr(self.eps_pos), capi.ptr(self.eps_feat), capi.ptr(self.eps_edge),
-                                           capi.ptr(self.x_next), capi.ptr(self.e_next), capi.ptr(self.x_mean),
-                                           capi.ptr(self.e_mean), st), 'jodo_sampler_step_tab')
+        if self.rng is not None:                   # draws generated inside the update kernel: draw index = step index
+            capi.check(L.jodo_sampler_step_rng(B, N, F, ch, capi.ptr(self.n_nodes), ctypes.c_float(0), ctypes.c_float(0),
+                                               ctypes.c_float(0), capi.ptr(self.tab), capi.ptr(self.step),
+                                               ctypes.c_uint64(self.rng.seed), ctypes.c_uint32(self.rng_base),
+                                               capi.ptr(self.x), capi.ptr(self.e), capi.ptr(pred), capi.ptr(epred),
+                                               capi.ptr(self.x_next), capi.ptr(self.e_next), capi.ptr(self.x_mean),
+                                               capi.ptr(self.e_mean), st), 'jodo_sampler_step_rng')
+        else:
+            self.eps_pos.normal_()                 # draw order of models/utils.py:67-99: positions, features, edges
+            self.eps_feat.normal_()
+            self.eps_edge.normal_()
+            capi.check(L.jodo_sampler_step_tab(B, N, F, ch, capi.ptr(self.n_nodes), capi.ptr(self.tab), capi.ptr(self.step),
+                                               capi.ptr(self.x), capi.ptr(self.e), capi.ptr(pred), capi.ptr(epred),
+                                               capi.ptr(self.eps_pos), capi.ptr(self.eps_feat), capi.ptr(self.eps_edge),
+                                               capi.ptr(self.x_next), capi.ptr(self.e_next), capi.ptr(self.x_mean),
+                                               capi.ptr(self.e_mean), st), 'jodo_sampler_step_tab')
         self.x.copy_(self.x_next); self.e.copy_(self.e_next)
         capi.check(L.jodo_step_end(capi.ptr(self.step), st), 'jodo_step_end')
 
@@ -81,6 +91,10 @@ class GraphedAncestralRound:
         smp, dev = self.sampler, z_T.device
         st = smp.init_state(z_T, edge_z_T)
         st = smp.step(self.model, 0, st, self.node_mask, self.edge_mask, self.context)      # step 0: eager, cond = None
+        self.rng = smp.device_noise
+        if self.rng is not None:
+            self.rng_base = self.rng.draw - 1            # step 0 took draw `rng_base`; step i takes rng_base + i
+            self.rng.draw += self.steps - 1
         self.done = 1
         self.last = (st['x_mean'], st['edge_x_mean'])
         if self.steps == 1:
@@ -166,21 +180,25 @@ class GraphedDPMRound:
         B, N, F = self.x.shape
         ch = self.e.shape[-1]
         st = capi.current_stream_ptr()
-        up = lambda col, x_pos, P, DA, DB, PP, xo, eo: capi.check(L.jodo_dpm_update(
-            B, N, F, ch, capi.ptr(self.n_nodes), None, capi.ptr(self.tab), capi.ptr(self.step), 16, col, capi.ptr(x_pos),
-            capi.ptr(self.x), capi.ptr(self.e), capi.ptr(P[0]), capi.ptr(P[1]), capi.ptr(DA[0]), capi.ptr(DA[1]), capi.ptr(DB[0]),
-            capi.ptr(DB[1]), capi.ptr(PP[0]), capi.ptr(self.eps), capi.ptr(xo), capi.ptr(eo), st), 'jodo_dpm_update')
+        def up(col, x_pos, P, DA, DB, PP, xo, eo):
+            tens = [capi.ptr(t) for t in (x_pos, self.x, self.e, P[0], P[1], DA[0], DA[1], DB[0], DB[1], PP[0])]
+            if self.rng is not None:                       # position noise drawn in the kernel: draws 2k and 2k + 1 of outer step k
+                capi.check(L.jodo_dpm_update_rng(B, N, F, ch, capi.ptr(self.n_nodes), None, capi.ptr(self.tab), capi.ptr(self.step),
+                                                 16, col, ctypes.c_uint64(self.rng.seed), ctypes.c_uint32(self.rng_base + col // 8),
+                                                 ctypes.c_uint32(2), *tens, capi.ptr(xo), capi.ptr(eo), st), 'jodo_dpm_update_rng')
+            else:
+                self.eps.normal_()
+                capi.check(L.jodo_dpm_update(B, N, F, ch, capi.ptr(self.n_nodes), None, capi.ptr(self.tab), capi.ptr(self.step), 16,
+                                             col, *tens, capi.ptr(self.eps), capi.ptr(xo), capi.ptr(eo), st), 'jodo_dpm_update')
         capi.check(L.jodo_step_begin_at(B, capi.ptr(self.tab), capi.ptr(self.step), 16, 0, capi.ptr(self.nl), st), 'jodo_step_begin_at')
         p0 = self.model(self.nl, self.x, self.node_mask, self.edge_mask, edge_x=self.e, noise_level=self.nl, cond_x=self.cx,
                         cond_edge_x=self.cex, context=self.context)
         self.cx.copy_(p0[0]); self.cex.copy_(p0[1])            # self-conditioning input of the next evaluation (:296-302)
         c0 = (self.cx, self.cex)
-        self.eps.normal_()
         up(0, self.x, c0, c0, c0, c0, self.x1, self.e1)
         capi.check(L.jodo_step_begin_at(B, capi.ptr(self.tab), capi.ptr(self.step), 16, 8, capi.ptr(self.nl), st), 'jodo_step_begin_at')
         p1 = self.model(self.nl, self.x1, self.node_mask, self.edge_mask, edge_x=self.e1, noise_level=self.nl, cond_x=self.cx,
                         cond_edge_x=self.cex, context=self.context)
-        self.eps.normal_()
         up(8, self.x1, c0, p1, c0, p1, self.x2, self.e2)
         self.cx.copy_(p1[0]); self.cex.copy_(p1[1])
         self.x.copy_(self.x2); self.e.copy_(self.e2)
@@ -192,6 +210,8 @@ class GraphedDPMRound:
         ns = sv.noise_schedule
         sv.cond_x = sv.cond_edge_x = None
         sv._noise_calls = 0
+        sv._n_nodes_dev = fused.n_nodes_from_mask(self.node_mask)      # this round's atom counts (the solver serves many rounds)
+        self.rng = sv.device_noise
         model_fn = sv.get_model_fn(self.model)
         outer = sv.get_time_steps('time_uniform', ns.T, 1. / ns.total_N, self.K, 'cpu')
         inner = sv.get_time_steps('time_uniform', outer[0].item(), outer[1].item(), 2, 'cpu')
@@ -208,7 +228,10 @@ class GraphedDPMRound:
             self.nl = torch.empty(self.x.shape[0], device=dev)
             self.tab = self.tab_host.to(dev)
             self.step = torch.ones(1, dtype=torch.int32, device=dev)
-            self.n_nodes = fused.n_nodes_from_mask(self.node_mask)
+            self.n_nodes = sv._n_nodes_dev
+            if self.rng is not None:
+                self.rng_base = self.rng.draw - 2                # outer step 0 took two draws; outer step k takes 2k, 2k + 1
+                self.rng.draw += 2 * (self.K - 1) - 1
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):

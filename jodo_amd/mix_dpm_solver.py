@@ -21,8 +21,10 @@ def merge_x(pos, feat):
 
 
 class DPM_Solver_hybrid:
-    def __init__(self, noise_schedule, config, noise_fn=None, fused=True):
+    def __init__(self, noise_schedule, config, noise_fn=None, fused=True, device_noise=None):
         self.noise_schedule = noise_schedule
+        self.device_noise = device_noise  # fused.DeviceNoise: position noise drawn inside jodo_dpm_update_rng (Philox)
+        self._n_nodes_dev = None          # int32 [B] atom counts of the round being sampled (set by `sampling`)
         self.cond_x = None
         self.cond_edge_x = None
         self.order = config.sampling.dpm_solver_order
@@ -76,14 +78,20 @@ class DPM_Solver_hybrid:
         P / DA / DB / PP are (node prediction, edge prediction) pairs.  On GPU tensors (and when no noise is being
         replayed) this is ONE fused kernel per tensor (jodo_dpm_update, csrc/sampler_kernels.hip) instead of ~25
         framework launches; the op order of the products is the same in both paths."""
-        if self.fused and x_base.is_cuda and self.noise_fn is None:
+        if self.fused and x_base.is_cuda:
             from . import fused
             c_x, c_pred, sigma = self.position_coefficients(t_from, t_to)
             coef = [float(c_x), float(c_pred), 0.0 if last_step else float(sigma), float(a), float(b),
                     0.0 if c is None else float(c), 1.0 if c2 is None else float(c2), 0.0]
+            eps = None
             if not last_step:
+                if self.noise_fn is not None:         # replayed draw (masked, CoM-free: the kernel's own steps are idempotent)
+                    eps = self.noise_fn(self._noise_calls, 'pos', split_x(x_pos)[0])
                 self._noise_calls += 1
-            return fused.dpm_update(self, coef, x_pos, x_base, edge_base, P, DA, DB, PP, node_mask)
+            if self._n_nodes_dev is None or self._n_nodes_dev.shape[0] != x_base.shape[0]:
+                self._n_nodes_dev = fused.n_nodes_from_mask(node_mask)      # direct callers of the update methods
+            return fused.dpm_update(self, coef, x_pos, x_base, edge_base, P, DA, DB, PP, self._n_nodes_dev, eps=eps,
+                                    rng=self.device_noise if self.noise_fn is None else None)
         pos_base, atom_base = split_x(x_base)
         _, atom_p = split_x(P[0])
         atom = a * atom_base - b * atom_p
@@ -225,6 +233,10 @@ class DPM_Solver_hybrid:
         steps, order = self.steps, self.order
         self.cond_x = self.cond_edge_x = None
         self._noise_calls = 0
+        self._n_nodes_dev = None
+        if self.fused and x.is_cuda:
+            from . import fused
+            self._n_nodes_dev = fused.n_nodes_from_mask(node_mask)      # per ROUND: a solver object serves many rounds
         model_fn = self.get_model_fn(model)
         ns = self.noise_schedule
         t_0 = 1. / ns.total_N if t_end is None else t_end
@@ -272,6 +284,6 @@ class DPM_Solver_hybrid:
             raise ValueError("Get wrong method {}".format(self.method))
 
         assert_mean_zero_with_mask(x[:, :, :3], node_mask)
-        if self.fused and x.is_cuda and self.noise_fn is None:
+        if self.fused and x.is_cuda:
             x, edge_x = x.clone(), edge_x.clone()        # the fused updates write into buffers the solver reuses
         return x, edge_x

@@ -12,7 +12,7 @@ in /root/reference/models/mol_gnn.py (:410-594, :597-794):
     noise_level=...)` -> `(xh_pred [B,N,3+nd], edge_pred [B,N,N,ch])`, inputs untouched.
 
 The arithmetic is NOT done by these torch modules: `forward` packs the weights once (MFMA operand
-order, jodo_amd/packing_model.py), builds a plan per batch of atom counts, and calls
+order, csrc/dgt_pack.cpp), builds a plan per batch of atom counts, and calls
 `jodo_dgt_forward` in libjodo_hip.so on the current HIP stream.  There is no CPU or eager fallback:
 on a non-GPU tensor, with gradients enabled, or with an unsupported config, forward raises.
 """
@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from .. import capi
-from ..packing_model import ModelDims
+from .dims import ModelDims
 from . import utils
 
 
@@ -99,6 +99,11 @@ def _mlp3(i, h, m, o):
     return nn.Sequential(nn.Linear(i, h), nn.SiLU(), nn.Linear(h, m), nn.SiLU(), nn.Linear(m, o))
 
 
+def _drop_packed_after_load(module, incompatible_keys):
+    """load_state_dict post hook (module-level so that the module stays picklable)."""
+    module.invalidate_packed_weights()
+
+
 _UNSUPPORTED = (('dist_gbf', True), ('cond_time', True), ('pred_data', True), ('gbf_name', 'CondGaussianLayer'),
                 ('CoM', True), ('softmax_inf', True))
 
@@ -157,7 +162,7 @@ class _DGTBase(nn.Module):
         self._packed = None           # (version_key, blob_dev, woff_host ctypes array)
         self._plans = {}              # plan cache keyed by the mask tensor identity
         self._cfg_struct = None
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed_weights())
+        self.register_load_state_dict_post_hook(_drop_packed_after_load)
         self.last_flags = None        # device int32[8] of the last call (NaN guard etc.)
         self.warn_nan = True
 
@@ -184,7 +189,7 @@ class _DGTBase(nn.Module):
         key = (str(device),) + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
         if self._packed is None or self._packed[0] != key:
             # C-side packer (csrc/dgt_pack.cpp, jodo_dgt_pack_weights): the state_dict goes through the C ABI as named
-            # fp32 tensors; jodo_amd/packing_model.py is an independent Python packer kept for tests (blob equality)
+            # fp32 tensors; tests/py_packing_model.py is an independent Python packer kept for tests (blob equality)
             blob_dev, woff_c, n_woff = capi.pack_weights(self._cfg(), self.state_dict(), device)
             self._packed = (key, blob_dev, woff_c, n_woff)
             self._packed_fingerprint = self._fingerprint()
@@ -277,8 +282,10 @@ class _DGTBase(nn.Module):
         f32 = lambda x: None if x is None else x.detach().to(torch.float32).contiguous()
         xh_, ex_, cx_, cex_, nl_ = f32(xh), f32(edge_x), f32(cond_x), f32(cond_edge_x), f32(noise_level)
         ctx_ = f32(context) if self.conditional else None
-        _, blob, woff_c, n_woff = self._weights(dev)
+        # plan first: building a plan for a new batch re-checks the weight fingerprint (`.data` updates such as the
+        # reference's EMA copy_to / restore) and drops a stale blob BEFORE this call fetches it
         plan = self._plan(node_mask, edge_mask, dev)
+        _, blob, woff_c, n_woff = self._weights(dev)
         out_x = torch.empty_like(xh_)
         out_e = torch.empty_like(ex_)
         L = capi.lib()
@@ -293,10 +300,13 @@ class _DGTBase(nn.Module):
     def take_nan_count(self):
         """Number of evaluations since the last call in which the NaN guard fired (sticky device counter, flags[5] of
         every cached plan); one host sync, so call it once per sampling round, not per step."""
-        total = 0
-        for plan in self._plans.values():
-            total += int(plan['flags'][5].item())
-            plan['flags'][5] = 0
+        plans = list(self._plans.values())
+        if not plans:
+            return 0
+        total = int(torch.stack([p['flags'][5] for p in plans]).sum().item())       # one host sync for all cached plans
+        if total:
+            for p in plans:
+                p['flags'][5] = 0
         return total
 
     def invalidate_packed_weights(self):

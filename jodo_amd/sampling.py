@@ -132,7 +132,7 @@ class _ParityNoise:
 
 def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, inverse_scaler, eps=1e-3,
                     prop_dist=None, shard=None, return_raw=False, fused_decode=True, hip_graph=False,
-                    shard_mode='perf', shard_assign='contiguous', seed=None):
+                    shard_mode='perf', shard_assign='contiguous', seed=None, device_noise=None):
     """sampling.py:148-232.  Without `shard` this is the reference's procedure, RNG use included.
 
     shard=(rank, world) — one process per GPU (replaces nn.DataParallel).  Seeding contract: every rank passes the SAME
@@ -141,11 +141,17 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
       shard_mode='perf'   the rounds * batch_size molecules are dealt to the ranks FIRST (contiguous slices, or
                           shard_assign='lpt': greedy longest-processing-time by n^2 for balance) and each rank cuts its
                           share into rounds of up to batch_size (BASELINE config 5: 10 000 molecules on 8 GPUs = one round
-                          of 1250 per GPU, not four rounds of 313); all noise comes from `seed + 1 + rank`, so no two
-                          ranks share a noise stream;
+                          of 1250 per GPU, not four rounds of 313); the initial noise comes from the generator seeded
+                          `(seed << 20) + 1 + rank` (streams of different (seed, rank) pairs never coincide, and none
+                          coincides with the atom-count stream `seed`), the per-step noise is drawn inside the fused
+                          update kernels (device_noise, below) keyed by (seed, rank, round);
       shard_mode='parity' every round of the unsharded run is split across the ranks and the unsharded run's noise is
                           replayed (_ParityNoise): the gathered result equals the world-size-1 run.  Slow (full-batch CPU
                           draws per step) — for tests.
+    device_noise — True: the per-step normal draws are generated inside the fused update kernels (Philox keyed by
+    (seed, rank, round), jodo_sampler_step_rng / jodo_dpm_update_rng) instead of three torch.randn launches per step; same
+    distribution, a different stream than the reference's.  Default: on for shard_mode='perf', off otherwise (an unsharded
+    seeded run consumes torch's generator exactly like the reference).  Ignored on CPU tensors and when noise is replayed.
     Returns this rank's molecules; `sampling_fn.last_indices` holds their indices in the global order (rounds *
     batch_size molecules, as the unsharded run generates them) for the caller's gather (jodo_amd/dist.py)."""
     device = config.device
@@ -163,7 +169,10 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
     if shard is not None and not (0 <= shard[0] < shard[1]):
         raise ValueError("shard=(rank, world) with 0 <= rank < world")
 
+    if device_noise is None:
+        device_noise = shard is not None and shard_mode == 'perf'
     rounds = int(np.ceil(n_samples / batch_size))
+    round_counter = [0]
     if config.sampling.method == 'ancestral':
         # schedule scalars are computed on the host: the VP coefficients near t -> 0 are ill-conditioned
         # in fp32 (sigma_s = sqrt(1 - exp(2 log alpha_s)) with log alpha_s ~ 1e-7), so their low bits depend
@@ -188,6 +197,12 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
             z, edge_z = noise.node(), noise.edge()
         assert_mean_zero_with_mask(z[:, :, :3], node_mask)
         sampler.noise_fn = noise
+        sampler.device_noise = None
+        if device_noise and noise is None and z.is_cuda:
+            from . import fused
+            sampler.device_noise = fused.DeviceNoise.for_rank(int(config.seed if seed is None else seed),
+                                                              shard[0] if shard is not None else 0, round_counter[0])
+        round_counter[0] += 1
         try:
             if hip_graph and noise is None and z.is_cuda and isinstance(sampler, AncestralSampler):
                 # one captured HIP graph per round, replayed for every step (jodo_amd/graphed.py)
@@ -201,6 +216,7 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
                 x_node, x_edge = sampler.sampling(model, z, node_mask, edge_mask, edge_z, context)
         finally:
             sampler.noise_fn = None
+            sampler.device_noise = None
         _warn_nan(model)
         if x_node.is_cuda and fused_decode and getattr(inverse_scaler, 'from_config', False):
             # device-side decode: compact u8/i8 results, one device->host copy per tensor
@@ -242,7 +258,8 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
                 else:
                     lo, hi = shard_range(total, rank, world)
                     mine = list(range(lo, hi))
-                torch.manual_seed(base + 1 + rank)             # this rank's own noise stream (CPU and device generators)
+                torch.manual_seed((base << 20) + 1 + rank)     # this rank's own stream (CPU and device generators); streams
+                                                               # of different (seed, rank) never coincide
                 for r0 in range(0, len(mine), batch_size):
                     idx = torch.as_tensor(mine[r0:r0 + batch_size], dtype=torch.long)
                     context = context_all[idx].to(device) if context_all is not None else None
@@ -308,8 +325,12 @@ class AncestralSampler:
     """Ancestral sampling for joint 2-D & 3-D generation; returns the noise-free mean of the last step."""
 
     def __init__(self, noise_scheduler, time_steps, model_pred_data, pred_edge=False, self_cond=False,
-                 cond_process_fn=None, noise_fn=None, fused=True):
+                 cond_process_fn=None, noise_fn=None, fused=True, device_noise=None):
         self.noise_scheduler = noise_scheduler
+        # device_noise: a fused.DeviceNoise — the per-step normal draws are generated inside the fused update kernel
+        # (counter-based Philox; same distribution, not the reference's stream); None = torch.randn draws in the
+        # reference's shapes and order, so that seeded runs consume the generator exactly like the reference
+        self.device_noise = device_noise
         # fused: on GPU tensors the update + noise construction run as one HIP kernel per tensor
         # (csrc/sampler_kernels.hip) instead of ~25 framework launches; same RNG draws in the same order
         self.fused = fused
@@ -353,18 +374,29 @@ class AncestralSampler:
         else:
             pred_t, edge_pred_t = model(vec_t, x, node_mask, edge_mask, edge_x=edge_x, noise_level=noise_level,
                                         context=context)
-        if self.fused and x.is_cuda and self.noise_fn is None and self.model_pred_data:
+        if self.fused and x.is_cuda and self.model_pred_data:
             from . import fused
             if st.get('_bufs') is None:
                 st['_bufs'] = fused.StepBuffers(x, edge_x)
                 st['_n_nodes'] = fused.n_nodes_from_mask(node_mask)
             N, nd, ch = x.shape[1], x.shape[2] - 3, edge_x.shape[-1]
-            eps_pos = torch.randn((bs, N, 3), device=x.device)          # draw order of models/utils.py:67-99
-            eps_feat = torch.randn((bs, N, nd), device=x.device)
-            eps_edge = torch.randn((bs, ch, N, N), device=x.device)
+            if self.noise_fn is not None:
+                # replayed draws (parity runs, tests against the reference's recorded trajectories): the recorded noise is
+                # already masked / CoM-free / symmetric and the kernel's own masking, CoM removal and mirroring are
+                # idempotent on it; node noise first, then edge noise (the reference's draw order)
+                node_eps = self.noise_fn(i, 'node', x)
+                eps = fused.split_replayed_noise(node_eps, self.noise_fn(i, 'edge', edge_x))
+                rng = None
+            elif self.device_noise is not None:
+                eps, rng = (None, None, None), self.device_noise       # drawn inside the kernel (Philox)
+            else:
+                eps = (torch.randn((bs, N, 3), device=x.device),           # draw order of models/utils.py:67-99
+                       torch.randn((bs, N, nd), device=x.device),
+                       torch.randn((bs, ch, N, N), device=x.device))
+                rng = None
             st['x'], st['edge_x'], st['x_mean'], st['edge_x_mean'] = fused.sampler_step(
                 st['_bufs'], st['_n_nodes'], float(c_x), float(c_pred), float(sigma), x, edge_x, pred_t, edge_pred_t,
-                eps_pos, eps_feat, eps_edge)
+                *eps, rng=rng)
             return st
         # the coefficients are scalars shared by the batch (the reference broadcasts them through
         # .repeat(bs) + expand_dims, sampling.py:569-589 — same values, same products)

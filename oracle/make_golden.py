@@ -18,6 +18,8 @@ cond_DGT_concat with `jodo_amd.models.init_utils.deterministic_init_` (weights a
                                                e_block, models/mol_gnn.py:562-568) captured with forward hooks
   traj_qm9_anc50.npz                           50-step ancestral trajectory; besides the replayable noise it records
                                                every step's input state and the reference's prediction (teacher forcing)
+  fwd_geom_l8.npz                              GEOM nf = 256 with n_layers = 8 (BASELINE configs[2] as worded), mlp_ratio 4
+  traj_geom_anc3.npz                           3-step ancestral trajectory of the GEOM model (3 bond channels: aromatic decode)
   traj_cond_dpm_multi8.npz / _single3.npz / _single1.npz
                                                hybrid DPM-solver: 2nd-order multistep (8 NFE), single-step order 3
                                                (6 NFE) and order 1 (3 NFE)
@@ -43,11 +45,13 @@ OUT = os.path.join(ROOT, 'tests', 'golden')
 HEAD_GAIN = 30.0      # scale the heads' last layers so that argmax / threshold decodes are not degenerate
 
 
-def build_reference_model(ref, cfg_name, seed, head_gain=1.0, nf=None):
+def build_reference_model(ref, cfg_name, seed, head_gain=1.0, nf=None, n_layers=None):
     cfg = reference_config(cfg_name)
     cfg.device = torch.device('cpu')
     if nf is not None:
         cfg.model.nf = nf                                         # README.md:168 `--config.model.nf 384`
+    if n_layers is not None:
+        cfg.model.n_layers = n_layers                             # BASELINE configs[2] as worded: "nf=256, 8 layers"
     model = ref.models.utils._MODELS[cfg.model.name](cfg).eval()
     deterministic_init_(model, seed=seed)
     if head_gain != 1.0:
@@ -66,8 +70,8 @@ def masks(n_nodes):
     return nm.unsqueeze(2), em.reshape(-1, 1)
 
 
-def forward_fixture(ref, cfg_name, n_nodes, seed, fname, nf=None):
-    cfg, model = build_reference_model(ref, cfg_name, seed, nf=nf)
+def forward_fixture(ref, cfg_name, n_nodes, seed, fname, nf=None, n_layers=None):
+    cfg, model = build_reference_model(ref, cfg_name, seed, nf=nf, n_layers=n_layers)
     hp = O.Hyper.from_config(cfg)
     g = torch.Generator().manual_seed(seed + 100)
     B, N = len(n_nodes), max(n_nodes)
@@ -91,14 +95,14 @@ def forward_fixture(ref, cfg_name, n_nodes, seed, fname, nf=None):
             err = max((d[0] - want[0]).abs().max().item(), (d[1] - want[1]).abs().max().item())
             assert err < 1e-5, "dense oracle vs reference: %g" % err
     np.savez_compressed(os.path.join(OUT, fname), cfg_name=cfg_name, seed=seed, n_nodes=np.array(n_nodes),
-                        nf=int(cfg.model.nf), xh=xh.numpy(), edge_x=ex.numpy(), noise_level=nl.numpy(),
+                        nf=int(cfg.model.nf), n_layers=int(cfg.model.n_layers), xh=xh.numpy(), edge_x=ex.numpy(), noise_level=nl.numpy(),
                         context=ctx.numpy() if ctx is not None else np.zeros(0, np.float32),
                         out1_x=r1[0].numpy(), out1_e=r1[1].numpy(), out2_x=r2[0].numpy(), out2_e=r2[1].numpy())
     print(fname, 'ok; |out| =', r2[0].abs().max().item(), r2[1].abs().max().item())
 
 
-def ancestral_fixture(ref, fname, steps=5, n_nodes=(9, 5, 17, 12), seed=21):
-    cfg, model = build_reference_model(ref, 'vpsde_qm9_uncond_jodo', seed, head_gain=HEAD_GAIN)
+def ancestral_fixture(ref, fname, steps=5, n_nodes=(9, 5, 17, 12), seed=21, cfg_name='vpsde_qm9_uncond_jodo'):
+    cfg, model = build_reference_model(ref, cfg_name, seed, head_gain=HEAD_GAIN)
     cfg.sampling.steps = steps
     S = ref.sampling
     ns = ref.diffusion.noise_schedule.NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0,
@@ -144,7 +148,8 @@ def ancestral_fixture(ref, fname, steps=5, n_nodes=(9, 5, 17, 12), seed=21):
     m_exist = (h_edge[..., 0] - 0.5).abs()[emk].min().item()
     o3 = h_edge[..., 1] * 3.
     m_order = torch.stack([(o3 - t).abs() for t in (0.5, 1.5, 2.5)]).min(0).values[emk].min().item() / 3.
-    np.savez_compressed(os.path.join(OUT, fname), seed=seed, steps=steps, head_gain=HEAD_GAIN, n_nodes=np.array(n_nodes),
+    np.savez_compressed(os.path.join(OUT, fname), cfg_name=cfg_name, seed=seed, steps=steps, head_gain=HEAD_GAIN,
+                        n_nodes=np.array(n_nodes),
                         z=z.numpy(), edge_z=ez.numpy(), node_noise=torch.stack(rec_node).numpy(),
                         edge_noise=torch.stack(rec_edge).numpy(), x_mean=x_mean.numpy(), edge_x_mean=e_mean.numpy(),
                         pos=pos.numpy(), atom_type=one_hot.argmax(2).numpy(), fc=fc.numpy(), edge_type=et.numpy(),
@@ -305,7 +310,10 @@ def main():
         ('fwd_geom384_big.npz', lambda f: forward_fixture(ref, 'vpsde_geom_uncond_jodo', [140, 100, 181], 16, f, nf=384)),
         ('blocks_qm9.npz', lambda f: blocks_fixture(ref, 'vpsde_qm9_uncond_jodo', [3, 9, 17, 29], 17, f)),
         ('blocks_geom.npz', lambda f: blocks_fixture(ref, 'vpsde_geom_uncond_jodo', [12, 33], 18, f)),
+        ('fwd_geom_l8.npz', lambda f: forward_fixture(ref, 'vpsde_geom_uncond_jodo', [7, 30, 52, 52, 75], 19, f, n_layers=8)),   # BASELINE configs[2] as worded: nf 256, 8 layers, r 4
         ('traj_qm9_anc5.npz', lambda f: ancestral_fixture(ref, f)),
+        # GEOM (3 bond channels: the aromatic decode branch of sampling.py:79-81), short
+        ('traj_geom_anc3.npz', lambda f: ancestral_fixture(ref, f, steps=3, n_nodes=(14, 7, 22), seed=30, cfg_name='vpsde_geom_uncond_jodo')),
         ('traj_qm9_anc50.npz', lambda f: ancestral_tf_fixture(ref, f)),
         ('traj_cond_dpm4.npz', lambda f: dpm_fixture(ref, f)),
         ('traj_cond_dpm_multi8.npz', lambda f: dpm_fixture(ref, f, nfe=8, seed=32, method='multistep', order=2)),

@@ -125,6 +125,8 @@ def check_decodes(cfg, fx, x_mean, e_mean, nm, em, margin=1e-3):
     o3 = h_edge[..., 1] * 3.
     m_edge = torch.minimum((h_edge[..., 0] - 0.5).abs(),
                            torch.stack([(o3 - t).abs() for t in (0.5, 1.5, 2.5)]).min(0).values / 3.)
+    if h_edge.shape[-1] == 3:                                   # aromatic channel (GEOM), sampling.py:79-81
+        m_edge = torch.minimum(m_edge, (h_edge[..., 2] - 0.5).abs())
     ok_edge = (m_edge > margin) | ~emk
     at = one_hot.argmax(2).numpy()
     assert np.array_equal(at[ok_atom.numpy()], fx['atom_type'][ok_atom.numpy()])

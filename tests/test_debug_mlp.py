@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from jodo_amd import packing as P
+import py_packing as P
 
 
 def _ref(x, W1, b1, W2, b2):

@@ -42,12 +42,16 @@ def run(model, xh, ex, nl, nm, em, cx=None, cex=None, ctx=None):
                                           # circulant pair walks of up to 90 offsets
                                           ("fwd_geom_big.npz", "auto"), ("fwd_geom_big.npz", "wide"),
                                           ("fwd_geom384_big.npz", "auto"),
-                                          ("fwd_qm9.npz", "wide"), ("fwd_geom.npz", "wide"), ("fwd_cond.npz", "wide")])
+                                          ("fwd_qm9.npz", "wide"), ("fwd_geom.npz", "wide"), ("fwd_cond.npz", "wide"),
+                                          # BASELINE configs[2] as worded: GEOM nf 256 with 8 layers (r 4, nd 17, ch 3)
+                                          ("fwd_geom_l8.npz", "auto"), ("fwd_geom_l8.npz", "wide")])
 def test_hip_matches_reference_fixture(fname, layout):
     fx = load_fixture(fname)
     over = dict(kernel_layout=layout)
     if 'nf' in fx:
         over['nf'] = int(fx['nf'])
+    if 'n_layers' in fx:
+        over['n_layers'] = int(fx['n_layers'])
     cfg = make_config(str(fx['cfg_name']), **over)
     model = make_model(cfg, int(fx['seed']), DEV)
     hp = O.Hyper.from_config(cfg)
@@ -72,6 +76,7 @@ def test_hip_matches_reference_fixture(fname, layout):
     ('vpsde_geom_uncond_jodo', [19] * 10 + [6] * 12, 1.0, 5, dict(nf=384, n_layers=8, mlp_ratio=2)),
     ('vpsde_qm9_cond_jodo', [9, 9, 14], 1.0, 5, dict(nf=384)),
     ('vpsde_qm9_uncond_jodo', [29, 1, 2, 18, 18, 7, 23], 1.5, 3, dict(kernel_layout='wide')),
+    ('vpsde_geom_uncond_jodo', [70, 33, 12, 1, 2], 1.5, 0, dict(n_layers=8)),             # BASELINE configs[2] as worded
 ])
 def test_hip_matches_oracle(cfg_name, n_nodes, gain, chunk, over):
     cfg = make_config(cfg_name, **over)
@@ -215,18 +220,22 @@ def test_nan_guard_zeroes_positions():
     assert x[:, :, :3].abs().max() == 0                      # batch-global reset (mol_gnn.py:587-589)
 
 
-def test_ancestral_trajectory_with_hip_model():
+@pytest.mark.parametrize("fname,fused_on", [('traj_qm9_anc5.npz', True), ('traj_qm9_anc5.npz', False),
+                                            ('traj_geom_anc3.npz', True), ('traj_geom_anc3.npz', False)])
+def test_ancestral_trajectory_with_hip_model(fname, fused_on):
+    """The reference's recorded trajectory (its own noise draws replayed) with the HIP model; fused_on: the per-step update
+    runs as the fused kernel jodo_sampler_step on the recorded draws (the product path), otherwise op by op in torch."""
     from jodo_amd.diffusion import NoiseScheduleVP
     from jodo_amd.sampling import AncestralSampler
     from jodo_amd.utils import get_self_cond_fn
-    fx = load_fixture('traj_qm9_anc5.npz')
-    cfg = make_config('vpsde_qm9_uncond_jodo')
+    fx = load_fixture(fname)
+    cfg = make_config(str(fx['cfg_name']))
     model = make_model(cfg, int(fx['seed']), DEV, head_gain=float(fx['head_gain']))
     nm, em = masks(fx['n_nodes'].tolist(), DEV)
     ns = NoiseScheduleVP(cfg.sde.schedule)
     noise = {'node': torch.from_numpy(fx['node_noise']).to(DEV), 'edge': torch.from_numpy(fx['edge_noise']).to(DEV)}
     sampler = AncestralSampler(ns, torch.linspace(ns.T, 1e-3, int(fx['steps'])), True, True, True,
-                               get_self_cond_fn(cfg), noise_fn=lambda i, kind, like: noise[kind][i])
+                               get_self_cond_fn(cfg), noise_fn=lambda i, kind, like: noise[kind][i], fused=fused_on)
     with torch.no_grad():
         x_mean, e_mean = sampler.sampling(model, torch.from_numpy(fx['z']).to(DEV), nm, em,
                                           torch.from_numpy(fx['edge_z']).to(DEV), None)
@@ -235,29 +244,31 @@ def test_ancestral_trajectory_with_hip_model():
     check_decodes(cfg, fx, x_mean, e_mean, nm, em)
 
 
+@pytest.mark.parametrize("fused_on", [True, False])
 @pytest.mark.parametrize("fname", ['traj_cond_dpm4.npz', 'traj_cond_dpm_multi8.npz', 'traj_cond_dpm_single3.npz',
                                    'traj_cond_dpm_single1.npz'])
-def test_dpm_solver_trajectory_with_hip_model(fname):
+def test_dpm_solver_trajectory_with_hip_model(fname, fused_on):
     from jodo_amd.diffusion import NoiseScheduleVP
     from jodo_amd.mix_dpm_solver import DPM_Solver_hybrid
     fx = load_fixture(fname)
     cfg = make_config('vpsde_qm9_cond_jodo')
     cfg.sampling.steps = int(fx['nfe'])
     cfg.sampling.method = 'fast'
-    cfg.sampling.dpm_solver_method = str(fx['method']) if 'method' in fx else 'singlestep_fixed'
-    cfg.sampling.dpm_solver_order = int(fx['order']) if 'order' in fx else 2
+    cfg.sampling.dpm_solver_method = str(fx['method'])
+    cfg.sampling.dpm_solver_order = int(fx['order'])
     model = make_model(cfg, int(fx['seed']), DEV, head_gain=float(fx['head_gain']))
     nm, em = masks(fx['n_nodes'].tolist(), DEV)
     pn = torch.from_numpy(fx['pos_noise']).to(DEV)
-    solver = DPM_Solver_hybrid(NoiseScheduleVP(cfg.sde.schedule), cfg, noise_fn=lambda i, kind, like: pn[i])
+    solver = DPM_Solver_hybrid(NoiseScheduleVP(cfg.sde.schedule), cfg, noise_fn=lambda i, kind, like: pn[i], fused=fused_on)
     x, ex = solver.sampling(model, torch.from_numpy(fx['z']).to(DEV), nm, em, torch.from_numpy(fx['edge_z']).to(DEV),
                             torch.from_numpy(fx['context']).to(DEV))
     close(x, torch.from_numpy(fx['x']), atol=1e-3, rtol=0)
     close(ex, torch.from_numpy(fx['edge_x']), atol=1e-3, rtol=0)
 
 
-def test_ancestral_50_steps_free_running_and_teacher_forced():
-    """K = 50: (a) free-running with the recorded noise, end state within the K-step tolerance and decodes
+@pytest.mark.parametrize("fused_on", [True, False])
+def test_ancestral_50_steps_free_running_and_teacher_forced(fused_on):
+    """K = 50: (a) free-running with the recorded noise (fused_on: updates by jodo_sampler_step), end state within the K-step tolerance and decodes
     bit-exact above margin; (b) teacher-forced: every one of the reference's 50 recorded step inputs through the
     kernels, against the reference's recorded prediction at the single-forward tolerance."""
     from jodo_amd.diffusion import NoiseScheduleVP
@@ -271,13 +282,15 @@ def test_ancestral_50_steps_free_running_and_teacher_forced():
     steps = int(fx['steps'])
     noise = {'node': torch.from_numpy(fx['node_noise']).to(DEV), 'edge': torch.from_numpy(fx['edge_noise']).to(DEV)}
     sampler = AncestralSampler(ns, torch.linspace(ns.T, 1e-3, steps), True, True, True,
-                               get_self_cond_fn(cfg), noise_fn=lambda i, kind, like: noise[kind][i])
+                               get_self_cond_fn(cfg), noise_fn=lambda i, kind, like: noise[kind][i], fused=fused_on)
     with torch.no_grad():
         x_mean, e_mean = sampler.sampling(model, torch.from_numpy(fx['z']).to(DEV), nm, em,
                                           torch.from_numpy(fx['edge_z']).to(DEV), None)
     close(x_mean, torch.from_numpy(fx['x_mean']), atol=1e-3, rtol=0)
     close(e_mean, torch.from_numpy(fx['edge_x_mean']), atol=1e-3, rtol=0)
     check_decodes(cfg, fx, x_mean, e_mean, nm, em)
+    if not fused_on:
+        return                                                   # the teacher-forced half does not depend on the update path
     t = lambda k, i: torch.from_numpy(fx[k][i]).to(DEV)
     worst = 0.0
     with torch.no_grad():
@@ -348,8 +361,14 @@ def test_per_block_intermediates(fname, layout):
 
 @pytest.mark.parametrize("cfg_name,info,B,over,n_sub", [
     ('vpsde_qm9_uncond_jodo', 'qm9_with_h', 2500, {}, 64),                     # BASELINE configs[1]
-    ('vpsde_geom_uncond_jodo', 'geom_with_h_1', 512, {}, 64),                  # BASELINE configs[2]
+    ('vpsde_geom_uncond_jodo', 'geom_with_h_1', 512, {}, 64),                  # BASELINE configs[2] (the config file's L = 10)
+    ('vpsde_geom_uncond_jodo', 'geom_with_h_1', 512, dict(n_layers=8), 64),    # BASELINE configs[2] as worded (8 layers)
     ('vpsde_geom_uncond_jodo', 'geom_with_h_1', 1250, dict(nf=384), 64),       # per-GPU share of BASELINE configs[3]
+    # BASELINE configs[4], conditional model with per-molecule context (mol_gnn.py:728-734): no shared modulation row,
+    # so the un-folded pair update and the four-block row GEMM run at the real batch (1250 = one round per GPU when the
+    # molecules are dealt to the ranks first; 313 = a quarter round)
+    ('vpsde_qm9_cond_jodo', 'qm9_second_half', 1250, {}, 64),
+    ('vpsde_qm9_cond_jodo', 'qm9_second_half', 313, {}, 64),
 ])
 def test_full_size_batches_match_oracle_on_sampled_molecules(cfg_name, info, B, over, n_sub):
     """The batch sizes the bench numbers are quoted on: a first-step and a self-conditioned evaluation of the FULL
@@ -366,12 +385,13 @@ def test_full_size_batches_match_oracle_on_sampled_molecules(cfg_name, info, B, 
     xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=7)
     xh[:, :, :3] -= xh[:, :, :3].sum(1, keepdim=True) / nm.sum(1, keepdim=True) * nm
     nl[:] = 0.5                                                              # sampling: one noise level per batch
-    x1, e1 = run(model, xh, ex, nl, nm, em)
+    shared = 0 if hp.cond_ch else 1                          # conditional: the context makes every modulation row different
+    x1, e1 = run(model, xh, ex, nl, nm, em, None, None, ctx)
     fl = model.last_flags.cpu().tolist()
-    assert (fl[0], fl[2], fl[3], fl[4]) == (0, 1, 0, 0)      # no NaN, shared time row, first-step branch (:544), pair path
-    x2, e2 = run(model, xh, ex, nl, nm, em, x1, e1)
+    assert (fl[0], fl[2], fl[3], fl[4]) == (0, shared, 0, 0)      # no NaN, shared time row, first-step branch (:544), pair path
+    x2, e2 = run(model, xh, ex, nl, nm, em, x1, e1, ctx)
     fl = model.last_flags.cpu().tolist()
-    assert (fl[0], fl[2], fl[3], fl[4]) == (0, 1, 1, 0)      # self-conditioned branch
+    assert (fl[0], fl[2], fl[3], fl[4]) == (0, shared, 1, 0)      # self-conditioned branch
     N = max(n_nodes)
     for x, e in ((x1, e1), (x2, e2)):
         assert torch.isfinite(x).all() and torch.isfinite(e).all()
@@ -389,9 +409,10 @@ def test_full_size_batches_match_oracle_on_sampled_molecules(cfg_name, info, B, 
         Ns = max(pn)
         nms, ems = masks(pn)
         cut = lambda a, k: a[part][:, :Ns] if k == 1 else a[part][:, :Ns, :Ns]
+        cp = ctx[part] if ctx is not None else None
         with torch.no_grad():
-            r1 = O.forward_dense(sd, hp, cut(xh, 1), nms, ems, cut(ex, 2), None, None, nl[part])
-            r2 = O.forward_dense(sd, hp, cut(xh, 1), nms, ems, cut(ex, 2), cut(x1, 1), cut(e1, 2), nl[part])
+            r1 = O.forward_dense(sd, hp, cut(xh, 1), nms, ems, cut(ex, 2), None, None, nl[part], cp)
+            r2 = O.forward_dense(sd, hp, cut(xh, 1), nms, ems, cut(ex, 2), cut(x1, 1), cut(e1, 2), nl[part], cp)
         close(cut(x1, 1), r1[0], atol=3e-5)
         close(cut(e1, 2), r1[1], atol=3e-5)
         close(cut(x2, 1), r2[0], atol=3e-5)

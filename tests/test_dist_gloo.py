@@ -143,7 +143,7 @@ def _parity_body(get_sampling_fn):
 
 def test_sharded_sampling_perf_mode_rng_contract_and_lpt():
     """shard_mode='perf': molecules are dealt to the ranks before rounds are cut, atom counts come from the shared
-    seed (identical on all ranks whatever their prior RNG state), noise from seed + 1 + rank (no two ranks share a
+    seed (identical on all ranks whatever their prior RNG state), noise from (seed << 20) + 1 + rank (no two (seed, rank) pairs share a
     stream), LPT balances the n^2 work."""
     from jodo_amd.dist import assign_lpt
     res = _run_world2('ancestral', 2, 'perf')

@@ -90,3 +90,45 @@ def test_post_process_thresholds():
     ex[0, 0, 1] = ex[0, 1, 0] = torch.tensor([1.0, -1.0, 1.0])      # exists, no order, aromatic -> 4
     _, _, _, et = post_process(xh, 16, True, nm, inv, ex, em, True)
     assert et[0].tolist() == [[0, 4], [4, 0]]
+
+
+def test_philox_known_answers():
+    """oracle/philox_ref.py (the checker of the in-kernel noise draws) against the published Random123 known-answer vectors of
+    philox4x32-10, and the structure of the noise it builds from them."""
+    import numpy as np
+    from oracle import philox_ref as PR
+    kat = [([0, 0, 0, 0], [0, 0], '6627e8d5 e169c58d bc57ac4c 9b00dbd8'),
+           ([0xffffffff] * 4, [0xffffffff] * 2, '408f276d 41c83b0e a20bc7c6 6d5451fd'),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], 'd16cfe09 94fdcceb 5001e420 24126ea1')]
+    for ctr, key, want in kat:
+        got = PR.philox4x32_10(np.array(ctr, dtype=np.uint32), np.array(key, dtype=np.uint32))
+        assert ' '.join('%08x' % v for v in got) == want
+    z = PR.normal4(12345, 3, 0, np.arange(100000))
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01 and np.isfinite(z).all()
+    n_nodes = [3, 5, 1]
+    x = PR.node_noise(7, 1, n_nodes, 5, 6)
+    assert np.abs(x[:, :, :3].sum(1)).max() < 1e-6 and x[0, 3:].any() == False and x[2, 1:].any() == False
+    e = PR.edge_noise(7, 1, n_nodes, 5, 2)
+    assert np.array_equal(e, e.transpose(0, 2, 1, 3)) and np.abs(e[:, np.arange(5), np.arange(5)]).max() == 0
+    assert e[2].any() == False and e[0, 3:].any() == False
+
+
+def test_plan_options_are_range_checked():
+    import ctypes
+    import numpy as np
+    from jodo_amd import capi
+    from jodo_amd.models.dgt import _DGTBase
+    lib = capi.lib()
+    cfg = _DGTBase._Cfg(256, 8, 16, 2, 2, 6, 2, 0, 2.0, 0.0, 0)
+    n = np.asarray([5, 9], dtype=np.int32)
+    h = ctypes.c_void_p()
+    assert lib.jodo_plan_create(ctypes.byref(cfg), 2, 9, n.ctypes.data_as(ctypes.c_void_p), 0, ctypes.byref(h)) == 0
+    try:
+        for opt, good, bad in ((0, (0, 1), (2, -1)), (1, (0, 1), (7,)), (2, (0, 1, 2, 4, 12, 14), (3, 5)), (3, (0, 1, 2, 3), (4, -1))):
+            for v in good:
+                assert lib.jodo_plan_set_option(h, opt, v) == 0
+            for v in bad:
+                assert lib.jodo_plan_set_option(h, opt, v) == -1 and b'plan_set_option' in lib.jodo_last_error()
+        assert lib.jodo_plan_set_option(h, 99, 0) == -1
+    finally:
+        lib.jodo_plan_destroy(h)

@@ -6,8 +6,9 @@ import re
 import numpy as np
 import pytest
 
-from jodo_amd import capi, packing as P
-from jodo_amd.packing_model import BLOCK_SLOTS, GLOBAL_SLOTS, ModelDims
+from jodo_amd import capi
+import py_packing as P
+from py_packing_model import BLOCK_SLOTS, GLOBAL_SLOTS, ModelDims
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, 'include', 'jodo_hip.h')
@@ -107,7 +108,7 @@ def test_c_packer_equals_python_packer(cfg_name, over):
     'module.'-prefixed state_dict (DataParallel checkpoints) packs identically; a missing tensor is a named error."""
     import torch
     from helpers import make_config, make_model
-    from jodo_amd.packing_model import pack_model
+    from py_packing_model import pack_model
     cfg = make_config(cfg_name, **over)
     model = make_model(cfg, 3)
     sd = model.state_dict()
@@ -117,7 +118,7 @@ def test_c_packer_equals_python_packer(cfg_name, over):
     assert blob_c.numel() == blob_py.size
     # bit-equal everywhere except the fused modulation projection, whose composed rows (coord_mlp.0 pushed through the
     # LayerNorm: products of two weight matrices) are accumulated in double by both packers but not in the same order
-    from jodo_amd.packing_model import GLOBAL_SLOTS
+    from py_packing_model import GLOBAL_SLOTS
     lo, hi = woff_py[GLOBAL_SLOTS.index('MOD_W')], woff_py[GLOBAL_SLOTS.index('MOD_B') + 1]
     bc, bp = blob_c.numpy(), blob_py
     assert np.array_equal(bc[:lo].view(np.uint32), bp[:lo].view(np.uint32)) and np.array_equal(bc[hi:].view(np.uint32), bp[hi:].view(np.uint32))
