@@ -228,6 +228,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay one captured HIP graph per step (jodo_amd/graphed.py)')
     ap.add_argument('--torch-noise', action='store_true',
                     help='per-step noise from three torch.randn launches (the reference RNG stream) instead of in-kernel Philox draws')
+    ap.add_argument('--no-pin', action='store_true', help='keep launching every kernel variant (device flags pick; experiments)')
     ap.add_argument('--plan-opt', action='append', default=[], help='jodo_plan_option=value (experiments), e.g. 3=0')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-full-round', action='store_true', help='skip the end-to-end 1000-step round')
@@ -280,6 +281,8 @@ def main():
     model.pair_chunk = args.pair_chunk
     model.spair_chunk = args.spair_chunk
     model.plan_options = {int(o.split('=')[0]): int(o.split('=')[1]) for o in args.plan_opt}
+    if args.no_pin:
+        model.pin_paths = lambda: None
     model.force_directed = bool(int(os.environ.get("JODO_FORCE_DIRECTED", "0")))   # debug: skip the symmetric pair kernels
 
     # synthetic inputs: atom counts from the training histogram (seed 42 + rank), reference noise shapes

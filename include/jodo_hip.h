@@ -131,7 +131,8 @@ int jodo_plan_stats(const jodo_plan* plan, int64_t* out6);
  *              [1] reserved (0), [2] = all molecules shared one noise level, [3] = the self-conditioning positions
  *              were not all equal (0 => the batch-global first-step branch of :544 was taken),
  *              [4] = edge inputs were not symmetric (directed kernels used), [5] = STICKY count of calls in which
- *              the NaN guard fired (only ever incremented by the library; the caller clears it when it reads it)
+ *              the NaN guard fired (only ever incremented by the library; the caller clears it when it reads it),
+ *              [6] = STICKY pin violations (JODO_OPT_PIN_*: bit 0 symmetry, bit 1 shared row), [7] reserved
  *   workspace: jodo_plan_workspace_bytes() bytes of device scratch
  *   dbg: optional device buffer for intermediates (tests) or NULL */
 int jodo_dgt_forward(jodo_plan* plan, const void* desc_dev, const float* packed_w, const int64_t* woff,
@@ -156,6 +157,15 @@ enum jodo_plan_option {
     JODO_OPT_NODE_POST_WAVES = 2, /* 0 (default): automatic; 1 / 2 / 4: waves per strip for every strip of k_node_post;
                                    * 12 / 14: automatic split, 2 / 4 waves per strip of the remainder launch */
     JODO_OPT_ATTN_VARIANT = 3,    /* nf 256 pair attention kernel, weight residency / hand-over granularity: 0 (default), 1, 2, 3 (dgt_kernels_attn.h); other values are rejected */
+    /* Path pinning.  By default every forward launches every kernel variant and device flags decide which ones work (no host
+     * sync); the idle variants cost a dispatch each (~5 us, 24 per forward at 8 blocks).  Inside one sampling round the inputs
+     * stay symmetric and the noise level stays shared, so a caller that has read flags [2] / [4] of one call may pin them for the
+     * following calls on this plan: only the working variants are then launched.  A call that violates a pin (e.g. asymmetric
+     * inputs under a symmetric pin) is detected on the device: flags[6] gets bit 0 (symmetry pin) / bit 1 (shared-row pin), sticky,
+     * and its outputs are unspecified — callers check flags[6] when they read the NaN counter. */
+    JODO_OPT_PIN_SYMMETRIC = 4,   /* 0 (default): decided per call on the device; 1: inputs are symmetric (pair kernels only);
+                                     2: asymmetric (directed kernels only) */
+    JODO_OPT_PIN_UNIFORM_T = 5,   /* 0 (default): per call; 1: one shared modulation row (folded pair update only); 2: per-molecule rows */
     JODO_OPT_COUNT
 };
 int jodo_plan_set_option(jodo_plan* plan, int option, int value);

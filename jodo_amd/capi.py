@@ -8,7 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libjodo_hip.so')
+# JODO_HIP_LIB: A/B experiments of tools/ load another build of the same library (csrc/Makefile LIB=...); tests and the
+# driver never set it
+LIB_PATH = os.environ.get('JODO_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libjodo_hip.so')
 _lib = None
 
 

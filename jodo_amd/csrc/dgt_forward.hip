@@ -99,10 +99,12 @@ int launch_update_sym(jodo_plan* p, hipStream_t st, KArgs& A) {
     const bool split = D != 256 && p->opt[JODO_OPT_DIR_SPLIT] != 0 && rem > 0 && rem <= 512;
     const int n1 = split ? full : p->n_pitems;
     A.item0 = 0; A.dir_split = 0;
-    if (n1 > 0) { if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2>), n1, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4>), n1, 64, A); }
+    // JODO_OPT_PIN_UNIFORM_T: 1 = every call shares one modulation row (only the folded variant is launched), 2 = never
+    const bool run_plain = p->opt[JODO_OPT_PIN_UNIFORM_T] != 1, run_fold = p->opt[JODO_OPT_PIN_UNIFORM_T] != 2 && d.cond_ch == 0;
+    if (run_plain && n1 > 0) { if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2>), n1, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4>), n1, 64, A); }
     // shared modulation row (device flag): the variant with the folded coord_mlp.0 does the work instead (never split)
-    if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2, true>), p->n_pitems, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4, true>), p->n_pitems, 64, A);
-    if (split) {
+    if (run_fold) { if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2, true>), p->n_pitems, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4, true>), p->n_pitems, 64, A); }
+    if (run_plain && split) {
         A.item0 = full; A.dir_split = 1;
         if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2>), 2 * rem, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4>), 2 * rem, 64, A);
         A.item0 = 0; A.dir_split = 0;
@@ -118,8 +120,8 @@ int launch_embed_nodes(hipStream_t st, const KArgs& A) {
 // symmetric inputs (device flag): one evaluation per unordered pair, written to both rows; otherwise every dense row
 template <int D, int NBK>
 int launch_edge_head(hipStream_t st, const KArgs& A) {
-    if (A.pd.n_ut_pad > 0) LAUNCH((wide::k_edge_head<D, NBK, true>), (unsigned)(A.pd.n_ut_pad / 32), 64, A);
-    LAUNCH((wide::k_edge_head<D, NBK, false>), (unsigned)((A.pd.rows + 31) / 32), 64, A);
+    if (A.pd.n_ut_pad > 0 && A.pin_sym != 2) LAUNCH((wide::k_edge_head<D, NBK, true>), (unsigned)(A.pd.n_ut_pad / 32), 64, A);
+    if (A.pin_sym != 1) LAUNCH((wide::k_edge_head<D, NBK, false>), (unsigned)((A.pd.rows + 31) / 32), 64, A);
     return JODO_OK;
 }
 
@@ -170,7 +172,8 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
     }
     if (rc) return rc;
     if (p->n_items > 0) LAUNCH((wide::k_embed_edges<D>), p->n_items, 64, A);
-    if (p->n_pitems > 0) {                         // folded coord_mlp.0 of every block (pair update, shared modulation row)
+    const bool pin_pair = p->opt[JODO_OPT_PIN_SYMMETRIC] == 1, pin_dir = p->opt[JODO_OPT_PIN_SYMMETRIC] == 2 || p->force_directed;
+    if (p->n_pitems > 0 && !pin_dir && p->opt[JODO_OPT_PIN_UNIFORM_T] != 2 && d.cond_ch == 0) {   // folded coord_mlp.0 of every block (pair update, shared modulation row)
         if (d.L > 16) return jodo_set_error(JODO_ERR_UNSUPPORTED, "more than 16 blocks");
         FoldOffs F;
         for (int l = 0; l < 16; ++l) {
@@ -217,14 +220,14 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
             // fused attention edge phase (dgt_kernels_attn.h): pair-mode items do the work for symmetric inputs, directed-mode
             // items for asymmetric inputs and for molecules larger than a group (device flag; the other launch exits at once)
             ProfScope ps(p, st, JODO_PROF_EDGE_ATTN);
-            if (p->n_aitems > 0) {
+            if (p->n_aitems > 0 && !pin_dir) {
                 const int var = TUNED ? p->opt[JODO_OPT_ATTN_VARIANT] : 0;
                 if (var == 1) LAUNCH((k_edge_attn<D, !TUNED, true, TUNED ? 1 : 0>), p->n_aitems, ATT_WAVES * 64, A);
                 else if (var == 2) LAUNCH((k_edge_attn<D, !TUNED, true, TUNED ? 2 : 0>), p->n_aitems, ATT_WAVES * 64, A);
                 else if (var == 3) LAUNCH((k_edge_attn<D, !TUNED, true, TUNED ? 3 : 0>), p->n_aitems, ATT_WAVES * 64, A);
                 else LAUNCH((k_edge_attn<D, !TUNED, true, 0>), p->n_aitems, ATT_WAVES * 64, A);
             }
-            if (p->n_aditems > 0) LAUNCH((k_edge_attn<D, !TUNED, false>), p->n_aditems, ATT_WAVES * 64, A);
+            if (p->n_aditems > 0 && (!pin_pair || p->has_big)) LAUNCH((k_edge_attn<D, !TUNED, false>), p->n_aditems, ATT_WAVES * 64, A);
         }
         {
             ProfScope ps(p, st, JODO_PROF_NODE_POST);
@@ -241,15 +244,15 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
                 if (d.r == 2) LAUNCH((wide::k_node_post<D, 2>), p->n_strips, 64, A); else LAUNCH((wide::k_node_post<D, 4>), p->n_strips, 64, A);
             }
             // per-node part of coord_mlp.0 pushed through the LayerNorm (pair update at nf = 256, dgt_kernels_wide.h)
-            if (p->n_pitems > 0) LAUNCH((wide::k_node_ab<D>), p->n_strips * 2, 64, A);
+            if (p->n_pitems > 0 && !pin_dir) LAUNCH((wide::k_node_ab<D>), p->n_strips * 2, 64, A);
         }
         if (p->n_items > 0) {
             ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);          // exactly one of the two does the work (device flag)
-            if (p->n_pitems > 0) {
+            if (p->n_pitems > 0 && !pin_dir) {
                 rc = launch_update_sym<D>(p, st, A);
                 if (rc) return rc;
             }
-            if (d.r == 2) LAUNCH((wide::k_edge_update<D, 2>), p->n_items, 64, A); else LAUNCH((wide::k_edge_update<D, 4>), p->n_items, 64, A);
+            if (!pin_pair) { if (d.r == 2) LAUNCH((wide::k_edge_update<D, 2>), p->n_items, 64, A); else LAUNCH((wide::k_edge_update<D, 4>), p->n_items, 64, A); }
             std::swap(A.e, A.e_out);               // the state the next block reads is the one just written
             p->last_e_buf ^= 1;
         }
@@ -307,7 +310,8 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     A.W = packed_w;
     for (int i = 0; i < JW_GLOBAL_COUNT; ++i) A.wg[i] = woff[i];
     for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = 0;
-    A.mod_base = 0; A.layer = 0; A.force_directed = p->force_directed; A.pre_mode = 0; A.strip0 = 0; A.item0 = 0; A.dir_split = 0; A.fuse_next = 0; A.mod_base_next = 0;
+    A.mod_base = 0; A.layer = 0; A.force_directed = p->force_directed; A.pin_sym = p->force_directed ? 0 : p->opt[JODO_OPT_PIN_SYMMETRIC];
+    A.pin_uni = p->opt[JODO_OPT_PIN_UNIFORM_T]; A.pre_mode = 0; A.strip0 = 0; A.item0 = 0; A.dir_split = 0; A.fuse_next = 0; A.mod_base_next = 0;
     for (int i = 0; i < 6; ++i) A.wbn[i] = 0;
     fill_ws(A, p, workspace);
     float* posbuf[2] = {ws_ptr<float>(workspace, p->ws.pos0), ws_ptr<float>(workspace, p->ws.pos1)};

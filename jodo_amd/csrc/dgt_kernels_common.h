@@ -4,7 +4,7 @@
 #include "dgt_plan.h"
 
 // flags_dev layout (int32[8])
-enum { FLAG_NAN = 0, FLAG_FIRST = 1, FLAG_UNIFORM_T = 2, FLAG_COND_NONZERO = 3, FLAG_ASYM = 4, FLAG_NAN_COUNT = 5 };
+enum { FLAG_NAN = 0, FLAG_FIRST = 1, FLAG_UNIFORM_T = 2, FLAG_COND_NONZERO = 3, FLAG_ASYM = 4, FLAG_NAN_COUNT = 5, FLAG_PIN_VIOLATED = 6 };
 
 struct KArgs {
     PlanDev pd;
@@ -15,6 +15,7 @@ struct KArgs {
     int64_t mod_base;                     // offset of the current block inside a modulation vector
     int layer;
     int force_directed;                   // debug: never take the symmetric pair path
+    int pin_sym, pin_uni;                 // JODO_OPT_PIN_*: variants the launcher left out (checked against the device flags in k_finalize_nodes)
     int strip0;                           // k_node_post*: first strip of this launch (a layer's strips may be split over two launches)
     int item0, dir_split;                 // pair update: first item of this launch; 1 = two workgroups per item, one direction each
     // k_node_post*: when fuse_next != 0 the kernel also produces the NEXT block's q / k / v (LN1 + modulate of the

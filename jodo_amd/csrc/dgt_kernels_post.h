@@ -41,6 +41,12 @@ __global__ void k_finalize_nodes(KArgs A) {
     // sticky count of evaluations in which the NaN guard fired: never reset by the library, read-and-cleared by the
     // caller once per sampling round (the reference prints its warning per forward, mol_gnn.py:588)
     if (idx == 0 && A.flags[FLAG_NAN] != 0) A.flags[FLAG_NAN_COUNT] += 1;
+    if (idx == 0) {                                           // a pinned path that this call's inputs did not take (sticky)
+        int bad = 0;
+        if (A.pin_sym == 1 && A.flags[FLAG_ASYM]) bad |= 1;       // (a directed pin forces FLAG_ASYM in k_flags_init: always valid)
+        if ((A.pin_uni == 1 && !A.flags[FLAG_UNIFORM_T]) || (A.pin_uni == 2 && A.flags[FLAG_UNIFORM_T])) bad |= 2;
+        if (bad) A.flags[FLAG_PIN_VIOLATED] |= bad;
+    }
     const int b = idx / A.pd.N, i = idx % A.pd.N;
     const int n = A.pd.orig_n[b], nd = A.d.nd;
     float* o = A.out_xh + (size_t)idx * (3 + nd);

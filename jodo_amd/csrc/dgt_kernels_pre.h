@@ -20,7 +20,7 @@ __global__ void k_flags_init(KArgs A) {
         A.flags[FLAG_NAN] = 0;
         A.flags[FLAG_FIRST] = 0;
         A.flags[FLAG_COND_NONZERO] = 0;
-        A.flags[FLAG_ASYM] = A.force_directed ? 1 : 0;
+        A.flags[FLAG_ASYM] = (A.force_directed || A.pin_sym == 2) ? 1 : 0;
         A.flags[FLAG_UNIFORM_T] = (A.d.cond_ch == 0 && !differs) ? 1 : 0;
     }
 }

@@ -113,6 +113,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     const bool spair_auto = spair_chunk <= 0;
     p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->last_e_buf = 0;
     p->opt[JODO_OPT_FUSE_NEXT_QKV] = 1; p->opt[JODO_OPT_DIR_SPLIT] = 1; p->opt[JODO_OPT_NODE_POST_WAVES] = 0; p->opt[JODO_OPT_ATTN_VARIANT] = 0;
+    p->opt[JODO_OPT_PIN_SYMMETRIC] = 0; p->opt[JODO_OPT_PIN_UNIFORM_T] = 0;
     p->prof_enabled = 0; p->force_directed = 0; p->dbg_timing = nullptr;
 
     // molecules by descending size (stable): neighbouring lanes share n, big work first
@@ -245,6 +246,8 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         for (const It& it : pit) { ai_group.push_back(it.g); ai_t0.push_back(it.t0); ai_t1.push_back(it.t1); ai_part.push_back(it.part); }
         for (const It& it : dit) { ad_group.push_back(it.g); ad_t0.push_back(it.t0); ad_t1.push_back(it.t1); ad_part.push_back(it.part); ad_big.push_back(it.big); }
         p->n_aitems = (int)pit.size(); p->n_aditems = (int)dit.size(); p->amax_parts = amax_parts;
+        p->has_big = 0;
+        for (int g = 0; g < ng; ++g) p->has_big |= g_big[g];
     }
 
     auto put = [&](const std::vector<int32_t>& a, size_t* off) {
@@ -412,6 +415,8 @@ extern "C" int jodo_plan_set_option(jodo_plan* p, int option, int value) {
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: node-post waves per strip must be 0 (auto), 1, 2 or 4");
     if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT) && value != 0 && value != 1)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: option %d is a switch (0 or 1), got %d", option, value);
+    if ((option == JODO_OPT_PIN_SYMMETRIC || option == JODO_OPT_PIN_UNIFORM_T) && (value < 0 || value > 2))
+        return jodo_set_error(JODO_ERR_ARG, "plan_set_option: a pin is 0 (none), 1 or 2, got %d", value);
     if (option == JODO_OPT_ATTN_VARIANT && (value < 0 || value > 3))
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: attention variant must be 0..3, got %d", value);
     p->opt[option] = value;

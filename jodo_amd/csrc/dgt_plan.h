@@ -67,6 +67,7 @@ struct jodo_plan {
     DgtDims dims;
     int B, N, Nn, Nn_pad, n_strips, n_items, n_pitems, max_parts;
     int n_agroups, n_aitems, n_aditems, amax_parts, n_ut_pad;
+    int has_big;                     // some molecule spans several attention groups (n > 128): its items always run in directed mode
     size_t off_ag_node, off_ai_group, off_ai_t0, off_ai_t1, off_ai_part, off_ad_group, off_ad_t0, off_ad_t1, off_ad_part, off_ad_big, off_anode_parts, off_ut_rows;
     int64_t rows, dir_edges;
     std::vector<int32_t> desc;       // concatenated descriptor tables

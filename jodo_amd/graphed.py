@@ -119,6 +119,10 @@ class GraphedAncestralRound:
         with torch.cuda.stream(side):
             self._one_step()
         torch.cuda.current_stream().wait_stream(side)
+        from .models.utils import model_hook
+        pin = model_hook(self.model, 'pin_paths')      # the captured step launches only the variants this round uses
+        if pin is not None:
+            pin()
         self._snapshot()
         self.done = 2
         self.last = (self.x_mean, self.e_mean)
@@ -211,6 +215,7 @@ class GraphedDPMRound:
         sv.cond_x = sv.cond_edge_x = None
         sv._noise_calls = 0
         sv._n_nodes_dev = fused.n_nodes_from_mask(self.node_mask)      # this round's atom counts (the solver serves many rounds)
+        sv._pinned = False
         self.rng = sv.device_noise
         model_fn = sv.get_model_fn(self.model)
         outer = sv.get_time_steps('time_uniform', ns.T, 1. / ns.total_N, self.K, 'cpu')
@@ -237,6 +242,10 @@ class GraphedDPMRound:
             with torch.cuda.stream(side):
                 self._outer_step()                               # outer step 1: eager warm-up on the static buffers
             torch.cuda.current_stream().wait_stream(side)
+            from .models.utils import model_hook
+            pin = model_hook(self.model, 'pin_paths')
+            if pin is not None:
+                pin()
             if self.K > 2:
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):

@@ -9,7 +9,7 @@ update (:44-59), first/second/third-order single-step updates (:61-227), multist
 """
 import torch
 
-from .models.utils import assert_mean_zero_with_mask, sample_center_gravity_zero_gaussian_with_mask
+from .models.utils import assert_mean_zero_with_mask, model_hook, sample_center_gravity_zero_gaussian_with_mask
 
 
 def split_x(x):
@@ -25,6 +25,7 @@ class DPM_Solver_hybrid:
         self.noise_schedule = noise_schedule
         self.device_noise = device_noise  # fused.DeviceNoise: position noise drawn inside jodo_dpm_update_rng (Philox)
         self._n_nodes_dev = None          # int32 [B] atom counts of the round being sampled (set by `sampling`)
+        self._pinned = False
         self.cond_x = None
         self.cond_edge_x = None
         self.order = config.sampling.dpm_solver_order
@@ -223,6 +224,12 @@ class DPM_Solver_hybrid:
         def model_fn(x, node_mask, edge_mask, edge_x, context, vec_t, noise_level):
             pred_t, edge_pred_t = model(vec_t, x, node_mask, edge_mask, edge_x=edge_x, noise_level=noise_level,
                                         cond_x=self.cond_x, cond_edge_x=self.cond_edge_x, context=context)
+            if self.cond_x is not None and not self._pinned and x.is_cuda:
+                # first self-conditioned evaluation of the round: pin the HIP model's kernel variants (sampling.py, step 1)
+                pin = model_hook(model, 'pin_paths')
+                if pin is not None:
+                    pin()
+                self._pinned = True
             self.cond_x, self.cond_edge_x = pred_t, edge_pred_t
             return pred_t, edge_pred_t
         return model_fn
@@ -234,6 +241,7 @@ class DPM_Solver_hybrid:
         self.cond_x = self.cond_edge_x = None
         self._noise_calls = 0
         self._n_nodes_dev = None
+        self._pinned = False
         if self.fused and x.is_cuda:
             from . import fused
             self._n_nodes_dev = fused.n_nodes_from_mask(node_mask)      # per ROUND: a solver object serves many rounds

@@ -303,11 +303,30 @@ class _DGTBase(nn.Module):
         plans = list(self._plans.values())
         if not plans:
             return 0
-        total = int(torch.stack([p['flags'][5] for p in plans]).sum().item())       # one host sync for all cached plans
-        if total:
+        both = torch.stack([p['flags'][5:7] for p in plans]).sum(0).tolist()        # one host sync for all cached plans
+        total, violated = int(both[0]), int(both[1])
+        if total or violated:
             for p in plans:
-                p['flags'][5] = 0
+                p['flags'][5:7] = 0
+        if violated:
+            raise RuntimeError("a call on a plan with pinned kernel paths (pin_paths) had inputs that take another path "
+                               "(asymmetric edge tensors or per-molecule noise levels): its outputs are invalid")
         return total
+
+    def pin_paths(self):
+        """Pin the kernel variants of the plan of the last call to the ones that call used (device flags [2] shared
+        modulation row, [4] asymmetric inputs; one host sync): later calls on the same masks launch only those variants
+        instead of every variant + device-side early exits (24 idle dispatches per forward at 8 blocks).  For callers that
+        know the inputs keep their structure — the samplers inside one round.  A violating call is detected on the
+        device and reported by take_nan_count()."""
+        plan = getattr(self, '_last_plan', None)
+        if plan is None or plan.get('pinned'):
+            return
+        fl = plan['flags'].cpu().tolist()
+        L = capi.lib()
+        capi.check(L.jodo_plan_set_option(plan['handle'], 4, 2 if fl[4] else 1), 'jodo_plan_set_option')
+        capi.check(L.jodo_plan_set_option(plan['handle'], 5, 1 if fl[2] else 2), 'jodo_plan_set_option')
+        plan['pinned'] = True
 
     def invalidate_packed_weights(self):
         """Drop the packed kernel weights; the next forward re-packs from the current parameters.  Needed after

@@ -46,6 +46,14 @@ class _ModulePrefix(torch.nn.Module):
         return self.module(*args, **kwargs)
 
 
+def model_hook(model, name):
+    """Optional method `name` of a score network or of the module it wraps (DataParallel-style `.module`), else None."""
+    fn = getattr(model, name, None)
+    if fn is None:
+        fn = getattr(getattr(model, 'module', None), name, None)
+    return fn
+
+
 def create_model(config, wrap='dataparallel_keys'):
     model = _MODELS[config.model.name](config)
     model = model.to(config.device)

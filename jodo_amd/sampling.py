@@ -22,7 +22,7 @@ import torch
 from torch.nn import functional as F
 
 from .mix_dpm_solver import DPM_Solver_hybrid
-from .models.utils import (assert_mean_zero_with_mask, sample_combined_position_feature_noise,
+from .models.utils import (assert_mean_zero_with_mask, model_hook, sample_combined_position_feature_noise,
                            sample_symmetric_edge_feature_noise)
 from .utils import expand_dims, get_self_cond_fn
 
@@ -303,7 +303,7 @@ def _warn_nan(model):
     """The reference prints 'Warning: detected nan, resetting output to zero.' in every forward that hits the guard
     (mol_gnn.py:587-589).  The kernels keep a sticky device counter instead of a host sync per step; it is read once
     per round here (one .item())."""
-    take = getattr(model, 'take_nan_count', None) or getattr(getattr(model, 'module', None), 'take_nan_count', None)
+    take = model_hook(model, 'take_nan_count')
     if take is not None:
         n = take()
         if n:
@@ -370,6 +370,13 @@ class AncestralSampler:
             assert self.model_pred_data
             pred_t, edge_pred_t = model(vec_t, x, node_mask, edge_mask, edge_x=edge_x, noise_level=noise_level,
                                         cond_x=st['cond_x'], cond_edge_x=st['cond_edge_x'], context=context)
+            if i == 1 and x.is_cuda:
+                # first self-conditioned evaluation of the round: from here on the inputs keep their structure (symmetric
+                # state and predictions, one noise level per batch), so the HIP model may stop launching the kernel
+                # variants its device flags rule out (jodo_amd/models/dgt.py pin_paths; one host sync per round)
+                pin = model_hook(model, 'pin_paths')
+                if pin is not None:
+                    pin()
             st['cond_x'], st['cond_edge_x'] = self.cond_process_fn(pred_t, edge_pred_t)
         else:
             pred_t, edge_pred_t = model(vec_t, x, node_mask, edge_mask, edge_x=edge_x, noise_level=noise_level,

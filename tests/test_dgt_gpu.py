@@ -710,3 +710,45 @@ def test_medium_batches_cross_the_decomposition_boundaries(cfg_name, info, B, ov
     c = run(m_pair, xh[:k, :Ns], ex[:k, :Ns, :Ns], nl[:k], nm2, em2)
     close(c[0], a[0][:k, :Ns], atol=2e-5)
     close(c[1], a[1][:k, :Ns, :Ns], atol=2e-5)
+
+
+@pytest.mark.parametrize("cfg_name,n_nodes,uniform", [('vpsde_qm9_uncond_jodo', [6, 11, 20, 29, 1, 2] * 3, True),
+                                                      ('vpsde_qm9_uncond_jodo', [6, 11, 20, 29, 1, 2], False),
+                                                      ('vpsde_qm9_cond_jodo', [9, 9, 14, 27], True),
+                                                      ('vpsde_geom_uncond_jodo', [140, 33, 12], True)])       # n > 128: directed attention items stay
+def test_pinned_paths_equal_flag_dispatch(cfg_name, n_nodes, uniform):
+    """pin_paths() (what the samplers do after the first self-conditioned evaluation of a round) makes the launcher leave
+    out the kernel variants the device flags rule out; the variants that do run are the same kernels on the same inputs, so
+    outputs are bit-identical.  A call that breaks the pinned structure is reported, not silently mis-computed."""
+    cfg = make_config(cfg_name)
+    hp = O.Hyper.from_config(cfg)
+    model = make_model(cfg, 9, DEV, gain=1.3, coord_scale=0.05)
+    xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=5)
+    if uniform:
+        nl[:] = 0.4
+    d = lambda x: None if x is None else x.to(DEV)
+    nmd, emd = d(nm), d(em)
+
+    def call(cx=None, cex=None, edge=None):
+        with torch.no_grad():
+            o = model(d(nl), d(xh), nmd, emd, edge_x=d(ex if edge is None else edge), cond_x=d(cx), cond_edge_x=d(cex), noise_level=d(nl),
+                      context=d(ctx))
+        torch.cuda.synchronize()
+        return o[0].cpu(), o[1].cpu()
+
+    a1 = call()
+    a2 = call(a1[0], a1[1])
+    flags = model.last_flags.cpu().tolist()
+    assert flags[4] == 0 and flags[2] == (1 if uniform and not hp.cond_ch else 0)
+    model.pin_paths()
+    assert model._last_plan.get('pinned')
+    b2 = call(a1[0], a1[1])
+    b1 = call()
+    assert torch.equal(a1[0], b1[0]) and torch.equal(a1[1], b1[1]) and torch.equal(a2[0], b2[0]) and torch.equal(a2[1], b2[1])
+    assert model.take_nan_count() == 0
+    bad = ex.clone()
+    bad[0, 0, 1, 0] += 1.0                                   # asymmetric input under a symmetric pin
+    call(edge=bad)
+    with pytest.raises(RuntimeError, match="pinned"):
+        model.take_nan_count()
+    assert model.take_nan_count() == 0                       # cleared by the read
