@@ -228,6 +228,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay one captured HIP graph per step (jodo_amd/graphed.py)')
     ap.add_argument('--torch-noise', action='store_true',
                     help='per-step noise from three torch.randn launches (the reference RNG stream) instead of in-kernel Philox draws')
+    ap.add_argument('--streams', type=int, default=1, help='evaluate the batch as that many concurrent sub-batches on separate HIP streams')
     ap.add_argument('--no-pin', action='store_true', help='keep launching every kernel variant (device flags pick; experiments)')
     ap.add_argument('--plan-opt', action='append', default=[], help='jodo_plan_option=value (experiments), e.g. 3=0')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -281,6 +282,7 @@ def main():
     model.pair_chunk = args.pair_chunk
     model.spair_chunk = args.spair_chunk
     model.plan_options = {int(o.split('=')[0]): int(o.split('=')[1]) for o in args.plan_opt}
+    model.n_streams = args.streams
     if args.no_pin:
         model.pin_paths = lambda: None
     model.force_directed = bool(int(os.environ.get("JODO_FORCE_DIRECTED", "0")))   # debug: skip the symmetric pair kernels
@@ -312,7 +314,6 @@ def main():
             rnd.prepare(z, edge_z)
             for _ in range(max(args.warmup - 2, 0)):
                 rnd.replay()
-            plan = model._last_plan
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -331,8 +332,7 @@ def main():
             st = sampler.init_state(z, edge_z)
             for i in range(args.warmup):
                 st = sampler.step(model, i, st, node_mask, edge_mask, context)
-            plan = model._last_plan
-            capi.check(L.jodo_profile_enable(plan['handle'], 1 if args.breakdown else 2), 'profile_enable')
+            model.profile_enable(1 if args.breakdown else 2)
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -346,13 +346,11 @@ def main():
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
     # HIP-event timings of exactly the timed region above
-    ms = (ctypes.c_float * 8)()
-    cnt = (ctypes.c_int32 * 8)()
-    capi.check(L.jodo_profile_read(plan['handle'], ms, cnt), 'profile_read')
-    capi.check(L.jodo_profile_enable(plan['handle'], 0), 'profile_enable')
+    ms, cnt = model.profile_read()
+    model.profile_enable(0)
     flags_now = model.last_flags.cpu().tolist()
-    work = (ctypes.c_double * 8)()
-    capi.check(L.jodo_plan_work(plan['handle'], int(flags_now[2]), int(not flags_now[4]), work), 'plan_work')
+    work = model.work_model()
+    n_sub = len(model._last_plans)                  # sub-batches evaluated concurrently (--streams)
     graph_info = None
     if not args.graph and world == 1:
         # extra, reported beside the headline: the same step replayed as ONE captured HIP graph (no per-step
@@ -462,8 +460,8 @@ def main():
         per_class = {names[c]: (ms[c] / max(cnt[c], 1), cnt[c]) for c in range(8)}
         upd_ms, upd_n = per_class['edge_update']
         nblk = dims.L
-        mfma_launch = work[6] / nblk                              # executed MFMA flops of ONE pair-update launch (one block)
-        valu_launch = E * edge_update_vector_flops_per_directed_edge(dims)
+        mfma_launch = work[6] / (nblk * n_sub)                    # executed MFMA flops of ONE pair-update launch (one block, one sub-batch)
+        valu_launch = E * edge_update_vector_flops_per_directed_edge(dims) / n_sub
         exec_launch = mfma_launch + valu_launch
         achieved = exec_launch / (upd_ms * 1e-3) if upd_ms > 0 else 0.0
         exec_step = sum(work)                                    # executed MFMA flops of one forward, all kernels
@@ -480,6 +478,7 @@ def main():
                        'directed_edges_per_step': E, 'nodes_per_step': sum(n_nodes), 'max_n': N,
                        'weights': 'deterministic random init (trained checkpoints are external downloads)',
                        'step_noise': 'torch.randn x3 per step' if args.torch_noise else 'in-kernel Philox4x32-10 (jodo_sampler_step_rng)',
+                       'streams_per_gpu': n_sub,
                        'parallelism': 'batch shard x%d, no data-path collective' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'k_edge_update_sym' if not flags_now[4] else 'k_edge_update',
                          'achieved': achieved / 1e12, 'peak': PEAK_FP32_MFMA / 1e12,
@@ -494,8 +493,8 @@ def main():
                          'avg_launch_ms': upd_ms, 'launches': upd_n,
                          'executed_mfma_flops_per_launch': mfma_launch, 'executed_vector_flops_per_launch': valu_launch,
                          'mfma_frac': (mfma_launch / (upd_ms * 1e-3) / PEAK_FP32_MFMA) if upd_ms > 0 else 0.0,
-                         'reference_formulation_flops_per_launch': E * ref_upd_edge,
-                         'reference_formulation_ratio': (E * ref_upd_edge / (upd_ms * 1e-3) / PEAK_FP32_MFMA) if upd_ms > 0 else 0.0,
+                         'reference_formulation_flops_per_launch': E * ref_upd_edge / n_sub,
+                         'reference_formulation_ratio': (E * ref_upd_edge / n_sub / (upd_ms * 1e-3) / PEAK_FP32_MFMA) if upd_ms > 0 else 0.0,
                          'whole_step_executed_mfma_TFLOP': exec_step / 1e12,
                          'whole_step_TFLOPs': exec_step / step_s / 1e12,
                          'whole_step_frac': exec_step / step_s / PEAK_FP32_MFMA,

@@ -36,6 +36,45 @@ __device__ __forceinline__ float tanh_f(float x) {
     const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);     // e^{2x}
     return fmaf(-2.f, fast_rcp(1.f + e), 1.f);
 }
+// two at a time on the packed fp32 pipe: v_pk_mul, 2 x v_exp, v_pk_add, 2 x v_rcp, v_pk_fma (3 full-rate instructions per
+// PAIR instead of per value; hipcc packs only the final fma by itself)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 tanh_f2(f32x2 x) {
+    const f32x2 t = x * 2.8853900817779268f;
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+    e = e + 1.f;
+    f32x2 r;
+    r.x = fast_rcp(e.x); r.y = fast_rcp(e.y);
+    return __builtin_elementwise_fma(r, (f32x2)(-2.f), (f32x2)(1.f));
+}
+// in place on an accumulator block (16 values)
+__device__ __forceinline__ void tanh16(const f32x16& acc, float (&T)[16]) {
+#pragma unroll
+    for (int s = 0; s < 16; s += 2) {
+        f32x2 v; v.x = acc[s]; v.y = acc[s + 1];
+        v = tanh_f2(v);
+        T[s] = v.x; T[s + 1] = v.y;
+    }
+}
+__device__ __forceinline__ f32x2 silu_f2(f32x2 x) {             // x * rcp(1 + e^{-x}), pairs on the packed pipe
+    const f32x2 t = x * -1.4426950408889634f;
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+    e = e + 1.f;
+    f32x2 r;
+    r.x = fast_rcp(e.x); r.y = fast_rcp(e.y);
+    return x * r;
+}
+__device__ __forceinline__ f32x2 pk2(float a, float b) { f32x2 v; v.x = a; v.y = b; return v; }
+// hid = SiLU(acc + bias) for an accumulator block
+__device__ __forceinline__ void silu_bias16(const f32x16& acc, const float (&bb)[16], float* hid) {
+#pragma unroll
+    for (int s = 0; s < 16; s += 2) {
+        const f32x2 v = silu_f2(pk2(acc[s], acc[s + 1]) + pk2(bb[s], bb[s + 1]));
+        hid[s] = v.x; hid[s + 1] = v.y;
+    }
+}
 __device__ __forceinline__ float silu_f(float x) { return x * fast_rcp(1.f + fast_exp(-x)); }
 
 // Make a pointer opaque to the optimiser at this program point.  Used at the top of per-edge loops:
@@ -298,21 +337,34 @@ __device__ __forceinline__ void acc_bias(const f32x16& acc, const float* __restr
 }
 
 // ---- LayerNorm (no affine, eps 1e-6, biased variance) over NR*2 features of an item ----------------
+// (element pairs on the packed fp32 pipe: v_pk_add / v_pk_fma / v_pk_mul do two features per instruction.  Back-to-back
+// DEPENDENT packed ops pay a wait state each, so the two reductions run over four independent accumulator pairs)
 template <int NR>
 __device__ __forceinline__ void layer_norm(float (&x)[NR]) {
-    float s = 0.f;
+    static_assert(NR % 8 == 0, "feature registers come in groups of eight");
+    f32x2 a[4];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) s += x[i];
-    const float mean = pair_sum(s) * (1.f / (2 * NR));
-    float v = 0.f;
+    for (int k = 0; k < 4; ++k) a[k] = pk2(0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        x[i] -= mean;
-        v = fmaf(x[i], x[i], v);
-    }
-    const float rstd = __builtin_amdgcn_rsqf(pair_sum(v) * (1.f / (2 * NR)) + 1e-6f);
+    for (int i = 0; i < NR; i += 8)
 #pragma unroll
-    for (int i = 0; i < NR; ++i) x[i] *= rstd;
+        for (int k = 0; k < 4; ++k) a[k] = a[k] + pk2(x[i + 2 * k], x[i + 2 * k + 1]);
+    const f32x2 st = (a[0] + a[1]) + (a[2] + a[3]);
+    const float mean = pair_sum(st.x + st.y) * (1.f / (2 * NR));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = pk2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NR; i += 8)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x2 v = pk2(x[i + 2 * k], x[i + 2 * k + 1]) - mean;
+            a[k] = __builtin_elementwise_fma(v, v, a[k]);
+            x[i + 2 * k] = v.x; x[i + 2 * k + 1] = v.y;
+        }
+    const f32x2 qt = (a[0] + a[1]) + (a[2] + a[3]);
+    const float rstd = __builtin_amdgcn_rsqf(pair_sum(qt.x + qt.y) * (1.f / (2 * NR)) + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < NR; i += 2) { const f32x2 v = pk2(x[i], x[i + 1]) * rstd; x[i] = v.x; x[i + 1] = v.y; }
 }
 
 // x = x * (1 + scale) + shift with scale/shift vectors in natural order (NB blocks)
@@ -326,6 +378,9 @@ __device__ __forceinline__ void modulate(float (&x)[NB * 16], const float* __res
         load16(scale + b * 32 + half * 16, sc);
 #pragma unroll
         for (int s = 0; s < 16; ++s) x[b * 16 + s] = fmaf(x[b * 16 + s], 1.f + sc[s], sh[s]);
+        // (kept scalar on purpose: written with packed pairs hipcc sinks every 16-byte load of the modulation row down to its
+        // use and waits for it there — k_node_pre 0.116 -> 0.146 ms per launch at QM9 B = 1250 — while this form keeps a dozen
+        // loads in flight)
     }
 }
 

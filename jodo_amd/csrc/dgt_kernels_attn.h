@@ -66,6 +66,8 @@ struct AttnT {
     static constexpr bool PH = (D_ / 16 == 16) && !(D_ > 256);     // C = 16: a half-lane's registers belong to heads 2b + half only, so it
     static constexpr int NS = PH ? 8 : 16;                         // tracks 8 heads (slot k = head 2k + half) instead of all 16
     static constexpr bool PREF = !(D_ > 256);                      // request the next source's edge row one iteration ahead (D/8 registers)
+    static constexpr bool QK2 = false;   // q / k rows two blocks ahead in two register sets: measured SLOWER on MI355X (QM9 B = 2500: attention
+                                         // 3.91 -> 4.00 ms/step, 455 -> 490 registers) — the block's wait is issue, not row latency; kept as a switch
     static constexpr bool LDSS = D_ > 256;                         // running softmax state in LDS (registers are short at nf = 384:
                                                                    // D/2 accumulators + D/8 inputs per lane; LDS is free, no resident weights)
     static constexpr float INV_SQRT_C = D_ == 256 ? 0.25f : (D_ == 384 ? 0.20412414523193150f : 0.f);
@@ -86,9 +88,15 @@ __device__ __forceinline__ void gbf_n(float d2, float scale, float shift, const 
         load16(tab + De + b * 32 + half * 16, is);
         load16(tab + 2 * De + b * 32 + half * 16, cf);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float z = (x - mu[s]) * is[s];
-            g[b * 16 + s] = fast_exp(-0.5f * z * z) * cf[s];
+        for (int s = 0; s < 16; s += 2) {                 // pairs on the packed pipe; e^{-z^2/2} = 2^{-(log2 e / 2) z^2}
+            f32x2 m, i2, c, z;
+            m.x = mu[s]; m.y = mu[s + 1]; i2.x = is[s]; i2.y = is[s + 1]; c.x = cf[s]; c.y = cf[s + 1];
+            z = (x - m) * i2;
+            z = (z * -0.72134752044448170f) * z;
+            f32x2 e;
+            e.x = __builtin_amdgcn_exp2f(z.x); e.y = __builtin_amdgcn_exp2f(z.y);
+            e = e * c;
+            g[b * 16 + s] = e.x; g[b * 16 + s + 1] = e.y;
         }
     }
     if (half == 0) g[0] = x;
@@ -141,17 +149,19 @@ __device__ __forceinline__ void attn_edge_input(const KArgs& A, AttnW<X>& w, con
 // scores of one pair for both directions from T0 = tanh(lin_edge0 x): S1 = edge (j -> i), S2 = edge (i -> j); all 16
 // heads in every lane (heads 0, 1 = adjacency heads from the edge flags f1 / f2, 2.. = learned)
 // first q / k rows of a pair (block 0): requested by the caller ahead of the edge-input projections where registers allow
+// q / k rows of a pair, one register set per block in flight (X::QK2: two alternating sets, [0] even blocks, [1] odd)
+struct QKRows { float qi[16], ki[16], qj[16], kj[16]; };
 template <bool BOTH>
-__device__ __forceinline__ void attn_first_rows(const BRow& qi, const BRow& ki, const BRow& qj, const BRow& kj,
-                                                float (&qin)[16], float (&kin)[16], float (&qjn)[16], float (&kjn)[16]) {
-    bload16(qi, 0, qin); bload16(kj, 0, kjn);
-    if (BOTH) { bload16(qj, 0, qjn); bload16(ki, 0, kin); }
+__device__ __forceinline__ void attn_rows(const BRow& qi, const BRow& ki, const BRow& qj, const BRow& kj, int b, QKRows& r) {
+    bload16(qi, b, r.qi); bload16(kj, b, r.kj);
+    if (BOTH) { bload16(qj, b, r.qj); bload16(ki, b, r.ki); }
 }
 
 template <typename X, bool BOTH>
 __device__ __forceinline__ void attn_scores(AttnW<X>& w, const float (&x)[X::HE], const BRow& qi, const BRow& ki, const BRow& qj,
                                             const BRow& kj, int half, int f1, int f2, float (&S1)[16], float (&S2)[16],
-                                            float (&qin)[16], float (&kin)[16], float (&qjn)[16], float (&kjn)[16]) {
+                                            QKRows (&rows)[X::QK2 ? 2 : 1]) {
+    // rows[b & 1] (QK2) / rows[0] holds block b on entry to iteration b: blocks 0 (and 1) were requested by the caller
     constexpr int NM = X::WQK ? 14 : 7;                 // blocks reduced per head / per head pair
     float m1[X::WQK ? 1 : 7], m2[X::WQK ? 1 : 7];
     S1[0] = (f1 & 1) ? 1.f : -1e10f; S1[1] = (f1 & 2) ? 1.f : -1e10f;           // extra heads, 0 -> -1e10 (layers.py:170-174)
@@ -159,24 +169,36 @@ __device__ __forceinline__ void attn_scores(AttnW<X>& w, const float (&x)[X::HE]
 #pragma unroll
     for (int b = 0; b < NM; ++b) {
         float a1[16], a2[16];
+        QKRows& R = rows[X::QK2 ? (b & 1) : 0];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) { a1[s] = qin[s] * kjn[s]; a2[s] = BOTH ? qjn[s] * kin[s] : 0.f; }
-        auto next_rows = [&]() {
-            if (b + 1 < X::NQB) {
-                bload16(qi, b + 1, qin); bload16(kj, b + 1, kjn);
-                if (BOTH) { bload16(qj, b + 1, qjn); bload16(ki, b + 1, kin); }
-            }
+        for (int s = 0; s < 16; s += 2) {
+            const f32x2 p1 = pk2(R.qi[s], R.qi[s + 1]) * pk2(R.kj[s], R.kj[s + 1]);
+            a1[s] = p1.x; a1[s + 1] = p1.y;
+            if (BOTH) { const f32x2 p2 = pk2(R.qj[s], R.qj[s + 1]) * pk2(R.ki[s], R.ki[s + 1]); a2[s] = p2.x; a2[s + 1] = p2.y; }
+            else { a2[s] = 0.f; a2[s + 1] = 0.f; }
+        }
+        auto next_rows = [&]() {                       // the set just consumed takes the block two (one) ahead
+            constexpr int AHEAD = X::QK2 ? 2 : 1;
+            if (b + AHEAD < X::NQB) attn_rows<BOTH>(qi, ki, qj, kj, b + AHEAD, R);
         };
         if constexpr (X::LDS_L0) pipeline_fence();
         const unsigned cur = w.oL0 + (unsigned)(b * X::KQE) * 1024;
         f32x16 acc = attn_block<X, X::LDS_L0>(w, w.wL0 + (b * X::KQE) * 64, cur, b + 1 < X::NQB ? cur + X::KQE * 1024 : w.oL1, x, zero16(), next_rows);
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float tt = tanh_f(acc[s]);
-            s1 = fmaf(tt, a1[s], s1);
-            s2 = fmaf(tt, a2[s], s2);
+        float tt[16];
+        tanh16(acc, tt);
+        f32x2 s1a = {0.f, 0.f}, s1b = s1a, s2a = s1a, s2b = s1a;   // partial sums on the packed pipe, two chains per direction
+#pragma unroll                                              // (dependent packed ops back to back pay a wait state)
+        for (int s = 0; s < 16; s += 4) {
+            const f32x2 t2 = pk2(tt[s], tt[s + 1]), t3 = pk2(tt[s + 2], tt[s + 3]);
+            s1a = __builtin_elementwise_fma(t2, pk2(a1[s], a1[s + 1]), s1a);
+            s1b = __builtin_elementwise_fma(t3, pk2(a1[s + 2], a1[s + 3]), s1b);
+            if (BOTH) {
+                s2a = __builtin_elementwise_fma(t2, pk2(a2[s], a2[s + 1]), s2a);
+                s2b = __builtin_elementwise_fma(t3, pk2(a2[s + 2], a2[s + 3]), s2b);
+            }
         }
+        const f32x2 s1v = s1a + s1b, s2v = s2a + s2b;
+        const float s1 = s1v.x + s1v.y, s2 = s2v.x + s2v.y;
         if constexpr (X::WQK) {                        // head g = block g (padded rows are zero in q and k)
             S1[2 + b] = pair_sum(s1) * X::INV_SQRT_C;                          // / sqrt(out_channels = D / H), layers.py:167
             S2[2 + b] = BOTH ? pair_sum(s2) * X::INV_SQRT_C : 0.f;
@@ -191,8 +213,9 @@ __device__ __forceinline__ void attn_scores(AttnW<X>& w, const float (&x)[X::HE]
 #pragma unroll
         for (int g = 0; g < 14; ++g) {
             const float tt = tanh_f(acc[g]);
-            tl1[g] = tt * qin[g] * kjn[g];
-            tl2[g] = BOTH ? tt * qjn[g] * kin[g] : 0.f;
+            const QKRows& R = rows[X::QK2 ? ((X::NQB - 1) & 1) : 0];
+            tl1[g] = tt * R.qi[g] * R.kj[g];
+            tl2[g] = BOTH ? tt * R.qj[g] * R.ki[g] : 0.f;
         }
 #pragma unroll
         for (int g = 0; g < 14; ++g) {
@@ -319,21 +342,22 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
         // the first q / k rows of the pair travel behind the edge-input projections (8k cycles) where registers allow
         const BRow qi = brow(A.q, X::NQB, L.v, half), ki = brow(A.k, X::NQB, L.v, half);
         const BRow qj = brow(A.q, X::NQB, u, half), kj = brow(A.k, X::NQB, u, half);
-        float qin[16], kin[16], qjn[16], kjn[16];
-        if constexpr (PREF) attn_first_rows<PAIR>(qi, ki, qj, kj, qin, kin, qjn, kjn);
+        QKRows rows[X::QK2 ? 2 : 1];
+        if constexpr (PREF) attn_rows<PAIR>(qi, ki, qj, kj, 0, rows[0]);
         attn_edge_input<X>(A, w, e, dx * dx + dy * dy + dz * dz, gscale, gshift, mrow, half, x);
         APT(1);
         if constexpr (PREF) {
             cur = source(t + 1 < t1 ? t + 1 : t);      // next source: its row, position and flags are requested now
             request();
         } else {
-            attn_first_rows<PAIR>(qi, ki, qj, kj, qin, kin, qjn, kjn);
+            attn_rows<PAIR>(qi, ki, qj, kj, 0, rows[0]);
         }
+        if constexpr (X::QK2) attn_rows<PAIR>(qi, ki, qj, kj, 1, rows[1]);   // second set: requested behind the edge-input projections
         // ---- scores ----
         float Sa[X::NS], R[X::LDSS ? 1 : X::NS];           // scores of the own source / of the handed-over source per head slot
         {
             float S1[16], S2[16];
-            attn_scores<X, PAIR>(w, x, qi, ki, qj, kj, half, fl1, fl2, S1, S2, qin, kin, qjn, kjn);
+            attn_scores<X, PAIR>(w, x, qi, ki, qj, kj, half, fl1, fl2, S1, S2, rows);
             float Sb[X::NS];
 #pragma unroll
             for (int k = 0; k < X::NS; ++k) {
@@ -417,8 +441,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
             const unsigned cur = w.oL1 + (unsigned)(b * X::KQE) * 1024;
             f32x16 acc = mfma_block_p2<X::KQE>(w.wp, w.ws, cur, w.ws, b + 1 < X::ND ? cur + X::KQE * 1024 : ring0, x, zero16(), next_rows);
             float T[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) T[s] = tanh_f(acc[s]);
+            tanh16(acc, T);
             float sc_lo, sc_hi, p1_lo, p1_hi, p2_lo = 0.f, p2_hi = 0.f;
             if constexpr (X::LDSS) {
                 attn_pick_lds<X>(stc + 32 * 256, b, half, sc_lo, sc_hi);
@@ -435,13 +458,18 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
             if (PAIR) {                                 // this atom's unweighted message for the partner's accumulator
                 float4* ub = ux + (X::PHB == 1 ? (b & 1) : (b % X::PHB)) * 4 * 256;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    ub[q * 256 + slot] = make_float4(T[q * 4 + 0] * vo[q * 4 + 0], T[q * 4 + 1] * vo[q * 4 + 1],
-                                                     T[q * 4 + 2] * vo[q * 4 + 2], T[q * 4 + 3] * vo[q * 4 + 3]);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x2 u0 = pk2(T[q * 4 + 0], T[q * 4 + 1]) * pk2(vo[q * 4 + 0], vo[q * 4 + 1]);
+                    const f32x2 u1 = pk2(T[q * 4 + 2], T[q * 4 + 3]) * pk2(vo[q * 4 + 2], vo[q * 4 + 3]);
+                    ub[q * 256 + slot] = make_float4(u0.x, u0.y, u1.x, u1.y);
+                }
             }
 #pragma unroll
-            for (int s = 0; s < 16; ++s)                // own source
-                macc[b * 16 + s] = fmaf(macc[b * 16 + s], s < 8 ? sc_lo : sc_hi, (s < 8 ? p1_lo : p1_hi) * (T[s] * vv[s]));
+            for (int s = 0; s < 16; s += 2) {           // own source (element pairs on the packed pipe; a pair never straddles register 8)
+                const f32x2 m = pk2(T[s], T[s + 1]) * pk2(vv[s], vv[s + 1]) * (s < 8 ? p1_lo : p1_hi);
+                const f32x2 a = __builtin_elementwise_fma(pk2(macc[b * 16 + s], macc[b * 16 + s + 1]), (f32x2)(s < 8 ? sc_lo : sc_hi), m);
+                macc[b * 16 + s] = a.x; macc[b * 16 + s + 1] = a.y;
+            }
             if (PAIR && (b + 1) % X::PHB == 0) {        // end of a hand-over phase: the partners' messages of its blocks
                 __syncthreads();
 #pragma unroll
@@ -456,10 +484,11 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float4 r4 = ub[q * 256 + rslot];
-                        macc[bb * 16 + q * 4 + 0] = fmaf(q * 4 + 0 < 8 ? q_lo : q_hi, r4.x, macc[bb * 16 + q * 4 + 0]);
-                        macc[bb * 16 + q * 4 + 1] = fmaf(q * 4 + 1 < 8 ? q_lo : q_hi, r4.y, macc[bb * 16 + q * 4 + 1]);
-                        macc[bb * 16 + q * 4 + 2] = fmaf(q * 4 + 2 < 8 ? q_lo : q_hi, r4.z, macc[bb * 16 + q * 4 + 2]);
-                        macc[bb * 16 + q * 4 + 3] = fmaf(q * 4 + 3 < 8 ? q_lo : q_hi, r4.w, macc[bb * 16 + q * 4 + 3]);
+                        const f32x2 w2 = (f32x2)(q < 2 ? q_lo : q_hi);
+                        const f32x2 m0 = __builtin_elementwise_fma(w2, pk2(r4.x, r4.y), pk2(macc[bb * 16 + q * 4 + 0], macc[bb * 16 + q * 4 + 1]));
+                        const f32x2 m1 = __builtin_elementwise_fma(w2, pk2(r4.z, r4.w), pk2(macc[bb * 16 + q * 4 + 2], macc[bb * 16 + q * 4 + 3]));
+                        macc[bb * 16 + q * 4 + 0] = m0.x; macc[bb * 16 + q * 4 + 1] = m0.y;
+                        macc[bb * 16 + q * 4 + 2] = m1.x; macc[bb * 16 + q * 4 + 3] = m1.y;
                     }
                 }
             }

@@ -158,8 +158,7 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
                 float bb[16];
                 load16(b1 + (c * 2 + b2) * 32 + half * 16, bb);
                 f32x16 acc = mfma_block_p<32>(wp, ws, cur, nxt, hx, zero16());
-#pragma unroll
-                for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(acc[s] + bb[s]);
+                silu_bias16(acc, bb, hid + b2 * 16);
             }
 #pragma unroll
             for (int ob = 0; ob < 8; ++ob) {
@@ -306,8 +305,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_node_postw(KArgs A) {
                 float bb[16];
                 load16(b1 + (c * 2 + b2) * 32 + half * 16, bb);
                 f32x16 acc = mfma_block_p<32>(wp, ws, cur, nxt, hx, zero16());
-#pragma unroll
-                for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(acc[s] + bb[s]);
+                silu_bias16(acc, bb, hid + b2 * 16);
             }
 #pragma unroll
             for (int ob = 0; ob < 8; ++ob) {

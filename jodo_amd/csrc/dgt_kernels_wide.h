@@ -236,8 +236,7 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
                     float bb[16];
                     load16(b1 + (c * 2 + b2i) * 32 + half * 16, bb);
                     f32x16 acc = mfma_block_p<X::KQD>(wp, ws, cur, nxt, hx, zero16());
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) hid[b2i * 16 + s] = silu_f(acc[s] + bb[s]);
+                    silu_bias16(acc, bb, hid + b2i * 16);
                 }
 #pragma unroll
                 for (int ob = 0; ob < NOB; ++ob) {
@@ -447,8 +446,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
                     float bb[16];
                     load16(b3_ + (c * 2 + b2) * 32 + half * 16, bb);
                     f32x16 acc = mfma_block_p<X::KQE>(wp, ws, wcur, wnx, en, zero16());
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(acc[s] + bb[s]);
+                    silu_bias16(acc, bb, hid + b2 * 16);
                 }
 #pragma unroll
                 for (int ob = 0; ob < X::NE; ++ob) {
@@ -620,8 +618,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                     float bb[16];
                     load16(b3_ + (c * 2 + b2) * 32 + half * 16, bb);
                     f32x16 acc = mfma_block_p<X::KQE>(wp, ws, wcur, wnx, en, zero16());
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) hid[b2 * 16 + s] = silu_f(acc[s] + bb[s]);
+                    silu_bias16(acc, bb, hid + b2 * 16);
                 }
 #pragma unroll
                 for (int ob = 0; ob < X::NE; ++ob) {
@@ -682,7 +679,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             const float m01 = A.rmean[(size_t)P.u * 2] + A.rmean[(size_t)L.v * 2 + 1];          // direction 1: a = j, c = i
             float sg[FOLD ? 1 : X::HD];
             const WSrc wm = make_wsrc(A.mfold + (size_t)A.layer * D * 2 * X::De, lane);      // FOLD: W0 (1 + sc) W_in[e ; G]
-            float ssum = 0.f, q0 = 0.f, q1 = 0.f;
+            f32x2 ssum2 = {0.f, 0.f}, q02 = {0.f, 0.f}, q12 = {0.f, 0.f};
             float n0[16], n1[16], n2[16], n3[16];
             bload16(own_r, 0, n0); bload16(wcol_j, 0, n1); bload16(wrow_j, 0, n2); bload16(own_c, 0, n3);
 #pragma unroll
@@ -691,7 +688,10 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                 float g[16], t0[16], t1[16];
                 if constexpr (!FOLD) load16(qsc_ + b * 32 + half * 16, g);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) { t0[s] = (n0[s] + n1[s]) - m00; t1[s] = (n2[s] + n3[s]) - m01; }
+                for (int s = 0; s < 16; s += 2) {
+                    const f32x2 a = (pk2(n0[s], n0[s + 1]) + pk2(n1[s], n1[s + 1])) - m00, c = (pk2(n2[s], n2[s + 1]) + pk2(n3[s], n3[s + 1])) - m01;
+                    t0[s] = a.x; t0[s + 1] = a.y; t1[s] = c.x; t1[s + 1] = c.y;
+                }
                 // the next block's rows are requested behind the last weight prefetch of this block (see mfma_block_p2)
                 auto next_rows = [&]() {
                     if (b + 1 < X::ND) { bload16(own_r, b + 1, n0); bload16(wcol_j, b + 1, n1); bload16(wrow_j, b + 1, n2); bload16(own_c, b + 1, n3); }
@@ -704,29 +704,32 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                 else acc = mfma_block_p2<X::KQE>(wp, ws, wg_, ws, b + 1 < X::ND ? wg_ + X::KQE * 1024 : o0, G, acc, next_rows);
                 PT(3);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const float sv = acc[s];
-                    ssum += sv;
-                    if constexpr (!FOLD) sg[b * 16 + s] = sv * (1.f + g[s]);
-                    const float d0 = sv + t0[s], d1 = sv + t1[s];
-                    q0 = fmaf(d0, d0, q0);
-                    q1 = fmaf(d1, d1, q1);
+                for (int s = 0; s < 16; s += 2) {                // element pairs on the packed fp32 pipe
+                    const f32x2 sv = pk2(acc[s], acc[s + 1]);
+                    ssum2 = ssum2 + sv;
+                    if constexpr (!FOLD) { const f32x2 m = sv * (pk2(g[s], g[s + 1]) + 1.f); sg[b * 16 + s] = m.x; sg[b * 16 + s + 1] = m.y; }
+                    const f32x2 d0 = sv + pk2(t0[s], t0[s + 1]), d1 = sv + pk2(t1[s], t1[s + 1]);
+                    q02 = __builtin_elementwise_fma(d0, d0, q02);
+                    q12 = __builtin_elementwise_fma(d1, d1, q12);
                 }
                 PT(4);
             }
-            const float meanS = pair_sum(ssum) * (1.f / D);
-            const float rstd0 = __builtin_amdgcn_rsqf(fmaxf(pair_sum(q0) * (1.f / D) - meanS * meanS, 0.f) + 1e-6f);
-            const float rstd1 = __builtin_amdgcn_rsqf(fmaxf(pair_sum(q1) * (1.f / D) - meanS * meanS, 0.f) + 1e-6f);
+            const float meanS = pair_sum(ssum2.x + ssum2.y) * (1.f / D);
+            const float rstd0 = __builtin_amdgcn_rsqf(fmaxf(pair_sum(q02.x + q02.y) * (1.f / D) - meanS * meanS, 0.f) + 1e-6f);
+            const float rstd1 = __builtin_amdgcn_rsqf(fmaxf(pair_sum(q12.x + q12.y) * (1.f / D) - meanS * meanS, 0.f) + 1e-6f);
             const float mr0 = (meanS + m00) * rstd0, mr1 = (meanS + m01) * rstd1;
             PT(4);
             const float* wg_v = launder(mrow + X::M_WG);
             const float* bs_v = wg_v + D;
-            float c00 = 0.f, c01 = 0.f, c02 = 0.f, c10 = 0.f, c11 = 0.f, c12 = 0.f;
+            f32x2 c00 = {0.f, 0.f}, c01 = c00, c02 = c00, c10 = c00, c11 = c00, c12 = c00;
 #pragma unroll 1
             for (int b = 0; b < X::ND; ++b) {
                 float t0[16], t1[16], wgb[16], bsb[16];
 #pragma unroll
-                for (int s = 0; s < 16; ++s) { t0[s] = n0[s] + n1[s]; t1[s] = n2[s] + n3[s]; }
+                for (int s = 0; s < 16; s += 2) {
+                    const f32x2 a = pk2(n0[s], n0[s + 1]) + pk2(n1[s], n1[s + 1]), c = pk2(n2[s], n2[s + 1]) + pk2(n3[s], n3[s + 1]);
+                    t0[s] = a.x; t0[s + 1] = a.y; t1[s] = c.x; t1[s + 1] = c.y;
+                }
                 auto next_rows = [&]() {                         // next block's rows (the last iteration re-requests its own),
                     const int bn = b + 1 < X::ND ? b + 1 : b;    // behind the last weight prefetch of this block
                     bload16(ua_i, bn, n0); bload16(ub_j, bn, n1); bload16(ua_j, bn, n2); bload16(ub_i, bn, n3);
@@ -758,20 +761,34 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                     const int fo = b * 32 + half * 16 + hq * 8;
                     ld8(w2_ + fo, k0); ld8(w2_ + D + fo, k1); ld8(w2_ + 2 * D + fo, k2);
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) ca[s] = fmaf(-mr0, wgb[hq * 8 + s], bsb[hq * 8 + s]);
-                    pipeline_fence();
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-                        const float ys0 = silu_f(fmaf(z[hq * 8 + s] + t0[hq * 8 + s], rstd0, ca[s]));
-                        c00 = fmaf(ys0, k0[s], c00); c01 = fmaf(ys0, k1[s], c01); c02 = fmaf(ys0, k2[s], c02);
+                    for (int s = 0; s < 8; s += 2) {               // element pairs on the packed fp32 pipe; the three dot products
+                        const f32x2 w2_ = pk2(wgb[hq * 8 + s], wgb[hq * 8 + s + 1]), b2_ = pk2(bsb[hq * 8 + s], bsb[hq * 8 + s + 1]);   // keep even / odd partial sums
+                        const f32x2 c = __builtin_elementwise_fma((f32x2)(-mr0), w2_, b2_);
+                        ca[s] = c.x; ca[s + 1] = c.y;
                     }
                     pipeline_fence();
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) ca[s] = fmaf(-mr1, wgb[hq * 8 + s], bsb[hq * 8 + s]);
+                    for (int s = 0; s < 8; s += 2) {
+                        const f32x2 pre = pk2(z[hq * 8 + s], z[hq * 8 + s + 1]) + pk2(t0[hq * 8 + s], t0[hq * 8 + s + 1]);
+                        const f32x2 ys0 = silu_f2(__builtin_elementwise_fma(pre, (f32x2)(rstd0), pk2(ca[s], ca[s + 1])));
+                        c00 = __builtin_elementwise_fma(ys0, pk2(k0[s], k0[s + 1]), c00);
+                        c01 = __builtin_elementwise_fma(ys0, pk2(k1[s], k1[s + 1]), c01);
+                        c02 = __builtin_elementwise_fma(ys0, pk2(k2[s], k2[s + 1]), c02);
+                    }
+                    pipeline_fence();
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-                        const float ys1 = silu_f(fmaf(z[hq * 8 + s] + t1[hq * 8 + s], rstd1, ca[s]));
-                        c10 = fmaf(ys1, k0[s], c10); c11 = fmaf(ys1, k1[s], c11); c12 = fmaf(ys1, k2[s], c12);
+                    for (int s = 0; s < 8; s += 2) {
+                        const f32x2 w2_ = pk2(wgb[hq * 8 + s], wgb[hq * 8 + s + 1]), b2_ = pk2(bsb[hq * 8 + s], bsb[hq * 8 + s + 1]);
+                        const f32x2 c = __builtin_elementwise_fma((f32x2)(-mr1), w2_, b2_);
+                        ca[s] = c.x; ca[s + 1] = c.y;
+                    }
+#pragma unroll
+                    for (int s = 0; s < 8; s += 2) {
+                        const f32x2 pre = pk2(z[hq * 8 + s], z[hq * 8 + s + 1]) + pk2(t1[hq * 8 + s], t1[hq * 8 + s + 1]);
+                        const f32x2 ys1 = silu_f2(__builtin_elementwise_fma(pre, (f32x2)(rstd1), pk2(ca[s], ca[s + 1])));
+                        c10 = __builtin_elementwise_fma(ys1, pk2(k0[s], k0[s + 1]), c10);
+                        c11 = __builtin_elementwise_fma(ys1, pk2(k1[s], k1[s + 1]), c11);
+                        c12 = __builtin_elementwise_fma(ys1, pk2(k2[s], k2[s + 1]), c12);
                     }
                     pipeline_fence();
                 }
@@ -781,9 +798,9 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             const float nrm = fmaxf(sqrtf(d2), 1e-8f);
 #pragma unroll
             for (int dir = 0; dir < 2; ++dir) {
-                const float c0 = tanh_f(pair_sum(dir == 0 ? c00 : c10));
-                const float c1 = tanh_f(pair_sum(dir == 0 ? c01 : c11));
-                const float c2 = tanh_f(pair_sum(dir == 0 ? c02 : c12));
+                const float c0 = tanh_f(pair_sum(dir == 0 ? c00.x + c00.y : c10.x + c10.y));
+                const float c1 = tanh_f(pair_sum(dir == 0 ? c01.x + c01.y : c11.x + c11.y));
+                const float c2 = tanh_f(pair_sum(dir == 0 ? c02.x + c02.y : c12.x + c12.y));
                 const size_t rr = dir == 0 ? P.rij : P.rji;
                 const int fl = A.eflag[rr];
                 const float iota = (c0 + ((fl & 1) ? c1 : 0.f) + ((fl & 2) ? c2 : 0.f)) * (1.f / 3.f);

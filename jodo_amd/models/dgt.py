@@ -161,6 +161,8 @@ class _DGTBase(nn.Module):
         # ---- runtime state (not part of state_dict) ----
         self._packed = None           # (version_key, blob_dev, woff_host ctypes array)
         self._plans = {}              # plan cache keyed by the mask tensor identity
+        self._splits = {}             # sub-batch splits of n_streams > 1, keyed likewise
+        self.n_streams = 1            # > 1: sub-batches evaluated concurrently on that many HIP streams (_forward_split)
         self._cfg_struct = None
         self.register_load_state_dict_post_hook(_drop_packed_after_load)
         self.last_flags = None        # device int32[8] of the last call (NaN guard etc.)
@@ -249,7 +251,7 @@ class _DGTBase(nn.Module):
         stale = self._plans.pop(key, None)
         if stale is not None:
             L.jodo_plan_destroy(stale['handle'])
-        if len(self._plans) >= 4:                        # bounded cache
+        if len(self._plans) >= 8:                        # bounded cache
             old = self._plans.pop(next(iter(self._plans)))
             L.jodo_plan_destroy(old['handle'])
         self._plans[key] = plan
@@ -282,19 +284,86 @@ class _DGTBase(nn.Module):
         f32 = lambda x: None if x is None else x.detach().to(torch.float32).contiguous()
         xh_, ex_, cx_, cex_, nl_ = f32(xh), f32(edge_x), f32(cond_x), f32(cond_edge_x), f32(noise_level)
         ctx_ = f32(context) if self.conditional else None
+        streams = int(getattr(self, 'n_streams', 1))
+        if streams > 1 and B >= 2 * streams:
+            return self._forward_split(streams, node_mask, edge_mask, xh_, ex_, cx_, cex_, nl_, ctx_, dev)
         # plan first: building a plan for a new batch re-checks the weight fingerprint (`.data` updates such as the
         # reference's EMA copy_to / restore) and drops a stale blob BEFORE this call fetches it
         plan = self._plan(node_mask, edge_mask, dev)
         _, blob, woff_c, n_woff = self._weights(dev)
         out_x = torch.empty_like(xh_)
         out_e = torch.empty_like(ex_)
-        L = capi.lib()
-        capi.check(L.jodo_dgt_forward(plan['handle'], capi.ptr(plan['desc']), capi.ptr(blob), woff_c, n_woff,
-                                      capi.ptr(xh_), capi.ptr(ex_), capi.ptr(cx_), capi.ptr(cex_), capi.ptr(nl_),
-                                      capi.ptr(ctx_), capi.ptr(out_x), capi.ptr(out_e), capi.ptr(plan['flags']),
-                                      capi.ptr(plan['ws']), capi.current_stream_ptr()), 'jodo_dgt_forward')
+        self._launch(plan, blob, woff_c, n_woff, xh_, ex_, cx_, cex_, nl_, ctx_, out_x, out_e)
         self.last_flags = plan['flags']
         self._last_plan = plan
+        self._last_plans = [plan]
+        return out_x, out_e
+
+    def _launch(self, plan, blob, woff_c, n_woff, xh_, ex_, cx_, cex_, nl_, ctx_, out_x, out_e):
+        capi.check(capi.lib().jodo_dgt_forward(plan['handle'], capi.ptr(plan['desc']), capi.ptr(blob), woff_c, n_woff,
+                                               capi.ptr(xh_), capi.ptr(ex_), capi.ptr(cx_), capi.ptr(cex_), capi.ptr(nl_),
+                                               capi.ptr(ctx_), capi.ptr(out_x), capi.ptr(out_e), capi.ptr(plan['flags']),
+                                               capi.ptr(plan['ws']), capi.current_stream_ptr()), 'jodo_dgt_forward')
+
+    # -- stream-interleaved evaluation -----------------------------------------------------------
+    def _split_of(self, node_mask, edge_mask, k):
+        """Contiguous split of the batch into k sub-batches of about equal pair work (sum n^2), cached per mask tensor:
+        [(lo, hi, node_mask[lo:hi], edge_mask rows of lo..hi)] — the sub-mask tensors are kept so that their plans stay cached."""
+        key = (id(node_mask), k)
+        ent = self._splits.get(key)
+        if ent is not None and ent[0] is node_mask and ent[1] == node_mask._version:
+            return ent[2]
+        B, N = node_mask.shape[0], node_mask.shape[1]
+        n = node_mask.reshape(B, N).sum(1).round().long().cpu()                 # one sync per new batch
+        cum = torch.cumsum(n.double() ** 2, 0)
+        cuts = [0]
+        for j in range(1, k):
+            c = int(torch.searchsorted(cum, cum[-1] * j / k).item()) + 1
+            cuts.append(min(max(c, cuts[-1] + 1), B - (k - j)))
+        cuts.append(B)
+        em = edge_mask.reshape(B, N * N, -1)
+        parts = [(lo, hi, node_mask[lo:hi], em[lo:hi].reshape((hi - lo) * N * N, -1)) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        if len(self._splits) >= 4:
+            self._splits.pop(next(iter(self._splits)))
+        self._splits[key] = (node_mask, node_mask._version, parts)
+        return parts
+
+    def _forward_split(self, k, node_mask, edge_mask, xh_, ex_, cx_, cex_, nl_, ctx_, dev):
+        """n_streams = k > 1: the batch is cut into k contiguous sub-batches (molecules are independent) that are evaluated
+        concurrently, sub-batch j on HIP stream j (stream 0 = the caller's).  Every launch of this path is one wave per SIMD
+        with item counts that are not multiples of the chip (1409 node strips, 12 666 pair items at QM9 B = 2500), so a
+        single stream leaves the tail round of every launch partly idle and serialises the latency-bound prologue /
+        epilogue chains; with two streams the other sub-batch's workgroups fill those slots.  The C library still only ever
+        sees the stream it is handed; the side streams belong to this module, fork from and join the caller's stream (works
+        under HIP-graph capture).  Batch-global semantics of the reference: the NaN guard (mol_gnn.py:587-589) is applied
+        across sub-batches below; the first-step switch (:544) is decided per sub-batch (identical unless a whole
+        sub-batch's self-conditioning positions coincide — the same caveat as sharding over GPUs)."""
+        parts = self._split_of(node_mask, edge_mask, k)
+        plans = [self._plan(nm, em, dev) for _, _, nm, em in parts]
+        _, blob, woff_c, n_woff = self._weights(dev)
+        out_x = torch.empty_like(xh_)
+        out_e = torch.empty_like(ex_)
+        if getattr(self, '_side_streams', None) is None or len(self._side_streams) < k - 1:
+            self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(k - 1)]
+        cur = torch.cuda.current_stream()
+        cut = lambda t, lo, hi: None if t is None else t[lo:hi]
+        for j, ((lo, hi, _, _), plan) in enumerate(zip(parts, plans)):
+            args = (plan, blob, woff_c, n_woff, xh_[lo:hi], ex_[lo:hi], cut(cx_, lo, hi), cut(cex_, lo, hi), nl_[lo:hi],
+                    cut(ctx_, lo, hi), out_x[lo:hi], out_e[lo:hi])
+            if j == 0:
+                self._launch(*args)
+            else:
+                side = self._side_streams[j - 1]
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    self._launch(*args)
+        for side in self._side_streams[:k - 1]:
+            cur.wait_stream(side)
+        flags = torch.stack([p['flags'] for p in plans]).amax(0)
+        out_x[:, :, :3] *= (flags[0] == 0).to(out_x.dtype)           # NaN guard is batch-global: any sub-batch resets all positions
+        self.last_flags = flags
+        self._last_plan = plans[0]
+        self._last_plans = plans
         return out_x, out_e
 
     def take_nan_count(self):
@@ -319,14 +388,39 @@ class _DGTBase(nn.Module):
         instead of every variant + device-side early exits (24 idle dispatches per forward at 8 blocks).  For callers that
         know the inputs keep their structure — the samplers inside one round.  A violating call is detected on the
         device and reported by take_nan_count()."""
-        plan = getattr(self, '_last_plan', None)
-        if plan is None or plan.get('pinned'):
+        plans = [p for p in getattr(self, '_last_plans', []) if not p.get('pinned')]
+        if not plans:
             return
-        fl = plan['flags'].cpu().tolist()
+        fl = torch.stack([p['flags'] for p in plans]).cpu().tolist()
         L = capi.lib()
-        capi.check(L.jodo_plan_set_option(plan['handle'], 4, 2 if fl[4] else 1), 'jodo_plan_set_option')
-        capi.check(L.jodo_plan_set_option(plan['handle'], 5, 1 if fl[2] else 2), 'jodo_plan_set_option')
-        plan['pinned'] = True
+        for plan, f in zip(plans, fl):
+            capi.check(L.jodo_plan_set_option(plan['handle'], 4, 2 if f[4] else 1), 'jodo_plan_set_option')
+            capi.check(L.jodo_plan_set_option(plan['handle'], 5, 1 if f[2] else 2), 'jodo_plan_set_option')
+            plan['pinned'] = True
+
+    # -- measurement plumbing (bench.py): HIP-event class timers and the executed-work model of the last call's plan(s) --
+    def profile_enable(self, mode):
+        for p in self._last_plans:
+            capi.check(capi.lib().jodo_profile_enable(p['handle'], int(mode)), 'jodo_profile_enable')
+
+    def profile_read(self):
+        """Summed milliseconds and launch counts per class (8 each) since the last read, over the last call's plans."""
+        ms_t, cnt_t = [0.0] * 8, [0] * 8
+        for p in self._last_plans:
+            ms, cnt = (ctypes.c_float * 8)(), (ctypes.c_int32 * 8)()
+            capi.check(capi.lib().jodo_profile_read(p['handle'], ms, cnt), 'jodo_profile_read')
+            ms_t = [a + b for a, b in zip(ms_t, ms)]
+            cnt_t = [a + b for a, b in zip(cnt_t, cnt)]
+        return ms_t, cnt_t
+
+    def work_model(self):
+        """Executed MFMA flops per launch class of ONE evaluation like the last one (jodo_plan_work, summed over its plans)."""
+        tot = [0.0] * 8
+        for p, f in zip(self._last_plans, torch.stack([p['flags'] for p in self._last_plans]).cpu().tolist()):
+            w = (ctypes.c_double * 8)()
+            capi.check(capi.lib().jodo_plan_work(p['handle'], int(f[2]), int(not f[4]), w), 'jodo_plan_work')
+            tot = [a + b for a, b in zip(tot, w)]
+        return tot
 
     def invalidate_packed_weights(self):
         """Drop the packed kernel weights; the next forward re-packs from the current parameters.  Needed after
