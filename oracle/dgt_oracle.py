@@ -327,6 +327,7 @@ def forward_dense(p, hp, xh, node_mask, edge_mask, edge_x, cond_x=None, cond_edg
             ehat = n2e[:, None, :] + n2e[None, :, :] + p[bk + '.node2edge_lin.bias']
             hn = _ln(h + ng1 * hhat) * (1 + nc2) + ns2
             h = hn + ng2 * _lin(p, bk + '.ff_linear2', F.silu(_lin(p, bk + '.ff_linear1', hn)))
+            e_in = e
             en = _ln(e + eg1 * ehat) * (1 + ec2) + es2
             e = en + eg2 * _lin(p, bk + '.ff_linear4', F.silu(_lin(p, bk + '.ff_linear3', en)))
             W = p[bk + '.equi_update.input_lin.weight']
@@ -349,6 +350,8 @@ def forward_dense(p, hp, xh, node_mask, edge_mask, edge_x, cond_x=None, cond_edg
             if return_intermediates:
                 blocks.append(dict(h=h.clone(), e=e.clone(), pos=x.clone(), hhat=hhat.clone(),
                                    S=S.clone(), alpha=alpha.clone()))
+                if return_intermediates == 'graph':      # graph-attached tensors of phase D (oracle/train_ref.edge_ffn_phase)
+                    blocks[-1].update(e_in=e_in, ehat=ehat, e_out=e, eg1=eg1, es2=es2, ec2=ec2, eg2=eg2)
         ahc = torch.cat(ah, dim=-1)
         ehc = torch.cat(eh, dim=-1)
         atom = _mlp3(p, 'node_pred_mlp', ahc)

@@ -20,6 +20,8 @@ cond_DGT_concat with `jodo_amd.models.init_utils.deterministic_init_` (weights a
                                                every step's input state and the reference's prediction (teacher forcing)
   fwd_geom_l8.npz                              GEOM nf = 256 with n_layers = 8 (BASELINE configs[2] as worded), mlp_ratio 4
   traj_geom_anc3.npz                           3-step ancestral trajectory of the GEOM model (3 bond channels: aromatic decode)
+  grad_qm9.npz                                 the reference's own training loss + loss.backward() gradients of selected
+                                               parameters on a small batch (pins the oracle's autograd)
   traj_cond_dpm_multi8.npz / _single3.npz / _single1.npz
                                                hybrid DPM-solver: 2nd-order multistep (8 NFE), single-step order 3
                                                (6 NFE) and order 1 (3 NFE)
@@ -298,6 +300,99 @@ def dpm_fixture(ref, fname, nfe=4, n_nodes=(9, 5, 17, 12), seed=31, method='sing
     print(fname, 'ok; noise draws', len(rec))
 
 
+def grad_fixture(ref, fname, n_nodes=(5, 9, 7), seed=41):
+    """The reference's OWN training loss and loss.backward() (losses.py:286-385: get_sde_graph_loss_fn, self-conditioned
+    branch taken, eval mode so that dropout is the identity) on a small synthetic batch of the QM9 model.  Recorded: what the
+    reference fed to the grad-enabled model call, the targets it built (scaled data, Kabsch-aligned positions), its loss, and
+    its gradients of a few parameters spread over the network (edge FFN of two blocks, an attention projection, the
+    coordinate MLP, the embeddings, a head) — the pins of the oracle's autograd (oracle/train_ref.py)."""
+    import random as pyrandom
+    cfg, model = build_reference_model(ref, 'vpsde_qm9_uncond_jodo', seed)
+    L = ref.losses
+    ns = ref.diffusion.noise_schedule.NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0,
+                                                      continuous_beta_1=cfg.sde.continuous_beta_1)
+    scaler = ref.utils.get_data_scaler(cfg)
+    n_nodes = list(n_nodes)
+    B, N = len(n_nodes), max(n_nodes)
+    nm, em = masks(n_nodes)
+    g = torch.Generator().manual_seed(seed)
+    at = torch.randint(0, cfg.data.atom_types, (B, N), generator=g)
+    bond = torch.randint(0, 4, (B, N, N), generator=g)
+    bond = torch.triu(bond, 1); bond = bond + bond.transpose(1, 2)
+    e_exist = (bond > 0).float()
+    batch = dict(positions=torch.randn(B, N, 3, generator=g) * nm,
+                 atom_mask=nm[..., 0], edge_mask=em,
+                 atom_one_hot=torch.nn.functional.one_hot(at, cfg.data.atom_types).float() * nm,
+                 edge_one_hot=torch.stack([e_exist, bond.float() / 3.], -1) * em.reshape(B, N, N, 1),      # compress_edge: (exists, order / 3)
+                 formal_charges=(torch.randint(-1, 2, (B, N, 1), generator=g).float()) * nm)
+    loss_fn = L.get_sde_graph_loss_fn(ns, False, scaler, cfg)
+    rec = {}
+    inner = model.forward
+
+    def recording_forward(t, xh, node_mask, edge_mask, context=None, **kw):
+        if torch.is_grad_enabled():
+            rec.update(t=t.clone(), z_t=xh.clone(), edge_z_t=kw['edge_x'].clone(), noise_level=kw['noise_level'].clone(),
+                       cond_x=None if kw.get('cond_x') is None else kw['cond_x'].clone(),
+                       cond_edge_x=None if kw.get('cond_edge_x') is None else kw['cond_edge_x'].clone())
+        out = inner(t, xh, node_mask, edge_mask, context, **kw)
+        if torch.is_grad_enabled():
+            rec.update(pred=out[0].detach().clone(), edge_pred=out[1].detach().clone())
+        return out
+
+    model.forward = recording_forward
+    orig_align = L.get_align_position
+
+    def rec_align(z_t, xh):
+        a = orig_align(z_t, xh)
+        rec.update(align_pos=a.clone(), xh=xh.clone())
+        return a
+
+    L.get_align_position = rec_align
+    for tries in range(64):                                    # a python-random seed whose first draw takes the self-cond branch
+        pyrandom.seed(seed + tries)
+        if pyrandom.random() < 0.5:
+            pyrandom.seed(seed + tries)
+            break
+    torch.manual_seed(seed)
+    model.zero_grad()
+    try:
+        loss = loss_fn(model, batch)
+        loss.backward()
+    finally:
+        L.get_align_position = orig_align
+        del model.forward
+    assert rec['cond_x'] is not None
+    xh, edge_x, _, _, _ = L.process_edge_batch(batch, cfg.device, cfg.model.include_fc_charge, scaler, None)
+    assert torch.equal(xh, rec['xh'])
+    alpha_t, sigma_t = ns.marginal_prob(rec['t'])
+    names = ['e_block_0.ff_linear3.weight', 'e_block_0.ff_linear3.bias', 'e_block_0.ff_linear4.weight', 'e_block_0.ff_linear4.bias',
+             'e_block_5.ff_linear3.weight', 'e_block_5.ff_linear4.weight', 'e_block_5.ff_linear4.bias',
+             'e_block_3.attn_mpnn.lin_edge0.weight', 'e_block_2.node2edge_lin.weight', 'e_block_7.equi_update.coord_mlp.2.weight',
+             'e_block_4.equi_update.coord_norm.scale', 'e_block_6.edge_emb.weight', 'edge_emb.weight', 'node_emb.weight',
+             'edge_exist_mlp.4.weight', 'time_mlp.0.weights', 'e_block_5.dist_layer.means.weight']
+    params = dict(model.named_parameters())
+    # the oracle's autograd against the reference's, here and now (the committed fixture is checked again by the CPU suite)
+    from oracle import train_ref as T
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    hp = O.Hyper.from_config(cfg)
+    px, pe = O.forward_dense(sd, hp, rec['z_t'], nm, em, rec['edge_z_t'], rec['cond_x'], rec['cond_edge_x'], rec['noise_level'], None)
+    lw = [float(w) for w in cfg.model.loss_weights.split(',')]
+    ol = T.sde_graph_loss(px, pe, xh, edge_x, rec['align_pos'], nm, em, alpha_t, sigma_t, lw, cfg.training.reduce_mean)
+    ol.backward()
+    assert abs(ol.item() - loss.item()) < 1e-5 * abs(loss.item()), (ol.item(), loss.item())
+    for k in names:
+        a, b = sd[k].grad, params[k].grad
+        rel = (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+        assert rel < 2e-4, "oracle gradient of %s: rel err %g" % (k, rel)
+    np.savez_compressed(os.path.join(OUT, fname), cfg_name='vpsde_qm9_uncond_jodo', seed=seed, n_nodes=np.array(n_nodes),
+                        t=rec['t'].numpy(), z_t=rec['z_t'].numpy(), edge_z_t=rec['edge_z_t'].numpy(), noise_level=rec['noise_level'].numpy(),
+                        cond_x=rec['cond_x'].numpy(), cond_edge_x=rec['cond_edge_x'].numpy(), xh=xh.numpy(), edge_x=edge_x.numpy(),
+                        align_pos=rec['align_pos'].numpy(), alpha_t=alpha_t.numpy(), sigma_t=sigma_t.numpy(),
+                        pred=rec['pred'].numpy(), edge_pred=rec['edge_pred'].numpy(), loss=np.float64(loss.item()),
+                        grad_names=np.array(names), **{'grad_%d' % i: params[k].grad.numpy() for i, k in enumerate(names)})
+    print(fname, 'ok; loss', loss.item(), 'max |grad|', max(params[k].grad.abs().max().item() for k in names))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
@@ -311,6 +406,7 @@ def main():
         ('blocks_qm9.npz', lambda f: blocks_fixture(ref, 'vpsde_qm9_uncond_jodo', [3, 9, 17, 29], 17, f)),
         ('blocks_geom.npz', lambda f: blocks_fixture(ref, 'vpsde_geom_uncond_jodo', [12, 33], 18, f)),
         ('fwd_geom_l8.npz', lambda f: forward_fixture(ref, 'vpsde_geom_uncond_jodo', [7, 30, 52, 52, 75], 19, f, n_layers=8)),   # BASELINE configs[2] as worded: nf 256, 8 layers, r 4
+        ('grad_qm9.npz', lambda f: grad_fixture(ref, f)),
         ('traj_qm9_anc5.npz', lambda f: ancestral_fixture(ref, f)),
         # GEOM (3 bond channels: the aromatic decode branch of sampling.py:79-81), short
         ('traj_geom_anc3.npz', lambda f: ancestral_fixture(ref, f, steps=3, n_nodes=(14, 7, 22), seed=30, cfg_name='vpsde_geom_uncond_jodo')),

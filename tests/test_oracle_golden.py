@@ -169,3 +169,34 @@ def test_dense_and_faithful_agree_with_edge_cases():
     # padded rows / diagonal exactly zero, edge output exactly symmetric
     assert a[0][0, 1:].abs().max() == 0 and a[1][0].abs().max() == 0
     assert torch.equal(a[1], a[1].transpose(1, 2))
+
+
+def test_oracle_gradients_match_reference_backward():
+    """tests/golden/grad_qm9.npz holds the reference's own loss and loss.backward() gradients
+    (losses.py:286-385, self-conditioned branch).  Autograd through the dense oracle + the loss restatement must reproduce
+    them — that pins the checker of the backward kernels; and phase D as a function (oracle/train_ref.edge_ffn_phase) must
+    reproduce the oracle's own block outputs exactly."""
+    from oracle import train_ref as T
+    fx = load_fixture('grad_qm9.npz')
+    cfg = make_config(str(fx['cfg_name']))
+    model = make_model(cfg, int(fx['seed']))
+    hp = O.Hyper.from_config(cfg)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    nm, em = masks(fx['n_nodes'].tolist())
+    t = lambda k: torch.from_numpy(fx[k])
+    px, pe, inter = O.forward_dense(sd, hp, t('z_t'), nm, em, t('edge_z_t'), t('cond_x'), t('cond_edge_x'), t('noise_level'), None,
+                                    return_intermediates='graph')
+    assert (px.detach() - t('pred')).abs().max() < 2e-5 and (pe.detach() - t('edge_pred')).abs().max() < 2e-5
+    lw = [float(w) for w in cfg.model.loss_weights.split(',')]
+    loss = T.sde_graph_loss(px, pe, t('xh'), t('edge_x'), t('align_pos'), nm, em, t('alpha_t'), t('sigma_t'), lw, cfg.training.reduce_mean)
+    assert abs(loss.item() - float(fx['loss'])) < 1e-5 * float(fx['loss'])
+    loss.backward()
+    for i, k in enumerate(fx['grad_names'].tolist()):
+        want = t('grad_%d' % i)
+        rel = (sd[k].grad - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+        assert rel < 2e-4, "%s: %g" % (k, rel)
+    blk = inter[1][5]                                          # molecule 1 (n = 9), block 5
+    p5 = 'e_block_5.'
+    out = T.edge_ffn_phase(blk['e_in'], blk['ehat'], blk['eg1'], blk['es2'], blk['ec2'], blk['eg2'], sd[p5 + 'ff_linear3.weight'],
+                           sd[p5 + 'ff_linear3.bias'], sd[p5 + 'ff_linear4.weight'], sd[p5 + 'ff_linear4.bias'])
+    assert torch.equal(out, blk['e_out'])
