@@ -565,6 +565,17 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                                                             // modulation row keeps one per direction (S (1 + sc) does not fit)
     constexpr int PLB = D > 256 ? X::ND / 2 : 0;            // blocks parked in LDS
     __shared__ float4 pl[PLB > 0 ? PLB * 4 * 64 : 1];
+    // coord_mlp.2 (3 x D, the same for every item): read 16 times per pair offset by the tails right where it is needed; from
+    // global memory each read was an exposed L1 round trip between two MFMA blocks, from LDS it is a short ds_read
+    __shared__ float4 w2s[HOIST ? 3 * D / 4 : 1];
+    if constexpr (HOIST) {
+        const float4* src = reinterpret_cast<const float4*>(A.W + A.wb[JB_C2_W]);
+        for (int i = lane; i < 3 * D / 4; i += 64) w2s[i] = src[i];
+        __syncthreads();
+    }
+    // (Tried and dropped: the trunk's other item-invariant vectors — modulation chunks, biases, Gaussian table, 3 KiB — from an
+    // LDS page as well: pair update 6.18 -> 6.77 ms/step at QM9 B = 2500, 55.3 -> 58.3 at nf = 384.  Their global loads are
+    // requested far ahead and overlap; the ds_reads wait in order behind each other.)
     float park[HOIST ? 1 : (X::ND - PLB) * 16];
     PT_INIT
     for (int t = t0; t < t1; ++t) {
@@ -759,11 +770,12 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                         r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = c.x; r[5] = c.y; r[6] = c.z; r[7] = c.w;
                     };
                     const int fo = b * 32 + half * 16 + hq * 8;
-                    ld8(w2_ + fo, k0); ld8(w2_ + D + fo, k1); ld8(w2_ + 2 * D + fo, k2);
+                    const float* w2l = reinterpret_cast<const float*>(w2s);
+                    ld8(w2l + fo, k0); ld8(w2l + D + fo, k1); ld8(w2l + 2 * D + fo, k2);
 #pragma unroll
                     for (int s = 0; s < 8; s += 2) {               // element pairs on the packed fp32 pipe; the three dot products
-                        const f32x2 w2_ = pk2(wgb[hq * 8 + s], wgb[hq * 8 + s + 1]), b2_ = pk2(bsb[hq * 8 + s], bsb[hq * 8 + s + 1]);   // keep even / odd partial sums
-                        const f32x2 c = __builtin_elementwise_fma((f32x2)(-mr0), w2_, b2_);
+                        const f32x2 wg2 = pk2(wgb[hq * 8 + s], wgb[hq * 8 + s + 1]), bs2 = pk2(bsb[hq * 8 + s], bsb[hq * 8 + s + 1]);   // keep even / odd partial sums
+                        const f32x2 c = __builtin_elementwise_fma((f32x2)(-mr0), wg2, bs2);
                         ca[s] = c.x; ca[s + 1] = c.y;
                     }
                     pipeline_fence();
@@ -778,8 +790,8 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                     pipeline_fence();
 #pragma unroll
                     for (int s = 0; s < 8; s += 2) {
-                        const f32x2 w2_ = pk2(wgb[hq * 8 + s], wgb[hq * 8 + s + 1]), b2_ = pk2(bsb[hq * 8 + s], bsb[hq * 8 + s + 1]);
-                        const f32x2 c = __builtin_elementwise_fma((f32x2)(-mr1), w2_, b2_);
+                        const f32x2 wg2 = pk2(wgb[hq * 8 + s], wgb[hq * 8 + s + 1]), bs2 = pk2(bsb[hq * 8 + s], bsb[hq * 8 + s + 1]);
+                        const f32x2 c = __builtin_elementwise_fma((f32x2)(-mr1), wg2, bs2);
                         ca[s] = c.x; ca[s + 1] = c.y;
                     }
 #pragma unroll
