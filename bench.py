@@ -60,7 +60,7 @@ WORKLOADS = {
     # BASELINE configs[4]: 10 000 molecules over 8 GPUs.  get_sampling_fn(shard=...) deals the molecules to the ranks before
     # cutting rounds, so a GPU runs ONE round of 1250 (round 1 ran four rounds of 313: --batch 313 reproduces that)
     'cond': dict(cfg='vpsde_qm9_cond_jodo', info='qm9_second_half', batch=1250,
-                 name='QM9 cond JODO (cond_DGT_concat), ancestral steps, batch 1250 per GPU'),
+                 name='QM9 cond JODO (cond_DGT_concat nf=256 L=8), ancestral steps, batch 1250 per GPU'),
 }
 PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 SAMPLING_STEPS = 1000
@@ -177,7 +177,7 @@ def load_pmc_traffic(workload, batch, upd_ms):
     (None, None).  Counters cannot be collected from inside the process being profiled, hence the committed pass."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))):
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic*.json'))):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
