@@ -64,12 +64,17 @@ enum jodo_wslot_global {
     JW_EH1_W, JW_EH1_B, JW_EH2_W, JW_EH2_B, JW_EH3_W, JW_EH3_B,
     JW_GLOBAL_COUNT
 };
+/* The last six block slots hold the rotated LayerNorm statistics of equi_update (pair update under a shared modulation row;
+ * DESIGN.md 4a): with P the centring projection and Q the orthogonal factor of  Q (P W_in[:, e ; G]) = [L ; 0]:
+ * ROWQ = Q P W_row, COLQ = Q P W_col, INQ_B = Q P b, LQ = L (block upper triangular, K = 2 De), INEC = P W_in[:, e ; G],
+ * QT = Q^T packed as a D x D projection (right-hand factor of the per-forward fold W0 diag(1 + sc) Q^T). */
 enum jodo_wslot_block {
     JB_WQ = 0, JB_BQ, JB_WK, JB_BK, JB_WV, JB_BV,
     JB_EE_W, JB_EE_B, JB_LE0_W, JB_LE1_W, JB_N2E_W, JB_N2E_B,
     JB_FF1_W, JB_FF1_B, JB_FF2_W, JB_FF2_B, JB_FF3_W, JB_FF3_B, JB_FF4_W, JB_FF4_B,
     JB_INE_W, JB_ROW_W, JB_COL_W, JB_IN_B, JB_C0_W, JB_C0_B, JB_C2_W, JB_CSCALE,
     JB_NRO_W, JB_NRO_B, JB_ERO_W, JB_ERO_B, JB_GBF,
+    JB_ROWQ_W, JB_COLQ_W, JB_INQ_B, JB_LQ_W, JB_INEC_W, JB_QT_W,
     JB_BLOCK_COUNT
 };
 /* table length = JW_GLOBAL_COUNT + n_layers * JB_BLOCK_COUNT; block l slot s lives at
@@ -166,6 +171,9 @@ enum jodo_plan_option {
     JODO_OPT_PIN_SYMMETRIC = 4,   /* 0 (default): decided per call on the device; 1: inputs are symmetric (pair kernels only);
                                      2: asymmetric (directed kernels only) */
     JODO_OPT_PIN_UNIFORM_T = 5,   /* 0 (default): per call; 1: one shared modulation row (folded pair update only); 2: per-molecule rows */
+    JODO_OPT_ROT_STATS = 6,       /* 1 (default): under a shared modulation row and symmetric inputs the LayerNorm statistics of
+                                     equi_update are taken in the rotated basis (Q P W_row h, Q P W_col h per node, the triangular
+                                     L [e ; G] per pair, a per-molecule Gram tile for the rest); 0: from S = W_in [e ; G] itself */
     JODO_OPT_COUNT
 };
 int jodo_plan_set_option(jodo_plan* plan, int option, int value);

@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 
 namespace jd {
 
@@ -327,6 +328,52 @@ __device__ __forceinline__ f32x16 mfma_block_p2(WPipe<PG>& p, const WSrc& w, uns
     }
     return acc;
 }
+
+// General form: the block has KQ quads of which the ring holds the first min(PG, KQ); the rest is prefetched in groups of up to PG
+// (KQ need not be a multiple of PG), and the last group prefetches NXT (<= PG) quads of the NEXT block (other buffer wn) — what the
+// next consumer expects to find in the ring.  Used by the block-upper-triangular projection of the rotated statistics, whose
+// blocks shrink by four quads each.  act points at KQ * 4 activation registers.
+template <int KQ, int NXT, int PG, typename After = NoHook>
+__device__ __forceinline__ f32x16 mfma_block_g(WPipe<PG>& p, const WSrc& w, unsigned cur_off, const WSrc& wn, unsigned next_off,
+                                               const float* act, f32x16 acc, After&& after = NoHook()) {
+    static_assert(NXT <= PG && KQ > 0, "prefetch group");
+    constexpr int NG = (KQ + PG - 1) / PG;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int ng = KQ - g * PG < PG ? KQ - g * PG : PG;
+        float4 cur[PG];
+#pragma unroll
+        for (int i = 0; i < PG; ++i) if (i < ng) cur[i] = p.q[i];
+        if (g + 1 < NG) {
+            const int nn = KQ - (g + 1) * PG < PG ? KQ - (g + 1) * PG : PG;
+#pragma unroll
+            for (int i = 0; i < PG; ++i) if (i < nn) p.q[i] = wload(w, cur_off, (g + 1) * PG + i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NXT; ++i) p.q[i] = wload(wn, next_off, i);
+            after();
+        }
+        pipeline_fence();
+#pragma unroll
+        for (int i = 0; i < PG; ++i) {
+            if (i < ng) {
+                const int k = (g * PG + i) * 4;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i].x, act[k + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i].y, act[k + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i].z, act[k + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i].w, act[k + 3], acc, 0, 0, 0);
+            }
+        }
+        pipeline_fence();
+    }
+    return acc;
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // accumulator (+ bias in slot order) -> registers [16]
 __device__ __forceinline__ void acc_bias(const f32x16& acc, const float* __restrict__ bias16, float (&r)[16]) {

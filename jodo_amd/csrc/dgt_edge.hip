@@ -22,7 +22,9 @@ int launch_update_sym(jodo_plan* p, hipStream_t st, KArgs& A) {
     const bool run_plain = p->opt[JODO_OPT_PIN_UNIFORM_T] != 1, run_fold = p->opt[JODO_OPT_PIN_UNIFORM_T] != 2 && d.cond_ch == 0;
     if (run_plain && n1 > 0) { if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2>), n1, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4>), n1, 64, A); }
     // shared modulation row (device flag): the variant with the folded coord_mlp.0 does the work instead (never split)
-    if (run_fold) { if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2, true>), p->n_pitems, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4, true>), p->n_pitems, 64, A); }
+    // (A.rot: LayerNorm statistics in the rotated basis the node kernels of this forward wrote — decided by the launcher, not a flag)
+    if (run_fold && A.rot) { if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2, true, true>), p->n_pitems, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4, true, true>), p->n_pitems, 64, A); }
+    if (run_fold && !A.rot) { if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2, true>), p->n_pitems, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4, true>), p->n_pitems, 64, A); }
     if (run_plain && split) {
         A.item0 = full; A.dir_split = 1;
         if (d.r == 2) LAUNCH((wide::k_edge_update_sym<D, 2>), 2 * rem, 64, A); else LAUNCH((wide::k_edge_update_sym<D, 4>), 2 * rem, 64, A);

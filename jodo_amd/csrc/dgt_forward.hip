@@ -31,6 +31,7 @@ PlanDev make_plan_dev(const jodo_plan* p, const void* desc_dev) {
     d.Nn = p->Nn; d.Nn_pad = p->Nn_pad; d.n_strips = p->n_strips; d.n_items = p->n_items; d.B = p->B; d.N = p->N;
     d.max_parts = p->max_parts; d.rows = p->rows;
     d.ut_rows = base + p->off_ut_rows; d.n_ut_pad = p->n_ut_pad;
+    d.gt_sa = base + p->off_gt_sa; d.gt_sc = base + p->off_gt_sc; d.n_gtiles = p->n_gtiles;
     return d;
 }
 
@@ -45,12 +46,12 @@ void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
     A.h = ws_ptr<float>(ws, w.h); A.hhat = ws_ptr<float>(ws, w.hhat); A.astat = ws_ptr<float>(ws, w.astat); A.q = ws_ptr<float>(ws, w.q);
     A.k = ws_ptr<float>(ws, w.k); A.v = ws_ptr<float>(ws, w.v); A.n2e = ws_ptr<float>(ws, w.n2e);
     A.wrow = ws_ptr<float>(ws, w.wrow); A.wcol = ws_ptr<float>(ws, w.wcol); A.ua = ws_ptr<float>(ws, w.ua); A.ub = ws_ptr<float>(ws, w.ub);
-    A.rmean = ws_ptr<float>(ws, w.rmean); A.mfold = ws_ptr<float>(ws, w.mfold); A.ahid = ws_ptr<float>(ws, w.ahid);
+    A.rmean = ws_ptr<float>(ws, w.rmean); A.mfold = ws_ptr<float>(ws, w.mfold); A.ffold = ws_ptr<float>(ws, w.ffold); A.ahid = ws_ptr<float>(ws, w.ahid);
     A.apred = ws_ptr<float>(ws, w.apred);
     A.eflag = ws_ptr<int>(ws, w.eflag); A.e = ws_ptr<float>(ws, w.e);
     A.ehid = ws_ptr<float>(ws, w.ehid); A.epred = ws_ptr<float>(ws, w.epred);
     A.e_out = ws_ptr<float>(ws, w.e2);
-    A.dposE = ws_ptr<float>(ws, w.dposE);
+    A.dposE = ws_ptr<float>(ws, w.dposE); A.gramE = ws_ptr<float>(ws, w.gramE);
 }
 
 int rowgemm(hipStream_t st, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* Wp, const float* bias,
@@ -142,14 +143,22 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
     if (rc) return rc;
     if (p->n_items > 0) LAUNCH((wide::k_embed_edges<D>), p->n_items, 64, A);
     const bool pin_pair = p->opt[JODO_OPT_PIN_SYMMETRIC] == 1, pin_dir = p->opt[JODO_OPT_PIN_SYMMETRIC] == 2 || p->force_directed;
-    if (p->n_pitems > 0 && !pin_dir && p->opt[JODO_OPT_PIN_UNIFORM_T] != 2 && d.cond_ch == 0) {   // folded coord_mlp.0 of every block (pair update, shared modulation row)
+    // shared modulation row + symmetric inputs (device flags; both can be pinned): folded coord_mlp.0 of every block, and with
+    // JODO_OPT_ROT_STATS the LayerNorm statistics of equi_update in the rotated basis (A.rot tells the node kernels and k_node_ab)
+    const bool can_fold = p->n_pitems > 0 && !pin_dir && p->opt[JODO_OPT_PIN_UNIFORM_T] != 2 && d.cond_ch == 0;
+    A.rot = (can_fold && p->opt[JODO_OPT_ROT_STATS] != 0) ? 1 : 0;
+    if (can_fold) {
         if (d.L > 16) return jodo_set_error(JODO_ERR_UNSUPPORTED, "more than 16 blocks");
         FoldOffs F;
         for (int l = 0; l < 16; ++l) {
             F.c0[l] = l < d.L ? woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + JB_C0_W] : 0;
-            F.ine[l] = l < d.L ? woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + JB_INE_W] : 0;
+            F.ine[l] = l < d.L ? woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + (A.rot ? JB_INEC_W : JB_INE_W)] : 0;     // rot: centred factor
         }
-        LAUNCH((wide::k_fold_coord<D>), d.L * (D / 32) * (d.De / 4), 64, A, F);
+        LAUNCH((wide::k_fold_coord<D, D / 16>), d.L * (D / 32) * (d.De / 4), 64, A, F, A.mfold, 0);
+        if (A.rot) {                               // F_l = W0 diag(1 + sc_l) Q_l^T: what k_node_ab applies to the rotated rows
+            for (int l = 0; l < d.L; ++l) F.ine[l] = woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + JB_QT_W];
+            LAUNCH((wide::k_fold_coord<D, D / 8>), d.L * (D / 32) * (D / 8), 64, A, F, A.ffold, 1);
+        }
     }
     pro.reset();
     // ---- DGT blocks ----
@@ -208,6 +217,7 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
             }
             // per-node part of coord_mlp.0 pushed through the LayerNorm (pair update at nf = 256, dgt_kernels_wide.h)
             if (p->n_pitems > 0 && !pin_dir) LAUNCH((wide::k_node_ab<D>), p->n_strips * 2, 64, A);
+            if (A.rot && p->n_gtiles > 0) LAUNCH((wide::k_node_gram<D>), p->n_gtiles, 64, A);
         }
         if (p->n_items > 0) {
             ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);          // exactly one of the two does the work (device flag)
@@ -271,7 +281,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     for (int i = 0; i < JW_GLOBAL_COUNT; ++i) A.wg[i] = woff[i];
     for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = 0;
     A.mod_base = 0; A.layer = 0; A.force_directed = p->force_directed; A.pin_sym = p->force_directed ? 0 : p->opt[JODO_OPT_PIN_SYMMETRIC];
-    A.pin_uni = p->opt[JODO_OPT_PIN_UNIFORM_T]; A.pre_mode = 0; A.strip0 = 0; A.item0 = 0; A.dir_split = 0; A.fuse_next = 0; A.mod_base_next = 0;
+    A.pin_uni = p->opt[JODO_OPT_PIN_UNIFORM_T]; A.pre_mode = 0; A.strip0 = 0; A.item0 = 0; A.dir_split = 0; A.rot = 0; A.fuse_next = 0; A.mod_base_next = 0;
     for (int i = 0; i < 6; ++i) A.wbn[i] = 0;
     fill_ws(A, p, workspace);
     float* posbuf[2] = {ws_ptr<float>(workspace, p->ws.pos0), ws_ptr<float>(workspace, p->ws.pos1)};

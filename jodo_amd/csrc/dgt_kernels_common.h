@@ -18,6 +18,8 @@ struct KArgs {
     int pin_sym, pin_uni;                 // JODO_OPT_PIN_*: variants the launcher left out (checked against the device flags in k_finalize_nodes)
     int strip0;                           // k_node_post*: first strip of this launch (a layer's strips may be split over two launches)
     int item0, dir_split;                 // pair update: first item of this launch; 1 = two workgroups per item, one direction each
+    int rot;                              // JODO_OPT_ROT_STATS and a launch sequence that can use it: under FLAG_UNIFORM_T && !FLAG_ASYM the node
+                                          // kernels write Q P (W_row h + b), Q P W_col h and the pair update takes its LayerNorm statistics from them
     // k_node_post*: when fuse_next != 0 the kernel also produces the NEXT block's q / k / v (LN1 + modulate of the
     // h it has just computed), with the next block's weights (wbn = its WQ, BQ, WK, BK, WV, BV slots) and modulation
     int fuse_next;
@@ -26,9 +28,9 @@ struct KArgs {
     int pre_mode;                         // k_node_pre: 0 = also advance the positions, 1 = q/k/v only (k_pos_final did it)
     // workspace
     float *hid1, *temb, *mods, *condh, *condh2;
-    float *pos_in, *pos_out, *dpos, *cpos, *feat, *h, *hhat, *astat, *q, *k, *v, *n2e, *wrow, *wcol, *ua, *ub, *rmean, *mfold, *ahid, *apred;
+    float *pos_in, *pos_out, *dpos, *cpos, *feat, *h, *hhat, *astat, *q, *k, *v, *n2e, *wrow, *wcol, *ua, *ub, *rmean, *mfold, *ffold, *ahid, *apred;
     int* eflag;
-    float *e, *ehid, *epred, *dposE;
+    float *e, *ehid, *epred, *dposE, *gramE;
     float* e_out;                         // edge state written by the update kernels (ping-pong with e: never in place,
                                           // two workgroups of a direction-split item read the same input rows)
     int* flags;
@@ -39,7 +41,12 @@ struct KArgs {
 };
 
 // k_fold_coord: per-layer slot offsets of coord_mlp.0 and of the [e ; G] part of input_lin (one launch covers every block)
-struct FoldOffs { int64_t c0[16], ine[16]; };
+struct FoldOffs { int64_t c0[16], ine[16]; };      // ine: the right-hand factor of the launch ([e ; G] part of input_lin, its centred copy, or Q^T)
+
+namespace jd {
+// the rotated-statistics path is taken by a call iff the launcher allows it and the call has a shared modulation row and symmetric inputs
+__device__ __forceinline__ bool rot_active(const KArgs& A) { return A.rot && A.flags[FLAG_UNIFORM_T] && !A.flags[FLAG_ASYM]; }
+}
 
 namespace jd {
 

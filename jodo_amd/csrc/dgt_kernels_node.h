@@ -125,7 +125,8 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
     const float* ng2 = mr + 5 * 256;
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned oN2E = (unsigned)(A.wb[JB_N2E_W] * 4), oF1 = (unsigned)(A.wb[JB_FF1_W] * 4), oF2 = (unsigned)(A.wb[JB_FF2_W] * 4);
-    const unsigned oRow = (unsigned)(A.wb[JB_ROW_W] * 4), oCol = (unsigned)(A.wb[JB_COL_W] * 4), oNro = (unsigned)(A.wb[JB_NRO_W] * 4);
+    const bool rot = rot_active(A);                           // rotated statistics: Q P (W_row h + b), Q P W_col h instead (dgt_pack.cpp rot_stats)
+    const unsigned oRow = (unsigned)(A.wb[rot ? JB_ROWQ_W : JB_ROW_W] * 4), oCol = (unsigned)(A.wb[rot ? JB_COLQ_W : JB_COL_W] * 4), oNro = (unsigned)(A.wb[JB_NRO_W] * 4);
     WPipe<8> wp;
     wpipe_prime(wp, ws, oN2E);
     float hx[128];                                            // first the messages, then (in place) the FFN input
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
     store_nat<8>(A.h + (size_t)L.v * 256, half, hx);
     // per-node halves of equi_update.input_lin: W_row h (+ bias), W_col h
     {
-        const float* bin = A.W + A.wb[JB_IN_B];
+        const float* bin = A.W + A.wb[rot ? JB_INQ_B : JB_IN_B];
 #pragma unroll 1
         for (int b = 0; b < 8; ++b) {
             const unsigned cr = oRow + (unsigned)b * 32 * 1024, cc = oCol + (unsigned)b * 32 * 1024;
@@ -267,7 +268,8 @@ __global__ __launch_bounds__(NW * 64, 1) void k_node_postw(KArgs A) {
     const float* ng2 = mr + 5 * 256;
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned oN2E = (unsigned)(A.wb[JB_N2E_W] * 4), oF1 = (unsigned)(A.wb[JB_FF1_W] * 4), oF2 = (unsigned)(A.wb[JB_FF2_W] * 4);
-    const unsigned oRow = (unsigned)(A.wb[JB_ROW_W] * 4), oCol = (unsigned)(A.wb[JB_COL_W] * 4), oNro = (unsigned)(A.wb[JB_NRO_W] * 4);
+    const bool rot = rot_active(A);                           // rotated statistics: Q P (W_row h + b), Q P W_col h instead (dgt_pack.cpp rot_stats)
+    const unsigned oRow = (unsigned)(A.wb[rot ? JB_ROWQ_W : JB_ROW_W] * 4), oCol = (unsigned)(A.wb[rot ? JB_COLQ_W : JB_COL_W] * 4), oNro = (unsigned)(A.wb[JB_NRO_W] * 4);
     constexpr int NCH = R * 4, CPW = NCH / NW;                // hidden chunks of 64, chunks per wave
     constexpr int KQ2 = R * 256 / 8;
     constexpr int PER = 16 / NW;                              // W_row / W_col blocks per wave in the last phase
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_node_postw(KArgs A) {
             hx[b * 16 + q * 4 + 0] = v.x; hx[b * 16 + q * 4 + 1] = v.y; hx[b * 16 + q * 4 + 2] = v.z; hx[b * 16 + q * 4 + 3] = v.w;
         }
     {   // this wave's share of the 16 W_row / W_col blocks; the W_col waves then take the readout blocks
-        const float* bin = A.W + A.wb[JB_IN_B];
+        const float* bin = A.W + A.wb[rot ? JB_INQ_B : JB_IN_B];
         float* dst = is_row ? A.wrow : A.wcol;
         const int ro0 = (wave % ROW_WAVES) * NRO_PER;         // first readout block of this (W_col) wave
         const unsigned oAfter = is_row ? oLast : oNro + (unsigned)ro0 * 32 * 1024;

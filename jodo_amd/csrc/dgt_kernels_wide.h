@@ -186,7 +186,8 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
     const float* ng1 = mr + 2 * D, *ns2 = mr + 3 * D, *nc2 = mr + 4 * D, *ng2 = mr + 5 * D;
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned oN2E = (unsigned)(A.wb[JB_N2E_W] * 4), oF1 = (unsigned)(A.wb[JB_FF1_W] * 4), oF2 = (unsigned)(A.wb[JB_FF2_W] * 4);
-    const unsigned oRow = (unsigned)(A.wb[JB_ROW_W] * 4), oCol = (unsigned)(A.wb[JB_COL_W] * 4), oNro = (unsigned)(A.wb[JB_NRO_W] * 4);
+    const bool rot = rot_active(A);                        // rotated statistics: Q P (W_row h + b), Q P W_col h instead (dgt_pack.cpp rot_stats)
+    const unsigned oRow = (unsigned)(A.wb[rot ? JB_ROWQ_W : JB_ROW_W] * 4), oCol = (unsigned)(A.wb[rot ? JB_COLQ_W : JB_COL_W] * 4), oNro = (unsigned)(A.wb[JB_NRO_W] * 4);
     WPipe<X::PG> wp;
     wpipe_prime(wp, ws, oN2E);
     float hx[X::HD];
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
         load_nat<X::ND>(hrow, half, hx);                                  // hx = h_out from here on
     }
     {   // per-node halves of equi_update.input_lin: W_row h (+ bias), W_col h
-        const float* bin = A.W + A.wb[JB_IN_B];
+        const float* bin = A.W + A.wb[rot ? JB_INQ_B : JB_IN_B];
 #pragma unroll 1
         for (int b = 0; b < X::ND; ++b) {
             const unsigned cr = oRow + (unsigned)b * X::KQD * 1024, cc = oCol + (unsigned)b * X::KQD * 1024;
@@ -295,6 +296,9 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
 // coord_mlp.0 pushed through the LayerNorm of equi_update, per-node part (see k_edge_update_sym): piece 0: A = W0 (R (1 + sc)),
 // R = W_row h + b (A.wrow); piece 1: B = W0 (C (1 + sc)), C = W_col h (A.wcol); also the feature means of R and C, which
 // add up to the LayerNorm mean of a directed edge.  One (strip, piece) item per wave: 2 x n_strips items.
+// Rotated statistics (rot_active): the rows are Q P R / Q P C; A' = F (Q P R) with the folded F = W0 diag(1 + sc) Q^T of this
+// forward (k_fold_coord, A.ffold) — no scaling, no means (P removed them) —, and rmean receives the squared norms of the rows'
+// upper features (>= 2 De), which k_node_gram turns into the per-edge part of the variance.
 template <int D>
 __global__ __launch_bounds__(64, 1) void k_node_ab(KArgs A) {
     if (D != 256 && !A.flags[FLAG_UNIFORM_T]) return;       // nf = 384 pushes coord_mlp.0 through only with a shared modulation row
@@ -302,22 +306,38 @@ __global__ __launch_bounds__(64, 1) void k_node_ab(KArgs A) {
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
     const int strip = blockIdx.x >> 1, piece = blockIdx.x & 1;
     const LaneNode L = lane_node(A, strip, j);
+    const bool rot = rot_active(A);
     const float* qsc = mod_row(A, L.b) + A.mod_base + X::M_EQUI + D;       // equi_update.time_mlp: (shift, scale)
     const TRow src = trow(piece == 0 ? A.wrow : A.wcol, X::ND, L.v, half);
     float x[X::HD];
     float sum = 0.f;
+    if (rot) {                                              // (one branch around two straight-line loops: a branch per block
+#pragma unroll                                              //  serialised the row loads — 116 -> 161 us per launch)
+        for (int b = 0; b < X::ND; ++b) {
+            float t[16];
+            load16T(src, b, t);
 #pragma unroll
-    for (int b = 0; b < X::ND; ++b) {
-        float t[16], g[16];
-        load16T(src, b, t);
-        load16(qsc + b * 32 + half * 16, g);
+            for (int s = 0; s < 16; ++s) x[b * 16 + s] = t[s];
+        }
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 16; ++s) { sum += t[s]; x[b * 16 + s] = t[s] * (1.f + g[s]); }
+        for (int i = 2 * X::NE * 16; i < X::HD; ++i) s4[i & 3] = fmaf(x[i], x[i], s4[i & 3]);
+        sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    } else {
+#pragma unroll
+        for (int b = 0; b < X::ND; ++b) {
+            float t[16], g[16];
+            load16T(src, b, t);
+            load16(qsc + b * 32 + half * 16, g);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { sum += t[s]; x[b * 16 + s] = t[s] * (1.f + g[s]); }
+        }
     }
-    const float mean = pair_sum(sum) * (1.f / D);
-    if (half == 0) A.rmean[(size_t)L.v * 2 + piece] = mean;
-    const WSrc ws = make_wsrc(A.W, lane);
-    const unsigned o0 = (unsigned)(A.wb[JB_C0_W] * 4);
+    const float red = pair_sum(sum);
+    if (half == 0) A.rmean[(size_t)L.v * 2 + piece] = rot ? red : red * (1.f / D);
+    const WSrc wsw = make_wsrc(A.W, lane), wsf = make_wsrc(A.ffold + (size_t)A.layer * D * D, lane);
+    const WSrc ws = rot ? wsf : wsw;
+    const unsigned o0 = rot ? 0u : (unsigned)(A.wb[JB_C0_W] * 4);
     WPipe<X::PG> wp;
     wpipe_prime(wp, ws, o0);
     float* dst = piece == 0 ? A.ua : A.ub;
@@ -332,16 +352,51 @@ __global__ __launch_bounds__(64, 1) void k_node_ab(KArgs A) {
     }
 }
 
+// Rotated statistics, the features a pair's [e ; G] projection cannot reach: |(Q P R_a + Q P C_c)[2 De:]|^2 for every directed edge
+// (a, c) of a molecule = |R''_a|^2 + |C''_c|^2 + 2 <R''_a, C''_c>.  The inner products of a 32 x 32 tile of atoms are ONE chain of
+// (D - 2 De) / 2 MFMAs: the strip-transposed row arrays are at once the A operand (atom a = lane & 31 supplies its k-slot) and the
+// B operand (atom c).  One tile per wave; tiles = ordered pairs of strips that share a molecule (plan list gt_sa / gt_sc).
+template <int D>
+__global__ __launch_bounds__(64) void k_node_gram(KArgs A) {
+    if (!rot_active(A)) return;
+    using X = Dim<D>;
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const int sa = A.pd.gt_sa[blockIdx.x], sc = A.pd.gt_sc[blockIdx.x];
+    const float4* ra = reinterpret_cast<const float4*>(A.wrow) + (size_t)sa * X::ND * 256 + lane;
+    const float4* cc = reinterpret_cast<const float4*>(A.wcol) + (size_t)sc * X::ND * 256 + lane;
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int b = 2 * X::NE; b < X::ND; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = ra[(b * 4 + q) * 64], c = cc[(b * 4 + q) * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, c.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, c.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, c.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, c.w, acc, 0, 0, 0);
+        }
+    const int vc = sc * 32 + j;
+    const int nc = A.pd.node_n[vc], noffc = A.pd.node_noff[vc], ic = A.pd.node_i[vc];
+    const size_t eoffc = (size_t)A.pd.node_eoff[vc];
+    const float nC = A.rmean[(size_t)vc * 2 + 1];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {                          // accumulator register s of half h holds row 8 (s / 4) + 4 h + s % 4
+        const int va = sa * 32 + 8 * (s >> 2) + 4 * half + (s & 3);
+        if (nc > 0 && A.pd.node_n[va] > 0 && A.pd.node_noff[va] == noffc)
+            A.gramE[eoffc + (size_t)A.pd.node_i[va] * nc + ic] = A.rmean[(size_t)va * 2] + nC + 2.f * acc[s];
+    }
+}
+
 // M_l = coord_mlp.0 diag(1 + sc_l) input_lin[:, e ; G] for every block l, in the streaming layout of input_lin's [e ; G]
 // part (pack_projection: [out block][quad][lane] float4) — valid when all molecules share one modulation row (device flag
 // UNIFORM_T), which is how sampling runs an unconditional model.  Both factors are read in their packed layouts: row o of
 // coord_mlp.0 sits at lane (s & 3) + 4 h + 8 (s >> 2) of block o / 32 (o % 32 = 16 h + s), its column j at register
 // m = 16 (j / 32) + j % 16 of half (j % 32) / 16.  One float4 of M per thread, sums in double; 2 x 134 MFLOP per forward.
-template <int D>
-__global__ __launch_bounds__(64) void k_fold_coord(KArgs A, FoldOffs F) {
-    if (!A.flags[FLAG_UNIFORM_T]) return;
+template <int D, int KQI>     // KQI = quads per output block of the right-hand factor: 2 KQE ([e ; G] part of input_lin), KQD (Q^T)
+__global__ __launch_bounds__(64) void k_fold_coord(KArgs A, FoldOffs F, float* out, int need_rot) {
+    if (!A.flags[FLAG_UNIFORM_T] || (need_rot && !rot_active(A))) return;
     using X = Dim<D>;
-    constexpr int KQI = 2 * X::KQE, PER_L = X::ND * KQI;
+    constexpr int PER_L = X::ND * KQI;
     const int l = blockIdx.x / PER_L, r = blockIdx.x % PER_L, nb = r / KQI, q = r % KQI;
     const int lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     const float* sc = A.mods + 32 + (size_t)l * A.d.MB + X::M_EQUI + D;
@@ -364,7 +419,7 @@ __global__ __launch_bounds__(64) void k_fold_coord(KArgs A, FoldOffs F) {
             }
         }
     }
-    reinterpret_cast<float4*>(A.mfold)[((size_t)l * PER_L + r) * 64 + lane] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+    reinterpret_cast<float4*>(out)[((size_t)l * PER_L + r) * 64 + lane] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -531,8 +586,9 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
 // lane) is kept in a per-lane array for both directions (registers at D = 256, partly spilled to scratch at
 // D = 384 — four waves' LDS slabs of 48 KiB would not fit the CU's 160 KiB), and each direction requests its
 // per-node rows with buffer loads pinned ahead of their use (BRow, dgt_device.h).
-template <int D, int R, bool FOLD = false>
+template <int D, int R, bool FOLD = false, bool ROT = false>
 __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
+    static_assert(FOLD || !ROT, "the rotated statistics need the shared modulation row");
     if (A.flags[FLAG_ASYM]) return;
     // FOLD: every molecule shares one modulation row (unconditional sampling, one noise level per batch), so
     // coord_mlp.0 (1 + sc) input_lin[e ; G] is ONE D x 2De matrix per block (k_fold_coord) — see the hoist below.
@@ -653,11 +709,30 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             store_nat<X::NE>(A.e_out + P.rji * X::De, half, en);
         }
         PT(1);
+        // per-node rows of the coord_mlp.0 hoist (own rows do not depend on the pair offset: without an opaque offset LICM
+        // hoists and spills them)
+        unsigned opq = 0;
+        asm volatile("" : "+v"(opq));
+        BRow ua_i = brow(A.ua, X::ND, L.v, half), ub_i = brow(A.ub, X::ND, L.v, half);
+        const BRow ua_j = brow(A.ua, X::ND, P.u, half), ub_j = brow(A.ub, X::ND, P.u, half);
+        BRow own_r = wrow_i, own_c = wcol_i;
+        ua_i.voff += opq; ub_i.voff += opq; own_r.voff += opq; own_c.voff += opq;
+        float n0[16], n1[16], n2[16], n3[16];
+        constexpr int NB2 = 2 * X::NE;                          // blocks of the triangular factor L (K = 2 De)
+        constexpr int KQL = 2 * X::KQE;                         // quads per block row of the packed L
+        const unsigned oL = (unsigned)(A.wb[JB_LQ_W] * 4);
+        float gr0 = 0.f, gr1 = 0.f;
+        if constexpr (ROT) {                                    // rows of the first (shortest) L block: requested ahead of the readout
+            bload16(own_r, NB2 - 1, n0); bload16(wcol_j, NB2 - 1, n1); bload16(wrow_j, NB2 - 1, n2); bload16(own_c, NB2 - 1, n3);
+            gr0 = A.gramE[P.rij]; gr1 = A.gramE[P.rji];
+        }
         // ---- readout ----
         {
             float bb[16];
             load16(bro_ + half * 16, bb);
-            f32x16 acc = mfma_block_p<X::KQE>(wp, ws, oro, oi, en, zero16());
+            f32x16 acc;
+            if constexpr (ROT) acc = mfma_block_g<X::KQE, (4 < X::PG ? 4 : X::PG)>(wp, ws, oro, ws, oL + (unsigned)((NB2 - 1) * KQL + 4 * (NB2 - 1)) * 1024, en, zero16());
+            else acc = mfma_block_p<X::KQE>(wp, ws, oro, oi, en, zero16());
             float rr[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) rr[s] = acc[s] + bb[s];
@@ -680,18 +755,55 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             // of pre is meanS + mean(R_a) + mean(C_c); only meanS is unknown while S is being produced, so the variance is
             // accumulated around m0 = mean(R_a) + mean(C_c) and corrected: var = E[(pre - m0)^2] - meanS^2 (meanS is the
             // mean of a bias-free projection of a normalised vector: small against the spread, no cancellation).
-            unsigned opq = 0;                                    // own rows do not depend on the pair offset: without an opaque
-            asm volatile("" : "+v"(opq));                        // offset LICM hoists and spills them
-            BRow ua_i = brow(A.ua, X::ND, L.v, half), ub_i = brow(A.ub, X::ND, L.v, half);
-            const BRow ua_j = brow(A.ua, X::ND, P.u, half), ub_j = brow(A.ub, X::ND, P.u, half);
-            BRow own_r = wrow_i, own_c = wcol_i;
-            ua_i.voff += opq; ub_i.voff += opq; own_r.voff += opq; own_c.voff += opq;
-            const float m00 = A.rmean[(size_t)L.v * 2] + A.rmean[(size_t)P.u * 2 + 1];          // direction 0: a = i, c = j
-            const float m01 = A.rmean[(size_t)P.u * 2] + A.rmean[(size_t)L.v * 2 + 1];          // direction 1: a = j, c = i
             float sg[FOLD ? 1 : X::HD];
             const WSrc wm = make_wsrc(A.mfold + (size_t)A.layer * D * 2 * X::De, lane);      // FOLD: W0 (1 + sc) W_in[e ; G]
-            f32x2 ssum2 = {0.f, 0.f}, q02 = {0.f, 0.f}, q12 = {0.f, 0.f};
-            float n0[16], n1[16], n2[16], n3[16];
+            f32x2 q02 = {0.f, 0.f}, q12 = {0.f, 0.f};
+            float rstd0, rstd1, mr0 = 0.f, mr1 = 0.f;
+            if constexpr (ROT) {
+                // ---- rotated statistics (dgt_pack.cpp rot_stats) ----
+                // The rows are Rq = Q P (W_row h + b), Cq = Q P W_col h with Q (P W_in[:, e ; G]) = [L ; 0], L upper triangular
+                // (2 De x 2 De):  D var(pre) = |L z + Rq_a[:2De] + Cq_c[:2De]|^2 + |Rq_a[2De:] + Cq_c[2De:]|^2.  The first term costs
+                // a TRIANGULAR projection (160 instead of 512 MFMAs at nf 256) and half of the row gathers; the second is one number
+                // per directed edge from k_node_gram.  No means anywhere: P removed them (the folded matrix and F are built from the
+                // centred factors).  Shortest block first, so that the rows of the tail's first block, requested behind the longest
+                // block's last weight prefetch, get its 4k cycles of cover.
+                float z[2 * X::HE];
+#pragma unroll
+                for (int s = 0; s < X::HE; ++s) { z[s] = en[s]; z[X::HE + s] = G[s]; }
+                static_for<NB2>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value, b = NB2 - 1 - k;
+                    constexpr int KQ = 4 * (NB2 - b), KQN = 4 * (NB2 - b + 1);
+                    constexpr int NXT = (k + 1 < NB2 && KQN < X::PG) ? KQN : X::PG;
+                    float t0[16], t1[16];
+#pragma unroll
+                    for (int s = 0; s < 16; s += 2) {
+                        const f32x2 a = pk2(n0[s], n0[s + 1]) + pk2(n1[s], n1[s + 1]), c = pk2(n2[s], n2[s + 1]) + pk2(n3[s], n3[s + 1]);
+                        t0[s] = a.x; t0[s + 1] = a.y; t1[s] = c.x; t1[s + 1] = c.y;
+                    }
+                    auto next_rows = [&]() {
+                        if constexpr (k + 1 < NB2) { bload16(own_r, b - 1, n0); bload16(wcol_j, b - 1, n1); bload16(wrow_j, b - 1, n2); bload16(own_c, b - 1, n3); }
+                        else { bload16(ua_i, 0, n0); bload16(ub_j, 0, n1); bload16(ua_j, 0, n2); bload16(ub_i, 0, n3); }    // first block of the tail
+                    };
+                    const unsigned cur = oL + (unsigned)(b * KQL + 4 * b) * 1024;
+                    f32x16 acc;
+                    if constexpr (k + 1 < NB2) acc = mfma_block_g<KQ, NXT>(wp, ws, cur, ws, oL + (unsigned)((b - 1) * KQL + 4 * (b - 1)) * 1024, z + 16 * b, zero16(), next_rows);
+                    else acc = mfma_block_g<KQ, NXT>(wp, ws, cur, wm, 0u, z + 16 * b, zero16(), next_rows);
+                    PT(3);
+#pragma unroll
+                    for (int s = 0; s < 16; s += 2) {
+                        const f32x2 sv = pk2(acc[s], acc[s + 1]);
+                        const f32x2 d0 = sv + pk2(t0[s], t0[s + 1]), d1 = sv + pk2(t1[s], t1[s + 1]);
+                        q02 = __builtin_elementwise_fma(d0, d0, q02);
+                        q12 = __builtin_elementwise_fma(d1, d1, q12);
+                    }
+                    PT(4);
+                });
+                rstd0 = __builtin_amdgcn_rsqf((pair_sum(q02.x + q02.y) + gr0) * (1.f / D) + 1e-6f);
+                rstd1 = __builtin_amdgcn_rsqf((pair_sum(q12.x + q12.y) + gr1) * (1.f / D) + 1e-6f);
+            } else {
+            const float m00 = A.rmean[(size_t)L.v * 2] + A.rmean[(size_t)P.u * 2 + 1];          // direction 0: a = i, c = j
+            const float m01 = A.rmean[(size_t)P.u * 2] + A.rmean[(size_t)L.v * 2 + 1];          // direction 1: a = j, c = i
+            f32x2 ssum2 = {0.f, 0.f};
             bload16(own_r, 0, n0); bload16(wcol_j, 0, n1); bload16(wrow_j, 0, n2); bload16(own_c, 0, n3);
 #pragma unroll
             for (int b = 0; b < X::ND; ++b) {
@@ -726,9 +838,10 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                 PT(4);
             }
             const float meanS = pair_sum(ssum2.x + ssum2.y) * (1.f / D);
-            const float rstd0 = __builtin_amdgcn_rsqf(fmaxf(pair_sum(q02.x + q02.y) * (1.f / D) - meanS * meanS, 0.f) + 1e-6f);
-            const float rstd1 = __builtin_amdgcn_rsqf(fmaxf(pair_sum(q12.x + q12.y) * (1.f / D) - meanS * meanS, 0.f) + 1e-6f);
-            const float mr0 = (meanS + m00) * rstd0, mr1 = (meanS + m01) * rstd1;
+            rstd0 = __builtin_amdgcn_rsqf(fmaxf(pair_sum(q02.x + q02.y) * (1.f / D) - meanS * meanS, 0.f) + 1e-6f);
+            rstd1 = __builtin_amdgcn_rsqf(fmaxf(pair_sum(q12.x + q12.y) * (1.f / D) - meanS * meanS, 0.f) + 1e-6f);
+            mr0 = (meanS + m00) * rstd0; mr1 = (meanS + m01) * rstd1;
+            }
             PT(4);
             const float* wg_v = launder(mrow + X::M_WG);
             const float* bs_v = wg_v + D;
@@ -745,7 +858,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                     const int bn = b + 1 < X::ND ? b + 1 : b;    // behind the last weight prefetch of this block
                     bload16(ua_i, bn, n0); bload16(ub_j, bn, n1); bload16(ua_j, bn, n2); bload16(ub_i, bn, n3);
                 };
-                load16(wg_v + b * 32 + half * 16, wgb);
+                if constexpr (!ROT) load16(wg_v + b * 32 + half * 16, wgb);
                 load16(bs_v + b * 32 + half * 16, bsb);
                 f32x16 z;
                 if constexpr (FOLD) {                            // Z = M [e ; G]: K = 2 De instead of D, and no S to keep
@@ -774,8 +887,9 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                     ld8(w2l + fo, k0); ld8(w2l + D + fo, k1); ld8(w2l + 2 * D + fo, k2);
 #pragma unroll
                     for (int s = 0; s < 8; s += 2) {               // element pairs on the packed fp32 pipe; the three dot products
-                        const f32x2 wg2 = pk2(wgb[hq * 8 + s], wgb[hq * 8 + s + 1]), bs2 = pk2(bsb[hq * 8 + s], bsb[hq * 8 + s + 1]);   // keep even / odd partial sums
-                        const f32x2 c = __builtin_elementwise_fma((f32x2)(-mr0), wg2, bs2);
+                        const f32x2 bs2 = pk2(bsb[hq * 8 + s], bsb[hq * 8 + s + 1]);   // keep even / odd partial sums
+                        f32x2 c = bs2;                                  // ROT: the mean is gone (centred factors)
+                        if constexpr (!ROT) c = __builtin_elementwise_fma((f32x2)(-mr0), pk2(wgb[hq * 8 + s], wgb[hq * 8 + s + 1]), bs2);
                         ca[s] = c.x; ca[s + 1] = c.y;
                     }
                     pipeline_fence();
@@ -790,8 +904,9 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                     pipeline_fence();
 #pragma unroll
                     for (int s = 0; s < 8; s += 2) {
-                        const f32x2 wg2 = pk2(wgb[hq * 8 + s], wgb[hq * 8 + s + 1]), bs2 = pk2(bsb[hq * 8 + s], bsb[hq * 8 + s + 1]);
-                        const f32x2 c = __builtin_elementwise_fma((f32x2)(-mr1), wg2, bs2);
+                        const f32x2 bs2 = pk2(bsb[hq * 8 + s], bsb[hq * 8 + s + 1]);
+                        f32x2 c = bs2;
+                        if constexpr (!ROT) c = __builtin_elementwise_fma((f32x2)(-mr1), pk2(wgb[hq * 8 + s], wgb[hq * 8 + s + 1]), bs2);
                         ca[s] = c.x; ca[s + 1] = c.y;
                     }
 #pragma unroll

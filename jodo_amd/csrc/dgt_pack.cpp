@@ -87,6 +87,75 @@ IMap hid_in(int base, int L, int cnt, int pad) {
     return nat;
 }
 
+// Rotated LayerNorm statistics of equi_update.  pre = W_in [h_a ; h_c ; e ; G] + b enters its LayerNorm only
+// through P pre (P = I - 11^T / D).  With the Householder QR factorisation  Q (P W_eg) = [L ; 0]  of the centred [e ; G] columns
+// (Q orthogonal D x D, L upper triangular KL x KL, KL = 2 De):  |P pre|^2 = |L z + (Q P R)[:KL] + (Q P C)[:KL]|^2 + |(Q P R + Q P C)[KL:]|^2,
+// so the per-pair projection shrinks from D x KL to a triangular KL x KL one.  Everything in double; out: row-major float matrices.
+struct RotStats {
+    std::vector<float> rowq, colq, bq, lq, wec, qt;     // [D,D] [D,D] [D] [KL,KL] [D,KL] [D,D] (qt[f][j] = Q[j][f])
+};
+RotStats rot_stats(const float* Win, const float* bin, int D, int De) {
+    const int KL = 2 * De, KIN = 2 * D + KL;
+    std::vector<double> A((size_t)D * KL), Q((size_t)D * D, 0.0), v((size_t)D);
+    for (int k = 0; k < KL; ++k) {                       // centred columns of the [e ; G] part
+        double m = 0.0;
+        for (int f = 0; f < D; ++f) m += Win[(size_t)f * KIN + 2 * D + k];
+        m /= D;
+        for (int f = 0; f < D; ++f) A[(size_t)f * KL + k] = (double)Win[(size_t)f * KIN + 2 * D + k] - m;
+    }
+    RotStats r;
+    r.wec.resize((size_t)D * KL);
+    for (size_t i = 0; i < r.wec.size(); ++i) r.wec[i] = (float)A[i];
+    for (int i = 0; i < D; ++i) Q[(size_t)i * D + i] = 1.0;
+    for (int k = 0; k < KL; ++k) {                       // Householder reflections H_k, Q = H_{KL-1} ... H_0
+        double nrm = 0.0;
+        for (int i = k; i < D; ++i) nrm += A[(size_t)i * KL + k] * A[(size_t)i * KL + k];
+        nrm = std::sqrt(nrm);
+        if (nrm == 0.0) continue;
+        const double alpha = A[(size_t)k * KL + k] > 0.0 ? -nrm : nrm;
+        double vn = 0.0;
+        for (int i = k; i < D; ++i) { v[i] = A[(size_t)i * KL + k]; if (i == k) v[i] -= alpha; vn += v[i] * v[i]; }
+        if (vn == 0.0) continue;
+        const double s2 = 2.0 / vn;
+        for (int j = k; j < KL; ++j) {
+            double s = 0.0;
+            for (int i = k; i < D; ++i) s += v[i] * A[(size_t)i * KL + j];
+            s *= s2;
+            for (int i = k; i < D; ++i) A[(size_t)i * KL + j] -= s * v[i];
+        }
+        std::vector<double> sj((size_t)D, 0.0);
+        for (int i = k; i < D; ++i) { const double vi = v[i]; const double* q = &Q[(size_t)i * D]; for (int j = 0; j < D; ++j) sj[j] += vi * q[j]; }
+        for (int i = k; i < D; ++i) { const double vi = v[i] * s2; double* q = &Q[(size_t)i * D]; for (int j = 0; j < D; ++j) q[j] -= vi * sj[j]; }
+    }
+    r.lq.assign((size_t)KL * KL, 0.f);
+    for (int i = 0; i < KL; ++i) for (int j = i; j < KL; ++j) r.lq[(size_t)i * KL + j] = (float)A[(size_t)i * KL + j];
+    r.qt.resize((size_t)D * D);
+    for (int f = 0; f < D; ++f) for (int j = 0; j < D; ++j) r.qt[(size_t)f * D + j] = (float)Q[(size_t)j * D + f];
+    // Q P = Q - (Q 1) 1^T / D, then Q P W_row, Q P W_col, Q P b
+    std::vector<double> QP(Q);
+    for (int i = 0; i < D; ++i) {
+        double m = 0.0;
+        for (int f = 0; f < D; ++f) m += Q[(size_t)i * D + f];
+        m /= D;
+        for (int f = 0; f < D; ++f) QP[(size_t)i * D + f] -= m;
+    }
+    r.rowq.resize((size_t)D * D); r.colq.resize((size_t)D * D); r.bq.resize((size_t)D);
+    std::vector<double> acc((size_t)2 * D);
+    for (int i = 0; i < D; ++i) {
+        std::fill(acc.begin(), acc.end(), 0.0);
+        double b = 0.0;
+        for (int f = 0; f < D; ++f) {
+            const double qf = QP[(size_t)i * D + f];
+            const float* w = Win + (size_t)f * KIN;      // columns 0..2D-1: h_row | h_col
+            for (int c = 0; c < 2 * D; ++c) acc[c] += qf * (double)w[c];
+            b += qf * (double)bin[f];
+        }
+        for (int c = 0; c < D; ++c) { r.rowq[(size_t)i * D + c] = (float)acc[c]; r.colq[(size_t)i * D + c] = (float)acc[D + c]; }
+        r.bq[i] = (float)b;
+    }
+    return r;
+}
+
 struct Packer {
     std::vector<float> blob;
     std::vector<int64_t> offs;        // in put() order
@@ -318,6 +387,21 @@ int pack(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, Packer&
         proj("node_" + std::to_string(l) + ".weight", cn, D, nat_in(D), omn); P.put_vec(S(W("node_" + std::to_string(l) + ".bias", cn)), omn);
         proj("edge_" + std::to_string(l) + ".weight", ce, De, nat_in(De), ome); P.put_vec(S(W("edge_" + std::to_string(l) + ".bias", ce)), ome);
         P.put(gbf_table(lk, b + ".dist_layer", De));
+        {   // rotated LayerNorm statistics (JB_ROWQ_W .. JB_QT_W)
+            const float* win = W(b + ".equi_update.input_lin.weight", (int64_t)D * KIN);
+            const float* bin = W(b + ".equi_update.input_lin.bias", D);
+            if (win && bin) {
+                const RotStats rs = rot_stats(win, bin, D, De);
+                P.put_proj(rs.rowq.data(), D, nat_in(D), nat_out(D));
+                P.put_proj(rs.colq.data(), D, nat_in(D), nat_out(D));
+                P.put(rs.bq);
+                P.put_proj(rs.lq.data(), 2 * De, cat(nat_in(De), nat_in(De, De)), nat_out(2 * De));
+                P.put_proj(rs.wec.data(), 2 * De, cat(nat_in(De), nat_in(De, De)), nat_out(D));
+                P.put_proj(rs.qt.data(), D, nat_in(D), nat_out(D));
+            } else {
+                for (int i = 0; i < 6; ++i) P.put_zero1();
+            }
+        }
     }
     if (!lk.missing.empty()) return jodo_set_error(JODO_ERR_ARG, "pack_weights: parameter '%s' missing from the tensor list", lk.missing.c_str());
     if ((int)P.offs.size() != JW_GLOBAL_COUNT + L * JB_BLOCK_COUNT)

@@ -113,7 +113,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     const bool spair_auto = spair_chunk <= 0;
     p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->last_e_buf = 0;
     p->opt[JODO_OPT_FUSE_NEXT_QKV] = 1; p->opt[JODO_OPT_DIR_SPLIT] = 1; p->opt[JODO_OPT_NODE_POST_WAVES] = 0; p->opt[JODO_OPT_ATTN_VARIANT] = 0;
-    p->opt[JODO_OPT_PIN_SYMMETRIC] = 0; p->opt[JODO_OPT_PIN_UNIFORM_T] = 0;
+    p->opt[JODO_OPT_PIN_SYMMETRIC] = 0; p->opt[JODO_OPT_PIN_UNIFORM_T] = 0; p->opt[JODO_OPT_ROT_STATS] = 1;
     p->prof_enabled = 0; p->force_directed = 0; p->dbg_timing = nullptr;
 
     // molecules by descending size (stable): neighbouring lanes share n, big work first
@@ -275,6 +275,22 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         p->n_ut_pad = (int)(ut.size() / 2);
         put(ut, &p->off_ut_rows);
     }
+    {   // Gram tiles of the rotated statistics: every ordered pair of strips that share a molecule (sizes descend and molecules
+        // are contiguous, so the strips of the molecules touching strip s form one range)
+        std::vector<int32_t> gsa, gsc;
+        for (int s = 0; s < p->n_strips; ++s) {
+            int lo = s, hi = s;
+            for (int j = 0; j < 32; ++j) {
+                const int v0 = s * 32 + j;
+                if (node_n[v0] <= 0) continue;
+                lo = std::min(lo, (int)node_noff[v0] / 32);
+                hi = std::max(hi, (int)(node_noff[v0] + node_n[v0] - 1) / 32);
+            }
+            for (int c = lo; c <= hi; ++c) { gsa.push_back(s); gsc.push_back(c); }
+        }
+        p->n_gtiles = (int)gsa.size();
+        put(gsa, &p->off_gt_sa); put(gsc, &p->off_gt_sc);
+    }
 
     // workspace layout
     const DgtDims& d = p->dims;
@@ -288,10 +304,10 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     w.feat = take(NP * d.ndp * f); w.h = take(NP * d.D * f); w.hhat = take(NP * amax_parts * d.D * f);
     w.astat = take(NP * amax_parts * 32 * f);
     w.q = take(NP * d.QKP * f); w.k = take(NP * d.QKP * f); w.v = take(NP * d.D * f); w.n2e = take(NP * d.De * f);
-    w.wrow = take(NP * d.D * f); w.wcol = take(NP * d.D * f); w.ua = take(NP * d.D * f); w.ub = take(NP * d.D * f); w.rmean = take(NP * 2 * f); w.mfold = take((size_t)d.L * d.D * 2 * d.De * f); w.ahid = take(NP * d.KNH * f);
+    w.wrow = take(NP * d.D * f); w.wcol = take(NP * d.D * f); w.ua = take(NP * d.D * f); w.ub = take(NP * d.D * f); w.rmean = take(NP * 2 * f); w.mfold = take((size_t)d.L * d.D * 2 * d.De * f); w.ffold = take((size_t)d.L * d.D * d.D * f); w.ahid = take(NP * d.KNH * f);
     w.apred = take(NP * 32 * f);
     w.eflag = take(R * sizeof(int32_t)); w.e = take(R * d.De * f); w.e2 = take(R * d.De * f);
-    w.ehid = take(R * d.KEH * f); w.epred = take(R * 4 * f); w.dposE = take(R * 4 * f);
+    w.ehid = take(R * d.KEH * f); w.epred = take(R * 4 * f); w.dposE = take(R * 4 * f); w.gramE = take(R * f);
     w.total = o;
     *out = p;
     return JODO_OK;
@@ -378,8 +394,15 @@ extern "C" int jodo_plan_work(const jodo_plan* p, int uniform_t, int symmetric, 
     // edge update: trunk (edge FFN, readout, e + distance part S of input_lin) + coord_mlp.0 in its form of the call
     const double trunk = proj(r * De, De) + proj(De, r * De) + proj(d.cep, De) + proj(D, 2 * De);
     if (sym) {
-        const double c0 = (uniform_t && d.cond_ch == 0) ? proj(D, 2 * De) : (hoist ? proj(D, D) : 2 * proj(D, D));
-        cls[JODO_PROF_EDGE_UPDATE] += L * pair_iters * (trunk + c0);
+        const bool fold = uniform_t && d.cond_ch == 0;
+        const double c0 = fold ? proj(D, 2 * De) : (hoist ? proj(D, D) : 2 * proj(D, D));
+        double tr = trunk;
+        if (fold && p->opt[JODO_OPT_ROT_STATS]) {            // rotated statistics: triangular L [e ; G] instead of S, + the Gram tiles
+            tr -= proj(D, 2 * De);
+            for (int b = 0; b < 2 * De / 32; ++b) tr += (double)(2 * De - 32 * b) / 2;
+            cls[JODO_PROF_NODE_POST] += L * (double)p->n_gtiles * (double)(D - 2 * De) / 2;
+        }
+        cls[JODO_PROF_EDGE_UPDATE] += L * pair_iters * (tr + c0);
     } else {
         cls[JODO_PROF_EDGE_UPDATE] += L * dir_iters * (trunk + proj(D, D));
     }
@@ -413,7 +436,7 @@ extern "C" int jodo_plan_set_option(jodo_plan* p, int option, int value) {
     if (option < 0 || option >= JODO_OPT_COUNT) return jodo_set_error(JODO_ERR_ARG, "plan_set_option: unknown option %d", option);
     if (option == JODO_OPT_NODE_POST_WAVES && value != 0 && value != 1 && value != 2 && value != 4 && value != 12 && value != 14)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: node-post waves per strip must be 0 (auto), 1, 2 or 4");
-    if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT) && value != 0 && value != 1)
+    if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT || option == JODO_OPT_ROT_STATS) && value != 0 && value != 1)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: option %d is a switch (0 or 1), got %d", option, value);
     if ((option == JODO_OPT_PIN_SYMMETRIC || option == JODO_OPT_PIN_UNIFORM_T) && (value < 0 || value > 2))
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: a pin is 0 (none), 1 or 2, got %d", value);

@@ -50,6 +50,9 @@ struct PlanDev {
     const int* anode_parts; // [Nn_pad] number of attention partials of a node
     const int* ut_rows;     // [n_ut_pad][2] dense edge row (a, c) with a < c and its mirror (c, a); -1 = padding (edge head, symmetric inputs)
     int n_ut_pad;
+    const int* gt_sa;       // Gram tiles of the rotated statistics (k_node_gram): strip of the row atoms a, strip of the column atoms c
+    const int* gt_sc;
+    int n_gtiles;
     int n_agroups, n_aitems, n_aditems, amax_parts;
     int Nn, Nn_pad, n_strips, n_items, n_pitems, B, N, max_parts;
     int64_t rows;
@@ -57,8 +60,8 @@ struct PlanDev {
 
 struct WsLayout {   // byte offsets into the workspace
     size_t hid1, temb, mods, condh, condh2;
-    size_t pos0, pos1, dpos, cpos, feat, h, hhat, astat, q, k, v, n2e, wrow, wcol, ua, ub, rmean, mfold, ahid, apred;
-    size_t eflag, e, e2, ehid, epred, dposE;
+    size_t pos0, pos1, dpos, cpos, feat, h, hhat, astat, q, k, v, n2e, wrow, wcol, ua, ub, rmean, mfold, ffold, ahid, apred;
+    size_t eflag, e, e2, ehid, epred, dposE, gramE;
     size_t total;
 };
 
@@ -66,9 +69,9 @@ struct jodo_plan {
     jodo_cfg cfg;
     DgtDims dims;
     int B, N, Nn, Nn_pad, n_strips, n_items, n_pitems, max_parts;
-    int n_agroups, n_aitems, n_aditems, amax_parts, n_ut_pad;
+    int n_agroups, n_aitems, n_aditems, amax_parts, n_ut_pad, n_gtiles;
     int has_big;                     // some molecule spans several attention groups (n > 128): its items always run in directed mode
-    size_t off_ag_node, off_ai_group, off_ai_t0, off_ai_t1, off_ai_part, off_ad_group, off_ad_t0, off_ad_t1, off_ad_part, off_ad_big, off_anode_parts, off_ut_rows;
+    size_t off_ag_node, off_ai_group, off_ai_t0, off_ai_t1, off_ai_part, off_ad_group, off_ad_t0, off_ad_t1, off_ad_part, off_ad_big, off_anode_parts, off_ut_rows, off_gt_sa, off_gt_sc;
     int64_t rows, dir_edges;
     std::vector<int32_t> desc;       // concatenated descriptor tables
     size_t off_node_b, off_node_i, off_node_n, off_node_noff, off_node_eoff, off_orig_n, off_orig_noff,

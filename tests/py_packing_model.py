@@ -25,6 +25,7 @@ BLOCK_SLOTS = [
     'FF1_W', 'FF1_B', 'FF2_W', 'FF2_B', 'FF3_W', 'FF3_B', 'FF4_W', 'FF4_B',
     'INE_W', 'ROW_W', 'COL_W', 'IN_B', 'C0_W', 'C0_B', 'C2_W', 'CSCALE',
     'NRO_W', 'NRO_B', 'ERO_W', 'ERO_B', 'GBF',
+    'ROWQ_W', 'COLQ_W', 'INQ_B', 'LQ_W', 'INEC_W', 'QT_W',
 ]
 
 
@@ -43,6 +44,33 @@ def _gbf_table(sd, prefix, De):
     tab[2, 1:] = 1.0 / (a * sg)
     tab[1, 0] = 1.0
     return tab.astype(np.float32).reshape(-1)
+
+
+def rot_stats(Win, bin_, D, De):
+    """Rotated LayerNorm statistics of equi_update (csrc/dgt_pack.cpp rot_stats): Householder QR of the centred [e ; G]
+    columns of input_lin, Q (P W_eg) = [L ; 0]; returns (Q P W_row, Q P W_col, Q P b, L, P W_eg, Q^T) in float64."""
+    KL = 2 * De
+    Win = Win.astype(np.float64)
+    A = Win[:, 2 * D:2 * D + KL].copy()
+    A -= A.mean(axis=0, keepdims=True)
+    wec = A.copy()
+    Q = np.eye(D)
+    for k in range(KL):
+        x = A[k:, k]
+        nrm = np.sqrt((x * x).sum())
+        if nrm == 0.0:
+            continue
+        alpha = -nrm if x[0] > 0.0 else nrm
+        v = x.copy()
+        v[0] -= alpha
+        vn = (v * v).sum()
+        if vn == 0.0:
+            continue
+        A[k:, k:] -= np.outer(v, (2.0 / vn) * (v @ A[k:, k:]))
+        Q[k:, :] -= np.outer((2.0 / vn) * v, v @ Q[k:, :])
+    L = np.triu(A[:KL, :])
+    QP = Q - Q.mean(axis=1, keepdims=True)
+    return QP @ Win[:, :D], QP @ Win[:, D:2 * D], QP @ bin_.astype(np.float64), L, wec, Q.T.copy()
 
 
 def _hid_in_map(base_w, n_layers, per_block_true, per_block_pad):
@@ -203,6 +231,14 @@ def pack_model(sd, dims):
         put(pre + 'ERO_W', P.pack_projection(w('edge_%d.weight' % l), nat(De), ome))
         put(pre + 'ERO_B', P.pack_vector(w('edge_%d.bias' % l), ome))
         put(pre + 'GBF', _gbf_table(sd, b + '.dist_layer', De))
+        rowq, colq, bq, Lq, wec, qt = rot_stats(Win, w(b + '.equi_update.input_lin.bias'), D, De)
+        eg = P.concat_in_maps(nat(De), nat(De) + De)
+        put(pre + 'ROWQ_W', P.pack_projection(rowq.astype(np.float32), nat(D), nout(D)))
+        put(pre + 'COLQ_W', P.pack_projection(colq.astype(np.float32), nat(D), nout(D)))
+        put(pre + 'INQ_B', bq.astype(np.float32))
+        put(pre + 'LQ_W', P.pack_projection(Lq.astype(np.float32), eg, nout(2 * De)))
+        put(pre + 'INEC_W', P.pack_projection(wec.astype(np.float32), eg, nout(D)))
+        put(pre + 'QT_W', P.pack_projection(qt.astype(np.float32), nat(D), nout(D)))
 
     woff = [offs[s] for s in GLOBAL_SLOTS]
     for l in range(L):

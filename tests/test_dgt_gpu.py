@@ -155,6 +155,41 @@ def test_uniform_and_per_molecule_noise_levels_agree(cfg_name, n_nodes, gain, ov
     close(a1[1][1:], b[1][1:], atol=5e-5)
 
 
+@pytest.mark.parametrize("cfg_name,n_nodes,gain,over,atol", [
+    ('vpsde_qm9_uncond_jodo', [6, 11, 20, 29, 1, 2, 29, 29, 17, 3], 1.5, {}, 5e-5),
+    ('vpsde_qm9_uncond_jodo', [5] * 14 + [19] * 10, 1.5, dict(kernel_layout='wide'), 5e-5),
+    # molecules across many strips, n > 128: position sums over 149 neighbours at gain 1.5 — measured against the oracle in
+    # float64 (tools/rot_err.py): rotated 1.1e-4, plain fold 2.7e-4, the float32 oracle itself 4e-5
+    ('vpsde_geom_uncond_jodo', [70, 33, 12, 150, 1, 2], 1.5, {}, 4e-4),
+    ('vpsde_geom_uncond_jodo', [70, 33, 12, 1, 2], 1.5, dict(nf=384), 5e-5),
+])
+def test_rotated_statistics_match_plain_fold_and_oracle(cfg_name, n_nodes, gain, over, atol):
+    """JODO_OPT_ROT_STATS (default on): under a shared modulation row the pair update takes the LayerNorm statistics of
+    equi_update in the rotated basis (triangular L [e ; G] per pair, Q P W_row h / Q P W_col h per node, Gram tile per molecule).
+    Different arithmetic from the plain folded path (option 6 = 0): both are held to the oracle and to each other."""
+    cfg = make_config(cfg_name, **over)
+    hp = O.Hyper.from_config(cfg)
+    xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=17)
+    nl = torch.full_like(nl, -0.8)
+    outs = {}
+    for rot in (1, 0):
+        model = make_model(cfg, 11, DEV, gain=gain, coord_scale=0.05)
+        model.plan_options = {6: rot}
+        o1 = run(model, xh, ex, nl, nm, em)
+        assert model.last_flags.cpu().tolist()[2] == 1 and model.last_flags.cpu().tolist()[4] == 0
+        outs[rot] = (o1, run(model, xh, ex, nl, nm, em, o1[0], o1[1]))
+    sd = state_dict_cpu(model)
+    with torch.no_grad():
+        r1 = O.forward_dense(sd, hp, xh, nm, em, ex, None, None, nl)
+    for rot in (1, 0):
+        close(outs[rot][0][0], r1[0], atol=atol)
+        close(outs[rot][0][1], r1[1], atol=atol)
+    for k in (0, 1):
+        close(outs[1][k][0], outs[0][k][0], atol=atol)
+        close(outs[1][k][1], outs[0][k][1], atol=atol)
+    assert not torch.equal(outs[1][0][0], outs[0][0][0])          # the two paths really differ
+
+
 def test_invariants():
     cfg = make_config('vpsde_qm9_uncond_jodo')
     model = make_model(cfg, 4, DEV, gain=1.5, coord_scale=0.05)

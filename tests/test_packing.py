@@ -119,10 +119,20 @@ def test_c_packer_equals_python_packer(cfg_name, over):
     # bit-equal everywhere except the fused modulation projection, whose composed rows (coord_mlp.0 pushed through the
     # LayerNorm: products of two weight matrices) are accumulated in double by both packers but not in the same order
     from py_packing_model import GLOBAL_SLOTS
-    lo, hi = woff_py[GLOBAL_SLOTS.index('MOD_W')], woff_py[GLOBAL_SLOTS.index('MOD_B') + 1]
+    # ... and the rotated-statistics slots of every block (Householder QR in double, different summation orders)
+    from py_packing_model import BLOCK_SLOTS
     bc, bp = blob_c.numpy(), blob_py
-    assert np.array_equal(bc[:lo].view(np.uint32), bp[:lo].view(np.uint32)) and np.array_equal(bc[hi:].view(np.uint32), bp[hi:].view(np.uint32))
+    exact = np.ones(bc.size, bool)
+    lo, hi = woff_py[GLOBAL_SLOTS.index('MOD_W')], woff_py[GLOBAL_SLOTS.index('MOD_B') + 1]
+    exact[lo:hi] = False
     assert np.allclose(bc[lo:hi], bp[lo:hi], rtol=1e-6, atol=1e-9)
+    nb, ng = len(BLOCK_SLOTS), len(GLOBAL_SLOTS)
+    for l in range(model.dims.L):
+        lo = woff_py[ng + l * nb + BLOCK_SLOTS.index('ROWQ_W')]
+        hi = woff_py[ng + (l + 1) * nb] if l + 1 < model.dims.L else bc.size
+        exact[lo:hi] = False
+        assert np.allclose(bc[lo:hi], bp[lo:hi], rtol=1e-5, atol=2e-6)
+    assert np.array_equal(bc[exact].view(np.uint32), bp[exact].view(np.uint32))
     blob_m, woff_m, _ = capi.pack_weights(model._cfg(), {'module.' + k: v for k, v in sd.items()})
     assert torch.equal(blob_m, blob_c) and list(woff_m) == list(woff_c)
     bad = dict(sd)
@@ -190,3 +200,33 @@ def test_coord_mlp0_through_the_layer_norm_algebra():
     # shared modulation row: Z through the folded matrix M = W0 diag(1 + sc) W_in
     Win, x = rng.standard_normal((D, 128)) / 11, rng.standard_normal(128)
     assert np.allclose((W0 * (1 + sc)[None, :]) @ Win @ x, W0 @ ((Win @ x) * (1 + sc)), rtol=1e-12, atol=1e-12)
+
+
+def test_rotated_statistics_algebra():
+    """The rewrite behind JODO_OPT_ROT_STATS, in float64 with the Python packer's factors: with P the centring
+    projection and Q (P W_eg) = [L ; 0],  W0 [LN(pre) (1 + sc) + sh] + b0  ==  [M' z + F Rq + F Cq] rstd + bs  where
+    Rq = Q P (W_row h_a + b), Cq = Q P W_col h_c, M' = W0 diag(1 + sc) P W_eg, F = W0 diag(1 + sc) Q^T, and
+    D var(pre) = |L z + Rq[:KL] + Cq[:KL]|^2 + |Rq[KL:] + Cq[KL:]|^2; L is upper triangular, Q orthogonal."""
+    from py_packing_model import rot_stats
+    rng = np.random.default_rng(3)
+    D, De = 256, 64
+    KL = 2 * De
+    Win = (rng.standard_normal((D, 2 * D + KL)) / 12).astype(np.float32)
+    b_in = rng.standard_normal(D).astype(np.float32)
+    rowq, colq, bq, Lq, wec, qt = rot_stats(Win, b_in, D, De)
+    Q = qt.T
+    assert np.allclose(Q @ Q.T, np.eye(D), atol=1e-12)
+    assert np.allclose(Q @ wec, np.vstack([Lq, np.zeros((D - KL, KL))]), atol=1e-12) and np.allclose(Lq, np.triu(Lq))
+    W0, b0 = rng.standard_normal((D, D)) / 16, rng.standard_normal(D)
+    sc, sh = 0.3 * rng.standard_normal(D), rng.standard_normal(D)
+    ha, hc, z = rng.standard_normal(D), rng.standard_normal(D), rng.standard_normal(KL)
+    W = Win.astype(np.float64)
+    pre = W[:, :D] @ ha + W[:, D:2 * D] @ hc + W[:, 2 * D:] @ z + b_in
+    ln = (pre - pre.mean()) / np.sqrt(pre.var() + 1e-6)
+    want = W0 @ (ln * (1 + sc) + sh) + b0
+    Rq, Cq = rowq @ ha + bq, colq @ hc
+    var = (((Lq @ z + Rq[:KL] + Cq[:KL]) ** 2).sum() + ((Rq[KL:] + Cq[KL:]) ** 2).sum()) / D
+    assert abs(var - pre.var()) < 1e-12
+    Mp, F = (W0 * (1 + sc)[None, :]) @ wec, (W0 * (1 + sc)[None, :]) @ qt
+    got = (Mp @ z + F @ Rq + F @ Cq) / np.sqrt(var + 1e-6) + (W0 @ sh + b0)
+    assert np.allclose(got, want, rtol=1e-11, atol=1e-11)
