@@ -172,15 +172,16 @@ def test_rotated_statistics_match_plain_fold_and_oracle(cfg_name, n_nodes, gain,
     xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=17)
     nl = torch.full_like(nl, -0.8)
     outs = {}
+    model = make_model(cfg, 11, DEV, gain=gain, coord_scale=0.05)
+    sd = state_dict_cpu(model)
+    with torch.no_grad():
+        r1 = O.forward_dense(sd, hp, xh, nm, em, ex, None, None, nl)
     for rot in (1, 0):
         model = make_model(cfg, 11, DEV, gain=gain, coord_scale=0.05)
         model.plan_options = {6: rot}
         o1 = run(model, xh, ex, nl, nm, em)
         assert model.last_flags.cpu().tolist()[2] == 1 and model.last_flags.cpu().tolist()[4] == 0
-        outs[rot] = (o1, run(model, xh, ex, nl, nm, em, o1[0], o1[1]))
-    sd = state_dict_cpu(model)
-    with torch.no_grad():
-        r1 = O.forward_dense(sd, hp, xh, nm, em, ex, None, None, nl)
+        outs[rot] = (o1, run(model, xh, ex, nl, nm, em, r1[0], r1[1]))       # self-conditioned on the oracle's prediction: same inputs
     for rot in (1, 0):
         close(outs[rot][0][0], r1[0], atol=atol)
         close(outs[rot][0][1], r1[1], atol=atol)
