@@ -89,11 +89,13 @@ def reference_formulation_flops(d, n_nodes, shared_time):
     return total, upd
 
 
-def edge_update_vector_flops_per_directed_edge(d):
+def edge_update_vector_flops_per_directed_edge(d, rot=False):
     """fp32 flops the pair update issues on the VALU per DIRECTED edge besides its MFMAs: LayerNorm statistics of
     pre = S + R_a + C_c (add, subtract, fma per feature: 4 D), the assembled coord_mlp.0 output + SiLU (7 D), coord_mlp.2's
-    three dot products (6 D) and the shared edge LN2 / modulate / gate work (12 De per pair = 6 De per direction)."""
-    return 17 * d.D + 6 * d.De
+    three dot products (6 D) and the shared edge LN2 / modulate / gate work (12 De per pair = 6 De per direction).  With the
+    rotated statistics (shared modulation row, JODO_OPT_ROT_STATS): the statistics touch 2 De = D / 2 features (2 D flops) and
+    the assembled output loses its mean term (5 D)."""
+    return (13 if rot else 17) * d.D + 6 * d.De
 
 
 def cpu_model():
@@ -461,7 +463,8 @@ def main():
         upd_ms, upd_n = per_class['edge_update']
         nblk = dims.L
         mfma_launch = work[6] / (nblk * n_sub)                    # executed MFMA flops of ONE pair-update launch (one block, one sub-batch)
-        valu_launch = E * edge_update_vector_flops_per_directed_edge(dims) / n_sub
+        rot_stats = shared_row and not flags_now[4] and int(getattr(model, 'plan_options', {}).get(6, 1)) == 1
+        valu_launch = E * edge_update_vector_flops_per_directed_edge(dims, rot_stats) / n_sub
         exec_launch = mfma_launch + valu_launch
         achieved = exec_launch / (upd_ms * 1e-3) if upd_ms > 0 else 0.0
         exec_step = sum(work)                                    # executed MFMA flops of one forward, all kernels

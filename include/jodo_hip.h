@@ -174,6 +174,9 @@ enum jodo_plan_option {
     JODO_OPT_ROT_STATS = 6,       /* 1 (default): under a shared modulation row and symmetric inputs the LayerNorm statistics of
                                      equi_update are taken in the rotated basis (Q P W_row h, Q P W_col h per node, the triangular
                                      L [e ; G] per pair, a per-molecule Gram tile for the rest); 0: from S = W_in [e ; G] itself */
+    JODO_OPT_NODE_MIX = 7,        /* 1 (default): when k_node_post runs as full rounds + a remainder launch, the remainder launch also carries
+                                     the k_node_ab items and Gram tiles of the strips the full rounds finished (they fill the SIMDs the
+                                     remainder's cooperative workgroups leave idle); 0: separate launches */
     JODO_OPT_COUNT
 };
 int jodo_plan_set_option(jodo_plan* plan, int option, int value);

@@ -95,11 +95,32 @@ int launch_edge_head(hipStream_t st, const KArgs& A) {
     return JODO_OK;
 }
 
+// One launch for a block's remainder strips (k_node_postw role: NW waves per strip, long items first) and for the fine-grained
+// per-node items that do not depend on them — k_node_ab items and Gram tiles of the strips the preceding full-round k_node_post
+// launch finished, NW per workgroup.  The cooperative remainder workgroups occupy 2 x 385 of 1024 SIMDs for 211 us at QM9
+// B = 2500; the small items fill the rest instead of running as a launch of their own afterwards.
+template <int R, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void k_node_mix(KArgs A) {
+    __shared__ float4 part[NW * 8 * 4 * 64];
+    const int wg = blockIdx.x, wave = threadIdx.x >> 6;
+    if (wg < A.mix_nw) { node_postw_body<R, NW>(A, wg + A.strip0, part); return; }
+    const int nab = (A.ab1 - A.ab0 + NW - 1) / NW;
+    if (wg < A.mix_nw + nab) {
+        const int it = A.ab0 + (wg - A.mix_nw) * NW + wave;
+        if (it < A.ab1) wide::node_ab_body<256>(A, it);
+        return;
+    }
+    const int t = A.g0 + (wg - A.mix_nw - nab) * NW + wave;
+    if (t < A.g1) wide::node_gram_body<256>(A, t);
+}
+
 // nf = 256 node kernels (dgt_kernels_node.h): k_node_post with one wave per strip for every full round of 1024 strips (one
 // per SIMD); the remainder r — which would otherwise occupy r SIMDs for a whole item while the rest idle — goes to a second
 // launch in which a workgroup of 4 (r <= 256) or 2 (r <= 512) waves shares each strip.  Measured on MI355X: 177 strips
 // 1.7 -> 0.75 ms/step with 4 waves; all 1409 strips with 2 / 4 waves 3.7 / 4.1 vs 3.6 ms/step with 1.
-int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A) {
+// with_ab: the pair path runs, so k_node_ab (and with A.rot the Gram tiles) follow — issued here, merged with the remainder launch
+// where that pays (JODO_OPT_NODE_MIX)
+int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A, bool with_ab) {
     const DgtDims& d = p->dims;
     const int force = p->opt[JODO_OPT_NODE_POST_WAVES];                      // 0 = automatic
     const bool rem_only = force >= 10;                                       // 12 / 14: automatic split, 2 / 4 waves for the remainder
@@ -110,6 +131,28 @@ int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A) {
         A.strip0 = 0;
         if (d.r == 2) LAUNCH(k_node_post<2>, full, 64, A); else LAUNCH(k_node_post<4>, full, 64, A);
     }
+    A.ab0 = 0; A.ab1 = 2 * p->n_strips; A.g0 = 0; A.g1 = A.rot ? p->n_gtiles : 0; A.mix_nw = 0;
+    const bool mix = with_ab && full > 0 && rem > 0 && nw >= 2 && p->opt[JODO_OPT_NODE_MIX] != 0;
+    if (mix) {
+        if (p->gt_cache_full != full) {                      // Gram tiles among the strips of the full rounds: a prefix of the sorted list
+            const int32_t* sa = p->desc.data() + p->off_gt_sa, *sc = p->desc.data() + p->off_gt_sc;
+            int c = 0;
+            while (c < p->n_gtiles && sa[c] < full && sc[c] < full) ++c;
+            p->gt_cache_full = full; p->gt_cache_count = c;
+        }
+        const int gpre = A.rot ? p->gt_cache_count : 0;
+        // remainder strips + what the full rounds already allow
+        A.strip0 = full; A.mix_nw = rem; A.ab0 = 0; A.ab1 = 2 * full; A.g0 = 0; A.g1 = gpre;
+        const int g1 = rem + (A.ab1 - A.ab0 + nw - 1) / nw + (A.g1 - A.g0 + nw - 1) / nw;
+        if (nw == 2) { if (d.r == 2) LAUNCH((k_node_mix<2, 2>), g1, 128, A); else LAUNCH((k_node_mix<4, 2>), g1, 128, A); }
+        else { if (d.r == 2) LAUNCH((k_node_mix<2, 4>), g1, 256, A); else LAUNCH((k_node_mix<4, 4>), g1, 256, A); }
+        // the remainder strips' own items
+        A.strip0 = 0; A.mix_nw = 0; A.ab0 = 2 * full; A.ab1 = 2 * p->n_strips; A.g0 = gpre; A.g1 = A.rot ? p->n_gtiles : 0;
+        const int g2 = (A.ab1 - A.ab0 + 1) / 2 + (A.g1 - A.g0 + 1) / 2;
+        if (d.r == 2) LAUNCH((k_node_mix<2, 2>), g2, 128, A); else LAUNCH((k_node_mix<4, 2>), g2, 128, A);
+        A.ab0 = 0; A.g0 = 0;
+        return JODO_OK;
+    }
     if (rem > 0) {
         A.strip0 = full;
         if (nw == 1) { if (d.r == 2) LAUNCH(k_node_post<2>, rem, 64, A); else LAUNCH(k_node_post<4>, rem, 64, A); }
@@ -117,6 +160,10 @@ int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A) {
         else { if (d.r == 2) LAUNCH((k_node_postw<2, 4>), rem, 256, A); else LAUNCH((k_node_postw<4, 4>), rem, 256, A); }
     }
     A.strip0 = 0;
+    if (with_ab) {
+        LAUNCH((wide::k_node_ab<256>), p->n_strips * 2, 64, A);
+        if (A.rot && p->n_gtiles > 0) LAUNCH((wide::k_node_gram<256>), p->n_gtiles, 64, A);
+    }
     return JODO_OK;
 }
 
@@ -210,14 +257,15 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
                     for (int i = 0; i < 6; ++i) A.wbn[i] = woff[JW_GLOBAL_COUNT + (l + 1) * JB_BLOCK_COUNT + slots[i]];
                     A.mod_base_next = 32 + (int64_t)(l + 1) * d.MB;
                 }
-                rc = launch_node_post_256(p, st, A);
+                // (+ the per-node part of coord_mlp.0 pushed through the LayerNorm and the Gram tiles, dgt_kernels_wide.h)
+                rc = launch_node_post_256(p, st, A, p->n_pitems > 0 && !pin_dir);
                 if (rc) return rc;
             } else {
                 if (d.r == 2) LAUNCH((wide::k_node_post<D, 2>), p->n_strips, 64, A); else LAUNCH((wide::k_node_post<D, 4>), p->n_strips, 64, A);
+                A.ab0 = 0; A.g0 = 0;
+                if (p->n_pitems > 0 && !pin_dir) LAUNCH((wide::k_node_ab<D>), p->n_strips * 2, 64, A);
+                if (A.rot && p->n_gtiles > 0) LAUNCH((wide::k_node_gram<D>), p->n_gtiles, 64, A);
             }
-            // per-node part of coord_mlp.0 pushed through the LayerNorm (pair update at nf = 256, dgt_kernels_wide.h)
-            if (p->n_pitems > 0 && !pin_dir) LAUNCH((wide::k_node_ab<D>), p->n_strips * 2, 64, A);
-            if (A.rot && p->n_gtiles > 0) LAUNCH((wide::k_node_gram<D>), p->n_gtiles, 64, A);
         }
         if (p->n_items > 0) {
             ProfScope ps(p, st, JODO_PROF_EDGE_UPDATE);          // exactly one of the two does the work (device flag)
@@ -281,7 +329,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     for (int i = 0; i < JW_GLOBAL_COUNT; ++i) A.wg[i] = woff[i];
     for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = 0;
     A.mod_base = 0; A.layer = 0; A.force_directed = p->force_directed; A.pin_sym = p->force_directed ? 0 : p->opt[JODO_OPT_PIN_SYMMETRIC];
-    A.pin_uni = p->opt[JODO_OPT_PIN_UNIFORM_T]; A.pre_mode = 0; A.strip0 = 0; A.item0 = 0; A.dir_split = 0; A.rot = 0; A.fuse_next = 0; A.mod_base_next = 0;
+    A.pin_uni = p->opt[JODO_OPT_PIN_UNIFORM_T]; A.pre_mode = 0; A.strip0 = 0; A.item0 = 0; A.dir_split = 0; A.rot = 0; A.mix_nw = 0; A.ab0 = 0; A.ab1 = 0; A.g0 = 0; A.g1 = 0; A.fuse_next = 0; A.mod_base_next = 0;
     for (int i = 0; i < 6; ++i) A.wbn[i] = 0;
     fill_ws(A, p, workspace);
     float* posbuf[2] = {ws_ptr<float>(workspace, p->ws.pos0), ws_ptr<float>(workspace, p->ws.pos1)};

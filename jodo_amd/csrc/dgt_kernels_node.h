@@ -258,11 +258,9 @@ __device__ __forceinline__ void node_postw_reduce(const KArgs& A, const LaneNode
     }
 }
 
-template <int R, int NW>   // mlp_ratio, waves per strip (2 or 4)
-__global__ __launch_bounds__(NW * 64, 1) void k_node_postw(KArgs A) {
-    __shared__ float4 part[NW * 8 * 4 * 64];                  // [NW waves][8 blocks][4 quads][64 lanes] = NW x 32 KiB
+template <int R, int NW>   // mlp_ratio, waves per strip (2 or 4); part: [NW waves][8 blocks][4 quads][64 lanes] float4 = NW x 32 KiB of LDS
+__device__ __forceinline__ void node_postw_body(const KArgs& A, int strip, float4* part) {
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
-    const int strip = blockIdx.x + A.strip0;
     const LaneNode L = lane_node(A, strip, j);
     const float* mr = mod_row(A, L.b) + A.mod_base;
     const float* ng2 = mr + 5 * 256;
@@ -374,6 +372,11 @@ __global__ __launch_bounds__(NW * 64, 1) void k_node_postw(KArgs A) {
             node_next_qkv(A, L, half, hx, ws, wp, g0, g0 + 24 / NW);
         }
     }
+}
+template <int R, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void k_node_postw(KArgs A) {
+    __shared__ float4 part[NW * 8 * 4 * 64];
+    node_postw_body<R, NW>(A, (int)blockIdx.x + A.strip0, part);
 }
 
 }  // namespace jd

@@ -297,14 +297,13 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
 // R = W_row h + b (A.wrow); piece 1: B = W0 (C (1 + sc)), C = W_col h (A.wcol); also the feature means of R and C, which
 // add up to the LayerNorm mean of a directed edge.  One (strip, piece) item per wave: 2 x n_strips items.
 // Rotated statistics (rot_active): the rows are Q P R / Q P C; A' = F (Q P R) with the folded F = W0 diag(1 + sc) Q^T of this
-// forward (k_fold_coord, A.ffold) — no scaling, no means (P removed them) —, and rmean receives the squared norms of the rows'
-// upper features (>= 2 De), which k_node_gram turns into the per-edge part of the variance.
+// forward (k_fold_coord, A.ffold) — no scaling, no means (P removed them).
 template <int D>
-__global__ __launch_bounds__(64, 1) void k_node_ab(KArgs A) {
+__device__ __forceinline__ void node_ab_body(const KArgs& A, int item) {
     if (D != 256 && !A.flags[FLAG_UNIFORM_T]) return;       // nf = 384 pushes coord_mlp.0 through only with a shared modulation row
     using X = Dim<D>;
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int strip = blockIdx.x >> 1, piece = blockIdx.x & 1;
+    const int strip = item >> 1, piece = item & 1;
     const LaneNode L = lane_node(A, strip, j);
     const bool rot = rot_active(A);
     const float* qsc = mod_row(A, L.b) + A.mod_base + X::M_EQUI + D;       // equi_update.time_mlp: (shift, scale)
@@ -319,10 +318,6 @@ __global__ __launch_bounds__(64, 1) void k_node_ab(KArgs A) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) x[b * 16 + s] = t[s];
         }
-        float s4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 2 * X::NE * 16; i < X::HD; ++i) s4[i & 3] = fmaf(x[i], x[i], s4[i & 3]);
-        sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     } else {
 #pragma unroll
         for (int b = 0; b < X::ND; ++b) {
@@ -333,8 +328,10 @@ __global__ __launch_bounds__(64, 1) void k_node_ab(KArgs A) {
             for (int s = 0; s < 16; ++s) { sum += t[s]; x[b * 16 + s] = t[s] * (1.f + g[s]); }
         }
     }
-    const float red = pair_sum(sum);
-    if (half == 0) A.rmean[(size_t)L.v * 2 + piece] = rot ? red : red * (1.f / D);
+    if (!rot) {
+        const float red = pair_sum(sum);
+        if (half == 0) A.rmean[(size_t)L.v * 2 + piece] = red * (1.f / D);
+    }
     const WSrc wsw = make_wsrc(A.W, lane), wsf = make_wsrc(A.ffold + (size_t)A.layer * D * D, lane);
     const WSrc ws = rot ? wsf : wsw;
     const unsigned o0 = rot ? 0u : (unsigned)(A.wb[JB_C0_W] * 4);
@@ -351,20 +348,23 @@ __global__ __launch_bounds__(64, 1) void k_node_ab(KArgs A) {
         store16T(dst, X::ND, L.v, half, b, r);
     }
 }
+template <int D>
+__global__ __launch_bounds__(64, 1) void k_node_ab(KArgs A) { node_ab_body<D>(A, A.ab0 + (int)blockIdx.x); }
 
 // Rotated statistics, the features a pair's [e ; G] projection cannot reach: |(Q P R_a + Q P C_c)[2 De:]|^2 for every directed edge
 // (a, c) of a molecule = |R''_a|^2 + |C''_c|^2 + 2 <R''_a, C''_c>.  The inner products of a 32 x 32 tile of atoms are ONE chain of
 // (D - 2 De) / 2 MFMAs: the strip-transposed row arrays are at once the A operand (atom a = lane & 31 supplies its k-slot) and the
 // B operand (atom c).  One tile per wave; tiles = ordered pairs of strips that share a molecule (plan list gt_sa / gt_sc).
 template <int D>
-__global__ __launch_bounds__(64) void k_node_gram(KArgs A) {
+__device__ __forceinline__ void node_gram_body(const KArgs& A, int tile) {
     if (!rot_active(A)) return;
     using X = Dim<D>;
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int sa = A.pd.gt_sa[blockIdx.x], sc = A.pd.gt_sc[blockIdx.x];
+    const int sa = A.pd.gt_sa[tile], sc = A.pd.gt_sc[tile];
     const float4* ra = reinterpret_cast<const float4*>(A.wrow) + (size_t)sa * X::ND * 256 + lane;
     const float4* cc = reinterpret_cast<const float4*>(A.wcol) + (size_t)sc * X::ND * 256 + lane;
     f32x16 acc = zero16();
+    float na[4] = {0.f, 0.f, 0.f, 0.f}, nc4[4] = {0.f, 0.f, 0.f, 0.f};      // squared norms of this lane's halves of R''_a, C''_c
 #pragma unroll
     for (int b = 2 * X::NE; b < X::ND; ++b)
 #pragma unroll
@@ -374,18 +374,24 @@ __global__ __launch_bounds__(64) void k_node_gram(KArgs A) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, c.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, c.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, c.w, acc, 0, 0, 0);
+            na[0] = fmaf(a.x, a.x, na[0]); na[1] = fmaf(a.y, a.y, na[1]); na[2] = fmaf(a.z, a.z, na[2]); na[3] = fmaf(a.w, a.w, na[3]);
+            nc4[0] = fmaf(c.x, c.x, nc4[0]); nc4[1] = fmaf(c.y, c.y, nc4[1]); nc4[2] = fmaf(c.z, c.z, nc4[2]); nc4[3] = fmaf(c.w, c.w, nc4[3]);
         }
+    const float nR = pair_sum((na[0] + na[1]) + (na[2] + na[3]));           // |R''|^2 of atom sa * 32 + (lane & 31), in both halves
+    const float nC = pair_sum((nc4[0] + nc4[1]) + (nc4[2] + nc4[3]));
     const int vc = sc * 32 + j;
     const int nc = A.pd.node_n[vc], noffc = A.pd.node_noff[vc], ic = A.pd.node_i[vc];
     const size_t eoffc = (size_t)A.pd.node_eoff[vc];
-    const float nC = A.rmean[(size_t)vc * 2 + 1];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {                          // accumulator register s of half h holds row 8 (s / 4) + 4 h + s % 4
-        const int va = sa * 32 + 8 * (s >> 2) + 4 * half + (s & 3);
+        const int m = 8 * (s >> 2) + 4 * half + (s & 3), va = sa * 32 + m;
+        const float nRa = __shfl(nR, m);
         if (nc > 0 && A.pd.node_n[va] > 0 && A.pd.node_noff[va] == noffc)
-            A.gramE[eoffc + (size_t)A.pd.node_i[va] * nc + ic] = A.rmean[(size_t)va * 2] + nC + 2.f * acc[s];
+            A.gramE[eoffc + (size_t)A.pd.node_i[va] * nc + ic] = nRa + nC + 2.f * acc[s];
     }
 }
+template <int D>
+__global__ __launch_bounds__(64) void k_node_gram(KArgs A) { node_gram_body<D>(A, A.g0 + (int)blockIdx.x); }
 
 // M_l = coord_mlp.0 diag(1 + sc_l) input_lin[:, e ; G] for every block l, in the streaming layout of input_lin's [e ; G]
 // part (pack_projection: [out block][quad][lane] float4) — valid when all molecules share one modulation row (device flag

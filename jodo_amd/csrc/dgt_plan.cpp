@@ -113,7 +113,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     const bool spair_auto = spair_chunk <= 0;
     p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->last_e_buf = 0;
     p->opt[JODO_OPT_FUSE_NEXT_QKV] = 1; p->opt[JODO_OPT_DIR_SPLIT] = 1; p->opt[JODO_OPT_NODE_POST_WAVES] = 0; p->opt[JODO_OPT_ATTN_VARIANT] = 0;
-    p->opt[JODO_OPT_PIN_SYMMETRIC] = 0; p->opt[JODO_OPT_PIN_UNIFORM_T] = 0; p->opt[JODO_OPT_ROT_STATS] = 1;
+    p->opt[JODO_OPT_PIN_SYMMETRIC] = 0; p->opt[JODO_OPT_PIN_UNIFORM_T] = 0; p->opt[JODO_OPT_ROT_STATS] = 1; p->opt[JODO_OPT_NODE_MIX] = 1;
     p->prof_enabled = 0; p->force_directed = 0; p->dbg_timing = nullptr;
 
     // molecules by descending size (stable): neighbouring lanes share n, big work first
@@ -288,7 +288,13 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
             }
             for (int c = lo; c <= hi; ++c) { gsa.push_back(s); gsc.push_back(c); }
         }
-        p->n_gtiles = (int)gsa.size();
+        {   // by the larger of the two strips: the tiles among the first k strips are a prefix (k_node_mix)
+            std::vector<int> ord(gsa.size());
+            std::iota(ord.begin(), ord.end(), 0);
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return std::max(gsa[a], gsc[a]) < std::max(gsa[b], gsc[b]); });
+            permute(gsa, ord); permute(gsc, ord);
+        }
+        p->n_gtiles = (int)gsa.size(); p->gt_cache_full = -1; p->gt_cache_count = 0;
         put(gsa, &p->off_gt_sa); put(gsc, &p->off_gt_sc);
     }
 
@@ -436,7 +442,7 @@ extern "C" int jodo_plan_set_option(jodo_plan* p, int option, int value) {
     if (option < 0 || option >= JODO_OPT_COUNT) return jodo_set_error(JODO_ERR_ARG, "plan_set_option: unknown option %d", option);
     if (option == JODO_OPT_NODE_POST_WAVES && value != 0 && value != 1 && value != 2 && value != 4 && value != 12 && value != 14)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: node-post waves per strip must be 0 (auto), 1, 2 or 4");
-    if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT || option == JODO_OPT_ROT_STATS) && value != 0 && value != 1)
+    if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT || option == JODO_OPT_ROT_STATS || option == JODO_OPT_NODE_MIX) && value != 0 && value != 1)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: option %d is a switch (0 or 1), got %d", option, value);
     if ((option == JODO_OPT_PIN_SYMMETRIC || option == JODO_OPT_PIN_UNIFORM_T) && (value < 0 || value > 2))
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: a pin is 0 (none), 1 or 2, got %d", value);

@@ -88,6 +88,7 @@ struct jodo_plan {
     int last_pos_buf;                // debug: which pos buffer holds the latest positions
     int last_e_buf;                  // debug: which edge-state buffer holds the latest state
     int opt[JODO_OPT_COUNT];         // jodo_plan_set_option values
+    int gt_cache_full, gt_cache_count;   // Gram tiles whose strips all lie below gt_cache_full (tiles are sorted by their larger strip)
 };
 
 int dgt_dims_from_cfg(const jodo_cfg* cfg, DgtDims* d);
