@@ -62,9 +62,11 @@ int launch_update(jodo_plan* p, hipStream_t st, KArgs& A, bool pin_pair, bool pi
 
 int jd_launch_edge_attn(jodo_plan* p, hipStream_t st, KArgs& A, int D, bool tuned, bool pin_pair, bool pin_dir) {
     if (D == 256) return tuned ? launch_attn<256, true>(p, st, A, pin_pair, pin_dir) : launch_attn<256, false>(p, st, A, pin_pair, pin_dir);
+    if (D == 128) return launch_attn<128, false>(p, st, A, pin_pair, pin_dir);
     return launch_attn<384, false>(p, st, A, pin_pair, pin_dir);
 }
 
 int jd_launch_edge_update(jodo_plan* p, hipStream_t st, KArgs& A, int D, bool pin_pair, bool pin_dir) {
+    if (D == 128) return launch_update<128>(p, st, A, pin_pair, pin_dir);
     return D == 256 ? launch_update<256>(p, st, A, pin_pair, pin_dir) : launch_update<384>(p, st, A, pin_pair, pin_dir);
 }

@@ -283,6 +283,8 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
     p->last_pos_buf = cur ^ 1;
     LAUNCH((wide::k_node_head<D>), p->n_strips, 64, A);
     switch (d.KEH / 32) {
+        case 3: rc = launch_edge_head<D, 3>(st, A); break;
+        case 4: rc = launch_edge_head<D, 4>(st, A); break;
         case 5: rc = launch_edge_head<D, 5>(st, A); break;
         case 6: rc = launch_edge_head<D, 6>(st, A); break;
         case 7: rc = launch_edge_head<D, 7>(st, A); break;
@@ -365,6 +367,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
                  uflag);
     if (rc) return rc;
     if (!d.wide) return forward_blocks<256, true>(p, st, A, woff, posbuf, pro);
+    if (d.D == 128) return forward_blocks<128, false>(p, st, A, woff, posbuf, pro);
     return d.D == 256 ? forward_blocks<256, false>(p, st, A, woff, posbuf, pro) : forward_blocks<384, false>(p, st, A, woff, posbuf, pro);
 }
 

@@ -70,7 +70,7 @@ struct AttnT {
                                          // 3.91 -> 4.00 ms/step, 455 -> 490 registers) — the block's wait is issue, not row latency; kept as a switch
     static constexpr bool LDSS = D_ > 256;                         // running softmax state in LDS (registers are short at nf = 384:
                                                                    // D/2 accumulators + D/8 inputs per lane; LDS is free, no resident weights)
-    static constexpr float INV_SQRT_C = D_ == 256 ? 0.25f : (D_ == 384 ? 0.20412414523193150f : 0.f);
+    static constexpr float INV_SQRT_C = D_ == 256 ? 0.25f : (D_ == 384 ? 0.20412414523193150f : (D_ == 128 ? 0.35355339059327379f : 0.f));
     static constexpr int M_EDGE = 6 * D_, M_GBF = 6 * D_ + 6 * (D_ / 4) + 2 * D_;
     static_assert(!(LDS_EE || LDS_L0) || D_ == 256, "LDS-resident weights are sized for nf = 256");
     static_assert(C % 8 == 0, "message blocks are split at register 8 between two heads");

@@ -1,5 +1,5 @@
 // Width-generic kernel set (template <int D>): every per-block kernel of dgt_kernels_{pre,node,block,post}.h
-// restated for any node width D = 128 * k (BASELINE config 4 runs nf = 384: De = 96, T = 1536, 14 x 27
+// restated for any node width D = 128 * k (the README's GEOM Base model runs nf = 128, BASELINE config 4 nf = 384: De = 96, T = 1536, 14 x 27
 // score channels, 16 x 24 value channels).  Same strip model, same HBM layouts, same launch sequence;
 // what differs from the tuned nf = 256 set:
 //   * all weights are streamed from L2 through the software-pipelined ring (the K = De projections of
@@ -27,9 +27,8 @@ struct Dim {
     static constexpr int KQD = D_ / 8, KQE = D_ / 32;             // weight quads per output block for K = D / K = De
     static constexpr int PG = (D_ % 256 == 0) ? 8 : 4;             // weight quads in flight per prefetch group (must divide D/32)
     static constexpr int C = D_ / 16;                              // value channels per head
-    static constexpr float INV_SQRT_C = D_ == 256 ? 0.25f : (D_ == 384 ? 0.20412414523193150f : 0.f);
-    static constexpr int CNP = D_ / 4, NRO = CNP / 32;             // padded node readout width / blocks
-    static constexpr int CEP = (D_ / 16 + 15) / 16 * 16;           // padded edge readout width (16 or 32)
+    static constexpr float INV_SQRT_C = D_ == 256 ? 0.25f : (D_ == 384 ? 0.20412414523193150f : (D_ == 128 ? 0.35355339059327379f : 0.f));
+    // (the padded readout widths cnp / cep depend on n_layers too: run-time values A.d.cnp, A.d.cep — dgt_plan.cpp)
     // modulation slice of one block: node 6 x D | edge 6 x De | equi (shift, scale) 2 x D | gbf (scale, shift)
     static constexpr int M_EDGE = 6 * D_, M_EQUI = 6 * D_ + 6 * (D_ / 4), M_GBF = 6 * D_ + 6 * (D_ / 4) + 2 * D_;
     static constexpr int M_WG = M_GBF + 32, M_BS = M_WG + D_;      // coord_mlp.0 pushed through the LayerNorm: W0 (1 + sc) | W0 sh + b0
@@ -280,15 +279,16 @@ __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {
     }
     {   // readout node_l(h) -> atom_hids[:, D + l*CNP ...]
         const float* bias = A.W + A.wb[JB_NRO_B];
-#pragma unroll
-        for (int b = 0; b < X::NRO; ++b) {
+        const int nro = A.d.cnp / 32;                       // 2 D / n_layers features padded to whole blocks
+#pragma unroll 1
+        for (int b = 0; b < nro; ++b) {
             const unsigned cur = oNro + (unsigned)b * X::KQD * 1024;
             float bb[16], r[16];
             load16(bias + b * 32 + half * 16, bb);
-            f32x16 acc = mfma_block_p<X::KQD>(wp, ws, cur, b + 1 < X::NRO ? cur + X::KQD * 1024 : oNro, hx, zero16());
+            f32x16 acc = mfma_block_p<X::KQD>(wp, ws, cur, b + 1 < nro ? cur + X::KQD * 1024 : oNro, hx, zero16());
 #pragma unroll
             for (int s = 0; s < 16; ++s) r[s] = acc[s] + bb[s];
-            store16(A.ahid + (size_t)L.v * A.d.KNH + D + A.layer * X::CNP + b * 32 + half * 16, r);
+            store16(A.ahid + (size_t)L.v * A.d.KNH + D + A.layer * A.d.cnp + b * 32 + half * 16, r);
         }
     }
 }
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
             float rr[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) rr[s] = acc[s] + bb[s];
-            if (inr && (half == 0 || X::CEP == 32)) store16(A.ehid + r * A.d.KEH + X::De + A.layer * X::CEP + half * 16, rr);
+            if (inr && (half == 0 || A.d.cep == 32)) store16(A.ehid + r * A.d.KEH + X::De + A.layer * A.d.cep + half * 16, rr);
         }
         // ---- equivariant update: u = W_e e + W_d G + (W_row h_a + b) + W_col h_c ----
         float uu[X::HD];
@@ -742,9 +742,9 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             float rr[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) rr[s] = acc[s] + bb[s];
-            if (P.ok && dsel != 1 && (half == 0 || X::CEP == 32)) {
-                store16(A.ehid + P.rij * A.d.KEH + X::De + A.layer * X::CEP + half * 16, rr);
-                store16(A.ehid + P.rji * A.d.KEH + X::De + A.layer * X::CEP + half * 16, rr);
+            if (P.ok && dsel != 1 && (half == 0 || A.d.cep == 32)) {
+                store16(A.ehid + P.rij * A.d.KEH + X::De + A.layer * A.d.cep + half * 16, rr);
+                store16(A.ehid + P.rji * A.d.KEH + X::De + A.layer * A.d.cep + half * 16, rr);
             }
         }
         PT(2);

@@ -39,8 +39,8 @@ static void permute(std::vector<int32_t>& a, const std::vector<int>& ord) {
 }
 
 int dgt_dims_from_cfg(const jodo_cfg* c, DgtDims* d) {
-    if (c->nf != 256 && c->nf != 384)
-        return jodo_set_error(JODO_ERR_UNSUPPORTED, "nf=%d: kernels are built for nf=256 and nf=384", c->nf);
+    if (c->nf != 128 && c->nf != 256 && c->nf != 384)
+        return jodo_set_error(JODO_ERR_UNSUPPORTED, "nf=%d: kernels are built for nf=128, nf=256 and nf=384", c->nf);
     if (c->layout != 0 && c->layout != 1) return jodo_set_error(JODO_ERR_ARG, "layout=%d (0 or 1)", c->layout);
     if (c->n_heads != 16 || c->n_extra != 2)
         return jodo_set_error(JODO_ERR_UNSUPPORTED, "n_heads=%d n_extra_heads=%d: kernels are built for 16/2", c->n_heads, c->n_extra);
@@ -53,14 +53,17 @@ int dgt_dims_from_cfg(const jodo_cfg* c, DgtDims* d) {
     d->D = c->nf; d->De = c->nf / 4; d->T = c->nf * 4; d->L = c->n_layers; d->H = c->n_heads; d->XH = c->n_extra;
     d->SH = d->H - d->XH; d->C = d->D / d->H; d->SC = (d->H * d->C) / d->SH; d->r = c->mlp_ratio;
     d->nd = c->in_node_dim; d->ch = c->edge_ch; d->cond_ch = c->cond_ch;
-    d->wide = (c->nf != 256 || c->layout == 1) ? 1 : 0;
+    // per-block readout widths 2 D / L and 2 De / L (models/mol_gnn.py:452-455), padded to whole 32-row blocks / to 16 or 32
+    const int cn = (2 * d->D) / d->L, ce = (2 * d->De) / d->L;
+    d->cnp = std::max(d->D / 4, (cn + 31) / 32 * 32);
+    d->cep = std::max((d->D / 16 + 15) / 16 * 16, (ce + 15) / 16 * 16);            // 64 / 16 at nf 256 (L >= 8), 96 / 32 at nf 384
+    if (d->cep > 32) return jodo_set_error(JODO_ERR_UNSUPPORTED, "n_layers=%d at nf=%d: edge readout width %d beyond one 32-row block", d->L, d->D, ce);
+    // the nf = 256 node kernels of dgt_kernels_node.h are written for the 64-wide node readout
+    d->wide = (c->nf != 256 || c->layout == 1 || d->cnp != 64) ? 1 : 0;
     int tail = d->SC - 16;
     d->QKP = d->wide ? d->SH * 32 : (d->SH / 2 + (tail + 1) / 2) * 32;      // wide: one head per 32-row block
     d->ndp = (2 * d->nd + 7) / 8 * 8;
     d->einp = (2 * d->ch + 7) / 8 * 8;
-    d->cnp = d->D / 4; d->cep = (d->D / 16 + 15) / 16 * 16;               // 64 / 16 at nf 256, 96 / 32 at nf 384
-    if ((2 * d->D) / d->L > d->cnp || (2 * d->De) / d->L > d->cep)
-        return jodo_set_error(JODO_ERR_UNSUPPORTED, "n_layers=%d gives readout widths beyond the padded slots", d->L);
     d->KNH = d->D + d->L * d->cnp; d->KEH = d->De + d->L * d->cep;
     if (d->KEH % 32 != 0) return jodo_set_error(JODO_ERR_UNSUPPORTED, "edge head width %d not a multiple of 32", d->KEH);
     d->MB = 6 * d->D + 6 * d->De + 2 * d->D + 32 + 2 * d->D;     // node | edge | equi (shift, scale) | gbf | W0 (1 + scale) | W0 shift + b0

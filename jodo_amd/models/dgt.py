@@ -125,17 +125,17 @@ class _DGTBase(nn.Module):
         D, De, L = m.nf, m.nf // 4, m.n_layers
         T = D * 4
         cond_ch = int(m.cond_ch) if self.conditional else 0
-        if D not in (256, 384) or m.n_heads != 16 or m.n_extra_heads != 2 or m.mlp_ratio not in (2, 4):
-            raise NotImplementedError("HIP kernels are built for nf in {256, 384}, n_heads=16, n_extra_heads=2, "
+        if D not in (128, 256, 384) or m.n_heads != 16 or m.n_extra_heads != 2 or m.mlp_ratio not in (2, 4):
+            raise NotImplementedError("HIP kernels are built for nf in {128, 256, 384}, n_heads=16, n_extra_heads=2, "
                                       "mlp_ratio in {2,4} (got nf=%d heads=%d/%d ratio=%d)" %
                                       (D, m.n_heads, m.n_extra_heads, m.mlp_ratio))
         # kernel_layout (not a reference key): 'wide' runs the width-generic kernel set at nf=256 too (tests)
         wide = getattr(m, 'kernel_layout', 'auto') == 'wide'
         self.dims = ModelDims(D, L, m.n_heads, m.n_extra_heads, m.mlp_ratio, in_node_dim, m.edge_ch, cond_ch, wide=wide)
-        if self.dims.cn > self.dims.cnp or self.dims.ce > self.dims.cep or L % 2:
-            raise NotImplementedError("n_layers=%d: per-block readout widths (%d, %d) exceed the padded slots (%d, %d) "
-                                      "or n_layers is odd; supported: even n_layers >= 8" %
-                                      (L, self.dims.cn, self.dims.ce, self.dims.cnp, self.dims.cep))
+        if self.dims.cep > 32 or self.dims.KEH % 32 or not 3 <= self.dims.KEH // 32 <= 15 or self.dims.KEH // 32 == 14 or L > 16:
+            raise NotImplementedError("n_layers=%d at nf=%d: the edge head input (De + n_layers x %d = %d) must be a multiple of 32 in "
+                                      "[96, 480] and the per-block edge readout (%d) at most 32 wide" %
+                                      (L, D, self.dims.cep, self.dims.KEH, self.dims.ce))
         self.edge_th = float(m.edge_quan_th)
         self.spatial_cut_off = float(m.spatial_cut_off)
         self.n_layers = L

@@ -13,12 +13,15 @@ class ModelDims:
         self.SC = (n_heads * self.C) // self.SH
         # wide = width-generic kernel set + its q/k arrangement (always for nf != 256; optional at 256)
         self.wide = bool(nf != 256) if wide is None else bool(wide or nf != 256)
-        tail = self.SC - 16
-        self.QKP = self.SH * 32 if self.wide else (self.SH // 2 + (tail + 1) // 2) * 32
         self.ndp = (2 * in_node_dim + 7) // 8 * 8
         self.einp = (2 * edge_ch + 7) // 8 * 8
         self.cn, self.ce = (2 * nf) // n_layers, (2 * self.De) // n_layers
-        self.cnp, self.cep = nf // 4, (nf // 16 + 15) // 16 * 16          # 64 / 16 at nf 256, 96 / 32 at nf 384
+        # padded per-block readout widths (mirror of dgt_dims_from_cfg): 64 / 16 at nf 256 (L >= 8), 96 / 32 at nf 384, 64 / 16 at nf 128 L 6
+        self.cnp = max(nf // 4, (self.cn + 31) // 32 * 32)
+        self.cep = max((nf // 16 + 15) // 16 * 16, (self.ce + 15) // 16 * 16)
+        self.wide = self.wide or self.cnp != 64
+        tail = self.SC - 16
+        self.QKP = self.SH * 32 if self.wide else (self.SH // 2 + (tail + 1) // 2) * 32
         self.KNH, self.KEH = nf + n_layers * self.cnp, self.De + n_layers * self.cep
         # modulation slice of a block: node 6D | edge 6De | equi (shift, scale) 2D | gbf 2 (+30 pad) | coord_mlp.0 pushed
         # through the LayerNorm of equi_update: W0 (1 + scale) [D] | W0 shift + b0 [D]  (csrc/dgt_kernels_wide.h, pair update)

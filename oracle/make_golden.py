@@ -18,6 +18,7 @@ cond_DGT_concat with `jodo_amd.models.init_utils.deterministic_init_` (weights a
                                                e_block, models/mol_gnn.py:562-568) captured with forward hooks
   traj_qm9_anc50.npz                           50-step ancestral trajectory; besides the replayable noise it records
                                                every step's input state and the reference's prediction (teacher forcing)
+  fwd_geom_base.npz                            the README's GEOM Base model: nf = 128, n_layers = 6 (README.md:150)
   fwd_geom_l8.npz                              GEOM nf = 256 with n_layers = 8 (BASELINE configs[2] as worded), mlp_ratio 4
   traj_geom_anc3.npz                           3-step ancestral trajectory of the GEOM model (3 bond channels: aromatic decode)
   grad_qm9.npz                                 the reference's own training loss + loss.backward() gradients of selected
@@ -406,6 +407,8 @@ def main():
         ('blocks_qm9.npz', lambda f: blocks_fixture(ref, 'vpsde_qm9_uncond_jodo', [3, 9, 17, 29], 17, f)),
         ('blocks_geom.npz', lambda f: blocks_fixture(ref, 'vpsde_geom_uncond_jodo', [12, 33], 18, f)),
         ('fwd_geom_l8.npz', lambda f: forward_fixture(ref, 'vpsde_geom_uncond_jodo', [7, 30, 52, 52, 75], 19, f, n_layers=8)),   # BASELINE configs[2] as worded: nf 256, 8 layers, r 4
+        # the README's GEOM "Base" model: --config.model.n_layers 6 --config.model.nf 128 (README.md:150,162); one molecule above a group (n > 128)
+        ('fwd_geom_base.npz', lambda f: forward_fixture(ref, 'vpsde_geom_uncond_jodo', [9, 31, 64, 75, 131, 2], 20, f, nf=128, n_layers=6)),
         ('grad_qm9.npz', lambda f: grad_fixture(ref, f)),
         ('traj_qm9_anc5.npz', lambda f: ancestral_fixture(ref, f)),
         # GEOM (3 bond channels: the aromatic decode branch of sampling.py:79-81), short

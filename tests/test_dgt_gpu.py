@@ -44,7 +44,9 @@ def run(model, xh, ex, nl, nm, em, cx=None, cex=None, ctx=None):
                                           ("fwd_geom384_big.npz", "auto"),
                                           ("fwd_qm9.npz", "wide"), ("fwd_geom.npz", "wide"), ("fwd_cond.npz", "wide"),
                                           # BASELINE configs[2] as worded: GEOM nf 256 with 8 layers (r 4, nd 17, ch 3)
-                                          ("fwd_geom_l8.npz", "auto"), ("fwd_geom_l8.npz", "wide")])
+                                          ("fwd_geom_l8.npz", "auto"), ("fwd_geom_l8.npz", "wide"),
+                                          # the README's GEOM Base model (README.md:150): nf 128, 6 layers, n up to 131
+                                          ("fwd_geom_base.npz", "auto")])
 def test_hip_matches_reference_fixture(fname, layout):
     fx = load_fixture(fname)
     over = dict(kernel_layout=layout)
@@ -125,6 +127,8 @@ def test_attention_kernel_variants_agree():
     ('vpsde_geom_uncond_jodo', [70, 33, 12, 1, 2], 1.5, dict(nf=384)),                  # BASELINE config 4 width
     ('vpsde_geom_uncond_jodo', [19] * 8 + [6] * 10, 1.0, dict(nf=384, n_layers=8, mlp_ratio=2)),
     ('vpsde_qm9_uncond_jodo', [29, 1, 2, 18, 18, 7, 23], 1.5, dict(kernel_layout='wide')),
+    ('vpsde_geom_uncond_jodo', [40, 33, 12, 1, 2], 1.5, dict(nf=128, n_layers=6)),           # GEOM Base
+    ('vpsde_qm9_uncond_jodo', [29, 1, 2, 18, 18, 7, 23], 1.5, dict(n_layers=6)),              # nf 256 with the 96-wide node readout
 ])
 def test_uniform_and_per_molecule_noise_levels_agree(cfg_name, n_nodes, gain, over):
     """One noise level for the whole batch (how every sampler calls an unconditional model) takes the shared-row path:
@@ -162,6 +166,7 @@ def test_uniform_and_per_molecule_noise_levels_agree(cfg_name, n_nodes, gain, ov
     # float64 (tools/rot_err.py): rotated 1.1e-4, plain fold 2.7e-4, the float32 oracle itself 4e-5
     ('vpsde_geom_uncond_jodo', [70, 33, 12, 150, 1, 2], 1.5, {}, 4e-4),
     ('vpsde_geom_uncond_jodo', [70, 33, 12, 1, 2], 1.5, dict(nf=384), 5e-5),
+    ('vpsde_geom_uncond_jodo', [70, 33, 12, 1, 2], 1.5, dict(nf=128, n_layers=6), 5e-5),
 ])
 def test_rotated_statistics_match_plain_fold_and_oracle(cfg_name, n_nodes, gain, over, atol):
     """JODO_OPT_ROT_STATS (default on): under a shared modulation row the pair update takes the LayerNorm statistics of

@@ -13,10 +13,11 @@ from oracle import dgt_oracle as O
 from helpers import OracleModel, check_decodes, load_fixture, make_config, make_model, masks, state_dict_cpu
 
 
-@pytest.mark.parametrize("fname", ["fwd_qm9.npz", "fwd_geom.npz", "fwd_cond.npz"])
+@pytest.mark.parametrize("fname", ["fwd_qm9.npz", "fwd_geom.npz", "fwd_cond.npz", "fwd_geom_base.npz"])
 def test_oracle_matches_reference_fixture(fname):
     fx = load_fixture(fname)
-    cfg = make_config(str(fx['cfg_name']))
+    over = {k: int(fx[k]) for k in ('nf', 'n_layers') if k in fx}       # fwd_geom_base: the README's nf 128 / 6-layer GEOM model
+    cfg = make_config(str(fx['cfg_name']), **over)
     sd = state_dict_cpu(make_model(cfg, int(fx['seed'])))
     hp = O.Hyper.from_config(cfg)
     nm, em = masks(fx['n_nodes'].tolist())

@@ -101,6 +101,7 @@ def test_small_and_qk_maps_are_bijections():
 
 @pytest.mark.parametrize("cfg_name,over", [('vpsde_qm9_uncond_jodo', {}), ('vpsde_qm9_uncond_jodo', dict(kernel_layout='wide')),
                                            ('vpsde_geom_uncond_jodo', {}), ('vpsde_geom_uncond_jodo', dict(nf=384)),
+                                           ('vpsde_geom_uncond_jodo', dict(nf=128, n_layers=6)), ('vpsde_qm9_uncond_jodo', dict(n_layers=6)),
                                            ('vpsde_qm9_cond_jodo', {})])
 def test_c_packer_equals_python_packer(cfg_name, over):
     """jodo_dgt_pack_weights_host (csrc/dgt_pack.cpp) against the independent Python packer: same blob bit for bit,
