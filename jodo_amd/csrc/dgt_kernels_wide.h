@@ -332,8 +332,9 @@ __device__ __forceinline__ void node_ab_body(const KArgs& A, int item) {
         const float red = pair_sum(sum);
         if (half == 0) A.rmean[(size_t)L.v * 2 + piece] = red * (1.f / D);
     }
-    const WSrc wsw = make_wsrc(A.W, lane), wsf = make_wsrc(A.ffold + (size_t)A.layer * D * D, lane);
-    const WSrc ws = rot ? wsf : wsw;
+    // (the base pointer is selected, not the descriptor: a select between two buffer resources went through scratch)
+    const float* wbase = rot ? A.ffold + (size_t)A.layer * D * D : A.W;
+    const WSrc ws = make_wsrc(wbase, lane);
     const unsigned o0 = rot ? 0u : (unsigned)(A.wb[JB_C0_W] * 4);
     WPipe<X::PG> wp;
     wpipe_prime(wp, ws, o0);

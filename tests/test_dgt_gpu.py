@@ -129,6 +129,7 @@ def test_attention_kernel_variants_agree():
     ('vpsde_qm9_uncond_jodo', [29, 1, 2, 18, 18, 7, 23], 1.5, dict(kernel_layout='wide')),
     ('vpsde_geom_uncond_jodo', [40, 33, 12, 1, 2], 1.5, dict(nf=128, n_layers=6)),           # GEOM Base
     ('vpsde_qm9_uncond_jodo', [29, 1, 2, 18, 18, 7, 23], 1.5, dict(n_layers=6)),              # nf 256 with the 96-wide node readout
+    ('vpsde_qm9_uncond_jodo', [29, 1, 2, 18, 18, 7, 23], 1.5, dict(n_layers=5)),              # an odd number of blocks
 ])
 def test_uniform_and_per_molecule_noise_levels_agree(cfg_name, n_nodes, gain, over):
     """One noise level for the whole batch (how every sampler calls an unconditional model) takes the shared-row path:
@@ -410,6 +411,10 @@ def test_per_block_intermediates(fname, layout):
     # molecules are dealt to the ranks first; 313 = a quarter round)
     ('vpsde_qm9_cond_jodo', 'qm9_second_half', 1250, {}, 64),
     ('vpsde_qm9_cond_jodo', 'qm9_second_half', 313, {}, 64),
+    # ~1 100 node strips: one full round of k_node_post + a remainder of < 256 strips, i.e. the four-wave form of the merged
+    # remainder launch (k_node_mix<., 4>; B = 2500 takes the two-wave form), 24 molecules re-evaluated
+    ('vpsde_qm9_uncond_jodo', 'qm9_with_h', 1950, {}, 24),
+    ('vpsde_geom_uncond_jodo', 'geom_with_h_1', 256, dict(nf=128, n_layers=6), 24),      # the README's GEOM Base model at a real batch
 ])
 def test_full_size_batches_match_oracle_on_sampled_molecules(cfg_name, info, B, over, n_sub):
     """The batch sizes the bench numbers are quoted on: a first-step and a self-conditioned evaluation of the FULL

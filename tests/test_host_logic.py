@@ -36,11 +36,24 @@ def test_create_model_exposes_dataparallel_keys():
 
 
 def test_unsupported_settings_fail_loudly():
-    for key, val in (('dist_gbf', False), ('cond_time', False), ('pred_data', False), ('nf', 512), ('n_layers', 4)):
+    # (n_layers = 3 at nf 256: the per-block edge readout, 2 De / 3 = 42 features, does not fit one 32-row block)
+    for key, val in (('dist_gbf', False), ('cond_time', False), ('pred_data', False), ('nf', 512), ('n_layers', 3)):
         cfg = configs.get('vpsde_qm9_uncond_jodo')
         cfg.model[key] = val
         with pytest.raises(NotImplementedError):
             get_model_class('DGT_concat')(cfg)
+
+
+def test_reference_model_variants_construct():
+    """The README's model variants beside the three configs: GEOM Base (nf 128, 6 layers, README.md:150) and Large (nf 384,
+    README.md:168); derived sizes as the C side computes them (csrc/dgt_plan.cpp dgt_dims_from_cfg)."""
+    for over, want in ((dict(nf=128, n_layers=6), (64, 16, 512, 128, True)), (dict(nf=384), (96, 32, 1344, 416, True)),
+                       (dict(n_layers=8), (64, 16, 768, 192, False)), (dict(), (64, 16, 896, 224, False))):
+        cfg = configs.get('vpsde_geom_uncond_jodo')
+        for k, v in over.items():
+            cfg.model[k] = v
+        d = get_model_class('DGT_concat')(cfg).dims
+        assert (d.cnp, d.cep, d.KNH, d.KEH, d.wide) == want, (over, (d.cnp, d.cep, d.KNH, d.KEH, d.wide))
 
 
 def test_cosine_schedule_values():
