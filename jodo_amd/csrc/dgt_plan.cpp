@@ -220,11 +220,35 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         }
         const int ng = (int)g_nmax.size();
         p->n_agroups = ng;
-        if (achunk <= 0) {                                      // automatic: coarse items amortise the per-item partial
-            int64_t iters = 0;                                  // (1 KiB per atom), fine items fill 256 CUs evenly
-            for (int g = 0; g < ng; ++g) iters += std::max(1, g_nmax[g] / 2);
-            achunk = 6;                                         // measured at QM9 B = 2500: 1 -> 5.45, 3 -> 4.42, 6 -> 4.05, 8 -> 4.25,
-            while (achunk > 1 && iters / achunk < 2 * 256) --achunk;   // 15 -> 4.67 ms/step for the kernel (k_node_post follows the part count)
+        if (achunk <= 0 && p->dims.wide) {                      // streamed-weight kernels (nf 128 / 384): no staging cost per item;
+            int64_t iters = 0;                                  // the model below, fitted to the LDS-resident kernel, picked coarser
+            for (int g = 0; g < ng; ++g) iters += std::max(1, g_nmax[g] / 2);    // items and lost 27 % at nf 384 (39.5 -> 50.3 ms/step)
+            achunk = 6;
+            while (achunk > 1 && iters / achunk < 2 * 256) --achunk;
+        }
+        if (achunk <= 0) {
+            // automatic: coarse items amortise the per-item cost (96 KiB of weights staged, 1 KiB of partial per atom), fine items
+            // fill the chip evenly — and the kernel's time is the makespan of ~10^3 items on 256 one-workgroup CUs, which moves
+            // by +-10 % with the decomposition (measured at QM9 B = 2500, ms/step of the kernel for 4 / 5 / 6 / 7 / 8 / 9 / 10 / 12
+            // offsets per item: 4.12 / 4.32 / 3.91 / 4.06 / 4.08 / 3.79 / 4.23 / 4.47).  A two-parameter cost model — item time =
+            // 0.8 + (number of offsets), in units of one offset, fitted to those eight points — reproduces the ranking, so the plan
+            // simulates the launch (items longest first onto the least loaded CU, exactly what the dispatcher does) for every
+            // chunk size and keeps the best; ties go to the coarser decomposition (fewer partials to merge).
+            std::vector<double> slot(256);
+            double best = 0.0;
+            for (int c = 1; c <= 16; ++c) {
+                std::vector<int> len;
+                for (int g = 0; g < ng; ++g) {
+                    if (g_big[g]) { len.push_back(g_nmax[g]); continue; }        // directed items: not modelled
+                    const int dmax = g_nmax[g] / 2, parts = std::max(1, (dmax + c - 1) / c), cp = dmax > 0 ? (dmax + parts - 1) / parts : 0;
+                    for (int q = 0; q < parts; ++q) len.push_back(std::min(dmax, (q + 1) * cp) - std::min(dmax, q * cp));
+                }
+                std::stable_sort(len.begin(), len.end(), [](int a, int b) { return a > b; });
+                std::fill(slot.begin(), slot.end(), 0.0);
+                for (int l : len) { auto it = std::min_element(slot.begin(), slot.end()); *it += 0.8 + (double)l; }
+                const double mk = *std::max_element(slot.begin(), slot.end());
+                if (achunk <= 0 || mk <= best) { best = mk; achunk = c; }
+            }
         }
         struct It { int g, t0, t1, part, big; };
         std::vector<It> pit, dit;
