@@ -181,6 +181,10 @@ enum jodo_plan_option {
 };
 int jodo_plan_set_option(jodo_plan* plan, int option, int value);
 
+/* debug / tests: the pair-mode attention schedule of a plan.  out8 = items, their total pair offsets, partials per atom (max),
+ * persistent schedule (0 / 1), and for a persistent schedule: smallest / largest slot load (offsets), most items in a slot, idle slots */
+int jodo_debug_attn_schedule(const jodo_plan* plan, int64_t* out8);
+
 /* debug: copy an internal per-block intermediate out of the workspace after a forward.
  * what: 0 = h [Nn,D], 1 = e [rows,De], 2 = pos [Nn,4] (raw, not centred), 3 = the attention partials
  * [Nn, parts, D] (unnormalised) of the last block run, 5 = the modulation row, 6 = q.  dst must hold the full array; returns element count via *count. */

@@ -38,10 +38,11 @@ template <int D, bool TUNED>
 int launch_attn(jodo_plan* p, hipStream_t st, KArgs& A, bool pin_pair, bool pin_dir) {
     if (p->n_aitems > 0 && !pin_dir) {
         const int var = TUNED ? p->opt[JODO_OPT_ATTN_VARIANT] : 0;
-        if (var == 1) LAUNCH((k_edge_attn<D, !TUNED, true, TUNED ? 1 : 0>), p->n_aitems, ATT_WAVES * 64, A);
-        else if (var == 2) LAUNCH((k_edge_attn<D, !TUNED, true, TUNED ? 2 : 0>), p->n_aitems, ATT_WAVES * 64, A);
-        else if (var == 3) LAUNCH((k_edge_attn<D, !TUNED, true, TUNED ? 3 : 0>), p->n_aitems, ATT_WAVES * 64, A);
-        else LAUNCH((k_edge_attn<D, !TUNED, true, 0>), p->n_aitems, ATT_WAVES * 64, A);
+        const int grid = p->a_persist ? JODO_ATT_SLOTS : p->n_aitems;          // persistent: one workgroup per slot of the plan's schedule
+        if (var == 1) LAUNCH((k_edge_attn<D, !TUNED, true, TUNED ? 1 : 0>), grid, ATT_WAVES * 64, A);
+        else if (var == 2) LAUNCH((k_edge_attn<D, !TUNED, true, TUNED ? 2 : 0>), grid, ATT_WAVES * 64, A);
+        else if (var == 3) LAUNCH((k_edge_attn<D, !TUNED, true, TUNED ? 3 : 0>), grid, ATT_WAVES * 64, A);
+        else LAUNCH((k_edge_attn<D, !TUNED, true, 0>), grid, ATT_WAVES * 64, A);
     }
     if (p->n_aditems > 0 && (!pin_pair || p->has_big)) LAUNCH((k_edge_attn<D, !TUNED, false>), p->n_aditems, ATT_WAVES * 64, A);
     return JODO_OK;

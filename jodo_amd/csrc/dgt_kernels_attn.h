@@ -247,9 +247,12 @@ template <int D, bool WQK, bool PAIR, int VAR = 0>
 __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
     using X = AttnT<D, WQK, VAR>;
     constexpr bool PREF = X::PREF;
-    const int it = blockIdx.x;
     const bool asym = A.flags[FLAG_ASYM] != 0;
-    if (PAIR ? asym : !(asym || A.pd.ad_big[it])) return;
+    if (PAIR ? asym : !(asym || A.pd.ad_big[blockIdx.x])) return;
+    // pair mode under the plan's wrap-around schedule: this workgroup is slot blockIdx.x and works through its items (the
+    // resident weights below are staged once); otherwise one item per workgroup
+    const bool pers = PAIR && A.pd.a_persist != 0;
+    const int it0 = pers ? A.pd.aw_off[blockIdx.x] : (int)blockIdx.x, it1 = pers ? A.pd.aw_off[blockIdx.x + 1] : (int)blockIdx.x + 1;
     __shared__ float4 wl[(X::LDS_EE ? 32 * 64 : 0) + (X::LDS_L0 ? (X::LDS_TAIL ? 64 : 56) * 64 : 0) + (X::LDS_EE && !X::LDS_TAIL ? 0 : 1)];   // edge_emb (2 x 16 quads) | lin_edge0 (8 x 8 quads)
     __shared__ float4 sx[PAIR ? 2 * 256 : 1];            // scores handed to the partner: [quad][half * 128 + lane], heads 8h .. 8h + 7
     __shared__ float4 ux[PAIR ? (X::PHB == 1 ? 2 : X::PHB) * 4 * 256 : 1];   // unweighted messages: one block double buffered, or a phase of PHB blocks
@@ -260,6 +263,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
     if constexpr (X::LDS_EE || X::LDS_L0) __syncthreads();
     const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
     const int ln = wave * 32 + (lane & 31);             // lane of the group
+  for (int it = it0; it < it1; ++it) {
+    if (it > it0) __syncthreads();                      // the hand-over buffers of the previous item have been read everywhere
     const int grp = PAIR ? A.pd.ai_group[it] : A.pd.ad_group[it];
     const int t0 = PAIR ? A.pd.ai_t0[it] : A.pd.ad_t0[it], t1 = PAIR ? A.pd.ai_t1[it] : A.pd.ad_t1[it];
     const int part = PAIR ? A.pd.ai_part[it] : A.pd.ad_part[it];
@@ -516,6 +521,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
     }
     APT(6);
     APT_FLUSH;
+  }
 }
 
 // merge the attention partials of a node (k_node_post*): hhat = sum_p acc_p e^{m_p - M} / (sum_p l_p e^{m_p - M} + 1e-16),

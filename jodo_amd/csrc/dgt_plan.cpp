@@ -187,11 +187,14 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     // largest remaining molecules that still fit (lanes of a smaller molecule idle during the larger offsets, which
     // is better than idling throughout).  A molecule larger than a group (n > 128, GEOM's tail) gets groups of
     // consecutive atoms of its own and is walked in directed form (every lane visits all its sources, no hand-over).
-    std::vector<int32_t> ag_node, ai_group, ai_t0, ai_t1, ai_part, ad_group, ad_t0, ad_t1, ad_part, ad_big, anode_parts(p->Nn_pad, 0);
+    std::vector<int32_t> ag_node, ai_group, ai_t0, ai_t1, ai_part, ad_group, ad_t0, ad_t1, ad_part, ad_big, anode_parts(p->Nn_pad, 0), aw_off;
     int amax_parts = 1;
     {
         constexpr int G = 128;
-        int achunk = spair_auto ? 0 : spair_chunk;
+        // spair_chunk: 0 = automatic: persistent workgroups with a wrap-around schedule (below); 1..200 = that many offsets per
+        // item, one workgroup per item; 255 = the automatic choice of a per-item chunk (the round-3 rule before the schedule)
+        const bool persist = spair_auto;
+        int achunk = (spair_auto || spair_chunk == 255) ? 0 : spair_chunk;
         std::vector<int> mol_n(B), mol_noff(B);
         for (int m = 0; m < B; ++m) { mol_n[m] = n_nodes[order[m]]; mol_noff[m] = orig_noff[order[m]]; }
         std::vector<char> used(B, 0);
@@ -220,6 +223,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         }
         const int ng = (int)g_nmax.size();
         p->n_agroups = ng;
+        if (persist) achunk = 6;                                // (directed items of molecules larger than a group keep the fixed rule)
         if (achunk <= 0 && p->dims.wide) {                      // streamed-weight kernels (nf 128 / 384): no staging cost per item;
             int64_t iters = 0;                                  // the model below, fitted to the LDS-resident kernel, picked coarser
             for (int g = 0; g < ng; ++g) iters += std::max(1, g_nmax[g] / 2);    // items and lost 27 % at nf 384 (39.5 -> 50.3 ms/step)
@@ -252,15 +256,57 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         }
         struct It { int g, t0, t1, part, big; };
         std::vector<It> pit, dit;
+        std::vector<int> g_parts(ng, 1);
+        if (persist) {
+            // Persistent workgroups (one per CU, k_edge_attn loops over its slot's items; the LDS-resident weights are staged once per
+            // workgroup instead of once per item) with a wrap-around schedule: the pair offsets of all groups, laid end to end
+            // with the per-item cost in front of every piece, are cut into JODO_ATT_SLOTS runs of equal cost.  A group that straddles
+            // a cut becomes two items (two partials for its atoms) — at most one cut per slot, so the launch is balanced to within
+            // one offset, where the dispatcher's longest-first greedy over whole items left 9 % (simulated and measured).
+            const double a_item = 0.6;                             // cost of starting an item, in pair offsets
+            double total = 0.0;
+            for (int g = 0; g < ng; ++g) if (!g_big[g]) total += a_item + (double)(g_nmax[g] / 2);
+            // every cut adds an item (and its cost) that `total` did not count: the slot capacity T grows until the walk ends
+            // inside the last slot's capacity
+            double T = std::max(total / JODO_ATT_SLOTS, a_item + 1.0);
+            aw_off.assign(JODO_ATT_SLOTS + 1, 0);
+            for (int attempt = 0; attempt < 400; ++attempt, T *= 1.004) {
+                pit.clear();
+                int slot = 0;
+                double load = 0.0;
+                auto next_slot = [&]() { if (slot + 1 < JODO_ATT_SLOTS) { ++slot; load = 0.0; } };
+                for (int g = 0; g < ng; ++g) {
+                    if (g_big[g]) continue;
+                    const int dmax = g_nmax[g] / 2;
+                    int t = 0, part = 0;
+                    do {
+                        double room = T - load - a_item;
+                        if (room < 0.75 && load > 0.0 && slot + 1 < JODO_ATT_SLOTS) { next_slot(); room = T - a_item; }
+                        int take = std::min(dmax - t, std::max(1, (int)(room + 0.5)));
+                        take = std::max(take, 0);
+                        pit.push_back({g, t, t + take, part++, slot});      // `big` holds the slot until the lists are written
+                        load += a_item + (double)take;
+                        t += take;
+                        if (load >= T - 0.5) next_slot();
+                    } while (t < dmax);
+                    g_parts[g] = part;
+                }
+                if (load <= T + 0.5) break;                                  // the last slot did not overflow
+            }
+            // items are already in slot order (slots ascend along the walk)
+            for (const It& it : pit) aw_off[it.big + 1]++;
+            for (int sl = 0; sl < JODO_ATT_SLOTS; ++sl) aw_off[sl + 1] += aw_off[sl];
+            for (It& it : pit) it.big = 0;
+        }
         for (int g = 0; g < ng; ++g) {
             const int nmax = g_nmax[g], dmax = nmax / 2;
             int parts;
             if (g_big[g]) parts = std::max(1, (nmax + 2 * achunk - 1) / (2 * achunk));
-            else parts = std::max(1, (dmax + achunk - 1) / achunk);
+            else parts = persist ? g_parts[g] : std::max(1, (dmax + achunk - 1) / achunk);
             amax_parts = std::max(amax_parts, parts);
             const int cp = dmax > 0 ? (dmax + parts - 1) / parts : 0, cd = (nmax + parts - 1) / parts;
             for (int q = 0; q < parts; ++q) {
-                if (!g_big[g]) pit.push_back({g, std::min(dmax, q * cp), std::min(dmax, (q + 1) * cp), q, 0});
+                if (!g_big[g] && !persist) pit.push_back({g, std::min(dmax, q * cp), std::min(dmax, (q + 1) * cp), q, 0});
                 dit.push_back({g, std::min(nmax, q * cd), std::min(nmax, (q + 1) * cd), q, g_big[g]});
             }
             for (int k = 0; k < G; ++k) { const int v = ag_node[(size_t)g * G + k]; if (v >= 0) anode_parts[v] = parts; }
@@ -268,11 +314,13 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         // longest items first (the tail of the launch is then filled with short ones); stable, so neighbours in the
         // queue stay neighbours in memory
         auto lpt = [](const It& a, const It& b) { return (a.t1 - a.t0) > (b.t1 - b.t0); };
-        std::stable_sort(pit.begin(), pit.end(), lpt);
+        if (!persist) std::stable_sort(pit.begin(), pit.end(), lpt);
         std::stable_sort(dit.begin(), dit.end(), lpt);
         for (const It& it : pit) { ai_group.push_back(it.g); ai_t0.push_back(it.t0); ai_t1.push_back(it.t1); ai_part.push_back(it.part); }
         for (const It& it : dit) { ad_group.push_back(it.g); ad_t0.push_back(it.t0); ad_t1.push_back(it.t1); ad_part.push_back(it.part); ad_big.push_back(it.big); }
         p->n_aitems = (int)pit.size(); p->n_aditems = (int)dit.size(); p->amax_parts = amax_parts;
+        p->a_persist = persist ? 1 : 0;
+        if (!persist) aw_off.assign(1, 0);
         p->has_big = 0;
         for (int g = 0; g < ng; ++g) p->has_big |= g_big[g];
     }
@@ -289,7 +337,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     put(pi_strip, &p->off_pitem_strip); put(pi_t0, &p->off_pitem_t0); put(pi_t1, &p->off_pitem_t1);
     put(ag_node, &p->off_ag_node); put(ai_group, &p->off_ai_group); put(ai_t0, &p->off_ai_t0); put(ai_t1, &p->off_ai_t1); put(ai_part, &p->off_ai_part);
     put(ad_group, &p->off_ad_group); put(ad_t0, &p->off_ad_t0); put(ad_t1, &p->off_ad_t1); put(ad_part, &p->off_ad_part); put(ad_big, &p->off_ad_big);
-    put(anode_parts, &p->off_anode_parts);
+    put(anode_parts, &p->off_anode_parts); put(aw_off, &p->off_aw_off);
     {   // upper-triangle rows of every molecule's dense edge tile + their mirrors: the edge head evaluates a symmetric pair once
         std::vector<int32_t> ut;
         for (int b = 0; b < B; ++b) {
@@ -476,6 +524,26 @@ extern "C" int jodo_plan_set_option(jodo_plan* p, int option, int value) {
     if (option == JODO_OPT_ATTN_VARIANT && (value < 0 || value > 3))
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: attention variant must be 0..3, got %d", value);
     p->opt[option] = value;
+    return JODO_OK;
+}
+// out8: pair-mode attention items, their total offsets, partials per atom (max), persistent schedule (0 / 1), and for the
+// persistent schedule the smallest / largest slot load in offsets, the largest item count of a slot and the number of idle slots
+extern "C" int jodo_debug_attn_schedule(const jodo_plan* p, int64_t* o) {
+    if (!p || !o) return jodo_set_error(JODO_ERR_ARG, "attn_schedule: null");
+    const int32_t* d = p->desc.data();
+    int64_t iters = 0;
+    for (int i = 0; i < p->n_aitems; ++i) iters += d[p->off_ai_t1 + i] - d[p->off_ai_t0 + i];
+    o[0] = p->n_aitems; o[1] = iters; o[2] = p->amax_parts; o[3] = p->a_persist; o[4] = o[5] = o[6] = o[7] = 0;
+    if (p->a_persist) {
+        int64_t lo = INT64_MAX, hi = 0, mi = 0, idle = 0;
+        for (int s = 0; s < JODO_ATT_SLOTS; ++s) {
+            const int k0 = d[p->off_aw_off + s], k1 = d[p->off_aw_off + s + 1];
+            int64_t l = 0;
+            for (int k = k0; k < k1; ++k) l += d[p->off_ai_t1 + k] - d[p->off_ai_t0 + k];
+            lo = std::min(lo, l); hi = std::max(hi, l); mi = std::max<int64_t>(mi, k1 - k0); idle += (k1 == k0);
+        }
+        o[4] = lo; o[5] = hi; o[6] = mi; o[7] = idle;
+    }
     return JODO_OK;
 }
 extern "C" int jodo_debug_set_max_blocks(jodo_plan* p, int mb) {

@@ -5,6 +5,10 @@
 #include <vector>
 #include "../../include/jodo_hip.h"
 
+// workgroups of the persistent pair-mode attention launch: one per CU of an MI355X (each holds a CU: 4 waves of ~480 registers,
+// 96 + 40 KiB of LDS); a device with fewer CUs runs them in rounds — slower, never wrong
+constexpr int JODO_ATT_SLOTS = 256;
+
 struct DgtDims {
     int D, De, T, L, H, XH, SH, SC, C, r, nd, ch, cond_ch;
     int QKP;        // padded q/k width in floats (slot order)
@@ -48,6 +52,8 @@ struct PlanDev {
     const int* ad_part;
     const int* ad_big;      // 1 = group of a molecule that spans several groups: directed mode even for symmetric inputs
     const int* anode_parts; // [Nn_pad] number of attention partials of a node
+    const int* aw_off;      // persistent pair-mode launch: items [aw_off[w], aw_off[w + 1]) belong to workgroup w (JODO_ATT_SLOTS + 1 entries)
+    int a_persist;
     const int* ut_rows;     // [n_ut_pad][2] dense edge row (a, c) with a < c and its mirror (c, a); -1 = padding (edge head, symmetric inputs)
     int n_ut_pad;
     const int* gt_sa;       // Gram tiles of the rotated statistics (k_node_gram): strip of the row atoms a, strip of the column atoms c
@@ -70,6 +76,8 @@ struct jodo_plan {
     DgtDims dims;
     int B, N, Nn, Nn_pad, n_strips, n_items, n_pitems, max_parts;
     int n_agroups, n_aitems, n_aditems, amax_parts, n_ut_pad, n_gtiles;
+    int a_persist;                   // pair-mode attention items are scheduled onto JODO_ATT_SLOTS persistent workgroups (off_aw_off)
+    size_t off_aw_off;
     int has_big;                     // some molecule spans several attention groups (n > 128): its items always run in directed mode
     size_t off_ag_node, off_ai_group, off_ai_t0, off_ai_t1, off_ai_part, off_ad_group, off_ad_t0, off_ad_t1, off_ad_part, off_ad_big, off_anode_parts, off_ut_rows, off_gt_sa, off_gt_sc;
     int64_t rows, dir_edges;

@@ -80,6 +80,35 @@ def test_plan_statistics_and_errors():
     lib3.jodo_plan_destroy(h3)
 
 
+def test_attention_schedule_is_balanced_and_complete():
+    """The pair-mode attention launch runs as JODO_ATT_SLOTS = 256 persistent workgroups; the plan cuts the groups' pair offsets
+    into runs of equal cost (csrc/dgt_plan.cpp).  Against the one-workgroup-per-item decomposition of the same batch: the same
+    total of offsets (every pair offset of every group exactly once), loads within one offset + the item cost of the mean, no
+    more than a few partials per atom; small batches spread over the slots instead of leaving them idle."""
+    import torch
+    from jodo_amd.models import get_node_dist, load_dataset_info
+    lib = capi.lib()
+    for info, B, cfg in (('qm9_with_h', 2500, None), ('geom_with_h_1', 512, _Cfg(256, 10, 16, 2, 4, 17, 3, 0, 3.0, 0.0)),
+                         ('qm9_second_half', 313, _Cfg(256, 8, 16, 2, 2, 6, 2, 1, 2.0, 0.0))):
+        torch.manual_seed(42)
+        n = get_node_dist(load_dataset_info(info)).sample(B).tolist()
+        out = {}
+        for mode, chunk in (('persistent', 0), ('per-item', 255 << 24)):
+            _, rc, h = _plan(n, cfg=cfg, chunk=chunk)
+            assert rc == 0
+            o = (ctypes.c_int64 * 8)()
+            assert lib.jodo_debug_attn_schedule(h, o) == 0
+            out[mode] = list(o)
+            lib.jodo_plan_destroy(h)
+        p, q = out['persistent'], out['per-item']
+        assert p[3] == 1 and q[3] == 0 and p[1] == q[1] > 0            # same pair offsets in total
+        mean = p[1] / 256.0
+        assert p[5] <= mean + 0.6 * p[6] + 1.5 and p[6] <= 8, (info, p)    # largest slot load, items per slot
+        assert p[2] <= max(3, q[2] + 2), (info, p, q)                   # partials per atom
+        if p[1] >= 4 * 256:
+            assert p[7] <= 8, (info, p)                                  # (almost) no idle slot: the capacity search stops at the first fit
+
+
 def test_small_and_qk_maps_are_bijections():
     for sh, sc in ((14, 18), (14, 27)):
         m = P.qk_out_map(sh, sc).reshape(-1)
