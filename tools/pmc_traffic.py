@@ -100,7 +100,7 @@ def main():
             row['avg_ms_per_block'] = t / (n_fwd_s * L) * 1e-6
         kernels[cls] = row
     out = {'workload': 'qm9' if 'QM9 uncond' in cfg['workload'] else ('geom384' if 'nf=384' in cfg['workload'] else
-                                                                         ('cond' if 'cond' in cfg['workload'] else 'geom')),
+                                                                         ('cond' if 'QM9 cond' in cfg['workload'] else 'geom')),
            'batch': cfg['batch_per_gpu'], 'command': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- ' + a.command,
            'corrections': 'FETCH_SIZE x 1024 B x 2 (gfx950: 64 B tallied per 128-B request); WRITE_SIZE x 1024 B as reported',
            'forwards_profiled': n_fwd_f, 'blocks_per_forward': L, 'directed_edges': E, 'nodes': Nn, 'kernels': kernels}
