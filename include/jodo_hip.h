@@ -111,8 +111,9 @@ typedef struct jodo_plan jodo_plan;
  * (prefix masks, diagonal excluded), which is what the reference's samplers produce
  * (sampling.py:193-201).  max_chunk packs three work-item sizes (0 in a field = automatic): bits 0-15 sources per
  * directed edge work item (embeddings, directed update; default 8), bits 16-23 pair offsets per item of the pair update
- * kernel (default 1), bits 24-31 pair offsets per item of the fused attention kernel (default 6, fewer for batches that
- * would not fill the chip). */
+ * kernel (default 1), bits 24-31 the pair-mode decomposition of the fused attention kernel: 0 = automatic — 256 persistent
+ * workgroups on a wrap-around schedule of equal-cost runs of pair offsets; 1..200 = that many pair offsets per
+ * item, one workgroup per item; 255 = one workgroup per item with the chunk chosen by the plan's launch model. */
 int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes_host, int max_chunk,
                      jodo_plan** out);
 void jodo_plan_destroy(jodo_plan* plan);
