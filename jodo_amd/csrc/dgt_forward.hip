@@ -56,12 +56,12 @@ void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
 }
 
 int rowgemm(hipStream_t st, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* Wp, const float* bias,
-            int rows, int K, int NB, int in_act, int accumulate, const int* uniform_flag) {
+            int rows, int K, int NB, int in_act, int accumulate, const int* uniform_flag, float* Ysilu = nullptr) {
     if (K % 64 != 0) return jodo_set_error(JODO_ERR_ARG, "rowgemm: K=%d not a multiple of 64", K);
     // few rows (the sampling case: one shared time row): one output block per wave so that the launch
     // still has hundreds of waves; many rows: four blocks per wave to reuse the activation chunk
     const int nob = (rows <= 64 || uniform_flag) ? 1 : 4;
-    RowGemmArgs G{X, ldx, Y, ldy, Wp, bias, rows, K, NB, in_act, accumulate, uniform_flag, nob};
+    RowGemmArgs G{X, ldx, Y, ldy, Wp, bias, rows, K, NB, in_act, accumulate, uniform_flag, nob, Ysilu};
     dim3 grid((rows + 31) / 32, (NB + nob - 1) / nob);
     hipLaunchKernelGGL(k_rowgemm, grid, dim3(64), 0, st, G);
     return jodo_check_launch("k_rowgemm");
@@ -353,7 +353,10 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     // a conditional model never shares the modulation row (k_flags_init): no flag, and rowgemm then reuses each activation
     // chunk for four output blocks instead of one
     const int* uflag = d.cond_ch > 0 ? nullptr : flags_dev + FLAG_UNIFORM_T;
-    rc = rowgemm(st, A.hid1, d.T, A.temb, d.T, W + A.wg[JW_TIME_W3], W + A.wg[JW_TIME_B3], p->B, d.T, d.T / 32, 0, 0, uflag);
+    // (the last writer of the time embedding also leaves SiLU(time_emb): the input of the fused modulation projection)
+    float* tembs = ws_ptr<float>(workspace, p->ws.tembs);
+    rc = rowgemm(st, A.hid1, d.T, A.temb, d.T, W + A.wg[JW_TIME_W3], W + A.wg[JW_TIME_B3], p->B, d.T, d.T / 32, 0, 0, uflag,
+                 d.cond_ch > 0 ? nullptr : tembs);
     if (rc) return rc;
     if (d.cond_ch > 0) {
         LAUNCH(k_cond1, p->B * d.cond_ch, 256, A);
@@ -361,10 +364,10 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
                      d.D / 32, 0, 0, nullptr);
         if (rc) return rc;
         rc = rowgemm(st, A.condh2, (int64_t)d.cond_ch * d.D, A.temb, d.T, W + A.wg[JW_COND_LIN_W], W + A.wg[JW_COND_LIN_B],
-                     p->B, d.cond_ch * d.D, d.T / 32, 0, 1, nullptr);
+                     p->B, d.cond_ch * d.D, d.T / 32, 0, 1, nullptr, tembs);
         if (rc) return rc;
     }
-    rc = rowgemm(st, A.temb, d.T, A.mods, d.Mtot, W + A.wg[JW_MOD_W], W + A.wg[JW_MOD_B], p->B, d.T, (int)(d.Mtot / 32), 1, 0,
+    rc = rowgemm(st, tembs, d.T, A.mods, d.Mtot, W + A.wg[JW_MOD_W], W + A.wg[JW_MOD_B], p->B, d.T, (int)(d.Mtot / 32), 0, 0,
                  uflag);
     if (rc) return rc;
     if (!d.wide) return forward_blocks<256, true>(p, st, A, woff, posbuf, pro);

@@ -80,7 +80,11 @@ __global__ void k_cond1(KArgs A) {
 }
 
 // Generic row GEMM on the strip model: Y[row, :] (+)= act_in(X[row, :]) * W^T + bias
-// rows in lanes, K in chunks of 64 features, 4 output blocks per wave.
+// rows in lanes, K in chunks of 64 features, up to 4 output blocks per wave.  The weights go through the software-pipelined
+// ring of dgt_device.h (one group of 8 quads in flight across the (chunk, block) sequence) and the next activation chunk is
+// requested while the current one is multiplied: with per-molecule modulation rows (conditional model, B = 1250: 60 GFLOP per
+// forward) the plain load -> wait -> MFMA form ran at 40 % of the matrix peak.  Ysilu (optional): SiLU of the result as a second
+// output, so that the modulation projection reads SiLU(time_emb) instead of recomputing it in every one of its waves.
 struct RowGemmArgs {
     const float* X; int64_t ldx;
     float* Y; int64_t ldy;
@@ -90,6 +94,7 @@ struct RowGemmArgs {
     int accumulate;                          // Y += result
     const int* uniform_flag;                 // if non-null and *flag != 0: only row 0 is computed
     int nob;                                 // output blocks per wave (1 for few rows: more waves; 4 otherwise)
+    float* Ysilu;                            // nullable: SiLU(Y) [rows, ldy]
 };
 
 __global__ __launch_bounds__(64) void k_rowgemm(RowGemmArgs G) {
@@ -100,27 +105,40 @@ __global__ __launch_bounds__(64) void k_rowgemm(RowGemmArgs G) {
     const int row = r0 + j;
     const int rowc = row < rows ? row : rows - 1;
     const int ob0 = blockIdx.y * G.nob;
-    const int kq = G.K / 8;                  // quads per output block
+    const int nv = G.NB - ob0 < G.nob ? G.NB - ob0 : G.nob;          // output blocks of this wave (1..4)
+    const int kq = G.K / 8, nch = G.K / 64;  // quads per output block, activation chunks
     f32x16 acc[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) acc[o] = zero16();
-    const float4* wp = reinterpret_cast<const float4*>(G.Wp) + lane;
-    for (int c = 0; c < G.K / 64; ++c) {
+    const WSrc ws = make_wsrc(G.Wp, lane);
+    auto woff = [&](int o, int c) { return (unsigned)(((size_t)(ob0 + o) * kq + (size_t)c * 8) * 1024); };
+    WPipe<8> wp;
+    wpipe_prime(wp, ws, woff(0, 0));
+    const float* xrow = G.X + (size_t)rowc * G.ldx;
+    float xn[32];
+    load_nat<2>(xrow, half, xn);
+    for (int c = 0; c < nch; ++c) {
         float x[32];
-        load_nat<2>(G.X + (size_t)rowc * G.ldx + c * 64, half, x);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) x[s] = xn[s];
+        if (c + 1 < nch) load_nat<2>(xrow + (c + 1) * 64, half, xn);      // next chunk: in flight behind this chunk's MFMAs
         if (G.in_act == 1) {
 #pragma unroll
             for (int s = 0; s < 32; ++s) x[s] = silu_f(x[s]);
         }
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            if (o < G.nob && ob0 + o < G.NB) acc[o] = mfma_block<8>(wp + ((size_t)(ob0 + o) * kq + c * 8) * 64, x, acc[o]);
+            if (o < nv) {
+                const bool last_o = o + 1 >= nv;
+                const unsigned nxt = !last_o ? woff(o + 1, c) : (c + 1 < nch ? woff(0, c + 1) : woff(0, 0));
+                acc[o] = mfma_block_p<8>(wp, ws, woff(o, c), nxt, x, acc[o]);
+            }
         }
     }
     if (row >= rows) return;
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-        if (o < G.nob && ob0 + o < G.NB) {
+        if (o < nv) {
             float r[16];
             acc_bias(acc[o], G.bias + (ob0 + o) * 32 + half * 16, r);
             float* yp = G.Y + (size_t)row * G.ldy + (ob0 + o) * 32 + half * 16;
@@ -131,6 +149,11 @@ __global__ __launch_bounds__(64) void k_rowgemm(RowGemmArgs G) {
                 for (int s = 0; s < 16; ++s) r[s] += old[s];
             }
             store16(yp, r);
+            if (G.Ysilu) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) r[s] = silu_f(r[s]);
+                store16(G.Ysilu + (size_t)row * G.ldy + (ob0 + o) * 32 + half * 16, r);
+            }
         }
     }
 }

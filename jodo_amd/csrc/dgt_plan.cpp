@@ -379,7 +379,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
     const size_t f = sizeof(float), NP = (size_t)p->Nn_pad, R = (size_t)rows + 32, Bp = align_up((size_t)B, 32);
     WsLayout& w = p->ws;
-    w.hid1 = take(Bp * d.T * f); w.temb = take(Bp * d.T * f); w.mods = take(Bp * (size_t)d.Mtot * f);
+    w.hid1 = take(Bp * d.T * f); w.temb = take(Bp * d.T * f); w.tembs = take(Bp * d.T * f); w.mods = take(Bp * (size_t)d.Mtot * f);
     w.condh = take(Bp * (size_t)std::max(1, d.cond_ch) * d.D * f); w.condh2 = take(Bp * (size_t)std::max(1, d.cond_ch) * d.D * f);
     w.pos0 = take(NP * 4 * f); w.pos1 = take(NP * 4 * f); w.dpos = take(NP * max_parts * 4 * f); w.cpos = take(NP * 4 * f);
     w.feat = take(NP * d.ndp * f); w.h = take(NP * d.D * f); w.hhat = take(NP * amax_parts * d.D * f);

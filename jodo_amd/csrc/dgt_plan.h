@@ -65,7 +65,7 @@ struct PlanDev {
 };
 
 struct WsLayout {   // byte offsets into the workspace
-    size_t hid1, temb, mods, condh, condh2;
+    size_t hid1, temb, tembs, mods, condh, condh2;
     size_t pos0, pos1, dpos, cpos, feat, h, hhat, astat, q, k, v, n2e, wrow, wcol, ua, ub, rmean, mfold, ffold, ahid, apred;
     size_t eflag, e, e2, ehid, epred, dposE, gramE;
     size_t total;
