@@ -53,6 +53,9 @@ class JodoTensor(ctypes.Structure):             # jodo_tensor (include/jodo_hip.
                 ('ndim', ctypes.c_int32)]
 
 
+_PACKED_SIZE = {}
+
+
 def pack_weights(cfg_struct, state_dict, device=None):
     """state_dict (reference key names; values on any device) -> (blob, woff ctypes int64 array, n_woff) through the
     C packer jodo_dgt_pack_weights[_host].  device=None: blob is a CPU torch tensor; otherwise it is packed straight
@@ -67,9 +70,16 @@ def pack_weights(cfg_struct, state_dict, device=None):
         name = k.encode()
         keep.append((t, shp, name))
         arr[i] = JodoTensor(name, t.ctypes.data_as(ctypes.c_void_p), shp, t.ndim)
+    # the packed size depends on the configuration only; asking for it runs the whole packer (QR factorisations included), so it
+    # is asked once per configuration — a missing or mis-sized tensor is still a named error of the packing call below
+    key = bytes(cfg_struct)
     n_floats, n_woff = ctypes.c_size_t(), ctypes.c_int()
-    check(L.jodo_dgt_packed_size(ctypes.byref(cfg_struct), arr, len(keep), ctypes.byref(n_floats), ctypes.byref(n_woff)),
-          'jodo_dgt_packed_size')
+    if key in _PACKED_SIZE:
+        n_floats.value, n_woff.value = _PACKED_SIZE[key]
+    else:
+        check(L.jodo_dgt_packed_size(ctypes.byref(cfg_struct), arr, len(keep), ctypes.byref(n_floats), ctypes.byref(n_woff)),
+              'jodo_dgt_packed_size')
+        _PACKED_SIZE[key] = (n_floats.value, n_woff.value)
     woff = (ctypes.c_int64 * n_woff.value)()
     if device is None:
         blob = torch.empty(n_floats.value, dtype=torch.float32)
