@@ -135,7 +135,6 @@ int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A, bool with_ab) {
     A.ab0 = 0; A.ab1 = 2 * p->n_strips; A.g0 = 0; A.g1 = A.rot ? p->n_gtiles : 0; A.mix_nw = 0;
     const bool mix = with_ab && full > 0 && rem > 0 && nw >= 2 && p->opt[JODO_OPT_NODE_MIX] != 0;
     if (mix) {
-        A.ab_halves = 1;                                     // the merged launch packs whole k_node_ab items
         if (p->gt_cache_full != full) {                      // Gram tiles among the strips of the full rounds: a prefix of the sorted list
             const int32_t* sa = p->desc.data() + p->off_gt_sa, *sc = p->desc.data() + p->off_gt_sc;
             int c = 0;
@@ -163,8 +162,7 @@ int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A, bool with_ab) {
     }
     A.strip0 = 0;
     if (with_ab) {
-        A.ab1 = 2 * p->n_strips * A.ab_halves;
-        LAUNCH((wide::k_node_ab<256>), p->n_strips * 2 * A.ab_halves, 64, A);
+        LAUNCH((wide::k_node_ab<256>), p->n_strips * 2, 64, A);
         if (A.rot && p->n_gtiles > 0) LAUNCH((wide::k_node_gram<256>), p->n_gtiles, 64, A);
     }
     return JODO_OK;
@@ -173,20 +171,10 @@ int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A, bool with_ab) {
 // Everything after the time / modulation prologue.  One kernel set for every width (dgt_kernels_wide.h, dgt_kernels_attn.h);
 // TUNED (nf = 256 with the 8-block q / k arrangement) swaps in the nf = 256 node kernels of dgt_kernels_node.h and the
 // LDS-resident-weight variant of the attention kernel.
-// Items of a launch whose work splits into n equal items, or 2 n half items at `half_cost` of an item each (the per-item prologue
-// is paid twice): whichever needs less time in rounds of 1024 one-wave SIMDs.  710 strips x 3 k_node_pre items = 2.08 rounds
-// = 3 rounds; as 4260 halves 4.16 -> 5 half rounds = 2.8.  Used for k_node_ab (GEOM B = 512: node class 4.54 -> 4.44 ms/step);
-// for k_node_pre the halves cost more than they save (dgt_kernels_node.h).
-static int halves_for(int n_items, double half_cost) {
-    const double whole = (double)((n_items + 1023) / 1024), split = (double)((2 * n_items + 1023) / 1024) * half_cost;
-    return split < whole ? 2 : 1;
-}
-
 template <int D, bool TUNED>
 int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, float* const posbuf[2], std::unique_ptr<ProfScope>& pro) {
     const DgtDims& d = p->dims;
     int rc = JODO_OK;
-    A.ab_halves = halves_for(p->n_strips * 2, 0.56);
     // ---- pack inputs, embeddings ----
     LAUNCH(k_pack_nodes, (p->Nn_pad + 255) / 256, 256, A);
     switch (d.ndp / 8) {
@@ -276,7 +264,7 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
             } else {
                 if (d.r == 2) LAUNCH((wide::k_node_post<D, 2>), p->n_strips, 64, A); else LAUNCH((wide::k_node_post<D, 4>), p->n_strips, 64, A);
                 A.ab0 = 0; A.g0 = 0;
-                if (p->n_pitems > 0 && !pin_dir) LAUNCH((wide::k_node_ab<D>), p->n_strips * 2 * A.ab_halves, 64, A);
+                if (p->n_pitems > 0 && !pin_dir) LAUNCH((wide::k_node_ab<D>), p->n_strips * 2, 64, A);
                 if (A.rot && p->n_gtiles > 0) LAUNCH((wide::k_node_gram<D>), p->n_gtiles, 64, A);
             }
         }
@@ -344,7 +332,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     for (int i = 0; i < JW_GLOBAL_COUNT; ++i) A.wg[i] = woff[i];
     for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = 0;
     A.mod_base = 0; A.layer = 0; A.force_directed = p->force_directed; A.pin_sym = p->force_directed ? 0 : p->opt[JODO_OPT_PIN_SYMMETRIC];
-    A.pin_uni = p->opt[JODO_OPT_PIN_UNIFORM_T]; A.pre_mode = 0; A.ab_halves = 1; A.strip0 = 0; A.item0 = 0; A.dir_split = 0; A.rot = 0; A.mix_nw = 0; A.ab0 = 0; A.ab1 = 0; A.g0 = 0; A.g1 = 0; A.fuse_next = 0; A.mod_base_next = 0;
+    A.pin_uni = p->opt[JODO_OPT_PIN_UNIFORM_T]; A.pre_mode = 0; A.strip0 = 0; A.item0 = 0; A.dir_split = 0; A.rot = 0; A.mix_nw = 0; A.ab0 = 0; A.ab1 = 0; A.g0 = 0; A.g1 = 0; A.fuse_next = 0; A.mod_base_next = 0;
     for (int i = 0; i < 6; ++i) A.wbn[i] = 0;
     fill_ws(A, p, workspace);
     float* posbuf[2] = {ws_ptr<float>(workspace, p->ws.pos0), ws_ptr<float>(workspace, p->ws.pos1)};

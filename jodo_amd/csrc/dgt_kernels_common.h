@@ -27,7 +27,6 @@ struct KArgs {
     int64_t wbn[6];
     int64_t mod_base_next;
     int pre_mode;                         // k_node_pre: 0 = also advance the positions, 1 = q/k/v only (k_pos_final did it)
-    int ab_halves;                        // items per piece of k_node_ab: 1, or 2 = half the output blocks each
     // workspace
     float *hid1, *temb, *mods, *condh, *condh2;
     float *pos_in, *pos_out, *dpos, *cpos, *feat, *h, *hhat, *astat, *q, *k, *v, *n2e, *wrow, *wcol, *ua, *ub, *rmean, *mfold, *ffold, *ahid, *apred;

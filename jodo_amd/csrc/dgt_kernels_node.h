@@ -14,8 +14,6 @@ namespace jd {
 
 // ------------------------------------------------------------------------------------------------
 // piece 0 / 1 / 2 = q / k / v; piece 0 also advances the positions
-// (six half-projection items per strip instead of three were measured for launches that fill their last round badly — 710 strips:
-// 2130 items = 2.08 rounds — and lost: GEOM B = 512 1.17 -> 1.35 ms/step, every item repeats the latency-bound LayerNorm prologue)
 __global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
     const int strip = blockIdx.x / 3, piece = blockIdx.x % 3;

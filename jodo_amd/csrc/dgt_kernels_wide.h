@@ -303,11 +303,7 @@ __device__ __forceinline__ void node_ab_body(const KArgs& A, int item) {
     if (D != 256 && !A.flags[FLAG_UNIFORM_T]) return;       // nf = 384 pushes coord_mlp.0 through only with a shared modulation row
     using X = Dim<D>;
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    // A.ab_halves = 2: four items per strip, each half of the output blocks of a piece (launches whose 2 x n_strips items would
-    // leave the last round of 1024 SIMDs nearly empty)
-    const int hsel = A.ab_halves == 2 ? item & 1 : 0, pit_ = A.ab_halves == 2 ? item >> 1 : item;
-    const int b_lo = hsel * (X::ND / A.ab_halves), b_hi = b_lo + X::ND / A.ab_halves;
-    const int strip = pit_ >> 1, piece = pit_ & 1;
+    const int strip = item >> 1, piece = item & 1;
     const LaneNode L = lane_node(A, strip, j);
     const bool rot = rot_active(A);
     const float* qsc = mod_row(A, L.b) + A.mod_base + X::M_EQUI + D;       // equi_update.time_mlp: (shift, scale)
@@ -334,19 +330,19 @@ __device__ __forceinline__ void node_ab_body(const KArgs& A, int item) {
     }
     if (!rot) {
         const float red = pair_sum(sum);
-        if (half == 0 && hsel == 0) A.rmean[(size_t)L.v * 2 + piece] = red * (1.f / D);
+        if (half == 0) A.rmean[(size_t)L.v * 2 + piece] = red * (1.f / D);
     }
     // (the base pointer is selected, not the descriptor: a select between two buffer resources went through scratch)
     const float* wbase = rot ? A.ffold + (size_t)A.layer * D * D : A.W;
     const WSrc ws = make_wsrc(wbase, lane);
     const unsigned o0 = rot ? 0u : (unsigned)(A.wb[JB_C0_W] * 4);
     WPipe<X::PG> wp;
-    wpipe_prime(wp, ws, o0 + (unsigned)b_lo * X::KQD * 1024);
+    wpipe_prime(wp, ws, o0);
     float* dst = piece == 0 ? A.ua : A.ub;
 #pragma unroll 1
-    for (int b = b_lo; b < b_hi; ++b) {
+    for (int b = 0; b < X::ND; ++b) {
         const unsigned cur = o0 + (unsigned)b * X::KQD * 1024;
-        f32x16 acc = mfma_block_p<X::KQD>(wp, ws, cur, b + 1 < b_hi ? cur + X::KQD * 1024 : o0, x, zero16());
+        f32x16 acc = mfma_block_p<X::KQD>(wp, ws, cur, b + 1 < X::ND ? cur + X::KQD * 1024 : o0, x, zero16());
         float r[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) r[s] = acc[s];
