@@ -109,6 +109,34 @@ def test_attention_schedule_is_balanced_and_complete():
             assert p[7] <= 8, (info, p)                                  # (almost) no idle slot: the capacity search stops at the first fit
 
 
+def test_work_model_follows_the_rotated_statistics():
+    """jodo_plan_work (the numerator of bench.py's roofline fraction): with JODO_OPT_ROT_STATS the pair update issues the triangular
+    2De x 2De projection (160 MFMAs per pair-offset iteration at nf 256) instead of S = W_in [e ; G] (512), and the node class
+    gains the Gram tiles (64 MFMAs each); everything else is unchanged.  The per-iteration total is 960 MFMAs."""
+    import torch
+    from jodo_amd.models import get_node_dist, load_dataset_info
+    lib = capi.lib()
+    torch.manual_seed(42)
+    n = get_node_dist(load_dataset_info('qm9_with_h')).sample(600).tolist()
+    _, rc, h = _plan(n)
+    assert rc == 0
+    work = {}
+    for rot in (1, 0):
+        assert lib.jodo_plan_set_option(h, 6, rot) == 0
+        w = (ctypes.c_double * 8)()
+        assert lib.jodo_plan_work(h, 1, 1, w) == 0
+        work[rot] = list(w)
+    assert lib.jodo_plan_set_option(h, 6, 2) < 0                       # a switch: 0 or 1
+    L, UPD, NODE = 8, 6, 5                                            # blocks; JODO_PROF_EDGE_UPDATE, JODO_PROF_NODE_POST
+    iters = (work[0][UPD] - work[1][UPD]) / (L * (512 - 160) * 4096.0)
+    assert iters > 0 and abs(iters - round(iters)) < 1e-9             # pair-offset iterations of one block
+    assert abs(work[1][UPD] - L * iters * 960 * 4096.0) < 1.0 and abs(work[0][UPD] - L * iters * 1312 * 4096.0) < 1.0
+    tiles = (work[1][NODE] - work[0][NODE]) / (L * 64 * 4096.0)
+    assert tiles > 0 and abs(tiles - round(tiles)) < 1e-9             # Gram tiles of one block
+    assert all(work[0][c] == work[1][c] for c in range(8) if c not in (UPD, NODE))
+    lib.jodo_plan_destroy(h)
+
+
 def test_small_and_qk_maps_are_bijections():
     for sh, sc in ((14, 18), (14, 27)):
         m = P.qk_out_map(sh, sc).reshape(-1)
