@@ -435,8 +435,17 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             tr = time.perf_counter()
+            mine, local_err = [], None
+            try:                                       # the sampling itself has no collective: a rank that fails here must still
+                with contextlib.redirect_stdout(sys.stderr):       # take part in the ones below, or the others wait for it forever
+                    mine = fn(model)
+            except Exception as exc:
+                local_err = repr(exc)
+            okf = torch.tensor([0 if local_err else 1], device=dev, dtype=torch.int64)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf) == 0:
+                raise RuntimeError("sharded round failed on a rank" + (": " + local_err if local_err else ""))
             with contextlib.redirect_stdout(sys.stderr):
-                mine = fn(model)
                 everyone = gather_sampled(mine, fn.last_indices, device=dev)          # RCCL all_gather of the decoded molecules
             torch.cuda.synchronize()
             dist.barrier()
