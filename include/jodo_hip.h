@@ -183,7 +183,9 @@ enum jodo_plan_option {
 int jodo_plan_set_option(jodo_plan* plan, int option, int value);
 
 /* debug / tests: the pair-mode attention schedule of a plan.  out8 = items, their total pair offsets, partials per atom (max),
- * persistent schedule (0 / 1), and for a persistent schedule: smallest / largest slot load (offsets), most items in a slot, idle slots */
+ * persistent schedule (0 / 1), and for a persistent schedule: smallest / largest slot load (offsets), most items in a slot, idle slots.
+ * Also checks the item lists themselves (every group's pair offsets tiled exactly once, partial indices 0 .. parts - 1, parts as its
+ * atoms expect) and returns an error if they are inconsistent. */
 int jodo_debug_attn_schedule(const jodo_plan* plan, int64_t* out8);
 
 /* debug: copy an internal per-block intermediate out of the workspace after a forward.

@@ -3,6 +3,7 @@
 // (models/mol_gnn.py:512-514) with a once-per-batch host computation.
 #include <algorithm>
 #include <numeric>
+#include <utility>
 #include <new>
 #include "dgt_plan.h"
 #include "jodo_hip_internal.h"
@@ -534,6 +535,36 @@ extern "C" int jodo_debug_attn_schedule(const jodo_plan* p, int64_t* o) {
     int64_t iters = 0;
     for (int i = 0; i < p->n_aitems; ++i) iters += d[p->off_ai_t1 + i] - d[p->off_ai_t0 + i];
     o[0] = p->n_aitems; o[1] = iters; o[2] = p->amax_parts; o[3] = p->a_persist; o[4] = o[5] = o[6] = o[7] = 0;
+    {   // self-check: the items of every group of whole molecules tile its pair offsets [0, nmax / 2) exactly once, and their
+        // partial indices are 0 .. parts - 1 with parts = what the atoms of the group expect (anode_parts)
+        std::vector<std::vector<std::pair<int, int>>> per((size_t)p->n_agroups);
+        std::vector<std::vector<int>> parts((size_t)p->n_agroups);
+        for (int i = 0; i < p->n_aitems; ++i) {
+            const int g = d[p->off_ai_group + i];
+            if (g < 0 || g >= p->n_agroups) return jodo_set_error(JODO_ERR_ARG, "attn_schedule: item %d names group %d", i, g);
+            per[g].push_back({d[p->off_ai_t0 + i], d[p->off_ai_t1 + i]});
+            parts[g].push_back(d[p->off_ai_part + i]);
+        }
+        for (int g = 0; g < p->n_agroups; ++g) {
+            int nmax = 0, want_parts = 0;
+            for (int k = 0; k < 128; ++k) {
+                const int v = d[p->off_ag_node + (size_t)g * 128 + k];
+                if (v >= 0) { nmax = std::max(nmax, (int)d[p->off_node_n + v]); want_parts = d[p->off_anode_parts + v]; }
+            }
+            if (nmax > 128) { if (!per[g].empty()) return jodo_set_error(JODO_ERR_ARG, "attn_schedule: pair items for the big group %d", g); continue; }
+            std::sort(per[g].begin(), per[g].end());
+            std::sort(parts[g].begin(), parts[g].end());
+            int at = 0;
+            for (const auto& it : per[g]) {
+                if (it.first != at || it.second < it.first) return jodo_set_error(JODO_ERR_ARG, "attn_schedule: group %d offsets not tiled at %d", g, at);
+                at = it.second;
+            }
+            if (at != nmax / 2 || per[g].empty()) return jodo_set_error(JODO_ERR_ARG, "attn_schedule: group %d covers %d of %d offsets", g, at, nmax / 2);
+            for (size_t q = 0; q < parts[g].size(); ++q)
+                if (parts[g][q] != (int)q) return jodo_set_error(JODO_ERR_ARG, "attn_schedule: group %d partial indices are not 0..%d", g, (int)parts[g].size() - 1);
+            if ((int)parts[g].size() != want_parts) return jodo_set_error(JODO_ERR_ARG, "attn_schedule: group %d has %d items, its atoms expect %d partials", g, (int)parts[g].size(), want_parts);
+        }
+    }
     if (p->a_persist) {
         int64_t lo = INT64_MAX, hi = 0, mi = 0, idle = 0;
         for (int s = 0; s < JODO_ATT_SLOTS; ++s) {

@@ -107,6 +107,16 @@ def test_attention_schedule_is_balanced_and_complete():
         assert p[2] <= max(3, q[2] + 2), (info, p, q)                   # partials per atom
         if p[1] >= 4 * 256:
             assert p[7] <= 8, (info, p)                                  # (almost) no idle slot: the capacity search stops at the first fit
+    # jodo_debug_attn_schedule also verifies the item lists (every group's pair offsets tiled exactly once, partial indices and
+    # counts as the atoms expect) and returns an error otherwise: odd batches, all three decompositions
+    geom = _Cfg(256, 10, 16, 2, 4, 17, 3, 0, 3.0, 0.0)
+    for n in ([1, 1, 1], [150, 3, 29, 1], [29] * 5, [181, 140, 100, 64, 64, 2], list(range(1, 30)) * 3, [2], [128, 129]):
+        for chunk in (0, 255 << 24, 6 << 24, 1 << 24):
+            _, rc, h = _plan(n, cfg=geom, chunk=chunk)
+            assert rc == 0
+            o = (ctypes.c_int64 * 8)()
+            assert lib.jodo_debug_attn_schedule(h, o) == 0, (n, chunk >> 24, lib.jodo_last_error())
+            lib.jodo_plan_destroy(h)
 
 
 def test_work_model_follows_the_rotated_statistics():
