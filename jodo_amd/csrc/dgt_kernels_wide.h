@@ -805,8 +805,9 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                     }
                     PT(4);
                 });
-                rstd0 = __builtin_amdgcn_rsqf((pair_sum(q02.x + q02.y) + gr0) * (1.f / D) + 1e-6f);
-                rstd1 = __builtin_amdgcn_rsqf((pair_sum(q12.x + q12.y) + gr1) * (1.f / D) + 1e-6f);
+                // (max with 0: the Gram form |R''|^2 + |C''|^2 + 2 <R'', C''> can round a hair below zero when the variance itself is ~ 0)
+                rstd0 = __builtin_amdgcn_rsqf(fmaxf((pair_sum(q02.x + q02.y) + gr0) * (1.f / D), 0.f) + 1e-6f);
+                rstd1 = __builtin_amdgcn_rsqf(fmaxf((pair_sum(q12.x + q12.y) + gr1) * (1.f / D), 0.f) + 1e-6f);
             } else {
             const float m00 = A.rmean[(size_t)L.v * 2] + A.rmean[(size_t)P.u * 2 + 1];          // direction 0: a = i, c = j
             const float m01 = A.rmean[(size_t)P.u * 2] + A.rmean[(size_t)L.v * 2 + 1];          // direction 1: a = j, c = i
