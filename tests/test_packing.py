@@ -298,3 +298,26 @@ def test_rotated_statistics_algebra():
     Mp, F = (W0 * (1 + sc)[None, :]) @ wec, (W0 * (1 + sc)[None, :]) @ qt
     got = (Mp @ z + F @ Rq + F @ Cq) / np.sqrt(var + 1e-6) + (W0 @ sh + b0)
     assert np.allclose(got, want, rtol=1e-11, atol=1e-11)
+
+
+def test_rotated_statistics_survive_degenerate_weights():
+    """Householder QR of the centred [e ; G] columns (csrc/dgt_pack.cpp rot_stats) when columns vanish: all-zero columns
+    (an untrained or pruned block) and constant columns (centring makes them zero).  The reflections are skipped, the blob stays
+    finite, and the factors still satisfy Q (P W_eg) = [L ; 0] (restated with the Python packer's rot_stats)."""
+    import torch
+    from helpers import make_config, make_model
+    from py_packing_model import rot_stats
+    cfg = make_config('vpsde_qm9_uncond_jodo')
+    model = make_model(cfg, 3)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    D = 256
+    sd['e_block_2.equi_update.input_lin.weight'][:, 2 * D:] = 0.0
+    sd['e_block_3.equi_update.input_lin.weight'][:, 2 * D:2 * D + 5] = 1.0
+    blob, _, _ = capi.pack_weights(model._cfg(), sd)
+    assert bool(torch.isfinite(blob).all())
+    for key in ('e_block_2', 'e_block_3'):
+        Win = sd[key + '.equi_update.input_lin.weight'].numpy()
+        rowq, colq, bq, Lq, wec, qt = rot_stats(Win, sd[key + '.equi_update.input_lin.bias'].numpy(), D, 64)
+        Q = qt.T
+        assert np.isfinite(Lq).all() and np.allclose(Q @ Q.T, np.eye(D), atol=1e-12)
+        assert np.allclose(Q @ wec, np.vstack([Lq, np.zeros((D - 128, 128))]), atol=1e-12)
