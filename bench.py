@@ -253,7 +253,10 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     import torch.distributed as dist
-    if world > 1:
+    # under a launcher (torch.distributed.run sets WORLD_SIZE) the RCCL leg runs whatever the world size: a 1-rank launch takes
+    # the same init / barrier / all_reduce / all_gather path as N > 1, so the N = 1 point of a scaling sweep is like the others
+    use_dist = 'WORLD_SIZE' in os.environ
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if torch.cuda.device_count() < world:
@@ -317,14 +320,14 @@ def main():
             for _ in range(max(args.warmup - 2, 0)):
                 rnd.replay()
             torch.cuda.synchronize()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 rnd.replay()
             torch.cuda.synchronize()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
@@ -336,14 +339,14 @@ def main():
                 st = sampler.step(model, i, st, node_mask, edge_mask, context)
             model.profile_enable(1 if args.breakdown else 2)
             torch.cuda.synchronize()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(args.warmup, args.warmup + args.steps):
                 st = sampler.step(model, i, st, node_mask, edge_mask, context)
             torch.cuda.synchronize()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
@@ -387,7 +390,7 @@ def main():
             steady = {'steps': 100, 'ms_per_step': (time.perf_counter() - ts0) * 10.0}
         steady['value'] = B / (SAMPLING_STEPS * steady['ms_per_step'] * 1e-3)
         steady['unit'] = 'molecules/s'
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
@@ -404,7 +407,8 @@ def main():
     full_round = None
     if world == 1 and not args.no_full_round and (args.workload == 'qm9' or args.full_round):
         full_round = {}
-        for mode, hg, dn in (('eager', False, not args.torch_noise), ('eager_torch_randn', False, False)):
+        # (under a launcher the sharded round below is the third complete round: leave the torch.randn variant out there)
+        for mode, hg, dn in (('eager', False, not args.torch_noise), ('eager_torch_randn', False, False))[:1 if use_dist else 2]:
             try:
                 torch.manual_seed(cfg.seed)
                 fn = get_sampling_fn(cfg, ns, nodes_dist, B, B, get_data_inverse_scaler(cfg), prop_dist=prop, return_raw=True,
@@ -425,9 +429,9 @@ def main():
                               'clock (weights already packed); eager draws the per-step noise inside the update kernel '
                               '(Philox), eager_torch_randn with three torch.randn launches per step (the reference RNG stream)'
                               % int(cfg.sampling.steps))
-    # ---- N > 1: one complete SHARDED round + the RCCL gather of the generated molecules --------------------------------
+    # ---- under a launcher (any N): one complete SHARDED round + the RCCL gather of the generated molecules --------------------------------
     sharded = None
-    if world > 1 and not args.no_full_round:
+    if use_dist and not args.no_full_round:
         from jodo_amd.dist import gather_sampled
         try:
             fn = get_sampling_fn(cfg, ns, nodes_dist, B, B * world, get_data_inverse_scaler(cfg), prop_dist=prop, return_raw=True,
@@ -446,7 +450,8 @@ def main():
             if int(okf) == 0:
                 raise RuntimeError("sharded round failed on a rank" + (": " + local_err if local_err else ""))
             with contextlib.redirect_stdout(sys.stderr):
-                everyone = gather_sampled(mine, fn.last_indices, device=dev)          # RCCL all_gather of the decoded molecules
+                # RCCL all_gather of the DEVICE tensors jodo_decode left (nothing re-packed on the host)
+                everyone = gather_sampled(fn.last_decoded, fn.last_indices, device=dev)
             torch.cuda.synchronize()
             dist.barrier()
             tr = time.perf_counter() - tr
@@ -526,7 +531,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg.seed)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

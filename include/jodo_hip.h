@@ -174,7 +174,9 @@ enum jodo_plan_option {
     JODO_OPT_PIN_UNIFORM_T = 5,   /* 0 (default): per call; 1: one shared modulation row (folded pair update only); 2: per-molecule rows */
     JODO_OPT_ROT_STATS = 6,       /* 1 (default): under a shared modulation row and symmetric inputs the LayerNorm statistics of
                                      equi_update are taken in the rotated basis (Q P W_row h, Q P W_col h per node, the triangular
-                                     L [e ; G] per pair, a per-molecule Gram tile for the rest); 0: from S = W_in [e ; G] itself */
+                                     L [e ; G] per pair, a per-molecule Gram tile — taken around the molecule's first atom, so that a
+                                     common component of the two rows is gone before anything is squared — for the rest);
+                                     0: from S = W_in [e ; G] itself; 2 (tests): rotated with the uncentred Gram tiles of round 3 */
     JODO_OPT_NODE_MIX = 7,        /* 1 (default): when k_node_post runs as full rounds + a remainder launch, the remainder launch also carries
                                      the k_node_ab items and Gram tiles of the strips the full rounds finished (they fill the SIMDs the
                                      remainder's cooperative workgroups leave idle); 0: separate launches */

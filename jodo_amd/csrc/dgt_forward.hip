@@ -190,11 +190,11 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
     }
     if (rc) return rc;
     if (p->n_items > 0) LAUNCH((wide::k_embed_edges<D>), p->n_items, 64, A);
-    const bool pin_pair = p->opt[JODO_OPT_PIN_SYMMETRIC] == 1, pin_dir = p->opt[JODO_OPT_PIN_SYMMETRIC] == 2 || p->force_directed;
+    const bool pin_pair = p->opt[JODO_OPT_PIN_SYMMETRIC] == 1 && !p->force_directed, pin_dir = p->opt[JODO_OPT_PIN_SYMMETRIC] == 2 || p->force_directed;
     // shared modulation row + symmetric inputs (device flags; both can be pinned): folded coord_mlp.0 of every block, and with
     // JODO_OPT_ROT_STATS the LayerNorm statistics of equi_update in the rotated basis (A.rot tells the node kernels and k_node_ab)
     const bool can_fold = p->n_pitems > 0 && !pin_dir && p->opt[JODO_OPT_PIN_UNIFORM_T] != 2 && d.cond_ch == 0;
-    A.rot = (can_fold && p->opt[JODO_OPT_ROT_STATS] != 0) ? 1 : 0;
+    A.rot = can_fold ? p->opt[JODO_OPT_ROT_STATS] : 0;      // 2: rotated with the uncentred Gram tiles (tests)
     if (can_fold) {
         if (d.L > 16) return jodo_set_error(JODO_ERR_UNSUPPORTED, "more than 16 blocks");
         FoldOffs F;

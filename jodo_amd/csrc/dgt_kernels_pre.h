@@ -28,7 +28,7 @@ __global__ void k_flags_init(KArgs A) {
 // Symmetry test of the caller's edge tensors (edge_x, cond_edge_x): the samplers always pass symmetric
 // tensors (symmetric noise, symmetrised predictions), which makes the edge hidden state exactly
 // symmetric and lets the pair kernels (dgt_kernels_sym.h) do the symmetric work once per unordered
-// pair.  Anything else (or a NaN) selects the directed kernels — decided on the device, no host sync.
+// pair.  Anything else selects the directed kernels — decided on the device, no host sync.
 __global__ void k_check_sym(KArgs A) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (b, a, c)
     const size_t NN = (size_t)A.pd.N * A.pd.N;
@@ -40,8 +40,14 @@ __global__ void k_check_sym(KArgs A) {
     const size_t r1 = idx * ch, r2 = ((size_t)b * NN + (size_t)c * A.pd.N + a) * ch;
     bool diff = false;
     for (int f = 0; f < ch; ++f) {
-        diff |= !(A.edge_x[r1 + f] == A.edge_x[r2 + f]);
-        if (A.cond_edge_x) diff |= !(A.cond_edge_x[r1 + f] == A.cond_edge_x[r2 + f]);
+        // (a NaN on both sides counts as equal: a state that went NaN stays on the pair path — also under a symmetric pin — and
+        //  ends in the NaN guard like the reference's, mol_gnn.py:587-589, instead of as a pin violation)
+        const float x1 = A.edge_x[r1 + f], x2 = A.edge_x[r2 + f];
+        diff |= !(x1 == x2 || (x1 != x1 && x2 != x2));
+        if (A.cond_edge_x) {
+            const float c1 = A.cond_edge_x[r1 + f], c2 = A.cond_edge_x[r2 + f];
+            diff |= !(c1 == c2 || (c1 != c1 && c2 != c2));
+        }
     }
     if (diff) atomicOr(&A.flags[FLAG_ASYM], 1);
 }

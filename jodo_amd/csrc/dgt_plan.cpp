@@ -510,6 +510,8 @@ extern "C" int jodo_debug_set_timing_buffer(jodo_plan* p, void* dev16xu64) {
 }
 extern "C" int jodo_debug_set_force_directed(jodo_plan* p, int on) {
     if (!p) return jodo_set_error(JODO_ERR_ARG, "null plan");
+    if (on && p->opt[JODO_OPT_PIN_SYMMETRIC] == 1)
+        return jodo_set_error(JODO_ERR_ARG, "set_force_directed: the plan is pinned to the symmetric path");
     p->force_directed = on;
     return JODO_OK;
 }
@@ -518,8 +520,12 @@ extern "C" int jodo_plan_set_option(jodo_plan* p, int option, int value) {
     if (option < 0 || option >= JODO_OPT_COUNT) return jodo_set_error(JODO_ERR_ARG, "plan_set_option: unknown option %d", option);
     if (option == JODO_OPT_NODE_POST_WAVES && value != 0 && value != 1 && value != 2 && value != 4 && value != 12 && value != 14)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: node-post waves per strip must be 0 (auto), 1, 2 or 4");
-    if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT || option == JODO_OPT_ROT_STATS || option == JODO_OPT_NODE_MIX) && value != 0 && value != 1)
+    if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT || option == JODO_OPT_NODE_MIX) && value != 0 && value != 1)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: option %d is a switch (0 or 1), got %d", option, value);
+    if (option == JODO_OPT_ROT_STATS && (value < 0 || value > 2))
+        return jodo_set_error(JODO_ERR_ARG, "plan_set_option: rotated statistics are 0 (off), 1 (on) or 2 (on, uncentred Gram tiles: tests), got %d", value);
+    if (option == JODO_OPT_PIN_SYMMETRIC && value == 1 && p->force_directed)
+        return jodo_set_error(JODO_ERR_ARG, "plan_set_option: the symmetric pin contradicts jodo_debug_set_force_directed");
     if ((option == JODO_OPT_PIN_SYMMETRIC || option == JODO_OPT_PIN_UNIFORM_T) && (value < 0 || value > 2))
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: a pin is 0 (none), 1 or 2, got %d", value);
     if (option == JODO_OPT_ATTN_VARIANT && (value < 0 || value > 3))

@@ -71,24 +71,36 @@ def unpack_molecules(g):
     return [(pos[i, :k], at[i, :k], bd[i, :k, :k], ch[i, :k]) for i, k in enumerate(n)]
 
 
-def gather_sampled(mols, indices, device=None, group=None):
-    """End-of-sampling collective for `get_sampling_fn(shard=...)`: every rank passes its list of molecule tuples
-    (pos[n,3], atom_type[n], edge_type[n,n], fc[n]) and their global indices (`sampling_fn.last_indices`); returns, on
-    every rank, the full list in global order — the list an unsharded run would have produced.  One all_gather per
-    tensor (RCCL over xGMI on the GPU box when `device` is the rank's GPU; gloo on CPU)."""
-    device = device or 'cpu'
-    B = len(mols)
-    N = max([int(m[0].shape[0]) for m in mols], default=1)
-    pos = torch.zeros(B, N, 3)
-    at = torch.zeros(B, N, dtype=torch.uint8)
-    ch = torch.zeros(B, N, dtype=torch.int8)
-    bd = torch.zeros(B, N, N, dtype=torch.uint8)
-    n = torch.zeros(B, dtype=torch.int32)
-    for k, m in enumerate(mols):
-        nk = int(m[0].shape[0])
-        n[k] = nk
-        pos[k, :nk], at[k, :nk], bd[k, :nk, :nk], ch[k, :nk] = m[0], m[1].to(torch.uint8), m[2].to(torch.uint8), m[3].to(torch.int8)
-    g = gather_molecules(pos.to(device), at.to(device), ch.to(device), bd.to(device), n.to(device), group=group)
+def _cat_rounds(decoded):
+    """Rounds of padded decoded tensors (sampling_fn.last_decoded) -> one padded batch, on the device they live on."""
+    if not decoded:
+        raise ValueError("gather_sampled: no decoded rounds (a rank with no molecules passes decoded=[] and device=...)")
+    N = max(int(r[0].shape[1]) for r in decoded)
+    cat = lambda k, shape: torch.cat([_pad_to(r[k], (r[k].shape[0],) + shape) for r in decoded], dim=0)
+    return cat(0, (N, 3)), cat(1, (N,)), cat(2, (N,)), cat(3, (N, N)), torch.cat([r[4] for r in decoded], dim=0)
+
+
+def gather_sampled(decoded, indices, device=None, group=None):
+    """End-of-sampling collective for `get_sampling_fn(shard=...)`: every rank passes the decoded tensors of its rounds
+    (`sampling_fn.last_decoded`: per round pos [B,N,3] f32, atom_type [B,N] u8, charge [B,N] i8, bond [B,N,N] u8, n_nodes [B] i32 —
+    on the GPU box the outputs of jodo_decode, still on the device: nothing is re-packed on the host) and their global indices
+    (`sampling_fn.last_indices`); returns, on every rank, the full list of molecule tuples (pos[n,3], atom_type[n],
+    edge_type[n,n], fc[n]) in global order — the list an unsharded run would have produced.  One all_gather per tensor
+    (RCCL over xGMI with device tensors and the "nccl" backend; gloo with CPU tensors)."""
+    if decoded:
+        pos, at, ch, bd, n = _cat_rounds(decoded)
+        device = pos.device if device is None else torch.device(device)
+        if pos.device != device:
+            pos, at, ch, bd, n = (t.to(device) for t in (pos, at, ch, bd, n))
+    else:                                                      # a rank whose share is empty still takes part in the collectives
+        device = torch.device(device or 'cpu')
+        pos = torch.zeros(0, 1, 3, device=device)
+        at, ch = torch.zeros(0, 1, dtype=torch.uint8, device=device), torch.zeros(0, 1, dtype=torch.int8, device=device)
+        bd, n = torch.zeros(0, 1, 1, dtype=torch.uint8, device=device), torch.zeros(0, dtype=torch.int32, device=device)
+    B = int(pos.shape[0])
+    if len(indices) != B:
+        raise ValueError("gather_sampled: %d molecules but %d global indices" % (B, len(indices)))
+    g = gather_molecules(pos, at, ch, bd, n, group=group)
     world = dist.get_world_size(group)
     cnt = torch.tensor([B], dtype=torch.int64, device=device)
     cnts = [torch.empty_like(cnt) for _ in range(world)]

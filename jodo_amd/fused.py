@@ -36,10 +36,28 @@ class StepBuffers:
         self.cur = 0
 
 
+def mix64(*words):
+    """splitmix64 finaliser chained over integer words -> one 64-bit value: distinct (seed, rank, round) triples give
+    unrelated keys whatever their sizes (no shifting, no truncation: seeds above 2^32 and ranks above 2^16 stay distinct)."""
+    M = 0xFFFFFFFFFFFFFFFF
+    z = 0x9E3779B97F4A7C15
+    for w in words:
+        w = int(w)
+        while True:                                           # every 64-bit limb of the word, at least one
+            z = (z + (w & M) + 0x9E3779B97F4A7C15) & M
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+            z ^= z >> 31
+            w >>= 64
+            if w <= 0:
+                break
+    return z
+
+
 class DeviceNoise:
     """In-kernel normal draws (jodo_sampler_step_rng / jodo_dpm_update_rng, include/jodo_hip.h): Philox4x32-10 keyed by a
-    64-bit seed; the draw index counts the updates of a round.  `for_rank` derives non-overlapping per-rank keys:
-    the rank sits in the high 32 bits, so rank r of seed s never meets rank r' of seed s'."""
+    64-bit seed; the draw index counts the updates of a round.  `for_rank` hashes (seed, rank, round) into the key
+    (mix64), so the streams of different triples are unrelated."""
 
     def __init__(self, seed, draw=0):
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -47,7 +65,7 @@ class DeviceNoise:
 
     @classmethod
     def for_rank(cls, seed, rank=0, round_index=0):
-        return cls(((int(rank) & 0xFFFF) << 48) | ((int(round_index) & 0xFFFF) << 32) | (int(seed) & 0xFFFFFFFF))
+        return cls(mix64(seed, rank, round_index))
 
     def next_draw(self):
         d = self.draw

@@ -237,6 +237,14 @@ class DPM_Solver_hybrid:
     @torch.no_grad()
     def sampling(self, model, x, node_mask, edge_mask, edge_x, context=None, t_start=None, t_end=None,
                  skip_type='time_uniform'):
+        try:
+            return self._sampling_round(model, x, node_mask, edge_mask, edge_x, context, t_start, t_end, skip_type)
+        finally:
+            unpin = model_hook(model, 'unpin_paths')       # the pin of the first self-conditioned evaluation is scoped to this round
+            if unpin is not None:
+                unpin()
+
+    def _sampling_round(self, model, x, node_mask, edge_mask, edge_x, context, t_start, t_end, skip_type):
         steps, order = self.steps, self.order
         self.cond_x = self.cond_edge_x = None
         self._noise_calls = 0

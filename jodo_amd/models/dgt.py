@@ -386,8 +386,9 @@ class _DGTBase(nn.Module):
         """Pin the kernel variants of the plan of the last call to the ones that call used (device flags [2] shared
         modulation row, [4] asymmetric inputs; one host sync): later calls on the same masks launch only those variants
         instead of every variant + device-side early exits (24 idle dispatches per forward at 8 blocks).  For callers that
-        know the inputs keep their structure — the samplers inside one round.  A violating call is detected on the
-        device and reported by take_nan_count()."""
+        know the inputs keep their structure — the samplers inside one round, which unpin when the round ends
+        (unpin_paths).  A violating call is detected on the device and reported by take_nan_count(); a state that went NaN
+        is not a violation (k_check_sym counts NaN == NaN), it ends in the NaN guard like the reference's."""
         plans = [p for p in getattr(self, '_last_plans', []) if not p.get('pinned')]
         if not plans:
             return
@@ -397,6 +398,18 @@ class _DGTBase(nn.Module):
             capi.check(L.jodo_plan_set_option(plan['handle'], 4, 2 if f[4] else 1), 'jodo_plan_set_option')
             capi.check(L.jodo_plan_set_option(plan['handle'], 5, 1 if f[2] else 2), 'jodo_plan_set_option')
             plan['pinned'] = True
+
+    def unpin_paths(self):
+        """End of the scope of pin_paths(): every cached plan goes back to launching all kernel variants and letting the device
+        flags decide.  The samplers call it when a round ends (also when it ends in an exception), so a later caller that
+        reuses the same mask tensors with other inputs — asymmetric edge tensors, per-molecule noise levels: a likelihood or
+        loss evaluation — gets the right kernels instead of a pin violation."""
+        L = capi.lib()
+        for plan in self._plans.values():
+            if plan.get('pinned'):
+                capi.check(L.jodo_plan_set_option(plan['handle'], 4, 0), 'jodo_plan_set_option')
+                capi.check(L.jodo_plan_set_option(plan['handle'], 5, 0), 'jodo_plan_set_option')
+                plan['pinned'] = False
 
     # -- measurement plumbing (bench.py): HIP-event class timers and the executed-work model of the last call's plan(s) --
     def profile_enable(self, mode):

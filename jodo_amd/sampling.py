@@ -142,9 +142,9 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
                           shard_assign='lpt': greedy longest-processing-time by n^2 for balance) and each rank cuts its
                           share into rounds of up to batch_size (BASELINE config 5: 10 000 molecules on 8 GPUs = one round
                           of 1250 per GPU, not four rounds of 313); the initial noise comes from the generator seeded
-                          `(seed << 20) + 1 + rank` (streams of different (seed, rank) pairs never coincide, and none
-                          coincides with the atom-count stream `seed`), the per-step noise is drawn inside the fused
-                          update kernels (device_noise, below) keyed by (seed, rank, round);
+                          with a 63-bit hash of (seed, 1 + rank) (fused.mix64: unrelated streams for different pairs of any
+                          size, none of them the atom-count stream `seed`), the per-step noise is drawn inside the fused
+                          update kernels (device_noise, below) keyed by a hash of (seed, rank, round);
       shard_mode='parity' every round of the unsharded run is split across the ranks and the unsharded run's noise is
                           replayed (_ParityNoise): the gathered result equals the world-size-1 run.  Slow (full-batch CPU
                           draws per step) — for tests.
@@ -153,7 +153,9 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
     distribution, a different stream than the reference's.  Default: on for shard_mode='perf', off otherwise (an unsharded
     seeded run consumes torch's generator exactly like the reference).  Ignored on CPU tensors and when noise is replayed.
     Returns this rank's molecules; `sampling_fn.last_indices` holds their indices in the global order (rounds *
-    batch_size molecules, as the unsharded run generates them) for the caller's gather (jodo_amd/dist.py)."""
+    batch_size molecules, as the unsharded run generates them) and `sampling_fn.last_decoded` the decoded, padded tensors of
+    every round as they left the decode (on the GPU: the outputs of jodo_decode, still on the device) — what the caller's
+    gather sends (jodo_amd/dist.gather_sampled)."""
     device = config.device
     steps = config.sampling.steps
     atom_types = config.data.atom_types
@@ -217,20 +219,34 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
         finally:
             sampler.noise_fn = None
             sampler.device_noise = None
+            unpin = model_hook(model, 'unpin_paths')       # (the graph-replayed rounds pin too)
+            if unpin is not None:
+                unpin()
         _warn_nan(model)
         if x_node.is_cuda and fused_decode and getattr(inverse_scaler, 'from_config', False):
             # device-side decode: compact u8/i8 results, one device->host copy per tensor
             from . import fused
-            dec = fused.decode(config, x_node, x_edge, fused.n_nodes_from_mask(node_mask))
+            nd = fused.n_nodes_from_mask(node_mask)
+            dec = fused.decode(config, x_node, x_edge, nd)
+            if shard is not None:                              # the gather takes the decoded DEVICE tensors as they are (dist.gather_sampled)
+                decoded_rounds.append(dec + (nd,))
             return fused.mols_from_decoded(*dec, n_nodes)
         pos, one_hot, fc, edge_types = post_process(x_node, atom_types, include_fc, node_mask, inverse_scaler, x_edge,
                                                     edge_mask, compress_edge)
         assert_mean_zero_with_mask(pos, node_mask)
+        if shard is not None:
+            fcq = fc[..., 0] if fc.shape[-1] != 0 else torch.zeros(fc.shape[:2], device=fc.device)
+            decoded_rounds.append((pos, one_hot.argmax(2).to(torch.uint8), fcq.round().to(torch.int8), edge_types.to(torch.uint8),
+                                   torch.as_tensor([int(n) for n in n_nodes], dtype=torch.int32, device=pos.device)))
         return mol_process(one_hot, pos, fc, n_nodes, edge_types)
+
+    decoded_rounds = []          # per round of a sharded run: (pos [B,N,3] f32, atom_type [B,N] u8, charge [B,N] i8, bond [B,N,N] u8, n_nodes [B] i32)
 
     def sampling_fn(model):
         model.eval()
         mols = []
+        del decoded_rounds[:]
+        sampling_fn.last_decoded = decoded_rounds
         total = rounds * batch_size
         with torch.no_grad():
             if shard is None:                                  # the reference's procedure
@@ -258,8 +274,9 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
                 else:
                     lo, hi = shard_range(total, rank, world)
                     mine = list(range(lo, hi))
-                torch.manual_seed((base << 20) + 1 + rank)     # this rank's own stream (CPU and device generators); streams
-                                                               # of different (seed, rank) never coincide
+                from .fused import mix64
+                torch.manual_seed(mix64(base, 1 + rank) >> 1)  # this rank's own stream (CPU and device generators): a 63-bit
+                                                               # hash of (seed, rank), any seed / rank size
                 for r0 in range(0, len(mine), batch_size):
                     idx = torch.as_tensor(mine[r0:r0 + batch_size], dtype=torch.long)
                     context = context_all[idx].to(device) if context_all is not None else None
@@ -285,6 +302,7 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
         return mols                                            # caller gathers / shuffles
 
     sampling_fn.last_indices = None
+    sampling_fn.last_decoded = decoded_rounds
     return sampling_fn
 
 
@@ -424,7 +442,12 @@ class AncestralSampler:
         if not self.pred_edge:
             raise NotImplementedError("edge-free sampling is out of scope")
         st = self.init_state(z_T, edge_z_T)
-        for i in range(len(self.t_array)):
-            st = self.step(model, i, st, node_mask, edge_mask, context)
+        try:
+            for i in range(len(self.t_array)):
+                st = self.step(model, i, st, node_mask, edge_mask, context)
+        finally:
+            unpin = model_hook(model, 'unpin_paths')       # the pin of step 1 is scoped to this round
+            if unpin is not None:
+                unpin()
         assert_mean_zero_with_mask(st['x_mean'][:, :, :3], node_mask)
         return st['x_mean'], st['edge_x_mean']

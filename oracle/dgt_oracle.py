@@ -265,8 +265,9 @@ def forward_dense(p, hp, xh, node_mask, edge_mask, edge_x, cond_x=None, cond_edg
     else:
         first = True
 
-    out_x = torch.zeros(bs, N, 3 + hp.in_node_dim)
-    out_e = torch.zeros(bs, N, N, hp.edge_ch)
+    dt = xh.dtype                        # float64 inputs + a float64 state_dict give the yardstick of the GPU tests
+    out_x = torch.zeros(bs, N, 3 + hp.in_node_dim, dtype=dt)
+    out_e = torch.zeros(bs, N, N, hp.edge_ch, dtype=dt)
     inter = [] if return_intermediates else None
     pos_all = []
     for b in range(bs):
@@ -280,22 +281,22 @@ def forward_dense(p, hp, xh, node_mask, edge_mask, edge_x, cond_x=None, cond_edg
             cpos = cond_x[b, :n, 0:3]
             cfeat = cond_x[b, :n, 3:]
             cex = cond_edge_x[b, :n, :n]
-            adj2d = (cex[..., 0] >= hp.edge_quan_th).float()
+            adj2d = (cex[..., 0] >= hp.edge_quan_th).to(dt)
         else:
-            cpos = torch.zeros(n, 3)
+            cpos = torch.zeros(n, 3, dtype=dt)
             cfeat = torch.zeros_like(feat)
             cex = torch.zeros_like(ex)
-            adj2d = torch.ones(n, n)
+            adj2d = torch.ones(n, n, dtype=dt)
         d2c = ((cpos[:, None, :] - cpos[None, :, :]) ** 2).sum(-1, keepdim=True)   # [n,n,1]
-        adjsp = (d2c[..., 0] <= hp.spatial_cut_off).float()
+        adjsp = (d2c[..., 0] <= hp.spatial_cut_off).to(dt)
         if first:
-            G0 = torch.zeros(n, n, De)
+            G0 = torch.zeros(n, n, De, dtype=dt)
         else:
             G0 = _gbf(p, 'dist_layer', d2c, tb)
         e = _lin(p, 'edge_emb', torch.cat([ex, cex, G0], dim=-1))                   # [n,n,De]
         h = _lin(p, 'node_emb', torch.cat([feat, cfeat], dim=-1))                  # [n,D]
         ah, eh = [h], [e]
-        negmask = torch.where(offd, 0.0, float('-inf'))                             # exclude a == c
+        negmask = torch.where(offd, 0.0, float('-inf')).to(dt)                             # exclude a == c
         blocks = []
         for l in range(L):
             bk = 'e_block_%d' % l
@@ -311,8 +312,8 @@ def forward_dense(p, hp, xh, node_mask, edge_mask, edge_x, cond_x=None, cond_edg
             v = _lin(p, bk + '.attn_mpnn.lin_value', ht).reshape(n, H, C)
             t0 = torch.tanh(_lin(p, bk + '.attn_mpnn.lin_edge0', et, bias=False)).reshape(n, n, SH, SC)
             S = (q[None, :, :, :] * k[:, None, :, :] * t0).sum(-1) / math.sqrt(C)   # [a,c,SH]
-            h0 = torch.where(adj2d > 0, 1.0, -1e10)
-            h1 = torch.where(adjsp > 0, 1.0, -1e10)
+            h0 = torch.where(adj2d > 0, 1.0, -1e10).to(dt)
+            h1 = torch.where(adjsp > 0, 1.0, -1e10).to(dt)
             S = torch.cat([h0[..., None], h1[..., None], S], dim=-1)               # [a,c,H]
             Sm = S + negmask[..., None]
             if n > 1:
@@ -338,7 +339,7 @@ def forward_dense(p, hp, xh, node_mask, edge_mask, edge_x, cond_x=None, cond_edg
             u = _ln(pre) * (1 + sc) + sh
             inv = torch.tanh(F.linear(F.silu(_lin(p, bk + '.equi_update.coord_mlp.0', u)),
                                       p[bk + '.equi_update.coord_mlp.2.weight']))   # [a,c,3]
-            adjs = torch.stack([torch.ones(n, n), adj2d, adjsp], dim=-1)
+            adjs = torch.stack([torch.ones(n, n, dtype=dt), adj2d, adjsp], dim=-1)
             iota = (inv * adjs).mean(-1, keepdim=True)
             nrm = diff.norm(dim=-1, keepdim=True).clamp(min=1e-8)
             trans = diff / nrm * p[bk + '.equi_update.coord_norm.scale'] * iota

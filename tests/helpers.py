@@ -102,6 +102,65 @@ def debug_fetch(model, what, count):
     return dst[:cnt.value].cpu()
 
 
+# ---- the forward tolerance and its float64 yardstick -------------------------------------------------------------------
+# SURVEY.md §8c / DESIGN.md §2: a single forward agrees with the reference within atol 2e-5 + rtol 1e-4.  Against the fixtures the
+# reference itself produced that bound is applied as it stands (test_hip_matches_reference_fixture).  On fresh inputs the checker is
+# the float32 CPU oracle, which is itself only an fp32 evaluation: where its own distance from the float64 evaluation of the same
+# formulas exceeds the bound (long position sums at gain 1.5, n = 150), "HIP vs oracle32" measures the oracle, not the kernels.
+# close64 therefore compares with the FLOAT64 oracle and allows  max(2e-5 + 1e-4 |x|,  K64 * max |oracle32 - oracle64|):
+# the stated bound wherever fp32 arithmetic can meet it, and never more than K64 times the error of an fp32 evaluation in the
+# reference's own operation order.  Every comparison is logged (gpurun_out/parity_errors.jsonl) so that DESIGN.md quotes measured
+# numbers.
+FWD_ATOL, FWD_RTOL, K64 = 2e-5, 1e-4, 4.0
+_SD64 = {}
+
+
+def oracle_dense(sd, hp, xh, nm, em, ex, cx=None, cex=None, nl=None, ctx=None, dtype=torch.float32):
+    """oracle.forward_dense at float32 (the checker the round-1..3 tests used) or float64 (the yardstick)."""
+    if dtype == torch.float64:
+        key = id(sd)
+        if key not in _SD64 or _SD64[key][0] is not sd:
+            _SD64.clear()
+            _SD64[key] = (sd, {k: v.double() for k, v in sd.items()})
+        sd = _SD64[key][1]
+    c = lambda t: None if t is None else t.detach().cpu().to(dtype)
+    with torch.no_grad():
+        return O.forward_dense(sd, hp, c(xh), c(nm), c(em), c(ex), c(cx), c(cex), c(nl), c(ctx))
+
+
+def oracle_32_64(sd, hp, xh, nm, em, ex, cx=None, cex=None, nl=None, ctx=None):
+    return (oracle_dense(sd, hp, xh, nm, em, ex, cx, cex, nl, ctx, torch.float32),
+            oracle_dense(sd, hp, xh, nm, em, ex, cx, cex, nl, ctx, torch.float64))
+
+
+def _log_parity(rec):
+    import json
+    try:
+        d = os.path.join(os.path.dirname(GOLDEN.rstrip('/')), '..', 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        rec['test'] = os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0]
+        with open(os.path.join(d, 'parity_errors.jsonl'), 'a') as f:
+            f.write(json.dumps(rec) + '\n')
+    except OSError:
+        pass
+
+
+def close64(got, r32, r64, what='', k=K64, atol=FWD_ATOL, rtol=FWD_RTOL):
+    """got (HIP) against the float64 oracle r64: elementwise |got - r64| <= max(atol + rtol |r64|, k * e32) with
+    e32 = max |r32 - r64| over the tensor (the float32 oracle's own error).  Returns (err, e32)."""
+    g, a, b = got.detach().cpu().double(), r32.detach().cpu().double(), r64.detach().cpu().double()
+    err = (g - b).abs()
+    e32 = float((a - b).abs().max()) if a.numel() else 0.0
+    bound = torch.clamp(atol + rtol * b.abs(), min=k * e32)
+    worst = float(err.max()) if err.numel() else 0.0
+    inside = bool((err <= atol + rtol * b.abs()).all())
+    _log_parity(dict(what=what, err_hip_vs_f64=worst, err_oracle32_vs_f64=e32, max_abs=float(b.abs().max()) if b.numel() else 0.0,
+                     inside_stated_bound=inside))
+    assert bool((err <= bound).all()), "%s: max |HIP - f64| %.3e; stated bound %.0e + %.0e |x|; float32 oracle is %.3e from f64 (x%.0f allowed)" % (
+        what, worst, atol, rtol, e32, k)
+    return worst, e32
+
+
 def max_err(a, b):
     return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
 

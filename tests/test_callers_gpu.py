@@ -20,7 +20,7 @@ import torch
 from oracle import dgt_oracle as O
 from oracle import philox_ref as PR
 
-from helpers import load_fixture, make_config, make_model, masks, state_dict_cpu
+from helpers import close64, load_fixture, make_config, make_model, masks, oracle_32_64, state_dict_cpu
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -278,10 +278,10 @@ def test_dpm_50_nfe_round_teacher_forced_against_oracle():
     with torch.no_grad():
         for k, (xs, es, cx, ce, nl, cs, ox, oe) in enumerate(rec):
             assert (cx is None) == (k == 0)
-            r = O.forward_dense(sd, hp, xs, nms, ems, es, cx, ce, nl, cs)
-            close(ox, r[0], atol=5e-5)
-            close(oe, r[1], atol=5e-5)
-            worst = max(worst, (ox - r[0]).abs().max().item(), (oe - r[1]).abs().max().item())
+            r, r64 = oracle_32_64(sd, hp, xs, nms, ems, es, cx, ce, nl, cs)
+            wx, _ = close64(ox, r[0], r64[0], 'DPM evaluation %d nodes' % k)
+            we, _ = close64(oe, r[1], r64[1], 'DPM evaluation %d edges' % k)
+            worst = max(worst, wx, we)
     print("50-NFE teacher-forced worst |err| (24 of 313 molecules, every evaluation): %.2e" % worst)
 
 
@@ -342,6 +342,89 @@ def test_two_dpm_rounds_through_one_sampling_fn(hip_graph):
     assert [int(m[0].shape[0]) for m in both] == r1 + r2
 
 
+# ---- the RCCL leg at world size 1: the code the 8-GPU run takes, executed on the one GPU there is -------------
+_NCCL_WORKER = r"""
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, os.environ['JODO_ROOT']); sys.path.insert(0, os.path.join(os.environ['JODO_ROOT'], 'tests'))
+from helpers import make_config, make_model
+from jodo_amd.diffusion import NoiseScheduleVP
+from jodo_amd.dist import gather_sampled
+from jodo_amd.models import load_dataset_info, get_node_dist
+from jodo_amd.sampling import get_sampling_fn
+from jodo_amd.utils import get_data_inverse_scaler
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1)
+out = {}
+for method, steps in (('ancestral', 4), ('fast', 6)):
+    cfg = make_config('vpsde_qm9_uncond_jodo')
+    cfg.device = torch.device('cuda:0')
+    cfg.sampling.steps, cfg.sampling.method = steps, method
+    cfg.sampling['dpm_solver_method'], cfg.sampling['dpm_solver_order'] = 'singlestep_fixed', 2
+    model = make_model(cfg, 5, 'cuda:0', head_gain=30.0)
+    ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
+    nodes_dist, inv = get_node_dist(load_dataset_info('qm9_with_h')), get_data_inverse_scaler(cfg)
+    torch.manual_seed(77)
+    want = get_sampling_fn(cfg, ns, nodes_dist, 5, 9, inv, return_raw=True)(model)          # the reference's procedure, unsharded
+    res = {}
+    for mode in ('parity', 'perf'):
+        fn = get_sampling_fn(cfg, ns, nodes_dist, 5, 9, inv, shard=(0, 1), shard_mode=mode, seed=77)
+        mine = fn(model)
+        assert all(t.is_cuda for r in fn.last_decoded for t in r), "the gather must take the device tensors jodo_decode left"
+        full = gather_sampled(fn.last_decoded, fn.last_indices, device='cuda:0')        # all_reduce + all_gather over RCCL
+        torch.cuda.synchronize()
+        res[mode] = dict(n=len(full), indices_ok=fn.last_indices == list(range(10)),
+                         same_as_local=all(all(torch.equal(a, b) for a, b in zip(m, w)) for m, w in zip(full, mine)),
+                         sizes_as_unsharded=[int(m[0].shape[0]) for m in full] == [int(m[0].shape[0]) for m in want],
+                         sizes=[int(m[0].shape[0]) for m in full], mols=full)
+    again = get_sampling_fn(cfg, ns, nodes_dist, 5, 9, inv, shard=(0, 1), shard_mode='parity', seed=77)
+    again(model)
+    rep = gather_sampled(again.last_decoded, again.last_indices, device='cuda:0')
+    res['parity']['replayable'] = all(all(torch.equal(a, b) for a, b in zip(m, w)) for m, w in zip(rep, res['parity']['mols']))
+    for mode in res:
+        del res[mode]['mols']
+    out[method] = res
+# the collective itself on every dtype of the wire format
+for dt in (torch.uint8, torch.int8, torch.int32, torch.int64, torch.float32):
+    t = (torch.arange(12, device='cuda:0') % 5).to(dt).reshape(3, 4)
+    buf = [torch.empty_like(t)]
+    dist.all_gather(buf, t)
+    assert torch.equal(buf[0], t), dt
+dist.barrier()
+out['backend'] = dist.get_backend()
+dist.destroy_process_group()
+print('RESULT ' + json.dumps(out))
+"""
+
+
+def test_rccl_leg_at_world_size_one():
+    """dist.init_process_group('nccl', world_size=1) on cuda:0 in a child process: sharded rounds (parity and perf mode, ancestral
+    and hybrid DPM-solver) through get_sampling_fn(shard=(0, 1)) + dist.gather_sampled on the decoded DEVICE tensors: the gathered
+    list must equal the rank's own molecules bit for bit and in global order, carry the atom counts of the unsharded run (shared
+    seed), and a parity-mode run must be replayable.  (Molecule-for-molecule equality with the UNSHARDED run is the gloo test's
+    job, tests/test_dist_gloo.py: parity mode replays CPU draws, an unsharded GPU run draws on the device.)  These are the exact
+    calls the 8-GPU run makes (all_reduce MAX of the padded sizes, one all_gather per tensor of u8 / i8 / i32 /
+    i64 / f32), with HSA_ENABLE_IPC_MODE_LEGACY as the launcher exports it."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, JODO_ROOT=root, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    p = subprocess.run([sys.executable, '-c', _NCCL_WORKER], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith('RESULT ')][-1]
+    out = json.loads(line[7:])
+    assert out['backend'] == 'nccl'
+    for method in ('ancestral', 'fast'):
+        par, perf = out[method]['parity'], out[method]['perf']
+        assert par['n'] == 10 and par['indices_ok'] and par['same_as_local'] and par['sizes_as_unsharded'] and par['replayable'], out
+        assert perf['n'] == 10 and perf['indices_ok'] and perf['same_as_local'] and perf['sizes_as_unsharded'] and len(set(perf['sizes'])) > 1, out
+
+
 # ---- checkpoint ingestion on the device (SURVEY.md §8f row 3) --------------------------------------------------------
 def test_checkpoint_ema_overwrite_reaches_the_kernels(tmp_path):
     """Reference-format checkpoint (utils.py:23-30: DataParallel keys, positional EMA shadow list) -> load_for_sampling ->
@@ -379,13 +462,12 @@ def test_checkpoint_ema_overwrite_reaches_the_kernels(tmp_path):
         return o[0].cpu(), o[1].cpu()
 
     def oracle(src):
-        with torch.no_grad():
-            return O.forward_dense(state_dict_cpu(src), hp, xh, nm, em, ex, None, None, nl)
+        return oracle_32_64(state_dict_cpu(src), hp, xh, nm, em, ex, None, None, nl)
 
     got = hip(d(nm), d(em))
-    want = oracle(shadow_src)
-    close(got[0], want[0], atol=5e-5)
-    close(got[1], want[1], atol=5e-5)
+    want, w64 = oracle(shadow_src)
+    close64(got[0], want[0], w64[0], 'EMA weights nodes')
+    close64(got[1], want[1], w64[1], 'EMA weights edges')
     # reference-style EMA restore: param.data.copy_ (no version bump), then a NEW round (new mask tensors)
     third = make_model(cfg, 3, 'cpu', gain=0.8, coord_scale=0.05)
     versions = [p._version for p in model.parameters()]
@@ -393,7 +475,7 @@ def test_checkpoint_ema_overwrite_reaches_the_kernels(tmp_path):
         p.data.copy_(q.data.to(DEV))
     assert [p._version for p in model.parameters()] == versions
     got = hip(d(nm.clone()), d(em.clone()))
-    want = oracle(third)
-    close(got[0], want[0], atol=5e-5)
-    close(got[1], want[1], atol=5e-5)
-    assert not torch.allclose(want[0], oracle(shadow_src)[0], atol=1e-3)          # the two weight sets really differ
+    want, w64 = oracle(third)
+    close64(got[0], want[0], w64[0], 'copied weights nodes')
+    close64(got[1], want[1], w64[1], 'copied weights edges')
+    assert not torch.allclose(want[0], oracle(shadow_src)[0][0], atol=1e-3)          # the two weight sets really differ

@@ -11,7 +11,7 @@ import torch
 
 from oracle import dgt_oracle as O
 
-from helpers import (check_decodes, debug_fetch, load_fixture, make_config, make_model, masks, random_inputs,
+from helpers import (check_decodes, close64, debug_fetch, load_fixture, make_config, make_model, masks, oracle_32_64, random_inputs,
                      reference_blocks_dense, state_dict_cpu)
 
 pytestmark = pytest.mark.gpu
@@ -23,6 +23,16 @@ def close(got, want, atol=2e-5, rtol=1e-4):
     err = (got - want).abs()
     bound = atol + rtol * want.abs()
     assert bool((err <= bound).all()), "max err %.3e (bound %.1e + %.0e*|x|)" % (err.max().item(), atol, rtol)
+
+
+def check64(got, sd, hp, xh, nm, em, ex, cx, cex, nl, ctx=None, what=''):
+    """HIP outputs against the float64 oracle on the same inputs, at the forward tolerance (helpers.close64: the stated
+    2e-5 + 1e-4 |x|, widened only where the float32 oracle itself is further than that from float64).  Returns the float32
+    oracle's outputs (self-conditioning inputs of a following call)."""
+    r32, r64 = oracle_32_64(sd, hp, xh, nm, em, ex, cx, cex, nl, ctx)
+    close64(got[0], r32[0], r64[0], what + ' nodes')
+    close64(got[1], r32[1], r64[1], what + ' edges')
+    return r32
 
 
 def run(model, xh, ex, nl, nm, em, cx=None, cex=None, ctx=None):
@@ -87,14 +97,10 @@ def test_hip_matches_oracle(cfg_name, n_nodes, gain, chunk, over):
     hp = O.Hyper.from_config(cfg)
     sd = state_dict_cpu(model)
     xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=len(n_nodes))
-    with torch.no_grad():
-        r1 = O.forward_dense(sd, hp, xh, nm, em, ex, None, None, nl, ctx)
-        r2 = O.forward_dense(sd, hp, xh, nm, em, ex, r1[0], r1[1], nl, ctx)
     o1 = run(model, xh, ex, nl, nm, em, None, None, ctx)
+    r1 = check64(o1, sd, hp, xh, nm, em, ex, None, None, nl, ctx, 'first step')
     o2 = run(model, xh, ex, nl, nm, em, r1[0], r1[1], ctx)
-    for got, want in ((o1, r1), (o2, r2)):
-        close(got[0], want[0], atol=5e-5)
-        close(got[1], want[1], atol=5e-5)
+    check64(o2, sd, hp, xh, nm, em, ex, r1[0], r1[1], nl, ctx, 'self-conditioned')
 
 
 def test_attention_kernel_variants_agree():
@@ -111,11 +117,7 @@ def test_attention_kernel_variants_agree():
         o1 = run(model, xh, ex, nl, nm, em)
         outs.append(run(model, xh, ex, nl, nm, em, o1[0], o1[1]))
     sd = state_dict_cpu(model)
-    with torch.no_grad():
-        r1 = O.forward_dense(sd, hp, xh, nm, em, ex, None, None, nl)
-        r2 = O.forward_dense(sd, hp, xh, nm, em, ex, r1[0], r1[1], nl)
-    close(outs[0][0], r2[0], atol=5e-5)
-    close(outs[0][1], r2[1], atol=5e-5)
+    check64(outs[0], sd, hp, xh, nm, em, ex, o1[0], o1[1], nl, None, 'variant 0, self-conditioned on its own first step')
     for o in outs[1:]:
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
 
@@ -142,37 +144,36 @@ def test_uniform_and_per_molecule_noise_levels_agree(cfg_name, n_nodes, gain, ov
     sd = state_dict_cpu(model)
     xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=1)
     nl_u = torch.full_like(nl, 0.37)
-    with torch.no_grad():
-        r1 = O.forward_dense(sd, hp, xh, nm, em, ex, None, None, nl_u, ctx)
-        r2 = O.forward_dense(sd, hp, xh, nm, em, ex, r1[0], r1[1], nl_u, ctx)
     a1 = run(model, xh, ex, nl_u, nm, em)
     assert model.last_flags.cpu().tolist()[2] == 1          # shared time row
+    r1 = check64(a1, sd, hp, xh, nm, em, ex, None, None, nl_u, ctx, 'shared row, first step')
     a2 = run(model, xh, ex, nl_u, nm, em, r1[0], r1[1])
     assert model.last_flags.cpu().tolist()[2] == 1
-    for got, want in ((a1, r1), (a2, r2)):
-        close(got[0], want[0], atol=5e-5)
-        close(got[1], want[1], atol=5e-5)
+    check64(a2, sd, hp, xh, nm, em, ex, r1[0], r1[1], nl_u, ctx, 'shared row, self-conditioned')
     nl_p = nl_u.clone()
     nl_p[0] += 1e-6                                          # forces the per-molecule path for the others
     b = run(model, xh, ex, nl_p, nm, em)
     assert model.last_flags.cpu().tolist()[2] == 0
-    close(a1[0][1:], b[0][1:], atol=5e-5)
-    close(a1[1][1:], b[1][1:], atol=5e-5)
+    check64(b, sd, hp, xh, nm, em, ex, None, None, nl_p, ctx, 'per-molecule rows, first step')
+    # path against path: each side is held to the forward tolerance above, so the two differ by at most twice that
+    close(a1[0][1:], b[0][1:], atol=4e-5, rtol=2e-4)
+    close(a1[1][1:], b[1][1:], atol=4e-5, rtol=2e-4)
 
 
-@pytest.mark.parametrize("cfg_name,n_nodes,gain,over,atol", [
-    ('vpsde_qm9_uncond_jodo', [6, 11, 20, 29, 1, 2, 29, 29, 17, 3], 1.5, {}, 5e-5),
-    ('vpsde_qm9_uncond_jodo', [5] * 14 + [19] * 10, 1.5, dict(kernel_layout='wide'), 5e-5),
-    # molecules across many strips, n > 128: position sums over 149 neighbours at gain 1.5 — measured against the oracle in
-    # float64 (tools/rot_err.py): rotated 1.1e-4, plain fold 2.7e-4, the float32 oracle itself 4e-5
-    ('vpsde_geom_uncond_jodo', [70, 33, 12, 150, 1, 2], 1.5, {}, 4e-4),
-    ('vpsde_geom_uncond_jodo', [70, 33, 12, 1, 2], 1.5, dict(nf=384), 5e-5),
-    ('vpsde_geom_uncond_jodo', [70, 33, 12, 1, 2], 1.5, dict(nf=128, n_layers=6), 5e-5),
+@pytest.mark.parametrize("cfg_name,n_nodes,gain,over", [
+    ('vpsde_qm9_uncond_jodo', [6, 11, 20, 29, 1, 2, 29, 29, 17, 3], 1.5, {}),
+    ('vpsde_qm9_uncond_jodo', [5] * 14 + [19] * 10, 1.5, dict(kernel_layout='wide')),
+    # molecules across many strips, n > 128: position sums over 149 neighbours at gain 1.5 — here the float32 oracle itself
+    # is ~4e-5 from float64 (round 3 measured rotated 1.1e-4, plain fold 2.7e-4 against float64 and used atol 4e-4)
+    ('vpsde_geom_uncond_jodo', [70, 33, 12, 150, 1, 2], 1.5, {}),
+    ('vpsde_geom_uncond_jodo', [70, 33, 12, 1, 2], 1.5, dict(nf=384)),
+    ('vpsde_geom_uncond_jodo', [70, 33, 12, 1, 2], 1.5, dict(nf=128, n_layers=6)),
 ])
-def test_rotated_statistics_match_plain_fold_and_oracle(cfg_name, n_nodes, gain, over, atol):
+def test_rotated_statistics_match_plain_fold_and_oracle(cfg_name, n_nodes, gain, over):
     """JODO_OPT_ROT_STATS (default on): under a shared modulation row the pair update takes the LayerNorm statistics of
     equi_update in the rotated basis (triangular L [e ; G] per pair, Q P W_row h / Q P W_col h per node, Gram tile per molecule).
-    Different arithmetic from the plain folded path (option 6 = 0): both are held to the oracle and to each other."""
+    Different arithmetic from the plain folded path (option 6 = 0): both — first-step AND self-conditioned outputs — are held to
+    the float64 oracle at the forward tolerance, and to each other at twice that."""
     cfg = make_config(cfg_name, **over)
     hp = O.Hyper.from_config(cfg)
     xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=17)
@@ -180,21 +181,83 @@ def test_rotated_statistics_match_plain_fold_and_oracle(cfg_name, n_nodes, gain,
     outs = {}
     model = make_model(cfg, 11, DEV, gain=gain, coord_scale=0.05)
     sd = state_dict_cpu(model)
-    with torch.no_grad():
-        r1 = O.forward_dense(sd, hp, xh, nm, em, ex, None, None, nl)
+    r1 = r2 = None
     for rot in (1, 0):
         model = make_model(cfg, 11, DEV, gain=gain, coord_scale=0.05)
         model.plan_options = {6: rot}
         o1 = run(model, xh, ex, nl, nm, em)
         assert model.last_flags.cpu().tolist()[2] == 1 and model.last_flags.cpu().tolist()[4] == 0
-        outs[rot] = (o1, run(model, xh, ex, nl, nm, em, r1[0], r1[1]))       # self-conditioned on the oracle's prediction: same inputs
-    for rot in (1, 0):
-        close(outs[rot][0][0], r1[0], atol=atol)
-        close(outs[rot][0][1], r1[1], atol=atol)
+        if r1 is None:
+            r1 = oracle_32_64(sd, hp, xh, nm, em, ex, None, None, nl)
+            r2 = oracle_32_64(sd, hp, xh, nm, em, ex, r1[0][0], r1[0][1], nl)
+        outs[rot] = (o1, run(model, xh, ex, nl, nm, em, r1[0][0], r1[0][1]))     # self-conditioned on the oracle's prediction: same inputs
+        for step, got, (r32, r64) in ((1, outs[rot][0], r1), (2, outs[rot][1], r2)):
+            close64(got[0], r32[0], r64[0], 'rot %d step %d nodes' % (rot, step))
+            close64(got[1], r32[1], r64[1], 'rot %d step %d edges' % (rot, step))
+    e32 = max(float((r1[0][k].double() - r1[1][k]).abs().max()) for k in (0, 1))
     for k in (0, 1):
-        close(outs[1][k][0], outs[0][k][0], atol=atol)
-        close(outs[1][k][1], outs[0][k][1], atol=atol)
+        close(outs[1][k][0], outs[0][k][0], atol=max(4e-5, 8 * e32), rtol=2e-4)
+        close(outs[1][k][1], outs[0][k][1], atol=max(4e-5, 8 * e32), rtol=2e-4)
     assert not torch.equal(outs[1][0][0], outs[0][0][0])          # the two paths really differ
+
+
+def _make_adversarial(model, D, L, eps, common, seed=0):
+    """Weights random initialisation never visits and trained ones plausibly do (round-3 review): a DISTANCE-LIKE input_lin,
+    W_col = -W_row + eps * noise, so that the per-node halves of `pre` cancel wherever two atoms carry similar features, and a large
+    component shared by all atoms of a molecule in h (the LayerNorm2 shift of every block, node_time_mlp chunk ns2, + common *
+    unit-variance vector) — kappa = |W_row h_a| / |W_row h_a + W_col h_c| ~ common / sqrt(2).  The uncentred Gram form of the rotated
+    statistics loses kappa^2 eps_fp32 there (modelled in tests/test_packing.py), the reference-centred one kappa eps_fp32."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        sd = model.state_dict()
+        for l in range(L):
+            W = sd['e_block_%d.equi_update.input_lin.weight' % l]
+            b = float(W[:, :D].abs().max())
+            noise = ((torch.rand(D, D, generator=g) * 2 - 1) * b).to(W.device)
+            W[:, D:2 * D] = -W[:, :D] + eps * noise
+            sd['e_block_%d.node_time_mlp.1.bias' % l][3 * D:4 * D] += common * torch.randn(D, generator=g).to(W.device)
+    return model
+
+
+@pytest.mark.parametrize("cfg_name,n_nodes,gain,eps,common,over", [
+    ('vpsde_qm9_uncond_jodo', [2, 29, 29, 17, 5, 1, 23, 29, 9, 2], 1.5, 1e-3, 100.0, {}),
+    ('vpsde_qm9_uncond_jodo', [2, 29, 29, 17, 5, 1, 23, 29, 9, 2], 3.0, 1e-2, 30.0, {}),
+    ('vpsde_qm9_uncond_jodo', [2, 29, 18, 18, 7], 5.0, 0.0, 100.0, dict(kernel_layout='wide')),
+    ('vpsde_geom_uncond_jodo', [181, 2, 29, 70], 3.0, 1e-3, 100.0, {}),
+    ('vpsde_geom_uncond_jodo', [181, 2, 29, 70], 1.5, 1e-3, 100.0, dict(nf=384)),
+])
+def test_rotated_statistics_on_adversarial_weights(cfg_name, n_nodes, gain, eps, common, over):
+    """JODO_OPT_ROT_STATS on weights built to make the two per-node rows of equi_update's LayerNorm input cancel (see
+    _make_adversarial), uniform noise level (the only case the rotated path runs in), n in {1, 2, 29, 181}, trunk gain 1.5 - 5.
+    The default path (rotated statistics, Gram tiles taken around a reference atom) and the plain fold must both stay within the
+    forward tolerance of the float64 oracle; the uncentred Gram tiles of round 3 (option value 2) are run beside them and their
+    error is logged — on these weights they are the ones that drift."""
+    cfg = make_config(cfg_name, **over)
+    hp = O.Hyper.from_config(cfg)
+    xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=23)
+    nl = torch.full_like(nl, 0.4)
+    errs, r = {}, None
+    for rot in (1, 0, 2):
+        model = _make_adversarial(make_model(cfg, 13, DEV, gain=gain, coord_scale=0.05), hp.nf, hp.n_layers, eps, common)
+        model.plan_options = {6: rot}
+        o1 = run(model, xh, ex, nl, nm, em)
+        fl = model.last_flags.cpu().tolist()
+        assert fl[0] == 0 and fl[2] == 1 and fl[4] == 0          # no NaN, shared row, pair path
+        if r is None:
+            sd = state_dict_cpu(model)
+            r1 = oracle_32_64(sd, hp, xh, nm, em, ex, None, None, nl)
+            r = (r1, oracle_32_64(sd, hp, xh, nm, em, ex, r1[0][0], r1[0][1], nl))
+        o2 = run(model, xh, ex, nl, nm, em, r[0][0][0], r[0][0][1])
+        errs[rot] = max(float((g.double() - w64[k]).abs().max()) for g2, (w32, w64) in ((o1, r[0]), (o2, r[1])) for k, g in enumerate(g2))
+        if rot != 2:
+            for step, got, (r32, r64) in ((1, o1, r[0]), (2, o2, r[1])):
+                close64(got[0], r32[0], r64[0], 'adversarial rot %d step %d nodes' % (rot, step))
+                close64(got[1], r32[1], r64[1], 'adversarial rot %d step %d edges' % (rot, step))
+    e32 = max(float((a.double() - b).abs().max()) for (r32, r64) in r for a, b in zip(r32, r64))
+    print("adversarial %s gain %g eps %g common %g: |HIP - f64| rotated %.2e, plain fold %.2e, uncentred Gram %.2e; float32 oracle %.2e"
+          % (cfg_name, gain, eps, common, errs[1], errs[0], errs[2], e32))
+    from helpers import _log_parity
+    _log_parity(dict(what='adversarial summary', rotated=errs[1], plain=errs[0], uncentred=errs[2], oracle32=e32, gain=gain, eps=eps, common=common))
 
 
 def test_invariants():
@@ -245,10 +308,10 @@ def test_asymmetric_inputs_follow_the_reference_semantics():
     cx = torch.randn_like(xh) * nm
     cex = torch.randn_like(ex) * em.reshape(2, 13, 13, 1)
     with torch.no_grad():
-        want = O.forward_faithful(sd, hp, xh, nm, em, ex, cx, cex, nl)
+        want = O.forward_faithful(sd, hp, xh, nm, em, ex, cx, cex, nl)      # the reference's own (sparse) formulation
     got = run(model, xh, ex, nl, nm, em, cx, cex)
-    close(got[0], want[0], atol=5e-5)
-    close(got[1], want[1], atol=5e-5)
+    r32 = check64(got, sd, hp, xh, nm, em, ex, cx, cex, nl, None, 'asymmetric inputs')
+    assert (want[0] - r32[0]).abs().max() < 1e-5 and (want[1] - r32[1]).abs().max() < 1e-5      # dense == faithful on them too
 
 
 def test_nan_guard_zeroes_positions():
@@ -456,13 +519,9 @@ def test_full_size_batches_match_oracle_on_sampled_molecules(cfg_name, info, B, 
         nms, ems = masks(pn)
         cut = lambda a, k: a[part][:, :Ns] if k == 1 else a[part][:, :Ns, :Ns]
         cp = ctx[part] if ctx is not None else None
-        with torch.no_grad():
-            r1 = O.forward_dense(sd, hp, cut(xh, 1), nms, ems, cut(ex, 2), None, None, nl[part], cp)
-            r2 = O.forward_dense(sd, hp, cut(xh, 1), nms, ems, cut(ex, 2), cut(x1, 1), cut(e1, 2), nl[part], cp)
-        close(cut(x1, 1), r1[0], atol=3e-5)
-        close(cut(e1, 2), r1[1], atol=3e-5)
-        close(cut(x2, 1), r2[0], atol=3e-5)
-        close(cut(e2, 2), r2[1], atol=3e-5)
+        check64((cut(x1, 1), cut(e1, 2)), sd, hp, cut(xh, 1), nms, ems, cut(ex, 2), None, None, nl[part], cp, 'B=%d first step, molecules %d..' % (B, lo))
+        check64((cut(x2, 1), cut(e2, 2)), sd, hp, cut(xh, 1), nms, ems, cut(ex, 2), cut(x1, 1), cut(e1, 2), nl[part], cp,
+                'B=%d self-conditioned, molecules %d..' % (B, lo))
 
 
 def test_full_size_batch_properties():
@@ -518,19 +577,17 @@ def test_pair_path_equals_directed_path(cfg_name, n_nodes, over):
     m_dir = make_model(cfg, 3, DEV, gain=1.5, coord_scale=0.05)
     m_dir.force_directed = True
     sd = state_dict_cpu(m_pair)
-    with torch.no_grad():
-        r1 = O.forward_dense(sd, hp, xh, nm, em, ex, None, None, nl)
-        r2 = O.forward_dense(sd, hp, xh, nm, em, ex, r1[0], r1[1], nl)
-    for cx, cex, want in ((None, None, r1), (r1[0], r1[1], r2)):
+    cx = cex = None
+    for step in (1, 2):
         a = run(m_pair, xh, ex, nl, nm, em, cx, cex)
         assert m_pair.last_flags.cpu().tolist()[4] == 0          # pair path taken
         b = run(m_dir, xh, ex, nl, nm, em, cx, cex)
         assert m_dir.last_flags.cpu().tolist()[4] == 1           # directed path taken
-        for got in (a, b):
-            close(got[0], want[0], atol=5e-5)
-            close(got[1], want[1], atol=5e-5)
+        r32 = check64(a, sd, hp, xh, nm, em, ex, cx, cex, nl, None, 'pair path, step %d' % step)
+        check64(b, sd, hp, xh, nm, em, ex, cx, cex, nl, None, 'directed path, step %d' % step)
         close(a[0], b[0], atol=1e-5)
         close(a[1], b[1], atol=1e-5)
+        cx, cex = r32
 
 
 # ---- caller-side kernels: fused ancestral update and fused decode ----------------
@@ -816,8 +873,6 @@ def test_stream_interleaved_sub_batches_equal_single_stream(cfg_name, n_nodes, k
     many = make_model(cfg, 4, DEV, gain=1.3, coord_scale=0.05)
     many.n_streams = k
     sd = state_dict_cpu(one)
-    with torch.no_grad():
-        r1 = O.forward_dense(sd, hp, xh, nm, em, ex, None, None, nl, ctx)
     a1 = run(one, xh, ex, nl, nm, em, None, None, ctx)
     nmd, emd = nm.to(DEV), em.to(DEV)
     d = lambda x: None if x is None else x.to(DEV)
@@ -830,8 +885,7 @@ def test_stream_interleaved_sub_batches_equal_single_stream(cfg_name, n_nodes, k
 
     b1 = split_call()
     assert len(many._last_plans) == k
-    close(b1[0], r1[0], atol=5e-5)
-    close(b1[1], r1[1], atol=5e-5)
+    check64(b1, sd, hp, xh, nm, em, ex, None, None, nl, ctx, '%d streams' % k)
     close(b1[0], a1[0], atol=2e-5)
     close(b1[1], a1[1], atol=2e-5)
     a2 = run(one, xh, ex, nl, nm, em, a1[0], a1[1], ctx)

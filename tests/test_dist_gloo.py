@@ -89,7 +89,8 @@ def _sample_worker(rank, world, port, method, steps, mode, assign, q):
     torch.manual_seed(1234 + rank)                       # whatever the process did before must not matter
     fn = get_sampling_fn(cfg, ns, nodes_dist, 5, 9, inv, shard=(rank, world), shard_mode=mode, shard_assign=assign, seed=77)
     mols = fn(model)
-    full = gather_sampled(mols, fn.last_indices)
+    full = gather_sampled(fn.last_decoded, fn.last_indices)
+    assert len(mols) == len(fn.last_indices)
     q.put((rank, fn.last_indices, [tuple(t.numpy().copy() for t in m) for m in full]))      # by value (no shared-memory handles)
     dist.barrier()
     dist.destroy_process_group()
@@ -143,7 +144,7 @@ def _parity_body(get_sampling_fn):
 
 def test_sharded_sampling_perf_mode_rng_contract_and_lpt():
     """shard_mode='perf': molecules are dealt to the ranks before rounds are cut, atom counts come from the shared
-    seed (identical on all ranks whatever their prior RNG state), noise from (seed << 20) + 1 + rank (no two (seed, rank) pairs share a
+    seed (identical on all ranks whatever their prior RNG state), noise from a hash of (seed, 1 + rank) (no two (seed, rank) pairs share a
     stream), LPT balances the n^2 work."""
     from jodo_amd.dist import assign_lpt
     res = _run_world2('ancestral', 2, 'perf')

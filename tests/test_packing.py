@@ -136,7 +136,8 @@ def test_work_model_follows_the_rotated_statistics():
         w = (ctypes.c_double * 8)()
         assert lib.jodo_plan_work(h, 1, 1, w) == 0
         work[rot] = list(w)
-    assert lib.jodo_plan_set_option(h, 6, 2) < 0                       # a switch: 0 or 1
+    assert lib.jodo_plan_set_option(h, 6, 3) < 0                       # 0, 1, or 2 (tests: uncentred Gram tiles)
+    assert lib.jodo_plan_set_option(h, 6, 1) == 0
     L, UPD, NODE = 8, 6, 5                                            # blocks; JODO_PROF_EDGE_UPDATE, JODO_PROF_NODE_POST
     iters = (work[0][UPD] - work[1][UPD]) / (L * (512 - 160) * 4096.0)
     assert iters > 0 and abs(iters - round(iters)) < 1e-9             # pair-offset iterations of one block
@@ -321,3 +322,45 @@ def test_rotated_statistics_survive_degenerate_weights():
         Q = qt.T
         assert np.isfinite(Lq).all() and np.allclose(Q @ Q.T, np.eye(D), atol=1e-12)
         assert np.allclose(Q @ wec, np.vstack([Lq, np.zeros((D - 128, 128))]), atol=1e-12)
+
+
+@pytest.mark.parametrize("eps,common", [(1e-3, 100.0), (0.0, 100.0), (1e-2, 30.0), (1.0, 0.0)])
+def test_reference_centred_gram_keeps_fp32_accuracy_when_the_rows_cancel(eps, common):
+    """fp32 model (numpy, every product rounded to float32) of the second term of the rotated statistics,
+    T2 = |R''_a + C''_c|^2 over the features the [e ; G] projection cannot reach, in the three forms the kernels have had:
+      uncentred   |R''_a|^2 + |C''_c|^2 + 2 <R''_a, C''_c>                                 (round 3, JODO_OPT_ROT_STATS = 2)
+      centred     a' = R''_a + C''_ref, c' = C''_c - C''_ref:  |a'|^2 + |c'|^2 + 2 <a', c'>   (k_node_gram now, ref = first atom)
+      direct      the vector sum squared                                                  (what the plain path's S + R + C amounts to)
+    on a distance-like input_lin (W_col = -W_row + eps noise) with a component shared by all atoms in h (kappa ~ common / sqrt 2).
+    The centred form must stay within a small factor of the direct one; the uncentred form loses kappa^2 eps_fp32 — which is
+    what this test has teeth for: it is asserted to be at least an order of magnitude worse in the adversarial cases."""
+    from py_packing_model import rot_stats
+    rng = np.random.default_rng(7)
+    D, De, n = 256, 64, 29
+    KL, f = 2 * De, np.float32
+    b = 1 / np.sqrt(2 * D + KL)
+    Win = rng.uniform(-b, b, (D, 2 * D + KL))
+    Win[:, D:2 * D] = -Win[:, :D] + eps * rng.uniform(-b, b, (D, D))
+    bin_ = rng.uniform(-b, b, D)
+    h = rng.standard_normal((n, D)) + common * rng.standard_normal(D)[None, :]
+    z = rng.standard_normal((n, n, KL))
+    pre = (h @ Win[:, :D].T + bin_)[:, None, :] + (h @ Win[:, D:2 * D].T)[None, :, :] + z @ Win[:, 2 * D:].T
+    var = pre.var(-1)                                                            # float64 truth
+    rowq, colq, bq, L, _, _ = rot_stats(Win.astype(f), bin_.astype(f), D, De)
+    h32 = h.astype(f)
+    Rq, Cq = (h32 @ rowq.astype(f).T + bq.astype(f)).astype(f), (h32 @ colq.astype(f).T).astype(f)
+    t = ((z.astype(f) @ L.astype(f).T).astype(f) + Rq[:, None, :KL] + Cq[None, :, :KL]).astype(f)
+    T1 = (t * t).sum(-1, dtype=f)
+    Ru, Cu = Rq[:, KL:], Cq[:, KL:]
+    sq = lambda x: (x * x).sum(-1, dtype=f)
+    T2 = dict(uncentred=(sq(Ru)[:, None] + sq(Cu)[None, :] + f(2) * (Ru @ Cu.T).astype(f)).astype(f))
+    ap, cp = (Ru + Cu[0][None, :]).astype(f), (Cu - Cu[0][None, :]).astype(f)
+    T2['centred'] = (sq(ap)[:, None] + sq(cp)[None, :] + f(2) * (ap @ cp.T).astype(f)).astype(f)
+    T2['direct'] = sq((Ru[:, None, :] + Cu[None, :, :]).astype(f))
+    rs0 = 1 / np.sqrt(var + 1e-6)
+    err = {k: float(np.abs(1 / np.sqrt(np.maximum((T1.astype(np.float64) + v.astype(np.float64)) / D, 0) + 1e-6) / rs0 - 1).max())
+           for k, v in T2.items()}
+    assert err['centred'] < 3 * err['direct'] + 1e-6, err
+    assert err['centred'] < 5e-5, err
+    if common >= 30:
+        assert err['uncentred'] > 10 * err['centred'], err
