@@ -12,7 +12,7 @@ import torch
 from oracle import dgt_oracle as O
 
 from helpers import (check_decodes, close64, debug_fetch, load_fixture, make_config, make_model, masks, oracle_32_64, random_inputs,
-                     reference_blocks_dense, state_dict_cpu)
+                     reference_blocks_dense, state_dict_cpu, K64, K64_HARD, k64_for)
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -25,13 +25,13 @@ def close(got, want, atol=2e-5, rtol=1e-4):
     assert bool((err <= bound).all()), "max err %.3e (bound %.1e + %.0e*|x|)" % (err.max().item(), atol, rtol)
 
 
-def check64(got, sd, hp, xh, nm, em, ex, cx, cex, nl, ctx=None, what=''):
+def check64(got, sd, hp, xh, nm, em, ex, cx, cex, nl, ctx=None, what='', k=K64):
     """HIP outputs against the float64 oracle on the same inputs, at the forward tolerance (helpers.close64: the stated
     2e-5 + 1e-4 |x|, widened only where the float32 oracle itself is further than that from float64).  Returns the float32
     oracle's outputs (self-conditioning inputs of a following call)."""
     r32, r64 = oracle_32_64(sd, hp, xh, nm, em, ex, cx, cex, nl, ctx)
-    close64(got[0], r32[0], r64[0], what + ' nodes')
-    close64(got[1], r32[1], r64[1], what + ' edges')
+    close64(got[0], r32[0], r64[0], what + ' nodes', k=k)
+    close64(got[1], r32[1], r64[1], what + ' edges', k=k)
     return r32
 
 
@@ -144,17 +144,18 @@ def test_uniform_and_per_molecule_noise_levels_agree(cfg_name, n_nodes, gain, ov
     sd = state_dict_cpu(model)
     xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=1)
     nl_u = torch.full_like(nl, 0.37)
+    k = k64_for(hp, n_nodes)
     a1 = run(model, xh, ex, nl_u, nm, em)
     assert model.last_flags.cpu().tolist()[2] == 1          # shared time row
-    r1 = check64(a1, sd, hp, xh, nm, em, ex, None, None, nl_u, ctx, 'shared row, first step')
+    r1 = check64(a1, sd, hp, xh, nm, em, ex, None, None, nl_u, ctx, 'shared row, first step', k=k)
     a2 = run(model, xh, ex, nl_u, nm, em, r1[0], r1[1])
     assert model.last_flags.cpu().tolist()[2] == 1
-    check64(a2, sd, hp, xh, nm, em, ex, r1[0], r1[1], nl_u, ctx, 'shared row, self-conditioned')
+    check64(a2, sd, hp, xh, nm, em, ex, r1[0], r1[1], nl_u, ctx, 'shared row, self-conditioned', k=k)
     nl_p = nl_u.clone()
     nl_p[0] += 1e-6                                          # forces the per-molecule path for the others
     b = run(model, xh, ex, nl_p, nm, em)
     assert model.last_flags.cpu().tolist()[2] == 0
-    check64(b, sd, hp, xh, nm, em, ex, None, None, nl_p, ctx, 'per-molecule rows, first step')
+    check64(b, sd, hp, xh, nm, em, ex, None, None, nl_p, ctx, 'per-molecule rows, first step', k=k)
     # path against path: each side is held to the forward tolerance above, so the two differ by at most twice that
     close(a1[0][1:], b[0][1:], atol=4e-5, rtol=2e-4)
     close(a1[1][1:], b[1][1:], atol=4e-5, rtol=2e-4)
@@ -192,8 +193,8 @@ def test_rotated_statistics_match_plain_fold_and_oracle(cfg_name, n_nodes, gain,
             r2 = oracle_32_64(sd, hp, xh, nm, em, ex, r1[0][0], r1[0][1], nl)
         outs[rot] = (o1, run(model, xh, ex, nl, nm, em, r1[0][0], r1[0][1]))     # self-conditioned on the oracle's prediction: same inputs
         for step, got, (r32, r64) in ((1, outs[rot][0], r1), (2, outs[rot][1], r2)):
-            close64(got[0], r32[0], r64[0], 'rot %d step %d nodes' % (rot, step))
-            close64(got[1], r32[1], r64[1], 'rot %d step %d edges' % (rot, step))
+            close64(got[0], r32[0], r64[0], 'rot %d step %d nodes' % (rot, step), k=k64_for(hp, n_nodes))
+            close64(got[1], r32[1], r64[1], 'rot %d step %d edges' % (rot, step), k=k64_for(hp, n_nodes))
     e32 = max(float((r1[0][k].double() - r1[1][k]).abs().max()) for k in (0, 1))
     for k in (0, 1):
         close(outs[1][k][0], outs[0][k][0], atol=max(4e-5, 8 * e32), rtol=2e-4)
@@ -236,7 +237,7 @@ def test_rotated_statistics_on_adversarial_weights(cfg_name, n_nodes, gain, eps,
     hp = O.Hyper.from_config(cfg)
     xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=23)
     nl = torch.full_like(nl, 0.4)
-    errs, r = {}, None
+    errs, outs, r = {}, {}, None
     for rot in (1, 0, 2):
         model = _make_adversarial(make_model(cfg, 13, DEV, gain=gain, coord_scale=0.05), hp.nf, hp.n_layers, eps, common)
         model.plan_options = {6: rot}
@@ -248,16 +249,26 @@ def test_rotated_statistics_on_adversarial_weights(cfg_name, n_nodes, gain, eps,
             r1 = oracle_32_64(sd, hp, xh, nm, em, ex, None, None, nl)
             r = (r1, oracle_32_64(sd, hp, xh, nm, em, ex, r1[0][0], r1[0][1], nl))
         o2 = run(model, xh, ex, nl, nm, em, r[0][0][0], r[0][0][1])
-        errs[rot] = max(float((g.double() - w64[k]).abs().max()) for g2, (w32, w64) in ((o1, r[0]), (o2, r[1])) for k, g in enumerate(g2))
-        if rot != 2:
-            for step, got, (r32, r64) in ((1, o1, r[0]), (2, o2, r[1])):
-                close64(got[0], r32[0], r64[0], 'adversarial rot %d step %d nodes' % (rot, step))
-                close64(got[1], r32[1], r64[1], 'adversarial rot %d step %d edges' % (rot, step))
+        errs[rot] = max(float((g.cpu().double() - w64[k]).abs().max()) for g2, (w32, w64) in ((o1, r[0]), (o2, r[1])) for k, g in enumerate(g2))
+        outs[rot] = (o1, o2)
     e32 = max(float((a.double() - b).abs().max()) for (r32, r64) in r for a, b in zip(r32, r64))
     print("adversarial %s gain %g eps %g common %g: |HIP - f64| rotated %.2e, plain fold %.2e, uncentred Gram %.2e; float32 oracle %.2e"
           % (cfg_name, gain, eps, common, errs[1], errs[0], errs[2], e32))
     from helpers import _log_parity
     _log_parity(dict(what='adversarial summary', rotated=errs[1], plain=errs[0], uncentred=errs[2], oracle32=e32, gain=gain, eps=eps, common=common))
+    # everything has been evaluated and logged; now the assertions.  At trunk gain 3 - 5 the outputs reach 1e3 - 1e7 and the float32
+    # oracle itself is 1e-2 - 1e3 from float64: the forward tolerance can only be held relative to that (K64_HARD, helpers.py).
+    failures = []
+    for rot in (1, 0):
+        for step, got, (r32, r64) in ((1, outs[rot][0], r[0]), (2, outs[rot][1], r[1])):
+            for k, name in ((0, 'nodes'), (1, 'edges')):
+                try:
+                    close64(got[k], r32[k], r64[k], 'adversarial rot %d step %d %s' % (rot, step, name), k=K64_HARD)
+                except AssertionError as e:
+                    failures.append(str(e).split('\n')[0])
+    assert not failures, '; '.join(failures)
+    # the point of the exercise: the rotated statistics are no worse than the plain fold on weights built against them
+    assert errs[1] <= max(2.0 * errs[0], K64 * e32), "rotated %.3e vs plain fold %.3e (float32 oracle %.3e)" % (errs[1], errs[0], e32)
 
 
 def test_invariants():
