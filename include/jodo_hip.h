@@ -309,6 +309,41 @@ int jodo_edge_ffn_backward(int rows, int De, int mlp_ratio, int n_mod_rows, cons
                            float* d_ehat, float* d_mods, float* dW3, float* db3, float* dW4, float* db4, void* workspace,
                            void* stream);
 
+/* ---- training step: the whole network ------------------------------------------------------------------
+ * jodo_train_forward   <- the grad-enabled model call of get_sde_graph_loss_fn, losses.py:335-343 (DGT_concat.forward /
+ *                         Cond_DGT_concat.forward under model.train(): dropout on the attention weights, layers.py:179, and in the
+ *                         four FFN positions, mol_gnn.py:262-268) with every activation the backward needs kept in `workspace`
+ * jodo_train_backward  <- loss.backward(), losses.py:109: d loss / d parameter for EVERY tensor of the state_dict, given
+ *                         d loss / d out_xh and d loss / d out_edge (the loss itself, losses.py:350-385, stays host code)
+ * Parameters are NOT packed here: params_dev[i] / grads_dev[i] are DEVICE pointers to contiguous fp32 tensors in PyTorch layout,
+ * in the order of the `params` array given to jodo_train_create (names = state_dict keys, a leading "module." is ignored; `data`
+ * of that array is not read, shapes are checked).  grads are fully written (not accumulated).  Inputs need no gradient (the
+ * self-conditioning inputs are detached, losses.py:339).  The handle fixes the batch: B molecules with n_nodes[b] atoms, padded
+ * width N of the dense tensors (same layouts as jodo_dgt_forward).  dropout_p = config.model.dropout under model.train(), 0 under
+ * model.eval(); masks come from a counter-based generator keyed by `seed` (same law as torch's, a different stream) and are
+ * regenerated, not stored: pass the same (dropout_p, seed) to the backward.  flags_out (optional): int32[8], [0] = NaN guard
+ * fired (mol_gnn.py:587-589: positions zeroed, their gradient is zero), [3] = self-conditioning distances present (0 => the
+ * first-step branch of :544).  workspace: jodo_train_workspace_bytes() bytes, kept by the caller between forward and backward.
+ * desc_dev: jodo_train_desc_bytes() bytes of device memory filled by jodo_train_upload (synchronises the stream once). */
+typedef struct jodo_train jodo_train;
+int jodo_train_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes_host, const jodo_tensor* params, int n_params,
+                      jodo_train** out);
+void jodo_train_destroy(jodo_train* t);
+size_t jodo_train_desc_bytes(const jodo_train* t);
+size_t jodo_train_workspace_bytes(const jodo_train* t);
+int jodo_train_upload(jodo_train* t, void* desc_dev, void* stream);
+int jodo_train_forward(jodo_train* t, const void* desc_dev, const float* const* params_dev, int n_params, const float* xh,
+                       const float* edge_x, const float* cond_x, const float* cond_edge_x, const float* noise_level,
+                       const float* context, float dropout_p, uint64_t seed, float* out_xh, float* out_edge, int32_t* flags_out,
+                       void* workspace, void* stream);
+int jodo_train_backward(jodo_train* t, const void* desc_dev, const float* const* params_dev, float* const* grads_dev, int n_params,
+                        const float* noise_level, const float* d_out_xh, const float* d_out_edge, float dropout_p, uint64_t seed,
+                        void* workspace, void* stream);
+/* the training path's fp32 MFMA GEMM on its own (tests):  C[M, N] (+)= op(A) op(B) (+ bias[N]);  tA = 0: A[m lda + k], 1: A[k lda + m];
+ * tB = 0: B[k ldb + n], 1: B[n ldb + k];  ws / ws_floats: device scratch for split-K partial tiles (NULL: never split) */
+int jodo_train_gemm(int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                    const float* bias, int acc, float* ws, size_t ws_floats, void* stream);
+
 const char* jodo_last_error(void);
 
 /* measurement helper (synchronises, default stream): fp32 MFMA throughput of the box in TFLOP/s from a

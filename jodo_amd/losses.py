@@ -1,0 +1,217 @@
+"""Training step around the HIP score network, host Python with the reference's entry points (/root/reference/losses.py):
+
+  get_optimizer             :14-26    Adam / AdamW(amsgrad, weight_decay 1e-12)
+  optimization_manager      :75-94    linear warm-up + adaptive gradient clipping (gradient_clipping :29-50, Queue :53-72)
+  get_step_fn               :97-125   zero_grad -> loss -> backward -> optimise -> EMA update; evaluation under the EMA weights
+  get_sde_graph_loss_fn     :286-385  per-molecule t, forward diffusion of nodes and edges, Kabsch-aligned position target,
+                                      50 % self-conditioning double forward, weighted data-prediction loss
+  kabsch_batch, get_align_position / get_align_noise  :388-440
+  process_edge_batch        :470-498
+
+The arithmetic of the model call — forward with kept activations and loss.backward() — is jodo_train_forward / jodo_train_backward
+(csrc/dgt_train.hip) behind models/dgt.py; everything here is the thin tensor algebra the reference also keeps in Python.
+"""
+import random
+
+import numpy as np
+import torch
+
+from .models.utils import (remove_mean_with_mask, sample_combined_position_feature_noise,
+                           sample_symmetric_edge_feature_noise)
+from .utils import expand_dims, get_self_cond_fn
+
+
+def get_optimizer(config, params):
+    o = config.optim
+    if o.optimizer == 'Adam':
+        return torch.optim.Adam(params, lr=o.lr, betas=(o.beta1, 0.999), eps=o.eps, weight_decay=o.weight_decay)
+    if o.optimizer == 'AdamW':
+        return torch.optim.AdamW(params, lr=o.lr, amsgrad=True, weight_decay=1e-12)
+    raise NotImplementedError(f'Optimizer {o.optimizer} not supported yet!')
+
+
+class Queue:
+    """Recent gradient norms, newest first, bounded."""
+
+    def __init__(self, max_len=50):
+        self.items, self.max_len = [], max_len
+
+    def __len__(self):
+        return len(self.items)
+
+    def add(self, item):
+        self.items.insert(0, item)
+        del self.items[self.max_len:]
+
+    def mean(self):
+        return np.mean(self.items)
+
+    def std(self):
+        return np.std(self.items)
+
+
+def gradient_clipping(params, gradnorm_queue, max_grad, disable_log):
+    """max_grad <= 1: plain norm clipping.  Otherwise the allowed norm follows the recent history: 1.5 x mean + 2 x std of
+    the queue, capped at max_grad; the (clipped) norm is pushed to the queue."""
+    params = list(params)
+    if max_grad <= 1.0:
+        torch.nn.utils.clip_grad_norm_(params, max_norm=max_grad)
+        return None
+    allowed = min(1.5 * gradnorm_queue.mean() + 2 * gradnorm_queue.std(), max_grad)
+    grad_norm = torch.nn.utils.clip_grad_norm_(params, max_norm=allowed, norm_type=2.0)
+    gradnorm_queue.add(float(min(float(grad_norm), allowed)))
+    if not disable_log and float(grad_norm) > 1.5 * gradnorm_queue.mean() + 2 * gradnorm_queue.std():
+        print(f'Clipped gradient with value {grad_norm:.1f} while allowed {allowed:.1f}')
+    return grad_norm
+
+
+def optimization_manager(config):
+    gradnorm_queue = Queue()
+    gradnorm_queue.add(3000)                       # large first entry, flushed by the history
+    disable_log = config.optim.disable_grad_log
+
+    def optimize_fn(optimizer, params, step, lr=config.optim.lr, warmup=config.optim.warmup, grad_clip=config.optim.grad_clip):
+        if warmup > 0:
+            for g in optimizer.param_groups:
+                g['lr'] = lr * np.minimum(step / warmup, 1.0)
+        if grad_clip >= 0:
+            gradient_clipping(params, gradnorm_queue, grad_clip, disable_log)
+        optimizer.step()
+
+    return optimize_fn
+
+
+def get_step_fn(noise_scheduler, train, optimize_fn, scaler, config, prop_dist=None):
+    if not config.pred_edge or config.only_2D:
+        raise NotImplementedError("the HIP path implements the 3D graph model (pred_edge, not only_2D)")
+    loss_fn = get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_dist)
+
+    def step_fn(state, batch):
+        model = state['model']
+        if train:
+            optimizer = state['optimizer']
+            optimizer.zero_grad()
+            loss = loss_fn(model, batch)
+            loss.backward()
+            optimize_fn(optimizer, model.parameters(), step=state['step'])
+            state['step'] += 1
+            state['ema'].update(model.parameters())
+            return loss
+        with torch.no_grad():
+            ema = state['ema']
+            ema.store(model.parameters())
+            ema.copy_to(model.parameters())
+            _weights_changed(model)
+            loss = loss_fn(model, batch)
+            ema.restore(model.parameters())
+            _weights_changed(model)
+        return loss
+
+    return step_fn
+
+
+def _weights_changed(model):
+    """EMA copy_to / restore write through `.data` (no version bump): tell the HIP module its packed inference weights are stale."""
+    inner = getattr(model, 'module', model)
+    if hasattr(inner, 'invalidate_packed_weights'):
+        inner.invalidate_packed_weights()
+
+
+@torch.no_grad()
+def kabsch_batch(coords_pred, coords_tar):
+    """Per molecule the rotation R minimising |coords_pred - coords_tar R^T| (Kabsch): A = P^T Q = U S V^T, R = U diag(1, 1, sign det A) V^T."""
+    A = torch.einsum('...ki,...kj->...ij', coords_pred, coords_tar)
+    U, _, Vt = torch.linalg.svd(A)
+    fix = torch.ones(A.size(0), 3, device=A.device, dtype=A.dtype)
+    fix[:, -1] = torch.sign(torch.det(A))
+    return torch.einsum('...ij,...jk,...kl->...il', U, torch.diag_embed(fix), Vt)
+
+
+@torch.no_grad()
+def get_align_position(z_t, xh):
+    rot = kabsch_batch(z_t[:, :, :3], xh[:, :, :3])
+    return torch.einsum('...ki,...ji->...jk', rot, xh[:, :, :3])
+
+
+@torch.no_grad()
+def get_align_noise(z_t, xh, alpha_t, sigma_t, noise, node_mask):
+    pos_t = z_t[:, :, :3]
+    aligned = get_align_position(z_t, xh)
+    noise[:, :, :3] = (pos_t - expand_dims(alpha_t, 3) * aligned) / expand_dims(sigma_t, 3)
+    return noise
+
+
+@torch.no_grad()
+def process_edge_batch(batch, device, include_charges, scaler, prop_norm):
+    pos = batch['positions'].to(device)
+    node_mask = batch['atom_mask'].to(device).unsqueeze(2)
+    edge_mask = batch['edge_mask'].to(device)
+    atom_type = batch['atom_one_hot'].to(device)
+    edge_type = batch['edge_one_hot'].to(device)
+    fc_charge = (batch['formal_charges'] if include_charges else torch.zeros(0)).to(device)
+    context = batch['context'].to(device) if 'context' in batch else None
+    pos = remove_mean_with_mask(pos, node_mask)
+    pos, atom_type, fc_charge, edge_type = scaler(pos, atom_type, fc_charge, node_mask, edge_type, edge_mask)
+    if context is not None:
+        for i, key in enumerate(prop_norm.keys()):
+            context[:, i] = (context[:, i] - prop_norm[key]['mean']) / prop_norm[key]['mad']
+    return torch.cat([pos, atom_type, fc_charge], dim=2), edge_type, node_mask, edge_mask, context
+
+
+def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None):
+    """loss_fn(model, batch) -> scalar: node, position and edge data-prediction loss of one batch at per-molecule random times."""
+    device = config.device
+    include_charges = config.model.include_fc_charge
+    reduce_mean = config.training.reduce_mean
+    noise_align = config.model.noise_align
+    pred_data = config.model.pred_data
+    w_pos, w_atom, w_edge = (float(w) for w in config.model.loss_weights.split(','))
+    self_cond = config.model.self_cond
+    cond_process_fn = get_self_cond_fn(config) if self_cond else None
+
+    def loss_fn(model, batch):
+        model.train() if train else model.eval()
+        xh, edge_x, node_mask, edge_mask, context = process_edge_batch(batch, device, include_charges, scaler, prop_norm)
+        B = xh.shape[0]
+        n_nodes = node_mask.squeeze(-1).sum(-1)
+        t = torch.rand(B, device=xh.device) * (1. - 1e-5) + 1e-5
+        alpha_t, sigma_t = noise_scheduler.marginal_prob(t)
+        noise = sample_combined_position_feature_noise(B, xh.shape[1], xh.shape[2] - 3, node_mask)
+        edge_noise = sample_symmetric_edge_feature_noise(B, edge_x.shape[1], edge_x.shape[-1], edge_mask)
+        z_t = expand_dims(alpha_t, 3) * xh + expand_dims(sigma_t, 3) * noise
+        edge_z_t = expand_dims(alpha_t, 4) * edge_x + expand_dims(sigma_t, 4) * edge_noise
+        if noise_align:
+            if pred_data:
+                align_pos = get_align_position(z_t, xh)
+            else:
+                noise = get_align_noise(z_t, xh, alpha_t, sigma_t, noise, node_mask)
+        else:
+            align_pos = xh[:, :, :3]
+        noise_level = torch.log(alpha_t ** 2 / sigma_t ** 2)
+        kw = dict(edge_x=edge_z_t, noise_level=noise_level, context=context)
+        if self_cond:
+            assert pred_data
+            cond_x = cond_edge_x = None
+            if random.random() < 0.5:
+                with torch.no_grad():
+                    cond_x, cond_edge_x = model(t, z_t, node_mask, edge_mask, cond_x=None, cond_edge_x=None, **kw)
+                    cond_x, cond_edge_x = cond_process_fn(cond_x.detach(), cond_edge_x.detach())
+            pred, edge_pred = model(t, z_t, node_mask, edge_mask, cond_x=cond_x, cond_edge_x=cond_edge_x, **kw)
+        else:
+            pred, edge_pred = model(t, z_t, node_mask, edge_mask, **kw)
+        if pred_data:
+            tar_pos, tar_atom, tar_edge = align_pos, xh[:, :, 3:], edge_x
+        else:
+            tar_pos, tar_atom, tar_edge = noise[:, :, :3], noise[:, :, 3:], edge_noise
+        l_pos = torch.square(pred[:, :, :3] - tar_pos).mean(-1).sum(-1)
+        l_atom = torch.square(pred[:, :, 3:] - tar_atom).mean(-1).sum(-1)
+        l_edge = torch.square(tar_edge - edge_pred).mean(-1).reshape(B, -1).sum(-1)
+        if reduce_mean:
+            l_pos, l_atom = l_pos / n_nodes, l_atom / n_nodes
+            l_edge = l_edge / (edge_mask.reshape(B, -1).sum(-1) + 1e-8)
+        losses = w_pos * l_pos + w_atom * l_atom + w_edge * l_edge
+        if pred_data:
+            losses = torch.sqrt(alpha_t / sigma_t) * losses
+        return losses.mean()
+
+    return loss_fn

@@ -272,10 +272,16 @@ class _DGTBase(nn.Module):
         if not xh.is_cuda:
             raise RuntimeError("jodo_amd DGT runs on an MI355X only (got a %s tensor); there is no CPU fallback — "
                                "use oracle/dgt_oracle.py for CPU checks" % xh.device)
-        if torch.is_grad_enabled() and (xh.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise RuntimeError("backward through the HIP DGT is not implemented: call under torch.no_grad()")
         if self.conditional and context is None:
             raise ValueError("cond_DGT_concat needs `context`")
+        if torch.is_grad_enabled() and any(t_ is not None and t_.requires_grad for t_ in (xh, edge_x, cond_x, cond_edge_x, noise_level, context)):
+            raise RuntimeError("the HIP DGT returns parameter gradients only: detach the inputs (the reference's loss detaches the "
+                               "self-conditioning inputs, losses.py:339, and needs no input gradient)")
+        wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if wants_grad or (self.training and self.dropout_p > 0):
+            # training path (csrc/dgt_train.hip): activations kept for loss.backward(); under model.train() dropout is active
+            # in the no-grad self-conditioning forward too (losses.py:335-339), which is why that call comes here as well
+            return self._forward_train(xh, edge_x, cond_x, cond_edge_x, noise_level, context, node_mask, edge_mask, wants_grad)
         dev = xh.device
         d = self.dims
         B, N, dims = xh.shape
@@ -297,6 +303,55 @@ class _DGTBase(nn.Module):
         self.last_flags = plan['flags']
         self._last_plan = plan
         self._last_plans = [plan]
+        return out_x, out_e
+
+    # -- training path ---------------------------------------------------------------------------
+    def _train_engine(self, node_mask, edge_mask, device):
+        """One TrainEngine (jodo_train handle + device tables + activation workspace) per batch of atom counts, keyed by the
+        counts themselves: data loaders build new mask tensors every step, equal shapes recur."""
+        from ..train import TrainEngine
+        B, N = node_mask.shape[0], node_mask.shape[1]
+        nm = node_mask.reshape(B, N)
+        n_nodes = nm.sum(1).round().to(torch.int32)
+        prefix = (torch.arange(N, device=nm.device).unsqueeze(0) < n_nodes.unsqueeze(1)).to(nm.dtype)
+        if not torch.equal(prefix, nm):
+            raise ValueError("node_mask must be a prefix mask (real atoms first)")
+        em = edge_mask.reshape(B, N, N)
+        want = prefix.unsqueeze(1) * prefix.unsqueeze(2) * (~torch.eye(N, dtype=torch.bool, device=nm.device))
+        if not torch.equal(want.to(em.dtype), em):
+            raise ValueError("edge_mask must be node_mask x node_mask with the diagonal removed")
+        n_host = n_nodes.cpu().numpy()
+        key = (str(device), N) + tuple(int(v) for v in n_host)
+        cache = self.__dict__.setdefault('_train_engines', {})
+        eng = cache.pop(key, None)
+        if eng is None:
+            named = [(k, tuple(v.shape)) for k, v in self.state_dict().items()]
+            eng = TrainEngine(self._cfg(), n_host, N, named, device)
+            while len(cache) >= 4:                              # bounded: a workspace holds every activation of a batch
+                cache.pop(next(iter(cache)))
+        cache[key] = eng                                        # most recently used last
+        return eng
+
+    def _forward_train(self, xh, edge_x, cond_x, cond_edge_x, noise_level, context, node_mask, edge_mask, wants_grad):
+        from ..train import dgt_autograd
+        d = self.dims
+        B, N, dims = xh.shape
+        if dims != 3 + d.nd or edge_x.shape != (B, N, N, d.ch):
+            raise ValueError("shape mismatch: xh %s edge_x %s" % (tuple(xh.shape), tuple(edge_x.shape)))
+        f32 = lambda x: None if x is None else x.detach().to(torch.float32).contiguous()
+        eng = self._train_engine(node_mask, edge_mask, xh.device)
+        p = float(self.dropout_p) if self.training else 0.0
+        # dropout masks: counter-based, keyed by a seed drawn from torch's generator (so torch.manual_seed reproduces a step)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+        ctx_ = f32(context) if self.conditional else None
+        # parameters in state_dict order = the order the engine was created with (parameters() of this tree, no buffers)
+        params = list(self.parameters())
+        args = (eng, p, seed, f32(xh), f32(edge_x), f32(cond_x), f32(cond_edge_x), f32(noise_level), ctx_)
+        if wants_grad:
+            out_x, out_e = dgt_autograd(*args, params)
+        else:
+            out_x, out_e = eng.forward([q.detach().contiguous() for q in params], *args[3:], p, seed)
+        self.last_flags = eng.flags
         return out_x, out_e
 
     def _launch(self, plan, blob, woff_c, n_woff, xh_, ex_, cx_, cex_, nl_, ctx_, out_x, out_e):

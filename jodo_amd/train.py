@@ -1,10 +1,15 @@
-"""Python plumbing of the training-side slice: the backward of phase D of a DGT block — edge residual,
-LayerNorm2 + modulate, edge FFN (/root/reference/models/mol_gnn.py:313-317) — as HIP kernels behind the C ABI
-(jodo_edge_ffn_backward, csrc/train_kernels.hip).  Device tensors in, device tensors out; no CPU fallback.
+"""Python plumbing of the training side behind the C ABI; device tensors in, device tensors out, no CPU
+fallback.
 
-This is a building block, not a training loop: the forward of the HIP modules still refuses to run under autograd
-(models/dgt.py); the slice is exercised by tests/test_train_gpu.py against torch.autograd through the CPU oracle, whose
-gradients are pinned by the reference's own loss.backward() (tests/golden/grad_qm9.npz)."""
+  TrainEngine / dgt_autograd   the whole score network under autograd: jodo_train_forward keeps the activations,
+                               jodo_train_backward returns the gradient of every parameter (csrc/dgt_train.hip, train_ops.h,
+                               train_gemm.hip) — what loss.backward() does in /root/reference/losses.py:286-385.  models/dgt.py
+                               routes a grad-enabled forward here, so `loss.backward()` works on the registered module.
+  EdgeFFNBackward              round 3's first slice: phase D of a block (mol_gnn.py:313-317) as strip-model kernels with
+                               recomputed activations (jodo_edge_ffn_backward, csrc/train_kernels.hip).
+
+Checked by tests/test_train_gpu.py against torch.autograd through the CPU oracle, whose gradients are pinned by the reference's
+own loss.backward() (tests/golden/grad_qm9.npz)."""
 import ctypes
 
 import numpy as np
@@ -62,3 +67,98 @@ class EdgeFFNBackward:
             capi.ptr(out['db4']), capi.ptr(ws), capi.current_stream_ptr()), 'jodo_edge_ffn_backward')
         self._ws = ws                                   # keep the scratch alive until the stream has consumed it
         return out
+
+
+class TrainEngine:
+    """One batch shape (atom counts) of the training path: owns the jodo_train handle, its device tables and the workspace that
+    carries the activations from forward to backward.  `lib` / `stream_ptr` exist for the build container's CPU suite, which
+    drives the host-emulation build of the same sources (tests/emul/) with host tensors; the product path (models/dgt.py) never
+    passes them and always runs libjodo_hip.so on the current HIP stream."""
+
+    def __init__(self, cfg_struct, n_nodes, N, named_shapes, device, lib=None, stream_ptr=None):
+        self.L = lib if lib is not None else capi.lib()
+        self._check = capi.check if lib is None else self._check_foreign
+        self._stream = stream_ptr if stream_ptr is not None else capi.current_stream_ptr
+        self.device = device
+        self.n_params = len(named_shapes)
+        n_host = np.ascontiguousarray(np.asarray(n_nodes, dtype=np.int32))
+        self.B, self.N = int(n_host.shape[0]), int(N)
+        arr = (capi.JodoTensor * self.n_params)()
+        keep = []
+        for i, (name, shape) in enumerate(named_shapes):
+            shp = (ctypes.c_int64 * max(len(shape), 1))(*shape)
+            nm = name.encode()
+            keep.append((shp, nm))
+            arr[i] = capi.JodoTensor(nm, None, shp, len(shape))
+        self.handle = ctypes.c_void_p()
+        self._check(self.L.jodo_train_create(ctypes.byref(cfg_struct), self.B, self.N, n_host.ctypes.data_as(ctypes.c_void_p), arr,
+                                             self.n_params, ctypes.byref(self.handle)), 'jodo_train_create')
+        self.L.jodo_train_desc_bytes.restype = ctypes.c_size_t
+        self.L.jodo_train_workspace_bytes.restype = ctypes.c_size_t
+        self.L.jodo_train_desc_bytes.argtypes = [ctypes.c_void_p]
+        self.L.jodo_train_workspace_bytes.argtypes = [ctypes.c_void_p]
+        self.desc = torch.empty(self.L.jodo_train_desc_bytes(self.handle), dtype=torch.uint8, device=device)
+        self.ws = torch.zeros(self.L.jodo_train_workspace_bytes(self.handle), dtype=torch.uint8, device=device)
+        self._check(self.L.jodo_train_upload(self.handle, capi.ptr(self.desc), self._stream()), 'jodo_train_upload')
+        self.flags = torch.zeros(8, dtype=torch.int32, device=device)
+
+    def _check_foreign(self, code, what=''):
+        if code != 0:
+            self.L.jodo_last_error.restype = ctypes.c_char_p
+            raise capi.JodoHipError("%s failed (%d): %s" % (what, code, (self.L.jodo_last_error() or b'').decode()))
+
+    def __del__(self):
+        try:
+            self.L.jodo_train_destroy.argtypes = [ctypes.c_void_p]
+            self.L.jodo_train_destroy(self.handle)
+        except Exception:
+            pass
+
+    @staticmethod
+    def _ptrs(tensors):
+        return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def forward(self, params, xh, edge_x, cond_x, cond_edge_x, noise_level, context, dropout_p, seed):
+        """params: contiguous float32 tensors in the order of `named_shapes`.  Returns (out_xh, out_edge); the activations stay
+        in self.ws until the next forward."""
+        assert len(params) == self.n_params
+        self.stamp = getattr(self, 'stamp', 0) + 1              # the workspace now belongs to this forward
+        out_x, out_e = torch.empty_like(xh), torch.empty_like(edge_x)
+        self._check(self.L.jodo_train_forward(
+            self.handle, capi.ptr(self.desc), self._ptrs(params), self.n_params, capi.ptr(xh), capi.ptr(edge_x), capi.ptr(cond_x),
+            capi.ptr(cond_edge_x), capi.ptr(noise_level), capi.ptr(context), ctypes.c_float(dropout_p), ctypes.c_uint64(seed),
+            capi.ptr(out_x), capi.ptr(out_e), capi.ptr(self.flags), capi.ptr(self.ws), self._stream()), 'jodo_train_forward')
+        return out_x, out_e
+
+    def backward(self, params, noise_level, d_out_x, d_out_e, dropout_p, seed):
+        grads = [torch.empty_like(p) for p in params]
+        self._check(self.L.jodo_train_backward(
+            self.handle, capi.ptr(self.desc), self._ptrs(params), self._ptrs(grads), self.n_params, capi.ptr(noise_level),
+            capi.ptr(d_out_x), capi.ptr(d_out_e), ctypes.c_float(dropout_p), ctypes.c_uint64(seed), capi.ptr(self.ws),
+            self._stream()), 'jodo_train_backward')
+        return grads
+
+
+class _DGTTrainFn(torch.autograd.Function):
+    """The score network as one autograd node: inputs need no gradient (the self-conditioning inputs are detached,
+    losses.py:339); the parameters get theirs from jodo_train_backward."""
+
+    @staticmethod
+    def forward(ctx, engine, dropout_p, seed, xh, edge_x, cond_x, cond_edge_x, noise_level, context, *params):
+        ps = [p.detach().contiguous() for p in params]
+        out_x, out_e = engine.forward(ps, xh, edge_x, cond_x, cond_edge_x, noise_level, context, dropout_p, seed)
+        ctx.engine, ctx.dropout_p, ctx.seed, ctx.ps, ctx.nl = engine, dropout_p, seed, ps, noise_level
+        ctx.stamp = engine.stamp
+        return out_x, out_e
+
+    @staticmethod
+    def backward(ctx, d_out_x, d_out_e):
+        if ctx.engine.stamp != ctx.stamp:
+            raise RuntimeError("the activations of this forward were overwritten by a later grad-enabled forward on the same "
+                               "batch shape; call backward before the next forward")
+        grads = ctx.engine.backward(ctx.ps, ctx.nl, d_out_x.contiguous(), d_out_e.contiguous(), ctx.dropout_p, ctx.seed)
+        return (None,) * 9 + tuple(grads)
+
+
+def dgt_autograd(engine, dropout_p, seed, xh, edge_x, cond_x, cond_edge_x, noise_level, context, params):
+    return _DGTTrainFn.apply(engine, dropout_p, seed, xh, edge_x, cond_x, cond_edge_x, noise_level, context, *params)

@@ -15,6 +15,33 @@ def _norm_factors(config):
     return list(nf)
 
 
+def get_data_scaler(config):
+    """Training normalisation (/root/reference/utils.py:33-68): fn(pos, atom_type, fc_charge, node_mask, edge_type=None,
+    edge_mask=None) divides by the factors of config.model.normalize_factors, maps one-hots to [-1, 1] when
+    config.data.centered, and masks."""
+    nf = _norm_factors(config)
+    pos_norm, atom_norm, fc_norm = nf[0], nf[1], nf[2]
+    edge_norm = nf[3] if len(nf) > 3 else 1
+    centered = config.data.centered
+
+    def scale_fn(pos, atom_type, fc_charge, node_mask, edge_type=None, edge_mask=None):
+        if centered:
+            atom_type = atom_type * 2. - 1.
+        if pos is not None:
+            pos = pos / pos_norm * node_mask
+        atom_type = atom_type / atom_norm * node_mask
+        fc_charge = fc_charge / fc_norm * node_mask
+        if edge_type is None:
+            return pos, atom_type, fc_charge
+        if centered:
+            edge_type = edge_type * 2. - 1.
+        n = node_mask.size(1)
+        edge_type = edge_type / edge_norm * edge_mask.reshape(node_mask.size(0), n, n, 1)
+        return pos, atom_type, fc_charge, edge_type
+
+    return scale_fn
+
+
 def get_data_inverse_scaler(config):
     """Returns fn(pos, atom_type, fc_charge, node_mask, edge_type=None, edge_mask=None) that undoes
     the training normalisation: multiply by the factors, and map centred [-1,1] one-hots to [0,1]."""
