@@ -108,16 +108,17 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(seed=42, steps=50, batch=64):
+def cpu_baseline(seed=42, steps=50, batch=64, config2_batch=2500):
     """BASELINE config 1 in full: vpsde_qm9_uncond_jodo, batch 64, 50 ancestral steps on the host CPU with the
     port of the reference's path (jodo_amd's host sampler driving oracle.forward_faithful, the op-for-op mirror of
     the reference's sparse formulation; the reference itself cannot travel to the GPU box).  Same procedure as
     oracle/calibrate_cpu.py, which times it against the real reference in the build container.
 
-    Threads: min(os.cpu_count(), 32), reported as `cores`.  torch's CPU scatter / index code does not scale to a
-    big box's core count — measured on the GPU box of round 2 (EPYC 9575F, 256 hardware threads): 0.96 s per step
-    with 32 threads, 162.9 s per step with 256 (oversubscribed OpenMP barriers) — so the baseline runs where the
-    reference's own torch code would run best, and says so."""
+    Threads: the best of {16, 32, 64} (capped at os.cpu_count()) on a short sweep, reported as `cores`.  torch's CPU
+    scatter / index code does not scale to a big box's core count — measured on the GPU box of round 2 (EPYC 9575F, 256
+    hardware threads): 0.96 s per step with 32 threads, 162.9 s per step with 256 (oversubscribed OpenMP barriers) — so the
+    baseline runs where the reference's own torch code runs best, and says so.  `config2`: the GPU's own batch (B = 2500)
+    for up to 3 steps, extrapolated."""
     from jodo_amd import configs
     from jodo_amd.diffusion import NoiseScheduleVP
     from jodo_amd.models import get_model_class, deterministic_init_, load_dataset_info, get_node_dist
@@ -144,21 +145,63 @@ def cpu_baseline(seed=42, steps=50, batch=64):
     ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
     smp = AncestralSampler(ns, torch.linspace(ns.T, 1e-3, steps), True, True, True, get_self_cond_fn(cfg))
     ncpu = os.cpu_count() or 1
-    threads = max(1, min(ncpu, 32))
+    # thread sweep (BASELINE.md 2.2 asks for the host's cores; torch's CPU scatter / index code stops scaling long before a big
+    # box's core count): three denoise steps of config 1 at {16, 32, 64} threads (one untimed), the full run at the best
+    sweep = {}
+    with torch.no_grad():
+        for th in sorted({min(c_, ncpu) for c_ in (16, 32, 64)}):
+            torch.set_num_threads(th)
+            stt = smp.init_state(z, ez)
+            stt = smp.step(Port(), 0, stt, nm, em, None)
+            t0 = time.perf_counter()
+            for i in (1, 2):
+                stt = smp.step(Port(), i, stt, nm, em, None)
+            sweep[th] = (time.perf_counter() - t0) / 2
+    threads = min(sweep, key=sweep.get)
     torch.set_num_threads(threads)
     with torch.no_grad():
         t0 = time.perf_counter()
         x_mean, e_mean = smp.sampling(Port(), z, nm, em, ez, None)
         wall = time.perf_counter() - t0
     assert bool(torch.isfinite(x_mean).all())
+    # config 2's own batch on the host as well — B = 2500 molecules, up to 3 denoise steps of the same port
+    # (first-step + self-conditioned evaluations), bounded at ~100 s; a 1000-step round is extrapolated from the per-step time
+    config2 = None
+    try:
+        torch.manual_seed(seed)
+        b2 = config2_batch
+        n2 = get_node_dist(load_dataset_info('qm9_with_h')).sample(b2).tolist()
+        N2 = max(n2)
+        nm2, em2 = build_masks(n2, N2, 'cpu')
+        z2 = sample_combined_position_feature_noise(b2, N2, 6, nm2)
+        ez2 = sample_symmetric_edge_feature_noise(b2, N2, 2, em2)
+        smp2 = AncestralSampler(ns, torch.linspace(ns.T, 1e-3, SAMPLING_STEPS), True, True, True, get_self_cond_fn(cfg))
+        per_step = []
+        with torch.no_grad():
+            st2 = smp2.init_state(z2, ez2)
+            for i in range(3):
+                t0 = time.perf_counter()
+                st2 = smp2.step(Port(), i, st2, nm2, em2, None)
+                per_step.append(time.perf_counter() - t0)
+                if sum(per_step) > 100.0:
+                    break
+        s2 = sum(per_step) / len(per_step)
+        config2 = dict(batch=b2, steps_timed=len(per_step), s_per_step=s2, seconds_each=per_step, value=b2 / (s2 * SAMPLING_STEPS),
+                       unit='molecules/s', extrapolated=True,
+                       note='BASELINE config 2 on the host: %d denoise steps of the port at B = %d (%d directed edges), value = B / '
+                            '(mean step time x 1000): extrapolated from %d steps, not a full round'
+                            % (len(per_step), b2, sum(n_ * (n_ - 1) for n_ in n2), len(per_step)))
+    except Exception as exc:                          # e.g. a host without the memory for [E, 1024] temporaries at B = 2500
+        config2 = dict(error=repr(exc))
     return dict(value=batch / (wall * SAMPLING_STEPS / steps), unit='molecules/s', cores=threads, kind='port',
                 sample='BASELINE config 1 in full: QM9 uncond, batch %d, %d ancestral steps, %.1f s wall (%.3f s/step); value = '
                        'molecules/s of a 1000-step round = batch / (wall x %d) (per-step cost is step-independent)'
                        % (batch, steps, wall, wall / steps, SAMPLING_STEPS // steps),
                 config1_wall_s=wall, config1_molecules_per_s=batch / wall, ms_per_step=wall / steps * 1e3,
-                cpu=cpu_model(), cpu_count=ncpu,
-                threads_note='min(cpu_count, 32): with all 256 hardware threads of the round-2 box the same port ran 170x slower '
-                             '(162.9 vs 0.96 s/step: thread_probe_s_per_step in profiles/r02_bench_qm9_baseline.json)',
+                cpu=cpu_model(), cpu_count=ncpu, thread_sweep_s_per_step={str(k): v for k, v in sweep.items()},
+                config2=config2,
+                threads_note='best of {16, 32, 64} threads on 2 timed steps of config 1 (thread_sweep_s_per_step); with all 256 hardware '
+                             'threads of the round-2 box the same port ran 170x slower (profiles/r02_bench_qm9_baseline.json)',
                 calibration='port vs the real reference on this config: see BASELINE.md §3 (build container, 8 threads)')
 
 
@@ -337,7 +380,16 @@ def main():
             st = sampler.init_state(z, edge_z)
             for i in range(args.warmup):
                 st = sampler.step(model, i, st, node_mask, edge_mask, context)
-            model.profile_enable(1 if args.breakdown else 2)
+                if i == 0 and args.warmup > 1:
+                    model.profile_enable(1)            # class timers on every launch class for the rest of the warm-up
+            # the launch class that took the most time in the warm-up is the one the timed region brackets (roofline leg)
+            dom, warm_classes = 6, None
+            if args.warmup > 1:
+                wms, wcnt = model.profile_read()
+                if sum(wcnt) > 0:
+                    dom = max(range(8), key=lambda c_: wms[c_])
+                    warm_classes = (wms, wcnt, args.warmup - 1)
+            model.profile_enable(1 if args.breakdown else 16 + dom)
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
@@ -474,15 +526,40 @@ def main():
         ref_total, ref_upd_edge = reference_formulation_flops(dims, n_nodes, shared_row)
         names = ['prologue', 'node_pre', 'edge_attn', 'reserved3', 'reserved4', 'node_post', 'edge_update', 'epilogue']
         per_class = {names[c]: (ms[c] / max(cnt[c], 1), cnt[c]) for c in range(8)}
-        upd_ms, upd_n = per_class['edge_update']
+        if args.graph:
+            dom, warm_classes = 6, None
         nblk = dims.L
-        mfma_launch = work[6] / (nblk * n_sub)                    # executed MFMA flops of ONE pair-update launch (one block, one sub-batch)
+        # the dominant launch class of THIS run (largest class time in the warm-up, bracketed with HIP events over the timed region)
+        dom_name = names[dom]
+        dom_ms, dom_n = per_class[dom_name]
+        brackets_per_fwd = (dom_n / args.steps) if dom_n else nblk      # one bracket per block (per forward for prologue / epilogue)
+        mfma_launch = work[dom] / max(brackets_per_fwd, 1)           # executed MFMA flops inside ONE bracket of that class
+        achieved = mfma_launch / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
+        # the pair update beside it (round 1-3's roofline kernel): from the timed region when it is the dominant class, else from the
+        # class timers of the warm-up steps of this run
+        if dom == 6:
+            upd_ms, upd_n, upd_src = dom_ms, dom_n, 'timed region'
+        elif warm_classes is not None and warm_classes[1][6] > 0:
+            upd_ms, upd_n, upd_src = warm_classes[0][6] / warm_classes[1][6], warm_classes[1][6], 'warm-up steps of this run (class timers)'
+        else:
+            upd_ms, upd_n, upd_src = per_class['edge_update'][0], per_class['edge_update'][1], 'timed region'
+        upd_mfma = work[6] / (nblk * n_sub)
         rot_stats = shared_row and not flags_now[4] and int(getattr(model, 'plan_options', {}).get(6, 1)) == 1
-        valu_launch = E * edge_update_vector_flops_per_directed_edge(dims, rot_stats) / n_sub
-        exec_launch = mfma_launch + valu_launch
-        achieved = exec_launch / (upd_ms * 1e-3) if upd_ms > 0 else 0.0
+        upd_valu = E * edge_update_vector_flops_per_directed_edge(dims, rot_stats) / n_sub
         exec_step = sum(work)                                    # executed MFMA flops of one forward, all kernels
         traffic, hbm = load_pmc_traffic(args.workload, B, upd_ms)
+        if hbm is not None and dom_name in hbm and isinstance(hbm[dom_name], dict):
+            traffic = hbm[dom_name].get('hbm_bytes_per_launch', traffic)
+        classes = None
+        if warm_classes is not None:
+            wms, wcnt, wsteps = warm_classes
+            classes = {names[c]: {'ms_per_step': wms[c] / wsteps, 'brackets_per_step': wcnt[c] / wsteps,
+                                  'mfma_frac': (work[c] / (wms[c] / wsteps * 1e-3) / PEAK_FP32_MFMA) if wms[c] > 0 else None}
+                       for c in range(8) if wcnt[c] > 0}
+        kernel_names = {'edge_update': 'k_edge_update_sym' if not flags_now[4] else 'k_edge_update',
+                        'node_post': 'node class: k_node_post + the two k_node_mix launches (k_node_ab items, Gram tiles)',
+                        'edge_attn': 'k_edge_attn', 'node_pre': 'k_node_pre', 'prologue': 'prologue (time / fold / embeddings)',
+                        'epilogue': 'epilogue (k_node_head, k_edge_head, outputs)'}
         out = {
             'metric': 'molecules/sec (1000-step ancestral)',
             'value': B * world / (SAMPLING_STEPS * step_s),
@@ -497,21 +574,26 @@ def main():
                        'step_noise': 'torch.randn x3 per step' if args.torch_noise else 'in-kernel Philox4x32-10 (jodo_sampler_step_rng)',
                        'streams_per_gpu': n_sub,
                        'parallelism': 'batch shard x%d, no data-path collective' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_edge_update_sym' if not flags_now[4] else 'k_edge_update',
+            'roofline': {'bound': 'mfma', 'kernel': kernel_names.get(dom_name, dom_name), 'launch_class': dom_name,
                          'achieved': achieved / 1e12, 'peak': PEAK_FP32_MFMA / 1e12,
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA, 'traffic': traffic, 'hbm': hbm,
-                         'note': 'achieved = fp32 flops the kernel EXECUTES per launch (MFMA flops from the plan work model '
-                                 'jodo_plan_work = SQ_INSTS_MFMA x 4096 of the committed PMC pass, + the vector flops of its '
-                                 'per-direction tails) / launch time; frac <= 1 by construction.  One launch = the pair-update work '
-                                 'of one block inside one HIP-event bracket on the launch stream.  reference_formulation_ratio = the '
-                                 'SURVEY.md 8d count for the same launch (reference formulation: per directed edge, no pair symmetry, '
-                                 'coord_mlp.0 per edge) / launch time / peak: an algorithmic speed-up figure, > 1 is not a hardware '
-                                 'fraction',
-                         'avg_launch_ms': upd_ms, 'launches': upd_n,
-                         'executed_mfma_flops_per_launch': mfma_launch, 'executed_vector_flops_per_launch': valu_launch,
-                         'mfma_frac': (mfma_launch / (upd_ms * 1e-3) / PEAK_FP32_MFMA) if upd_ms > 0 else 0.0,
-                         'reference_formulation_flops_per_launch': E * ref_upd_edge / n_sub,
-                         'reference_formulation_ratio': (E * ref_upd_edge / n_sub / (upd_ms * 1e-3) / PEAK_FP32_MFMA) if upd_ms > 0 else 0.0,
+                         'note': 'kernel = the launch class that took the most time in this run (class timers over the warm-up steps); '
+                                 'achieved = fp32 MFMA flops that class EXECUTES per HIP-event bracket (one bracket = its launches of one '
+                                 'block; plan work model jodo_plan_work = SQ_INSTS_MFMA x 4096 of the committed PMC pass) / the mean '
+                                 'bracket time measured over the timed region; vector flops are NOT in the numerator (reported '
+                                 'separately for the pair update).  traffic: HBM bytes per bracket from the committed PMC passes of the '
+                                 'same command (`hbm.source`), not from this run.  reference_formulation_ratio = the SURVEY.md 8d count '
+                                 '(reference formulation: per directed edge, no pair symmetry, coord_mlp.0 per edge) / time / peak: an '
+                                 'algorithmic speed-up figure, > 1 is not a hardware fraction',
+                         'avg_launch_ms': dom_ms, 'launches': dom_n,
+                         'executed_mfma_flops_per_launch': mfma_launch,
+                         'mfma_frac': achieved / PEAK_FP32_MFMA,
+                         'classes': classes,
+                         'pair_update': {'kernel': kernel_names['edge_update'], 'avg_launch_ms': upd_ms, 'launches': upd_n, 'measured_over': upd_src,
+                                         'executed_mfma_flops_per_launch': upd_mfma, 'executed_vector_flops_per_launch': upd_valu,
+                                         'mfma_frac': (upd_mfma / (upd_ms * 1e-3) / PEAK_FP32_MFMA) if upd_ms > 0 else 0.0,
+                                         'reference_formulation_flops_per_launch': E * ref_upd_edge / n_sub,
+                                         'reference_formulation_ratio': (E * ref_upd_edge / n_sub / (upd_ms * 1e-3) / PEAK_FP32_MFMA) if upd_ms > 0 else 0.0},
                          'whole_step_executed_mfma_TFLOP': exec_step / 1e12,
                          'whole_step_TFLOPs': exec_step / step_s / 1e12,
                          'whole_step_frac': exec_step / step_s / PEAK_FP32_MFMA,

@@ -207,7 +207,8 @@ int jodo_debug_set_timing_buffer(jodo_plan* plan, void* dev16xu64);
 /* Per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * enable = 1 makes every subsequent jodo_dgt_forward bracket every launch class with events (two event
  * packets per class boundary cost ~10 us each: ~0.5 ms per forward at 8 blocks); enable = 2 brackets only the
- * dominant class JODO_PROF_EDGE_UPDATE (what the roofline leg needs; ~0.1 ms); jodo_profile_read synchronises those events and returns, per class, the summed
+ * dominant class JODO_PROF_EDGE_UPDATE (~0.1 ms); enable = 16 + c brackets only class c (what the roofline leg needs: the class that was largest in
+ * this run's warm-up); jodo_profile_read synchronises those events and returns, per class, the summed
  * milliseconds and launch counts since the last read (arrays of JODO_PROF_COUNT), then resets. */
 enum jodo_prof_class {
     JODO_PROF_PROLOGUE = 0, JODO_PROF_NODE_PRE, JODO_PROF_EDGE_ATTN, JODO_PROF_RESERVED3, JODO_PROF_RESERVED4,

@@ -75,7 +75,7 @@ struct ProfScope {
         hipEvent_t e; (void)hipEventCreate(&e); return e;
     }
     ProfScope(jodo_plan* p_, hipStream_t st_, int cls_)
-        : p(p_), st(st_), cls(cls_), on(p_->prof_enabled == 1 || (p_->prof_enabled == 2 && cls_ == JODO_PROF_EDGE_UPDATE)) {
+        : p(p_), st(st_), cls(cls_), on(p_->prof_enabled == 1 || (p_->prof_enabled == 2 && cls_ == JODO_PROF_EDGE_UPDATE) || p_->prof_enabled == 16 + cls_) {
         if (on) { hipEvent_t e = get(p); (void)hipEventRecord(e, st); p->prof_ev.push_back(e); }
     }
     ~ProfScope() {

@@ -29,9 +29,13 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, c
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
     const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    f32x16 c;
+    // four accumulator blocks taken in turn by the k-pairs: each rounding chain is a quarter of the K range (weight gradients
+    // contract over every row of the batch; a single fp32 chain of that length costs a digit against blocked CPU summation)
+    f32x16 c4[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c4[j][i] = 0.f;
     for (int k0 = kbeg; k0 < kend; k0 += TK) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -58,10 +62,13 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, c
         for (int kk = 0; kk < TK; kk += 2) {
             const float a = As[kk + (lane >> 5)][wm + (lane & 31)];
             const float b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+            c4[(kk >> 1) & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c4[(kk >> 1) & 3], 0, 0, 0);
         }
         __syncthreads();
     }
+    f32x16 c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = (c4[0][i] + c4[1][i]) + (c4[2][i] + c4[3][i]);
     // C/D map of the 32x32 forms: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     const int col = n0 + wn + (lane & 31);
     if (col >= N) return;
@@ -94,8 +101,10 @@ void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, in
     if (M <= 0 || N <= 0) return;
     const int gx = (N + TN - 1) / TN, gy = (M + TM - 1) / TM;
     int nsplit = 1;
-    if (K >= 2048 && (long)gx * gy < 512 && ws) {          // few output tiles, long K: the weight-gradient shape
-        nsplit = (K + 1023) / 1024;
+    if (ws && K >= 512 && (tA || (K >= 2048 && (long)gx * gy < 512))) {
+        // the weight-gradient shape (few output tiles, K = every row of the batch): partial sums over 256 rows each — fills the chip
+        // and keeps every fp32 rounding chain short; the partial tiles are added in a fixed order by k_splitk_sum
+        nsplit = (K + 255) / 256;
         const long cap = (long)(ws_floats / ((size_t)M * N));
         if (nsplit > cap) nsplit = (int)cap;
         if (nsplit > 256) nsplit = 256;

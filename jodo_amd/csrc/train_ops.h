@@ -166,11 +166,11 @@ __global__ void k_seg_colsum(int S, int F, const int* __restrict__ off, const fl
                              float* __restrict__ out, int ldo, int ocol, int acc) {
     JT_IDX((long)S * F);
     const int s = (int)(i_ / F), f = (int)(i_ % F);
-    float t = 0.f;
-    if (b) for (long r = off[s]; r < off[s + 1]; ++r) t += a[r * F + f] * b[r * F + f];
-    else for (long r = off[s]; r < off[s + 1]; ++r) t += a[r * F + f];
+    double t = 0.0;                                  // gradient sums cancel: accumulated in double, stored in float
+    if (b) for (long r = off[s]; r < off[s + 1]; ++r) t += (double)(a[r * F + f] * b[r * F + f]);
+    else for (long r = off[s]; r < off[s + 1]; ++r) t += (double)a[r * F + f];
     float* o = out + (long)s * ldo + ocol + f;
-    *o = acc ? *o + t : t;
+    *o = acc ? *o + (float)t : (float)t;
 }
 // column sums of a [rows, F] (row stride lda) in two deterministic stages: part[c, f] = sum of chunk c, then out[f] (+)= sum_c
 __global__ void k_colsum_part(long rows, int F, int chunk, const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, float* __restrict__ part) {
@@ -178,16 +178,16 @@ __global__ void k_colsum_part(long rows, int F, int chunk, const float* __restri
     JT_IDX(nchunks * F);
     const long c = i_ / F; const int f = (int)(i_ % F);
     const long r1 = (c + 1) * chunk < rows ? (c + 1) * chunk : rows;
-    float t = 0.f;
-    if (b) for (long r = c * chunk; r < r1; ++r) t += a[r * lda + f] * b[r * ldb + f];
-    else for (long r = c * chunk; r < r1; ++r) t += a[r * lda + f];
-    part[i_] = t;
+    double t = 0.0;
+    if (b) for (long r = c * chunk; r < r1; ++r) t += (double)(a[r * lda + f] * b[r * ldb + f]);
+    else for (long r = c * chunk; r < r1; ++r) t += (double)a[r * lda + f];
+    part[i_] = (float)t;
 }
 __global__ void k_colsum_fin(long nchunks, int F, const float* __restrict__ part, float* __restrict__ out, int acc) {
     JT_IDX(F);
-    float t = 0.f;
-    for (long c = 0; c < nchunks; ++c) t += part[c * F + i_];
-    out[i_] = acc ? out[i_] + t : t;
+    double t = 0.0;
+    for (long c = 0; c < nchunks; ++c) t += (double)part[c * F + i_];
+    out[i_] = acc ? out[i_] + (float)t : (float)t;
 }
 
 // ================================================================ gates, broadcasts between node and edge arrays ================
@@ -321,22 +321,23 @@ __global__ void k_gbf_bwd_row(long rows, int De, const float* __restrict__ d2, c
     const float* g = gm + (long)row_mol[i_] * 2;
     const float x = d2[i_] * (g[0] + 1.f) + g[1];
     const float* d = dG + i_ * ldg + gcol;
-    float s = d[0];
+    double sum = (double)d[0];
     for (int k = 0; k < De - 1; ++k) {
         const float sd = fabsf(stds[k]) + 1e-5f;
         const float z = (x - means[k]) / sd;
         const float gk = expf(-0.5f * (z * z)) / (2.5066272f * sd);
-        s += d[1 + k] * gk * (-z / sd);
+        sum += (double)(d[1 + k] * gk * (-z / sd));
     }
+    const float s = (float)sum;
     dxp[i_] = s;
     if (dd2) dd2[i_] = (acc ? dd2[i_] : 0.f) + s * (g[0] + 1.f);
 }
 // per molecule: dscale = sum dx' d2, dshift = sum dx'
 __global__ void k_gbf_bwd_mol(int B, const int* __restrict__ off, const float* __restrict__ d2, const float* __restrict__ dxp, float* __restrict__ dgm) {
     JT_IDX(B);
-    float a = 0.f, b = 0.f;
-    for (long r = off[i_]; r < off[i_ + 1]; ++r) { a += dxp[r] * d2[r]; b += dxp[r]; }
-    dgm[i_ * 2] = a; dgm[i_ * 2 + 1] = b;
+    double a = 0.0, b = 0.0;
+    for (long r = off[i_]; r < off[i_ + 1]; ++r) { a += (double)dxp[r] * (double)d2[r]; b += (double)dxp[r]; }
+    dgm[i_ * 2] = (float)a; dgm[i_ * 2 + 1] = (float)b;
 }
 // parameter gradients, stage 1 over row chunks: part[c, k] (means), part[nchunks * K + c * K + k] (stds)
 __global__ void k_gbf_bwd_par(long rows, int De, int chunk, const float* __restrict__ d2, const int* __restrict__ row_mol, const float* __restrict__ gm,
@@ -349,18 +350,18 @@ __global__ void k_gbf_bwd_par(long rows, int De, int chunk, const float* __restr
     const long r1 = (c + 1) * chunk < rows ? (c + 1) * chunk : rows;
     const float w = stds[k];
     const float sd = fabsf(w) + 1e-5f, sg = w < 0.f ? -1.f : (w > 0.f ? 1.f : 0.f);
-    float dm = 0.f, ds = 0.f;
+    double dm = 0.0, ds = 0.0;
     for (long r = c * chunk; r < r1; ++r) {
         const float* g = gm + (long)row_mol[r] * 2;
         const float x = d2[r] * (g[0] + 1.f) + g[1];
         const float z = (x - means[k]) / sd;
         const float gk = expf(-0.5f * (z * z)) / (2.5066272f * sd);
         const float d = dG[r * ldg + gcol + 1 + k] * gk;
-        dm += d * (z / sd);
-        ds += d * ((z * z - 1.f) / sd) * sg;
+        dm += (double)(d * (z / sd));
+        ds += (double)(d * ((z * z - 1.f) / sd) * sg);
     }
-    part[i_] = dm;
-    part[nchunks * K + i_] = ds;
+    part[i_] = (float)dm;
+    part[nchunks * K + i_] = (float)ds;
 }
 
 // ================================================================ attention (TransMixLayer, layers.py:131-186) =================

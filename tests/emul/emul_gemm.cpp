@@ -4,19 +4,40 @@
 thread_local emu_idx threadIdx, blockIdx;
 thread_local dim3 blockDim, gridDim;
 namespace jt {
+// Mirrors the ROUNDING STRUCTURE of the device kernel so that the CPU suite predicts its accuracy: fp32 fused multiply-adds, four
+// accumulators taken in turn by the k-pairs, split-K partial sums over 256-wide chunks (rounded up to the 16-wide tile) added in order.
 void gemm(hipStream_t, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-          const float* bias, int acc, float*, size_t) {
+          const float* bias, int acc, float* ws, size_t ws_floats) {
+    const int gx = (N + 63) / 64, gy = (M + 63) / 64;
+    int nsplit = 1;
+    if (ws && K >= 512 && (tA || (K >= 2048 && (long)gx * gy < 512))) {
+        nsplit = (K + 255) / 256;
+        const long cap = (long)(ws_floats / ((size_t)M * N));
+        if (nsplit > cap) nsplit = (int)cap;
+        if (nsplit > 256) nsplit = 256;
+        if (nsplit < 1) nsplit = 1;
+    }
+    int kchunk = (K + nsplit - 1) / nsplit;
+    kchunk = (kchunk + 15) / 16 * 16;
+    if (kchunk < 16) kchunk = 16;
+    nsplit = K > 0 ? (K + kchunk - 1) / kchunk : 1;
     for (int m = 0; m < M; ++m)
         for (int n = 0; n < N; ++n) {
-            double s = 0.0;
-            for (int k = 0; k < K; ++k) {
-                const float a = tA ? A[(long)k * lda + m] : A[(long)m * lda + k];
-                const float b = tB ? B[(long)n * ldb + k] : B[(long)k * ldb + n];
-                s += (double)a * (double)b;
+            float total = 0.f;
+            for (int z = 0; z < nsplit; ++z) {
+                float c4[4] = {0.f, 0.f, 0.f, 0.f};
+                const int k1 = K < (z + 1) * kchunk ? K : (z + 1) * kchunk;
+                for (int k = z * kchunk; k < k1; ++k) {
+                    const float a = tA ? A[(long)k * lda + m] : A[(long)m * lda + k];
+                    const float b = tB ? B[(long)n * ldb + k] : B[(long)k * ldb + n];
+                    float& c = c4[((k - z * kchunk) >> 1) & 3];
+                    c = fmaf(a, b, c);
+                }
+                total += (c4[0] + c4[1]) + (c4[2] + c4[3]);
             }
-            if (bias) s += bias[n];
+            if (bias) total += bias[n];
             float* o = C + (long)m * ldc + n;
-            *o = acc ? (float)(*o + s) : (float)s;
+            *o = acc ? *o + total : total;
         }
 }
 }
