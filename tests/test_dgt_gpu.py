@@ -560,7 +560,7 @@ def test_full_size_batch_properties():
     close(e2, e1[sub][:, :Ns, :Ns], atol=2e-5)
 
 
-def test_cpu_tensor_and_grad_are_rejected_loudly():
+def test_cpu_tensor_and_input_grad_are_rejected_loudly():
     cfg = make_config('vpsde_qm9_uncond_jodo')
     model = make_model(cfg, 4, DEV)
     hp = O.Hyper.from_config(cfg)
@@ -568,8 +568,12 @@ def test_cpu_tensor_and_grad_are_rejected_loudly():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model(nl, xh, nm, em, edge_x=ex, cond_x=None, cond_edge_x=None, noise_level=nl)
     d = lambda x: x.to(DEV)
-    with pytest.raises(RuntimeError, match="backward"):
-        model(d(nl), d(xh), d(nm), d(em), edge_x=d(ex), cond_x=None, cond_edge_x=None, noise_level=d(nl))
+    # since round 4 a grad-enabled call runs the training path (parameter gradients, tests/test_train_gpu.py); what it does
+    # not provide — gradients with respect to the INPUTS — is refused, not silently dropped
+    with pytest.raises(RuntimeError, match="parameter gradients only"):
+        model(d(nl), d(xh).requires_grad_(True), d(nm), d(em), edge_x=d(ex), cond_x=None, cond_edge_x=None, noise_level=d(nl))
+    out = model(d(nl), d(xh), d(nm), d(em), edge_x=d(ex), cond_x=None, cond_edge_x=None, noise_level=d(nl))
+    assert out[0].requires_grad and out[1].requires_grad
 
 
 @pytest.mark.parametrize("cfg_name,n_nodes,over", [

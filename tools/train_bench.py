@@ -1,0 +1,109 @@
+"""Training-step timing of the HIP score network: get_step_fn (jodo_amd/losses.py) on a synthetic batch of
+config.training.batch_size molecules with the dataset's atom-count histogram — per-molecule noise levels, the 50 % self-conditioning
+double forward, dropout 0.1, loss.backward() through jodo_train_backward, AdamW + clipping + EMA.  Prints one JSON line.
+
+    python tools/train_bench.py [--workload qm9|geom] [--batch B] [--steps K] [--warmup W]
+
+Work model: a grad-enabled forward + backward costs 3 x the forward's projection flops (forward, input gradient, weight gradient);
+the no-grad self-conditioning forward (half of the steps) one more; `gemm_flops_per_step` prices the projections only
+(oracle.algorithmic_flops with per-molecule time rows), against the fp32 MFMA peak."""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def synthetic_batch(cfg, n_nodes, seed):
+    from jodo_amd.sampling import build_masks
+    g = torch.Generator().manual_seed(seed)
+    B, N = len(n_nodes), max(n_nodes)
+    nm, em = build_masks(n_nodes, N, 'cpu')
+    at = torch.randint(0, cfg.data.atom_types, (B, N), generator=g)
+    nb = 4 if cfg.model.edge_ch == 2 else 5
+    bond = torch.triu(torch.randint(0, nb, (B, N, N), generator=g), 1)
+    bond = bond + bond.transpose(1, 2)
+    if cfg.model.edge_ch == 2:
+        eoh = torch.stack([(bond > 0).float(), bond.clamp(max=3).float() / 3.], -1)
+    else:
+        eoh = torch.stack([(bond > 0).float(), bond.clamp(max=3).float() / 3., (bond == 4).float()], -1)
+    return dict(positions=torch.randn(B, N, 3, generator=g) * nm, atom_mask=nm[..., 0], edge_mask=em,
+                atom_one_hot=torch.nn.functional.one_hot(at, cfg.data.atom_types).float() * nm,
+                edge_one_hot=eoh * em.reshape(B, N, N, 1), formal_charges=torch.randint(-1, 2, (B, N, 1), generator=g).float() * nm)
+
+
+def run(workload='qm9', batch=0, steps=10, warmup=3, seed=42):
+    from jodo_amd import configs, losses as L
+    from jodo_amd.diffusion import NoiseScheduleVP
+    from jodo_amd.models import get_model_class, deterministic_init_, load_dataset_info, get_node_dist
+    from jodo_amd.models.ema import ExponentialMovingAverage
+    from jodo_amd.utils import get_data_scaler
+    name, info = dict(qm9=('vpsde_qm9_uncond_jodo', 'qm9_with_h'), geom=('vpsde_geom_uncond_jodo', 'geom_with_h_1'))[workload]
+    cfg = configs.get(name)
+    dev = torch.device('cuda:0')
+    cfg.device = dev
+    B = batch or int(cfg.training.batch_size)
+    torch.manual_seed(seed)
+    random.seed(seed)
+    n_nodes = get_node_dist(load_dataset_info(info)).sample(B).tolist()
+    data = synthetic_batch(cfg, n_nodes, seed)
+    model = deterministic_init_(get_model_class(cfg.model.name)(cfg), seed=seed).to(dev)
+    ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
+    state = dict(model=model, optimizer=L.get_optimizer(cfg, model.parameters()),
+                 ema=ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_decay), step=1)
+    step_fn = L.get_step_fn(ns, True, L.optimization_manager(cfg), get_data_scaler(cfg), cfg)
+    losses = []
+    for _ in range(warmup):
+        losses.append(float(step_fn(state, data)))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses.append(float(step_fn(state, data)))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    # forward / backward alone (no self-conditioning forward, no optimiser), HIP events
+    from jodo_amd.sampling import build_masks
+    nm, em = build_masks(n_nodes, max(n_nodes), dev)
+    xh = torch.randn(B, max(n_nodes), 3 + model.dims.nd, device=dev) * nm
+    ex = torch.randn(B, max(n_nodes), max(n_nodes), model.dims.ch, device=dev)
+    ex = (ex + ex.transpose(1, 2)) * em.reshape(B, max(n_nodes), max(n_nodes), 1)
+    nl = torch.randn(B, device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    fwd = bwd = 0.0
+    for _ in range(3):
+        model.zero_grad()
+        ev[0].record()
+        ox, oe = model(nl, xh, nm, em, edge_x=ex, cond_x=None, cond_edge_x=None, noise_level=nl)
+        ev[1].record()
+        (ox.square().sum() + oe.square().sum()).backward()
+        ev[2].record()
+        torch.cuda.synchronize()
+        fwd, bwd = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    sys.path.insert(0, ROOT)
+    from oracle import dgt_oracle as O                      # work model only (checker-side formulas)
+    hp = O.Hyper.from_config(cfg)
+    f_fwd = O.algorithmic_flops(hp, n_nodes, shared_time=False)['total']
+    peak = 157.3e12
+    return dict(workload=name, batch=B, steps=steps, s_per_step=dt, molecules_per_s=B / dt, loss_first=losses[0], loss_last=losses[-1],
+                forward_ms=fwd, backward_ms=bwd, forward_algorithmic_flops=f_fwd,
+                forward_frac_of_fp32_mfma_peak=f_fwd / (fwd * 1e-3) / peak, backward_frac_of_fp32_mfma_peak=2 * f_fwd / (bwd * 1e-3) / peak,
+                note='one optimiser step = (50 %: no-grad self-conditioning forward) + grad forward + backward + AdamW / clipping / EMA; '
+                     'forward_ms / backward_ms: one grad-enabled forward and its backward alone (HIP events); fractions price the '
+                     'SURVEY.md 8d forward count (x 2 for the two gradient products of every projection) against 157.3 TFLOP/s — '
+                     'first-correct kernels (train_ops.h), not yet tuned')
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--workload', default='qm9')
+    ap.add_argument('--batch', type=int, default=0)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    a = ap.parse_args()
+    print(json.dumps(run(a.workload, a.batch, a.steps, a.warmup)))
