@@ -55,8 +55,8 @@ struct Bufs {
     float *nh1pre, *nh1, *nh2pre, *nh2, *atom, *x1pre[2], *x1[2], *x2pre[2], *x2[2], *Ep, *posf;
     // scratch shared by all phases
     float *tE_D[3], *tE_De[4], *tE_QK, *tE_rD, *tE_H, *tN_D[4], *tN_QK[2], *tN_rD, *tN_De, *tRow[3], *tE3[3], *tN3[4], *tcatn, *tcate;
-    float *dtau, *dtemb, *dnmod, *demod, *dqmod, *dgm, *tB_T[2], *tB_cD[2], *part, *splitk;
-    size_t splitk_floats, part_floats;
+    float *dtau, *dtemb, *dnmod, *demod, *dqmod, *dgm, *tB_T[2], *tB_cD[2], *part, *part2, *splitk;
+    size_t splitk_floats, part_floats, part2_floats;
 };
 
 }  // namespace
@@ -65,8 +65,9 @@ struct jodo_train {
     jodo_cfg cfg;
     int B, N, Nn, R;
     int D, De, T, L, H, XH, SC, QK, C, r, nd, ch, cc, cn, ce, catn, cate, half;
-    std::vector<int> tables;          // node_off | edge_off | nn | node_mol | edge_mol | edge_a | edge_c
-    size_t o_node_off, o_edge_off, o_nn, o_node_mol, o_edge_mol, o_edge_a, o_edge_c;
+    std::vector<int> tables;          // node_off | edge_off | nn | node_mol | edge_mol | edge_a | edge_c | ec_off | ec_mol_off
+    size_t o_node_off, o_edge_off, o_nn, o_node_mol, o_edge_mol, o_edge_a, o_edge_c, o_ec_off, o_ec_mol_off;
+    int NC;                           // chunks of edge rows (two-level per-molecule sums)
     int n_params;
     std::vector<size_t> numel;
     // parameter indices
@@ -116,8 +117,10 @@ void layout(const jodo_train& t, Arena& a, Bufs& b) {
     for (int s = 0; s < 2; ++s) { b.tB_T[s] = a.f(B * T); b.tB_cD[s] = a.f(B * cc * D); }
     const size_t rows = R > Nn ? R : Nn;
     const size_t maxF = std::max<size_t>({(size_t)6 * D, T, r * D});
-    b.part_floats = ((rows + 255) / 256 + 1) * 2 * maxF;
+    b.part_floats = ((rows + 31) / 32 + B + 1) * maxF;        // first-level partial sums: 32-row chunks x the widest reduced array
     b.part = a.f(b.part_floats);
+    b.part2_floats = (b.part_floats / maxF / 32 + 2) * maxF;
+    b.part2 = a.f(b.part2_floats);
     b.splitk_floats = (size_t)32 << 20;      // 128 MiB of split-K partial tiles at most
     const size_t need = ((rows + 1023) / 1024 + 1) * (size_t)D * (2 * D + 2 * De);
     if (b.splitk_floats > need) b.splitk_floats = need;
@@ -140,12 +143,25 @@ struct Ctx {
     void lin_dw(const float* dY, int ldy, int rows, int N, const float* X, int ldx, int K, float* dW, int lddw) const {
         gemm(s, 1, 0, N, K, rows, dY, ldy, X, ldx, dW, lddw, nullptr, 1, b.splitk, b.splitk_floats);
     }
-    // db[F] += column sums of a[rows, F] (row stride lda), optionally of a * bb
+    // out[F] += column sums of a[rows, F] (row stride lda), optionally of a * bb: 32-row partial sums, then partial sums of those
+    // until at most 64 rows are left (every level a launch with rows x F / 32 threads; fixed order, no atomics)
     void colsum(const float* a, int lda, const float* bb, int ldb, long rows, int F, float* out) const {
-        const int chunk = 256;
-        const long nch = (rows + chunk - 1) / chunk;
-        JT_LAUNCH(k_colsum_part, nch * F, s, rows, F, chunk, a, lda, bb, ldb, b.part);
-        JT_LAUNCH(k_colsum_fin, F, s, nch, F, (const float*)b.part, out, 1);
+        const int chunk = 32;
+        float* dst = b.part; float* other = b.part2;
+        long n = rows;
+        while (true) {
+            const long nch = (n + chunk - 1) / chunk;
+            JT_LAUNCH(k_colsum_part, nch * F, s, n, F, chunk, a, lda, bb, ldb, dst);
+            a = dst; lda = F; bb = nullptr; ldb = 0; n = nch;
+            if (n <= 64) break;
+            std::swap(dst, other);
+        }
+        JT_LAUNCH(k_colsum_fin, F, s, n, F, a, out, 1);
+    }
+    // per-molecule sums over EDGE rows (two levels over the plan's chunks), out[mol, ocol + f] written
+    void seg_edge(int F, const float* a, const float* bb, float* out, int ldo, int ocol) const {
+        JT_LAUNCH(k_seg_part, (long)tp.NC * F, s, tp.NC, F, tp.ec_off, a, bb, b.part);
+        JT_LAUNCH(k_seg_fin, (long)t.B * F, s, t.B, F, tp.ec_mol_off, (const float*)b.part, out, ldo, ocol, 0);
     }
     void silu(long n, const float* x, float* y, Drop d) const { JT_LAUNCH(k_silu_fwd, n, s, n, x, y, d); }
     void silu_bwd(long n, const float* x, const float* dy, float* dx, Drop d) const { JT_LAUNCH(k_silu_bwd, n, s, n, x, dy, dx, d); }
@@ -157,14 +173,16 @@ struct Ctx {
     // LayerNorm + modulate backward: modulation gradients into dmods[:, sh], [:, sc] (written), dx (acc)
     void ln_mod_bwd(long rows, int F, const float* dy, const float* xhat, const float* rstd, const int* row_mol, const int* seg_off, const float* mods,
                     int ldm, int sh, int sc, float* dmods, float* dx, int acc) const {
-        JT_LAUNCH(k_seg_colsum, (long)t.B * F, s, t.B, F, seg_off, dy, (const float*)nullptr, dmods, ldm, sh, 0);
-        JT_LAUNCH(k_seg_colsum, (long)t.B * F, s, t.B, F, seg_off, dy, xhat, dmods, ldm, sc, 0);
+        seg(F, seg_off, dy, nullptr, dmods, ldm, sh);
+        seg(F, seg_off, dy, xhat, dmods, ldm, sc);
         JT_LAUNCH(k_ln_bwd_stats, rows, s, rows, F, dy, xhat, row_mol, mods, ldm, sc, b.tRow[0], b.tRow[1]);
         JT_LAUNCH(k_ln_bwd_apply, rows * F, s, rows, F, dy, xhat, rstd, (const float*)b.tRow[0], (const float*)b.tRow[1], row_mol, mods,
                            ldm, sc, dx, acc);
     }
+    // per-molecule sums: edge rows in two levels, node rows (at most 181 per molecule) directly
     void seg(int F, const int* off, const float* a, const float* bb, float* out, int ldo, int ocol) const {
-        JT_LAUNCH(k_seg_colsum, (long)t.B * F, s, t.B, F, off, a, bb, out, ldo, ocol, 0);
+        if (off == tp.edge_off) seg_edge(F, a, bb, out, ldo, ocol);
+        else JT_LAUNCH(k_seg_colsum, (long)t.B * F, s, t.B, F, off, a, bb, out, ldo, ocol, 0);
     }
     void copy2d(long rows, int F, const float* src, int lds, int scol, float* dst, int ldd, int dcol, int acc) const {
         JT_LAUNCH(k_copy2d, rows * F, s, rows, F, src, lds, scol, dst, ldd, dcol, acc);
@@ -333,12 +351,14 @@ void gbf_bwd(const Ctx& c, long rows, const float* d2, const float* gm, int mean
     const jodo_train& t = c.t; Bufs& b = c.b; hipStream_t s = c.s;
     const int De = t.De, K = De - 1;
     JT_LAUNCH(k_gbf_bwd_row, rows, s, rows, De, d2, c.tp.edge_mol, gm, c.p(means), c.p(stds), dG, ldg, gcol, b.tRow[2], dd2, 0);
-    JT_LAUNCH(k_gbf_bwd_mol, t.B, s, t.B, c.tp.edge_off, d2, (const float*)b.tRow[2], b.dgm);
-    const int chunk = 256;
+    c.seg_edge(1, b.tRow[2], d2, b.dgm, 2, 0);              // d scale = sum dx' d2,  d shift = sum dx'  per molecule
+    c.seg_edge(1, b.tRow[2], nullptr, b.dgm, 2, 1);
+    const int chunk = 32;
     const long nch = (rows + chunk - 1) / chunk;
-    JT_LAUNCH(k_gbf_bwd_par, nch * K, s, rows, De, chunk, d2, c.tp.edge_mol, gm, c.p(means), c.p(stds), dG, ldg, gcol, b.part);
-    JT_LAUNCH(k_colsum_fin, K, s, nch, K, (const float*)b.part, c.g(means), 1);
-    JT_LAUNCH(k_colsum_fin, K, s, nch, K, (const float*)(b.part + nch * K), c.g(stds), 1);
+    float *pm = b.tE_QK, *ps = b.tE_QK + nch * K;            // (the attention scratch is free here)
+    JT_LAUNCH(k_gbf_bwd_par, nch * K, s, rows, De, chunk, d2, c.tp.edge_mol, gm, c.p(means), c.p(stds), dG, ldg, gcol, pm, ps);
+    c.colsum(pm, K, nullptr, 0, nch, K, c.g(means));
+    c.colsum(ps, K, nullptr, 0, nch, K, c.g(stds));
     mod_bwd(c, time, b.dgm, 2);
 }
 
@@ -531,6 +551,7 @@ Topo make_topo(const jodo_train& t, const void* desc_dev) {
     tp.B = t.B; tp.Nn = t.Nn; tp.R = t.R; tp.N = t.N;
     tp.node_off = d + t.o_node_off; tp.edge_off = d + t.o_edge_off; tp.nn = d + t.o_nn; tp.node_mol = d + t.o_node_mol;
     tp.edge_mol = d + t.o_edge_mol; tp.edge_a = d + t.o_edge_a; tp.edge_c = d + t.o_edge_c;
+    tp.NC = t.NC; tp.ec_off = d + t.o_ec_off; tp.ec_mol_off = d + t.o_ec_mol_off;
     return tp;
 }
 
@@ -558,7 +579,25 @@ int jodo_train_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes,
     std::vector<int>& tb = t->tables;
     t->o_node_off = 0; t->o_edge_off = t->o_node_off + B + 1; t->o_nn = t->o_edge_off + B + 1; t->o_node_mol = t->o_nn + B;
     t->o_edge_mol = t->o_node_mol + Nn; t->o_edge_a = t->o_edge_mol + R; t->o_edge_c = t->o_edge_a + R;
-    tb.assign(t->o_edge_c + R, 0);
+    // chunks of a molecule's edge rows: at most 64 per molecule, at least 32 rows each
+    std::vector<int> ec_off, ec_mol_off;
+    {
+        int eo2 = 0;
+        for (int b = 0; b < B; ++b) {
+            const int n2 = n_nodes[b] * n_nodes[b];
+            const int ch = std::max(32, (n2 + 63) / 64);
+            ec_mol_off.push_back((int)ec_off.size());
+            for (int r0 = 0; r0 < n2; r0 += ch) ec_off.push_back(eo2 + r0);
+            eo2 += n2;
+        }
+        ec_mol_off.push_back((int)ec_off.size());
+        ec_off.push_back(eo2);
+    }
+    t->NC = (int)ec_off.size() - 1;
+    t->o_ec_off = t->o_edge_c + R; t->o_ec_mol_off = t->o_ec_off + ec_off.size();
+    tb.assign(t->o_ec_mol_off + ec_mol_off.size(), 0);
+    std::copy(ec_off.begin(), ec_off.end(), tb.begin() + t->o_ec_off);
+    std::copy(ec_mol_off.begin(), ec_mol_off.end(), tb.begin() + t->o_ec_mol_off);
     int no = 0, eo = 0;
     for (int b = 0; b < B; ++b) {
         const int n = n_nodes[b];

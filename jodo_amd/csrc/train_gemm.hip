@@ -5,11 +5,13 @@
 //     input grad   dX = dY W             A = dY [M, N'] row-major,           B = W stored [N', K'] as [K, N]
 //     weight grad  dW = dY^T X           A = dY stored [rows, N'] = [K, M] (TA), B = X [rows, K'] = [K, N]; K = rows is the long
 //                                        dimension: split over grid.z, partial tiles summed by k_splitk_sum in a fixed order
-// Tile: 64 x 64 outputs per 256-thread workgroup (4 waves, one 32 x 32 accumulator block each), K in steps of 16 through LDS
-// ([k][m] / [k][n], consecutive lanes read consecutive m / n: conflict-free operand reads; global loads run along whichever
-// index is contiguous in memory).  Bounds are checked on every edge (N = 3, K = 17 and ragged row counts all occur).
-// First-correct kernel of the training row: no double buffering, no XCD-aware tile order yet.
+// Tile: 64 x 64 outputs per 256-thread workgroup (4 waves, one 32 x 32 accumulator block each), K in steps of 32 through LDS
+// ([k][m] / [k][n], consecutive lanes read consecutive m / n: conflict-free operand reads); global loads are 16 bytes per thread
+// along whichever index is contiguous in memory, and the next K tile is in flight (registers) while the current one is multiplied.
+// Bounds are checked on every edge (N = 3, K = 17 and ragged row counts all occur; unaligned operands take an element-wise path).
+// Not yet: XCD-aware tile order, larger tiles for the square node-level products.
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include "train_gemm.h"
 
 namespace jt {
@@ -17,14 +19,52 @@ namespace jt {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TM 64
 #define TN 64
-#define TK 16
+#define TK 32
 #define LDSW (TM + 4)
+
+// one operand tile (64 x TK) from global memory into registers: two 16-byte loads per thread along whichever index is contiguous
+// in memory (KC: the k index is contiguous — X / dY rows, W rows; otherwise the m / n index is: transposed reads of dY, plain B),
+// element-wise with bounds checks where a quad is not whole or not 16-byte aligned.  r[e * 4 + j] <-> (kk, i) as store_tile says.
+template <bool KC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int i0, int imax, int k0, int kend, bool vec, int tid, float (&r)[8]) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        int i, kk;                                           // first element of this thread's quad
+        if (KC) { i = (tid >> 3) + 32 * e; kk = (tid & 7) * 4; } else { kk = (tid >> 4) + 16 * e; i = (tid & 15) * 4; }
+        const int gi = i0 + i, gk = k0 + kk;
+        const bool whole = KC ? (gi < imax && gk + 3 < kend) : (gk < kend && gi + 3 < imax);
+        if (vec && whole) {
+            const float4 v = *reinterpret_cast<const float4*>(KC ? P + (long)gi * ld + gk : P + (long)gk * ld + gi);
+            r[e * 4 + 0] = v.x; r[e * 4 + 1] = v.y; r[e * 4 + 2] = v.z; r[e * 4 + 3] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ii = KC ? gi : gi + j, kq = KC ? gk + j : gk;
+                r[e * 4 + j] = (ii < imax && kq < kend) ? (KC ? P[(long)ii * ld + kq] : P[(long)kq * ld + ii]) : 0.f;
+            }
+        }
+    }
+}
+template <bool KC>
+__device__ __forceinline__ void store_tile(float (*S)[LDSW], int tid, const float (&r)[8]) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if (KC) {
+            const int i = (tid >> 3) + 32 * e, kk = (tid & 7) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) S[kk + j][i] = r[e * 4 + j];
+        } else {
+            const int kk = (tid >> 4) + 16 * e, i = (tid & 15) * 4;
+            *reinterpret_cast<float4*>(&S[kk][i]) = make_float4(r[e * 4 + 0], r[e * 4 + 1], r[e * 4 + 2], r[e * 4 + 3]);
+        }
+    }
+}
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                              float* __restrict__ C, int ldc, const float* __restrict__ bias, int acc, float* __restrict__ part) {
-    __shared__ float As[TK][LDSW];
-    __shared__ float Bs[TK][LDSW];
+                                              float* __restrict__ C, int ldc, const float* __restrict__ bias, int acc, float* __restrict__ part, int vecA, int vecB) {
+    __shared__ __attribute__((aligned(16))) float As[TK][LDSW];
+    __shared__ __attribute__((aligned(16))) float Bs[TK][LDSW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
     const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
@@ -36,28 +76,20 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, c
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) c4[j][i] = 0.f;
+    float ra[8], rb[8];
+    // A is k-contiguous unless transposed; B (stored [N, K] when TB) is k-contiguous when TB
+    if (kbeg < kend) {
+        load_tile<!TA>(A, lda, m0, M, kbeg, kend, vecA != 0, tid, ra);
+        load_tile<TB>(B, ldb, n0, N, kbeg, kend, vecB != 0, tid, rb);
+    }
     for (int k0 = kbeg; k0 < kend; k0 += TK) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = tid + 256 * e;
-            {   // A tile: As[kk][i]
-                int i, kk;
-                if (TA) { i = idx % TM; kk = idx / TM; } else { kk = idx % TK; i = idx / TK; }
-                const int gm = m0 + i, gk = k0 + kk;
-                float v = 0.f;
-                if (gm < M && gk < kend) v = TA ? A[(long)gk * lda + gm] : A[(long)gm * lda + gk];
-                As[kk][i] = v;
-            }
-            {   // B tile: Bs[kk][j]
-                int j, kk;
-                if (TB) { kk = idx % TK; j = idx / TK; } else { j = idx % TN; kk = idx / TN; }
-                const int gn = n0 + j, gk = k0 + kk;
-                float v = 0.f;
-                if (gn < N && gk < kend) v = TB ? B[(long)gn * ldb + gk] : B[(long)gk * ldb + gn];
-                Bs[kk][j] = v;
-            }
-        }
+        store_tile<!TA>(As, tid, ra);
+        store_tile<TB>(Bs, tid, rb);
         __syncthreads();
+        if (k0 + TK < kend) {                                // the next tile travels while this one is multiplied
+            load_tile<!TA>(A, lda, m0, M, k0 + TK, kend, vecA != 0, tid, ra);
+            load_tile<TB>(B, ldb, n0, N, k0 + TK, kend, vecB != 0, tid, rb);
+        }
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 2) {
             const float a = As[kk + (lane >> 5)][wm + (lane & 31)];
@@ -116,10 +148,14 @@ void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, in
     nsplit = K > 0 ? (K + kchunk - 1) / kchunk : 1;
     float* part = nsplit > 1 ? ws : nullptr;
     const dim3 grid(gx, gy, nsplit), block(256);
-    if (tA && tB) hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part);
-    else if (tA) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part);
-    else if (tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part);
-    else hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part);
+    // 16-byte loads need an aligned base and a row stride that keeps every quad aligned (column offsets of sliced weights included
+    // in the base pointer); otherwise the element-wise path
+    const int vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
+    const int vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
+    if (tA && tB) hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
+    else if (tA) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
+    else if (tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
+    else hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
     if (nsplit > 1)
         hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, s, M, N, nsplit, part, C, ldc, bias, acc);
 }

@@ -35,6 +35,10 @@ struct Topo {                 // device tables of one batch
     const int* edge_mol;      // [R]
     const int* edge_a;        // [R] global node row of the row atom
     const int* edge_c;        // [R] global node row of the column atom
+    // edge rows of a molecule cut into chunks (at most 64 per molecule, at least 32 rows each): two-level per-molecule sums
+    int NC;
+    const int* ec_off;        // [NC + 1] first row of every chunk
+    const int* ec_mol_off;    // [B + 1] first chunk of every molecule
 };
 
 // ---- dropout masks: Philox4x32-10 keyed by the call's seed, counter = (element / 4, site); the backward regenerates them ----
@@ -169,6 +173,24 @@ __global__ void k_seg_colsum(int S, int F, const int* __restrict__ off, const fl
     double t = 0.0;                                  // gradient sums cancel: accumulated in double, stored in float
     if (b) for (long r = off[s]; r < off[s + 1]; ++r) t += (double)(a[r * F + f] * b[r * F + f]);
     else for (long r = off[s]; r < off[s + 1]; ++r) t += (double)a[r * F + f];
+    float* o = out + (long)s * ldo + ocol + f;
+    *o = acc ? *o + (float)t : (float)t;
+}
+// the same over the edge rows of every molecule in two levels (a molecule has up to 181^2 rows): part[c, f] = sum over chunk c,
+// then out[mol, ocol + f] = sum over the molecule's chunks — fixed order, no atomics
+__global__ void k_seg_part(int NC, int F, const int* __restrict__ ec_off, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part) {
+    JT_IDX((long)NC * F);
+    const int c = (int)(i_ / F), f = (int)(i_ % F);
+    double t = 0.0;
+    if (b) for (long r = ec_off[c]; r < ec_off[c + 1]; ++r) t += (double)(a[r * F + f] * b[r * F + f]);
+    else for (long r = ec_off[c]; r < ec_off[c + 1]; ++r) t += (double)a[r * F + f];
+    part[i_] = (float)t;
+}
+__global__ void k_seg_fin(int S, int F, const int* __restrict__ mol_off, const float* __restrict__ part, float* __restrict__ out, int ldo, int ocol, int acc) {
+    JT_IDX((long)S * F);
+    const int s = (int)(i_ / F), f = (int)(i_ % F);
+    double t = 0.0;
+    for (int c = mol_off[s]; c < mol_off[s + 1]; ++c) t += (double)part[(long)c * F + f];
     float* o = out + (long)s * ldo + ocol + f;
     *o = acc ? *o + (float)t : (float)t;
 }
@@ -332,17 +354,10 @@ __global__ void k_gbf_bwd_row(long rows, int De, const float* __restrict__ d2, c
     dxp[i_] = s;
     if (dd2) dd2[i_] = (acc ? dd2[i_] : 0.f) + s * (g[0] + 1.f);
 }
-// per molecule: dscale = sum dx' d2, dshift = sum dx'
-__global__ void k_gbf_bwd_mol(int B, const int* __restrict__ off, const float* __restrict__ d2, const float* __restrict__ dxp, float* __restrict__ dgm) {
-    JT_IDX(B);
-    double a = 0.0, b = 0.0;
-    for (long r = off[i_]; r < off[i_ + 1]; ++r) { a += (double)dxp[r] * (double)d2[r]; b += (double)dxp[r]; }
-    dgm[i_ * 2] = (float)a; dgm[i_ * 2 + 1] = (float)b;
-}
-// parameter gradients, stage 1 over row chunks: part[c, k] (means), part[nchunks * K + c * K + k] (stds)
+// parameter gradients, stage 1 over row chunks: part_m[c, k] (means), part_s[c, k] (stds)
 __global__ void k_gbf_bwd_par(long rows, int De, int chunk, const float* __restrict__ d2, const int* __restrict__ row_mol, const float* __restrict__ gm,
                               const float* __restrict__ means, const float* __restrict__ stds, const float* __restrict__ dG, int ldg, int gcol,
-                              float* __restrict__ part) {
+                              float* __restrict__ part_m, float* __restrict__ part_s) {
     const int K = De - 1;
     const long nchunks = (rows + chunk - 1) / chunk;
     JT_IDX(nchunks * K);
@@ -360,8 +375,8 @@ __global__ void k_gbf_bwd_par(long rows, int De, int chunk, const float* __restr
         dm += (double)(d * (z / sd));
         ds += (double)(d * ((z * z - 1.f) / sd) * sg);
     }
-    part[i_] = (float)dm;
-    part[nchunks * K + i_] = (float)ds;
+    part_m[i_] = (float)dm;
+    part_s[i_] = (float)ds;
 }
 
 // ================================================================ attention (TransMixLayer, layers.py:131-186) =================

@@ -6,7 +6,7 @@ thread_local emu_idx threadIdx, blockIdx;
 thread_local dim3 blockDim, gridDim;
 namespace jt {
 // Mirrors the ROUNDING STRUCTURE of the device kernel so that the CPU suite predicts its accuracy: fp32 fused multiply-adds, four
-// accumulators taken in turn by the k-pairs, split-K partial sums over 256-wide chunks (rounded up to the 16-wide tile) added in order.
+// accumulators taken in turn by the k-pairs, split-K partial sums over 256-wide chunks (rounded up to the 32-wide tile) added in order.
 void gemm(hipStream_t, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
           const float* bias, int acc, float* ws, size_t ws_floats) {
     // debugging aid: products summed in double; value = bit mask of the products it applies to (1 forward, 2 input gradient, 4 weight gradient)
@@ -34,8 +34,8 @@ void gemm(hipStream_t, int tA, int tB, int M, int N, int K, const float* A, int 
         if (nsplit < 1) nsplit = 1;
     }
     int kchunk = (K + nsplit - 1) / nsplit;
-    kchunk = (kchunk + 15) / 16 * 16;
-    if (kchunk < 16) kchunk = 16;
+    kchunk = (kchunk + 31) / 32 * 32;                   // the device kernel's K tile
+    if (kchunk < 32) kchunk = 32;
     nsplit = K > 0 ? (K + kchunk - 1) / kchunk : 1;
     for (int m = 0; m < M; ++m)
         for (int n = 0; n < N; ++n) {

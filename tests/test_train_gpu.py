@@ -123,22 +123,26 @@ def test_edge_ffn_backward_rejects_other_shapes():
 
 
 # ---- the whole network under autograd (csrc/dgt_train.hip, train_ops.h, train_gemm.hip) ----------------------------------------
-@pytest.mark.parametrize("tA,tB,M,N,K,acc,bias", [
-    (0, 1, 155, 64, 128, 0, True),            # forward linear, ragged rows
-    (0, 1, 3, 1536, 1024, 0, True),           # modulation projection of 3 molecules
-    (0, 1, 700, 3, 256, 0, False),            # coord_mlp.2: N = 3
-    (0, 1, 5, 1024, 17, 1, True),             # time_mlp.1: K = 17, accumulate
-    (0, 0, 333, 640, 256, 1, False),          # input gradient
-    (1, 0, 256, 64, 50000, 1, False),         # weight gradient, split over the rows
-    (1, 0, 3, 256, 9000, 0, False),
-    (1, 1, 70, 33, 129, 0, True),
+@pytest.mark.parametrize("tA,tB,M,N,K,acc,bias,pad", [
+    (0, 1, 155, 64, 128, 0, True, 0),         # forward linear, ragged rows; pad 0: aligned rows -> the 16-byte load path
+    (0, 1, 3, 1536, 1024, 0, True, 0),        # modulation projection of 3 molecules
+    (0, 1, 700, 3, 256, 0, False, 4),         # coord_mlp.2: N = 3
+    (0, 1, 5, 1024, 17, 1, True, 3),          # time_mlp.1: K = 17, accumulate; pad 3: unaligned rows -> the element-wise path
+    (0, 1, 1187, 256, 68, 0, True, 0),        # K = 68: the last quad of a row is whole, the tile is not
+    (0, 0, 333, 640, 256, 1, False, 0),       # input gradient
+    (0, 0, 333, 640, 256, 1, False, 5),
+    (1, 0, 256, 64, 50000, 1, False, 0),      # weight gradient, split over the rows
+    (1, 0, 3, 256, 9000, 0, False, 1),
+    (1, 0, 252, 64, 1187, 1, False, 0),       # lin_edge0: 252 rows of dW
+    (1, 1, 70, 33, 129, 0, True, 2),
 ])
-def test_train_gemm_matches_float64(tA, tB, M, N, K, acc, bias):
+def test_train_gemm_matches_float64(tA, tB, M, N, K, acc, bias, pad):
     import ctypes
     from jodo_amd import capi
     g = torch.Generator().manual_seed(M + N + K)
-    A = torch.randn((K, M + 5) if tA else (M, K + 3), generator=g)
-    B = torch.randn((N, K + 2) if tB else (K, N + 7), generator=g)
+    r4 = lambda v: (v + 3) // 4 * 4 + pad
+    A = torch.randn((K, r4(M)) if tA else (M, r4(K)), generator=g)
+    B = torch.randn((N, r4(K)) if tB else (K, r4(N)), generator=g)
     C0 = torch.randn(M, N + 4, generator=g)
     bv = torch.randn(N, generator=g) if bias else None
     a = A[:, :M].t() if tA else A[:, :K]
