@@ -55,7 +55,7 @@ struct Bufs {
     float *nh1pre, *nh1, *nh2pre, *nh2, *atom, *x1pre[2], *x1[2], *x2pre[2], *x2[2], *Ep, *posf;
     // scratch shared by all phases
     float *tE_D[3], *tE_De[4], *tE_QK, *tE_rD, *tE_H, *tN_D[4], *tN_QK[2], *tN_rD, *tN_De, *tRow[3], *tE3[3], *tN3[4], *tcatn, *tcate;
-    float *dtau, *dtemb, *dnmod, *demod, *dqmod, *dgm, *tB_T[2], *tB_cD[2], *part, *part2, *splitk;
+    float *dtau, *dtemb, *dnmod, *demod, *dqmod, *dgm, *tB_T[2], *tB_cD[2], *part, *part2, *rowpart, *splitk;
     size_t splitk_floats, part_floats, part2_floats;
 };
 
@@ -121,6 +121,7 @@ void layout(const jodo_train& t, Arena& a, Bufs& b) {
     b.part = a.f(b.part_floats);
     b.part2_floats = (b.part_floats / maxF / 32 + 2) * maxF;
     b.part2 = a.f(b.part2_floats);
+    b.rowpart = a.f(rows * 16);                               // eight (sum, sum of squares) pairs per row
     b.splitk_floats = (size_t)32 << 20;      // 128 MiB of split-K partial tiles at most
     const size_t need = ((rows + 1023) / 1024 + 1) * (size_t)D * (2 * D + 2 * De);
     if (b.splitk_floats > need) b.splitk_floats = need;
@@ -165,7 +166,10 @@ struct Ctx {
     }
     void silu(long n, const float* x, float* y, Drop d) const { JT_LAUNCH(k_silu_fwd, n, s, n, x, y, d); }
     void silu_bwd(long n, const float* x, const float* dy, float* dx, Drop d) const { JT_LAUNCH(k_silu_bwd, n, s, n, x, dy, dx, d); }
-    void stats(long rows, int F, const float* x, float* mean, float* rstd) const { JT_LAUNCH(k_row_stats, rows, s, rows, F, x, mean, rstd); }
+    void stats(long rows, int F, const float* x, float* mean, float* rstd) const {
+        JT_LAUNCH(k_row_part, rows * 8, s, rows, F, x, b.rowpart);
+        JT_LAUNCH(k_row_stats, rows, s, rows, F, x, (const float*)b.rowpart, mean, rstd);
+    }
     void ln_mod(long rows, int F, const float* x, const float* mean, const float* rstd, const int* row_mol, const float* mods, int ldm, int sh, int sc,
                 float* xhat, float* y) const {
         JT_LAUNCH(k_ln_mod_fwd, rows * F, s, rows, F, x, mean, rstd, row_mol, mods, ldm, sh, sc, xhat, y);
@@ -175,7 +179,8 @@ struct Ctx {
                     int ldm, int sh, int sc, float* dmods, float* dx, int acc) const {
         seg(F, seg_off, dy, nullptr, dmods, ldm, sh);
         seg(F, seg_off, dy, xhat, dmods, ldm, sc);
-        JT_LAUNCH(k_ln_bwd_stats, rows, s, rows, F, dy, xhat, row_mol, mods, ldm, sc, b.tRow[0], b.tRow[1]);
+        JT_LAUNCH(k_ln_bwd_part, rows * 8, s, rows, F, dy, xhat, row_mol, mods, ldm, sc, b.rowpart);
+        JT_LAUNCH(k_ln_bwd_stats, rows, s, rows, F, (const float*)b.rowpart, b.tRow[0], b.tRow[1]);
         JT_LAUNCH(k_ln_bwd_apply, rows * F, s, rows, F, dy, xhat, rstd, (const float*)b.tRow[0], (const float*)b.tRow[1], row_mol, mods,
                            ldm, sc, dx, acc);
     }

@@ -134,9 +134,9 @@ void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, in
     const int gx = (N + TN - 1) / TN, gy = (M + TM - 1) / TM;
     int nsplit = 1;
     if (ws && K >= 512 && (tA || (K >= 2048 && (long)gx * gy < 512))) {
-        // the weight-gradient shape (few output tiles, K = every row of the batch): partial sums over 256 rows each — fills the chip
+        // the weight-gradient shape (few output tiles, K = every row of the batch): partial sums over 512 rows each — fills the chip
         // and keeps every fp32 rounding chain short; the partial tiles are added in a fixed order by k_splitk_sum
-        nsplit = (K + 255) / 256;
+        nsplit = (K + 511) / 512;
         const long cap = (long)(ws_floats / ((size_t)M * N));
         if (nsplit > cap) nsplit = (int)cap;
         if (nsplit > 256) nsplit = 256;

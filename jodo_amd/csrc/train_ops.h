@@ -120,17 +120,26 @@ __global__ void k_copy2d(long rows, int F, const float* __restrict__ src, int ld
 }
 
 // ================================================================ LayerNorm + modulate ========================================
-// per-row mean and rstd (biased variance, eps 1e-6; LayerNorm(elementwise_affine=False), mol_gnn.py:234-245, :64)
-__global__ void k_row_stats(long rows, int F, const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ rstd) {
+// per-row mean and rstd (biased variance, eps 1e-6; LayerNorm(elementwise_affine=False), mol_gnn.py:234-245, :64) in two small
+// launches: eight threads per row sum a contiguous eighth each (a wave reads whole cache lines; one thread per row walked 64
+// different lines per load) of d = x - x[row, 0] and d^2 — shifted, so that the one-pass variance does not cancel — and a second
+// launch combines the eight partial sums in double.
+__global__ void k_row_part(long rows, int F, const float* __restrict__ x, float* __restrict__ part) {
+    JT_IDX(rows * 8);
+    const long r = i_ >> 3; const int p = (int)(i_ & 7), w = F / 8;
+    const float* q = x + r * F;
+    const float x0 = q[0];
+    float s = 0.f, s2 = 0.f;
+    for (int f = p * w; f < (p + 1) * w; ++f) { const float d = q[f] - x0; s += d; s2 += d * d; }
+    part[i_ * 2] = s; part[i_ * 2 + 1] = s2;
+}
+__global__ void k_row_stats(long rows, int F, const float* __restrict__ x, const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd) {
     JT_IDX(rows);
-    const float* p = x + i_ * F;
-    float s = 0.f;
-    for (int f = 0; f < F; ++f) s += p[f];
-    const float m = s / (float)F;
-    float v = 0.f;
-    for (int f = 0; f < F; ++f) { const float d = p[f] - m; v += d * d; }
-    mean[i_] = m;
-    rstd[i_] = 1.f / sqrtf(v / (float)F + 1e-6f);
+    double s = 0.0, s2 = 0.0;
+    for (int p = 0; p < 8; ++p) { s += (double)part[(i_ * 8 + p) * 2]; s2 += (double)part[(i_ * 8 + p) * 2 + 1]; }
+    const double md = s / F, var = s2 / F - md * md;
+    mean[i_] = (float)((double)x[i_ * F] + md);
+    rstd[i_] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + 1e-6));
 }
 // xhat = (x - mean) rstd;  y = xhat (1 + sc[mol]) + sh[mol]      (modulate, mol_gnn.py:12-13)
 __global__ void k_ln_mod_fwd(long rows, int F, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -143,15 +152,22 @@ __global__ void k_ln_mod_fwd(long rows, int F, const float* __restrict__ x, cons
     xhat[i_] = xh;
     y[i_] = xh * (1.f + m[sc_off + f]) + m[sh_off + f];
 }
-// backward, pass 1: per row c1 = mean_f(g), c2 = mean_f(g xhat) with g = dy (1 + sc)
-__global__ void k_ln_bwd_stats(long rows, int F, const float* __restrict__ dy, const float* __restrict__ xhat, const int* __restrict__ row_mol,
-                               const float* __restrict__ mods, int ldm, int sc_off, float* __restrict__ c1, float* __restrict__ c2) {
-    JT_IDX(rows);
-    const float* m = mods + (long)row_mol[i_] * ldm + sc_off;
-    const float* d = dy + i_ * F; const float* xh = xhat + i_ * F;
+// backward, pass 1: per row c1 = mean_f(g), c2 = mean_f(g xhat) with g = dy (1 + sc) — eight partial sums per row, then combined
+__global__ void k_ln_bwd_part(long rows, int F, const float* __restrict__ dy, const float* __restrict__ xhat, const int* __restrict__ row_mol,
+                              const float* __restrict__ mods, int ldm, int sc_off, float* __restrict__ part) {
+    JT_IDX(rows * 8);
+    const long r = i_ >> 3; const int p = (int)(i_ & 7), w = F / 8;
+    const float* m = mods + (long)row_mol[r] * ldm + sc_off;
+    const float* d = dy + r * F; const float* xh = xhat + r * F;
     float a = 0.f, b = 0.f;
-    for (int f = 0; f < F; ++f) { const float g = d[f] * (1.f + m[f]); a += g; b += g * xh[f]; }
-    c1[i_] = a / (float)F; c2[i_] = b / (float)F;
+    for (int f = p * w; f < (p + 1) * w; ++f) { const float g = d[f] * (1.f + m[f]); a += g; b += g * xh[f]; }
+    part[i_ * 2] = a; part[i_ * 2 + 1] = b;
+}
+__global__ void k_ln_bwd_stats(long rows, int F, const float* __restrict__ part, float* __restrict__ c1, float* __restrict__ c2) {
+    JT_IDX(rows);
+    double a = 0.0, b = 0.0;
+    for (int p = 0; p < 8; ++p) { a += (double)part[(i_ * 8 + p) * 2]; b += (double)part[(i_ * 8 + p) * 2 + 1]; }
+    c1[i_] = (float)(a / F); c2[i_] = (float)(b / F);
 }
 // pass 2: dx = rstd (g - c1 - xhat c2)         (acc: dx += ...)
 __global__ void k_ln_bwd_apply(long rows, int F, const float* dy, const float* __restrict__ xhat, const float* __restrict__ rstd,

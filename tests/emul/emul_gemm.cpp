@@ -6,7 +6,7 @@ thread_local emu_idx threadIdx, blockIdx;
 thread_local dim3 blockDim, gridDim;
 namespace jt {
 // Mirrors the ROUNDING STRUCTURE of the device kernel so that the CPU suite predicts its accuracy: fp32 fused multiply-adds, four
-// accumulators taken in turn by the k-pairs, split-K partial sums over 256-wide chunks (rounded up to the 32-wide tile) added in order.
+// accumulators taken in turn by the k-pairs, split-K partial sums over 512-wide chunks (rounded up to the 32-wide tile) added in order.
 void gemm(hipStream_t, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
           const float* bias, int acc, float* ws, size_t ws_floats) {
     // debugging aid: products summed in double; value = bit mask of the products it applies to (1 forward, 2 input gradient, 4 weight gradient)
@@ -27,7 +27,7 @@ void gemm(hipStream_t, int tA, int tB, int M, int N, int K, const float* A, int 
     const int gx = (N + 63) / 64, gy = (M + 63) / 64;
     int nsplit = 1;
     if (ws && K >= 512 && (tA || (K >= 2048 && (long)gx * gy < 512))) {
-        nsplit = (K + 255) / 256;
+        nsplit = (K + 511) / 512;
         const long cap = (long)(ws_floats / ((size_t)M * N));
         if (nsplit > cap) nsplit = (int)cap;
         if (nsplit > 256) nsplit = 256;
