@@ -180,6 +180,8 @@ enum jodo_plan_option {
     JODO_OPT_NODE_MIX = 7,        /* 1 (default): when k_node_post runs as full rounds + a remainder launch, the remainder launch also carries
                                      the k_node_ab items and Gram tiles of the strips the full rounds finished (they fill the SIMDs the
                                      remainder's cooperative workgroups leave idle); 0: separate launches */
+    JODO_OPT_HEADS_MIX = 8,       /* 1 (default): under a symmetric pin the node head and the pair form of the edge head share one launch
+                                     (node strips first: the edge head's short items fill the SIMDs the node head's last round leaves idle) */
     JODO_OPT_COUNT
 };
 int jodo_plan_set_option(jodo_plan* plan, int option, int value);

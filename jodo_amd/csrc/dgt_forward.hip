@@ -89,8 +89,14 @@ int launch_embed_nodes(hipStream_t st, const KArgs& A) {
     return JODO_OK;
 }
 // symmetric inputs (device flag): one evaluation per unordered pair, written to both rows; otherwise every dense row
+// merged = 1: pinned symmetric inputs and JODO_OPT_HEADS_MIX — node head and pair edge head share one launch (k_heads_sym)
 template <int D, int NBK>
-int launch_edge_head(hipStream_t st, const KArgs& A) {
+int launch_edge_head(hipStream_t st, const KArgs& A, bool merged) {
+    if (merged) {
+        LAUNCH((wide::k_heads_sym<D, NBK>), (unsigned)(A.pd.n_strips + A.pd.n_ut_pad / 32), 64, A);
+        return JODO_OK;
+    }
+    LAUNCH((wide::k_node_head<D>), A.pd.n_strips, 64, A);
     if (A.pd.n_ut_pad > 0 && A.pin_sym != 2) LAUNCH((wide::k_edge_head<D, NBK, true>), (unsigned)(A.pd.n_ut_pad / 32), 64, A);
     if (A.pin_sym != 1) LAUNCH((wide::k_edge_head<D, NBK, false>), (unsigned)((A.pd.rows + 31) / 32), 64, A);
     return JODO_OK;
@@ -282,20 +288,20 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
     A.layer = nblocks;                             // k_pos_final adds the last block's partial updates if any ran
     LAUNCH(k_pos_final, (p->Nn_pad + 255) / 256, 256, A);
     p->last_pos_buf = cur ^ 1;
-    LAUNCH((wide::k_node_head<D>), p->n_strips, 64, A);
+    const bool heads_mix = A.pin_sym == 1 && A.pd.n_ut_pad > 0 && p->opt[JODO_OPT_HEADS_MIX] != 0;
     switch (d.KEH / 32) {
-        case 3: rc = launch_edge_head<D, 3>(st, A); break;
-        case 4: rc = launch_edge_head<D, 4>(st, A); break;
-        case 5: rc = launch_edge_head<D, 5>(st, A); break;
-        case 6: rc = launch_edge_head<D, 6>(st, A); break;
-        case 7: rc = launch_edge_head<D, 7>(st, A); break;
-        case 8: rc = launch_edge_head<D, 8>(st, A); break;
-        case 9: rc = launch_edge_head<D, 9>(st, A); break;
-        case 10: rc = launch_edge_head<D, 10>(st, A); break;
-        case 11: rc = launch_edge_head<D, 11>(st, A); break;
-        case 12: rc = launch_edge_head<D, 12>(st, A); break;
-        case 13: rc = launch_edge_head<D, 13>(st, A); break;
-        case 15: rc = launch_edge_head<D, 15>(st, A); break;
+        case 3: rc = launch_edge_head<D, 3>(st, A, heads_mix); break;
+        case 4: rc = launch_edge_head<D, 4>(st, A, heads_mix); break;
+        case 5: rc = launch_edge_head<D, 5>(st, A, heads_mix); break;
+        case 6: rc = launch_edge_head<D, 6>(st, A, heads_mix); break;
+        case 7: rc = launch_edge_head<D, 7>(st, A, heads_mix); break;
+        case 8: rc = launch_edge_head<D, 8>(st, A, heads_mix); break;
+        case 9: rc = launch_edge_head<D, 9>(st, A, heads_mix); break;
+        case 10: rc = launch_edge_head<D, 10>(st, A, heads_mix); break;
+        case 11: rc = launch_edge_head<D, 11>(st, A, heads_mix); break;
+        case 12: rc = launch_edge_head<D, 12>(st, A, heads_mix); break;
+        case 13: rc = launch_edge_head<D, 13>(st, A, heads_mix); break;
+        case 15: rc = launch_edge_head<D, 15>(st, A, heads_mix); break;
         default: return jodo_set_error(JODO_ERR_UNSUPPORTED, "edge head width %d", d.KEH);
     }
     if (rc) return rc;

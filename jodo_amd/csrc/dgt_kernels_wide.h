@@ -1065,10 +1065,10 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
 // ------------------------------------------------------------------------------------------------
 // heads
 template <int D>
-__global__ __launch_bounds__(64, 1) void k_node_head(KArgs A) {
+__device__ __forceinline__ void node_head_body(const KArgs& A, int strip) {
     using X = Dim<D>;
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int v = blockIdx.x * 32 + j;
+    const int v = strip * 32 + j;
     const int KNH = A.d.KNH;
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned o1 = (unsigned)(A.wg[JW_NH1_W] * 4), o2 = (unsigned)(A.wg[JW_NH2_W] * 4), o3 = (unsigned)(A.wg[JW_NH3_W] * 4);
@@ -1123,16 +1123,18 @@ __global__ __launch_bounds__(64, 1) void k_node_head(KArgs A) {
         store16(A.apred + (size_t)v * 32 + half * 16, r);
     }
 }
+template <int D>
+__global__ __launch_bounds__(64, 1) void k_node_head(KArgs A) { node_head_body<D>(A, (int)blockIdx.x); }
 
 // SYM: the edge state and the readouts of (a, c) and (c, a) are bit-identical for symmetric inputs, so the head runs once per
 // unordered pair (plan list ut_rows) and writes both rows; the directed form covers asymmetric inputs (device flag).
 template <int D, int NBK, bool SYM>     // NBK = KEH / 32
-__global__ __launch_bounds__(64, 1) void k_edge_head(KArgs A) {
+__device__ __forceinline__ void edge_head_body(const KArgs& A, int blk) {
     if ((A.flags[FLAG_ASYM] != 0) == SYM) return;
     using X = Dim<D>;
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int ur = SYM ? A.pd.ut_rows[((size_t)blockIdx.x * 32 + j) * 2] : 0, um = SYM ? A.pd.ut_rows[((size_t)blockIdx.x * 32 + j) * 2 + 1] : 0;
-    const size_t r = SYM ? (size_t)(ur < 0 ? 0 : ur) : (size_t)blockIdx.x * 32 + j;
+    const int ur = SYM ? A.pd.ut_rows[((size_t)blk * 32 + j) * 2] : 0, um = SYM ? A.pd.ut_rows[((size_t)blk * 32 + j) * 2 + 1] : 0;
+    const size_t r = SYM ? (size_t)(ur < 0 ? 0 : ur) : (size_t)blk * 32 + j;
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned o1 = (unsigned)(A.wg[JW_EH1_W] * 4), o2 = (unsigned)(A.wg[JW_EH2_W] * 4), o3 = (unsigned)(A.wg[JW_EH3_W] * 4);
     WPipe<4> wp;
@@ -1178,6 +1180,18 @@ __global__ __launch_bounds__(64, 1) void k_edge_head(KArgs A) {
             reinterpret_cast<float4*>(A.epred)[r] = make_float4(rr[0], rr[1], rr[2], rr[3]);
         }
     }
+}
+template <int D, int NBK, bool SYM>
+__global__ __launch_bounds__(64, 1) void k_edge_head(KArgs A) { edge_head_body<D, NBK, SYM>(A, (int)blockIdx.x); }
+
+// Both heads in one launch (pinned symmetric inputs: the pair form of the edge head is known to be the one that works).  The node
+// head has one long item per strip — 1 409 at QM9 B = 2500: 1.38 rounds of one-wave items, the second round leaves 639 SIMDs idle
+// for ~100 us — and the edge head tens of thousands of short ones that fill them: node strips first, pair items behind.
+template <int D, int NBK>
+__global__ __launch_bounds__(64, 1) void k_heads_sym(KArgs A) {
+    const int ns = A.pd.n_strips;
+    if ((int)blockIdx.x < ns) node_head_body<D>(A, (int)blockIdx.x);
+    else edge_head_body<D, NBK, true>(A, (int)blockIdx.x - ns);
 }
 
 }  // namespace wide

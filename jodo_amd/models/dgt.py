@@ -290,7 +290,7 @@ class _DGTBase(nn.Module):
         f32 = lambda x: None if x is None else x.detach().to(torch.float32).contiguous()
         xh_, ex_, cx_, cex_, nl_ = f32(xh), f32(edge_x), f32(cond_x), f32(cond_edge_x), f32(noise_level)
         ctx_ = f32(context) if self.conditional else None
-        streams = int(getattr(self, 'n_streams', 1))
+        streams = min(int(getattr(self, 'n_streams', 1)), 4)     # the plan cache holds 8 plans: every sub-batch plan of a call stays alive
         if streams > 1 and B >= 2 * streams:
             return self._forward_split(streams, node_mask, edge_mask, xh_, ex_, cx_, cex_, nl_, ctx_, dev)
         # plan first: building a plan for a new batch re-checks the weight fingerprint (`.data` updates such as the
@@ -364,9 +364,9 @@ class _DGTBase(nn.Module):
     def _split_of(self, node_mask, edge_mask, k):
         """Contiguous split of the batch into k sub-batches of about equal pair work (sum n^2), cached per mask tensor:
         [(lo, hi, node_mask[lo:hi], edge_mask rows of lo..hi)] — the sub-mask tensors are kept so that their plans stay cached."""
-        key = (id(node_mask), k)
+        key = (id(node_mask), id(edge_mask), k)
         ent = self._splits.get(key)
-        if ent is not None and ent[0] is node_mask and ent[1] == node_mask._version:
+        if ent is not None and ent[0] is node_mask and ent[1] == node_mask._version and ent[3] is edge_mask and ent[4] == edge_mask._version:
             return ent[2]
         B, N = node_mask.shape[0], node_mask.shape[1]
         n = node_mask.reshape(B, N).sum(1).round().long().cpu()                 # one sync per new batch
@@ -380,7 +380,7 @@ class _DGTBase(nn.Module):
         parts = [(lo, hi, node_mask[lo:hi], em[lo:hi].reshape((hi - lo) * N * N, -1)) for lo, hi in zip(cuts[:-1], cuts[1:])]
         if len(self._splits) >= 4:
             self._splits.pop(next(iter(self._splits)))
-        self._splits[key] = (node_mask, node_mask._version, parts)
+        self._splits[key] = (node_mask, node_mask._version, parts, edge_mask, edge_mask._version)
         return parts
 
     def _forward_split(self, k, node_mask, edge_mask, xh_, ex_, cx_, cex_, nl_, ctx_, dev):

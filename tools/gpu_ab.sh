@@ -1,12 +1,15 @@
 #!/bin/bash
-# same-box A/B of plan options: bash tools/gpu_ab.sh TAG "3=0" "3=1" ...
-OUT=gpurun_out/${1:-r02k}; mkdir -p $OUT; shift
-timeout 600 python -m pytest tests/test_dgt_gpu.py -m gpu -q -x -k "variants or fixture" 2>&1 | tail -3
-for rep in 1 2; do for o in "$@"; do
-  timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-full-round --breakdown --plan-opt $o > $OUT/ab_${o}_$rep.json 2> $OUT/ab.err
+# A/B of plan options on one box: gpurun -- 'bash tools/gpu_ab.sh qm9 "8=0" "8=1"'   (each argument: a set of --plan-opt values, "-" = defaults)
+W=${1:-qm9}; shift
+OUT=gpurun_out/ab; mkdir -p $OUT
+for rep in 1 2; do
+for opts in "$@"; do
+  args=""; if [ "$opts" != "-" ]; then for o in $opts; do args="$args --plan-opt $o"; done; fi
+  timeout 600 python bench.py --workload $W --steps 40 --warmup 5 --no-cpu-baseline --no-full-round $args > $OUT/last.json 2> $OUT/last.err
   python - <<PY
 import json
-d=json.load(open("$OUT/ab_${o}_$rep.json"))
-print("opt $o rep $rep", round(d["ms_per_step"],3), d["kernel_ms"])
+d = json.load(open("$OUT/last.json")); c = d['roofline']['classes']
+print("$W [$opts] ms/step=%.3f graph=%.3f" % (d['ms_per_step'], (d.get('hip_graph_replay') or {}).get('ms_per_step', 0)), {k: round(v['ms_per_step'], 3) for k, v in c.items()})
 PY
-done; done
+done
+done

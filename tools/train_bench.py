@@ -99,11 +99,50 @@ def run(workload='qm9', batch=0, steps=10, warmup=3, seed=42):
                      'first-correct kernels (train_ops.h), not yet tuned')
 
 
+def cpu_step(workload='qm9', batch=16, steps=2, seed=42, threads=16):
+    """The same optimiser-free step on the host: forward + loss.backward() through the port of the reference's sparse formulation
+    (oracle.forward_faithful under torch.autograd, eval-mode dropout) — what the reference's CPU training step costs, per molecule."""
+    from jodo_amd import configs
+    from jodo_amd.models import get_model_class, deterministic_init_, load_dataset_info, get_node_dist
+    from jodo_amd.sampling import build_masks
+    from oracle import dgt_oracle as O
+    name, info = dict(qm9=('vpsde_qm9_uncond_jodo', 'qm9_with_h'), geom=('vpsde_geom_uncond_jodo', 'geom_with_h_1'))[workload]
+    cfg = configs.get(name)
+    torch.manual_seed(seed)
+    torch.set_num_threads(threads)
+    n_nodes = get_node_dist(load_dataset_info(info)).sample(batch).tolist()
+    model = deterministic_init_(get_model_class(cfg.model.name)(cfg), seed=seed)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    hp = O.Hyper.from_config(cfg)
+    N = max(n_nodes)
+    nm, em = build_masks(n_nodes, N, 'cpu')
+    xh = torch.randn(batch, N, 3 + hp.in_node_dim) * nm
+    ex = torch.randn(batch, N, N, hp.edge_ch)
+    ex = (ex + ex.transpose(1, 2)) * em.reshape(batch, N, N, 1)
+    nl = torch.randn(batch)
+    ts = []
+    for _ in range(steps + 1):
+        t0 = time.perf_counter()
+        ox, oe = O.forward_faithful(sd, hp, xh, nm, em, ex, None, None, nl, None)
+        (ox.square().sum() + oe.square().sum()).backward()
+        ts.append(time.perf_counter() - t0)
+        for v in sd.values():
+            v.grad = None
+    dt = sum(ts[1:]) / steps
+    return dict(batch=batch, threads=threads, s_per_forward_backward=dt, molecules_per_s=batch / dt,
+                note='oracle.forward_faithful + loss.backward() under torch.autograd on the host, one grad-enabled forward and backward')
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--workload', default='qm9')
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--cpu', action='store_true', help='also time the host port of the same forward + backward (small batch)')
     a = ap.parse_args()
-    print(json.dumps(run(a.workload, a.batch, a.steps, a.warmup)))
+    out = run(a.workload, a.batch, a.steps, a.warmup)
+    if a.cpu:
+        out['cpu'] = cpu_step(a.workload)
+        out['gpu_over_cpu_forward_backward'] = (out['batch'] / ((out['forward_ms'] + out['backward_ms']) * 1e-3)) / out['cpu']['molecules_per_s']
+    print(json.dumps(out))
