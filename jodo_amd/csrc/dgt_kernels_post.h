@@ -22,7 +22,17 @@ __global__ void k_pos_final(KArgs A) {
             } else {
                 const int n = A.pd.node_n[v], i = A.pd.node_i[v];
                 const float4* row = reinterpret_cast<const float4*>(A.dposE) + (size_t)A.pd.node_eoff[v] + (size_t)i * n;
-                for (int c = 0; c < n; ++c) {
+                // four rows in flight per step, added in column order (the sum is bit-identical to the one-load-per-iteration loop,
+                // which paid one exposed L2 round trip per neighbour: 15 us per launch at QM9 B = 2500, nine launches per forward)
+                int c = 0;
+                for (; c + 4 <= n; c += 4) {
+                    const float4 d0 = row[c], d1 = row[c + 1], d2 = row[c + 2], d3 = row[c + 3];
+                    if (c != i) { p.x += d0.x; p.y += d0.y; p.z += d0.z; }
+                    if (c + 1 != i) { p.x += d1.x; p.y += d1.y; p.z += d1.z; }
+                    if (c + 2 != i) { p.x += d2.x; p.y += d2.y; p.z += d2.z; }
+                    if (c + 3 != i) { p.x += d3.x; p.y += d3.y; p.z += d3.z; }
+                }
+                for (; c < n; ++c) {
                     if (c == i) continue;
                     const float4 dp = row[c];
                     p.x += dp.x; p.y += dp.y; p.z += dp.z;
