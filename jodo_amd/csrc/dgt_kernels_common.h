@@ -17,6 +17,8 @@ struct KArgs {
     int force_directed;                   // debug: never take the symmetric pair path
     int pin_sym, pin_uni;                 // JODO_OPT_PIN_*: variants the launcher left out (checked against the device flags in k_finalize_nodes)
     int strip0;                           // k_node_post*: first strip of this launch (a layer's strips may be split over two launches)
+    int half_rows;                        // pinned symmetric inputs, no molecule above a group: only the edge row of a pair's EVALUATING lane
+                                          // (pair_of: (i, i + d)) is ever read again, so e / ehid of the mirror row are not written
     int item0, dir_split;                 // pair update: first item of this launch; 1 = two workgroups per item, one direction each
     int mix_nw, ab0, ab1, g0, g1;         // k_node_mix: workgroups in the k_node_postw role; k_node_ab items [ab0, ab1); Gram tiles [g0, g1)
     int rot;                              // JODO_OPT_ROT_STATS and a launch sequence that can use it: under FLAG_UNIFORM_T && !FLAG_ASYM the node

@@ -80,6 +80,10 @@ __global__ __launch_bounds__(64) void k_embed_edges(KArgs A) {
         const int tc = ok ? t : 0;
         const int u = L.noff + tc;
         const size_t r = (size_t)L.eoff + (size_t)L.i * L.n + tc;
+        // half_rows: the state is only kept for the row a pair's evaluating lane reads back, (i, i + d) with the offsets of pair_of()
+        int dd = tc - L.i;
+        if (dd < 0) dd += L.n;
+        const bool wr = ok && (!A.half_rows || (dd != 0 && (2 * dd < L.n || (2 * dd == L.n && 2 * L.i < L.n))));
         const float4 pu = reinterpret_cast<const float4*>(A.cpos)[u];
         const float dx = pc.x - pu.x, dy = pc.y - pu.y, dz = pc.z - pu.z;
         const float d2c = dx * dx + dy * dy + dz * dz;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(64) void k_embed_edges(KArgs A) {
             acc = mfma_block<1>(w + (size_t)(b * (X::KQE + 1) + X::KQE) * 64, ein, acc);
             float rr[16];
             acc_bias(acc, bias + b * 32 + half * 16, rr);
-            if (ok) {
+            if (wr) {
                 store16(A.e + r * X::De + b * 32 + half * 16, rr);
                 store16(A.ehid + r * A.d.KEH + b * 32 + half * 16, rr);
             }
@@ -730,7 +734,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
         }
         if (P.ok && dsel != 1) {
             store_nat<X::NE>(A.e_out + P.rij * X::De, half, en);
-            store_nat<X::NE>(A.e_out + P.rji * X::De, half, en);
+            if (!A.half_rows) store_nat<X::NE>(A.e_out + P.rji * X::De, half, en);
         }
         PT(1);
         // per-node rows of the coord_mlp.0 hoist (own rows do not depend on the pair offset: without an opaque offset LICM
@@ -762,7 +766,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             for (int s = 0; s < 16; ++s) rr[s] = acc[s] + bb[s];
             if (P.ok && dsel != 1 && (half == 0 || A.d.cep == 32)) {
                 store16(A.ehid + P.rij * A.d.KEH + X::De + A.layer * A.d.cep + half * 16, rr);
-                store16(A.ehid + P.rji * A.d.KEH + X::De + A.layer * A.d.cep + half * 16, rr);
+                if (!A.half_rows) store16(A.ehid + P.rji * A.d.KEH + X::De + A.layer * A.d.cep + half * 16, rr);
             }
         }
         PT(2);

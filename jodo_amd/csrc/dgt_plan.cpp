@@ -116,7 +116,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     if (pair_chunk <= 0) pair_chunk = 1;     // measured best on MI355X (QM9 B=2500: 26.7 ms/step vs 27.7 at 2)
     const bool spair_auto = spair_chunk <= 0;
     p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->last_e_buf = 0;
-    p->opt[JODO_OPT_FUSE_NEXT_QKV] = 1; p->opt[JODO_OPT_DIR_SPLIT] = 1; p->opt[JODO_OPT_NODE_POST_WAVES] = 0; p->opt[JODO_OPT_ATTN_VARIANT] = 0; p->opt[JODO_OPT_HEADS_MIX] = 1;
+    p->opt[JODO_OPT_FUSE_NEXT_QKV] = 1; p->opt[JODO_OPT_DIR_SPLIT] = 1; p->opt[JODO_OPT_NODE_POST_WAVES] = 0; p->opt[JODO_OPT_ATTN_VARIANT] = 0; p->opt[JODO_OPT_HEADS_MIX] = 1; p->opt[JODO_OPT_HALF_ROWS] = 1;
     p->opt[JODO_OPT_PIN_SYMMETRIC] = 0; p->opt[JODO_OPT_PIN_UNIFORM_T] = 0; p->opt[JODO_OPT_ROT_STATS] = 1; p->opt[JODO_OPT_NODE_MIX] = 1;
     p->prof_enabled = 0; p->force_directed = 0; p->dbg_timing = nullptr;
 
@@ -339,13 +339,19 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     put(ag_node, &p->off_ag_node); put(ai_group, &p->off_ai_group); put(ai_t0, &p->off_ai_t0); put(ai_t1, &p->off_ai_t1); put(ai_part, &p->off_ai_part);
     put(ad_group, &p->off_ad_group); put(ad_t0, &p->off_ad_t0); put(ad_t1, &p->off_ad_t1); put(ad_part, &p->off_ad_part); put(ad_big, &p->off_ad_big);
     put(anode_parts, &p->off_anode_parts); put(aw_off, &p->off_aw_off);
-    {   // upper-triangle rows of every molecule's dense edge tile + their mirrors: the edge head evaluates a symmetric pair once
+    {   // one row per unordered pair of every molecule's dense edge tile + its mirror: the edge head evaluates a symmetric pair once.
+        // The row is the one the pair kernels' evaluating lane owns — (i, i + d mod n) of the circulant walk, pair_of() in
+        // dgt_kernels_sym.h — so that under JODO_OPT_HALF_ROWS the head reads exactly the rows that were written
         std::vector<int32_t> ut;
         for (int b = 0; b < B; ++b) {
             const int n = orig_n[b];
             const int64_t e0 = orig_eoff[b];
-            for (int a = 0; a < n; ++a)
-                for (int c = a + 1; c < n; ++c) { ut.push_back((int32_t)(e0 + (int64_t)a * n + c)); ut.push_back((int32_t)(e0 + (int64_t)c * n + a)); }
+            for (int i = 0; i < n; ++i)
+                for (int d = 1; 2 * d <= n; ++d) {
+                    if (2 * d == n && 2 * i >= n) continue;
+                    const int j = (i + d) % n;
+                    ut.push_back((int32_t)(e0 + (int64_t)i * n + j)); ut.push_back((int32_t)(e0 + (int64_t)j * n + i));
+                }
         }
         while ((ut.size() / 2) % 32) { ut.push_back(-1); ut.push_back(-1); }
         p->n_ut_pad = (int)(ut.size() / 2);
@@ -520,7 +526,7 @@ extern "C" int jodo_plan_set_option(jodo_plan* p, int option, int value) {
     if (option < 0 || option >= JODO_OPT_COUNT) return jodo_set_error(JODO_ERR_ARG, "plan_set_option: unknown option %d", option);
     if (option == JODO_OPT_NODE_POST_WAVES && value != 0 && value != 1 && value != 2 && value != 4 && value != 12 && value != 14)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: node-post waves per strip must be 0 (auto), 1, 2 or 4");
-    if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT || option == JODO_OPT_NODE_MIX || option == JODO_OPT_HEADS_MIX) && value != 0 && value != 1)
+    if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT || option == JODO_OPT_NODE_MIX || option == JODO_OPT_HEADS_MIX || option == JODO_OPT_HALF_ROWS) && value != 0 && value != 1)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: option %d is a switch (0 or 1), got %d", option, value);
     if (option == JODO_OPT_ROT_STATS && (value < 0 || value > 2))
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: rotated statistics are 0 (off), 1 (on) or 2 (on, uncentred Gram tiles: tests), got %d", value);
