@@ -182,7 +182,7 @@ enum jodo_plan_option {
                                      remainder's cooperative workgroups leave idle); 0: separate launches */
     JODO_OPT_HEADS_MIX = 8,       /* 1 (default): under a symmetric pin the node head and the pair form of the edge head share one launch
                                      (node strips first: the edge head's short items fill the SIMDs the node head's last round leaves idle) */
-    JODO_OPT_HALF_ROWS = 9,       /* 1 (default): under a symmetric pin (and no molecule above an attention group) the embedding and the pair
+    JODO_OPT_HALF_ROWS = 9,       /* 1 (default): under a symmetric pin, for molecules that fit an attention group (n <= 128), the embedding and the pair
                                      update write the edge state and the head inputs only for the row a pair's evaluating lane reads back —
                                      (i, i + d) of the circulant walk — instead of both mirror rows (the workspace copy of e is then half
                                      stale: jodo_debug_fetch(what = 1) is for unpinned calls) */

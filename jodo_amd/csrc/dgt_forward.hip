@@ -338,7 +338,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     for (int i = 0; i < JW_GLOBAL_COUNT; ++i) A.wg[i] = woff[i];
     for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = 0;
     A.mod_base = 0; A.layer = 0; A.force_directed = p->force_directed; A.pin_sym = p->force_directed ? 0 : p->opt[JODO_OPT_PIN_SYMMETRIC];
-    A.half_rows = (A.pin_sym == 1 && !p->has_big && p->n_pitems > 0 && p->opt[JODO_OPT_HALF_ROWS] != 0) ? 1 : 0;
+    A.half_rows = (A.pin_sym == 1 && p->n_pitems > 0 && p->opt[JODO_OPT_HALF_ROWS] != 0) ? 1 : 0;
     A.pin_uni = p->opt[JODO_OPT_PIN_UNIFORM_T]; A.pre_mode = 0; A.strip0 = 0; A.item0 = 0; A.dir_split = 0; A.rot = 0; A.mix_nw = 0; A.ab0 = 0; A.ab1 = 0; A.g0 = 0; A.g1 = 0; A.fuse_next = 0; A.mod_base_next = 0;
     for (int i = 0; i < 6; ++i) A.wbn[i] = 0;
     fill_ws(A, p, workspace);

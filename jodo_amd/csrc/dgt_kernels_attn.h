@@ -44,6 +44,7 @@ namespace jd {
 
 constexpr int ATT_WAVES = 4;
 constexpr int ATT_LANES = 128;
+static_assert(ATT_LANES == PAIR_GROUP_LANES, "group size");
 constexpr float ATT_NEG = -3.0e38f;                    // "no source yet": exp(ATT_NEG - m) == 0 for every real m
 
 template <int D_, bool WQK_, int VAR_ = 0>

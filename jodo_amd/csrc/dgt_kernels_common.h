@@ -17,7 +17,7 @@ struct KArgs {
     int force_directed;                   // debug: never take the symmetric pair path
     int pin_sym, pin_uni;                 // JODO_OPT_PIN_*: variants the launcher left out (checked against the device flags in k_finalize_nodes)
     int strip0;                           // k_node_post*: first strip of this launch (a layer's strips may be split over two launches)
-    int half_rows;                        // pinned symmetric inputs, no molecule above a group: only the edge row of a pair's EVALUATING lane
+    int half_rows;                        // pinned symmetric inputs: of a molecule that fits an attention group only the edge row of a pair's EVALUATING lane
                                           // (pair_of: (i, i + d)) is ever read again, so e / ehid of the mirror row are not written
     int item0, dir_split;                 // pair update: first item of this launch; 1 = two workgroups per item, one direction each
     int mix_nw, ab0, ab1, g0, g1;         // k_node_mix: workgroups in the k_node_postw role; k_node_ab items [ab0, ab1); Gram tiles [g0, g1)
@@ -47,6 +47,11 @@ struct KArgs {
 struct FoldOffs { int64_t c0[16], ine[16]; };      // ine: the right-hand factor of the launch ([e ; G] part of input_lin, its centred copy, or Q^T)
 
 namespace jd {
+
+// atoms of an attention group (dgt_kernels_attn.h ATT_LANES, dgt_plan.cpp G): a molecule above it runs the directed attention items,
+// which read every edge row of that molecule
+constexpr int PAIR_GROUP_LANES = 128;
+
 // the rotated-statistics path is taken by a call iff the launcher allows it and the call has a shared modulation row and symmetric inputs
 __device__ __forceinline__ bool rot_active(const KArgs& A) { return A.rot && A.flags[FLAG_UNIFORM_T] && !A.flags[FLAG_ASYM]; }
 }

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void k_embed_edges(KArgs A) {
         // half_rows: the state is only kept for the row a pair's evaluating lane reads back, (i, i + d) with the offsets of pair_of()
         int dd = tc - L.i;
         if (dd < 0) dd += L.n;
-        const bool wr = ok && (!A.half_rows || (dd != 0 && (2 * dd < L.n || (2 * dd == L.n && 2 * L.i < L.n))));
+        const bool wr = ok && (!A.half_rows || L.n > PAIR_GROUP_LANES || (dd != 0 && (2 * dd < L.n || (2 * dd == L.n && 2 * L.i < L.n))));
         const float4 pu = reinterpret_cast<const float4*>(A.cpos)[u];
         const float dx = pc.x - pu.x, dy = pc.y - pu.y, dz = pc.z - pu.z;
         const float d2c = dx * dx + dy * dy + dz * dz;
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
         }
         if (P.ok && dsel != 1) {
             store_nat<X::NE>(A.e_out + P.rij * X::De, half, en);
-            if (!A.half_rows) store_nat<X::NE>(A.e_out + P.rji * X::De, half, en);
+            if (!A.half_rows || L.n > PAIR_GROUP_LANES) store_nat<X::NE>(A.e_out + P.rji * X::De, half, en);
         }
         PT(1);
         // per-node rows of the coord_mlp.0 hoist (own rows do not depend on the pair offset: without an opaque offset LICM
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             for (int s = 0; s < 16; ++s) rr[s] = acc[s] + bb[s];
             if (P.ok && dsel != 1 && (half == 0 || A.d.cep == 32)) {
                 store16(A.ehid + P.rij * A.d.KEH + X::De + A.layer * A.d.cep + half * 16, rr);
-                if (!A.half_rows) store16(A.ehid + P.rji * A.d.KEH + X::De + A.layer * A.d.cep + half * 16, rr);
+                if (!A.half_rows || L.n > PAIR_GROUP_LANES) store16(A.ehid + P.rji * A.d.KEH + X::De + A.layer * A.d.cep + half * 16, rr);
             }
         }
         PT(2);
