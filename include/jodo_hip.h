@@ -186,6 +186,8 @@ enum jodo_plan_option {
                                      update write the edge state and the head inputs only for the row a pair's evaluating lane reads back —
                                      (i, i + d) of the circulant walk — instead of both mirror rows (the workspace copy of e is then half
                                      stale: jodo_debug_fetch(what = 1) is for unpinned calls) */
+    JODO_OPT_PRE_EMBED = 10,      /* 1 (default; nf 256 tuned kernel set): the edge embedding shares a launch with the first block's q / k / v
+                                     items (k_pre_embed: HBM-write-bound items beside matrix-bound ones); 0: a launch of its own */
     JODO_OPT_COUNT
 };
 int jodo_plan_set_option(jodo_plan* plan, int option, int value);

@@ -102,6 +102,16 @@ int launch_edge_head(hipStream_t st, const KArgs& A, bool merged) {
     return JODO_OK;
 }
 
+// First block only: its q / k / v items and the edge embedding in ONE launch.  The embedding is bound by its HBM writes (edge
+// state + head inputs of every pair), the projections by the matrix pipe, and neither depends on the other: the (strip, piece)
+// items go first, the embedding's items fill the SIMDs their partial last round leaves idle and overlap their stores with the MFMAs.
+__global__ __launch_bounds__(64, 1) void k_pre_embed(KArgs A) {
+    const int npre = A.pd.n_strips * 3;
+    if ((int)blockIdx.x < npre) node_pre_body(A, (int)blockIdx.x);
+    else wide::embed_edges_body<256>(A, (int)blockIdx.x - npre);
+}
+
+
 // One launch for a block's remainder strips (k_node_postw role: NW waves per strip, long items first) and for the fine-grained
 // per-node items that do not depend on them — k_node_ab items and Gram tiles of the strips the preceding full-round k_node_post
 // launch finished, NW per workgroup.  The cooperative remainder workgroups occupy 2 x 385 of 1024 SIMDs for 211 us at QM9
@@ -195,7 +205,9 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
         default: return jodo_set_error(JODO_ERR_UNSUPPORTED, "node input width %d", d.ndp);
     }
     if (rc) return rc;
-    if (p->n_items > 0) LAUNCH((wide::k_embed_edges<D>), p->n_items, 64, A);
+    // (nf = 256 tuned set: the edge embedding shares a launch with the first block's q / k / v items, k_pre_embed below)
+    const bool embed_merged = TUNED && p->n_items > 0 && p->opt[JODO_OPT_PRE_EMBED] != 0 && ((p->max_blocks >= 0 && p->max_blocks < d.L) ? p->max_blocks : d.L) > 0;
+    if (p->n_items > 0 && !embed_merged) LAUNCH((wide::k_embed_edges<D>), p->n_items, 64, A);
     const bool pin_pair = p->opt[JODO_OPT_PIN_SYMMETRIC] == 1 && !p->force_directed, pin_dir = p->opt[JODO_OPT_PIN_SYMMETRIC] == 2 || p->force_directed;
     // shared modulation row + symmetric inputs (device flags; both can be pinned): folded coord_mlp.0 of every block, and with
     // JODO_OPT_ROT_STATS the LayerNorm statistics of equi_update in the rotated basis (A.rot tells the node kernels and k_node_ab)
@@ -233,14 +245,16 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
             if constexpr (TUNED) {
                 if (!fuse_pre) {
                     A.pre_mode = 0;
-                    LAUNCH(k_node_pre, p->n_strips * 3, 64, A);
+                    if (l == 0 && embed_merged) LAUNCH(k_pre_embed, p->n_strips * 3 + p->n_items, 64, A);
+                    else LAUNCH(k_node_pre, p->n_strips * 3, 64, A);
                 } else {
                     // positions entering the block (needs the previous update); the q/k/v projections of this block were
                     // produced by the previous block's k_node_post: they only need h
                     LAUNCH(k_pos_final, (p->Nn_pad + 255) / 256, 256, A);
                     if (l == 0) {
                         A.pre_mode = 1;
-                        LAUNCH(k_node_pre, p->n_strips * 3, 64, A);
+                        if (embed_merged) LAUNCH(k_pre_embed, p->n_strips * 3 + p->n_items, 64, A);
+                        else LAUNCH(k_node_pre, p->n_strips * 3, 64, A);
                     }
                 }
             } else {

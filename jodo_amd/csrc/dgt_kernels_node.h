@@ -14,9 +14,9 @@ namespace jd {
 
 // ------------------------------------------------------------------------------------------------
 // piece 0 / 1 / 2 = q / k / v; piece 0 also advances the positions
-__global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
+__device__ __forceinline__ void node_pre_body(const KArgs& A, int blk) {
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int strip = blockIdx.x / 3, piece = blockIdx.x % 3;
+    const int strip = blk / 3, piece = blk % 3;
     const LaneNode L = lane_node(A, strip, j);
     // positions entering this block: previous positions + the contributions of the previous update
     if (piece == 0 && A.pre_mode == 0) {
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
         store16T(outp, 8, L.v, half, b, r);
     }
 }
-
+__global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) { node_pre_body(A, (int)blockIdx.x); }
 // hh = aggregated attention messages: flash-style merge of the per-item partials of the fused attention kernel
 // (attn_merge, dgt_kernels_attn.h), fixed order
 __device__ __forceinline__ void node_load_hh(const KArgs& A, const LaneNode& L, int half, float (&hh)[128]) {

@@ -61,10 +61,9 @@ __global__ __launch_bounds__(64) void k_embed_nodes(KArgs A) {
 }
 
 template <int D>
-__global__ __launch_bounds__(64) void k_embed_edges(KArgs A) {
+__device__ __forceinline__ void embed_edges_body(const KArgs& A, int it) {
     using X = Dim<D>;
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int it = blockIdx.x;
     const int strip = A.pd.item_strip[it], t0 = A.pd.item_t0[it], t1 = A.pd.item_t1[it];
     const LaneNode L = lane_node(A, strip, j);
     const int ch = A.d.ch;
@@ -121,6 +120,8 @@ __global__ __launch_bounds__(64) void k_embed_edges(KArgs A) {
         if (ok && half == 0) A.eflag[r] = adj2d | (adjsp << 1);
     }
 }
+template <int D>
+__global__ __launch_bounds__(64) void k_embed_edges(KArgs A) { embed_edges_body<D>(A, (int)blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------------
 // node side

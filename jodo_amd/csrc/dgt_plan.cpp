@@ -116,7 +116,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     if (pair_chunk <= 0) pair_chunk = 1;     // measured best on MI355X (QM9 B=2500: 26.7 ms/step vs 27.7 at 2)
     const bool spair_auto = spair_chunk <= 0;
     p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->last_e_buf = 0;
-    p->opt[JODO_OPT_FUSE_NEXT_QKV] = 1; p->opt[JODO_OPT_DIR_SPLIT] = 1; p->opt[JODO_OPT_NODE_POST_WAVES] = 0; p->opt[JODO_OPT_ATTN_VARIANT] = 0; p->opt[JODO_OPT_HEADS_MIX] = 1; p->opt[JODO_OPT_HALF_ROWS] = 1;
+    p->opt[JODO_OPT_FUSE_NEXT_QKV] = 1; p->opt[JODO_OPT_DIR_SPLIT] = 1; p->opt[JODO_OPT_NODE_POST_WAVES] = 0; p->opt[JODO_OPT_ATTN_VARIANT] = 0; p->opt[JODO_OPT_HEADS_MIX] = 1; p->opt[JODO_OPT_HALF_ROWS] = 1; p->opt[JODO_OPT_PRE_EMBED] = 1;
     p->opt[JODO_OPT_PIN_SYMMETRIC] = 0; p->opt[JODO_OPT_PIN_UNIFORM_T] = 0; p->opt[JODO_OPT_ROT_STATS] = 1; p->opt[JODO_OPT_NODE_MIX] = 1;
     p->prof_enabled = 0; p->force_directed = 0; p->dbg_timing = nullptr;
 
@@ -462,7 +462,8 @@ extern "C" int jodo_plan_work(const jodo_plan* p, int uniform_t, int symmetric, 
     double dir_iters = 0, pair_iters = 0;                 // wave iterations of the directed / pair item lists
     for (int i = 0; i < p->n_items; ++i) dir_iters += dsc[p->off_item_t1 + i] - dsc[p->off_item_t0 + i];
     for (int i = 0; i < p->n_pitems; ++i) pair_iters += dsc[p->off_pitem_t1 + i] - dsc[p->off_pitem_t0 + i];
-    cls[JODO_PROF_PROLOGUE] += dir_iters * proj(De, d.einp + De);                       // k_embed_edges: every dense row
+    // k_embed_edges: every dense row; under JODO_OPT_PRE_EMBED (tuned set) it runs inside the first block's node-pre launch
+    cls[(tuned && p->opt[JODO_OPT_PRE_EMBED] != 0 && L > 0) ? JODO_PROF_NODE_PRE : JODO_PROF_PROLOGUE] += dir_iters * proj(De, d.einp + De);
     // per block
     const int nqb = tuned ? 8 : d.SH;                                                    // 32-row blocks of q / k / lin_edge0
     const double qkv = 2.0 * nqb * (D / 2) + proj(D, D);
@@ -526,7 +527,7 @@ extern "C" int jodo_plan_set_option(jodo_plan* p, int option, int value) {
     if (option < 0 || option >= JODO_OPT_COUNT) return jodo_set_error(JODO_ERR_ARG, "plan_set_option: unknown option %d", option);
     if (option == JODO_OPT_NODE_POST_WAVES && value != 0 && value != 1 && value != 2 && value != 4 && value != 12 && value != 14)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: node-post waves per strip must be 0 (auto), 1, 2 or 4");
-    if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT || option == JODO_OPT_NODE_MIX || option == JODO_OPT_HEADS_MIX || option == JODO_OPT_HALF_ROWS) && value != 0 && value != 1)
+    if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT || option == JODO_OPT_NODE_MIX || option == JODO_OPT_HEADS_MIX || option == JODO_OPT_HALF_ROWS || option == JODO_OPT_PRE_EMBED) && value != 0 && value != 1)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: option %d is a switch (0 or 1), got %d", option, value);
     if (option == JODO_OPT_ROT_STATS && (value < 0 || value > 2))
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: rotated statistics are 0 (off), 1 (on) or 2 (on, uncentred Gram tiles: tests), got %d", value);

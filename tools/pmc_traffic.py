@@ -29,7 +29,7 @@ CLASSES = [                      # (class name, regex on the kernel name)
     ('edge_msgs', r'k_edge_msgs'),
     ('softmax', r'k_softmax'),
     ('node_post', r'k_node_post|k_node_ab|k_node_gram|k_node_mix'),
-    ('node_pre', r'k_node_pre'),
+    ('node_pre', r'k_node_pre|k_pre_embed'),
 ]
 
 

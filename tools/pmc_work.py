@@ -12,7 +12,7 @@ import sys
 from collections import defaultdict
 
 CLASSES = [('edge_update', r'k_edge_update'), ('edge_attn', r'k_edge_attn'), ('node_post', r'k_node_post|k_node_ab|k_node_gram|k_node_mix'),
-           ('node_pre', r'k_node_pre'), ('epilogue', r'k_node_head|k_edge_head|k_heads_sym'),
+           ('node_pre', r'k_node_pre|k_pre_embed'), ('epilogue', r'k_node_head|k_edge_head|k_heads_sym'),
            ('prologue', r'k_rowgemm|k_embed_nodes|k_embed_edges|k_time1|k_cond1|k_fold_coord')]
 
 
