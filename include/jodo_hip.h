@@ -188,6 +188,8 @@ enum jodo_plan_option {
                                      stale: jodo_debug_fetch(what = 1) is for unpinned calls) */
     JODO_OPT_PRE_EMBED = 10,      /* 1 (default; nf 256 tuned kernel set): the edge embedding shares a launch with the first block's q / k / v
                                      items (k_pre_embed: HBM-write-bound items beside matrix-bound ones); 0: a launch of its own */
+    JODO_OPT_AB_PRE = 11,         /* 1 (default; nf 256 tuned kernel set, fewer than 1024 node strips): the next block's q / k / v items share
+                                     the launch of this block's k_node_ab items and Gram tiles (k_node_ab_pre); 0: a k_node_pre launch per block */
     JODO_OPT_COUNT
 };
 int jodo_plan_set_option(jodo_plan* plan, int option, int value);

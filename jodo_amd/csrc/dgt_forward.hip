@@ -107,10 +107,23 @@ int launch_edge_head(hipStream_t st, const KArgs& A, bool merged) {
 // items go first, the embedding's items fill the SIMDs their partial last round leaves idle and overlap their stores with the MFMAs.
 __global__ __launch_bounds__(64, 1) void k_pre_embed(KArgs A) {
     const int npre = A.pd.n_strips * 3;
-    if ((int)blockIdx.x < npre) node_pre_body(A, (int)blockIdx.x);
+    if ((int)blockIdx.x < npre) node_pre_body<false>(A, (int)blockIdx.x);
     else wide::embed_edges_body<256>(A, (int)blockIdx.x - npre);
 }
 
+
+// Fewer than 1 024 strips (GEOM B = 512, conditional B = 1 250): k_node_post cannot also produce the next block's q / k / v (its
+// single round is the critical path), and as launches of their own the 3 n_strips q / k / v items and the 2 n_strips k_node_ab items
+// each end in a sparsely filled round (2 130 -> 3 rounds, 1 420 -> 2 rounds at 710 strips).  They are independent — the next block's
+// q / k / v need h', k_node_ab needs W_row h' / W_col h', both written by k_node_post — so one launch carries both plus the Gram
+// tiles: 3 550 items -> 4 rounds instead of 5.  A.ab1 - A.ab0 items of k_node_ab, A.g1 - A.g0 tiles, A.mix_nw = number of next-pre items.
+__global__ __launch_bounds__(64, 1) void k_node_ab_pre(KArgs A) {
+    const int npre = A.mix_nw, nab = A.ab1 - A.ab0;
+    const int b = (int)blockIdx.x;
+    if (b < npre) node_pre_body<true>(A, b);
+    else if (b < npre + nab) wide::node_ab_body<256>(A, A.ab0 + b - npre);
+    else wide::node_gram_body<256>(A, A.g0 + b - npre - nab);
+}
 
 // One launch for a block's remainder strips (k_node_postw role: NW waves per strip, long items first) and for the fine-grained
 // per-node items that do not depend on them — k_node_ab items and Gram tiles of the strips the preceding full-round k_node_post
@@ -137,7 +150,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_node_mix(KArgs A) {
 // 1.7 -> 0.75 ms/step with 4 waves; all 1409 strips with 2 / 4 waves 3.7 / 4.1 vs 3.6 ms/step with 1.
 // with_ab: the pair path runs, so k_node_ab (and with A.rot the Gram tiles) follow — issued here, merged with the remainder launch
 // where that pays (JODO_OPT_NODE_MIX)
-int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A, bool with_ab) {
+int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A, bool with_ab, bool next_pre) {
     const DgtDims& d = p->dims;
     const int force = p->opt[JODO_OPT_NODE_POST_WAVES];                      // 0 = automatic
     const bool rem_only = force >= 10;                                       // 12 / 14: automatic split, 2 / 4 waves for the remainder
@@ -177,6 +190,13 @@ int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A, bool with_ab) {
         else { if (d.r == 2) LAUNCH((k_node_postw<2, 4>), rem, 256, A); else LAUNCH((k_node_postw<4, 4>), rem, 256, A); }
     }
     A.strip0 = 0;
+    if (next_pre) {                                  // (with or without the k_node_ab items: the next block's q / k / v ride along)
+        A.mix_nw = 3 * p->n_strips;
+        if (!with_ab) { A.ab1 = A.ab0; A.g1 = A.g0; }
+        LAUNCH(k_node_ab_pre, A.mix_nw + (A.ab1 - A.ab0) + (A.g1 - A.g0), 64, A);
+        A.mix_nw = 0;
+        return JODO_OK;
+    }
     if (with_ab) {
         LAUNCH((wide::k_node_ab<256>), p->n_strips * 2, 64, A);
         if (A.rot && p->n_gtiles > 0) LAUNCH((wide::k_node_gram<256>), p->n_gtiles, 64, A);
@@ -234,6 +254,8 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
     // strips: 23.31 -> 23.18 ms/step).  With fewer strips the separate kernel's 3x finer items fill the chip better
     // (GEOM B = 512, 710 strips: fused 35.1 vs 34.6 ms/step), so it stays separate there.
     const bool fuse_pre = TUNED && p->opt[JODO_OPT_FUSE_NEXT_QKV] != 0 && nblocks > 1 && p->n_strips >= 1024;
+    // below 1 024 strips the next block's q / k / v items ride in the launch of this block's k_node_ab items (k_node_ab_pre)
+    const bool ab_pre = TUNED && !fuse_pre && p->opt[JODO_OPT_AB_PRE] != 0 && nblocks > 1 && p->n_strips < 1024 && p->opt[JODO_OPT_NODE_POST_WAVES] == 0;
     int cur = 0;                                   // posbuf[cur] holds the positions entering the block
     for (int l = 0; l < nblocks; ++l) {
         A.layer = l;
@@ -243,7 +265,7 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
         {
             ProfScope ps(p, st, JODO_PROF_NODE_PRE);
             if constexpr (TUNED) {
-                if (!fuse_pre) {
+                if (!fuse_pre && !ab_pre) {
                     A.pre_mode = 0;
                     if (l == 0 && embed_merged) LAUNCH(k_pre_embed, p->n_strips * 3 + p->n_items, 64, A);
                     else LAUNCH(k_node_pre, p->n_strips * 3, 64, A);
@@ -273,13 +295,14 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
             ProfScope ps(p, st, JODO_PROF_NODE_POST);
             if constexpr (TUNED) {
                 A.fuse_next = (fuse_pre && l + 1 < nblocks) ? 1 : 0;
-                if (A.fuse_next) {
+                const bool next_pre = ab_pre && l + 1 < nblocks;
+                if (A.fuse_next || next_pre) {
                     static const int slots[6] = {JB_WQ, JB_BQ, JB_WK, JB_BK, JB_WV, JB_BV};
                     for (int i = 0; i < 6; ++i) A.wbn[i] = woff[JW_GLOBAL_COUNT + (l + 1) * JB_BLOCK_COUNT + slots[i]];
                     A.mod_base_next = 32 + (int64_t)(l + 1) * d.MB;
                 }
                 // (+ the per-node part of coord_mlp.0 pushed through the LayerNorm and the Gram tiles, dgt_kernels_wide.h)
-                rc = launch_node_post_256(p, st, A, p->n_pitems > 0 && !pin_dir);
+                rc = launch_node_post_256(p, st, A, p->n_pitems > 0 && !pin_dir, next_pre);
                 if (rc) return rc;
             } else {
                 if (d.r == 2) LAUNCH((wide::k_node_post<D, 2>), p->n_strips, 64, A); else LAUNCH((wide::k_node_post<D, 4>), p->n_strips, 64, A);

@@ -14,12 +14,15 @@ namespace jd {
 
 // ------------------------------------------------------------------------------------------------
 // piece 0 / 1 / 2 = q / k / v; piece 0 also advances the positions
+// NEXT: the items of the FOLLOWING block (weights A.wbn, modulation row A.mod_base_next; h already holds that block's input),
+// issued from the launch that carries this block's k_node_ab items (k_node_ab_pre, dgt_forward.hip); positions are not touched
+template <bool NEXT = false>
 __device__ __forceinline__ void node_pre_body(const KArgs& A, int blk) {
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
     const int strip = blk / 3, piece = blk % 3;
     const LaneNode L = lane_node(A, strip, j);
     // positions entering this block: previous positions + the contributions of the previous update
-    if (piece == 0 && A.pre_mode == 0) {
+    if (!NEXT && piece == 0 && A.pre_mode == 0) {
         float4 p = reinterpret_cast<const float4*>(A.pos_in)[L.v];
         if (A.layer > 0) {
             if (A.flags[FLAG_ASYM]) {
@@ -39,14 +42,14 @@ __device__ __forceinline__ void node_pre_body(const KArgs& A, int blk) {
         }
         if (half == 0) reinterpret_cast<float4*>(A.pos_out)[L.v] = p;
     }
-    const float* mr = mod_row(A, L.b) + A.mod_base;          // node chunks: ns1, nc1, ng1, ns2, nc2, ng2
+    const float* mr = mod_row(A, L.b) + (NEXT ? A.mod_base_next : A.mod_base);          // node chunks: ns1, nc1, ng1, ns2, nc2, ng2
     float hx[128];
     load_nat<8>(A.h + (size_t)L.v * 256, half, hx);
     layer_norm<128>(hx);
     modulate<8>(hx, mr, mr + 256, half);
     const WSrc ws = make_wsrc(A.W, lane);
-    const unsigned woff = (unsigned)(A.wb[piece == 0 ? JB_WQ : (piece == 1 ? JB_WK : JB_WV)] * 4);
-    const float* bias = A.W + A.wb[piece == 0 ? JB_BQ : (piece == 1 ? JB_BK : JB_BV)];
+    const unsigned woff = (unsigned)((NEXT ? A.wbn[2 * piece] : A.wb[piece == 0 ? JB_WQ : (piece == 1 ? JB_WK : JB_WV)]) * 4);
+    const float* bias = A.W + (NEXT ? A.wbn[2 * piece + 1] : A.wb[piece == 0 ? JB_BQ : (piece == 1 ? JB_BK : JB_BV)]);
     float* outp = piece == 0 ? A.q : (piece == 1 ? A.k : A.v);
     WPipe<8> wp;
     wpipe_prime(wp, ws, woff);
@@ -62,7 +65,7 @@ __device__ __forceinline__ void node_pre_body(const KArgs& A, int blk) {
         store16T(outp, 8, L.v, half, b, r);
     }
 }
-__global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) { node_pre_body(A, (int)blockIdx.x); }
+__global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) { node_pre_body<false>(A, (int)blockIdx.x); }
 // hh = aggregated attention messages: flash-style merge of the per-item partials of the fused attention kernel
 // (attn_merge, dgt_kernels_attn.h), fixed order
 __device__ __forceinline__ void node_load_hh(const KArgs& A, const LaneNode& L, int half, float (&hh)[128]) {

@@ -116,7 +116,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     if (pair_chunk <= 0) pair_chunk = 1;     // measured best on MI355X (QM9 B=2500: 26.7 ms/step vs 27.7 at 2)
     const bool spair_auto = spair_chunk <= 0;
     p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->last_e_buf = 0;
-    p->opt[JODO_OPT_FUSE_NEXT_QKV] = 1; p->opt[JODO_OPT_DIR_SPLIT] = 1; p->opt[JODO_OPT_NODE_POST_WAVES] = 0; p->opt[JODO_OPT_ATTN_VARIANT] = 0; p->opt[JODO_OPT_HEADS_MIX] = 1; p->opt[JODO_OPT_HALF_ROWS] = 1; p->opt[JODO_OPT_PRE_EMBED] = 1;
+    p->opt[JODO_OPT_FUSE_NEXT_QKV] = 1; p->opt[JODO_OPT_DIR_SPLIT] = 1; p->opt[JODO_OPT_NODE_POST_WAVES] = 0; p->opt[JODO_OPT_ATTN_VARIANT] = 0; p->opt[JODO_OPT_HEADS_MIX] = 1; p->opt[JODO_OPT_HALF_ROWS] = 1; p->opt[JODO_OPT_PRE_EMBED] = 1; p->opt[JODO_OPT_AB_PRE] = 1;
     p->opt[JODO_OPT_PIN_SYMMETRIC] = 0; p->opt[JODO_OPT_PIN_UNIFORM_T] = 0; p->opt[JODO_OPT_ROT_STATS] = 1; p->opt[JODO_OPT_NODE_MIX] = 1;
     p->prof_enabled = 0; p->force_directed = 0; p->dbg_timing = nullptr;
 
@@ -468,8 +468,10 @@ extern "C" int jodo_plan_work(const jodo_plan* p, int uniform_t, int symmetric, 
     const int nqb = tuned ? 8 : d.SH;                                                    // 32-row blocks of q / k / lin_edge0
     const double qkv = 2.0 * nqb * (D / 2) + proj(D, D);
     const bool fuse_pre = tuned && p->opt[JODO_OPT_FUSE_NEXT_QKV] != 0 && L > 1 && p->n_strips >= 1024;
-    cls[JODO_PROF_NODE_PRE] += strips * qkv * (fuse_pre ? 1 : L);
-    if (fuse_pre) cls[JODO_PROF_NODE_POST] += strips * qkv * (L - 1);
+    // (k_node_ab_pre: below 1024 strips the following block's q / k / v items run in the node-post bracket as well)
+    const bool ab_pre = tuned && !fuse_pre && p->opt[JODO_OPT_AB_PRE] != 0 && L > 1 && p->n_strips < 1024 && p->opt[JODO_OPT_NODE_POST_WAVES] == 0;
+    cls[JODO_PROF_NODE_PRE] += strips * qkv * ((fuse_pre || ab_pre) ? 1 : L);
+    if (fuse_pre || ab_pre) cls[JODO_PROF_NODE_POST] += strips * qkv * (L - 1);
     cls[JODO_PROF_NODE_POST] += L * strips * (proj(De, D) + proj(r * D, D) + proj(D, r * D) + 2 * proj(D, D) + proj(d.cnp, D));
     const bool hoist = sym && (D == 256 || uniform_t);                                  // coord_mlp.0 pushed through the LayerNorm
     if (p->n_pitems > 0 && (D == 256 || uniform_t)) cls[JODO_PROF_NODE_POST] += L * strips * 2 * proj(D, D);      // k_node_ab
@@ -527,7 +529,7 @@ extern "C" int jodo_plan_set_option(jodo_plan* p, int option, int value) {
     if (option < 0 || option >= JODO_OPT_COUNT) return jodo_set_error(JODO_ERR_ARG, "plan_set_option: unknown option %d", option);
     if (option == JODO_OPT_NODE_POST_WAVES && value != 0 && value != 1 && value != 2 && value != 4 && value != 12 && value != 14)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: node-post waves per strip must be 0 (auto), 1, 2 or 4");
-    if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT || option == JODO_OPT_NODE_MIX || option == JODO_OPT_HEADS_MIX || option == JODO_OPT_HALF_ROWS || option == JODO_OPT_PRE_EMBED) && value != 0 && value != 1)
+    if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT || option == JODO_OPT_NODE_MIX || option == JODO_OPT_HEADS_MIX || option == JODO_OPT_HALF_ROWS || option == JODO_OPT_PRE_EMBED || option == JODO_OPT_AB_PRE) && value != 0 && value != 1)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: option %d is a switch (0 or 1), got %d", option, value);
     if (option == JODO_OPT_ROT_STATS && (value < 0 || value > 2))
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: rotated statistics are 0 (off), 1 (on) or 2 (on, uncentred Gram tiles: tests), got %d", value);

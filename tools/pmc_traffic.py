@@ -28,7 +28,7 @@ CLASSES = [                      # (class name, regex on the kernel name)
     ('edge_scores', r'k_edge_scores'),
     ('edge_msgs', r'k_edge_msgs'),
     ('softmax', r'k_softmax'),
-    ('node_post', r'k_node_post|k_node_ab|k_node_gram|k_node_mix'),
+    ('node_post', r'k_node_post|k_node_ab|k_node_gram|k_node_mix|k_node_ab_pre'),
     ('node_pre', r'k_node_pre|k_pre_embed'),
 ]
 

@@ -11,7 +11,7 @@ import re
 import sys
 from collections import defaultdict
 
-CLASSES = [('edge_update', r'k_edge_update'), ('edge_attn', r'k_edge_attn'), ('node_post', r'k_node_post|k_node_ab|k_node_gram|k_node_mix'),
+CLASSES = [('edge_update', r'k_edge_update'), ('edge_attn', r'k_edge_attn'), ('node_post', r'k_node_post|k_node_ab|k_node_gram|k_node_mix|k_node_ab_pre'),
            ('node_pre', r'k_node_pre|k_pre_embed'), ('epilogue', r'k_node_head|k_edge_head|k_heads_sym'),
            ('prologue', r'k_rowgemm|k_embed_nodes|k_embed_edges|k_time1|k_cond1|k_fold_coord')]
 
