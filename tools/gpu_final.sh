@@ -6,11 +6,11 @@ timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -30 > $OUT/pytest_gpu.
 cp gpurun_out/parity_errors.jsonl $OUT/ 2>/dev/null
 timeout 900 python bench.py > $OUT/bench_qm9.json 2> $OUT/bench_qm9.err; cut -c1-260 $OUT/bench_qm9.json
 for w in geom geom384 cond; do
-  timeout 900 python bench.py --workload $w --steps 30 --warmup 5 --no-cpu-baseline --breakdown > $OUT/bench_${w}_breakdown.json 2> $OUT/bench_$w.err
+  timeout 900 python bench.py --workload $w --steps 40 --warmup 5 --no-cpu-baseline > $OUT/bench_${w}.json 2> $OUT/bench_$w.err
   python - <<PY
 import json
-d = json.load(open("$OUT/bench_${w}_breakdown.json"))
-print("$w ms/step=%.3f graph=%.3f whole=%.3f dom=%s frac=%.3f" % (d['ms_per_step'], (d.get('hip_graph_replay') or {}).get('ms_per_step', 0), d['roofline']['whole_step_frac'], d['roofline']['launch_class'], d['roofline']['frac']), d['kernel_ms'])
+d = json.load(open("$OUT/bench_${w}.json"))
+print("$w ms/step=%.3f graph=%.3f whole=%.3f dom=%s frac=%.3f" % (d['ms_per_step'], (d.get('hip_graph_replay') or {}).get('ms_per_step', 0), d['roofline']['whole_step_frac'], d['roofline']['launch_class'], d['roofline']['frac']), {k: round(v['ms_per_step'], 3) for k, v in d['roofline']['classes'].items()})
 PY
 done
 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_torchrun_raw.txt 2> $OUT/bench_torchrun.err
