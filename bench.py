@@ -108,7 +108,7 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(seed=42, steps=50, batch=64, config2_batch=2500):
+def cpu_baseline(seed=42, steps=50, batch=64, config2_batch=2500, config2_steps=2):
     """BASELINE config 1 in full: vpsde_qm9_uncond_jodo, batch 64, 50 ancestral steps on the host CPU with the
     port of the reference's path (jodo_amd's host sampler driving oracle.forward_faithful, the op-for-op mirror of
     the reference's sparse formulation; the reference itself cannot travel to the GPU box).  Same procedure as
@@ -165,7 +165,7 @@ def cpu_baseline(seed=42, steps=50, batch=64, config2_batch=2500):
         wall = time.perf_counter() - t0
     assert bool(torch.isfinite(x_mean).all())
     # config 2's own batch on the host as well — B = 2500 molecules, up to 3 denoise steps of the same port
-    # (first-step + self-conditioned evaluations), bounded at ~3 minutes; a 1000-step round is extrapolated from the per-step time
+    # (first-step + self-conditioned evaluations; 2 by default, --cpu-config2-steps 3 for SURVEY.md 8d's three); a 1000-step round is extrapolated from the per-step time
     config2 = None
     try:
         torch.manual_seed(seed)
@@ -179,11 +179,11 @@ def cpu_baseline(seed=42, steps=50, batch=64, config2_batch=2500):
         per_step = []
         with torch.no_grad():
             st2 = smp2.init_state(z2, ez2)
-            for i in range(3):
+            for i in range(config2_steps):
                 t0 = time.perf_counter()
                 st2 = smp2.step(Port(), i, st2, nm2, em2, None)
                 per_step.append(time.perf_counter() - t0)
-                if sum(per_step) > 130.0:
+                if sum(per_step) + per_step[-1] > 75.0 * config2_steps:      # keeps the default run within a few minutes on a slow host
                     break
         s2 = sum(per_step) / len(per_step)
         config2 = dict(batch=b2, steps_timed=len(per_step), s_per_step=s2, seconds_each=per_step, value=b2 / (s2 * SAMPLING_STEPS),
@@ -277,6 +277,8 @@ def main():
     ap.add_argument('--no-pin', action='store_true', help='keep launching every kernel variant (device flags pick; experiments)')
     ap.add_argument('--plan-opt', action='append', default=[], help='jodo_plan_option=value (experiments), e.g. 3=0')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-config2-steps', type=int, default=2,
+                    help='denoise steps of the host port at B = 2500 (about a minute each; profiles/r04_bench_qm9.json was taken with 3)')
     ap.add_argument('--no-full-round', action='store_true', help='skip the end-to-end 1000-step round')
     ap.add_argument('--full-round', action='store_true', help='run the end-to-end round for workloads other than qm9 too')
     ap.add_argument('--breakdown', action='store_true',
@@ -611,7 +613,7 @@ def main():
         if args.breakdown:
             print(json.dumps(per_class), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(cfg.seed)
+            out['cpu_baseline'] = cpu_baseline(cfg.seed, config2_steps=args.cpu_config2_steps)
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
