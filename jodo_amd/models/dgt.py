@@ -307,8 +307,9 @@ class _DGTBase(nn.Module):
 
     # -- training path ---------------------------------------------------------------------------
     def _train_engine(self, node_mask, edge_mask, device):
-        """One TrainEngine (jodo_train handle + device tables + activation workspace) per batch of atom counts, keyed by the
-        counts themselves: data loaders build new mask tensors every step, equal shapes recur."""
+        """One TrainEngine (jodo_train handle + device tables) per batch of atom counts, keyed by the counts themselves — data
+        loaders build new mask tensors every step, equal shapes recur; all of them share ONE activation workspace, grown to the
+        largest batch seen (the backward of a forward must run before the module's next training-path forward)."""
         from ..train import TrainEngine
         B, N = node_mask.shape[0], node_mask.shape[1]
         nm = node_mask.reshape(B, N)
@@ -326,8 +327,9 @@ class _DGTBase(nn.Module):
         eng = cache.pop(key, None)
         if eng is None:
             named = [(k, tuple(v.shape)) for k, v in self.state_dict().items()]
-            eng = TrainEngine(self._cfg(), n_host, N, named, device)
-            while len(cache) >= 4:                              # bounded: a workspace holds every activation of a batch
+            pool = self.__dict__.setdefault('_train_pool', {'buf': None, 'stamp': 0})     # one activation workspace per module
+            eng = TrainEngine(self._cfg(), n_host, N, named, device, pool=pool)
+            while len(cache) >= 16:                             # handles are small (index tables); the workspace is shared
                 cache.pop(next(iter(cache)))
         cache[key] = eng                                        # most recently used last
         return eng

@@ -75,7 +75,7 @@ class TrainEngine:
     drives the host-emulation build of the same sources (tests/emul/) with host tensors; the product path (models/dgt.py) never
     passes them and always runs libjodo_hip.so on the current HIP stream."""
 
-    def __init__(self, cfg_struct, n_nodes, N, named_shapes, device, lib=None, stream_ptr=None):
+    def __init__(self, cfg_struct, n_nodes, N, named_shapes, device, lib=None, stream_ptr=None, pool=None):
         self.L = lib if lib is not None else capi.lib()
         self._check = capi.check if lib is None else self._check_foreign
         self._stream = stream_ptr if stream_ptr is not None else capi.current_stream_ptr
@@ -98,7 +98,11 @@ class TrainEngine:
         self.L.jodo_train_desc_bytes.argtypes = [ctypes.c_void_p]
         self.L.jodo_train_workspace_bytes.argtypes = [ctypes.c_void_p]
         self.desc = torch.empty(self.L.jodo_train_desc_bytes(self.handle), dtype=torch.uint8, device=device)
-        self.ws = torch.zeros(self.L.jodo_train_workspace_bytes(self.handle), dtype=torch.uint8, device=device)
+        # The activation workspace (2.6 GB at QM9 batch 128) is shared by every engine of a module through `pool`: data loaders
+        # produce a new set of atom counts every step, so handles come and go while one buffer, grown to the largest request,
+        # serves them all.  pool['stamp'] names the forward whose activations the buffer holds.
+        self.ws_bytes = int(self.L.jodo_train_workspace_bytes(self.handle))
+        self.pool = pool if pool is not None else {'buf': None, 'stamp': 0}
         self._check(self.L.jodo_train_upload(self.handle, capi.ptr(self.desc), self._stream()), 'jodo_train_upload')
         self.flags = torch.zeros(8, dtype=torch.int32, device=device)
 
@@ -122,19 +126,24 @@ class TrainEngine:
         """params: contiguous float32 tensors in the order of `named_shapes`.  Returns (out_xh, out_edge); the activations stay
         in self.ws until the next forward."""
         assert len(params) == self.n_params
-        self.stamp = getattr(self, 'stamp', 0) + 1              # the workspace now belongs to this forward
+        pool = self.pool
+        if pool['buf'] is None or pool['buf'].numel() < self.ws_bytes or pool['buf'].device != xh.device:
+            pool['buf'] = None                                   # release before growing
+            pool['buf'] = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=xh.device)
+        pool['stamp'] += 1                                       # the workspace now belongs to this forward
+        self.stamp = pool['stamp']
         out_x, out_e = torch.empty_like(xh), torch.empty_like(edge_x)
         self._check(self.L.jodo_train_forward(
             self.handle, capi.ptr(self.desc), self._ptrs(params), self.n_params, capi.ptr(xh), capi.ptr(edge_x), capi.ptr(cond_x),
             capi.ptr(cond_edge_x), capi.ptr(noise_level), capi.ptr(context), ctypes.c_float(dropout_p), ctypes.c_uint64(seed),
-            capi.ptr(out_x), capi.ptr(out_e), capi.ptr(self.flags), capi.ptr(self.ws), self._stream()), 'jodo_train_forward')
+            capi.ptr(out_x), capi.ptr(out_e), capi.ptr(self.flags), capi.ptr(pool['buf']), self._stream()), 'jodo_train_forward')
         return out_x, out_e
 
     def backward(self, params, noise_level, d_out_x, d_out_e, dropout_p, seed):
         grads = [torch.empty_like(p) for p in params]
         self._check(self.L.jodo_train_backward(
             self.handle, capi.ptr(self.desc), self._ptrs(params), self._ptrs(grads), self.n_params, capi.ptr(noise_level),
-            capi.ptr(d_out_x), capi.ptr(d_out_e), ctypes.c_float(dropout_p), ctypes.c_uint64(seed), capi.ptr(self.ws),
+            capi.ptr(d_out_x), capi.ptr(d_out_e), ctypes.c_float(dropout_p), ctypes.c_uint64(seed), capi.ptr(self.pool['buf']),
             self._stream()), 'jodo_train_backward')
         return grads
 
@@ -153,9 +162,9 @@ class _DGTTrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out_x, d_out_e):
-        if ctx.engine.stamp != ctx.stamp:
-            raise RuntimeError("the activations of this forward were overwritten by a later grad-enabled forward on the same "
-                               "batch shape; call backward before the next forward")
+        if ctx.engine.pool['stamp'] != ctx.stamp:
+            raise RuntimeError("the activations of this forward were overwritten by a later training-path forward of the same "
+                               "module (one activation workspace per module); call backward before the next forward")
         grads = ctx.engine.backward(ctx.ps, ctx.nl, d_out_x.contiguous(), d_out_e.contiguous(), ctx.dropout_p, ctx.seed)
         return (None,) * 9 + tuple(grads)
 

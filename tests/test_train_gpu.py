@@ -342,3 +342,39 @@ def test_training_steps_through_get_step_fn():
         want = O.forward_dense({k: v.cpu() for k, v in model.state_dict().items()}, hp, xh, nm, em, ex, None, None, nl)
     close(got[0], want[0], atol=2e-5)
     close(got[1], want[1], atol=2e-5)
+
+
+def test_varying_batches_share_one_workspace():
+    """Data loaders hand over different atom counts every step: every batch shape gets its own handle, all of them share the module's
+    one activation workspace (grown to the largest).  Gradients of a batch do not depend on what ran before it (bit-equal), and a
+    backward whose activations were overwritten by a later forward is refused, not computed from the wrong batch."""
+    from helpers import random_inputs
+    cfg = make_config('vpsde_qm9_uncond_jodo')
+    model = make_model(cfg, 5, DEV)
+    hp = O.Hyper.from_config(cfg)
+    d = lambda x: None if x is None else x.to(DEV)
+
+    def batch(n_nodes, seed):
+        xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=seed)
+        return d(nl), d(xh), d(nm), d(em), d(ex)
+
+    def grads(b):
+        nl, xh, nm, em, ex = b
+        model.zero_grad()
+        ox, oe = model(nl, xh, nm, em, edge_x=ex, cond_x=None, cond_edge_x=None, noise_level=nl)
+        (ox.square().sum() + oe.square().sum()).backward()
+        return [p.grad.clone() for p in model.parameters()]
+
+    small, big = batch([5, 9, 3], 1), batch([29, 17, 23, 29, 12], 2)
+    g_small = grads(small)
+    ws_small = model._train_pool['buf'].numel()
+    g_big = grads(big)
+    assert model._train_pool['buf'].numel() > ws_small and len(model._train_engines) == 2
+    assert all(torch.equal(a, b) for a, b in zip(g_small, grads(small)))          # the larger workspace, the same numbers
+    assert all(torch.equal(a, b) for a, b in zip(g_big, grads(big)))
+    nl, xh, nm, em, ex = small
+    ox, oe = model(nl, xh, nm, em, edge_x=ex, cond_x=None, cond_edge_x=None, noise_level=nl)
+    nl2, xh2, nm2, em2, ex2 = big
+    model(nl2, xh2, nm2, em2, edge_x=ex2, cond_x=None, cond_edge_x=None, noise_level=nl2)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        (ox.square().sum() + oe.square().sum()).backward()
