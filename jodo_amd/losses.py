@@ -97,15 +97,16 @@ def get_step_fn(noise_scheduler, train, optimize_fn, scaler, config, prop_dist=N
             state['step'] += 1
             state['ema'].update(model.parameters())
             return loss
+        averaged = state['ema']                      # evaluation runs under the averaged weights, then puts the live ones back
         with torch.no_grad():
-            ema = state['ema']
-            ema.store(model.parameters())
-            ema.copy_to(model.parameters())
+            averaged.store(model.parameters())
+            averaged.copy_to(model.parameters())
             _weights_changed(model)
-            loss = loss_fn(model, batch)
-            ema.restore(model.parameters())
-            _weights_changed(model)
-        return loss
+            try:
+                return loss_fn(model, batch)
+            finally:
+                averaged.restore(model.parameters())
+                _weights_changed(model)
 
     return step_fn
 
@@ -143,30 +144,27 @@ def get_align_noise(z_t, xh, alpha_t, sigma_t, noise, node_mask):
 
 @torch.no_grad()
 def process_edge_batch(batch, device, include_charges, scaler, prop_norm):
-    pos = batch['positions'].to(device)
-    node_mask = batch['atom_mask'].to(device).unsqueeze(2)
-    edge_mask = batch['edge_mask'].to(device)
-    atom_type = batch['atom_one_hot'].to(device)
-    edge_type = batch['edge_one_hot'].to(device)
-    fc_charge = (batch['formal_charges'] if include_charges else torch.zeros(0)).to(device)
-    context = batch['context'].to(device) if 'context' in batch else None
-    pos = remove_mean_with_mask(pos, node_mask)
-    pos, atom_type, fc_charge, edge_type = scaler(pos, atom_type, fc_charge, node_mask, edge_type, edge_mask)
-    if context is not None:
-        for i, key in enumerate(prop_norm.keys()):
-            context[:, i] = (context[:, i] - prop_norm[key]['mean']) / prop_norm[key]['mad']
-    return torch.cat([pos, atom_type, fc_charge], dim=2), edge_type, node_mask, edge_mask, context
+    """Batch dict of the data loader -> (xh [B,N,3+nd], edge_x [B,N,N,ch], node_mask [B,N,1], edge_mask, context): positions
+    centred per molecule, everything through the training scaler, conditioning properties standardised by their (mean, mad)."""
+    on = lambda key: batch[key].to(device)
+    node_mask, edge_mask = on('atom_mask').unsqueeze(2), on('edge_mask')
+    charges = on('formal_charges') if include_charges else torch.zeros(0, device=device)
+    centred = remove_mean_with_mask(on('positions'), node_mask)
+    pos, atoms, charges, edges = scaler(centred, on('atom_one_hot'), charges, node_mask, on('edge_one_hot'), edge_mask)
+    context = None
+    if 'context' in batch:
+        context = on('context')
+        for col, stats in enumerate(prop_norm.values()):
+            context[:, col] = (context[:, col] - stats['mean']) / stats['mad']
+    return torch.cat([pos, atoms, charges], dim=2), edges, node_mask, edge_mask, context
 
 
 def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None):
     """loss_fn(model, batch) -> scalar: node, position and edge data-prediction loss of one batch at per-molecule random times."""
-    device = config.device
-    include_charges = config.model.include_fc_charge
-    reduce_mean = config.training.reduce_mean
-    noise_align = config.model.noise_align
-    pred_data = config.model.pred_data
-    w_pos, w_atom, w_edge = (float(w) for w in config.model.loss_weights.split(','))
-    self_cond = config.model.self_cond
+    m = config.model
+    device, include_charges, reduce_mean = config.device, m.include_fc_charge, config.training.reduce_mean
+    noise_align, pred_data, self_cond = m.noise_align, m.pred_data, m.self_cond
+    w_pos, w_atom, w_edge = (float(w) for w in m.loss_weights.split(','))
     cond_process_fn = get_self_cond_fn(config) if self_cond else None
 
     def loss_fn(model, batch):
