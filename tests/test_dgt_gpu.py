@@ -830,15 +830,21 @@ def test_medium_batches_cross_the_decomposition_boundaries(cfg_name, info, B, ov
     close(c[1], a[1][:k, :Ns, :Ns], atol=2e-5)
 
 
-@pytest.mark.parametrize("cfg_name,n_nodes,uniform", [('vpsde_qm9_uncond_jodo', [6, 11, 20, 29, 1, 2] * 3, True),
-                                                      ('vpsde_qm9_uncond_jodo', [6, 11, 20, 29, 1, 2], False),
-                                                      ('vpsde_qm9_cond_jodo', [9, 9, 14, 27], True),
-                                                      ('vpsde_geom_uncond_jodo', [140, 33, 12], True)])       # n > 128: directed attention items stay
-def test_pinned_paths_equal_flag_dispatch(cfg_name, n_nodes, uniform):
+@pytest.mark.parametrize("cfg_name,n_nodes,uniform,over", [
+    ('vpsde_qm9_uncond_jodo', [6, 11, 20, 29, 1, 2] * 3, True, {}),
+    ('vpsde_qm9_uncond_jodo', [6, 11, 20, 29, 1, 2], False, {}),
+    ('vpsde_qm9_cond_jodo', [9, 9, 14, 27], True, {}),
+    ('vpsde_geom_uncond_jodo', [140, 33, 12], True, {}),                 # n > 128: directed attention items stay, both edge rows kept
+    # the width-generic kernel set under pins (half rows, merged heads): nf 384, nf 128 / 6 blocks, nf 256 'wide'; even and odd n
+    ('vpsde_geom_uncond_jodo', [44, 33, 12, 2, 1], True, dict(nf=384)),
+    ('vpsde_geom_uncond_jodo', [40, 33, 131, 7], True, dict(nf=128, n_layers=6)),
+    ('vpsde_qm9_uncond_jodo', [6, 11, 20, 29, 1, 2], True, dict(kernel_layout='wide')),
+])
+def test_pinned_paths_equal_flag_dispatch(cfg_name, n_nodes, uniform, over):
     """pin_paths() (what the samplers do after the first self-conditioned evaluation of a round) makes the launcher leave
     out the kernel variants the device flags rule out; the variants that do run are the same kernels on the same inputs, so
     outputs are bit-identical.  A call that breaks the pinned structure is reported, not silently mis-computed."""
-    cfg = make_config(cfg_name)
+    cfg = make_config(cfg_name, **over)
     hp = O.Hyper.from_config(cfg)
     model = make_model(cfg, 9, DEV, gain=1.3, coord_scale=0.05)
     xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=5)
