@@ -134,11 +134,11 @@ struct Ctx {
     float* g(int i) const { return G[i]; }
     // Y[rows, N] (ldy) (+)= X[rows, K] (ldx) W[N, K]^T (ldw) + bias
     void lin(const float* X, int ldx, int rows, int K, const float* W, int ldw, int N, const float* bias, float* Y, int ldy, int acc) const {
-        gemm(s, 0, 1, rows, N, K, X, ldx, W, ldw, Y, ldy, bias, acc, nullptr, 0);
+        gemm(s, 0, 1, rows, N, K, X, ldx, W, ldw, Y, ldy, bias, acc, b.splitk, b.splitk_floats);
     }
     // dX[rows, K] (ldx) (+)= dY[rows, N] (ldy) W[N, K] (ldw)
     void lin_dx(const float* dY, int ldy, int rows, int N, const float* W, int ldw, int K, float* dX, int ldx, int acc) const {
-        gemm(s, 0, 0, rows, K, N, dY, ldy, W, ldw, dX, ldx, nullptr, acc, nullptr, 0);
+        gemm(s, 0, 0, rows, K, N, dY, ldy, W, ldw, dX, ldx, nullptr, acc, b.splitk, b.splitk_floats);
     }
     // dW[N, K] (lddw) += dY[rows, N]^T X[rows, K]
     void lin_dw(const float* dY, int ldy, int rows, int N, const float* X, int ldx, int K, float* dW, int lddw) const {

@@ -5,11 +5,12 @@
 //     input grad   dX = dY W             A = dY [M, N'] row-major,           B = W stored [N', K'] as [K, N]
 //     weight grad  dW = dY^T X           A = dY stored [rows, N'] = [K, M] (TA), B = X [rows, K'] = [K, N]; K = rows is the long
 //                                        dimension: split over grid.z, partial tiles summed by k_splitk_sum in a fixed order
-// Tile: 64 x 64 outputs per 256-thread workgroup (4 waves, one 32 x 32 accumulator block each), K in steps of 32 through LDS
-// ([k][m] / [k][n], consecutive lanes read consecutive m / n: conflict-free operand reads); global loads are 16 bytes per thread
-// along whichever index is contiguous in memory, and the next K tile is in flight (registers) while the current one is multiplied.
+// Tile (train_gemm.h gemm_plan): (64 rm) x (64 rn) outputs per 256-thread workgroup, 2 x 2 waves of rm x rn accumulator blocks each
+// (a wave reads rm + rn operand registers from LDS per rm rn MFMAs: 128 x 128 tiles need one read per instruction, 64 x 64 two), K in
+// steps of 32 through LDS ([k][m] / [k][n], consecutive lanes read consecutive m / n: conflict-free); global loads are 16 bytes per
+// thread along whichever index is contiguous in memory, and the next K tile is in flight (registers) while the current one is
+// multiplied.  Two accumulator chains per block (even / odd k-pairs) and short split-K partials keep the fp32 rounding chains short.
 // Bounds are checked on every edge (N = 3, K = 17 and ragged row counts all occur; unaligned operands take an element-wise path).
-// Not yet: XCD-aware tile order, larger tiles for the square node-level products.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "train_gemm.h"
@@ -17,20 +18,22 @@
 namespace jt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define TM 64
-#define TN 64
 #define TK 32
-#define LDSW (TM + 4)
 
-// one operand tile (64 x TK) from global memory into registers: two 16-byte loads per thread along whichever index is contiguous
-// in memory (KC: the k index is contiguous — X / dY rows, W rows; otherwise the m / n index is: transposed reads of dY, plain B),
-// element-wise with bounds checks where a quad is not whole or not 16-byte aligned.  r[e * 4 + j] <-> (kk, i) as store_tile says.
-template <bool KC>
-__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int i0, int imax, int k0, int kend, bool vec, int tid, float (&r)[8]) {
+// one operand tile (64 R rows x TK) from global memory into registers: 2 R 16-byte loads per thread along whichever index is
+// contiguous in memory (KC: the k index is — X / dY rows, W rows; otherwise the m / n index is: transposed reads of dY, plain B),
+// element-wise with bounds checks where a quad is not whole or not 16-byte aligned.
+template <bool KC, int R>
+__device__ __forceinline__ void tile_pos(int tid, int e, int& i, int& kk) {
+    if (KC) { i = (tid >> 3) + 32 * e; kk = (tid & 7) * 4; }
+    else { const int q = tid + 256 * e; kk = q / (16 * R); i = (q % (16 * R)) * 4; }
+}
+template <bool KC, int R>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int i0, int imax, int k0, int kend, bool vec, int tid, float (&r)[8 * R]) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        int i, kk;                                           // first element of this thread's quad
-        if (KC) { i = (tid >> 3) + 32 * e; kk = (tid & 7) * 4; } else { kk = (tid >> 4) + 16 * e; i = (tid & 15) * 4; }
+    for (int e = 0; e < 2 * R; ++e) {
+        int i, kk;
+        tile_pos<KC, R>(tid, e, i, kk);
         const int gi = i0 + i, gk = k0 + kk;
         const bool whole = KC ? (gi < imax && gk + 3 < kend) : (gk < kend && gi + 3 < imax);
         if (vec && whole) {
@@ -45,75 +48,89 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
         }
     }
 }
-template <bool KC>
-__device__ __forceinline__ void store_tile(float (*S)[LDSW], int tid, const float (&r)[8]) {
+template <bool KC, int R>
+__device__ __forceinline__ void store_tile(float (*S)[64 * R + 4], int tid, const float (&r)[8 * R]) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < 2 * R; ++e) {
+        int i, kk;
+        tile_pos<KC, R>(tid, e, i, kk);
         if (KC) {
-            const int i = (tid >> 3) + 32 * e, kk = (tid & 7) * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) S[kk + j][i] = r[e * 4 + j];
         } else {
-            const int kk = (tid >> 4) + 16 * e, i = (tid & 15) * 4;
             *reinterpret_cast<float4*>(&S[kk][i]) = make_float4(r[e * 4 + 0], r[e * 4 + 1], r[e * 4 + 2], r[e * 4 + 3]);
         }
     }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, int RM, int RN>
 __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                               float* __restrict__ C, int ldc, const float* __restrict__ bias, int acc, float* __restrict__ part, int vecA, int vecB) {
-    __shared__ __attribute__((aligned(16))) float As[TK][LDSW];
-    __shared__ __attribute__((aligned(16))) float Bs[TK][LDSW];
+    __shared__ __attribute__((aligned(16))) float As[TK][64 * RM + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[TK][64 * RN + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int m0 = blockIdx.y * 64 * RM, n0 = blockIdx.x * 64 * RN;
     const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    // four accumulator blocks taken in turn by the k-pairs: each rounding chain is a quarter of the K range (weight gradients
-    // contract over every row of the batch; a single fp32 chain of that length costs a digit against blocked CPU summation)
-    f32x16 c4[4];
+    const int wm = (wave >> 1) * 32 * RM, wn = (wave & 1) * 32 * RN;
+    // two accumulator chains per block, taken in turn by the k-pairs (weight gradients contract over every row of the batch; a single
+    // fp32 chain of that length costs a digit against blocked CPU summation)
+    f32x16 c[RM][RN][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < RM; ++r)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) c4[j][i] = 0.f;
-    float ra[8], rb[8];
+        for (int q = 0; q < RN; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) c[r][q][j][i] = 0.f;
+    float ra[8 * RM], rb[8 * RN];
     // A is k-contiguous unless transposed; B (stored [N, K] when TB) is k-contiguous when TB
     if (kbeg < kend) {
-        load_tile<!TA>(A, lda, m0, M, kbeg, kend, vecA != 0, tid, ra);
-        load_tile<TB>(B, ldb, n0, N, kbeg, kend, vecB != 0, tid, rb);
+        load_tile<!TA, RM>(A, lda, m0, M, kbeg, kend, vecA != 0, tid, ra);
+        load_tile<TB, RN>(B, ldb, n0, N, kbeg, kend, vecB != 0, tid, rb);
     }
     for (int k0 = kbeg; k0 < kend; k0 += TK) {
-        store_tile<!TA>(As, tid, ra);
-        store_tile<TB>(Bs, tid, rb);
+        store_tile<!TA, RM>(As, tid, ra);
+        store_tile<TB, RN>(Bs, tid, rb);
         __syncthreads();
         if (k0 + TK < kend) {                                // the next tile travels while this one is multiplied
-            load_tile<!TA>(A, lda, m0, M, k0 + TK, kend, vecA != 0, tid, ra);
-            load_tile<TB>(B, ldb, n0, N, k0 + TK, kend, vecB != 0, tid, rb);
+            load_tile<!TA, RM>(A, lda, m0, M, k0 + TK, kend, vecA != 0, tid, ra);
+            load_tile<TB, RN>(B, ldb, n0, N, k0 + TK, kend, vecB != 0, tid, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 2) {
-            const float a = As[kk + (lane >> 5)][wm + (lane & 31)];
-            const float b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
-            c4[(kk >> 1) & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c4[(kk >> 1) & 3], 0, 0, 0);
+            float a[RM], b[RN];
+#pragma unroll
+            for (int r = 0; r < RM; ++r) a[r] = As[kk + (lane >> 5)][wm + 32 * r + (lane & 31)];
+#pragma unroll
+            for (int q = 0; q < RN; ++q) b[q] = Bs[kk + (lane >> 5)][wn + 32 * q + (lane & 31)];
+#pragma unroll
+            for (int r = 0; r < RM; ++r)
+#pragma unroll
+                for (int q = 0; q < RN; ++q)
+                    c[r][q][(kk >> 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[q], c[r][q][(kk >> 1) & 1], 0, 0, 0);
         }
         __syncthreads();
     }
-    f32x16 c;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) c[i] = (c4[0][i] + c4[1][i]) + (c4[2][i] + c4[3][i]);
     // C/D map of the 32x32 forms: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-    const int col = n0 + wn + (lane & 31);
-    if (col >= N) return;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= M) continue;
-        if (part) part[((long)blockIdx.z * M + row) * N + col] = c[r];
-        else {
-            float v = c[r] + (bias ? bias[col] : 0.f);
-            float* o = C + (long)row * ldc + col;
-            *o = acc ? *o + v : v;
-        }
+    for (int q = 0; q < RN; ++q) {
+        const int col = n0 + wn + 32 * q + (lane & 31);
+        if (col >= N) continue;
+        const float bv = (bias && !part) ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int row = m0 + wm + 32 * r + (s & 3) + 8 * (s >> 2) + 4 * (lane >> 5);
+                if (row >= M) continue;
+                const float v = c[r][q][0][s] + c[r][q][1][s];
+                if (part) part[((long)blockIdx.z * M + row) * N + col] = v;
+                else {
+                    float* o = C + (long)row * ldc + col;
+                    *o = acc ? *o + (v + bv) : v + bv;
+                }
+            }
     }
 }
 
@@ -128,36 +145,32 @@ __global__ void k_splitk_sum(int M, int N, int nsplit, const float* __restrict__
     *o = acc ? *o + s : s;
 }
 
+template <int RM, int RN>
+static void launch(hipStream_t s, int tA, int tB, dim3 grid, int M, int N, int K, int kchunk, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                   const float* bias, int acc, float* part, int vecA, int vecB) {
+    const dim3 block(256);
+    if (tA && tB) hipLaunchKernelGGL((k_gemm<true, true, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
+    else if (tA) hipLaunchKernelGGL((k_gemm<true, false, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
+    else if (tB) hipLaunchKernelGGL((k_gemm<false, true, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
+    else hipLaunchKernelGGL((k_gemm<false, false, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
+}
+
 void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
           const float* bias, int acc, float* ws, size_t ws_floats) {
     if (M <= 0 || N <= 0) return;
-    const int gx = (N + TN - 1) / TN, gy = (M + TM - 1) / TM;
-    int nsplit = 1;
-    if (ws && K >= 512 && (tA || (K >= 2048 && (long)gx * gy < 512))) {
-        // the weight-gradient shape (few output tiles, K = every row of the batch): partial sums over 512 rows each — fills the chip
-        // and keeps every fp32 rounding chain short; the partial tiles are added in a fixed order by k_splitk_sum
-        nsplit = (K + 511) / 512;
-        const long cap = (long)(ws_floats / ((size_t)M * N));
-        if (nsplit > cap) nsplit = (int)cap;
-        if (nsplit > 256) nsplit = 256;
-        if (nsplit < 1) nsplit = 1;
-    }
-    int kchunk = (K + nsplit - 1) / nsplit;
-    kchunk = (kchunk + TK - 1) / TK * TK;
-    if (kchunk < TK) kchunk = TK;
-    nsplit = K > 0 ? (K + kchunk - 1) / kchunk : 1;
-    float* part = nsplit > 1 ? ws : nullptr;
-    const dim3 grid(gx, gy, nsplit), block(256);
+    const GemmPlan p = gemm_plan(tA, M, N, K, ws != nullptr, ws_floats);
+    float* part = p.nsplit > 1 ? ws : nullptr;
+    const dim3 grid((N + 64 * p.rn - 1) / (64 * p.rn), (M + 64 * p.rm - 1) / (64 * p.rm), p.nsplit);
     // 16-byte loads need an aligned base and a row stride that keeps every quad aligned (column offsets of sliced weights included
     // in the base pointer); otherwise the element-wise path
     const int vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     const int vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
-    if (tA && tB) hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
-    else if (tA) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
-    else if (tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
-    else hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
-    if (nsplit > 1)
-        hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, s, M, N, nsplit, part, C, ldc, bias, acc);
+    if (p.rm == 2 && p.rn == 2) launch<2, 2>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
+    else if (p.rm == 2) launch<2, 1>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
+    else if (p.rn == 2) launch<1, 2>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
+    else launch<1, 1>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
+    if (p.nsplit > 1)
+        hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, s, M, N, p.nsplit, part, C, ldc, bias, acc);
 }
 
 }  // namespace jt
