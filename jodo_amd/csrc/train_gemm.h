@@ -10,22 +10,33 @@ void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, in
 
 // Tiling decision, shared by the device launcher and by the host emulation of the CPU suite (tests/emul/emul_gemm.cpp mirrors the
 // kernel's rounding structure from the same numbers).  A workgroup of 4 waves (2 x 2) computes a (64 rm) x (64 rn) tile, every wave
-// rm x rn accumulator blocks of 32 x 32; K runs in tiles of 32.  Split-K over grid.z: weight gradients (tA: K = every row of the
+// rm x rn accumulator blocks of 32 x 32 (rm = rn = 1 is what runs, see below); K runs in tiles of 32.  Split-K over grid.z: weight gradients (tA: K = every row of the
 // batch) in partial sums over 512 rows; products with too few output tiles to fill the chip (the per-molecule modulation
 // projections: 128 rows) over 128-wide slices of K.
 struct GemmPlan { int rm, rn, nsplit, kchunk; };
 inline GemmPlan gemm_plan(int tA, int M, int N, int K, bool have_ws, size_t ws_floats) {
     GemmPlan p;
-    p.rm = M > 64 ? 2 : 1;
-    p.rn = N > 64 ? 2 : 1;
+    // 64 x 64 tiles everywhere: measured on MI355X (tools/gemm_bench.py, QM9 batch-128 shapes) the 128-wide tiles lose — 271
+    // registers leave one wave per SIMD, and with K <= 256 a tile has too few K steps to hide its own loads: c0 [43 000 x 256 x 256]
+    // 95.7 us at 64 x 64 (five to six workgroups per CU overlap each other's loads and barriers) against 139.3 us at 128 x 128,
+    // ff4 16.9 against 24.0 (128 x 64).  The kernel keeps the general form.
+    p.rm = 1;
+    p.rn = 1;
+    (void)M; (void)N;
     const long tiles = (long)((M + 64 * p.rm - 1) / (64 * p.rm)) * ((N + 64 * p.rn - 1) / (64 * p.rn));
     int nsplit = 1;
     if (have_ws && K >= 512 && (tA || tiles < 128)) {
-        nsplit = tA ? (K + 511) / 512 : (K + 127) / 128;
-        if (!tA && nsplit > 256 / tiles) nsplit = (int)(256 / tiles);
+        if (tA) {
+            // slices of 512 rows (finer slices for outputs of one or two tiles were measured slower: k_splitk_sum has only M N threads,
+            // each walking every slice — dW ff3 [128 x 64 x 43 000] 41.8 us at 84 slices, 96.2 us at 336)
+            nsplit = (K + 511) / 512;
+        } else {
+            nsplit = (K + 127) / 128;
+            if (nsplit > 256 / tiles) nsplit = (int)(256 / tiles);
+        }
         const long cap = (long)(ws_floats / ((size_t)M * N));
         if (nsplit > cap) nsplit = (int)cap;
-        if (nsplit > 256) nsplit = 256;
+        if (nsplit > 512) nsplit = 512;
         if (nsplit < 1) nsplit = 1;
     }
     int kchunk = (K + nsplit - 1) / nsplit;
