@@ -130,6 +130,7 @@ __global__ void k_row_part(long rows, int F, const float* __restrict__ x, float*
     const float* q = x + r * F;
     const float x0 = q[0];
     float s = 0.f, s2 = 0.f;
+#pragma unroll 8
     for (int f = p * w; f < (p + 1) * w; ++f) { const float d = q[f] - x0; s += d; s2 += d * d; }
     part[i_ * 2] = s; part[i_ * 2 + 1] = s2;
 }
@@ -160,6 +161,7 @@ __global__ void k_ln_bwd_part(long rows, int F, const float* __restrict__ dy, co
     const float* m = mods + (long)row_mol[r] * ldm + sc_off;
     const float* d = dy + r * F; const float* xh = xhat + r * F;
     float a = 0.f, b = 0.f;
+#pragma unroll 8
     for (int f = p * w; f < (p + 1) * w; ++f) { const float g = d[f] * (1.f + m[f]); a += g; b += g * xh[f]; }
     part[i_ * 2] = a; part[i_ * 2 + 1] = b;
 }
@@ -187,8 +189,13 @@ __global__ void k_seg_colsum(int S, int F, const int* __restrict__ off, const fl
     JT_IDX((long)S * F);
     const int s = (int)(i_ / F), f = (int)(i_ % F);
     double t = 0.0;                                  // gradient sums cancel: accumulated in double, stored in float
-    if (b) for (long r = off[s]; r < off[s + 1]; ++r) t += (double)(a[r * F + f] * b[r * F + f]);
-    else for (long r = off[s]; r < off[s + 1]; ++r) t += (double)a[r * F + f];
+    if (b) {
+#pragma unroll 8
+        for (long r = off[s]; r < off[s + 1]; ++r) t += (double)(a[r * F + f] * b[r * F + f]);
+    } else {
+#pragma unroll 8
+        for (long r = off[s]; r < off[s + 1]; ++r) t += (double)a[r * F + f];
+    }
     float* o = out + (long)s * ldo + ocol + f;
     *o = acc ? *o + (float)t : (float)t;
 }
@@ -198,14 +205,20 @@ __global__ void k_seg_part(int NC, int F, const int* __restrict__ ec_off, const 
     JT_IDX((long)NC * F);
     const int c = (int)(i_ / F), f = (int)(i_ % F);
     double t = 0.0;
-    if (b) for (long r = ec_off[c]; r < ec_off[c + 1]; ++r) t += (double)(a[r * F + f] * b[r * F + f]);
-    else for (long r = ec_off[c]; r < ec_off[c + 1]; ++r) t += (double)a[r * F + f];
+    if (b) {
+#pragma unroll 8
+        for (long r = ec_off[c]; r < ec_off[c + 1]; ++r) t += (double)(a[r * F + f] * b[r * F + f]);
+    } else {
+#pragma unroll 8
+        for (long r = ec_off[c]; r < ec_off[c + 1]; ++r) t += (double)a[r * F + f];
+    }
     part[i_] = (float)t;
 }
 __global__ void k_seg_fin(int S, int F, const int* __restrict__ mol_off, const float* __restrict__ part, float* __restrict__ out, int ldo, int ocol, int acc) {
     JT_IDX((long)S * F);
     const int s = (int)(i_ / F), f = (int)(i_ % F);
     double t = 0.0;
+#pragma unroll 8
     for (int c = mol_off[s]; c < mol_off[s + 1]; ++c) t += (double)part[(long)c * F + f];
     float* o = out + (long)s * ldo + ocol + f;
     *o = acc ? *o + (float)t : (float)t;
@@ -217,13 +230,19 @@ __global__ void k_colsum_part(long rows, int F, int chunk, const float* __restri
     const long c = i_ / F; const int f = (int)(i_ % F);
     const long r1 = (c + 1) * chunk < rows ? (c + 1) * chunk : rows;
     double t = 0.0;
-    if (b) for (long r = c * chunk; r < r1; ++r) t += (double)(a[r * lda + f] * b[r * ldb + f]);
-    else for (long r = c * chunk; r < r1; ++r) t += (double)a[r * lda + f];
+    if (b) {
+#pragma unroll 8
+        for (long r = c * chunk; r < r1; ++r) t += (double)(a[r * lda + f] * b[r * ldb + f]);
+    } else {
+#pragma unroll 8
+        for (long r = c * chunk; r < r1; ++r) t += (double)a[r * lda + f];
+    }
     part[i_] = (float)t;
 }
 __global__ void k_colsum_fin(long nchunks, int F, const float* __restrict__ part, float* __restrict__ out, int acc) {
     JT_IDX(F);
     double t = 0.0;
+#pragma unroll 8
     for (long c = 0; c < nchunks; ++c) t += (double)part[c * F + i_];
     out[i_] = acc ? out[i_] + (float)t : (float)t;
 }
@@ -261,11 +280,13 @@ __global__ void k_edge_to_node(Topo t, int F, const float* __restrict__ x, float
     const long e0 = t.edge_off[b];
     if (rowsum) {
         float s = 0.f;
+#pragma unroll 8
         for (int c = 0; c < n; ++c) s += x[(e0 + (long)i * n + c) * F + f];
         rowsum[i_] = acc ? rowsum[i_] + s : s;
     }
     if (colsum) {
         float s = 0.f;
+#pragma unroll 8
         for (int a = 0; a < n; ++a) s += x[(e0 + (long)a * n + i) * F + f];
         colsum[i_] = acc ? colsum[i_] + s : s;
     }
@@ -382,6 +403,7 @@ __global__ void k_gbf_bwd_par(long rows, int De, int chunk, const float* __restr
     const float w = stds[k];
     const float sd = fabsf(w) + 1e-5f, sg = w < 0.f ? -1.f : (w > 0.f ? 1.f : 0.f);
     double dm = 0.0, ds = 0.0;
+#pragma unroll 8
     for (long r = c * chunk; r < r1; ++r) {
         const float* g = gm + (long)row_mol[r] * 2;
         const float x = d2[r] * (g[0] + 1.f) + g[1];
@@ -409,6 +431,7 @@ __global__ void k_attn_scores(Topo t, int H, int XH, int SC, float inv_sqrt_c, c
         const float* kk = k + (long)t.edge_a[r] * QK + (hd - XH) * SC;
         const float* tt = t0 + r * QK + (hd - XH) * SC;
         float acc = 0.f;
+#pragma unroll 8
         for (int j = 0; j < SC; ++j) acc += qq[j] * kk[j] * tt[j];
         s = acc * inv_sqrt_c;
     }
@@ -421,9 +444,12 @@ __global__ void k_attn_softmax(Topo t, int H, float* __restrict__ S) {
     const int b = t.node_mol[node], n = t.nn[b], c = node - t.node_off[b];
     const long e0 = t.edge_off[b];
     float m = -INFINITY;
+#pragma unroll 8
     for (int a = 0; a < n; ++a) if (a != c) m = fmaxf(m, S[(e0 + (long)a * n + c) * H + hd]);
     float sum = 0.f;
+#pragma unroll 8
     for (int a = 0; a < n; ++a) if (a != c) sum += expf(S[(e0 + (long)a * n + c) * H + hd] - m);
+#pragma unroll 8
     for (int a = 0; a < n; ++a) {
         float* p = S + (e0 + (long)a * n + c) * H + hd;
         *p = a == c ? 0.f : expf(*p - m) / (sum + 1e-16f);
@@ -438,6 +464,7 @@ __global__ void k_attn_msg(Topo t, int D, int H, const float* __restrict__ v, co
     const long e0 = t.edge_off[b];
     const int hd = f / (D / H);
     float s = 0.f;
+#pragma unroll 8
     for (int a = 0; a < n; ++a) {
         const long r = e0 + (long)a * n + c;
         s += v[((long)t.node_off[b] + a) * D + f] * t1[r * D + f] * (alpha[r * H + hd] * drop_mul(dr, (unsigned long long)(r * H + hd)));
@@ -453,6 +480,7 @@ __global__ void k_attn_bwd_v(Topo t, int D, int H, const float* __restrict__ dhh
     const long e0 = t.edge_off[b];
     const int hd = f / (D / H);
     float s = 0.f;
+#pragma unroll 8
     for (int c = 0; c < n; ++c) {
         const long r = e0 + (long)a * n + c;
         s += dhhat[((long)t.node_off[b] + c) * D + f] * t1[r * D + f] * (alpha[r * H + hd] * drop_mul(dr, (unsigned long long)(r * H + hd)));
@@ -478,6 +506,7 @@ __global__ void k_attn_bwd_alpha(Topo t, int D, int H, const float* __restrict__
     const float* vv = v + (long)t.edge_a[r] * D + hd * C;
     const float* tt = t1 + r * D + hd * C;
     float s = 0.f;
+#pragma unroll 8
     for (int j = 0; j < C; ++j) s += dh[j] * vv[j] * tt[j];
     dalpha[i_] = s * drop_mul(dr, (unsigned long long)i_);
 }
@@ -488,7 +517,9 @@ __global__ void k_attn_bwd_softmax(Topo t, int H, const float* __restrict__ alph
     const int b = t.node_mol[node], n = t.nn[b], c = node - t.node_off[b];
     const long e0 = t.edge_off[b];
     float dot = 0.f;
+#pragma unroll 8
     for (int a = 0; a < n; ++a) { const long x = (e0 + (long)a * n + c) * H + hd; dot += alpha[x] * dalpha[x]; }
+#pragma unroll 8
     for (int a = 0; a < n; ++a) { const long x = (e0 + (long)a * n + c) * H + hd; dalpha[x] = alpha[x] * (dalpha[x] - dot); }
 }
 // dq[c, j] = sum_a dS[(a, c), hd] k[a, j] t0[(a, c), j] / sqrt(C);  dk[a, j] = sum_c dS[(a, c), hd] q[c, j] t0[(a, c), j] / sqrt(C)
@@ -501,6 +532,7 @@ __global__ void k_attn_bwd_qk(Topo t, int H, int XH, int SC, float inv_sqrt_c, c
     const long e0 = t.edge_off[b], n0 = t.node_off[b];
     const int hd = XH + j / SC;
     float sq = 0.f, sk = 0.f;
+#pragma unroll 8
     for (int o = 0; o < n; ++o) {
         const long rq = e0 + (long)o * n + i;          // (a = o, c = i)
         sq += dS[rq * H + hd] * k[(n0 + o) * QK + j] * t0[rq * QK + j];
@@ -543,6 +575,7 @@ __global__ void k_coord_sum(Topo t, const float* __restrict__ pos, const float* 
     const int b = t.node_mol[node], n = t.nn[b], a = node - t.node_off[b];
     const long e0 = t.edge_off[b];
     float s = 0.f;
+#pragma unroll 8
     for (int c = 0; c < n; ++c) s += trans[(e0 + (long)a * n + c) * 3 + d];
     out[i_] = pos[i_] + s;
 }
@@ -553,6 +586,7 @@ __global__ void k_center(Topo t, const float* __restrict__ x, const int* __restr
     const int n0 = t.node_off[b], n = t.nn[b];
     if (zero_if && *zero_if != 0) { for (int i = 0; i < n; ++i) out[(long)(n0 + i) * 3 + d] = 0.f; return; }
     float s = 0.f;
+#pragma unroll 8
     for (int i = 0; i < n; ++i) s += x[(long)(n0 + i) * 3 + d];
     const float m = s / (float)n;
     for (int i = 0; i < n; ++i) out[(long)(n0 + i) * 3 + d] = x[(long)(n0 + i) * 3 + d] - m;
@@ -602,6 +636,7 @@ __global__ void k_diff_to_node(Topo t, const float* __restrict__ ddiff, const fl
     const int b = t.node_mol[node], n = t.nn[b], a = node - t.node_off[b];
     const long e0 = t.edge_off[b];
     float s = base ? base[i_] : 0.f;
+#pragma unroll 8
     for (int c = 0; c < n; ++c) s += ddiff[(e0 + (long)a * n + c) * 3 + d] - ddiff[(e0 + (long)c * n + a) * 3 + d];
     dx[i_] = s;
 }
