@@ -372,7 +372,16 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
     const int B = t.B, Nn = t.Nn, R = t.R, D = t.D, De = t.De, T = t.T, L = t.L, QK = t.QK, H = t.H, r = t.r, nd = t.nd, ch = t.ch;
     const int F17 = 2 * t.half + 1, ldin = 2 * ch + De;
     const Drop nod = c.drop(0.f, 0, 0, 0);
-    for (int i = 0; i < t.n_params; ++i) (void)hipMemsetAsync(c.g(i), 0, t.numel[i] * 4, s);
+    // gradients are accumulated below: zero them first — adjacent buffers (a caller that carves all gradients out of one
+    // allocation, as jodo_amd/train.py does) in one fill instead of one per tensor
+    for (int i = 0; i < t.n_params;) {
+        char* beg = reinterpret_cast<char*>(c.g(i));
+        size_t bytes = t.numel[i] * 4;
+        int j = i + 1;
+        while (j < t.n_params && reinterpret_cast<char*>(c.g(j)) == beg + bytes) { bytes += t.numel[j] * 4; ++j; }
+        (void)hipMemsetAsync(beg, 0, bytes, s);
+        i = j;
+    }
     (void)hipMemsetAsync(b.dtau, 0, (size_t)B * T * 4, s);
     // outputs -> packed gradients; final centring (skipped, gradient zero, when the NaN guard fired)
     float *dposf = b.tN3[0], *datom = b.tN_De, *dEp = b.tE3[0];

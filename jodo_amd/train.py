@@ -140,7 +140,13 @@ class TrainEngine:
         return out_x, out_e
 
     def backward(self, params, noise_level, d_out_x, d_out_e, dropout_p, seed):
-        grads = [torch.empty_like(p) for p in params]
+        # one allocation for all gradients (the library then zeroes them with a single fill)
+        sizes = [p.numel() for p in params]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=params[0].device)
+        grads, off = [], 0
+        for p, n in zip(params, sizes):
+            grads.append(flat[off:off + n].view(p.shape))
+            off += n
         self._check(self.L.jodo_train_backward(
             self.handle, capi.ptr(self.desc), self._ptrs(params), self._ptrs(grads), self.n_params, capi.ptr(noise_level),
             capi.ptr(d_out_x), capi.ptr(d_out_e), ctypes.c_float(dropout_p), ctypes.c_uint64(seed), capi.ptr(self.pool['buf']),
