@@ -136,6 +136,16 @@ struct Ctx {
     void lin(const float* X, int ldx, int rows, int K, const float* W, int ldw, int N, const float* bias, float* Y, int ldy, int acc) const {
         gemm(s, 0, 1, rows, N, K, X, ldx, W, ldw, Y, ldy, bias, acc, b.splitk, b.splitk_floats);
     }
+    // Y = tanh(X W^T + bias)
+    void lin_tanh(const float* X, int ldx, int rows, int K, const float* W, int ldw, int N, const float* bias, float* Y) const {
+        GemmEpi e; e.act = 1; e.out2 = nullptr; e.drop = drop(0.f, 0, 0, 0);
+        gemm(s, 0, 1, rows, N, K, X, ldx, W, ldw, Y, N, bias, 0, b.splitk, b.splitk_floats, &e);
+    }
+    // pre = X W^T + bias (kept for the backward), act = SiLU(pre) * dropout; both dense [rows, N]
+    void lin_silu(const float* X, int ldx, int rows, int K, const float* W, int ldw, int N, const float* bias, float* pre, float* act, Drop d) const {
+        GemmEpi e; e.act = 2; e.out2 = act; e.drop = d;
+        gemm(s, 0, 1, rows, N, K, X, ldx, W, ldw, pre, N, bias, 0, b.splitk, b.splitk_floats, &e);
+    }
     // dX[rows, K] (ldx) (+)= dY[rows, N] (ldy) W[N, K] (ldw)
     void lin_dx(const float* dY, int ldy, int rows, int N, const float* W, int ldw, int K, float* dX, int ldx, int acc) const {
         gemm(s, 0, 0, rows, K, N, dY, ldy, W, ldw, dX, ldx, nullptr, acc, b.splitk, b.splitk_floats);
@@ -201,10 +211,8 @@ enum { SITE_ALPHA = 0, SITE_A1, SITE_F2, SITE_A3, SITE_F4 };
 void head_fwd(const Ctx& c, const float* X, int ldx, long rows, int K, Lin l0, Lin l2, Lin l4, int H1, int H2, int NO, float* p1, float* a1, float* p2, float* a2,
               float* out, int ldo) {
     const Drop nod = c.drop(0.f, 0, 0, 0);
-    c.lin(X, ldx, rows, K, c.p(l0.w), K, H1, c.p(l0.b), p1, H1, 0);
-    c.silu(rows * H1, p1, a1, nod);
-    c.lin(a1, H1, rows, H1, c.p(l2.w), H1, H2, c.p(l2.b), p2, H2, 0);
-    c.silu(rows * H2, p2, a2, nod);
+    c.lin_silu(X, ldx, rows, K, c.p(l0.w), K, H1, c.p(l0.b), p1, a1, nod);
+    c.lin_silu(a1, H1, rows, H1, c.p(l2.w), H1, H2, c.p(l2.b), p2, a2, nod);
     c.lin(a2, H2, rows, H2, c.p(l4.w), H2, NO, c.p(l4.b), out, ldo, 0);
 }
 // dX (ldx, acc) from dOut (ldo); t1 [rows, H1], t2 [rows, H2] scratch
@@ -276,10 +284,8 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
         c.lin(k.ht, D, Nn, D, c.p(ix.query.w), D, QK, c.p(ix.query.b), k.q, QK, 0);
         c.lin(k.ht, D, Nn, D, c.p(ix.key.w), D, QK, c.p(ix.key.b), k.k, QK, 0);
         c.lin(k.ht, D, Nn, D, c.p(ix.value.w), D, D, c.p(ix.value.b), k.v, D, 0);
-        c.lin(k.et, De, R, De, c.p(ix.le0), De, QK, nullptr, k.t0, QK, 0);
-        JT_LAUNCH(k_tanh_fwd, (long)R * QK, s, (long)R * QK, k.t0);
-        c.lin(k.et, De, R, De, c.p(ix.le1), De, D, nullptr, k.t1, D, 0);
-        JT_LAUNCH(k_tanh_fwd, (long)R * D, s, (long)R * D, k.t1);
+        c.lin_tanh(k.et, De, R, De, c.p(ix.le0), De, QK, nullptr, k.t0);
+        c.lin_tanh(k.et, De, R, De, c.p(ix.le1), De, D, nullptr, k.t1);
         JT_LAUNCH(k_attn_scores, (long)R * H, s, tp, H, t.XH, t.SC, 1.f / sqrtf((float)t.C), (const float*)k.q, (const float*)k.k,
                            (const float*)k.t0, (const float*)b.adj2d, (const float*)b.adjsp, k.alpha);
         JT_LAUNCH(k_attn_softmax, (long)Nn * H, s, tp, H, k.alpha);
@@ -292,8 +298,7 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
                            (const float*)k.emod, 6 * De, 2 * De, x1e);
         c.stats(R, De, x1e, b.tRow[0], k.rs_en);
         c.ln_mod(R, De, x1e, b.tRow[0], k.rs_en, tp.edge_mol, k.emod, 6 * De, 3 * De, 4 * De, k.xh_en, k.en);
-        c.lin(k.en, De, R, De, c.p(ix.ff3.w), De, r * De, c.p(ix.ff3.b), k.f3, r * De, 0);
-        c.silu((long)R * r * De, k.f3, k.a3, c.drop(p_drop, seed, l, SITE_A3));
+        c.lin_silu(k.en, De, R, De, c.p(ix.ff3.w), De, r * De, c.p(ix.ff3.b), k.f3, k.a3, c.drop(p_drop, seed, l, SITE_A3));
         c.lin(k.a3, r * De, R, r * De, c.p(ix.ff4.w), r * De, De, c.p(ix.ff4.b), k.f4, De, 0);
         JT_LAUNCH(k_drop, (long)R * De, s, (long)R * De, (const float*)k.f4, b.tE_De[1], c.drop(p_drop, seed, l, SITE_F4));
         JT_LAUNCH(k_gate_add, (long)R * De, s, (long)R, De, (const float*)k.en, (const float*)b.tE_De[1], tp.edge_mol, (const float*)k.emod,
@@ -304,8 +309,7 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
                            6 * D, 2 * D, x1n);
         c.stats(Nn, D, x1n, b.tRow[0], k.rs_hn);
         c.ln_mod(Nn, D, x1n, b.tRow[0], k.rs_hn, tp.node_mol, k.nmod, 6 * D, 3 * D, 4 * D, k.xh_hn, k.hn);
-        c.lin(k.hn, D, Nn, D, c.p(ix.ff1.w), D, r * D, c.p(ix.ff1.b), k.f1, r * D, 0);
-        c.silu((long)Nn * r * D, k.f1, k.a1, c.drop(p_drop, seed, l, SITE_A1));
+        c.lin_silu(k.hn, D, Nn, D, c.p(ix.ff1.w), D, r * D, c.p(ix.ff1.b), k.f1, k.a1, c.drop(p_drop, seed, l, SITE_A1));
         c.lin(k.a1, r * D, Nn, r * D, c.p(ix.ff2.w), r * D, D, c.p(ix.ff2.b), k.f2, D, 0);
         JT_LAUNCH(k_drop, (long)Nn * D, s, (long)Nn * D, (const float*)k.f2, b.tN_D[1], c.drop(p_drop, seed, l, SITE_F2));
         JT_LAUNCH(k_gate_add, (long)Nn * D, s, (long)Nn, D, (const float*)k.hn, (const float*)b.tN_D[1], tp.node_mol, (const float*)k.nmod,
@@ -322,10 +326,8 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
                            (const float*)nullptr, 0, 0, b.tE_D[1]);
         c.stats(R, D, b.tE_D[1], b.tRow[0], k.rs_pre);
         c.ln_mod(R, D, b.tE_D[1], b.tRow[0], k.rs_pre, tp.edge_mol, k.qmod, 2 * D, 0, D, k.xh_pre, k.u);
-        c.lin(k.u, D, R, D, c.p(ix.eq_c0.w), D, D, c.p(ix.eq_c0.b), k.c0pre, D, 0);
-        c.silu((long)R * D, k.c0pre, k.c0a, nod);
-        c.lin(k.c0a, D, R, D, c.p(ix.eq_c2), D, 3, nullptr, k.inv, 3, 0);
-        JT_LAUNCH(k_tanh_fwd, (long)R * 3, s, (long)R * 3, k.inv);
+        c.lin_silu(k.u, D, R, D, c.p(ix.eq_c0.w), D, D, c.p(ix.eq_c0.b), k.c0pre, k.c0a, nod);
+        c.lin_tanh(k.c0a, D, R, D, c.p(ix.eq_c2), D, 3, nullptr, k.inv);
         JT_LAUNCH(k_coord_fwd, R, s, tp, (const float*)b.pos[l], (const float*)k.inv, (const float*)b.adj2d, (const float*)b.adjsp,
                            c.p(ix.eq_scale), b.tE3[0]);
         JT_LAUNCH(k_coord_sum, (long)Nn * 3, s, tp, (const float*)b.pos[l], (const float*)b.tE3[0], b.tN3[0]);

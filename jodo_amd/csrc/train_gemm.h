@@ -4,9 +4,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include "train_common.h"
 namespace jt {
+// Activation fused behind the product (v = sum + bias):  act 1: C = tanh(v);  act 2: C = v (the pre-activation the backward needs)
+// and out2[m, n] = SiLU(v) * dropout(element m N + n) with out2 laid out like C.  Not combined with acc.
+struct GemmEpi { int act; float* out2; Drop drop; };
 void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-          const float* bias, int acc, float* ws, size_t ws_floats);
+          const float* bias, int acc, float* ws, size_t ws_floats, const GemmEpi* epi = nullptr);
+__host__ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, float v, float* C, long cidx, long didx) {
+    if (e.act == 1) C[cidx] = tanhf(v);
+    else { C[cidx] = v; e.out2[cidx] = silu_f(v) * drop_mul(e.drop, (unsigned long long)didx); }
+}
 
 // Tiling decision, shared by the device launcher and by the host emulation of the CPU suite (tests/emul/emul_gemm.cpp mirrors the
 // kernel's rounding structure from the same numbers).  A workgroup of 4 waves (2 x 2) computes a (64 rm) x (64 rn) tile, every wave

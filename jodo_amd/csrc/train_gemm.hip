@@ -65,7 +65,7 @@ __device__ __forceinline__ void store_tile(float (*S)[64 * R + 4], int tid, cons
 
 template <bool TA, bool TB, int RM, int RN>
 __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                              float* __restrict__ C, int ldc, const float* __restrict__ bias, int acc, float* __restrict__ part, int vecA, int vecB) {
+                                              float* __restrict__ C, int ldc, const float* __restrict__ bias, int acc, float* __restrict__ part, int vecA, int vecB, GemmEpi epi) {
     __shared__ __attribute__((aligned(16))) float As[TK][64 * RM + 4];
     __shared__ __attribute__((aligned(16))) float Bs[TK][64 * RN + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, c
                 if (row >= M) continue;
                 const float v = c[r][q][0][s] + c[r][q][1][s];
                 if (part) part[((long)blockIdx.z * M + row) * N + col] = v;
+                else if (epi.act) gemm_epilogue(epi, v + bv, C, (long)row * ldc + col, (long)row * N + col);
                 else {
                     float* o = C + (long)row * ldc + col;
                     *o = acc ? *o + (v + bv) : v + bv;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, c
     }
 }
 
-__global__ void k_splitk_sum(int M, int N, int nsplit, const float* __restrict__ part, float* __restrict__ C, int ldc, const float* __restrict__ bias, int acc) {
+__global__ void k_splitk_sum(int M, int N, int nsplit, const float* __restrict__ part, float* __restrict__ C, int ldc, const float* __restrict__ bias, int acc, GemmEpi epi) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)M * N) return;
     const int row = (int)(i / N), col = (int)(i % N);
@@ -151,23 +152,26 @@ __global__ void k_splitk_sum(int M, int N, int nsplit, const float* __restrict__
     }
     for (; z < nsplit; ++z) s += part[(long)z * MN + i];
     s += bias ? bias[col] : 0.f;
+    if (epi.act) { gemm_epilogue(epi, s, C, (long)row * ldc + col, i); return; }
     float* o = C + (long)row * ldc + col;
     *o = acc ? *o + s : s;
 }
 
 template <int RM, int RN>
 static void launch(hipStream_t s, int tA, int tB, dim3 grid, int M, int N, int K, int kchunk, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                   const float* bias, int acc, float* part, int vecA, int vecB) {
+                   const float* bias, int acc, float* part, int vecA, int vecB, GemmEpi epi) {
     const dim3 block(256);
-    if (tA && tB) hipLaunchKernelGGL((k_gemm<true, true, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
-    else if (tA) hipLaunchKernelGGL((k_gemm<true, false, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
-    else if (tB) hipLaunchKernelGGL((k_gemm<false, true, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
-    else hipLaunchKernelGGL((k_gemm<false, false, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
+    if (tA && tB) hipLaunchKernelGGL((k_gemm<true, true, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
+    else if (tA) hipLaunchKernelGGL((k_gemm<true, false, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
+    else if (tB) hipLaunchKernelGGL((k_gemm<false, true, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
+    else hipLaunchKernelGGL((k_gemm<false, false, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
 }
 
 void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-          const float* bias, int acc, float* ws, size_t ws_floats) {
+          const float* bias, int acc, float* ws, size_t ws_floats, const GemmEpi* epi_in) {
     if (M <= 0 || N <= 0) return;
+    GemmEpi epi;
+    if (epi_in) epi = *epi_in; else { epi.act = 0; epi.out2 = nullptr; epi.drop.p = 0.f; epi.drop.seed = 0; epi.drop.site = 0; }
     const GemmPlan p = gemm_plan(tA, M, N, K, ws != nullptr, ws_floats);
     float* part = p.nsplit > 1 ? ws : nullptr;
     const dim3 grid((N + 64 * p.rn - 1) / (64 * p.rn), (M + 64 * p.rm - 1) / (64 * p.rm), p.nsplit);
@@ -175,12 +179,12 @@ void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, in
     // in the base pointer); otherwise the element-wise path
     const int vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     const int vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
-    if (p.rm == 2 && p.rn == 2) launch<2, 2>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
-    else if (p.rm == 2) launch<2, 1>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
-    else if (p.rn == 2) launch<1, 2>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
-    else launch<1, 1>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB);
+    if (p.rm == 2 && p.rn == 2) launch<2, 2>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
+    else if (p.rm == 2) launch<2, 1>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
+    else if (p.rn == 2) launch<1, 2>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
+    else launch<1, 1>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
     if (p.nsplit > 1)
-        hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, s, M, N, p.nsplit, part, C, ldc, bias, acc);
+        hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, s, M, N, p.nsplit, part, C, ldc, bias, acc, epi);
 }
 
 }  // namespace jt

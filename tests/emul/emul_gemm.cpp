@@ -8,7 +8,7 @@ namespace jt {
 // Mirrors the ROUNDING STRUCTURE of the device kernel so that the CPU suite predicts its accuracy: fp32 fused multiply-adds, two
 // accumulator chains taken in turn by the k-pairs, the split-K slices of train_gemm.h gemm_plan() added in order.
 void gemm(hipStream_t, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-          const float* bias, int acc, float* ws, size_t ws_floats) {
+          const float* bias, int acc, float* ws, size_t ws_floats, const GemmEpi* epi) {
     // debugging aid: products summed in double; value = bit mask of the products it applies to (1 forward, 2 input gradient, 4 weight gradient)
     static const int exact_mask = getenv("JODO_EMUL_GEMM_DOUBLE") ? atoi(getenv("JODO_EMUL_GEMM_DOUBLE")) : 0;
     const int kind = tA ? 4 : (tB ? 1 : 2);
@@ -19,6 +19,7 @@ void gemm(hipStream_t, int tA, int tB, int M, int N, int K, const float* A, int 
                 double t = 0.0;
                 for (int k = 0; k < K; ++k) t += (double)(tA ? A[(long)k * lda + m] : A[(long)m * lda + k]) * (double)(tB ? B[(long)n * ldb + k] : B[(long)k * ldb + n]);
                 if (bias) t += bias[n];
+                if (epi && epi->act) { gemm_epilogue(*epi, (float)t, C, (long)m * ldc + n, (long)m * N + n); continue; }
                 float* o = C + (long)m * ldc + n;
                 *o = acc ? (float)(*o + t) : (float)t;
             }
@@ -42,6 +43,7 @@ void gemm(hipStream_t, int tA, int tB, int M, int N, int K, const float* A, int 
                 else total = c2[0] + c2[1];
             }
             if (bias) total += bias[n];
+            if (epi && epi->act) { gemm_epilogue(*epi, total, C, (long)m * ldc + n, (long)m * N + n); continue; }
             float* o = C + (long)m * ldc + n;
             *o = acc ? *o + total : total;
         }
