@@ -354,6 +354,10 @@ int jodo_train_backward(jodo_train* t, const void* desc_dev, const float* const*
  * tB = 0: B[k ldb + n], 1: B[n ldb + k];  ws / ws_floats: device scratch for split-K partial tiles (NULL: never split) */
 int jodo_train_gemm(int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                     const float* bias, int acc, float* ws, size_t ws_floats, void* stream);
+/* the same with the fused epilogues the training step uses (tests): act 1: C = tanh(.); act 2: C = pre-activation, out2 = SiLU(.) laid out
+ * like C; dbias (tA = 1, act = 0; C is accumulated into): dbias[m] += sum_k A(k, m), the bias gradient riding on a weight-gradient product */
+int jodo_train_gemm_ex(int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                       const float* bias, int act, float* out2, float* dbias, float* ws, size_t ws_floats, void* stream);
 
 const char* jodo_last_error(void);
 

@@ -138,12 +138,12 @@ struct Ctx {
     }
     // Y = tanh(X W^T + bias)
     void lin_tanh(const float* X, int ldx, int rows, int K, const float* W, int ldw, int N, const float* bias, float* Y) const {
-        GemmEpi e; e.act = 1; e.out2 = nullptr; e.drop = drop(0.f, 0, 0, 0);
+        GemmEpi e; e.act = 1; e.out2 = nullptr; e.drop = drop(0.f, 0, 0, 0); e.dbias = nullptr;
         gemm(s, 0, 1, rows, N, K, X, ldx, W, ldw, Y, N, bias, 0, b.splitk, b.splitk_floats, &e);
     }
     // pre = X W^T + bias (kept for the backward), act = SiLU(pre) * dropout; both dense [rows, N]
     void lin_silu(const float* X, int ldx, int rows, int K, const float* W, int ldw, int N, const float* bias, float* pre, float* act, Drop d) const {
-        GemmEpi e; e.act = 2; e.out2 = act; e.drop = d;
+        GemmEpi e; e.act = 2; e.out2 = act; e.drop = d; e.dbias = nullptr;
         gemm(s, 0, 1, rows, N, K, X, ldx, W, ldw, pre, N, bias, 0, b.splitk, b.splitk_floats, &e);
     }
     // dX[rows, K] (ldx) (+)= dY[rows, N] (ldy) W[N, K] (ldw)
@@ -151,8 +151,10 @@ struct Ctx {
         gemm(s, 0, 0, rows, K, N, dY, ldy, W, ldw, dX, ldx, nullptr, acc, b.splitk, b.splitk_floats);
     }
     // dW[N, K] (lddw) += dY[rows, N]^T X[rows, K]
-    void lin_dw(const float* dY, int ldy, int rows, int N, const float* X, int ldx, int K, float* dW, int lddw) const {
-        gemm(s, 1, 0, N, K, rows, dY, ldy, X, ldx, dW, lddw, nullptr, 1, b.splitk, b.splitk_floats);
+    // db (optional): the bias gradient, db[N] += column sums of dY, computed by the same launch
+    void lin_dw(const float* dY, int ldy, int rows, int N, const float* X, int ldx, int K, float* dW, int lddw, float* db = nullptr) const {
+        GemmEpi e; e.act = 0; e.out2 = nullptr; e.drop = drop(0.f, 0, 0, 0); e.dbias = db;
+        gemm(s, 1, 0, N, K, rows, dY, ldy, X, ldx, dW, lddw, nullptr, 1, b.splitk, b.splitk_floats, &e);
     }
     // out[F] += column sums of a[rows, F] (row stride lda), optionally of a * bb: 32-row partial sums, then partial sums of those
     // until at most 64 rows are left (every level a launch with rows x F / 32 threads; fixed order, no atomics)
@@ -219,16 +221,13 @@ void head_fwd(const Ctx& c, const float* X, int ldx, long rows, int K, Lin l0, L
 void head_bwd(const Ctx& c, const float* X, int ldx, long rows, int K, Lin l0, Lin l2, Lin l4, int H1, int H2, int NO, const float* p1, const float* a1,
               const float* p2, const float* a2, const float* dOut, int ldo, float* t1, float* t2, float* dX, int lddx, int acc) {
     const Drop nod = c.drop(0.f, 0, 0, 0);
-    c.lin_dw(dOut, ldo, rows, NO, a2, H2, H2, c.g(l4.w), H2);
-    c.colsum(dOut, ldo, nullptr, 0, rows, NO, c.g(l4.b));
+    c.lin_dw(dOut, ldo, rows, NO, a2, H2, H2, c.g(l4.w), H2, c.g(l4.b));
     c.lin_dx(dOut, ldo, rows, NO, c.p(l4.w), H2, H2, t2, H2, 0);
     c.silu_bwd(rows * H2, p2, t2, t2, nod);
-    c.lin_dw(t2, H2, rows, H2, a1, H1, H1, c.g(l2.w), H1);
-    c.colsum(t2, H2, nullptr, 0, rows, H2, c.g(l2.b));
+    c.lin_dw(t2, H2, rows, H2, a1, H1, H1, c.g(l2.w), H1, c.g(l2.b));
     c.lin_dx(t2, H2, rows, H2, c.p(l2.w), H1, H1, t1, H1, 0);
     c.silu_bwd(rows * H1, p1, t1, t1, nod);
-    c.lin_dw(t1, H1, rows, H1, X, ldx, K, c.g(l0.w), K);
-    c.colsum(t1, H1, nullptr, 0, rows, H1, c.g(l0.b));
+    c.lin_dw(t1, H1, rows, H1, X, ldx, K, c.g(l0.w), K, c.g(l0.b));
     c.lin_dx(t1, H1, rows, H1, c.p(l0.w), K, K, dX, lddx, acc);
 }
 
@@ -349,8 +348,7 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
 // one modulation projection: dW += dmod^T tau, db += column sums, dtau += dmod W
 void mod_bwd(const Ctx& c, Lin lin, const float* dmod, int F) {
     const jodo_train& t = c.t;
-    c.lin_dw(dmod, F, t.B, F, c.b.tau, t.T, t.T, c.g(lin.w), t.T);
-    c.colsum(dmod, F, nullptr, 0, t.B, F, c.g(lin.b));
+    c.lin_dw(dmod, F, t.B, F, c.b.tau, t.T, t.T, c.g(lin.w), t.T, c.g(lin.b));
     c.lin_dx(dmod, F, t.B, F, c.p(lin.w), t.T, t.T, c.b.dtau, t.T, 1);
 }
 
@@ -402,11 +400,9 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
     for (int l = L - 1; l >= 0; --l) {
         const BlkIx& ix = t.blk[l]; BlkBuf& k = b.blk[l];
         // readouts
-        c.lin_dw(dah + D + l * t.cn, t.catn, Nn, t.cn, b.h[l + 1], D, D, c.g(ix.node_ro.w), D);
-        c.colsum(dah + D + l * t.cn, t.catn, nullptr, 0, Nn, t.cn, c.g(ix.node_ro.b));
+        c.lin_dw(dah + D + l * t.cn, t.catn, Nn, t.cn, b.h[l + 1], D, D, c.g(ix.node_ro.w), D, c.g(ix.node_ro.b));
         c.lin_dx(dah + D + l * t.cn, t.catn, Nn, t.cn, c.p(ix.node_ro.w), D, D, dh, D, 1);
-        c.lin_dw(deh + De + l * t.ce, t.cate, R, t.ce, b.e[l + 1], De, De, c.g(ix.edge_ro.w), De);
-        c.colsum(deh + De + l * t.ce, t.cate, nullptr, 0, R, t.ce, c.g(ix.edge_ro.b));
+        c.lin_dw(deh + De + l * t.ce, t.cate, R, t.ce, b.e[l + 1], De, De, c.g(ix.edge_ro.w), De, c.g(ix.edge_ro.b));
         c.lin_dx(deh + De + l * t.ce, t.cate, R, t.ce, c.p(ix.edge_ro.w), De, De, de, De, 1);
         // ---- equivariant update, backwards: centring, position sums, CoorsNorm, tanh, coord_mlp, LayerNorm + modulate, input_lin
         float *dxp = b.tN3[3], *dinv = b.tE3[0], *ddiff = b.tE3[1];
@@ -419,20 +415,18 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         float* dc0 = b.tE_D[0];
         c.lin_dx(dinv, 3, R, 3, c.p(ix.eq_c2), D, D, dc0, D, 0);
         c.silu_bwd((long)R * D, k.c0pre, dc0, dc0, nod);
-        c.lin_dw(dc0, D, R, D, k.u, D, D, c.g(ix.eq_c0.w), D);
-        c.colsum(dc0, D, nullptr, 0, R, D, c.g(ix.eq_c0.b));
+        c.lin_dw(dc0, D, R, D, k.u, D, D, c.g(ix.eq_c0.w), D, c.g(ix.eq_c0.b));
         float *du = b.tE_D[1], *dpre = b.tE_D[2];
         c.lin_dx(dc0, D, R, D, c.p(ix.eq_c0.w), D, D, du, D, 0);
         c.ln_mod_bwd(R, D, du, k.xh_pre, k.rs_pre, tp.edge_mol, tp.edge_off, k.qmod, 2 * D, 0, D, b.dqmod, dpre, 0);
         mod_bwd(c, ix.eq_time, b.dqmod, 2 * D);
         const int ldw = 2 * D + 2 * De;
         const float* Win = c.p(ix.eq_in.w); float* dWin = c.g(ix.eq_in.w);
-        c.colsum(dpre, D, nullptr, 0, R, D, c.g(ix.eq_in.b));
         float *dhr = b.tN_D[0], *dhc = b.tN_D[1];
         JT_LAUNCH(k_edge_to_node, (long)Nn * D, s, tp, D, (const float*)dpre, dhr, dhc, 0);
         c.lin_dw(dhr, D, Nn, D, b.h[l + 1], D, D, dWin, ldw);
         c.lin_dw(dhc, D, Nn, D, b.h[l + 1], D, D, dWin + D, ldw);
-        c.lin_dw(dpre, D, R, D, b.e[l + 1], De, De, dWin + 2 * D, ldw);
+        c.lin_dw(dpre, D, R, D, b.e[l + 1], De, De, dWin + 2 * D, ldw, c.g(ix.eq_in.b));
         c.lin_dw(dpre, D, R, D, k.G, De, De, dWin + 2 * D + De, ldw);
         c.lin_dx(dhr, D, Nn, D, Win, ldw, D, dh, D, 1);
         c.lin_dx(dhc, D, Nn, D, Win + D, ldw, D, dh, D, 1);
@@ -445,12 +439,10 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         c.seg(De, tp.edge_off, de, dten, b.demod, 6 * De, 5 * De);                                   // d eg2
         JT_LAUNCH(k_gate_bwd, (long)R * De, s, (long)R, De, (const float*)de, tp.edge_mol, (const float*)k.emod, 6 * De, 5 * De, dten, 0);
         JT_LAUNCH(k_drop, (long)R * De, s, (long)R * De, (const float*)dten, dten, c.drop(p_drop, seed, l, SITE_F4));
-        c.lin_dw(dten, De, R, De, k.a3, r * De, r * De, c.g(ix.ff4.w), r * De);
-        c.colsum(dten, De, nullptr, 0, R, De, c.g(ix.ff4.b));
+        c.lin_dw(dten, De, R, De, k.a3, r * De, r * De, c.g(ix.ff4.w), r * De, c.g(ix.ff4.b));
         c.lin_dx(dten, De, R, De, c.p(ix.ff4.w), r * De, r * De, tE, r * De, 0);
         c.silu_bwd((long)R * r * De, k.f3, tE, tE, c.drop(p_drop, seed, l, SITE_A3));
-        c.lin_dw(tE, r * De, R, r * De, k.en, De, De, c.g(ix.ff3.w), De);
-        c.colsum(tE, r * De, nullptr, 0, R, r * De, c.g(ix.ff3.b));
+        c.lin_dw(tE, r * De, R, r * De, k.en, De, De, c.g(ix.ff3.w), De, c.g(ix.ff3.b));
         c.lin_dx(tE, r * De, R, r * De, c.p(ix.ff3.w), De, De, de, De, 1);                          // de is now d en
         c.ln_mod_bwd(R, De, de, k.xh_en, k.rs_en, tp.edge_mol, tp.edge_off, k.emod, 6 * De, 3 * De, 4 * De, b.demod, de_prev, 0);   // de_prev = d x1e = d e[l] (residual)
         float* ehat = dten;
@@ -472,12 +464,10 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         c.seg(D, tp.node_off, dh, dtn, b.dnmod, 6 * D, 5 * D);                                       // d ng2
         JT_LAUNCH(k_gate_bwd, (long)Nn * D, s, (long)Nn, D, (const float*)dh, tp.node_mol, (const float*)k.nmod, 6 * D, 5 * D, dtn, 0);
         JT_LAUNCH(k_drop, (long)Nn * D, s, (long)Nn * D, (const float*)dtn, dtn, c.drop(p_drop, seed, l, SITE_F2));
-        c.lin_dw(dtn, D, Nn, D, k.a1, r * D, r * D, c.g(ix.ff2.w), r * D);
-        c.colsum(dtn, D, nullptr, 0, Nn, D, c.g(ix.ff2.b));
+        c.lin_dw(dtn, D, Nn, D, k.a1, r * D, r * D, c.g(ix.ff2.w), r * D, c.g(ix.ff2.b));
         c.lin_dx(dtn, D, Nn, D, c.p(ix.ff2.w), r * D, r * D, tNr, r * D, 0);
         c.silu_bwd((long)Nn * r * D, k.f1, tNr, tNr, c.drop(p_drop, seed, l, SITE_A1));
-        c.lin_dw(tNr, r * D, Nn, r * D, k.hn, D, D, c.g(ix.ff1.w), D);
-        c.colsum(tNr, r * D, nullptr, 0, Nn, r * D, c.g(ix.ff1.b));
+        c.lin_dw(tNr, r * D, Nn, r * D, k.hn, D, D, c.g(ix.ff1.w), D, c.g(ix.ff1.b));
         c.lin_dx(tNr, r * D, Nn, r * D, c.p(ix.ff1.w), D, D, dh, D, 1);                              // dh is now d hn
         c.ln_mod_bwd(Nn, D, dh, k.xh_hn, k.rs_hn, tp.node_mol, tp.node_off, k.nmod, 6 * D, 3 * D, 4 * D, b.dnmod, dh_prev, 0);      // dh_prev = d x1n = d h[l] (residual)
         c.seg(D, tp.node_off, dh_prev, k.hhat, b.dnmod, 6 * D, 2 * D);                               // d ng1
@@ -498,22 +488,18 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         c.lin_dw(dt0, QK, R, QK, k.et, De, De, c.g(ix.le0), De);
         c.lin_dx(dt0, QK, R, QK, c.p(ix.le0), De, De, det, De, 1);
         float* dht = b.tN_D[0];
-        c.lin_dw(dv, D, Nn, D, k.ht, D, D, c.g(ix.value.w), D);
-        c.colsum(dv, D, nullptr, 0, Nn, D, c.g(ix.value.b));
+        c.lin_dw(dv, D, Nn, D, k.ht, D, D, c.g(ix.value.w), D, c.g(ix.value.b));
         c.lin_dx(dv, D, Nn, D, c.p(ix.value.w), D, D, dht, D, 0);
-        c.lin_dw(dq, QK, Nn, QK, k.ht, D, D, c.g(ix.query.w), D);
-        c.colsum(dq, QK, nullptr, 0, Nn, QK, c.g(ix.query.b));
+        c.lin_dw(dq, QK, Nn, QK, k.ht, D, D, c.g(ix.query.w), D, c.g(ix.query.b));
         c.lin_dx(dq, QK, Nn, QK, c.p(ix.query.w), D, D, dht, D, 1);
-        c.lin_dw(dk, QK, Nn, QK, k.ht, D, D, c.g(ix.key.w), D);
-        c.colsum(dk, QK, nullptr, 0, Nn, QK, c.g(ix.key.b));
+        c.lin_dw(dk, QK, Nn, QK, k.ht, D, D, c.g(ix.key.w), D, c.g(ix.key.b));
         c.lin_dx(dk, QK, Nn, QK, c.p(ix.key.w), D, D, dht, D, 1);
         // ---- the two modulated LayerNorms at the top of the block, edge_emb([G, e])
         float* de1 = b.tE_De[1];
         c.ln_mod_bwd(R, De, det, k.xh_e1, k.rs_e1, tp.edge_mol, tp.edge_off, k.emod, 6 * De, 0, De, b.demod, de1, 0);      // in place: dx written after its own row was read
         mod_bwd(c, ix.edge_time, b.demod, 6 * De);
-        c.lin_dw(de1, De, R, De, k.G, De, De, c.g(ix.edge_emb.w), 2 * De);
+        c.lin_dw(de1, De, R, De, k.G, De, De, c.g(ix.edge_emb.w), 2 * De, c.g(ix.edge_emb.b));
         c.lin_dw(de1, De, R, De, b.e[l], De, De, c.g(ix.edge_emb.w) + De, 2 * De);
-        c.colsum(de1, De, nullptr, 0, R, De, c.g(ix.edge_emb.b));
         c.lin_dx(de1, De, R, De, c.p(ix.edge_emb.w), 2 * De, De, dG, De, 1);
         c.lin_dx(de1, De, R, De, c.p(ix.edge_emb.w) + De, 2 * De, De, de_prev, De, 1);
         c.ln_mod_bwd(Nn, D, dht, k.xh_h, k.rs_h, tp.node_mol, tp.node_off, k.nmod, 6 * D, 0, D, b.dnmod, dh_prev, 1);
@@ -528,10 +514,8 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
     // embeddings
     c.copy2d(Nn, D, dah, t.catn, 0, dh, D, 0, 1);
     c.copy2d(R, De, deh, t.cate, 0, de, De, 0, 1);
-    c.lin_dw(dh, D, Nn, D, b.nin, 2 * nd, 2 * nd, c.g(t.node_emb.w), 2 * nd);
-    c.colsum(dh, D, nullptr, 0, Nn, D, c.g(t.node_emb.b));
-    c.lin_dw(de, De, R, De, b.ein, ldin, ldin, c.g(t.edge_emb.w), ldin);
-    c.colsum(de, De, nullptr, 0, R, De, c.g(t.edge_emb.b));
+    c.lin_dw(dh, D, Nn, D, b.nin, 2 * nd, 2 * nd, c.g(t.node_emb.w), 2 * nd, c.g(t.node_emb.b));
+    c.lin_dw(de, De, R, De, b.ein, ldin, ldin, c.g(t.edge_emb.w), ldin, c.g(t.edge_emb.b));
     float* dG0 = b.tE_De[0];
     c.lin_dx(de, De, R, De, c.p(t.edge_emb.w) + 2 * ch, ldin, De, dG0, De, 0);
     // the top-level Gaussian layer saw the self-conditioning distances, or nothing at all on a first step (flag [3] == 0: G0 = 0)
@@ -541,22 +525,17 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
     c.silu_bwd((long)B * T, b.temb, b.dtau, b.dtemb, nod);
     if (t.cc > 0) {
         const int cD = t.cc * D;
-        c.lin_dw(b.dtemb, T, B, T, b.cc2, cD, cD, c.g(t.cond_lin.w), cD);
-        c.colsum(b.dtemb, T, nullptr, 0, B, T, c.g(t.cond_lin.b));
+        c.lin_dw(b.dtemb, T, B, T, b.cc2, cD, cD, c.g(t.cond_lin.w), cD, c.g(t.cond_lin.b));
         c.lin_dx(b.dtemb, T, B, T, c.p(t.cond_lin.w), cD, cD, b.tB_cD[0], cD, 0);
-        c.lin_dw(b.tB_cD[0], D, B * t.cc, D, b.cc0a, D, D, c.g(t.cond2.w), D);
-        c.colsum(b.tB_cD[0], D, nullptr, 0, B * t.cc, D, c.g(t.cond2.b));
+        c.lin_dw(b.tB_cD[0], D, B * t.cc, D, b.cc0a, D, D, c.g(t.cond2.w), D, c.g(t.cond2.b));
         c.lin_dx(b.tB_cD[0], D, B * t.cc, D, c.p(t.cond2.w), D, D, b.tB_cD[1], D, 0);
         JT_LAUNCH(k_gelu_bwd, (long)B * cD, s, (long)B * cD, (const float*)b.cc0pre, (const float*)b.tB_cD[1], b.tB_cD[1]);
-        c.lin_dw(b.tB_cD[1], D, B * t.cc, D, b.ctx, 1, 1, c.g(t.cond0.w), 1);
-        c.colsum(b.tB_cD[1], D, nullptr, 0, B * t.cc, D, c.g(t.cond0.b));
+        c.lin_dw(b.tB_cD[1], D, B * t.cc, D, b.ctx, 1, 1, c.g(t.cond0.w), 1, c.g(t.cond0.b));
     }
-    c.lin_dw(b.dtemb, T, B, T, b.t1a, T, T, c.g(t.time3.w), T);
-    c.colsum(b.dtemb, T, nullptr, 0, B, T, c.g(t.time3.b));
+    c.lin_dw(b.dtemb, T, B, T, b.t1a, T, T, c.g(t.time3.w), T, c.g(t.time3.b));
     c.lin_dx(b.dtemb, T, B, T, c.p(t.time3.w), T, T, b.tB_T[0], T, 0);
     JT_LAUNCH(k_gelu_bwd, (long)B * T, s, (long)B * T, (const float*)b.t1pre, (const float*)b.tB_T[0], b.tB_T[0]);
-    c.lin_dw(b.tB_T[0], T, B, T, b.feat, F17, F17, c.g(t.time1.w), F17);
-    c.colsum(b.tB_T[0], T, nullptr, 0, B, T, c.g(t.time1.b));
+    c.lin_dw(b.tB_T[0], T, B, T, b.feat, F17, F17, c.g(t.time1.w), F17, c.g(t.time1.b));
     c.lin_dx(b.tB_T[0], T, B, T, c.p(t.time1.w), F17, F17, b.tB_T[1], F17, 0);
     JT_LAUNCH(k_time_feat_bwd, t.half, s, B, t.half, nl, c.p(t.time_w), (const float*)b.tB_T[1], c.g(t.time_w));
 }
@@ -725,6 +704,15 @@ int jodo_train_gemm(int tA, int tB, int M, int N, int K, const float* A, int lda
     if (!A || !B || !C || M < 0 || N < 0 || K < 0) return jodo_set_error(JODO_ERR_ARG, "jodo_train_gemm: bad argument");
     gemm(static_cast<hipStream_t>(stream), tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, acc, ws, ws_floats);
     return jodo_check_launch("jodo_train_gemm");
+}
+
+int jodo_train_gemm_ex(int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
+                       int act, float* out2, float* dbias, float* ws, size_t ws_floats, void* stream) {
+    if (!A || !B || !C || M < 0 || N < 0 || K < 0 || act < 0 || act > 2 || (act == 2 && !out2) || (dbias && (!tA || act)))
+        return jodo_set_error(JODO_ERR_ARG, "jodo_train_gemm_ex: bad argument");
+    GemmEpi e; e.act = act; e.out2 = out2; e.drop.p = 0.f; e.drop.seed = 0; e.drop.site = 0; e.dbias = dbias;
+    gemm(static_cast<hipStream_t>(stream), tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, dbias ? 1 : 0, ws, ws_floats, &e);
+    return jodo_check_launch("jodo_train_gemm_ex");
 }
 
 }  // extern "C"

@@ -8,7 +8,9 @@
 namespace jt {
 // Activation fused behind the product (v = sum + bias):  act 1: C = tanh(v);  act 2: C = v (the pre-activation the backward needs)
 // and out2[m, n] = SiLU(v) * dropout(element m N + n) with out2 laid out like C.  Not combined with acc.
-struct GemmEpi { int act; float* out2; Drop drop; };
+// dbias (weight-gradient products, tA = 1, act = 0): dbias[m] += sum_k A(k, m) — the bias gradient is the column sum of the very
+// dY tiles the product stages in LDS, so it rides along instead of a reduction pass of its own (accumulated in double per slice).
+struct GemmEpi { int act; float* out2; Drop drop; float* dbias; };
 void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
           const float* bias, int acc, float* ws, size_t ws_floats, const GemmEpi* epi = nullptr);
 __host__ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, float v, float* C, long cidx, long didx) {
@@ -42,7 +44,7 @@ inline GemmPlan gemm_plan(int tA, int M, int N, int K, bool have_ws, size_t ws_f
             nsplit = (K + 127) / 128;
             if (nsplit > 256 / tiles) nsplit = (int)(256 / tiles);
         }
-        const long cap = (long)(ws_floats / ((size_t)M * N));
+        const long cap = (long)(ws_floats / ((size_t)M * N + (size_t)M));      // partial tiles + partial bias sums
         if (nsplit > cap) nsplit = (int)cap;
         if (nsplit > 512) nsplit = 512;
         if (nsplit < 1) nsplit = 1;

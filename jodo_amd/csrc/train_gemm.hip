@@ -84,6 +84,8 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, c
 #pragma unroll
                 for (int i = 0; i < 16; ++i) c[r][q][j][i] = 0.f;
     float ra[8 * RM], rb[8 * RN];
+    double bsum = 0.0;                                       // epi.dbias: column sum of this workgroup's dY tiles (threads 0 .. 64 RM - 1)
+    const bool do_bias = TA && epi.dbias != nullptr && blockIdx.x == 0 && tid < 64 * RM;
     // A is k-contiguous unless transposed; B (stored [N, K] when TB) is k-contiguous when TB
     if (kbeg < kend) {
         load_tile<!TA, RM>(A, lda, m0, M, kbeg, kend, vecA != 0, tid, ra);
@@ -93,6 +95,10 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, c
         store_tile<!TA, RM>(As, tid, ra);
         store_tile<TB, RN>(Bs, tid, rb);
         __syncthreads();
+        if (do_bias) {
+#pragma unroll
+            for (int kk = 0; kk < TK; ++kk) bsum += (double)As[kk][tid];
+        }
         if (k0 + TK < kend) {                                // the next tile travels while this one is multiplied
             load_tile<!TA, RM>(A, lda, m0, M, k0 + TK, kend, vecA != 0, tid, ra);
             load_tile<TB, RN>(B, ldb, n0, N, k0 + TK, kend, vecB != 0, tid, rb);
@@ -111,6 +117,10 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, c
                     c[r][q][(kk >> 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[q], c[r][q][(kk >> 1) & 1], 0, 0, 0);
         }
         __syncthreads();
+    }
+    if (do_bias && m0 + tid < M) {
+        if (part) part[(long)gridDim.z * M * N + (long)blockIdx.z * M + m0 + tid] = (float)bsum;     // behind the partial tiles
+        else epi.dbias[m0 + tid] += (float)bsum;
     }
     // C/D map of the 32x32 forms: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
@@ -151,6 +161,11 @@ __global__ void k_splitk_sum(int M, int N, int nsplit, const float* __restrict__
         for (int j = 0; j < 8; ++j) s += v[j];
     }
     for (; z < nsplit; ++z) s += part[(long)z * MN + i];
+    if (epi.dbias && col == 0) {                            // partial bias sums of the slices, in slice order
+        float bs = 0.f;
+        for (int zz = 0; zz < nsplit; ++zz) bs += part[(long)nsplit * MN + (long)zz * M + row];
+        epi.dbias[row] += bs;
+    }
     s += bias ? bias[col] : 0.f;
     if (epi.act) { gemm_epilogue(epi, s, C, (long)row * ldc + col, i); return; }
     float* o = C + (long)row * ldc + col;
@@ -171,7 +186,7 @@ void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, in
           const float* bias, int acc, float* ws, size_t ws_floats, const GemmEpi* epi_in) {
     if (M <= 0 || N <= 0) return;
     GemmEpi epi;
-    if (epi_in) epi = *epi_in; else { epi.act = 0; epi.out2 = nullptr; epi.drop.p = 0.f; epi.drop.seed = 0; epi.drop.site = 0; }
+    if (epi_in) epi = *epi_in; else { epi.act = 0; epi.out2 = nullptr; epi.drop.p = 0.f; epi.drop.seed = 0; epi.drop.site = 0; epi.dbias = nullptr; }
     const GemmPlan p = gemm_plan(tA, M, N, K, ws != nullptr, ws_floats);
     float* part = p.nsplit > 1 ? ws : nullptr;
     const dim3 grid((N + 64 * p.rn - 1) / (64 * p.rn), (M + 64 * p.rm - 1) / (64 * p.rm), p.nsplit);

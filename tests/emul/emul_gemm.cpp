@@ -18,6 +18,7 @@ void gemm(hipStream_t, int tA, int tB, int M, int N, int K, const float* A, int 
             for (int n = 0; n < N; ++n) {
                 double t = 0.0;
                 for (int k = 0; k < K; ++k) t += (double)(tA ? A[(long)k * lda + m] : A[(long)m * lda + k]) * (double)(tB ? B[(long)n * ldb + k] : B[(long)k * ldb + n]);
+                if (epi && epi->dbias && tA && n == 0) { double bsum = 0.0; for (int k = 0; k < K; ++k) bsum += (double)A[(long)k * lda + m]; epi->dbias[m] += (float)bsum; }
                 if (bias) t += bias[n];
                 if (epi && epi->act) { gemm_epilogue(*epi, (float)t, C, (long)m * ldc + n, (long)m * N + n); continue; }
                 float* o = C + (long)m * ldc + n;
@@ -27,6 +28,18 @@ void gemm(hipStream_t, int tA, int tB, int M, int N, int K, const float* A, int 
     }
     const GemmPlan pl = gemm_plan(tA, M, N, K, ws != nullptr, ws_floats);
     const int nsplit = pl.nsplit, kchunk = pl.kchunk;
+    if (epi && epi->dbias && tA) {                              // bias gradient: per slice a double sum, slices added in order
+        for (int m = 0; m < M; ++m) {
+            float bs = 0.f;
+            for (int z = 0; z < nsplit; ++z) {
+                double t = 0.0;
+                const int k1 = K < (z + 1) * kchunk ? K : (z + 1) * kchunk;
+                for (int k = z * kchunk; k < k1; ++k) t += (double)A[(long)k * lda + m];
+                if (nsplit > 1) bs += (float)t; else bs = (float)t;
+            }
+            epi->dbias[m] += bs;
+        }
+    }
     for (int m = 0; m < M; ++m)
         for (int n = 0; n < N; ++n) {
             float total = 0.f;

@@ -378,3 +378,41 @@ def test_varying_batches_share_one_workspace():
     model(nl2, xh2, nm2, em2, edge_x=ex2, cond_x=None, cond_edge_x=None, noise_level=nl2)
     with pytest.raises(RuntimeError, match="overwritten"):
         (ox.square().sum() + oe.square().sum()).backward()
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 1187), (256, 64, 50000), (252, 256, 300), (3, 256, 9000)])
+def test_train_gemm_bias_gradient_rides_on_the_weight_gradient(M, N, K):
+    """dW += dY^T X with db += column sums of dY from the same launch (with and without split-K), against float64."""
+    import ctypes
+    from jodo_amd import capi
+    g = torch.Generator().manual_seed(M + K)
+    dY, X = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    dW0, db0 = torch.randn(M, N, generator=g), torch.randn(M, generator=g)
+    dW, db = dW0.clone().to(DEV), db0.clone().to(DEV)
+    ws = torch.empty(8 << 20, device=DEV)
+    dYd, Xd = dY.to(DEV), X.to(DEV)
+    capi.check(capi.lib().jodo_train_gemm_ex(1, 0, M, N, K, capi.ptr(dYd), M, capi.ptr(Xd), N, capi.ptr(dW), N, None, 0, None, capi.ptr(db), capi.ptr(ws),
+                                             ctypes.c_size_t(ws.numel()), capi.current_stream_ptr()), 'jodo_train_gemm_ex')
+    torch.cuda.synchronize()
+    close(dW, dW0.double() + dY.double().t() @ X.double(), atol=2e-6 * (K ** 0.5) * 4, rtol=2e-5)
+    close(db, db0.double() + dY.double().sum(0), atol=2e-6 * (K ** 0.5), rtol=2e-5)
+
+
+@pytest.mark.parametrize("act", [1, 2])
+def test_train_gemm_fused_activations(act):
+    import ctypes
+    from jodo_amd import capi
+    g = torch.Generator().manual_seed(act)
+    M, N, K = 333, 252, 64
+    X, W, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / 8, torch.randn(N, generator=g)
+    C, out2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    Xd, Wd, bd = X.to(DEV), W.to(DEV), bias.to(DEV)
+    capi.check(capi.lib().jodo_train_gemm_ex(0, 1, M, N, K, capi.ptr(Xd), K, capi.ptr(Wd), K, capi.ptr(C), N, capi.ptr(bd), act, capi.ptr(out2), None, None,
+                                             ctypes.c_size_t(0), capi.current_stream_ptr()), 'jodo_train_gemm_ex')
+    torch.cuda.synchronize()
+    pre = X.double() @ W.double().t() + bias.double()
+    if act == 1:
+        close(C, torch.tanh(pre), atol=2e-6)
+    else:
+        close(C, pre, atol=1e-5)
+        close(out2, torch.nn.functional.silu(pre), atol=1e-5)
