@@ -1,6 +1,6 @@
 #!/bin/bash
 # the other three workloads: bench line without class brackets, then the profile passes (kernel stats + FETCH / WRITE)
-for w in geom cond geom384; do
+for w in ${1:-geom cond geom384}; do
   mkdir -p gpurun_out/r04P
   timeout 900 python bench.py --workload $w --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/r04P/bench_$w.json 2> gpurun_out/r04P/bench_$w.err
   python -c "
