@@ -125,6 +125,24 @@ __global__ __launch_bounds__(64, 1) void k_node_ab_pre(KArgs A) {
     else wide::node_gram_body<256>(A, A.g0 + b - npre - nab);
 }
 
+// The same for the width-generic kernel set (nf 128 / 384, nf 256 'wide'), at any strip count: this set has no k_node_post that also
+// produces the next block's q / k / v, so the 3 n_strips items of the following block always ride with the 2 n_strips k_node_ab items.
+template <int D>
+__global__ __launch_bounds__(64, 1) void k_node_ab_pre_w(KArgs A) {
+    const int npre = A.mix_nw, nab = A.ab1 - A.ab0;
+    const int b = (int)blockIdx.x;
+    if (b < npre) wide::node_pre_body<D, true>(A, b);
+    else if (b < npre + nab) wide::node_ab_body<D>(A, A.ab0 + b - npre);
+    else wide::node_gram_body<D>(A, A.g0 + b - npre - nab);
+}
+// first block: its q / k / v items and the edge embedding in one launch (as k_pre_embed for the tuned set)
+template <int D>
+__global__ __launch_bounds__(64, 1) void k_pre_embed_w(KArgs A) {
+    const int npre = A.pd.n_strips * 3;
+    if ((int)blockIdx.x < npre) wide::node_pre_body<D, false>(A, (int)blockIdx.x);
+    else wide::embed_edges_body<D>(A, (int)blockIdx.x - npre);
+}
+
 // One launch for a block's remainder strips (k_node_postw role: NW waves per strip, long items first) and for the fine-grained
 // per-node items that do not depend on them — k_node_ab items and Gram tiles of the strips the preceding full-round k_node_post
 // launch finished, NW per workgroup.  The cooperative remainder workgroups occupy 2 x 385 of 1024 SIMDs for 211 us at QM9
@@ -226,7 +244,7 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
     }
     if (rc) return rc;
     // (nf = 256 tuned set: the edge embedding shares a launch with the first block's q / k / v items, k_pre_embed below)
-    const bool embed_merged = TUNED && p->n_items > 0 && p->opt[JODO_OPT_PRE_EMBED] != 0 && ((p->max_blocks >= 0 && p->max_blocks < d.L) ? p->max_blocks : d.L) > 0;
+    const bool embed_merged = p->n_items > 0 && p->opt[JODO_OPT_PRE_EMBED] != 0 && ((p->max_blocks >= 0 && p->max_blocks < d.L) ? p->max_blocks : d.L) > 0;
     if (p->n_items > 0 && !embed_merged) LAUNCH((wide::k_embed_edges<D>), p->n_items, 64, A);
     const bool pin_pair = p->opt[JODO_OPT_PIN_SYMMETRIC] == 1 && !p->force_directed, pin_dir = p->opt[JODO_OPT_PIN_SYMMETRIC] == 2 || p->force_directed;
     // shared modulation row + symmetric inputs (device flags; both can be pinned): folded coord_mlp.0 of every block, and with
@@ -255,7 +273,7 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
     // (GEOM B = 512, 710 strips: fused 35.1 vs 34.6 ms/step), so it stays separate there.
     const bool fuse_pre = TUNED && p->opt[JODO_OPT_FUSE_NEXT_QKV] != 0 && nblocks > 1 && p->n_strips >= 1024;
     // below 1 024 strips the next block's q / k / v items ride in the launch of this block's k_node_ab items (k_node_ab_pre)
-    const bool ab_pre = TUNED && !fuse_pre && p->opt[JODO_OPT_AB_PRE] != 0 && nblocks > 1 && p->n_strips < 1024 && p->opt[JODO_OPT_NODE_POST_WAVES] == 0;
+    const bool ab_pre = !fuse_pre && p->opt[JODO_OPT_AB_PRE] != 0 && nblocks > 1 && (!TUNED || (p->n_strips < 1024 && p->opt[JODO_OPT_NODE_POST_WAVES] == 0));
     int cur = 0;                                   // posbuf[cur] holds the positions entering the block
     for (int l = 0; l < nblocks; ++l) {
         A.layer = l;
@@ -279,8 +297,17 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
                         else LAUNCH(k_node_pre, p->n_strips * 3, 64, A);
                     }
                 }
+            } else if (!ab_pre) {
+                A.pre_mode = 0;
+                if (l == 0 && embed_merged) LAUNCH((k_pre_embed_w<D>), p->n_strips * 3 + p->n_items, 64, A);
+                else LAUNCH((wide::k_node_pre<D>), p->n_strips * 3, 64, A);
             } else {
-                LAUNCH((wide::k_node_pre<D>), p->n_strips * 3, 64, A);
+                LAUNCH(k_pos_final, (p->Nn_pad + 255) / 256, 256, A);
+                if (l == 0) {
+                    A.pre_mode = 1;
+                    if (embed_merged) LAUNCH((k_pre_embed_w<D>), p->n_strips * 3 + p->n_items, 64, A);
+                    else LAUNCH((wide::k_node_pre<D>), p->n_strips * 3, 64, A);
+                }
             }
         }
         cur ^= 1;                                  // the block's positions are in pos_out now
@@ -307,8 +334,20 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
             } else {
                 if (d.r == 2) LAUNCH((wide::k_node_post<D, 2>), p->n_strips, 64, A); else LAUNCH((wide::k_node_post<D, 4>), p->n_strips, 64, A);
                 A.ab0 = 0; A.g0 = 0;
-                if (p->n_pitems > 0 && !pin_dir) LAUNCH((wide::k_node_ab<D>), p->n_strips * 2, 64, A);
-                if (A.rot && p->n_gtiles > 0) LAUNCH((wide::k_node_gram<D>), p->n_gtiles, 64, A);
+                const bool with_ab = p->n_pitems > 0 && !pin_dir;
+                if (ab_pre && l + 1 < nblocks) {
+                    static const int slots[6] = {JB_WQ, JB_BQ, JB_WK, JB_BK, JB_WV, JB_BV};
+                    for (int i = 0; i < 6; ++i) A.wbn[i] = woff[JW_GLOBAL_COUNT + (l + 1) * JB_BLOCK_COUNT + slots[i]];
+                    A.mod_base_next = 32 + (int64_t)(l + 1) * d.MB;
+                    A.mix_nw = 3 * p->n_strips;
+                    A.ab1 = with_ab ? 2 * p->n_strips : 0;
+                    A.g1 = (with_ab && A.rot) ? p->n_gtiles : 0;
+                    LAUNCH((k_node_ab_pre_w<D>), A.mix_nw + A.ab1 + A.g1, 64, A);
+                    A.mix_nw = 0;
+                } else {
+                    if (with_ab) LAUNCH((wide::k_node_ab<D>), p->n_strips * 2, 64, A);
+                    if (A.rot && p->n_gtiles > 0) LAUNCH((wide::k_node_gram<D>), p->n_gtiles, 64, A);
+                }
             }
         }
         if (p->n_items > 0) {

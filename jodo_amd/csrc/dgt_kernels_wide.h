@@ -125,13 +125,16 @@ __global__ __launch_bounds__(64) void k_embed_edges(KArgs A) { embed_edges_body<
 
 // ------------------------------------------------------------------------------------------------
 // node side
-template <int D>
-__global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
+// NEXT: the items of the FOLLOWING block (weights A.wbn, modulation row A.mod_base_next; h already holds that block's input), issued
+// from the launch that carries this block's k_node_ab items (k_node_ab_pre_w, dgt_forward.hip); positions are not touched.
+// A.pre_mode == 1: the positions come from k_pos_final (every block when the items ride with k_node_ab)
+template <int D, bool NEXT = false>
+__device__ __forceinline__ void node_pre_body(const KArgs& A, int blk) {
     using X = Dim<D>;
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
-    const int strip = blockIdx.x / 3, piece = blockIdx.x % 3;
+    const int strip = blk / 3, piece = blk % 3;
     const LaneNode L = lane_node(A, strip, j);
-    if (piece == 0) {
+    if (!NEXT && piece == 0 && A.pre_mode == 0) {
         float4 p = reinterpret_cast<const float4*>(A.pos_in)[L.v];
         if (A.layer > 0) {
             if (A.flags[FLAG_ASYM]) {
@@ -161,14 +164,14 @@ __global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
         }
         if (half == 0) reinterpret_cast<float4*>(A.pos_out)[L.v] = p;
     }
-    const float* mr = mod_row(A, L.b) + A.mod_base;
+    const float* mr = mod_row(A, L.b) + (NEXT ? A.mod_base_next : A.mod_base);
     float hx[X::HD];
     load_nat<X::ND>(A.h + (size_t)L.v * D, half, hx);
     layer_norm<X::HD>(hx);
     modulate<X::ND>(hx, mr, mr + D, half);
     const WSrc ws = make_wsrc(A.W, lane);
-    const unsigned woff = (unsigned)(A.wb[piece == 0 ? JB_WQ : (piece == 1 ? JB_WK : JB_WV)] * 4);
-    const float* bias = A.W + A.wb[piece == 0 ? JB_BQ : (piece == 1 ? JB_BK : JB_BV)];
+    const unsigned woff = (unsigned)((NEXT ? A.wbn[2 * piece] : A.wb[piece == 0 ? JB_WQ : (piece == 1 ? JB_WK : JB_WV)]) * 4);
+    const float* bias = A.W + (NEXT ? A.wbn[2 * piece + 1] : A.wb[piece == 0 ? JB_BQ : (piece == 1 ? JB_BK : JB_BV)]);
     float* outp = piece == 0 ? A.q : (piece == 1 ? A.k : A.v);
     const int nb = piece == 2 ? X::ND : NHEAD_BLOCKS;
     WPipe<X::PG> wp;
@@ -185,6 +188,8 @@ __global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) {
         store16T(outp, nb, L.v, half, b, r);
     }
 }
+template <int D>
+__global__ __launch_bounds__(64, 1) void k_node_pre(KArgs A) { node_pre_body<D, false>(A, (int)blockIdx.x); }
 
 template <int D, int R>
 __global__ __launch_bounds__(64, 1) void k_node_post(KArgs A) {

@@ -463,13 +463,13 @@ extern "C" int jodo_plan_work(const jodo_plan* p, int uniform_t, int symmetric, 
     for (int i = 0; i < p->n_items; ++i) dir_iters += dsc[p->off_item_t1 + i] - dsc[p->off_item_t0 + i];
     for (int i = 0; i < p->n_pitems; ++i) pair_iters += dsc[p->off_pitem_t1 + i] - dsc[p->off_pitem_t0 + i];
     // k_embed_edges: every dense row; under JODO_OPT_PRE_EMBED (tuned set) it runs inside the first block's node-pre launch
-    cls[(tuned && p->opt[JODO_OPT_PRE_EMBED] != 0 && L > 0) ? JODO_PROF_NODE_PRE : JODO_PROF_PROLOGUE] += dir_iters * proj(De, d.einp + De);
+    cls[(p->opt[JODO_OPT_PRE_EMBED] != 0 && L > 0) ? JODO_PROF_NODE_PRE : JODO_PROF_PROLOGUE] += dir_iters * proj(De, d.einp + De);
     // per block
     const int nqb = tuned ? 8 : d.SH;                                                    // 32-row blocks of q / k / lin_edge0
     const double qkv = 2.0 * nqb * (D / 2) + proj(D, D);
     const bool fuse_pre = tuned && p->opt[JODO_OPT_FUSE_NEXT_QKV] != 0 && L > 1 && p->n_strips >= 1024;
     // (k_node_ab_pre: below 1024 strips the following block's q / k / v items run in the node-post bracket as well)
-    const bool ab_pre = tuned && !fuse_pre && p->opt[JODO_OPT_AB_PRE] != 0 && L > 1 && p->n_strips < 1024 && p->opt[JODO_OPT_NODE_POST_WAVES] == 0;
+    const bool ab_pre = !fuse_pre && p->opt[JODO_OPT_AB_PRE] != 0 && L > 1 && (!tuned || (p->n_strips < 1024 && p->opt[JODO_OPT_NODE_POST_WAVES] == 0));
     cls[JODO_PROF_NODE_PRE] += strips * qkv * ((fuse_pre || ab_pre) ? 1 : L);
     if (fuse_pre || ab_pre) cls[JODO_PROF_NODE_POST] += strips * qkv * (L - 1);
     cls[JODO_PROF_NODE_POST] += L * strips * (proj(De, D) + proj(r * D, D) + proj(D, r * D) + 2 * proj(D, D) + proj(d.cnp, D));
