@@ -29,9 +29,15 @@ class ExponentialMovingAverage:
         if self.num_updates is not None:
             self.num_updates += 1
             d = min(d, (1 + self.num_updates) / (10 + self.num_updates))
+        # the reference's per-tensor `s.sub_((1 - d) * (s - p))` (models/ema.py:38-40) as three multi-tensor launches instead of
+        # 3 x 351: the same three roundings per element, bit-identical (tests/test_losses_host.py), 1 050 launches fewer per step
         with torch.no_grad():
-            for s, p in zip(self.shadow_params, self._trainable(parameters)):
-                s.sub_((1.0 - d) * (s - p))
+            params = self._trainable(parameters)
+            if len(params) != len(self.shadow_params):
+                raise ValueError(f'EMA holds {len(self.shadow_params)} tensors, the model has {len(params)} trainable parameters')
+            delta = torch._foreach_sub(self.shadow_params, params)
+            torch._foreach_mul_(delta, 1.0 - d)
+            torch._foreach_sub_(self.shadow_params, delta)
 
     def copy_to(self, parameters):
         params = self._trainable(parameters)

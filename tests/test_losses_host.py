@@ -97,3 +97,24 @@ def test_optimization_manager_warmup_and_adaptive_clipping():
     for v in (1, 2, 3, 4):
         q.add(v)
     assert q.items == [4, 3, 2] and q.mean() == 3.0 and abs(q.std() - np.std([4, 3, 2])) < 1e-12
+
+
+def test_ema_update_is_the_reference_recurrence_bit_for_bit():
+    """models/ema.py:31-40: decay warmed up as min(decay, (1 + k) / (10 + k)); shadow <- shadow - (1 - d)(shadow - p) evaluated with the
+    reference's three roundings per element (the multi-tensor form must not change a bit)."""
+    from jodo_amd.models.ema import ExponentialMovingAverage
+    g = torch.Generator().manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in [(7, 5), (33,), (2, 3, 4)]]
+    frozen = torch.nn.Parameter(torch.randn(4, generator=g), requires_grad=False)
+    ema = ExponentialMovingAverage(params + [frozen], decay=0.999)
+    want = [p.detach().clone() for p in params]
+    for k in range(1, 6):
+        with torch.no_grad():
+            for p in params:
+                p.add_(torch.randn(p.shape, generator=g) * 0.1)
+        ema.update(params + [frozen])
+        d = min(0.999, (1 + k) / (10 + k))
+        for w, p in zip(want, params):
+            w.sub_((1.0 - d) * (w - p.detach()))
+        assert ema.num_updates == k and len(ema.shadow_params) == 3
+        assert all(torch.equal(s, w) for s, w in zip(ema.shadow_params, want))

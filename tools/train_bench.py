@@ -67,6 +67,24 @@ def run(workload='qm9', batch=0, steps=10, warmup=3, seed=42):
         losses.append(float(step_fn(state, data)))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # where a step's wall time goes (host-synchronised sections over the same step, 6 repetitions)
+    loss_fn = L.get_sde_graph_loss_fn(ns, True, get_data_scaler(cfg), cfg, None)
+    opt_fn = L.optimization_manager(cfg)
+    sec = dict(loss_forward=0.0, backward=0.0, clip_and_optimizer=0.0, ema=0.0)
+    reps = 6
+    for _ in range(reps):
+        torch.cuda.synchronize(); t = [time.perf_counter()]
+        state['optimizer'].zero_grad()
+        loss = loss_fn(model, data)
+        torch.cuda.synchronize(); t.append(time.perf_counter())
+        loss.backward()
+        torch.cuda.synchronize(); t.append(time.perf_counter())
+        opt_fn(state['optimizer'], model.parameters(), step=state['step'])
+        torch.cuda.synchronize(); t.append(time.perf_counter())
+        state['ema'].update(model.parameters())
+        torch.cuda.synchronize(); t.append(time.perf_counter())
+        for k, a, b in zip(sec, t, t[1:]):
+            sec[k] += (b - a) * 1e3 / reps
     # forward / backward alone (no self-conditioning forward, no optimiser), HIP events
     from jodo_amd.sampling import build_masks
     nm, em = build_masks(n_nodes, max(n_nodes), dev)
@@ -91,7 +109,7 @@ def run(workload='qm9', batch=0, steps=10, warmup=3, seed=42):
     f_fwd = O.algorithmic_flops(hp, n_nodes, shared_time=False)['total']
     peak = 157.3e12
     return dict(workload=name, batch=B, steps=steps, s_per_step=dt, molecules_per_s=B / dt, loss_first=losses[0], loss_last=losses[-1],
-                forward_ms=fwd, backward_ms=bwd, forward_algorithmic_flops=f_fwd,
+                forward_ms=fwd, backward_ms=bwd, sections_ms=sec, forward_algorithmic_flops=f_fwd,
                 forward_frac_of_fp32_mfma_peak=f_fwd / (fwd * 1e-3) / peak, backward_frac_of_fp32_mfma_peak=2 * f_fwd / (bwd * 1e-3) / peak,
                 note='one optimiser step = (50 %: no-grad self-conditioning forward) + grad forward + backward + AdamW / clipping / EMA; '
                      'forward_ms / backward_ms: one grad-enabled forward and its backward alone (HIP events); fractions price the '
