@@ -13,6 +13,8 @@
 // Bounds are checked on every edge (N = 3, K = 17 and ragged row counts all occur; unaligned operands take an element-wise path).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
+#include <cstdlib>
 #include "train_gemm.h"
 
 namespace jt {
@@ -185,6 +187,9 @@ static void launch(hipStream_t s, int tA, int tB, dim3 grid, int M, int N, int K
 void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
           const float* bias, int acc, float* ws, size_t ws_floats, const GemmEpi* epi_in) {
     if (M <= 0 || N <= 0) return;
+    // JODO_TRAIN_GEMM_LOG=<file>: one line per product (tools/train_gemm_shapes.py ranks a step's products by shape)
+    static FILE* shape_log = [] { const char* f = getenv("JODO_TRAIN_GEMM_LOG"); return f ? fopen(f, "a") : (FILE*)nullptr; }();
+    if (shape_log) { fprintf(shape_log, "%d %d %d %d %d %d %d %d\n", tA, tB, M, N, K, lda, ldb, ldc); fflush(shape_log); }
     GemmEpi epi;
     if (epi_in) epi = *epi_in; else { epi.act = 0; epi.out2 = nullptr; epi.drop.p = 0.f; epi.drop.seed = 0; epi.drop.site = 0; epi.dbias = nullptr; }
     const GemmPlan p = gemm_plan(tA, M, N, K, ws != nullptr, ws_floats);
