@@ -103,7 +103,7 @@ struct RowGemmArgs {
     float* Ysilu;                            // nullable: SiLU(Y) [rows, ldy]
 };
 
-__global__ __launch_bounds__(64) void k_rowgemm(RowGemmArgs G) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_rowgemm(RowGemmArgs G) {
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
     const int rows = (G.uniform_flag && *G.uniform_flag) ? 1 : G.rows;
     const int r0 = blockIdx.x * 32;

@@ -50,8 +50,12 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
         }
     }
 }
-template <bool KC, int R>
-__device__ __forceinline__ void store_tile(float (*S)[64 * R + 4], int tid, const float (&r)[8 * R]) {
+// LDS row length: k-contiguous operands are transposed on the way in (four 4-byte stores per quad; a wave covers 8 quads of k x 8 rows):
+// with 64 R + 2 words per k row the 64 lanes fall on every bank exactly twice (the minimum; 64 R + 4 put them on 8 banks, eight deep:
+// SQ_LDS_BANK_CONFLICT was 1.3 cycles per LDS instruction).  The other layout stores whole quads and needs 16-byte rows.
+template <bool KC, int R> struct TileLd { static constexpr int value = 64 * R + (KC ? 2 : 4); };
+template <bool KC, int R, int LD>
+__device__ __forceinline__ void store_tile(float (*S)[LD], int tid, const float (&r)[8 * R]) {
 #pragma unroll
     for (int e = 0; e < 2 * R; ++e) {
         int i, kk;
@@ -68,8 +72,8 @@ __device__ __forceinline__ void store_tile(float (*S)[64 * R + 4], int tid, cons
 template <bool TA, bool TB, int RM, int RN>
 __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                               float* __restrict__ C, int ldc, const float* __restrict__ bias, int acc, float* __restrict__ part, int vecA, int vecB, GemmEpi epi) {
-    __shared__ __attribute__((aligned(16))) float As[TK][64 * RM + 4];
-    __shared__ __attribute__((aligned(16))) float Bs[TK][64 * RN + 4];
+    __shared__ __attribute__((aligned(16))) float As[TK][TileLd<!TA, RM>::value];
+    __shared__ __attribute__((aligned(16))) float Bs[TK][TileLd<TB, RN>::value];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 64 * RM, n0 = blockIdx.x * 64 * RN;
     const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);

@@ -135,6 +135,11 @@ def test_edge_ffn_backward_rejects_other_shapes():
     (1, 0, 3, 256, 9000, 0, False, 1),
     (1, 0, 252, 64, 1187, 1, False, 0),       # lin_edge0: 252 rows of dW
     (1, 1, 70, 33, 129, 0, True, 2),
+    (0, 1, 9001, 256, 256, 0, True, 0),       # edge-row counts: hundreds of row tiles, ragged last one
+    (0, 1, 8200, 64, 64, 1, True, 0),         # ... accumulating, one column tile
+    (0, 0, 9001, 64, 256, 1, False, 0),       # ... input gradient
+    (0, 0, 8193, 256, 128, 0, False, 0),
+    (0, 1, 9001, 256, 256, 0, True, 2),       # the same shape with unaligned rows: the element-wise load path
 ])
 def test_train_gemm_matches_float64(tA, tB, M, N, K, acc, bias, pad):
     import ctypes
@@ -396,6 +401,52 @@ def test_train_gemm_bias_gradient_rides_on_the_weight_gradient(M, N, K):
     torch.cuda.synchronize()
     close(dW, dW0.double() + dY.double().t() @ X.double(), atol=2e-6 * (K ** 0.5) * 4, rtol=2e-5)
     close(db, db0.double() + dY.double().sum(0), atol=2e-6 * (K ** 0.5), rtol=2e-5)
+
+
+@pytest.mark.parametrize("tB", [1, 0])
+def test_train_gemm_on_slices_of_wider_operands(tB):
+    """The product as the training step calls it: the weight a column slice of a concatenated projection (ldb 640), the input and
+    the output column slices of wider buffers, bias and accumulation — against float64, and nothing written outside the slice."""
+    import ctypes
+    from jodo_amd import capi
+    g = torch.Generator().manual_seed(5 + tB)
+    M, N, K = 10007, 128, 192
+    Xw = torch.randn(M, 320, generator=g)                              # X = Xw[:, 64:64 + K]
+    Ww = torch.randn((N, 640) if tB else (K, 640), generator=g) / 8    # W = Ww[:, 256:256 + K] (tB) | Ww[:, 256:256 + N]
+    Cw0 = torch.randn(M, 200, generator=g)                             # C = Cw[:, 32:32 + N]
+    bias = torch.randn(N, generator=g)
+    w = Ww[:, 256:256 + K].t() if tB else Ww[:, 256:256 + N]
+    want = Cw0[:, 32:32 + N].double() + Xw[:, 64:64 + K].double() @ w.double() + bias.double()
+    Xd, Wd, Cd, bd = Xw.to(DEV), Ww.to(DEV), Cw0.clone().to(DEV), bias.to(DEV)
+    ws = torch.empty(8 << 20, device=DEV)
+    capi.check(capi.lib().jodo_train_gemm(0, tB, M, N, K, ctypes.c_void_p(Xd.data_ptr() + 64 * 4), 320, ctypes.c_void_p(Wd.data_ptr() + 256 * 4), 640,
+                                          ctypes.c_void_p(Cd.data_ptr() + 32 * 4), 200, capi.ptr(bd), 1, capi.ptr(ws), ctypes.c_size_t(ws.numel()),
+                                          capi.current_stream_ptr()), 'jodo_train_gemm')
+    torch.cuda.synchronize()
+    got = Cd.cpu()
+    assert torch.equal(got[:, :32], Cw0[:, :32]) and torch.equal(got[:, 32 + N:], Cw0[:, 32 + N:])
+    close(got[:, 32:32 + N], want, atol=2e-6 * (K ** 0.5) * 4, rtol=2e-5)
+
+
+@pytest.mark.parametrize("act", [1, 2])
+def test_train_gemm_fused_activations_many_rows(act):
+    import ctypes
+    from jodo_amd import capi
+    g = torch.Generator().manual_seed(act)
+    M, N, K = 8300, 128, 64
+    X, W, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / 8, torch.randn(N, generator=g)
+    C, out2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    Xd, Wd, bd = X.to(DEV), W.to(DEV), bias.to(DEV)
+    ws = torch.empty(1 << 20, device=DEV)
+    capi.check(capi.lib().jodo_train_gemm_ex(0, 1, M, N, K, capi.ptr(Xd), K, capi.ptr(Wd), K, capi.ptr(C), N, capi.ptr(bd), act, capi.ptr(out2), None, capi.ptr(ws),
+                                             ctypes.c_size_t(ws.numel()), capi.current_stream_ptr()), 'jodo_train_gemm_ex')
+    torch.cuda.synchronize()
+    pre = X.double() @ W.double().t() + bias.double()
+    if act == 1:
+        close(C, torch.tanh(pre), atol=2e-6)
+    else:
+        close(C, pre, atol=1e-5)
+        close(out2, torch.nn.functional.silu(pre), atol=1e-5)
 
 
 @pytest.mark.parametrize("act", [1, 2])
