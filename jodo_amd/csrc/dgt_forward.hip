@@ -61,8 +61,10 @@ int rowgemm(hipStream_t st, const float* X, int64_t ldx, float* Y, int64_t ldy, 
     // few rows (the sampling case: one shared time row): one output block per wave so that the launch
     // still has hundreds of waves; many rows: four blocks per wave to reuse the activation chunk
     const int nob = (rows <= 64 || uniform_flag) ? 1 : 4;
-    RowGemmArgs G{X, ldx, Y, ldy, Wp, bias, rows, K, NB, in_act, accumulate, uniform_flag, nob, Ysilu};
+    const int gx = uniform_flag ? 1 : 0;
+    RowGemmArgs G{X, ldx, Y, ldy, Wp, bias, rows, K, NB, in_act, accumulate, uniform_flag, nob, gx, Ysilu};
     dim3 grid((rows + 31) / 32, (NB + nob - 1) / nob);
+    if (gx) grid = dim3(grid.y, grid.x);
     hipLaunchKernelGGL(k_rowgemm, grid, dim3(64), 0, st, G);
     return jodo_check_launch("k_rowgemm");
 }

@@ -100,17 +100,21 @@ struct RowGemmArgs {
     int accumulate;                          // Y += result
     const int* uniform_flag;                 // if non-null and *flag != 0: only row 0 is computed
     int nob;                                 // output blocks per wave (1 for few rows: more waves; 4 otherwise)
+    int groups_in_x;                         // grid = (output groups, row strips) instead of (row strips, output groups), see k_rowgemm
     float* Ysilu;                            // nullable: SiLU(Y) [rows, ldy]
 };
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_rowgemm(RowGemmArgs G) {
     const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
     const int rows = (G.uniform_flag && *G.uniform_flag) ? 1 : G.rows;
-    const int r0 = blockIdx.x * 32;
+    // With a shared time row only strip 0 works.  Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest): with the
+    // strips in x, strip 0's workgroups are the ids 0, S, 2 S, ... — for S = 16 (GEOM B = 512) or 40 (B = 1250) all on XCD 0, and the
+    // modulation projection ran on 32 of the 256 CUs (322 us per forward at GEOM nf 256; 43 us at QM9, where S = 79 is odd).
+    const int r0 = (G.groups_in_x ? blockIdx.y : blockIdx.x) * 32;
     if (r0 >= rows) return;
     const int row = r0 + j;
     const int rowc = row < rows ? row : rows - 1;
-    const int ob0 = blockIdx.y * G.nob;
+    const int ob0 = (G.groups_in_x ? blockIdx.x : blockIdx.y) * G.nob;
     const int nv = G.NB - ob0 < G.nob ? G.NB - ob0 : G.nob;          // output blocks of this wave (1..4)
     const int kq = G.K / 8, nch = G.K / 64;  // quads per output block, activation chunks
     f32x16 acc[4];
