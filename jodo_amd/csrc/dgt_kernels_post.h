@@ -22,9 +22,18 @@ __global__ void k_pos_final(KArgs A) {
             } else {
                 const int n = A.pd.node_n[v], i = A.pd.node_i[v];
                 const float4* row = reinterpret_cast<const float4*>(A.dposE) + (size_t)A.pd.node_eoff[v] + (size_t)i * n;
-                // four rows in flight per step, added in column order (the sum is bit-identical to the one-load-per-iteration loop,
-                // which paid one exposed L2 round trip per neighbour: 15 us per launch at QM9 B = 2500, nine launches per forward)
+                // eight, then four rows in flight per step, added in column order (the sum is bit-identical to the one-load-per-iteration
+                // loop, which paid one exposed L2 round trip per neighbour: 15 us per launch at QM9 B = 2500, nine launches per forward;
+                // GEOM molecules have up to 181 atoms: 23 us per launch at four in flight)
                 int c = 0;
+                for (; c + 8 <= n; c += 8) {
+                    float4 d[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) d[u] = row[c + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (c + u != i) { p.x += d[u].x; p.y += d[u].y; p.z += d[u].z; }
+                }
                 for (; c + 4 <= n; c += 4) {
                     const float4 d0 = row[c], d1 = row[c + 1], d2 = row[c + 2], d3 = row[c + 3];
                     if (c != i) { p.x += d0.x; p.y += d0.y; p.z += d0.z; }
