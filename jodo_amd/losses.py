@@ -11,6 +11,7 @@
 The arithmetic of the model call — forward with kept activations and loss.backward() — is jodo_train_forward / jodo_train_backward
 (csrc/dgt_train.hip) behind models/dgt.py; everything here is the thin tensor algebra the reference also keeps in Python.
 """
+import os
 import random
 
 import numpy as np
@@ -22,11 +23,17 @@ from .utils import expand_dims, get_self_cond_fn
 
 
 def get_optimizer(config, params):
+    """losses.py:14-27 of the reference: the same torch optimisers with the same hyper-parameters.  On the GPU the update runs as
+    torch's fused multi-tensor kernel (one launch over all 351 tensors instead of a dozen foreach passes: clipping + update 4.0 -> 3.3 ms
+    per step at QM9, 2.6 ms with the clipping on the flat gradient buffer below);
+    JODO_OPTIM_FUSED=0 keeps torch's default implementation."""
     o = config.optim
+    params = list(params)
+    fused = bool(params) and all(p.is_cuda for p in params) and os.environ.get('JODO_OPTIM_FUSED', '1') != '0'
     if o.optimizer == 'Adam':
-        return torch.optim.Adam(params, lr=o.lr, betas=(o.beta1, 0.999), eps=o.eps, weight_decay=o.weight_decay)
+        return torch.optim.Adam(params, lr=o.lr, betas=(o.beta1, 0.999), eps=o.eps, weight_decay=o.weight_decay, fused=fused or None)
     if o.optimizer == 'AdamW':
-        return torch.optim.AdamW(params, lr=o.lr, amsgrad=True, weight_decay=1e-12)
+        return torch.optim.AdamW(params, lr=o.lr, amsgrad=True, weight_decay=1e-12, fused=fused or None)
     raise NotImplementedError(f'Optimizer {o.optimizer} not supported yet!')
 
 
@@ -50,15 +57,54 @@ class Queue:
         return np.std(self.items)
 
 
+def _flat_gradient(params):
+    """The one buffer every p.grad is a slice of (jodo_train_backward writes all gradients into one allocation, jodo_amd/train.py;
+    autograd hands the slices to p.grad without copying), as a 1-D tensor over that storage — or None when the gradients are ordinary
+    separate tensors, or do not tile their storage exactly."""
+    store, spans, dtype = None, [], None
+    for p in params:
+        g = p.grad
+        if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+            return None
+        st = g.untyped_storage()
+        if store is None:
+            store, dtype = st, g.dtype
+        elif st.data_ptr() != store.data_ptr():
+            return None
+        spans.append((g.storage_offset(), g.numel()))
+    if store is None:
+        return None
+    spans.sort()
+    at = 0
+    for off, n in spans:
+        if off != at:
+            return None
+        at += n
+    if at * 4 != store.nbytes():
+        return None
+    return torch.empty(0, dtype=dtype, device=params[0].grad.device).set_(store, 0, (at,))
+
+
+def _clip_grad_norm(params, max_norm):
+    """torch.nn.utils.clip_grad_norm_(params, max_norm, 2.0) — on the flat gradient buffer two launches instead of a multi-tensor
+    pass over 351 tensors each for the norms and for the scaling (the same formula: coef = min(1, max_norm / (norm + 1e-6)))."""
+    flat = _flat_gradient(params)
+    if flat is None:
+        return torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm, norm_type=2.0)
+    total = torch.linalg.vector_norm(flat, 2.0)
+    flat.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
+    return total
+
+
 def gradient_clipping(params, gradnorm_queue, max_grad, disable_log):
     """max_grad <= 1: plain norm clipping.  Otherwise the allowed norm follows the recent history: 1.5 x mean + 2 x std of
     the queue, capped at max_grad; the (clipped) norm is pushed to the queue."""
     params = list(params)
     if max_grad <= 1.0:
-        torch.nn.utils.clip_grad_norm_(params, max_norm=max_grad)
+        _clip_grad_norm(params, max_grad)
         return None
     allowed = min(1.5 * gradnorm_queue.mean() + 2 * gradnorm_queue.std(), max_grad)
-    grad_norm = torch.nn.utils.clip_grad_norm_(params, max_norm=allowed, norm_type=2.0)
+    grad_norm = _clip_grad_norm(params, float(allowed))
     gradnorm_queue.add(float(min(float(grad_norm), allowed)))
     if not disable_log and float(grad_norm) > 1.5 * gradnorm_queue.mean() + 2 * gradnorm_queue.std():
         print(f'Clipped gradient with value {grad_norm:.1f} while allowed {allowed:.1f}')

@@ -118,3 +118,31 @@ def test_ema_update_is_the_reference_recurrence_bit_for_bit():
             w.sub_((1.0 - d) * (w - p.detach()))
         assert ema.num_updates == k and len(ema.shadow_params) == 3
         assert all(torch.equal(s, w) for s, w in zip(ema.shadow_params, want))
+
+
+def test_clipping_on_the_flat_gradient_buffer_is_clip_grad_norm():
+    """jodo_train_backward hands out gradients that are slices of one buffer; gradient_clipping then takes the norm of and scales the
+    buffer itself.  Same norm and same clipped gradients as torch.nn.utils.clip_grad_norm_ on separate tensors (losses.py:29-50)."""
+    from jodo_amd import losses as L
+    g = torch.Generator().manual_seed(3)
+    shapes = [(5, 7), (11,), (2, 3, 2)]
+    flat = torch.randn(sum(torch.Size(s).numel() for s in shapes), generator=g) * 10
+    a = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    b = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    off = 0
+    for pa, pb in zip(a, b):
+        n = pa.numel()
+        pa.grad = flat[off:off + n].view(pa.shape).detach()          # what autograd leaves in p.grad: an alias without a base
+        pb.grad = flat[off:off + n].view(pb.shape).clone()
+        off += n
+    fa = L._flat_gradient(a)
+    assert fa is not None and fa.data_ptr() == flat.data_ptr() and fa.shape == flat.shape and L._flat_gradient(b) is None
+    want = torch.nn.utils.clip_grad_norm_(b, max_norm=2.5, norm_type=2.0)
+    got = L._clip_grad_norm(a, 2.5)
+    assert abs(float(got) - float(want)) <= 1e-6 * float(want)
+    for pa, pb in zip(a, b):
+        assert torch.allclose(pa.grad, pb.grad, rtol=1e-6, atol=0)
+    # a partial cover of the buffer (another tensor lives in it) is not taken for the flat case
+    assert L._flat_gradient([a[0], a[1]]) is None
+    q = L.Queue(); q.add(3000)
+    assert float(L.gradient_clipping(a, q, 1000.0, True)) > 0

@@ -331,6 +331,8 @@ def test_training_steps_through_get_step_fn():
     before = make_model(cfg, 6, DEV).state_dict()
     model, state, losses = run(3)
     assert model.training and all(np.isfinite(losses)) and state['step'] == 4
+    # the gradients are slices of the one buffer jodo_train_backward filled: the clipping ran on that buffer (two launches)
+    assert L._flat_gradient(list(model.parameters())) is not None
     moved = [k for k, v in model.state_dict().items() if not torch.equal(v, before[k])]
     assert len(moved) == len(before)
     model2, _, losses2 = run(3)
