@@ -178,6 +178,31 @@ __global__ void k_splitk_sum(int M, int N, int nsplit, const float* __restrict__
     *o = acc ? *o + s : s;
 }
 
+// first level of the two-level sum (gemm_plan group > 0): group g of `group` consecutive slices -> out[g]; tiles first ([nsplit][M N] ->
+// [ngroups][M N]), then the partial bias sums behind them ([nsplit][M] -> [ngroups][M]); eight slices in flight, added in slice order
+__global__ void k_splitk_group(long MN, int M, int nsplit, int group, int ngroups, int with_bias, const float* __restrict__ part, float* __restrict__ out) {
+    const long per = MN + (with_bias ? M : 0);
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per * ngroups) return;
+    const int g = (int)(t / per);
+    const long i = t % per;
+    const bool is_bias = i >= MN;
+    const float* src = is_bias ? part + (long)nsplit * MN + (i - MN) : part + i;
+    const long stride = is_bias ? M : MN;
+    const int z0 = g * group, z1 = min(nsplit, z0 + group);
+    float s = 0.f;
+    int z = z0;
+    for (; z + 8 <= z1; z += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(long)(z + j) * stride];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; z < z1; ++z) s += src[(long)z * stride];
+    out[is_bias ? (long)ngroups * MN + (long)g * M + (i - MN) : (long)g * MN + i] = s;
+}
+
 template <int RM, int RN>
 static void launch(hipStream_t s, int tA, int tB, dim3 grid, int M, int N, int K, int kchunk, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                    const float* bias, int acc, float* part, int vecA, int vecB, GemmEpi epi) {
@@ -207,8 +232,17 @@ void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, in
     else if (p.rm == 2) launch<2, 1>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
     else if (p.rn == 2) launch<1, 2>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
     else launch<1, 1>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
-    if (p.nsplit > 1)
-        hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, s, M, N, p.nsplit, part, C, ldc, bias, acc, epi);
+    if (p.nsplit > 1) {
+        int nfinal = p.nsplit;
+        if (p.group > 0) {
+            const int ngroups = (p.nsplit + p.group - 1) / p.group;
+            const long MN = (long)M * N, per = MN + (epi.dbias ? M : 0);
+            float* part2 = part + (size_t)p.nsplit * ((size_t)MN + M);
+            hipLaunchKernelGGL(k_splitk_group, dim3((unsigned)((per * ngroups + 255) / 256)), dim3(256), 0, s, MN, M, p.nsplit, p.group, ngroups, epi.dbias ? 1 : 0, part, part2);
+            part = part2; nfinal = ngroups;
+        }
+        hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, s, M, N, nfinal, part, C, ldc, bias, acc, epi);
+    }
 }
 
 }  // namespace jt
