@@ -53,7 +53,7 @@ inline GemmPlan gemm_plan(int tA, int M, int N, int K, bool have_ws, size_t ws_f
             if (nsplit > 256 / tiles) nsplit = (int)(256 / tiles);
         }
         long cap = (long)(ws_floats / ((size_t)M * N + (size_t)M));             // partial tiles + partial bias sums
-        if (tA) cap = cap * 16 / 17;                                             // + the group sums of the two-level form
+        if (tA) cap = (cap - 1) * 16 / 17;                                       // + the group sums of the two-level form (ceil(nsplit / 16) more)
         if (nsplit > cap) nsplit = (int)cap;
         if (nsplit > 512) nsplit = 512;
         if (nsplit < 1) nsplit = 1;
