@@ -75,7 +75,20 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, c
     __shared__ __attribute__((aligned(16))) float As[TK][TileLd<!TA, RM>::value];
     __shared__ __attribute__((aligned(16))) float Bs[TK][TileLd<TB, RN>::value];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 64 * RM, n0 = blockIdx.x * 64 * RN;
+    // Workgroups go to the 8 XCDs (one L2 each) round-robin in dispatch order, x fastest: the column tiles of one row tile — which read
+    // the same 64 rows of A — would land on different XCDs and fetch those rows once each (N = 256: four times).  Remapped so that a
+    // row tile's column tiles are the ids xcd, xcd + 8, xcd + 16, ...: same XCD, dispatched together.  (Whole groups of 8 row tiles
+    // only; the remainder and split-K launches keep the plain order.)
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.x > 1 && gridDim.z == 1) {
+        const int NT = gridDim.x, lin = blockIdx.y * NT + blockIdx.x;
+        if (lin < NT * 8 * ((int)gridDim.y / 8)) {
+            const int xcd = lin & 7, slot = lin >> 3;
+            by = (slot / NT) * 8 + xcd;
+            bx = slot % NT;
+        }
+    }
+    const int m0 = by * 64 * RM, n0 = bx * 64 * RN;
     const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
     const int wm = (wave >> 1) * 32 * RM, wn = (wave & 1) * 32 * RN;
     // two accumulator chains per block, taken in turn by the k-pairs (weight gradients contract over every row of the batch; a single
@@ -91,7 +104,7 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, c
                 for (int i = 0; i < 16; ++i) c[r][q][j][i] = 0.f;
     float ra[8 * RM], rb[8 * RN];
     double bsum = 0.0;                                       // epi.dbias: column sum of this workgroup's dY tiles (threads 0 .. 64 RM - 1)
-    const bool do_bias = TA && epi.dbias != nullptr && blockIdx.x == 0 && tid < 64 * RM;
+    const bool do_bias = TA && epi.dbias != nullptr && bx == 0 && tid < 64 * RM;
     // A is k-contiguous unless transposed; B (stored [N, K] when TB) is k-contiguous when TB
     if (kbeg < kend) {
         load_tile<!TA, RM>(A, lda, m0, M, kbeg, kend, vecA != 0, tid, ra);
