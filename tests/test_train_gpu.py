@@ -264,6 +264,9 @@ def test_loss_backward_on_the_module_reproduces_the_reference_gradients():
     # 19 - 23 x further on two bias gradients (reproduced to three digits by the CPU emulation build, tests/emul); at gain 1 they
     # sit on float32 autograd's own error (ratio ~1, all within 3e-4)
     ('vpsde_geom_uncond_jodo', [9, 31], dict(nf=128, n_layers=6), False, 1.0),
+    # the largest GEOM molecule (181 atoms: 32 761 edge rows in one molecule — several chunks of the two-level per-molecule sums, 181-term
+    # attention columns) next to the smallest
+    ('vpsde_geom_uncond_jodo', [181, 2], dict(nf=128, n_layers=2), True, 1.0),
 ])
 def test_parameter_gradients_match_autograd_through_the_oracle(cfg_name, n_nodes, over, selfcond, gain):
     cfg = make_config(cfg_name, **over)
