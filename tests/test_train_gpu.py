@@ -472,3 +472,54 @@ def test_train_gemm_fused_activations(act):
     else:
         close(C, pre, atol=1e-5)
         close(out2, torch.nn.functional.silu(pre), atol=1e-5)
+
+
+def test_full_training_batch_backward_is_linear_and_matches_the_oracle_on_a_slice():
+    """The config's own training batch (128 QM9 molecules from the dataset's atom-count histogram, ~43 000 edge rows), dropout on.
+    Size-independent properties of the backward: it is linear in the output gradient (grads(a d1 + b d2) == a grads(d1) + b grads(d2),
+    three backwards on one forward's activations) and a replay is bit-identical.  And the forward of the full batch equals the forward of
+    a slice of it evaluated alone (molecules do not interact), which the float64 oracle then checks at a size it finishes in seconds."""
+    from jodo_amd.models import load_dataset_info, get_node_dist
+    from jodo_amd.train import TrainEngine
+    from helpers import random_inputs
+    cfg = make_config('vpsde_qm9_uncond_jodo')
+    model = make_model(cfg, 8, DEV)
+    hp = O.Hyper.from_config(cfg)
+    torch.manual_seed(5)
+    n_nodes = get_node_dist(load_dataset_info('qm9_with_h')).sample(int(cfg.training.batch_size)).tolist()
+    xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=3)
+    d = lambda x: x.to(DEV)
+    named = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    eng = TrainEngine(model._cfg(), n_nodes, max(n_nodes), named, DEV)
+    params = [v.detach().float().contiguous() for v in model.state_dict().values()]
+    p, seed = 0.1, 77
+    ox, oe = eng.forward(params, d(xh), d(ex), None, None, d(nl), None, p, seed)
+    assert eng.flags.tolist()[0] == 0 and torch.isfinite(ox).all() and torch.isfinite(oe).all()
+    g = torch.Generator().manual_seed(1)
+    d1x, d1e, d2x, d2e = (torch.randn(s, generator=g).to(DEV) for s in (xh.shape, ex.shape, xh.shape, ex.shape))
+    g1 = [t.clone() for t in eng.backward(params, d(nl), d1x, d1e, p, seed)]
+    g2 = [t.clone() for t in eng.backward(params, d(nl), d2x, d2e, p, seed)]
+    g3 = eng.backward(params, d(nl), 0.5 * d1x - 2.0 * d2x, 0.5 * d1e - 2.0 * d2e, p, seed)
+    bad = []
+    for (name, _), a, b, c in zip(named, g1, g2, g3):
+        want = 0.5 * a.double() - 2.0 * b.double()
+        scale = max(float(a.abs().max()), float(b.abs().max()), 1e-12)
+        err = float((c.double() - want).abs().max())
+        if err > 2e-4 * scale:
+            bad.append('%s: %.3e of %.3e' % (name, err, scale))
+    assert not bad, bad[:10]
+    assert all(torch.equal(a, b) for a, b in zip(g1, eng.backward(params, d(nl), d1x, d1e, p, seed)))
+    # molecules do not interact: eval-mode forward of the full batch == forward of its first six molecules alone == float64 oracle
+    ox0, oe0 = eng.forward(params, d(xh), d(ex), None, None, d(nl), None, 0.0, 0)
+    k = 6
+    sub = n_nodes[:k]
+    Ns = max(sub)
+    nm_s, em_s = masks(sub)
+    xs, es, nls = xh[:k, :Ns] * nm_s, ex[:k, :Ns, :Ns] * em_s.reshape(k, Ns, Ns, 1), nl[:k]
+    eng_s = TrainEngine(model._cfg(), sub, Ns, named, DEV)
+    oxs, oes = eng_s.forward(params, d(xs.contiguous()), d(es.contiguous()), None, None, d(nls.contiguous()), None, 0.0, 0)
+    assert (ox0[:k, :Ns].cpu() * nm_s - oxs.cpu()).abs().max() < 2e-5 and (oe0[:k, :Ns, :Ns].cpu() * em_s.reshape(k, Ns, Ns, 1) - oes.cpu()).abs().max() < 2e-5
+    sd = {kk: v.detach().cpu().double() for kk, v in model.state_dict().items()}
+    px, pe = O.forward_dense(sd, hp, xs.double(), nm_s.double(), em_s.double(), es.double(), None, None, nls.double(), None)
+    close(oxs, px, atol=2e-5, rtol=1e-4)
+    close(oes, pe, atol=2e-5, rtol=1e-4)
