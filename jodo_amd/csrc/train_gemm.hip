@@ -50,6 +50,22 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
         }
     }
 }
+// The same without a single branch, for tiles whose K extent is whole and whose operands are 16-byte addressable (FAST): rows / columns
+// past the edge are clamped to the last valid ones — they only feed outputs that are never stored — so every load is unconditional and
+// the compiler can count them: several tiles then really stay in flight (around the bounds branches it waits for every load issued).
+template <bool KC, int R>
+__device__ __forceinline__ void load_tile_fast(const float* __restrict__ P, int ld, int i0, int imax, int k0, int tid, float (&r)[8 * R]) {
+#pragma unroll
+    for (int e = 0; e < 2 * R; ++e) {
+        int i, kk;
+        tile_pos<KC, R>(tid, e, i, kk);
+        int gi = i0 + i;
+        const int gk = k0 + kk;
+        if (KC) gi = gi < imax ? gi : imax - 1; else gi = gi + 3 < imax ? gi : imax - 4;
+        const float4 v = *reinterpret_cast<const float4*>(KC ? P + (long)gi * ld + gk : P + (long)gk * ld + gi);
+        r[e * 4 + 0] = v.x; r[e * 4 + 1] = v.y; r[e * 4 + 2] = v.z; r[e * 4 + 3] = v.w;
+    }
+}
 // LDS row length: k-contiguous operands are transposed on the way in (four 4-byte stores per quad; a wave covers 8 quads of k x 8 rows):
 // with 64 R + 2 words per k row the 64 lanes fall on every bank exactly twice (the minimum; 64 R + 4 put them on 8 banks, eight deep:
 // SQ_LDS_BANK_CONFLICT was 1.3 cycles per LDS instruction).  The other layout stores whole quads and needs 16-byte rows.
@@ -69,7 +85,10 @@ __device__ __forceinline__ void store_tile(float (*S)[LD], int tid, const float 
     }
 }
 
-template <bool TA, bool TB, int RM, int RN>
+// PF (FAST only): operand tiles in flight.  1: the next tile travels while the current one is multiplied — enough where five to seven
+// workgroups per CU cover each other's waits; 4: launches of fewer workgroups than the chip has SIMDs (node- and molecule-level products:
+// [2 260 x 256 x 256] is 144 workgroups of eight dependent K steps, each an exposed load latency).  Same arithmetic, same order.
+template <bool TA, bool TB, int RM, int RN, bool FAST, int PF>
 __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                               float* __restrict__ C, int ldc, const float* __restrict__ bias, int acc, float* __restrict__ part, int vecA, int vecB, GemmEpi epi) {
     __shared__ __attribute__((aligned(16))) float As[TK][TileLd<!TA, RM>::value];
@@ -102,40 +121,51 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, c
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) c[r][q][j][i] = 0.f;
-    float ra[8 * RM], rb[8 * RN];
+    float ra[PF][8 * RM], rb[PF][8 * RN];
     double bsum = 0.0;                                       // epi.dbias: column sum of this workgroup's dY tiles (threads 0 .. 64 RM - 1)
     const bool do_bias = TA && epi.dbias != nullptr && bx == 0 && tid < 64 * RM;
     // A is k-contiguous unless transposed; B (stored [N, K] when TB) is k-contiguous when TB
-    if (kbeg < kend) {
-        load_tile<!TA, RM>(A, lda, m0, M, kbeg, kend, vecA != 0, tid, ra);
-        load_tile<TB, RN>(B, ldb, n0, N, kbeg, kend, vecB != 0, tid, rb);
-    }
-    for (int k0 = kbeg; k0 < kend; k0 += TK) {
-        store_tile<!TA, RM>(As, tid, ra);
-        store_tile<TB, RN>(Bs, tid, rb);
-        __syncthreads();
-        if (do_bias) {
-#pragma unroll
-            for (int kk = 0; kk < TK; ++kk) bsum += (double)As[kk][tid];
+    auto fetch = [&](int u, int k0) {
+        if (FAST) {
+            load_tile_fast<!TA, RM>(A, lda, m0, M, k0, tid, ra[u]);
+            load_tile_fast<TB, RN>(B, ldb, n0, N, k0, tid, rb[u]);
+        } else {
+            load_tile<!TA, RM>(A, lda, m0, M, k0, kend, vecA != 0, tid, ra[u]);
+            load_tile<TB, RN>(B, ldb, n0, N, k0, kend, vecB != 0, tid, rb[u]);
         }
-        if (k0 + TK < kend) {                                // the next tile travels while this one is multiplied
-            load_tile<!TA, RM>(A, lda, m0, M, k0 + TK, kend, vecA != 0, tid, ra);
-            load_tile<TB, RN>(B, ldb, n0, N, k0 + TK, kend, vecB != 0, tid, rb);
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (kbeg + u * TK < kend) fetch(u, kbeg + u * TK);
+    for (int kb = kbeg; kb < kend; kb += PF * TK) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int k0 = kb + u * TK;
+            if (k0 < kend) {                                     // (uniform over the workgroup: the barriers below are safe)
+                store_tile<!TA, RM>(As, tid, ra[u]);
+                store_tile<TB, RN>(Bs, tid, rb[u]);
+                __syncthreads();
+                if (do_bias) {
+#pragma unroll
+                    for (int kk = 0; kk < TK; ++kk) bsum += (double)As[kk][tid];
+                }
+                if (k0 + PF * TK < kend) fetch(u, k0 + PF * TK);  // refill the slot just consumed: PF tiles stay in flight
+#pragma unroll
+                for (int kk = 0; kk < TK; kk += 2) {
+                    float a[RM], b[RN];
+#pragma unroll
+                    for (int r = 0; r < RM; ++r) a[r] = As[kk + (lane >> 5)][wm + 32 * r + (lane & 31)];
+#pragma unroll
+                    for (int q = 0; q < RN; ++q) b[q] = Bs[kk + (lane >> 5)][wn + 32 * q + (lane & 31)];
+#pragma unroll
+                    for (int r = 0; r < RM; ++r)
+#pragma unroll
+                        for (int q = 0; q < RN; ++q)
+                            c[r][q][(kk >> 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[q], c[r][q][(kk >> 1) & 1], 0, 0, 0);
+                }
+                __syncthreads();
+            }
         }
-#pragma unroll
-        for (int kk = 0; kk < TK; kk += 2) {
-            float a[RM], b[RN];
-#pragma unroll
-            for (int r = 0; r < RM; ++r) a[r] = As[kk + (lane >> 5)][wm + 32 * r + (lane & 31)];
-#pragma unroll
-            for (int q = 0; q < RN; ++q) b[q] = Bs[kk + (lane >> 5)][wn + 32 * q + (lane & 31)];
-#pragma unroll
-            for (int r = 0; r < RM; ++r)
-#pragma unroll
-                for (int q = 0; q < RN; ++q)
-                    c[r][q][(kk >> 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[q], c[r][q][(kk >> 1) & 1], 0, 0, 0);
-        }
-        __syncthreads();
     }
     if (do_bias && m0 + tid < M) {
         if (part) part[(long)gridDim.z * M * N + (long)blockIdx.z * M + m0 + tid] = (float)bsum;     // behind the partial tiles
@@ -216,14 +246,14 @@ __global__ void k_splitk_group(long MN, int M, int nsplit, int group, int ngroup
     out[is_bias ? (long)ngroups * MN + (long)g * M + (i - MN) : (long)g * MN + i] = s;
 }
 
-template <int RM, int RN>
+template <bool FAST, int PF>
 static void launch(hipStream_t s, int tA, int tB, dim3 grid, int M, int N, int K, int kchunk, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                    const float* bias, int acc, float* part, int vecA, int vecB, GemmEpi epi) {
     const dim3 block(256);
-    if (tA && tB) hipLaunchKernelGGL((k_gemm<true, true, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
-    else if (tA) hipLaunchKernelGGL((k_gemm<true, false, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
-    else if (tB) hipLaunchKernelGGL((k_gemm<false, true, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
-    else hipLaunchKernelGGL((k_gemm<false, false, RM, RN>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
+    if (tA && tB) hipLaunchKernelGGL((k_gemm<true, true, 1, 1, FAST, PF>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
+    else if (tA) hipLaunchKernelGGL((k_gemm<true, false, 1, 1, FAST, PF>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
+    else if (tB) hipLaunchKernelGGL((k_gemm<false, true, 1, 1, FAST, PF>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
+    else hipLaunchKernelGGL((k_gemm<false, false, 1, 1, FAST, PF>), grid, block, 0, s, M, N, K, kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
 }
 
 void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
@@ -241,10 +271,14 @@ void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, in
     // in the base pointer); otherwise the element-wise path
     const int vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     const int vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
-    if (p.rm == 2 && p.rn == 2) launch<2, 2>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
-    else if (p.rm == 2) launch<2, 1>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
-    else if (p.rn == 2) launch<1, 2>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
-    else launch<1, 1>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
+    if (p.rm != 1 || p.rn != 1) { fprintf(stderr, "jodo gemm: tile %d x %d is not instantiated\n", p.rm, p.rn); abort(); }
+    // FAST: every tile whole in K (K and the split chunk multiples of 32), 16-byte addressable operands, and at least one whole quad
+    // (m-/n-contiguous layouts) or row (k-contiguous) to clamp to
+    const bool fast = vecA && vecB && (K % TK) == 0 && (p.kchunk % TK) == 0 && (tA ? (M % 4) == 0 && M >= 4 : M >= 1) && (tB ? N >= 1 : (N % 4) == 0 && N >= 4);
+    const long wgs = (long)grid.x * grid.y * grid.z;
+    if (fast && wgs <= 512 && (K < p.kchunk ? K : p.kchunk) > 2 * TK) launch<true, 4>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
+    else if (fast) launch<true, 1>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
+    else launch<false, 1>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
     if (p.nsplit > 1) {
         int nfinal = p.nsplit;
         if (p.group > 0) {
