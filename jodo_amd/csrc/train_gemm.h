@@ -37,8 +37,8 @@ inline GemmPlan gemm_plan(int tA, int M, int N, int K, bool have_ws, size_t ws_f
     int nsplit = 1;
     if (have_ws && K >= 512 && (tA || tiles < 128)) {
         if (tA) {
-            // slices of 512 rows (finer slices for outputs of one or two tiles were measured slower: k_splitk_sum has only M N threads,
-            // each walking every slice — dW ff3 [128 x 64 x 43 000] 41.8 us at 84 slices, 96.2 us at 336)
+            // slices of 512 rows (finer slices summed by ONE level were measured slower: k_splitk_sum has only M N threads, each walking
+            // every slice — dW ff3 [128 x 64 x 43 000] 41.8 us at 84 slices, 96.2 us at 336)
             nsplit = (K + 511) / 512;
             // ... unless that leaves most of the chip idle (outputs of one to four tiles: [64 x 64], [128 x 64], [3 x 256] x 43 000 rows
             // ran 81 - 170 workgroups on 256 CUs, 24 - 33 us each): slices down to 64 rows until about 768 workgroups exist, and the

@@ -10,7 +10,9 @@
 // steps of 32 through LDS ([k][m] / [k][n], consecutive lanes read consecutive m / n: conflict-free); global loads are 16 bytes per
 // thread along whichever index is contiguous in memory, and the next K tile is in flight (registers) while the current one is
 // multiplied.  Two accumulator chains per block (even / odd k-pairs) and short split-K partials keep the fp32 rounding chains short.
-// Bounds are checked on every edge (N = 3, K = 17 and ragged row counts all occur; unaligned operands take an element-wise path).
+// Bounds are checked on every edge (N = 3, K = 17 and ragged row counts all occur; unaligned operands take an element-wise path);
+// products whose tiles are all whole in K take the branch-free loader (FAST), small launches with four tiles in flight.  The tile order
+// is XCD-aware (k_gemm).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdio>
