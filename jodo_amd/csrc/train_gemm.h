@@ -23,7 +23,7 @@ __host__ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, float v
 // rm x rn accumulator blocks of 32 x 32 (rm = rn = 1 is what runs, see below); K runs in tiles of 32.  Split-K over grid.z: weight gradients (tA: K = every row of the
 // batch) in partial sums over 512 rows; products with too few output tiles to fill the chip (the per-molecule modulation
 // projections: 128 rows) over 128-wide slices of K.
-struct GemmPlan { int rm, rn, nsplit, kchunk, group; };       // group > 0: the slices are summed in groups of `group`, then the group sums
+struct GemmPlan { int rm, rn, nsplit, kchunk; };
 inline GemmPlan gemm_plan(int tA, int M, int N, int K, bool have_ws, size_t ws_floats) {
     GemmPlan p;
     // 64 x 64 tiles everywhere: measured on MI355X (tools/gemm_bench.py, QM9 batch-128 shapes) the 128-wide tiles lose — 271
@@ -37,12 +37,11 @@ inline GemmPlan gemm_plan(int tA, int M, int N, int K, bool have_ws, size_t ws_f
     int nsplit = 1;
     if (have_ws && K >= 512 && (tA || tiles < 128)) {
         if (tA) {
-            // slices of 512 rows (finer slices summed by ONE level were measured slower: k_splitk_sum has only M N threads, each walking
-            // every slice — dW ff3 [128 x 64 x 43 000] 41.8 us at 84 slices, 96.2 us at 336)
+            // slices of 512 rows
             nsplit = (K + 511) / 512;
             // ... unless that leaves most of the chip idle (outputs of one to four tiles: [64 x 64], [128 x 64], [3 x 256] x 43 000 rows
-            // ran 81 - 170 workgroups on 256 CUs, 24 - 33 us each): slices down to 64 rows until about 768 workgroups exist, and the
-            // partial tiles are then summed in two levels (groups of 16 slices, then the group sums — the order stays fixed)
+            // ran 81 - 170 workgroups on 256 CUs, 24 - 33 us each): slices down to 64 rows until about 768 workgroups exist (k_splitk_sum
+            // spreads the slices of an output over eight lanes, so hundreds of slices cost it little)
             if (tiles * nsplit < 512) {
                 const long want = 768 / tiles, finest = (K + 63) / 64;
                 const long fine = want < finest ? want : finest;
@@ -52,8 +51,7 @@ inline GemmPlan gemm_plan(int tA, int M, int N, int K, bool have_ws, size_t ws_f
             nsplit = (K + 127) / 128;
             if (nsplit > 256 / tiles) nsplit = (int)(256 / tiles);
         }
-        long cap = (long)(ws_floats / ((size_t)M * N + (size_t)M));             // partial tiles + partial bias sums
-        if (tA) cap = (cap - 1) * 16 / 17;                                       // + the group sums of the two-level form (ceil(nsplit / 16) more)
+        const long cap = (long)(ws_floats / ((size_t)M * N + (size_t)M));      // partial tiles + partial bias sums
         if (nsplit > cap) nsplit = (int)cap;
         if (nsplit > 512) nsplit = 512;
         if (nsplit < 1) nsplit = 1;
@@ -63,7 +61,6 @@ inline GemmPlan gemm_plan(int tA, int M, int N, int K, bool have_ws, size_t ws_f
     if (kchunk < 32) kchunk = 32;
     p.nsplit = K > 0 ? (K + kchunk - 1) / kchunk : 1;
     p.kchunk = kchunk;
-    p.group = (tA && p.nsplit > 64) ? 16 : 0;
     return p;
 }
 }

@@ -196,56 +196,45 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, int kchunk, c
     }
 }
 
-__global__ void k_splitk_sum(int M, int N, int nsplit, const float* __restrict__ part, float* __restrict__ C, int ldc, const float* __restrict__ bias, int acc, GemmEpi epi) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)M * N) return;
+// Sum of the split-K partial tiles.  A block owns 32 consecutive outputs; its eight rows of 32 lanes take the slices z = g, g + 8, ...
+// (eight loads in flight each, coalesced 128-byte rows), the eight partial sums meet in LDS and are added in the order g = 0 .. 7:
+//     total = (...((s_0 + s_1) + s_2) ... + s_7),   s_g = sum over z = g (mod 8), ascending
+// — a fixed order (tests/emul/emul_gemm.cpp mirrors it).  One thread per output walking every slice took 7 us at 81 slices and forced a
+// second level above 64; this form needs one launch up to the plan's 512 slices.  Behind the output blocks, blocks of 32 rows do the same
+// for the partial bias sums (epi.dbias).
+__global__ __launch_bounds__(256) void k_splitk_sum(int M, int N, int nsplit, const float* __restrict__ part, float* __restrict__ C, int ldc,
+                                                    const float* __restrict__ bias, int acc, GemmEpi epi) {
+    __shared__ float sh[8][32];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long MN = (long)M * N, nmain = (MN + 31) / 32;
+    const bool is_bias = (long)blockIdx.x >= nmain;
+    const long i = (is_bias ? (long)blockIdx.x - nmain : (long)blockIdx.x) * 32 + e;
+    const long count = is_bias ? (long)M : MN, stride = count;
+    const float* src = is_bias ? part + (long)nsplit * MN : part;
+    float s = 0.f;
+    if (i < count) {
+        int z = g;
+        for (; z + 56 < nsplit; z += 64) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[(long)(z + 8 * j) * stride + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; z < nsplit; z += 8) s += src[(long)z * stride + i];
+    }
+    sh[g][e] = s;
+    __syncthreads();
+    if (g != 0 || i >= count) return;
+    float t = sh[0][e];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += sh[q][e];
+    if (is_bias) { epi.dbias[i] += t; return; }
     const int row = (int)(i / N), col = (int)(i % N);
-    // eight slices in flight per step, added in slice order (one load per iteration paid an exposed memory round trip each)
-    const long MN = (long)M * N;
-    float s = 0.f;
-    int z = 0;
-    for (; z + 8 <= nsplit; z += 8) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = part[(long)(z + j) * MN + i];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += v[j];
-    }
-    for (; z < nsplit; ++z) s += part[(long)z * MN + i];
-    if (epi.dbias && col == 0) {                            // partial bias sums of the slices, in slice order
-        float bs = 0.f;
-        for (int zz = 0; zz < nsplit; ++zz) bs += part[(long)nsplit * MN + (long)zz * M + row];
-        epi.dbias[row] += bs;
-    }
-    s += bias ? bias[col] : 0.f;
-    if (epi.act) { gemm_epilogue(epi, s, C, (long)row * ldc + col, i); return; }
+    t += bias ? bias[col] : 0.f;
+    if (epi.act) { gemm_epilogue(epi, t, C, (long)row * ldc + col, i); return; }
     float* o = C + (long)row * ldc + col;
-    *o = acc ? *o + s : s;
-}
-
-// first level of the two-level sum (gemm_plan group > 0): group g of `group` consecutive slices -> out[g]; tiles first ([nsplit][M N] ->
-// [ngroups][M N]), then the partial bias sums behind them ([nsplit][M] -> [ngroups][M]); eight slices in flight, added in slice order
-__global__ void k_splitk_group(long MN, int M, int nsplit, int group, int ngroups, int with_bias, const float* __restrict__ part, float* __restrict__ out) {
-    const long per = MN + (with_bias ? M : 0);
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= per * ngroups) return;
-    const int g = (int)(t / per);
-    const long i = t % per;
-    const bool is_bias = i >= MN;
-    const float* src = is_bias ? part + (long)nsplit * MN + (i - MN) : part + i;
-    const long stride = is_bias ? M : MN;
-    const int z0 = g * group, z1 = min(nsplit, z0 + group);
-    float s = 0.f;
-    int z = z0;
-    for (; z + 8 <= z1; z += 8) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = src[(long)(z + j) * stride];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += v[j];
-    }
-    for (; z < z1; ++z) s += src[(long)z * stride];
-    out[is_bias ? (long)ngroups * MN + (long)g * M + (i - MN) : (long)g * MN + i] = s;
+    *o = acc ? *o + t : t;
 }
 
 template <bool FAST, int PF>
@@ -282,15 +271,8 @@ void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, in
     else if (fast) launch<true, 1>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
     else launch<false, 1>(s, tA, tB, grid, M, N, K, p.kchunk, A, lda, B, ldb, C, ldc, bias, acc, part, vecA, vecB, epi);
     if (p.nsplit > 1) {
-        int nfinal = p.nsplit;
-        if (p.group > 0) {
-            const int ngroups = (p.nsplit + p.group - 1) / p.group;
-            const long MN = (long)M * N, per = MN + (epi.dbias ? M : 0);
-            float* part2 = part + (size_t)p.nsplit * ((size_t)MN + M);
-            hipLaunchKernelGGL(k_splitk_group, dim3((unsigned)((per * ngroups + 255) / 256)), dim3(256), 0, s, MN, M, p.nsplit, p.group, ngroups, epi.dbias ? 1 : 0, part, part2);
-            part = part2; nfinal = ngroups;
-        }
-        hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, s, M, N, nfinal, part, C, ldc, bias, acc, epi);
+        const long blocks = ((long)M * N + 31) / 32 + (epi.dbias ? (M + 31) / 32 : 0);
+        hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)blocks), dim3(256), 0, s, M, N, p.nsplit, part, C, ldc, bias, acc, epi);
     }
 }
 

@@ -6,8 +6,8 @@ thread_local emu_idx threadIdx, blockIdx;
 thread_local dim3 blockDim, gridDim;
 namespace jt {
 // Mirrors the ROUNDING STRUCTURE of the device kernel so that the CPU suite predicts its accuracy: fp32 fused multiply-adds, two
-// accumulator chains taken in turn by the k-pairs, the split-K slices of train_gemm.h gemm_plan() added in order (in groups first where
-// the plan says so).
+// accumulator chains taken in turn by the k-pairs, the split-K slices of train_gemm.h gemm_plan() added the way k_splitk_sum adds them:
+// eight interleaved partial sums (slices z = g mod 8, ascending), then those in the order g = 0 .. 7.
 void gemm(hipStream_t, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
           const float* bias, int acc, float* ws, size_t ws_floats, const GemmEpi* epi) {
     // debugging aid: products summed in double; value = bit mask of the products it applies to (1 forward, 2 input gradient, 4 weight gradient)
@@ -28,42 +28,36 @@ void gemm(hipStream_t, int tA, int tB, int M, int N, int K, const float* A, int 
         return;
     }
     const GemmPlan pl = gemm_plan(tA, M, N, K, ws != nullptr, ws_floats);
-    const int nsplit = pl.nsplit, kchunk = pl.kchunk, group = pl.group > 0 ? pl.group : nsplit;
+    const int nsplit = pl.nsplit, kchunk = pl.kchunk;
     if (epi && epi->dbias && tA) {                              // bias gradient: per slice a double sum, slices added in order
         for (int m = 0; m < M; ++m) {
-            float bs = 0.f;
-            for (int z0 = 0; z0 < nsplit; z0 += group) {
-                float gs = 0.f;
-                for (int z = z0; z < nsplit && z < z0 + group; ++z) {
-                    double t = 0.0;
-                    const int k1 = K < (z + 1) * kchunk ? K : (z + 1) * kchunk;
-                    for (int k = z * kchunk; k < k1; ++k) t += (double)A[(long)k * lda + m];
-                    if (nsplit > 1) gs += (float)t; else gs = (float)t;
-                }
-                if (nsplit > 1) bs += gs; else bs = gs;
+            float sg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bs = 0.f;
+            for (int z = 0; z < nsplit; ++z) {
+                double t = 0.0;
+                const int k1 = K < (z + 1) * kchunk ? K : (z + 1) * kchunk;
+                for (int k = z * kchunk; k < k1; ++k) t += (double)A[(long)k * lda + m];
+                if (nsplit > 1) sg[z & 7] += (float)t; else bs = (float)t;
             }
+            if (nsplit > 1) { bs = sg[0]; for (int g = 1; g < 8; ++g) bs += sg[g]; }
             epi->dbias[m] += bs;
         }
     }
     for (int m = 0; m < M; ++m)
         for (int n = 0; n < N; ++n) {
-            float total = 0.f;
-            for (int z0 = 0; z0 < nsplit; z0 += group) {
-                float gs = 0.f;
-                for (int z = z0; z < nsplit && z < z0 + group; ++z) {
-                    float c2[2] = {0.f, 0.f};                 // the device kernel's two chains: even / odd k-pairs of the slice
-                    const int k1 = K < (z + 1) * kchunk ? K : (z + 1) * kchunk;
-                    for (int k = z * kchunk; k < k1; ++k) {
-                        const float a = tA ? A[(long)k * lda + m] : A[(long)m * lda + k];
-                        const float b = tB ? B[(long)n * ldb + k] : B[(long)k * ldb + n];
-                        float& c = c2[((k - z * kchunk) >> 1) & 1];
-                        c = fmaf(a, b, c);
-                    }
-                    if (nsplit > 1) gs += c2[0] + c2[1];
-                    else gs = c2[0] + c2[1];
+            float sg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, total = 0.f;
+            for (int z = 0; z < nsplit; ++z) {
+                float c2[2] = {0.f, 0.f};                     // the device kernel's two chains: even / odd k-pairs of the slice
+                const int k1 = K < (z + 1) * kchunk ? K : (z + 1) * kchunk;
+                for (int k = z * kchunk; k < k1; ++k) {
+                    const float a = tA ? A[(long)k * lda + m] : A[(long)m * lda + k];
+                    const float b = tB ? B[(long)n * ldb + k] : B[(long)k * ldb + n];
+                    float& c = c2[((k - z * kchunk) >> 1) & 1];
+                    c = fmaf(a, b, c);
                 }
-                if (nsplit > 1) total += gs; else total = gs;
+                if (nsplit > 1) sg[z & 7] += c2[0] + c2[1];
+                else total = c2[0] + c2[1];
             }
+            if (nsplit > 1) { total = sg[0]; for (int g = 1; g < 8; ++g) total += sg[g]; }
             if (bias) total += bias[n];
             if (epi && epi->act) { gemm_epilogue(*epi, total, C, (long)m * ldc + n, (long)m * N + n); continue; }
             float* o = C + (long)m * ldc + n;
