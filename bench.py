@@ -384,12 +384,16 @@ def main():
                 st = sampler.step(model, i, st, node_mask, edge_mask, context)
                 if i == 0 and args.warmup > 1:
                     model.profile_enable(1)            # class timers on every launch class for the rest of the warm-up
-            # the launch class that took the most time in the warm-up is the one the timed region brackets (roofline leg)
+            # roofline leg: the timed region brackets the dominant KERNEL — the single dispatch that took the most time in the
+            # warm-up.  With pinned paths the attention class (2) and the pair-update class (6) are one dispatch per block each;
+            # the node class (5) is three dispatches per block, the largest of which (k_node_post, profiles/*_rocprofv3_kernel_stats_*.csv)
+            # is shorter than either edge kernel on every workload, so it can lead the CLASS table (`roofline.classes`,
+            # `roofline.dominant_class`) without being the kernel a profiler ranks first.
             dom, warm_classes = 6, None
             if args.warmup > 1:
                 wms, wcnt = model.profile_read()
                 if sum(wcnt) > 0:
-                    dom = max(range(8), key=lambda c_: wms[c_])
+                    dom = max((2, 6), key=lambda c_: wms[c_])
                     warm_classes = (wms, wcnt, args.warmup - 1)
             model.profile_enable(1 if args.breakdown else 16 + dom)
             torch.cuda.synchronize()
@@ -558,6 +562,32 @@ def main():
             classes = {names[c]: {'ms_per_step': wms[c] / wsteps, 'brackets_per_step': wcnt[c] / wsteps,
                                   'mfma_frac': (work[c] / (wms[c] / wsteps * 1e-3) / PEAK_FP32_MFMA) if wms[c] > 0 else None}
                        for c in range(8) if wcnt[c] > 0}
+        dom_class = None
+        if classes:
+            dc = max(classes, key=lambda k_: classes[k_]['ms_per_step'])
+            dom_class = {'launch_class': dc, 'ms_per_step': classes[dc]['ms_per_step'], 'mfma_frac': classes[dc]['mfma_frac'],
+                         'brackets_per_step': classes[dc]['brackets_per_step'],
+                         'note': 'the launch CLASS with the most time per step (warm-up class timers); a class can be several dispatches '
+                                 '(node_post: k_node_post + the merged k_node_ab / Gram / next-block q k v launches)'}
+        # multi-GPU balance predicted on the host (jodo_amd/scaling.py): rank r of `bench.py --gpus N` draws its own B
+        # molecules from seed + r — executed-work model per rank, mean / max = the efficiency the n^2 variance of the draws allows
+        scaling_pred = None
+        if world == 1:
+            try:
+                from jodo_amd import scaling
+                fr = {k_: v_['mfma_frac'] for k_, v_ in (classes or {}).items() if v_.get('mfma_frac')}
+                draws = []
+                for r_ in range(8):
+                    torch.manual_seed(cfg.seed + r_)
+                    draws.append(nodes_dist.sample(B).tolist())
+                scaling_pred = {'weak_scaling_as_bench_runs_it': {str(n_): scaling.predict_weak(model._cfg(), draws[:n_], int(shared_row), fr)
+                                                                   for n_ in (2, 4, 8)},
+                                'note': 'host-side prediction, not a measurement: executed MFMA flops of every rank\'s own draw (seed + rank) from '
+                                        'jodo_plan_work; predicted_efficiency = mean / max over ranks; *_time_model weights the classes by the '
+                                        'fractions measured in this run.  BASELINE configs[3] / [4] dealt to 8 ranks (contiguous / lpt): '
+                                        'profiles/r05_scaling_prediction.json (tools/scaling_predict.py)'}
+            except Exception as exc:
+                scaling_pred = {'error': repr(exc)}
         kernel_names = {'edge_update': 'k_edge_update_sym' if not flags_now[4] else 'k_edge_update',
                         'node_post': 'node class: k_node_post + the two k_node_mix launches (k_node_ab items, Gram tiles)',
                         'edge_attn': 'k_edge_attn', 'node_pre': 'k_node_pre', 'prologue': 'prologue (time / fold / embeddings)',
@@ -579,9 +609,10 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': kernel_names.get(dom_name, dom_name), 'launch_class': dom_name,
                          'achieved': achieved / 1e12, 'peak': PEAK_FP32_MFMA / 1e12,
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA, 'traffic': traffic, 'hbm': hbm,
-                         'note': 'kernel = the launch class that took the most time in this run (class timers over the warm-up steps); '
-                                 'achieved = fp32 MFMA flops that class EXECUTES per HIP-event bracket (one bracket = its launches of one '
-                                 'block; plan work model jodo_plan_work = SQ_INSTS_MFMA x 4096 of the committed PMC pass) / the mean '
+                         'note': 'kernel = the single dispatch that took the most time in this run (class timers over the warm-up steps; the '
+                                 'attention and pair-update classes are one dispatch per block under pinned paths — what rocprofv3 --stats ranks '
+                                 'first); achieved = fp32 MFMA flops it EXECUTES per launch '
+                                 '(plan work model jodo_plan_work = SQ_INSTS_MFMA x 4096 of the committed PMC pass) / the mean '
                                  'bracket time measured over the timed region; vector flops are NOT in the numerator (reported '
                                  'separately for the pair update).  traffic: HBM bytes per bracket from the committed PMC passes of the '
                                  'same command (`hbm.source`), not from this run.  reference_formulation_ratio = the SURVEY.md 8d count '
@@ -590,7 +621,7 @@ def main():
                          'avg_launch_ms': dom_ms, 'launches': dom_n,
                          'executed_mfma_flops_per_launch': mfma_launch,
                          'mfma_frac': achieved / PEAK_FP32_MFMA,
-                         'classes': classes,
+                         'classes': classes, 'dominant_class': dom_class,
                          'pair_update': {'kernel': kernel_names['edge_update'], 'avg_launch_ms': upd_ms, 'launches': upd_n, 'measured_over': upd_src,
                                          'executed_mfma_flops_per_launch': upd_mfma, 'executed_vector_flops_per_launch': upd_valu,
                                          'mfma_frac': (upd_mfma / (upd_ms * 1e-3) / PEAK_FP32_MFMA) if upd_ms > 0 else 0.0,
@@ -607,6 +638,7 @@ def main():
             'steady_state': steady,
             'full_round': full_round,
             'sharded_round': sharded,
+            'scaling_prediction': scaling_pred,
             'molecules_decoded': n_total, 'nan_guard': bool(nan_fired),
             'device_flags': dict(zip(('nan', 'first_step', 'uniform_t', 'cond_nonzero', 'asymmetric_edges'), flags_now[:5])),
         }

@@ -322,8 +322,9 @@ int jodo_edge_ffn_backward(int rows, int De, int mlp_ratio, int n_mod_rows, cons
 
 /* ---- training step: the whole network ------------------------------------------------------------------
  * jodo_train_forward   <- the grad-enabled model call of get_sde_graph_loss_fn, losses.py:335-343 (DGT_concat.forward /
- *                         Cond_DGT_concat.forward under model.train(): dropout on the attention weights, layers.py:179, and in the
- *                         four FFN positions, mol_gnn.py:262-268) with every activation the backward needs kept in `workspace`
+ *                         Cond_DGT_concat.forward under model.train(): dropout in the four FFN positions, mol_gnn.py:262-268; NOT on the
+ *                         attention weights — layers.py:179 is an identity because the block builds its TransMixLayer with the default
+ *                         dropout = 0, mol_gnn.py:230-231) with every activation the backward needs kept in `workspace`
  * jodo_train_backward  <- loss.backward(), losses.py:109: d loss / d parameter for EVERY tensor of the state_dict, given
  *                         d loss / d out_xh and d loss / d out_edge (the loss itself, losses.py:350-385, stays host code)
  * Parameters are NOT packed here: params_dev[i] / grads_dev[i] are DEVICE pointers to contiguous fp32 tensors in PyTorch layout,
@@ -342,6 +343,9 @@ int jodo_train_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes_
 void jodo_train_destroy(jodo_train* t);
 size_t jodo_train_desc_bytes(const jodo_train* t);
 size_t jodo_train_workspace_bytes(const jodo_train* t);
+/* tests: byte offset and element count of a kept activation inside the workspace; what 0 = hhat [Nn, D] (TransMixLayer's output,
+ * layers.py:153), 1 = alpha [R, H] (softmax weights, layers.py:178) of block `layer` */
+int jodo_train_debug_locate(const jodo_train* t, int what, int layer, size_t* byte_offset, size_t* count);
 int jodo_train_upload(jodo_train* t, void* desc_dev, void* stream);
 int jodo_train_forward(jodo_train* t, const void* desc_dev, const float* const* params_dev, int n_params, const float* xh,
                        const float* edge_x, const float* cond_x, const float* cond_edge_x, const float* noise_level,

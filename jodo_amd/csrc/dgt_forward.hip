@@ -25,7 +25,7 @@ PlanDev make_plan_dev(const jodo_plan* p, const void* desc_dev) {
     d.pitem_strip = base + p->off_pitem_strip; d.pitem_t0 = base + p->off_pitem_t0; d.pitem_t1 = base + p->off_pitem_t1;
     d.n_pitems = p->n_pitems;
     d.ag_node = base + p->off_ag_node; d.ai_group = base + p->off_ai_group; d.ai_t0 = base + p->off_ai_t0; d.ai_t1 = base + p->off_ai_t1;
-    d.ai_part = base + p->off_ai_part; d.ad_group = base + p->off_ad_group; d.ad_t0 = base + p->off_ad_t0; d.ad_t1 = base + p->off_ad_t1;
+    d.ai_part = base + p->off_ai_part; d.ai_dir = base + p->off_ai_dir; d.ad_group = base + p->off_ad_group; d.ad_t0 = base + p->off_ad_t0; d.ad_t1 = base + p->off_ad_t1;
     d.ad_part = base + p->off_ad_part; d.ad_big = base + p->off_ad_big; d.anode_parts = base + p->off_anode_parts;
     d.aw_off = base + p->off_aw_off; d.a_persist = p->a_persist;
     d.n_agroups = p->n_agroups; d.n_aitems = p->n_aitems; d.n_aditems = p->n_aditems; d.amax_parts = p->amax_parts;

@@ -242,33 +242,16 @@ __device__ __forceinline__ void attn_pick_lds(const float* col, int b, int half,
     hi = col[(half ? (b * 32 + 24) / X::C : (b * 32 + 8) / X::C) * 256];
 }
 
-// PAIR = true: pair-mode items (ai_*), exits when the inputs are asymmetric; PAIR = false: directed-mode items (ad_*),
-// runs when the inputs are asymmetric or the item belongs to a molecule that spans several groups
-template <int D, bool WQK, bool PAIR, int VAR = 0>
-__global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
-    using X = AttnT<D, WQK, VAR>;
+// One work item of the fused attention phase: group `grp` (128 lanes of whole molecules, ag_node), iterations [t0, t1) — pair
+// offsets d = t + 1 (PAIR) or sources t (directed) —, partial index `part`.  wl: the workgroup's LDS-resident weights;
+// sx / ux: the pair mode's hand-over buffers (untouched in directed mode); stt: the running softmax state where it lives in LDS.
+template <typename X, bool PAIR>
+__device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, float4* sx, float4* ux, float* stt, int grp, int t0, int t1, int part) {
+    constexpr int D = X::D;
     constexpr bool PREF = X::PREF;
-    const bool asym = A.flags[FLAG_ASYM] != 0;
-    if (PAIR ? asym : !(asym || A.pd.ad_big[blockIdx.x])) return;
-    // pair mode under the plan's wrap-around schedule: this workgroup is slot blockIdx.x and works through its items (the
-    // resident weights below are staged once); otherwise one item per workgroup
-    const bool pers = PAIR && A.pd.a_persist != 0;
-    const int it0 = pers ? A.pd.aw_off[blockIdx.x] : (int)blockIdx.x, it1 = pers ? A.pd.aw_off[blockIdx.x + 1] : (int)blockIdx.x + 1;
-    __shared__ float4 wl[(X::LDS_EE ? 32 * 64 : 0) + (X::LDS_L0 ? (X::LDS_TAIL ? 64 : 56) * 64 : 0) + (X::LDS_EE && !X::LDS_TAIL ? 0 : 1)];   // edge_emb (2 x 16 quads) | lin_edge0 (8 x 8 quads)
-    __shared__ float4 sx[PAIR ? 2 * 256 : 1];            // scores handed to the partner: [quad][half * 128 + lane], heads 8h .. 8h + 7
-    __shared__ float4 ux[PAIR ? (X::PHB == 1 ? 2 : X::PHB) * 4 * 256 : 1];   // unweighted messages: one block double buffered, or a phase of PHB blocks
-    __shared__ float stt[X::LDSS ? 5 * 16 * 256 : 1];    // per thread: running max, sum | rescale, p(own source), p(handed-over source)
-    float* const stc = stt + threadIdx.x;                // element (k, h) of this thread at stc[(k * 16 + h) * 256]
-    if constexpr (X::LDS_EE) stage_weights<32, ATT_WAVES>(wl, reinterpret_cast<const float4*>(A.W + A.wb[JB_EE_W]));
-    if constexpr (X::LDS_L0) stage_weights<(X::LDS_TAIL ? 64 : 56), ATT_WAVES>(wl + (X::LDS_EE ? 32 * 64 : 0), reinterpret_cast<const float4*>(A.W + A.wb[JB_LE0_W]));
-    if constexpr (X::LDS_EE || X::LDS_L0) __syncthreads();
     const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
     const int ln = wave * 32 + (lane & 31);             // lane of the group
-  for (int it = it0; it < it1; ++it) {
-    if (it > it0) __syncthreads();                      // the hand-over buffers of the previous item have been read everywhere
-    const int grp = PAIR ? A.pd.ai_group[it] : A.pd.ad_group[it];
-    const int t0 = PAIR ? A.pd.ai_t0[it] : A.pd.ad_t0[it], t1 = PAIR ? A.pd.ai_t1[it] : A.pd.ad_t1[it];
-    const int part = PAIR ? A.pd.ai_part[it] : A.pd.ad_part[it];
+    float* const stc = stt + threadIdx.x;                // element (k, h) of this thread at stc[(k * 16 + h) * 256]
     const int vraw = A.pd.ag_node[grp * ATT_LANES + ln];
     LaneNode L;
     L.valid = vraw >= 0;
@@ -522,7 +505,39 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
     }
     APT(6);
     APT_FLUSH;
-  }
+}
+
+// PAIR = true: the pair launch (ai_* items), exits when the inputs are asymmetric.  Its items are pair-mode items of groups of
+// whole molecules and — under the plan's persistent schedule — the directed-mode items of molecules larger than a group
+// (ai_dir: every lane visits all its sources, no hand-over), so that symmetric inputs need one launch whatever the sizes.
+// PAIR = false: the directed launch (ad_* items), runs when the inputs are asymmetric (and for ad_big items: molecules larger than
+// a group when the pair launch does not carry them, i.e. fixed-chunk plans)
+template <int D, bool WQK, bool PAIR, int VAR = 0>
+__global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
+    using X = AttnT<D, WQK, VAR>;
+    const bool asym = A.flags[FLAG_ASYM] != 0;
+    if (PAIR ? asym : !(asym || A.pd.ad_big[blockIdx.x])) return;
+    // pair mode under the plan's wrap-around schedule: this workgroup is slot blockIdx.x and works through its items (the
+    // resident weights below are staged once); otherwise one item per workgroup
+    const bool pers = PAIR && A.pd.a_persist != 0;
+    const int it0 = pers ? A.pd.aw_off[blockIdx.x] : (int)blockIdx.x, it1 = pers ? A.pd.aw_off[blockIdx.x + 1] : (int)blockIdx.x + 1;
+    __shared__ float4 wl[(X::LDS_EE ? 32 * 64 : 0) + (X::LDS_L0 ? (X::LDS_TAIL ? 64 : 56) * 64 : 0) + (X::LDS_EE && !X::LDS_TAIL ? 0 : 1)];   // edge_emb (2 x 16 quads) | lin_edge0 (8 x 8 quads)
+    __shared__ float4 sx[PAIR ? 2 * 256 : 1];            // scores handed to the partner: [quad][half * 128 + lane], heads 8h .. 8h + 7
+    __shared__ float4 ux[PAIR ? (X::PHB == 1 ? 2 : X::PHB) * 4 * 256 : 1];   // unweighted messages: one block double buffered, or a phase of PHB blocks
+    __shared__ float stt[X::LDSS ? 5 * 16 * 256 : 1];    // per thread: running max, sum | rescale, p(own source), p(handed-over source)
+    if constexpr (X::LDS_EE) stage_weights<32, ATT_WAVES>(wl, reinterpret_cast<const float4*>(A.W + A.wb[JB_EE_W]));
+    if constexpr (X::LDS_L0) stage_weights<(X::LDS_TAIL ? 64 : 56), ATT_WAVES>(wl + (X::LDS_EE ? 32 * 64 : 0), reinterpret_cast<const float4*>(A.W + A.wb[JB_LE0_W]));
+    if constexpr (X::LDS_EE || X::LDS_L0) __syncthreads();
+    for (int it = it0; it < it1; ++it) {
+        if (it > it0) __syncthreads();                  // the hand-over buffers of the previous item have been read everywhere
+        if constexpr (PAIR) {
+            const int grp = A.pd.ai_group[it], t0 = A.pd.ai_t0[it], t1 = A.pd.ai_t1[it], part = A.pd.ai_part[it];
+            if (A.pd.ai_dir[it]) attn_item<X, false>(A, wl, sx, ux, stt, grp, t0, t1, part);
+            else attn_item<X, true>(A, wl, sx, ux, stt, grp, t0, t1, part);
+        } else {
+            attn_item<X, false>(A, wl, sx, ux, stt, A.pd.ad_group[it], A.pd.ad_t0[it], A.pd.ad_t1[it], A.pd.ad_part[it]);
+        }
+    }
 }
 
 // merge the attention partials of a node (k_node_post*): hhat = sum_p acc_p e^{m_p - M} / (sum_p l_p e^{m_p - M} + 1e-16),

@@ -188,7 +188,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     // largest remaining molecules that still fit (lanes of a smaller molecule idle during the larger offsets, which
     // is better than idling throughout).  A molecule larger than a group (n > 128, GEOM's tail) gets groups of
     // consecutive atoms of its own and is walked in directed form (every lane visits all its sources, no hand-over).
-    std::vector<int32_t> ag_node, ai_group, ai_t0, ai_t1, ai_part, ad_group, ad_t0, ad_t1, ad_part, ad_big, anode_parts(p->Nn_pad, 0), aw_off;
+    std::vector<int32_t> ag_node, ai_group, ai_t0, ai_t1, ai_part, ai_dir, ad_group, ad_t0, ad_t1, ad_part, ad_big, anode_parts(p->Nn_pad, 0), aw_off;
     int amax_parts = 1;
     {
         constexpr int G = 128;
@@ -224,7 +224,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         }
         const int ng = (int)g_nmax.size();
         p->n_agroups = ng;
-        if (persist) achunk = 6;                                // (directed items of molecules larger than a group keep the fixed rule)
+        if (persist) achunk = 6;                                // (unused by the schedule below; keeps the fixed-chunk arithmetic defined)
         if (achunk <= 0 && p->dims.wide) {                      // streamed-weight kernels (nf 128 / 384): no staging cost per item;
             int64_t iters = 0;                                  // the model below, fitted to the LDS-resident kernel, picked coarser
             for (int g = 0; g < ng; ++g) iters += std::max(1, g_nmax[g] / 2);    // items and lost 27 % at nf 384 (39.5 -> 50.3 ms/step)
@@ -257,16 +257,22 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         }
         struct It { int g, t0, t1, part, big; };
         std::vector<It> pit, dit;
-        std::vector<int> g_parts(ng, 1);
+        std::vector<int> g_parts(ng, 1), pit_dir;
         if (persist) {
             // Persistent workgroups (one per CU, k_edge_attn loops over its slot's items; the LDS-resident weights are staged once per
             // workgroup instead of once per item) with a wrap-around schedule: the pair offsets of all groups, laid end to end
             // with the per-item cost in front of every piece, are cut into JODO_ATT_SLOTS runs of equal cost.  A group that straddles
             // a cut becomes two items (two partials for its atoms) — at most one cut per slot, so the launch is balanced to within
             // one offset, where the dispatcher's longest-first greedy over whole items left 9 % (simulated and measured).
+            // The groups of a molecule larger than a group (n > 128) take part with their sources instead of pair offsets: the
+            // kernel walks those items in directed mode (round 5; they used to be a second, nearly empty launch serialised behind
+            // this one: 710 us per block at nf 384 for two such molecules in 1 250).
             const double a_item = 0.3;                             // cost of starting an item, in pair offsets (0.3 / 0.6 / 0.9 / 1.3 measured: 3.58 / 3.62 / 3.62 / 3.76 ms/step)
+            const double w_dir = 0.9;                              // a directed iteration in pair offsets: the same matrix work, one direction's vector work, no hand-over
+            auto g_len = [&](int g) { return g_big[g] ? g_nmax[g] : g_nmax[g] / 2; };
+            auto g_wgt = [&](int g) { return g_big[g] ? w_dir : 1.0; };
             double total = 0.0;
-            for (int g = 0; g < ng; ++g) if (!g_big[g]) total += a_item + (double)(g_nmax[g] / 2);
+            for (int g = 0; g < ng; ++g) total += a_item + g_wgt(g) * (double)g_len(g);
             // every cut adds an item (and its cost) that `total` did not count: the slot capacity T grows until the walk ends
             // inside the last slot's capacity
             double T = std::max(total / JODO_ATT_SLOTS, a_item + 1.0);
@@ -277,19 +283,19 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
                 double load = 0.0;
                 auto next_slot = [&]() { if (slot + 1 < JODO_ATT_SLOTS) { ++slot; load = 0.0; } };
                 for (int g = 0; g < ng; ++g) {
-                    if (g_big[g]) continue;
-                    const int dmax = g_nmax[g] / 2;
+                    const int len = g_len(g);
+                    const double wg = g_wgt(g);
                     int t = 0, part = 0;
                     do {
                         double room = T - load - a_item;
                         if (room < 0.75 && load > 0.0 && slot + 1 < JODO_ATT_SLOTS) { next_slot(); room = T - a_item; }
-                        int take = std::min(dmax - t, std::max(1, (int)(room + 0.5)));
+                        int take = std::min(len - t, std::max(1, (int)(room / wg + 0.5)));
                         take = std::max(take, 0);
                         pit.push_back({g, t, t + take, part++, slot});      // `big` holds the slot until the lists are written
-                        load += a_item + (double)take;
+                        load += a_item + wg * (double)take;
                         t += take;
                         if (load >= T - 0.5) next_slot();
-                    } while (t < dmax);
+                    } while (t < len);
                     g_parts[g] = part;
                 }
                 if (load <= T + 0.5) break;                                  // the last slot did not overflow
@@ -297,18 +303,20 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
             // items are already in slot order (slots ascend along the walk)
             for (const It& it : pit) aw_off[it.big + 1]++;
             for (int sl = 0; sl < JODO_ATT_SLOTS; ++sl) aw_off[sl + 1] += aw_off[sl];
-            for (It& it : pit) it.big = 0;
+            for (It& it : pit) { it.big = 0; pit_dir.push_back(g_big[it.g]); }
         }
         for (int g = 0; g < ng; ++g) {
             const int nmax = g_nmax[g], dmax = nmax / 2;
             int parts;
-            if (g_big[g]) parts = std::max(1, (nmax + 2 * achunk - 1) / (2 * achunk));
-            else parts = persist ? g_parts[g] : std::max(1, (dmax + achunk - 1) / achunk);
+            if (persist) parts = g_parts[g];
+            else if (g_big[g]) parts = std::max(1, (nmax + 2 * achunk - 1) / (2 * achunk));
+            else parts = std::max(1, (dmax + achunk - 1) / achunk);
             amax_parts = std::max(amax_parts, parts);
             const int cp = dmax > 0 ? (dmax + parts - 1) / parts : 0, cd = (nmax + parts - 1) / parts;
             for (int q = 0; q < parts; ++q) {
                 if (!g_big[g] && !persist) pit.push_back({g, std::min(dmax, q * cp), std::min(dmax, (q + 1) * cp), q, 0});
-                dit.push_back({g, std::min(nmax, q * cd), std::min(nmax, (q + 1) * cd), q, g_big[g]});
+                // (the directed launch serves a big group for symmetric inputs only when the pair launch does not carry it)
+                dit.push_back({g, std::min(nmax, q * cd), std::min(nmax, (q + 1) * cd), q, (g_big[g] && !persist) ? 1 : 0});
             }
             for (int k = 0; k < G; ++k) { const int v = ag_node[(size_t)g * G + k]; if (v >= 0) anode_parts[v] = parts; }
         }
@@ -318,12 +326,14 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         if (!persist) std::stable_sort(pit.begin(), pit.end(), lpt);
         std::stable_sort(dit.begin(), dit.end(), lpt);
         for (const It& it : pit) { ai_group.push_back(it.g); ai_t0.push_back(it.t0); ai_t1.push_back(it.t1); ai_part.push_back(it.part); }
+        ai_dir.assign(pit.size(), 0);
+        for (size_t i = 0; i < pit_dir.size(); ++i) ai_dir[i] = pit_dir[i];
         for (const It& it : dit) { ad_group.push_back(it.g); ad_t0.push_back(it.t0); ad_t1.push_back(it.t1); ad_part.push_back(it.part); ad_big.push_back(it.big); }
         p->n_aitems = (int)pit.size(); p->n_aditems = (int)dit.size(); p->amax_parts = amax_parts;
         p->a_persist = persist ? 1 : 0;
         if (!persist) aw_off.assign(1, 0);
         p->has_big = 0;
-        for (int g = 0; g < ng; ++g) p->has_big |= g_big[g];
+        for (int g = 0; g < ng; ++g) p->has_big |= (g_big[g] && !persist) ? 1 : 0;
     }
 
     auto put = [&](const std::vector<int32_t>& a, size_t* off) {
@@ -336,7 +346,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     put(orig_n, &p->off_orig_n); put(orig_noff, &p->off_orig_noff); put(orig_eoff, &p->off_orig_eoff);
     put(it_strip, &p->off_item_strip); put(it_t0, &p->off_item_t0); put(it_t1, &p->off_item_t1); put(it_part, &p->off_item_part); put(strip_parts, &p->off_strip_parts);
     put(pi_strip, &p->off_pitem_strip); put(pi_t0, &p->off_pitem_t0); put(pi_t1, &p->off_pitem_t1);
-    put(ag_node, &p->off_ag_node); put(ai_group, &p->off_ai_group); put(ai_t0, &p->off_ai_t0); put(ai_t1, &p->off_ai_t1); put(ai_part, &p->off_ai_part);
+    put(ag_node, &p->off_ag_node); put(ai_group, &p->off_ai_group); put(ai_t0, &p->off_ai_t0); put(ai_t1, &p->off_ai_t1); put(ai_part, &p->off_ai_part); put(ai_dir, &p->off_ai_dir);
     put(ad_group, &p->off_ad_group); put(ad_t0, &p->off_ad_t0); put(ad_t1, &p->off_ad_t1); put(ad_part, &p->off_ad_part); put(ad_big, &p->off_ad_big);
     put(anode_parts, &p->off_anode_parts); put(aw_off, &p->off_aw_off);
     {   // one row per unordered pair of every molecule's dense edge tile + its mirror: the edge head evaluates a symmetric pair once.
@@ -566,7 +576,12 @@ extern "C" int jodo_debug_attn_schedule(const jodo_plan* p, int64_t* o) {
                 const int v = d[p->off_ag_node + (size_t)g * 128 + k];
                 if (v >= 0) { nmax = std::max(nmax, (int)d[p->off_node_n + v]); want_parts = d[p->off_anode_parts + v]; }
             }
-            if (nmax > 128) { if (!per[g].empty()) return jodo_set_error(JODO_ERR_ARG, "attn_schedule: pair items for the big group %d", g); continue; }
+            // a group of a molecule larger than a group: carried by the pair launch (persistent schedule) as directed-mode items that
+            // tile its SOURCES [0, n), or not at all (fixed-chunk plans: the directed launch serves it)
+            const bool bigg = nmax > 128;
+            if (bigg && !p->a_persist) { if (!per[g].empty()) return jodo_set_error(JODO_ERR_ARG, "attn_schedule: pair items for the big group %d", g); continue; }
+            for (int i = 0; i < p->n_aitems; ++i)
+                if (d[p->off_ai_group + i] == g && d[p->off_ai_dir + i] != (bigg ? 1 : 0)) return jodo_set_error(JODO_ERR_ARG, "attn_schedule: item %d of group %d has the wrong mode", i, g);
             std::sort(per[g].begin(), per[g].end());
             std::sort(parts[g].begin(), parts[g].end());
             int at = 0;
@@ -574,7 +589,8 @@ extern "C" int jodo_debug_attn_schedule(const jodo_plan* p, int64_t* o) {
                 if (it.first != at || it.second < it.first) return jodo_set_error(JODO_ERR_ARG, "attn_schedule: group %d offsets not tiled at %d", g, at);
                 at = it.second;
             }
-            if (at != nmax / 2 || per[g].empty()) return jodo_set_error(JODO_ERR_ARG, "attn_schedule: group %d covers %d of %d offsets", g, at, nmax / 2);
+            const int want_len = bigg ? nmax : nmax / 2;
+            if (at != want_len || per[g].empty()) return jodo_set_error(JODO_ERR_ARG, "attn_schedule: group %d covers %d of %d offsets", g, at, want_len);
             for (size_t q = 0; q < parts[g].size(); ++q)
                 if (parts[g][q] != (int)q) return jodo_set_error(JODO_ERR_ARG, "attn_schedule: group %d partial indices are not 0..%d", g, (int)parts[g].size() - 1);
             if ((int)parts[g].size() != want_parts) return jodo_set_error(JODO_ERR_ARG, "attn_schedule: group %d has %d items, its atoms expect %d partials", g, (int)parts[g].size(), want_parts);

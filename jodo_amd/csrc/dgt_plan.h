@@ -46,11 +46,12 @@ struct PlanDev {
     const int* ai_t0;
     const int* ai_t1;
     const int* ai_part;
+    const int* ai_dir;      // 1 = item of a molecule that spans several groups, carried by the pair launch in directed mode: sources t in [t0, t1)
     const int* ad_group;    // directed-mode items (asymmetric inputs; molecules larger than a group): sources t in [t0, t1)
     const int* ad_t0;
     const int* ad_t1;
     const int* ad_part;
-    const int* ad_big;      // 1 = group of a molecule that spans several groups: directed mode even for symmetric inputs
+    const int* ad_big;      // 1 = group of a molecule that spans several groups and the pair launch does not carry it (fixed-chunk plans): the directed launch works on it even for symmetric inputs
     const int* anode_parts; // [Nn_pad] number of attention partials of a node
     const int* aw_off;      // persistent pair-mode launch: items [aw_off[w], aw_off[w + 1]) belong to workgroup w (JODO_ATT_SLOTS + 1 entries)
     int a_persist;
@@ -78,8 +79,8 @@ struct jodo_plan {
     int n_agroups, n_aitems, n_aditems, amax_parts, n_ut_pad, n_gtiles;
     int a_persist;                   // pair-mode attention items are scheduled onto JODO_ATT_SLOTS persistent workgroups (off_aw_off)
     size_t off_aw_off;
-    int has_big;                     // some molecule spans several attention groups (n > 128): its items always run in directed mode
-    size_t off_ag_node, off_ai_group, off_ai_t0, off_ai_t1, off_ai_part, off_ad_group, off_ad_t0, off_ad_t1, off_ad_part, off_ad_big, off_anode_parts, off_ut_rows, off_gt_sa, off_gt_sc;
+    int has_big;                     // some molecule spans several attention groups (n > 128) AND the directed launch must serve it for symmetric inputs (ad_big)
+    size_t off_ag_node, off_ai_group, off_ai_t0, off_ai_t1, off_ai_part, off_ai_dir, off_ad_group, off_ad_t0, off_ad_t1, off_ad_part, off_ad_big, off_anode_parts, off_ut_rows, off_gt_sa, off_gt_sc;
     int64_t rows, dir_edges;
     std::vector<int32_t> desc;       // concatenated descriptor tables
     size_t off_node_b, off_node_i, off_node_n, off_node_noff, off_node_eoff, off_orig_n, off_orig_noff,

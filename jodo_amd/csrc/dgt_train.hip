@@ -207,6 +207,11 @@ struct Ctx {
     Drop drop(float p, unsigned long long seed, int l, int site) const { Drop d; d.p = p; d.seed = seed; d.site = (unsigned)(l * 8 + site); return d; }
 };
 
+// Dropout sites of a block.  Only the four FFN sites are live (mol_gnn.py:308-317: `self.dropout` after the activation and after the
+// second linear of the node and of the edge FFN).  SITE_ALPHA — F.dropout on the softmax weights, layers.py:179 — is an IDENTITY in the
+// reference: EquivariantMixBlock builds its TransMixLayer without a dropout argument (mol_gnn.py:230-231), so TransMixLayer.dropout keeps
+// its default 0.0 (layers.py:99) whatever config.model.dropout says.  The site is kept (with p = 0) so that the kernels' signatures and
+// the (seed, site) numbering of the four live sites do not move.
 enum { SITE_ALPHA = 0, SITE_A1, SITE_F2, SITE_A3, SITE_F4 };
 
 // MLP head: Linear SiLU Linear SiLU Linear; saves the two pre-activations and activations
@@ -289,7 +294,7 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
                            (const float*)k.t0, (const float*)b.adj2d, (const float*)b.adjsp, k.alpha);
         JT_LAUNCH(k_attn_softmax, (long)Nn * H, s, tp, H, k.alpha);
         JT_LAUNCH(k_attn_msg, (long)Nn * D, s, tp, D, H, (const float*)k.v, (const float*)k.t1, (const float*)k.alpha,
-                           c.drop(p_drop, seed, l, SITE_ALPHA), k.hhat);
+                           c.drop(0.f, seed, l, SITE_ALPHA), k.hhat);     // p = 0: see SITE_ALPHA
         c.lin(k.hhat, D, Nn, D, c.p(ix.n2e.w), D, De, nullptr, k.n2e, De, 0);
         // edges: gated residual, LayerNorm2 + modulate, FFN (:313-317)
         float* x1e = b.tE_De[0];
@@ -474,7 +479,7 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         JT_LAUNCH(k_gate_bwd, (long)Nn * D, s, (long)Nn, D, (const float*)dh_prev, tp.node_mol, (const float*)k.nmod, 6 * D, 2 * D, dhhat, 1);
         // ---- attention backwards
         const float isc = 1.f / sqrtf((float)t.C);
-        const Drop da = c.drop(p_drop, seed, l, SITE_ALPHA);
+        const Drop da = c.drop(0.f, seed, l, SITE_ALPHA);                    // p = 0: see SITE_ALPHA
         float *dv = b.tN_D[1], *dt1 = b.tE_D[0], *dS = b.tE_H, *dq = b.tN_QK[0], *dk = b.tN_QK[1], *dt0 = b.tE_QK;
         JT_LAUNCH(k_attn_bwd_v, (long)Nn * D, s, tp, D, H, (const float*)dhhat, (const float*)k.t1, (const float*)k.alpha, da, dv);
         JT_LAUNCH(k_attn_bwd_t1, (long)R * D, s, tp, D, H, (const float*)dhhat, (const float*)k.v, (const float*)k.t1, (const float*)k.alpha, da, dt1);
@@ -558,6 +563,10 @@ int jodo_train_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes,
     if (!cfg || !n_nodes || !params || !out || B <= 0 || N <= 0) return jodo_set_error(JODO_ERR_ARG, "jodo_train_create: null / non-positive argument");
     if (cfg->nf % cfg->n_heads || cfg->nf % 4 || cfg->n_heads <= cfg->n_extra || cfg->n_extra != 2)
         return jodo_set_error(JODO_ERR_UNSUPPORTED, "jodo_train_create: nf %d / n_heads %d / n_extra_heads %d", cfg->nf, cfg->n_heads, cfg->n_extra);
+    // k_row_part / k_ln_bwd_part (train_ops.h) cut a LayerNorm row of De = nf / 4 features into eight equal parts, and the MLP heads
+    // halve D and De: a width that is not a multiple of 32 would silently drop trailing features from the statistics
+    if (cfg->nf % 32)
+        return jodo_set_error(JODO_ERR_UNSUPPORTED, "jodo_train_create: nf %d is not a multiple of 32 (LayerNorm rows of nf / 4 features are reduced in eight equal parts)", cfg->nf);
     jodo_train* t = new jodo_train();
     t->cfg = *cfg; t->B = B; t->N = N;
     t->D = cfg->nf; t->De = cfg->nf / 4; t->T = cfg->nf * 4; t->L = cfg->n_layers; t->H = cfg->n_heads; t->XH = cfg->n_extra;
@@ -662,6 +671,23 @@ int jodo_train_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes,
 void jodo_train_destroy(jodo_train* t) { delete t; }
 size_t jodo_train_desc_bytes(const jodo_train* t) { return t ? t->tables.size() * sizeof(int) : 0; }
 size_t jodo_train_workspace_bytes(const jodo_train* t) { return t ? t->ws_bytes : 0; }
+// tests: where a kept activation lives in the workspace.  what 0 = hhat (attention output [Nn, D]), 1 = alpha (softmax weights
+// [R, H]) of block `layer`
+int jodo_train_debug_locate(const jodo_train* t, int what, int layer, size_t* byte_offset, size_t* count) {
+    if (!t || !byte_offset || !count) return jodo_set_error(JODO_ERR_ARG, "jodo_train_debug_locate: null argument");
+    if (layer < 0 || layer >= t->L) return jodo_set_error(JODO_ERR_ARG, "jodo_train_debug_locate: layer %d of %d", layer, t->L);
+    Arena a{reinterpret_cast<char*>(256), 0};              // any non-null base: only the differences are used
+    Bufs b;
+    layout(*t, a, b);
+    const float* ptr = nullptr;
+    size_t n = 0;
+    if (what == 0) { ptr = b.blk[layer].hhat; n = (size_t)t->Nn * t->D; }
+    else if (what == 1) { ptr = b.blk[layer].alpha; n = (size_t)t->R * t->H; }
+    else return jodo_set_error(JODO_ERR_ARG, "jodo_train_debug_locate: unknown selector %d", what);
+    *byte_offset = (size_t)(reinterpret_cast<const char*>(ptr) - reinterpret_cast<const char*>(256));
+    *count = n;
+    return JODO_OK;
+}
 int jodo_train_upload(jodo_train* t, void* desc_dev, void* stream) {
     if (!t || !desc_dev) return jodo_set_error(JODO_ERR_ARG, "jodo_train_upload: null argument");
     (void)hipMemcpyAsync(desc_dev, t->tables.data(), t->tables.size() * sizeof(int), hipMemcpyHostToDevice, static_cast<hipStream_t>(stream));

@@ -1,7 +1,7 @@
 // Training-side kernels of the DGT: forward with saved activations and the backward of every phase of
 //   DGT_concat.forward / Cond_DGT_concat.forward     /root/reference/models/mol_gnn.py:491-594, :687-794
 //   EquivariantMixBlock.forward                      models/mol_gnn.py:270-322
-//   TransMixLayer.forward / message                  models/layers.py:131-186   (dropout on alpha :179)
+//   TransMixLayer.forward / message                  models/layers.py:131-186   (F.dropout on alpha, :179, is an identity: the block builds the layer with its default dropout = 0, mol_gnn.py:230)
 //   MultiCondEquiUpdate.forward                      models/mol_gnn.py:71-94
 //   CondGaussianLayer / gaussian, CoorsNorm          models/layers.py:291-295, :328-334, :344-347
 // i.e. what loss.backward() (losses.py:286-385) differentiates.  Everything that is not a dense projection lives here; the

@@ -139,6 +139,14 @@ class TrainEngine:
             capi.ptr(out_x), capi.ptr(out_e), capi.ptr(self.flags), capi.ptr(pool['buf']), self._stream()), 'jodo_train_forward')
         return out_x, out_e
 
+    def debug_fetch(self, what, layer):
+        """tests: a kept activation of the last forward (jodo_train_debug_locate: 0 = hhat [Nn, D], 1 = alpha [R, H] of block `layer`)."""
+        off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+        self.L.jodo_train_debug_locate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self._check(self.L.jodo_train_debug_locate(self.handle, int(what), int(layer), ctypes.byref(off), ctypes.byref(cnt)), 'jodo_train_debug_locate')
+        buf = self.pool['buf']
+        return buf[off.value:off.value + 4 * cnt.value].view(torch.float32).clone()
+
     def backward(self, params, noise_level, d_out_x, d_out_e, dropout_p, seed):
         # one allocation for all gradients (the library then zeroes them with a single fill)
         sizes = [p.numel() for p in params]

@@ -123,7 +123,15 @@ def test_dropout_masks_are_shared_by_forward_and_backward(emul):
     params = [v.detach().float().contiguous() for v in model.state_dict().values()]
     p, seed = 0.1, 1234
     o0 = eng.forward(params, xh, ex, None, None, nl, None, 0.0, seed)
+    alpha0, hhat0 = eng.debug_fetch(1, 0), eng.debug_fetch(0, 0)
+    hhat0_last = eng.debug_fetch(0, hp.n_layers - 1)
     o1 = eng.forward(params, xh, ex, None, None, nl, None, p, seed)
+    # Where dropout acts.  The reference drops in the four FFN positions of a block (mol_gnn.py:262-268) and NOT on the attention
+    # weights: F.dropout(alpha, p=self.dropout) at layers.py:179 runs with TransMixLayer's default dropout = 0 because the block
+    # never passes its own (mol_gnn.py:230-231).  Block 0's attention precedes every live site, so its softmax weights and its
+    # output must not move with p; the last block's input has been through the FFN sites and must.
+    assert torch.equal(eng.debug_fetch(1, 0), alpha0) and torch.equal(eng.debug_fetch(0, 0), hhat0)
+    assert float(alpha0.abs().max()) > 0 and not torch.equal(eng.debug_fetch(0, hp.n_layers - 1), hhat0_last)
     o1b = eng.forward(params, xh, ex, None, None, nl, None, p, seed)
     o2 = eng.forward(params, xh, ex, None, None, nl, None, p, seed + 1)
     assert torch.equal(o1[0], o1b[0]) and torch.equal(o1[1], o1b[1])
