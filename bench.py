@@ -266,6 +266,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='qm9', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0)
+    ap.add_argument('--seed', type=int, default=-1, help='seed of the atom-count draw and the noise (default: config.seed = 42); e.g. --workload geom '
+                                                          '--seed 80 gives a batch with two molecules above an attention group (n = 144, 156)')
     ap.add_argument('--max-chunk', type=int, default=0)
     ap.add_argument('--pair-chunk', type=int, default=0)
     ap.add_argument('--spair-chunk', type=int, default=0)
@@ -338,6 +340,8 @@ def main():
     model.force_directed = bool(int(os.environ.get("JODO_FORCE_DIRECTED", "0")))   # debug: skip the symmetric pair kernels
 
     # synthetic inputs: atom counts from the training histogram (seed 42 + rank), reference noise shapes
+    if args.seed >= 0:
+        cfg.seed = args.seed
     torch.manual_seed(cfg.seed + rank)
     nodes_dist = get_node_dist(load_dataset_info(wl['info']))
     n_nodes = nodes_dist.sample(B).tolist()
@@ -601,7 +605,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': wl['name'], 'batch_per_gpu': B, 'sampling_steps': SAMPLING_STEPS,
-                       'directed_edges_per_step': E, 'nodes_per_step': sum(n_nodes), 'max_n': N,
+                       'directed_edges_per_step': E, 'nodes_per_step': sum(n_nodes), 'max_n': N, 'seed': int(cfg.seed),
                        'weights': 'deterministic random init (trained checkpoints are external downloads)',
                        'step_noise': 'torch.randn x3 per step' if args.torch_noise else 'in-kernel Philox4x32-10 (jodo_sampler_step_rng)',
                        'streams_per_gpu': n_sub,

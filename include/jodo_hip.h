@@ -190,6 +190,9 @@ enum jodo_plan_option {
                                      items (k_pre_embed: HBM-write-bound items beside matrix-bound ones); 0: a launch of its own */
     JODO_OPT_AB_PRE = 11,         /* 1 (default; nf 256 tuned kernel set, fewer than 1024 node strips): the next block's q / k / v items share
                                      the launch of this block's k_node_ab items and Gram tiles (k_node_ab_pre); 0: a k_node_pre launch per block */
+    JODO_OPT_Z_SPLIT = 12,        /* 1 (default): when the LAST round of the pair update's launch (n_pitems mod 1024) has at most 256 items, they run as
+                                   * workgroups of 4 waves that share the per-pair coord_mlp.0 output blocks (k_edge_update_sym<.., ZW = 4>); 2: also
+                                   * 2 waves for 257 .. 512 items (measured slower on MI355X, kept for A/B runs); 0: one wave per item throughout */
     JODO_OPT_COUNT
 };
 int jodo_plan_set_option(jodo_plan* plan, int option, int value);

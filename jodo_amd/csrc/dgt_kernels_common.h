@@ -85,6 +85,49 @@ __device__ __forceinline__ LaneNode lane_node(const KArgs& A, int strip, int j) 
     return L;
 }
 
+// Positions entering a block = previous positions + the previous update's contributions (MultiCondEquiUpdate, mol_gnn.py:90-92:
+// `pos + scatter(trans, row, reduce='add')`).  The contributions are summed AMONG THEMSELVES and added to the position once, as the
+// reference does: rounds 1-4 added every neighbour's term into the running position, i.e. up to 180 roundings at ulp(|x| ~ 4) per
+// block instead of one — the digit that the n > 128 tolerance regime of tests/helpers.py paid for (round-4 review, item 4).  The sum
+// runs in double (fixed column order; k_pos_final is a few microseconds of loads, not arithmetic).
+__device__ __forceinline__ float4 advance_position(const KArgs& A, float4 p, int v, int strip, int n, int i, int eoff) {
+    double sx = 0., sy = 0., sz = 0.;
+    if (A.flags[FLAG_ASYM]) {
+        const int parts = A.pd.strip_parts[strip];
+        for (int q = 0; q < parts; ++q) {
+            const float4 dp = reinterpret_cast<const float4*>(A.dpos)[(size_t)v * A.pd.max_parts + q];
+            sx += dp.x; sy += dp.y; sz += dp.z;
+        }
+    } else {                                               // pair path: one contribution per edge row (i, c)
+        const float4* row = reinterpret_cast<const float4*>(A.dposE) + (size_t)eoff + (size_t)i * n;
+        // eight, then four rows in flight per step (one load per iteration paid one exposed L2 round trip per neighbour: 15 us per
+        // launch at QM9 B = 2500, nine launches per forward; GEOM molecules have up to 181 atoms)
+        int c = 0;
+        for (; c + 8 <= n; c += 8) {
+            float4 d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[u] = row[c + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c + u != i) { sx += d[u].x; sy += d[u].y; sz += d[u].z; }
+        }
+        for (; c + 4 <= n; c += 4) {
+            const float4 d0 = row[c], d1 = row[c + 1], d2 = row[c + 2], d3 = row[c + 3];
+            if (c != i) { sx += d0.x; sy += d0.y; sz += d0.z; }
+            if (c + 1 != i) { sx += d1.x; sy += d1.y; sz += d1.z; }
+            if (c + 2 != i) { sx += d2.x; sy += d2.y; sz += d2.z; }
+            if (c + 3 != i) { sx += d3.x; sy += d3.y; sz += d3.z; }
+        }
+        for (; c < n; ++c) {
+            if (c == i) continue;
+            const float4 dp = row[c];
+            sx += dp.x; sy += dp.y; sz += dp.z;
+        }
+    }
+    p.x += (float)sx; p.y += (float)sy; p.z += (float)sz;
+    return p;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 }  // namespace jd

@@ -24,32 +24,7 @@ __device__ __forceinline__ void node_pre_body(const KArgs& A, int blk) {
     // positions entering this block: previous positions + the contributions of the previous update
     if (!NEXT && piece == 0 && A.pre_mode == 0) {
         float4 p = reinterpret_cast<const float4*>(A.pos_in)[L.v];
-        if (A.layer > 0) {
-            if (A.flags[FLAG_ASYM]) {
-                const int parts = A.pd.strip_parts[strip];
-                for (int q = 0; q < parts; ++q) {
-                    const float4 dp = reinterpret_cast<const float4*>(A.dpos)[(size_t)L.v * A.pd.max_parts + q];
-                    p.x += dp.x; p.y += dp.y; p.z += dp.z;
-                }
-            } else {                                       // pair path: one contribution per edge row (i, c)
-                const float4* row = reinterpret_cast<const float4*>(A.dposE) + (size_t)L.eoff + (size_t)L.i * L.n;
-                // four neighbour rows in flight per step, added in column order (bit-identical to one load per iteration, which
-                // paid an exposed memory round trip per neighbour: up to 181 at GEOM)
-                int c = 0;
-                for (; c + 4 <= L.n; c += 4) {
-                    const float4 d0 = row[c], d1 = row[c + 1], d2 = row[c + 2], d3 = row[c + 3];
-                    if (c != L.i) { p.x += d0.x; p.y += d0.y; p.z += d0.z; }
-                    if (c + 1 != L.i) { p.x += d1.x; p.y += d1.y; p.z += d1.z; }
-                    if (c + 2 != L.i) { p.x += d2.x; p.y += d2.y; p.z += d2.z; }
-                    if (c + 3 != L.i) { p.x += d3.x; p.y += d3.y; p.z += d3.z; }
-                }
-                for (; c < L.n; ++c) {
-                    if (c == L.i) continue;
-                    const float4 dp = row[c];
-                    p.x += dp.x; p.y += dp.y; p.z += dp.z;
-                }
-            }
-        }
+        if (A.layer > 0) p = advance_position(A, p, L.v, strip, L.n, L.i, L.eoff);
         if (half == 0) reinterpret_cast<float4*>(A.pos_out)[L.v] = p;
     }
     const float* mr = mod_row(A, L.b) + (NEXT ? A.mod_base_next : A.mod_base);          // node chunks: ns1, nc1, ng1, ns2, nc2, ng2

@@ -12,42 +12,8 @@ __global__ void k_pos_final(KArgs A) {
     if (v >= A.pd.Nn_pad) return;
     float4 p = reinterpret_cast<const float4*>(A.pos_in)[v];
     if (v < A.pd.Nn) {
-        if (A.layer > 0) {                                    // at least one block ran
-            if (A.flags[FLAG_ASYM]) {
-                const int parts = A.pd.strip_parts[v >> 5];
-                for (int q = 0; q < parts; ++q) {
-                    const float4 dp = reinterpret_cast<const float4*>(A.dpos)[(size_t)v * A.pd.max_parts + q];
-                    p.x += dp.x; p.y += dp.y; p.z += dp.z;
-                }
-            } else {
-                const int n = A.pd.node_n[v], i = A.pd.node_i[v];
-                const float4* row = reinterpret_cast<const float4*>(A.dposE) + (size_t)A.pd.node_eoff[v] + (size_t)i * n;
-                // eight, then four rows in flight per step, added in column order (the sum is bit-identical to the one-load-per-iteration
-                // loop, which paid one exposed L2 round trip per neighbour: 15 us per launch at QM9 B = 2500, nine launches per forward;
-                // GEOM molecules have up to 181 atoms: 23 us per launch at four in flight)
-                int c = 0;
-                for (; c + 8 <= n; c += 8) {
-                    float4 d[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) d[u] = row[c + u];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (c + u != i) { p.x += d[u].x; p.y += d[u].y; p.z += d[u].z; }
-                }
-                for (; c + 4 <= n; c += 4) {
-                    const float4 d0 = row[c], d1 = row[c + 1], d2 = row[c + 2], d3 = row[c + 3];
-                    if (c != i) { p.x += d0.x; p.y += d0.y; p.z += d0.z; }
-                    if (c + 1 != i) { p.x += d1.x; p.y += d1.y; p.z += d1.z; }
-                    if (c + 2 != i) { p.x += d2.x; p.y += d2.y; p.z += d2.z; }
-                    if (c + 3 != i) { p.x += d3.x; p.y += d3.y; p.z += d3.z; }
-                }
-                for (; c < n; ++c) {
-                    if (c == i) continue;
-                    const float4 dp = row[c];
-                    p.x += dp.x; p.y += dp.y; p.z += dp.z;
-                }
-            }
-        }
+        if (A.layer > 0)                                      // at least one block ran
+            p = advance_position(A, p, v, v >> 5, A.pd.node_n[v], A.pd.node_i[v], A.pd.node_eoff[v]);
         if (isnan(p.x) || isnan(p.y) || isnan(p.z)) atomicOr(&A.flags[FLAG_NAN], 1);
     }
     reinterpret_cast<float4*>(A.pos_out)[v] = p;
@@ -75,16 +41,18 @@ __global__ void k_finalize_nodes(KArgs A) {
     }
     const int v0 = A.pd.orig_noff[b];
     const bool nan = A.flags[FLAG_NAN] != 0;
-    float mx = 0.f, my = 0.f, mz = 0.f;
+    // centre of mass (remove_mean_with_mask, models/utils.py:38-45): the sum over up to 181 positions of size ~ 4 runs in double —
+    // in float its partial sums reach 10^2 and every addition rounds at their ulp, not at the positions'
+    double mx = 0., my = 0., mz = 0.;
     for (int k = 0; k < n; ++k) {
         const float4 p = reinterpret_cast<const float4*>(A.pos_out)[v0 + k];
         mx += p.x; my += p.y; mz += p.z;
     }
     const float4 p = reinterpret_cast<const float4*>(A.pos_out)[v0 + i];
-    const float inv = 1.f / (float)n;
-    o[0] = nan ? 0.f : p.x - mx * inv;
-    o[1] = nan ? 0.f : p.y - my * inv;
-    o[2] = nan ? 0.f : p.z - mz * inv;
+    const double inv = 1.0 / (double)n;
+    o[0] = nan ? 0.f : p.x - (float)(mx * inv);
+    o[1] = nan ? 0.f : p.y - (float)(my * inv);
+    o[2] = nan ? 0.f : p.z - (float)(mz * inv);
     const float* ap = A.apred + (size_t)(v0 + i) * 32;
     for (int f = 0; f < nd; ++f) o[3 + f] = ap[f];
 }

@@ -136,32 +136,7 @@ __device__ __forceinline__ void node_pre_body(const KArgs& A, int blk) {
     const LaneNode L = lane_node(A, strip, j);
     if (!NEXT && piece == 0 && A.pre_mode == 0) {
         float4 p = reinterpret_cast<const float4*>(A.pos_in)[L.v];
-        if (A.layer > 0) {
-            if (A.flags[FLAG_ASYM]) {
-                const int parts = A.pd.strip_parts[strip];
-                for (int q = 0; q < parts; ++q) {
-                    const float4 dp = reinterpret_cast<const float4*>(A.dpos)[(size_t)L.v * A.pd.max_parts + q];
-                    p.x += dp.x; p.y += dp.y; p.z += dp.z;
-                }
-            } else {                                       // pair path: one contribution per edge row (i, c)
-                const float4* row = reinterpret_cast<const float4*>(A.dposE) + (size_t)L.eoff + (size_t)L.i * L.n;
-                // four neighbour rows in flight per step, added in column order (bit-identical to one load per iteration, which
-                // paid an exposed memory round trip per neighbour: up to 181 at GEOM)
-                int c = 0;
-                for (; c + 4 <= L.n; c += 4) {
-                    const float4 d0 = row[c], d1 = row[c + 1], d2 = row[c + 2], d3 = row[c + 3];
-                    if (c != L.i) { p.x += d0.x; p.y += d0.y; p.z += d0.z; }
-                    if (c + 1 != L.i) { p.x += d1.x; p.y += d1.y; p.z += d1.z; }
-                    if (c + 2 != L.i) { p.x += d2.x; p.y += d2.y; p.z += d2.z; }
-                    if (c + 3 != L.i) { p.x += d3.x; p.y += d3.y; p.z += d3.z; }
-                }
-                for (; c < L.n; ++c) {
-                    if (c == L.i) continue;
-                    const float4 dp = row[c];
-                    p.x += dp.x; p.y += dp.y; p.z += dp.z;
-                }
-            }
-        }
+        if (A.layer > 0) p = advance_position(A, p, L.v, strip, L.n, L.i, L.eoff);
         if (half == 0) reinterpret_cast<float4*>(A.pos_out)[L.v] = p;
     }
     const float* mr = mod_row(A, L.b) + (NEXT ? A.mod_base_next : A.mod_base);
@@ -630,9 +605,14 @@ __global__ __launch_bounds__(64, 1) void k_edge_update(KArgs A) {
 // lane) is kept in a per-lane array for both directions (registers at D = 256, partly spilled to scratch at
 // D = 384 — four waves' LDS slabs of 48 KiB would not fit the CU's 160 KiB), and each direction requests its
 // per-node rows with buffer loads pinned ahead of their use (BRow, dgt_device.h).
-template <int D, int R, bool FOLD = false, bool ROT = false>
-__global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
+// ZW > 1 (round 5): the items of a launch's sparsely filled LAST round (launch_update_sym, dgt_edge.hip) run as workgroups of ZW
+// waves.  Every wave evaluates the shared trunk and the LayerNorm statistics; the output blocks of the per-pair coord_mlp.0
+// projection Z and their SiLU / coord_mlp.2 tails — half of a folded item's matrix work, 56 % of an unfolded one's — are dealt to
+// the waves, whose partial dot products meet in LDS in a fixed order (wave 0 finishes the item and does every store).
+template <int D, int R, bool FOLD = false, bool ROT = false, int ZW = 1>
+__global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
     static_assert(FOLD || !ROT, "the rotated statistics need the shared modulation row");
+    static_assert(ZW == 1 || D == 256 || FOLD, "the Z split needs the hoisted form (one coord_mlp.0 per pair)");
     if (A.flags[FLAG_ASYM]) return;
     // FOLD: every molecule shares one modulation row (unconditional sampling, one noise level per batch), so
     // coord_mlp.0 (1 + sc) input_lin[e ; G] is ONE D x 2De matrix per block (k_fold_coord) — see the hoist below.
@@ -642,6 +622,9 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
     constexpr int NCH = R * X::De / 64;
     constexpr int KQ4 = R * X::De / 8;
     const int lane = threadIdx.x & 63, jl = lane & 31, half = lane >> 5;
+    const int zw = ZW > 1 ? (int)(threadIdx.x >> 6) : 0;    // this wave's share of the Z blocks: [zb0, zb1)
+    const int zb0 = zw * (X::ND / ZW), zb1 = zb0 + X::ND / ZW;
+    static_assert(X::ND % ZW == 0, "Z blocks per wave");
     // dir_split: the items of a launch's sparsely filled last round get two workgroups each; both compute the
     // shared trunk, each evaluates one direction (item time x 0.64) — the trunk's stores come from direction 0
     const int it = A.item0 + (A.dir_split ? (int)(blockIdx.x >> 1) : (int)blockIdx.x);
@@ -668,9 +651,10 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
     // coord_mlp.2 (3 x D, the same for every item): read 16 times per pair offset by the tails right where it is needed; from
     // global memory each read was an exposed L1 round trip between two MFMA blocks, from LDS it is a short ds_read
     __shared__ float4 w2s[HOIST ? 3 * D / 4 : 1];
+    __shared__ float zred[ZW > 1 ? (ZW - 1) * 12 * 64 : 1];     // partial coord_mlp.2 dot products of waves 1 .. ZW - 1
     if constexpr (HOIST) {
         const float4* src = reinterpret_cast<const float4*>(A.W + A.wb[JB_C2_W]);
-        for (int i = lane; i < 3 * D / 4; i += 64) w2s[i] = src[i];
+        for (int i = threadIdx.x; i < 3 * D / 4; i += ZW * 64) w2s[i] = src[i];
         __syncthreads();
     }
     // (Tried and dropped: the trunk's other item-invariant vectors — modulation chunks, biases, Gaussian table, 3 KiB — from an
@@ -748,7 +732,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                 for (int s = 0; s < 16; ++s) en[b * 16 + s] = fmaf(og2[s], o[b][s] + ob4[s], en[b * 16 + s]);
             }
         }
-        if (P.ok && dsel != 1) {
+        if (P.ok && dsel != 1 && zw == 0) {
             store_nat<X::NE>(A.e_out + P.rij * X::De, half, en);
             if (!A.half_rows || L.n > PAIR_GROUP_LANES) store_nat<X::NE>(A.e_out + P.rji * X::De, half, en);
         }
@@ -780,7 +764,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             float rr[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) rr[s] = acc[s] + bb[s];
-            if (P.ok && dsel != 1 && (half == 0 || A.d.cep == 32)) {
+            if (P.ok && dsel != 1 && zw == 0 && (half == 0 || A.d.cep == 32)) {
                 store16(A.ehid + P.rij * A.d.KEH + X::De + A.layer * A.d.cep + half * 16, rr);
                 if (!A.half_rows || L.n > PAIR_GROUP_LANES) store16(A.ehid + P.rji * A.d.KEH + X::De + A.layer * A.d.cep + half * 16, rr);
             }
@@ -826,12 +810,12 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                     }
                     auto next_rows = [&]() {
                         if constexpr (k + 1 < NB2) { bload16(own_r, b - 1, n0); bload16(wcol_j, b - 1, n1); bload16(wrow_j, b - 1, n2); bload16(own_c, b - 1, n3); }
-                        else { bload16(ua_i, 0, n0); bload16(ub_j, 0, n1); bload16(ua_j, 0, n2); bload16(ub_i, 0, n3); }    // first block of the tail
+                        else { bload16(ua_i, zb0, n0); bload16(ub_j, zb0, n1); bload16(ua_j, zb0, n2); bload16(ub_i, zb0, n3); }    // first block of the tail
                     };
                     const unsigned cur = oL + (unsigned)(b * KQL + 4 * b) * 1024;
                     f32x16 acc;
                     if constexpr (k + 1 < NB2) acc = mfma_block_g<KQ, NXT>(wp, ws, cur, ws, oL + (unsigned)((b - 1) * KQL + 4 * (b - 1)) * 1024, z + 16 * b, zero16(), next_rows);
-                    else acc = mfma_block_g<KQ, NXT>(wp, ws, cur, wm, 0u, z + 16 * b, zero16(), next_rows);
+                    else acc = mfma_block_g<KQ, NXT>(wp, ws, cur, wm, (unsigned)zb0 * 2 * X::KQE * 1024, z + 16 * b, zero16(), next_rows);
                     PT(3);
 #pragma unroll
                     for (int s = 0; s < 16; s += 2) {
@@ -863,13 +847,13 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                 // the next block's rows are requested behind the last weight prefetch of this block (see mfma_block_p2)
                 auto next_rows = [&]() {
                     if (b + 1 < X::ND) { bload16(own_r, b + 1, n0); bload16(wcol_j, b + 1, n1); bload16(wrow_j, b + 1, n2); bload16(own_c, b + 1, n3); }
-                    else { bload16(ua_i, 0, n0); bload16(ub_j, 0, n1); bload16(ua_j, 0, n2); bload16(ub_i, 0, n3); }    // first block of the tail
+                    else { bload16(ua_i, zb0, n0); bload16(ub_j, zb0, n1); bload16(ua_j, zb0, n2); bload16(ub_i, zb0, n3); }    // first block of the tail
                 };
                 // (a second weight pipe — each part of a block prefetching its own part of the next block, two groups of
                 // cover — measured no gain: the blocks are bound by instruction issue, not by the wait for L2)
                 f32x16 acc = mfma_block_p<X::KQE>(wp, ws, we, wg_, en, zero16());
-                if (FOLD && b + 1 == X::ND) acc = mfma_block_p2<X::KQE>(wp, ws, wg_, wm, 0u, G, acc, next_rows);
-                else acc = mfma_block_p2<X::KQE>(wp, ws, wg_, ws, b + 1 < X::ND ? wg_ + X::KQE * 1024 : o0, G, acc, next_rows);
+                if (FOLD && b + 1 == X::ND) acc = mfma_block_p2<X::KQE>(wp, ws, wg_, wm, (unsigned)zb0 * 2 * X::KQE * 1024, G, acc, next_rows);
+                else acc = mfma_block_p2<X::KQE>(wp, ws, wg_, ws, b + 1 < X::ND ? wg_ + X::KQE * 1024 : o0 + (unsigned)zb0 * X::KQD * 1024, G, acc, next_rows);
                 PT(3);
 #pragma unroll
                 for (int s = 0; s < 16; s += 2) {                // element pairs on the packed fp32 pipe
@@ -892,7 +876,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
             const float* bs_v = wg_v + D;
             f32x2 c00 = {0.f, 0.f}, c01 = c00, c02 = c00, c10 = c00, c11 = c00, c12 = c00;
 #pragma unroll 1
-            for (int b = 0; b < X::ND; ++b) {
+            for (int b = zb0; b < zb1; ++b) {
                 float t0[16], t1[16], wgb[16], bsb[16];
 #pragma unroll
                 for (int s = 0; s < 16; s += 2) {
@@ -900,7 +884,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                     t0[s] = a.x; t0[s + 1] = a.y; t1[s] = c.x; t1[s + 1] = c.y;
                 }
                 auto next_rows = [&]() {                         // next block's rows (the last iteration re-requests its own),
-                    const int bn = b + 1 < X::ND ? b + 1 : b;    // behind the last weight prefetch of this block
+                    const int bn = b + 1 < zb1 ? b + 1 : b;      // behind the last weight prefetch of this block
                     bload16(ua_i, bn, n0); bload16(ub_j, bn, n1); bload16(ua_j, bn, n2); bload16(ub_i, bn, n3);
                 };
                 if constexpr (!ROT) load16(wg_v + b * 32 + half * 16, wgb);
@@ -910,12 +894,12 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                     const unsigned mcur = (unsigned)b * 2 * X::KQE * 1024;
                     WSrc wn = wm;
                     unsigned noff = mcur + 2 * X::KQE * 1024;
-                    if (b + 1 == X::ND) { wn = ws; noff = o3; }
+                    if (b + 1 == zb1) { wn = ws; noff = o3; }
                     z = mfma_block_p<X::KQE>(wp, wm, mcur, mcur + X::KQE * 1024, en, zero16());
                     z = mfma_block_p2<X::KQE>(wp, wm, mcur + X::KQE * 1024, wn, noff, G, z, next_rows);
                 } else {
                     const unsigned wcur = o0 + (unsigned)b * X::KQD * 1024;
-                    z = mfma_block_p2<X::KQD>(wp, ws, wcur, ws, b + 1 < X::ND ? wcur + X::KQD * 1024 : o3, sg, zero16(), next_rows);
+                    z = mfma_block_p2<X::KQD>(wp, ws, wcur, ws, b + 1 < zb1 ? wcur + X::KQD * 1024 : o3, sg, zero16(), next_rows);
                 }
                 PT(5);
                 // vector tail of this block, one direction after the other and eight registers at a time (fences keep the
@@ -967,6 +951,24 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                 PT(7);
             }
             PT(7);
+            if constexpr (ZW > 1) {                              // the waves' partial dot products: added by wave 0 in wave order
+                float* zr = zred + lane;
+                if (zw > 0) {
+                    float* o = zr + (zw - 1) * 12 * 64;
+                    o[0 * 64] = c00.x; o[1 * 64] = c00.y; o[2 * 64] = c01.x; o[3 * 64] = c01.y; o[4 * 64] = c02.x; o[5 * 64] = c02.y;
+                    o[6 * 64] = c10.x; o[7 * 64] = c10.y; o[8 * 64] = c11.x; o[9 * 64] = c11.y; o[10 * 64] = c12.x; o[11 * 64] = c12.y;
+                }
+                __syncthreads();
+                if (zw == 0) {
+#pragma unroll
+                    for (int w = 1; w < ZW; ++w) {
+                        const float* o = zr + (w - 1) * 12 * 64;
+                        c00.x += o[0 * 64]; c00.y += o[1 * 64]; c01.x += o[2 * 64]; c01.y += o[3 * 64]; c02.x += o[4 * 64]; c02.y += o[5 * 64];
+                        c10.x += o[6 * 64]; c10.y += o[7 * 64]; c11.x += o[8 * 64]; c11.y += o[9 * 64]; c12.x += o[10 * 64]; c12.y += o[11 * 64];
+                    }
+                }
+                if (t + 1 < t1) __syncthreads();                 // the next offset's partials may be written
+            }
             const float nrm = fmaxf(sqrtf(d2), 1e-8f);
 #pragma unroll
             for (int dir = 0; dir < 2; ++dir) {
@@ -978,7 +980,7 @@ __global__ __launch_bounds__(64, 1) void k_edge_update_sym(KArgs A) {
                 const float iota = (c0 + ((fl & 1) ? c1 : 0.f) + ((fl & 2) ? c2 : 0.f)) * (1.f / 3.f);
                 const float f = cscale * iota / nrm;
                 const float sgn = dir == 0 ? 1.f : -1.f;          // x_a - x_c
-                if (P.ok && half == 0)
+                if (P.ok && half == 0 && zw == 0)
                     reinterpret_cast<float4*>(A.dposE)[rr] = make_float4(sgn * dx * f, sgn * dy * f, sgn * dz * f, 0.f);
             }
             PT(6);

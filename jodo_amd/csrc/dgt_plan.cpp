@@ -116,7 +116,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     if (pair_chunk <= 0) pair_chunk = 1;     // measured best on MI355X (QM9 B=2500: 26.7 ms/step vs 27.7 at 2)
     const bool spair_auto = spair_chunk <= 0;
     p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->last_e_buf = 0;
-    p->opt[JODO_OPT_FUSE_NEXT_QKV] = 1; p->opt[JODO_OPT_DIR_SPLIT] = 1; p->opt[JODO_OPT_NODE_POST_WAVES] = 0; p->opt[JODO_OPT_ATTN_VARIANT] = 0; p->opt[JODO_OPT_HEADS_MIX] = 1; p->opt[JODO_OPT_HALF_ROWS] = 1; p->opt[JODO_OPT_PRE_EMBED] = 1; p->opt[JODO_OPT_AB_PRE] = 1;
+    p->opt[JODO_OPT_FUSE_NEXT_QKV] = 1; p->opt[JODO_OPT_DIR_SPLIT] = 1; p->opt[JODO_OPT_NODE_POST_WAVES] = 0; p->opt[JODO_OPT_ATTN_VARIANT] = 0; p->opt[JODO_OPT_HEADS_MIX] = 1; p->opt[JODO_OPT_HALF_ROWS] = 1; p->opt[JODO_OPT_PRE_EMBED] = 1; p->opt[JODO_OPT_AB_PRE] = 1; p->opt[JODO_OPT_Z_SPLIT] = 1;
     p->opt[JODO_OPT_PIN_SYMMETRIC] = 0; p->opt[JODO_OPT_PIN_UNIFORM_T] = 0; p->opt[JODO_OPT_ROT_STATS] = 1; p->opt[JODO_OPT_NODE_MIX] = 1;
     p->prof_enabled = 0; p->force_directed = 0; p->dbg_timing = nullptr;
 
@@ -504,6 +504,13 @@ extern "C" int jodo_plan_work(const jodo_plan* p, int uniform_t, int symmetric, 
             cls[JODO_PROF_NODE_POST] += L * (double)p->n_gtiles * (double)(D - 2 * De) / 2;
         }
         cls[JODO_PROF_EDGE_UPDATE] += L * pair_iters * (tr + c0);
+        // JODO_OPT_Z_SPLIT: the items of the last round run with zw waves each; every wave repeats the trunk and the statistics,
+        // the Z blocks (c0) are dealt out (launch_update_sym, dgt_edge.hip)
+        if (p->opt[JODO_OPT_Z_SPLIT] != 0 && hoist && p->opt[JODO_OPT_PIN_UNIFORM_T] != (fold ? 2 : 1)) {
+            const int rem = p->n_pitems % 1024;
+            const int zw = rem > 0 ? (rem <= 256 ? 4 : ((p->opt[JODO_OPT_Z_SPLIT] == 2 && rem <= 512) ? 2 : 1)) : 1;
+            cls[JODO_PROF_EDGE_UPDATE] += L * (double)rem * (zw - 1) * tr;
+        }
     } else {
         cls[JODO_PROF_EDGE_UPDATE] += L * dir_iters * (trunk + proj(D, D));
     }
@@ -541,6 +548,8 @@ extern "C" int jodo_plan_set_option(jodo_plan* p, int option, int value) {
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: node-post waves per strip must be 0 (auto), 1, 2 or 4");
     if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT || option == JODO_OPT_NODE_MIX || option == JODO_OPT_HEADS_MIX || option == JODO_OPT_HALF_ROWS || option == JODO_OPT_PRE_EMBED || option == JODO_OPT_AB_PRE) && value != 0 && value != 1)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: option %d is a switch (0 or 1), got %d", option, value);
+    if (option == JODO_OPT_Z_SPLIT && (value < 0 || value > 2))
+        return jodo_set_error(JODO_ERR_ARG, "plan_set_option: the Z split is 0 (off), 1 (four waves for a last round of <= 256 items) or 2 (also two waves up to 512), got %d", value);
     if (option == JODO_OPT_ROT_STATS && (value < 0 || value > 2))
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: rotated statistics are 0 (off), 1 (on) or 2 (on, uncentred Gram tiles: tests), got %d", value);
     if (option == JODO_OPT_PIN_SYMMETRIC && value == 1 && p->force_directed)

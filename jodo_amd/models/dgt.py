@@ -307,27 +307,40 @@ class _DGTBase(nn.Module):
 
     # -- training path ---------------------------------------------------------------------------
     def _train_engine(self, node_mask, edge_mask, device):
-        """One TrainEngine (jodo_train handle + device tables) per batch of atom counts, keyed by the counts themselves — data
-        loaders build new mask tensors every step, equal shapes recur; all of them share ONE activation workspace, grown to the
-        largest batch seen (the backward of a forward must run before the module's next training-path forward)."""
+        """One TrainEngine (jodo_train handle + device tables) per batch of atom counts, keyed by the counts themselves.  A shuffling
+        loader practically never repeats a key, so a real training step CREATES its engine (host tables of ~4 R ints, one upload):
+        tools/train_bench.py times that case (`fresh_batches`) as its headline; the 16-entry cache only serves repeated evaluation of
+        one batch (tests, the self-conditioning double forward of a step).  All engines of a module share its activation workspaces
+        (TrainEngine.new_pool: two, so that a second grad-enabled forward may run before the first one's backward)."""
         from ..train import TrainEngine
         B, N = node_mask.shape[0], node_mask.shape[1]
         nm = node_mask.reshape(B, N)
         n_nodes = nm.sum(1).round().to(torch.int32)
-        prefix = (torch.arange(N, device=nm.device).unsqueeze(0) < n_nodes.unsqueeze(1)).to(nm.dtype)
-        if not torch.equal(prefix, nm):
-            raise ValueError("node_mask must be a prefix mask (real atoms first)")
-        em = edge_mask.reshape(B, N, N)
-        want = prefix.unsqueeze(1) * prefix.unsqueeze(2) * (~torch.eye(N, dtype=torch.bool, device=nm.device))
-        if not torch.equal(want.to(em.dtype), em):
-            raise ValueError("edge_mask must be node_mask x node_mask with the diagonal removed")
-        n_host = n_nodes.cpu().numpy()
+        # mask validation and the atom counts reach the host in ONE transfer (one stream sync per new batch; round 4 paid three:
+        # two torch.equal and the counts).  model.validate_masks = False drops the comparison kernels as well (a loader that is
+        # known to build prefix masks, like the samplers' build_masks).
+        if getattr(self, 'validate_masks', True):
+            prefix = (torch.arange(N, device=nm.device).unsqueeze(0) < n_nodes.unsqueeze(1))
+            em = edge_mask.reshape(B, N, N)
+            want = prefix.unsqueeze(1) & prefix.unsqueeze(2) & (~torch.eye(N, dtype=torch.bool, device=nm.device))
+            ok = torch.stack([(prefix.to(nm.dtype) == nm).all(), (want.to(em.dtype) == em).all()]).to(torch.int32)
+            host = torch.cat([n_nodes, ok]).cpu().numpy()
+            if not host[B]:
+                raise ValueError("node_mask must be a prefix mask (real atoms first)")
+            if not host[B + 1]:
+                raise ValueError("edge_mask must be node_mask x node_mask with the diagonal removed")
+            n_host = np.ascontiguousarray(host[:B])
+        else:
+            n_host = n_nodes.cpu().numpy()
         key = (str(device), N) + tuple(int(v) for v in n_host)
         cache = self.__dict__.setdefault('_train_engines', {})
         eng = cache.pop(key, None)
         if eng is None:
-            named = [(k, tuple(v.shape)) for k, v in self.state_dict().items()]
-            pool = self.__dict__.setdefault('_train_pool', {'buf': None, 'stamp': 0})     # one activation workspace per module
+            # (the 351-entry name / shape table of the state_dict is built once per module, not once per batch)
+            named = self.__dict__.get('_train_named')
+            if named is None:
+                named = self.__dict__['_train_named'] = TrainEngine.named_table([(k, tuple(v.shape)) for k, v in self.state_dict().items()])
+            pool = self.__dict__.setdefault('_train_pool', TrainEngine.new_pool())     # the activation workspace(s) of this module
             eng = TrainEngine(self._cfg(), n_host, N, named, device, pool=pool)
             while len(cache) >= 16:                             # handles are small (index tables); the workspace is shared
                 cache.pop(next(iter(cache)))

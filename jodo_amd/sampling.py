@@ -306,6 +306,80 @@ def get_sampling_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, 
     return sampling_fn
 
 
+def full_edge_index(n_nodes, batch_size, device):
+    """cond_gen/utils.py:15-38 (get_adj_matrix_fn): the fully connected edge list of `batch_size` graphs of `n_nodes` nodes, self-loops
+    included, batch b offset by b * n_nodes, row-major (i, j) order — what the property classifier's EGNN is called with."""
+    idx = torch.arange(n_nodes, device=device)
+    rows = idx.repeat_interleave(n_nodes).unsqueeze(0) + (torch.arange(batch_size, device=device) * n_nodes).unsqueeze(1)
+    cols = idx.repeat(n_nodes).unsqueeze(0) + (torch.arange(batch_size, device=device) * n_nodes).unsqueeze(1)
+    return [rows.reshape(-1), cols.reshape(-1)]
+
+
+def get_cond_sampling_eval_fn(config, noise_scheduler, nodes_dist, batch_size, n_samples, inverse_scaler, eps=1e-3,
+                              prop_dist=None, prop_norm=None):
+    """sampling.py:283-392: conditional sampling scored by a property classifier.  Returns sampling_fn(model, classifier) ->
+    (molecules[:n_samples], mean |classifier(sample) - target| * outputNorm[cond_property]) like the reference; the classifier is the
+    caller's (the reference's pretrained EGNN, cond_gen/ — out of this path's scope) and is called with the reference's keywords
+    (h0, x, edges, edge_attr, node_mask, edge_mask, n_nodes).  The score network runs through the HIP kernels as in get_sampling_fn;
+    the round's RNG use (atom counts, context, initial noise, per-step draws) is the reference's."""
+    device = config.device
+    steps = config.sampling.steps
+    atom_types = config.data.atom_types
+    include_fc = config.model.include_fc_charge
+    node_nf = atom_types + int(include_fc)
+    edge_nf = config.model.edge_ch
+    compress_edge = config.data.compress_edge
+    if config.only_2D or not config.pred_edge:
+        raise NotImplementedError("only the 3-D + edge (vpsde_edge) sampling path is in scope")
+    if config.sampling.method != 'ancestral':
+        raise ValueError('Invalid sampling method!')                  # sampling.py:305
+    prop = config.cond_property
+    mean, mad = prop_norm[prop]['mean'], prop_norm[prop]['mad']
+    output_norm = {'mu': 1., 'alpha': 1, 'homo': 1000., 'lumo': 1000., 'gap': 1000, 'Cv': 1.}
+    rounds = int(np.ceil(n_samples / batch_size))
+    time_steps = torch.linspace(noise_scheduler.T, eps, steps)
+    sampler = AncestralSampler(noise_scheduler, time_steps, config.model.pred_data, config.pred_edge, config.model.self_cond,
+                               get_self_cond_fn(config))
+
+    def sampling_fn(model, classifier):
+        model.eval()
+        classifier.eval()
+        mols, maes = [], []
+        with torch.no_grad():
+            n_nodes_all = nodes_dist.sample(rounds * batch_size)
+            for r in range(rounds):
+                n_nodes = n_nodes_all[r * batch_size:(r + 1) * batch_size]
+                max_n = int(max(n_nodes))
+                context = prop_dist.sample_batch(n_nodes).to(device) if prop_dist is not None else None
+                node_mask, edge_mask = build_masks(n_nodes, max_n, device)
+                z = sample_combined_position_feature_noise(batch_size, max_n, node_nf, node_mask)
+                assert_mean_zero_with_mask(z[:, :, :3], node_mask)
+                edge_z = sample_symmetric_edge_feature_noise(batch_size, max_n, edge_nf, edge_mask)
+                try:
+                    x_node, x_edge = sampler.sampling(model, z, node_mask, edge_mask, edge_z, context)
+                finally:
+                    unpin = model_hook(model, 'unpin_paths')
+                    if unpin is not None:
+                        unpin()
+                _warn_nan(model)
+                pos, one_hot, fc, edge_types = post_process(x_node, atom_types, include_fc, node_mask, inverse_scaler, x_edge,
+                                                            edge_mask, compress_edge)
+                assert_mean_zero_with_mask(pos, node_mask)
+                bs, b_node, _ = pos.size()
+                pred = classifier(h0=one_hot.reshape(bs * b_node, -1), x=pos.reshape(bs * b_node, -1),
+                                  edges=full_edge_index(b_node, batch_size, device), edge_attr=None,
+                                  node_mask=node_mask.reshape(bs * b_node, -1), edge_mask=edge_mask, n_nodes=b_node)
+                assert context.size(-1) == 1
+                target = context.clone().squeeze(-1) * mad + mean
+                maes.append((pred * mad + mean - target).abs())
+                mols += mol_process(one_hot, pos, fc, n_nodes, edge_types)
+                print('Generate {}, Total {}.'.format(len(mols), n_samples))
+        mae = torch.cat(maes)[:n_samples]
+        return mols[:n_samples], mae.mean().item() * output_norm[prop]
+
+    return sampling_fn
+
+
 def _consume_round_noise(noise, sampler, steps):
     """Advance the CPU generator by exactly the draws one round makes (a rank whose slice of a round is empty)."""
     noise.node(); noise.edge()

@@ -75,23 +75,39 @@ class TrainEngine:
     drives the host-emulation build of the same sources (tests/emul/) with host tensors; the product path (models/dgt.py) never
     passes them and always runs libjodo_hip.so on the current HIP stream."""
 
-    def __init__(self, cfg_struct, n_nodes, N, named_shapes, device, lib=None, stream_ptr=None, pool=None):
-        self.L = lib if lib is not None else capi.lib()
-        self._check = capi.check if lib is None else self._check_foreign
-        self._stream = stream_ptr if stream_ptr is not None else capi.current_stream_ptr
-        self.device = device
-        self.n_params = len(named_shapes)
-        n_host = np.ascontiguousarray(np.asarray(n_nodes, dtype=np.int32))
-        self.B, self.N = int(n_host.shape[0]), int(N)
-        arr = (capi.JodoTensor * self.n_params)()
+    @staticmethod
+    def named_table(named_shapes):
+        """The jodo_tensor array (names + shapes, no data) that jodo_train_create reads: built once per module."""
+        n = len(named_shapes)
+        arr = (capi.JodoTensor * n)()
         keep = []
         for i, (name, shape) in enumerate(named_shapes):
             shp = (ctypes.c_int64 * max(len(shape), 1))(*shape)
             nm = name.encode()
             keep.append((shp, nm))
             arr[i] = capi.JodoTensor(nm, None, shp, len(shape))
+        return dict(arr=arr, keep=keep, n=n)
+
+    @staticmethod
+    def new_pool(slots=2):
+        """Activation workspaces shared by the engines of one module.  A forward takes a slot that no pending backward needs; with
+        `slots` = 2 two grad-enabled forwards may precede their backwards (gradient accumulation over two micro-batches, two loss
+        terms — the reference's module allows any number).  When every slot is waiting for a backward the oldest is
+        reused and ITS backward raises."""
+        return {'slots': [{'buf': None, 'stamp': 0, 'live': False} for _ in range(slots)], 'stamp': 0}
+
+    def __init__(self, cfg_struct, n_nodes, N, named_shapes, device, lib=None, stream_ptr=None, pool=None):
+        self.L = lib if lib is not None else capi.lib()
+        self._check = capi.check if lib is None else self._check_foreign
+        self._stream = stream_ptr if stream_ptr is not None else capi.current_stream_ptr
+        self.device = device
+        named = named_shapes if isinstance(named_shapes, dict) else self.named_table(named_shapes)
+        self._named = named                                      # keeps the ctypes name / shape storage alive
+        self.n_params = named['n']
+        n_host = np.ascontiguousarray(np.asarray(n_nodes, dtype=np.int32))
+        self.B, self.N = int(n_host.shape[0]), int(N)
         self.handle = ctypes.c_void_p()
-        self._check(self.L.jodo_train_create(ctypes.byref(cfg_struct), self.B, self.N, n_host.ctypes.data_as(ctypes.c_void_p), arr,
+        self._check(self.L.jodo_train_create(ctypes.byref(cfg_struct), self.B, self.N, n_host.ctypes.data_as(ctypes.c_void_p), named['arr'],
                                              self.n_params, ctypes.byref(self.handle)), 'jodo_train_create')
         self.L.jodo_train_desc_bytes.restype = ctypes.c_size_t
         self.L.jodo_train_workspace_bytes.restype = ctypes.c_size_t
@@ -99,12 +115,13 @@ class TrainEngine:
         self.L.jodo_train_workspace_bytes.argtypes = [ctypes.c_void_p]
         self.desc = torch.empty(self.L.jodo_train_desc_bytes(self.handle), dtype=torch.uint8, device=device)
         # The activation workspace (2.6 GB at QM9 batch 128) is shared by every engine of a module through `pool`: data loaders
-        # produce a new set of atom counts every step, so handles come and go while one buffer, grown to the largest request,
-        # serves them all.  pool['stamp'] names the forward whose activations the buffer holds.
+        # produce a new set of atom counts every step, so handles come and go while the pool's buffers, grown to the largest request,
+        # serve them all.  A slot's stamp names the forward whose activations it holds.
         self.ws_bytes = int(self.L.jodo_train_workspace_bytes(self.handle))
-        self.pool = pool if pool is not None else {'buf': None, 'stamp': 0}
+        self.pool = pool if pool is not None else self.new_pool()
         self._check(self.L.jodo_train_upload(self.handle, capi.ptr(self.desc), self._stream()), 'jodo_train_upload')
         self.flags = torch.zeros(8, dtype=torch.int32, device=device)
+        self._slot = None
 
     def _check_foreign(self, code, what=''):
         if code != 0:
@@ -122,32 +139,53 @@ class TrainEngine:
     def _ptrs(tensors):
         return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
-    def forward(self, params, xh, edge_x, cond_x, cond_edge_x, noise_level, context, dropout_p, seed):
-        """params: contiguous float32 tensors in the order of `named_shapes`.  Returns (out_xh, out_edge); the activations stay
-        in self.ws until the next forward."""
-        assert len(params) == self.n_params
+    def _take_slot(self, device, keep):
+        """A workspace slot for a forward: one that no pending backward needs (the most recently used of those first, so that a
+        plain forward / backward loop stays in one buffer), else the oldest.  keep: this forward's backward will need it."""
         pool = self.pool
-        if pool['buf'] is None or pool['buf'].numel() < self.ws_bytes or pool['buf'].device != xh.device:
-            pool['buf'] = None                                   # release before growing
-            pool['buf'] = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=xh.device)
-        pool['stamp'] += 1                                       # the workspace now belongs to this forward
-        self.stamp = pool['stamp']
+        free = [s_ for s_ in pool['slots'] if not s_['live']]
+        slot = max(free, key=lambda s_: s_['stamp']) if free else min(pool['slots'], key=lambda s_: s_['stamp'])
+        if slot['buf'] is None or slot['buf'].numel() < self.ws_bytes or slot['buf'].device != device:
+            slot['buf'] = None                                   # release before growing
+            slot['buf'] = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=device)
+        pool['stamp'] += 1
+        slot['stamp'], slot['live'] = pool['stamp'], bool(keep)
+        return slot
+
+    def forward(self, params, xh, edge_x, cond_x, cond_edge_x, noise_level, context, dropout_p, seed, keep=False):
+        """params: contiguous float32 tensors in the order of `named_shapes`.  Returns (out_xh, out_edge); the activations stay
+        in a workspace slot of the pool (self.stamp names it) — until the next forward, or, with keep=True, until `backward` /
+        `release` has been called for that stamp."""
+        assert len(params) == self.n_params
+        slot = self._take_slot(xh.device, keep)
+        self._slot, self.stamp = slot, slot['stamp']
         out_x, out_e = torch.empty_like(xh), torch.empty_like(edge_x)
         self._check(self.L.jodo_train_forward(
             self.handle, capi.ptr(self.desc), self._ptrs(params), self.n_params, capi.ptr(xh), capi.ptr(edge_x), capi.ptr(cond_x),
             capi.ptr(cond_edge_x), capi.ptr(noise_level), capi.ptr(context), ctypes.c_float(dropout_p), ctypes.c_uint64(seed),
-            capi.ptr(out_x), capi.ptr(out_e), capi.ptr(self.flags), capi.ptr(pool['buf']), self._stream()), 'jodo_train_forward')
+            capi.ptr(out_x), capi.ptr(out_e), capi.ptr(self.flags), capi.ptr(slot['buf']), self._stream()), 'jodo_train_forward')
         return out_x, out_e
+
+    def slot_of(self, stamp):
+        for s_ in self.pool['slots']:
+            if s_['stamp'] == stamp and s_['buf'] is not None:
+                return s_
+        return None
 
     def debug_fetch(self, what, layer):
         """tests: a kept activation of the last forward (jodo_train_debug_locate: 0 = hhat [Nn, D], 1 = alpha [R, H] of block `layer`)."""
         off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
         self.L.jodo_train_debug_locate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         self._check(self.L.jodo_train_debug_locate(self.handle, int(what), int(layer), ctypes.byref(off), ctypes.byref(cnt)), 'jodo_train_debug_locate')
-        buf = self.pool['buf']
+        buf = self._slot['buf']
         return buf[off.value:off.value + 4 * cnt.value].view(torch.float32).clone()
 
-    def backward(self, params, noise_level, d_out_x, d_out_e, dropout_p, seed):
+    def backward(self, params, noise_level, d_out_x, d_out_e, dropout_p, seed, stamp=None):
+        """Gradients of every parameter for the forward `stamp` (default: this engine's last forward)."""
+        slot = self.slot_of(self.stamp if stamp is None else stamp)
+        if slot is None:
+            raise RuntimeError("the activations of this forward were overwritten by later training-path forwards of the same module "
+                               "(%d activation workspaces per module, INTEGRATION.md §5); call backward earlier" % len(self.pool['slots']))
         # one allocation for all gradients (the library then zeroes them with a single fill)
         sizes = [p.numel() for p in params]
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=params[0].device)
@@ -157,8 +195,9 @@ class TrainEngine:
             off += n
         self._check(self.L.jodo_train_backward(
             self.handle, capi.ptr(self.desc), self._ptrs(params), self._ptrs(grads), self.n_params, capi.ptr(noise_level),
-            capi.ptr(d_out_x), capi.ptr(d_out_e), ctypes.c_float(dropout_p), ctypes.c_uint64(seed), capi.ptr(self.pool['buf']),
+            capi.ptr(d_out_x), capi.ptr(d_out_e), ctypes.c_float(dropout_p), ctypes.c_uint64(seed), capi.ptr(slot['buf']),
             self._stream()), 'jodo_train_backward')
+        slot['live'] = False                                     # (a second backward over the same activations still works until a forward takes the slot)
         return grads
 
 
@@ -169,17 +208,14 @@ class _DGTTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, dropout_p, seed, xh, edge_x, cond_x, cond_edge_x, noise_level, context, *params):
         ps = [p.detach().contiguous() for p in params]
-        out_x, out_e = engine.forward(ps, xh, edge_x, cond_x, cond_edge_x, noise_level, context, dropout_p, seed)
+        out_x, out_e = engine.forward(ps, xh, edge_x, cond_x, cond_edge_x, noise_level, context, dropout_p, seed, keep=True)
         ctx.engine, ctx.dropout_p, ctx.seed, ctx.ps, ctx.nl = engine, dropout_p, seed, ps, noise_level
         ctx.stamp = engine.stamp
         return out_x, out_e
 
     @staticmethod
     def backward(ctx, d_out_x, d_out_e):
-        if ctx.engine.pool['stamp'] != ctx.stamp:
-            raise RuntimeError("the activations of this forward were overwritten by a later training-path forward of the same "
-                               "module (one activation workspace per module); call backward before the next forward")
-        grads = ctx.engine.backward(ctx.ps, ctx.nl, d_out_x.contiguous(), d_out_e.contiguous(), ctx.dropout_p, ctx.seed)
+        grads = ctx.engine.backward(ctx.ps, ctx.nl, d_out_x.contiguous(), d_out_e.contiguous(), ctx.dropout_p, ctx.seed, stamp=ctx.stamp)
         return (None,) * 9 + tuple(grads)
 
 

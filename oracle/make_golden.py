@@ -19,6 +19,7 @@ cond_DGT_concat with `jodo_amd.models.init_utils.deterministic_init_` (weights a
   traj_qm9_anc50.npz                           50-step ancestral trajectory; besides the replayable noise it records
                                                every step's input state and the reference's prediction (teacher forcing)
   fwd_geom_base.npz                            the README's GEOM Base model: nf = 128, n_layers = 6 (README.md:150)
+  cond_eval.npz                                the reference's get_cond_sampling_eval_fn (sampling.py:283-392): molecules + scaled MAE, stub classifier
   fwd_geom_l8.npz                              GEOM nf = 256 with n_layers = 8 (BASELINE configs[2] as worded), mlp_ratio 4
   traj_geom_anc3.npz                           3-step ancestral trajectory of the GEOM model (3 bond channels: aromatic decode)
   grad_qm9.npz                                 the reference's own training loss + loss.backward() gradients of selected
@@ -43,6 +44,7 @@ sys.path.insert(0, ROOT)
 from oracle.ref_import import load_reference, reference_config          # noqa: E402
 from oracle import dgt_oracle as O                                      # noqa: E402
 from jodo_amd.models.init_utils import deterministic_init_              # noqa: E402
+from oracle.stubs import StubClassifier, FixedNodes, NormalContext      # noqa: E402
 
 OUT = os.path.join(ROOT, 'tests', 'golden')
 HEAD_GAIN = 30.0      # scale the heads' last layers so that argmax / threshold decodes are not degenerate
@@ -97,7 +99,7 @@ def forward_fixture(ref, cfg_name, n_nodes, seed, fname, nf=None, n_layers=None)
             assert torch.equal(f[0], want[0]) and torch.equal(f[1], want[1]), "faithful oracle != reference"
             err = max((d[0] - want[0]).abs().max().item(), (d[1] - want[1]).abs().max().item())
             assert err < 1e-5, "dense oracle vs reference: %g" % err
-    np.savez_compressed(os.path.join(OUT, fname), cfg_name=cfg_name, seed=seed, n_nodes=np.array(n_nodes),
+    np.savez_compressed(os.path.join(OUT, fname), torch_num_threads=torch.get_num_threads(), cfg_name=cfg_name, seed=seed, n_nodes=np.array(n_nodes),
                         nf=int(cfg.model.nf), n_layers=int(cfg.model.n_layers), xh=xh.numpy(), edge_x=ex.numpy(), noise_level=nl.numpy(),
                         context=ctx.numpy() if ctx is not None else np.zeros(0, np.float32),
                         out1_x=r1[0].numpy(), out1_e=r1[1].numpy(), out2_x=r2[0].numpy(), out2_e=r2[1].numpy())
@@ -151,7 +153,7 @@ def ancestral_fixture(ref, fname, steps=5, n_nodes=(9, 5, 17, 12), seed=21, cfg_
     m_exist = (h_edge[..., 0] - 0.5).abs()[emk].min().item()
     o3 = h_edge[..., 1] * 3.
     m_order = torch.stack([(o3 - t).abs() for t in (0.5, 1.5, 2.5)]).min(0).values[emk].min().item() / 3.
-    np.savez_compressed(os.path.join(OUT, fname), cfg_name=cfg_name, seed=seed, steps=steps, head_gain=HEAD_GAIN,
+    np.savez_compressed(os.path.join(OUT, fname), torch_num_threads=torch.get_num_threads(), cfg_name=cfg_name, seed=seed, steps=steps, head_gain=HEAD_GAIN,
                         n_nodes=np.array(n_nodes),
                         z=z.numpy(), edge_z=ez.numpy(), node_noise=torch.stack(rec_node).numpy(),
                         edge_noise=torch.stack(rec_edge).numpy(), x_mean=x_mean.numpy(), edge_x_mean=e_mean.numpy(),
@@ -201,7 +203,7 @@ def blocks_fixture(ref, cfg_name, n_nodes, seed, fname):
             offd = ~torch.eye(n, dtype=torch.bool)
             assert (blk['e'][offd] - es[l, eoff:eoff + n * (n - 1)]).abs().max() < 2e-5
         eoff += n * (n - 1)
-    np.savez_compressed(os.path.join(OUT, fname), cfg_name=cfg_name, seed=seed, n_nodes=np.array(n_nodes),
+    np.savez_compressed(os.path.join(OUT, fname), torch_num_threads=torch.get_num_threads(), cfg_name=cfg_name, seed=seed, n_nodes=np.array(n_nodes),
                         xh=xh.numpy(), edge_x=ex.numpy(), noise_level=nl.numpy(), out1_x=r1[0].numpy(), out1_e=r1[1].numpy(),
                         out2_x=r2[0].numpy(), out2_e=r2[1].numpy(), h=hs.numpy(), e=es.numpy(), pos=ps.numpy())
     print(fname, 'ok; blocks', hp.n_layers, 'E', es.shape[1])
@@ -252,7 +254,7 @@ def ancestral_tf_fixture(ref, fname, steps=50, n_nodes=(9, 5, 17, 12), seed=23):
     inv = ref.utils.get_data_inverse_scaler(cfg)
     pos, one_hot, fc, et = S.post_process(x_mean.clone(), cfg.data.atom_types, cfg.model.include_fc_charge, nm, inv,
                                           e_mean.clone(), em, cfg.data.compress_edge)
-    np.savez_compressed(os.path.join(OUT, fname), seed=seed, steps=steps, head_gain=HEAD_GAIN, n_nodes=np.array(n_nodes),
+    np.savez_compressed(os.path.join(OUT, fname), torch_num_threads=torch.get_num_threads(), seed=seed, steps=steps, head_gain=HEAD_GAIN, n_nodes=np.array(n_nodes),
                         z=z.numpy(), edge_z=ez.numpy(), node_noise=torch.stack(rec_node).numpy(),
                         edge_noise=torch.stack(rec_edge).numpy(), x_mean=x_mean.numpy(), edge_x_mean=e_mean.numpy(),
                         pos=pos.numpy(), atom_type=one_hot.argmax(2).numpy(), fc=fc.numpy(), edge_type=et.numpy(),
@@ -295,7 +297,7 @@ def dpm_fixture(ref, fname, nfe=4, n_nodes=(9, 5, 17, 12), seed=31, method='sing
         x, ex = solver.sampling(model, z, nm, em, ez, ctx)
     finally:
         M.sample_center_gravity_zero_gaussian_with_mask = orig
-    np.savez_compressed(os.path.join(OUT, fname), seed=seed, nfe=nfe, head_gain=HEAD_GAIN, n_nodes=np.array(n_nodes),
+    np.savez_compressed(os.path.join(OUT, fname), torch_num_threads=torch.get_num_threads(), seed=seed, nfe=nfe, head_gain=HEAD_GAIN, n_nodes=np.array(n_nodes),
                         method=method, order=order, z=z.numpy(), edge_z=ez.numpy(), context=ctx.numpy(), pos_noise=torch.stack(rec).numpy(),
                         x=x.numpy(), edge_x=ex.numpy())
     print(fname, 'ok; noise draws', len(rec))
@@ -385,13 +387,36 @@ def grad_fixture(ref, fname, n_nodes=(5, 9, 7), seed=41):
         a, b = sd[k].grad, params[k].grad
         rel = (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
         assert rel < 2e-4, "oracle gradient of %s: rel err %g" % (k, rel)
-    np.savez_compressed(os.path.join(OUT, fname), cfg_name='vpsde_qm9_uncond_jodo', seed=seed, n_nodes=np.array(n_nodes),
+    np.savez_compressed(os.path.join(OUT, fname), torch_num_threads=torch.get_num_threads(), cfg_name='vpsde_qm9_uncond_jodo', seed=seed, n_nodes=np.array(n_nodes),
                         t=rec['t'].numpy(), z_t=rec['z_t'].numpy(), edge_z_t=rec['edge_z_t'].numpy(), noise_level=rec['noise_level'].numpy(),
                         cond_x=rec['cond_x'].numpy(), cond_edge_x=rec['cond_edge_x'].numpy(), xh=xh.numpy(), edge_x=edge_x.numpy(),
                         align_pos=rec['align_pos'].numpy(), alpha_t=alpha_t.numpy(), sigma_t=sigma_t.numpy(),
                         pred=rec['pred'].numpy(), edge_pred=rec['edge_pred'].numpy(), loss=np.float64(loss.item()),
                         grad_names=np.array(names), **{'grad_%d' % i: params[k].grad.numpy() for i, k in enumerate(names)})
     print(fname, 'ok; loss', loss.item(), 'max |grad|', max(params[k].grad.abs().max().item() for k in names))
+
+
+def cond_eval_fixture(ref, fname, steps=4, n_nodes=(9, 5, 17, 12, 3, 18), batch=3, n_samples=5, seed=35):
+    """The reference's get_cond_sampling_eval_fn (sampling.py:283-392) on its own conditional model: two rounds of three molecules,
+    ancestral sampler, a stub property classifier; records what it returned (molecules, scaled MAE)."""
+    cfg, model = build_reference_model(ref, 'vpsde_qm9_cond_jodo', seed, head_gain=HEAD_GAIN)
+    cfg.sampling.steps = steps
+    cfg.sampling.method = 'ancestral'
+    S = ref.sampling
+    ns = ref.diffusion.noise_schedule.NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0,
+                                                      continuous_beta_1=cfg.sde.continuous_beta_1)
+    prop_norm = {cfg.cond_property: {'mean': 75.3, 'mad': 6.3}}
+    fn = S.get_cond_sampling_eval_fn(cfg, ns, FixedNodes(n_nodes), batch, n_samples, ref.utils.get_data_inverse_scaler(cfg),
+                                     prop_dist=NormalContext(), prop_norm=prop_norm)
+    torch.manual_seed(seed)
+    mols, score = fn(model, StubClassifier())
+    assert len(mols) == n_samples
+    out = dict(n_mols=len(mols), score=score, n_nodes=np.array(n_nodes), batch=batch, n_samples=n_samples, seed=seed, steps=steps,
+               head_gain=HEAD_GAIN, cond_property=str(cfg.cond_property), prop_mean=75.3, prop_mad=6.3)
+    for i, (pos, at, et, fc) in enumerate(mols):
+        out['pos_%d' % i] = pos.numpy(); out['atom_%d' % i] = at.numpy(); out['edge_%d' % i] = et.numpy(); out['fc_%d' % i] = fc.numpy()
+    np.savez_compressed(os.path.join(OUT, fname), torch_num_threads=torch.get_num_threads(), **out)
+    print(fname, 'ok; score', score, 'atoms', [int(m[0].shape[0]) for m in mols])
 
 
 def main():
@@ -418,6 +443,7 @@ def main():
         ('traj_cond_dpm_multi8.npz', lambda f: dpm_fixture(ref, f, nfe=8, seed=32, method='multistep', order=2)),
         ('traj_cond_dpm_single3.npz', lambda f: dpm_fixture(ref, f, nfe=6, seed=33, method='singlestep_fixed', order=3)),
         ('traj_cond_dpm_single1.npz', lambda f: dpm_fixture(ref, f, nfe=3, seed=34, method='singlestep_fixed', order=1)),
+        ('cond_eval.npz', lambda f: cond_eval_fixture(ref, f)),
     ]
     want = sys.argv[1:]
     for fname, job in jobs:

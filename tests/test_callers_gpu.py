@@ -342,6 +342,56 @@ def test_two_dpm_rounds_through_one_sampling_fn(hip_graph):
     assert [int(m[0].shape[0]) for m in both] == r1 + r2
 
 
+def test_cond_sampling_eval_fn_on_the_hip_model():
+    """get_cond_sampling_eval_fn (sampling.py:283-392) with the HIP conditional model: the sampled molecules equal those of
+    get_sampling_fn from the same generator state (same rounds, same draws), and the score is the stub classifier's scaled MAE
+    recomputed here from the returned molecules.  (The reference's own run of this function is reproduced on the CPU with the
+    oracle model: tests/test_oracle_golden.py::test_cond_sampling_eval_fn_reproduces_the_reference.)"""
+    from jodo_amd.diffusion import NoiseScheduleVP
+    from jodo_amd.sampling import get_cond_sampling_eval_fn, get_sampling_fn
+    from jodo_amd.utils import get_data_inverse_scaler
+    from oracle.stubs import StubClassifier
+    cfg = make_config('vpsde_qm9_cond_jodo')
+    cfg.device = torch.device(DEV)
+    cfg.sampling.steps, cfg.sampling.method = 5, 'ancestral'
+    model = make_model(cfg, 12, DEV, head_gain=10.0)
+    ns = NoiseScheduleVP(cfg.sde.schedule)
+    lists = [[27, 5, 9, 14], [8, 27, 2, 20]]
+    inv = get_data_inverse_scaler(cfg)
+    mean, mad = 75.3, 6.3
+
+    class Ctx:
+        def __init__(self):
+            self.seen = []
+
+        def sample_batch(self, n_nodes):
+            c = torch.randn(len(n_nodes), 1)
+            self.seen.append(c.clone())
+            return c
+
+    ctx = Ctx()
+    torch.manual_seed(41)
+    fn = get_cond_sampling_eval_fn(cfg, ns, _FixedNodes([sum(lists, [])]), 4, 7, inv, prop_dist=ctx,
+                                   prop_norm={cfg.cond_property: {'mean': mean, 'mad': mad}})
+    mols, score = fn(model, StubClassifier())
+    assert len(mols) == 7 and [int(m[0].shape[0]) for m in mols] == sum(lists, [])[:7]
+    torch.manual_seed(41)
+    plain = get_sampling_fn(cfg, ns, _FixedNodes([sum(lists, [])]), 4, 8, inv, prop_dist=Ctx(), return_raw=True, fused_decode=False,
+                            device_noise=False)(model)
+    for got, want in zip(mols, plain):
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    # the score from the returned molecules: classifier on (one-hot atoms, positions) per molecule, MAE against the drawn targets
+    errs = []
+    targets = torch.cat(ctx.seen).squeeze(-1)
+    for k, (pos, at, et, fc) in enumerate(mols):
+        h0 = torch.nn.functional.one_hot(at, cfg.data.atom_types).float()
+        w = torch.arange(1, h0.shape[1] + 1, dtype=torch.float32)
+        pred = ((h0 * w).sum(1) * 0.1 + pos.square().sum(1)).mean()
+        errs.append(abs(float(pred) * mad + mean - (float(targets[k]) * mad + mean)))
+    assert abs(score - sum(errs) / len(errs)) < 1e-3 * max(1.0, score)        # outputNorm['alpha'] = 1
+
+
 # ---- the RCCL leg at world size 1 (SURVEY.md §8e): the code the 8-GPU run takes, executed on the one GPU there is -------------
 _NCCL_WORKER = r"""
 import os, sys, json, torch, torch.distributed as dist

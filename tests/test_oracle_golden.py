@@ -201,3 +201,34 @@ def test_oracle_gradients_match_reference_backward():
     out = T.edge_ffn_phase(blk['e_in'], blk['ehat'], blk['eg1'], blk['es2'], blk['ec2'], blk['eg2'], sd[p5 + 'ff_linear3.weight'],
                            sd[p5 + 'ff_linear3.bias'], sd[p5 + 'ff_linear4.weight'], sd[p5 + 'ff_linear4.bias'])
     assert torch.equal(out, blk['e_out'])
+
+
+def test_cond_sampling_eval_fn_reproduces_the_reference():
+    """get_cond_sampling_eval_fn (sampling.py:283-392): the reference's own function on its conditional model, two rounds of three
+    molecules, ancestral sampler, a stub property classifier (oracle/make_golden.py cond_eval_fixture).  The mirror, driven by the
+    faithful oracle port of the model and the same seed, consumes the RNG identically: the same molecules (positions to the K-step
+    tolerance, atom / bond types and charges exactly) and the same scaled MAE."""
+    from jodo_amd.sampling import get_cond_sampling_eval_fn, full_edge_index
+    from oracle.stubs import StubClassifier, FixedNodes, NormalContext
+    fx = load_fixture('cond_eval.npz')
+    cfg = make_config('vpsde_qm9_cond_jodo')
+    cfg.device = 'cpu'
+    cfg.sampling.steps = int(fx['steps'])
+    cfg.sampling.method = 'ancestral'
+    model = make_model(cfg, int(fx['seed']), head_gain=float(fx['head_gain']))
+    om = OracleModel(state_dict_cpu(model), O.Hyper.from_config(cfg), faithful=True)
+    prop_norm = {str(fx['cond_property']): {'mean': float(fx['prop_mean']), 'mad': float(fx['prop_mad'])}}
+    assert str(fx['cond_property']) == cfg.cond_property
+    fn = get_cond_sampling_eval_fn(cfg, _schedule(cfg), FixedNodes(fx['n_nodes'].tolist()), int(fx['batch']), int(fx['n_samples']),
+                                   get_data_inverse_scaler(cfg), prop_dist=NormalContext(), prop_norm=prop_norm)
+    torch.manual_seed(int(fx['seed']))
+    mols, score = fn(om, StubClassifier())
+    assert len(mols) == int(fx['n_mols'])
+    for i, (pos, at, et, fc) in enumerate(mols):
+        assert (pos - torch.from_numpy(fx['pos_%d' % i])).abs().max() < 1e-3
+        assert torch.equal(at, torch.from_numpy(fx['atom_%d' % i])) and torch.equal(et, torch.from_numpy(fx['edge_%d' % i]))
+        assert torch.equal(fc, torch.from_numpy(fx['fc_%d' % i]))
+    assert abs(score - float(fx['score'])) < 1e-3 * max(1.0, abs(float(fx['score'])))
+    # the classifier's edge list: fully connected with self-loops, batch offsets, row-major (cond_gen/utils.py:15-38)
+    r, c = full_edge_index(3, 2, 'cpu')
+    assert r.tolist() == [0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5] and c.tolist() == [0, 1, 2] * 3 + [3, 4, 5] * 3

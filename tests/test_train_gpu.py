@@ -356,8 +356,10 @@ def test_training_steps_through_get_step_fn():
 
 def test_varying_batches_share_one_workspace():
     """Data loaders hand over different atom counts every step: every batch shape gets its own handle, all of them share the module's
-    one activation workspace (grown to the largest).  Gradients of a batch do not depend on what ran before it (bit-equal), and a
-    backward whose activations were overwritten by a later forward is refused, not computed from the wrong batch."""
+    activation workspaces (grown to the largest request; a plain forward / backward loop stays in ONE of them).  Gradients of a batch do
+    not depend on what ran before it (bit-equal).  Two grad-enabled forwards may precede their backwards (two workspaces: gradient
+    accumulation over two micro-batches, as the reference's module allows); a third one takes the oldest workspace and the backward
+    of the forward it displaced is refused, not computed from the wrong batch."""
     from helpers import random_inputs
     cfg = make_config('vpsde_qm9_uncond_jodo')
     model = make_model(cfg, 5, DEV)
@@ -377,17 +379,33 @@ def test_varying_batches_share_one_workspace():
 
     small, big = batch([5, 9, 3], 1), batch([29, 17, 23, 29, 12], 2)
     g_small = grads(small)
-    ws_small = model._train_pool['buf'].numel()
+    used = lambda: [s_['buf'].numel() for s_ in model._train_pool['slots'] if s_['buf'] is not None]
+    ws_small = used()
     g_big = grads(big)
-    assert model._train_pool['buf'].numel() > ws_small and len(model._train_engines) == 2
+    assert len(ws_small) == 1 and len(used()) == 1 and used()[0] > ws_small[0] and len(model._train_engines) == 2
     assert all(torch.equal(a, b) for a, b in zip(g_small, grads(small)))          # the larger workspace, the same numbers
     assert all(torch.equal(a, b) for a, b in zip(g_big, grads(big)))
+    # two forwards, then their backwards in either order: each backward sees its own activations (sum of the two == accumulated)
     nl, xh, nm, em, ex = small
-    ox, oe = model(nl, xh, nm, em, edge_x=ex, cond_x=None, cond_edge_x=None, noise_level=nl)
     nl2, xh2, nm2, em2, ex2 = big
-    model(nl2, xh2, nm2, em2, edge_x=ex2, cond_x=None, cond_edge_x=None, noise_level=nl2)
+    model.zero_grad()
+    ox, oe = model(nl, xh, nm, em, edge_x=ex, cond_x=None, cond_edge_x=None, noise_level=nl)
+    ox2, oe2 = model(nl2, xh2, nm2, em2, edge_x=ex2, cond_x=None, cond_edge_x=None, noise_level=nl2)
+    assert len(used()) == 2
+    (ox.square().sum() + oe.square().sum()).backward()
+    after_first = [p.grad.clone() for p in model.parameters()]
+    assert all(torch.equal(a, b) for a, b in zip(after_first, g_small))
+    (ox2.square().sum() + oe2.square().sum()).backward()
+    assert all(torch.equal(p.grad, a + b) for p, a, b in zip(model.parameters(), g_small, g_big))
+    # three pending forwards: the first one's activations are gone
+    ox, oe = model(nl, xh, nm, em, edge_x=ex, cond_x=None, cond_edge_x=None, noise_level=nl)
+    o2 = model(nl2, xh2, nm2, em2, edge_x=ex2, cond_x=None, cond_edge_x=None, noise_level=nl2)
+    o3 = model(nl2, xh2, nm2, em2, edge_x=ex2, cond_x=None, cond_edge_x=None, noise_level=nl2)
     with pytest.raises(RuntimeError, match="overwritten"):
         (ox.square().sum() + oe.square().sum()).backward()
+    (o3[0].square().sum() + o3[1].square().sum()).backward()                      # the later ones still have theirs
+    (o2[0].square().sum() + o2[1].square().sum()).backward()
+    del o2, o3
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 64, 1187), (256, 64, 50000), (252, 256, 300), (3, 256, 9000)])

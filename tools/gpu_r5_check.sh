@@ -6,7 +6,7 @@ WL=${@:-qm9 geom geom384 cond}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 rm -f gpurun_out/parity_errors.jsonl
 if [ "$TESTS" = "all" ]; then
-  timeout 2700 python -m pytest tests -m gpu -q -x 2>&1 | tail -30 > $OUT/pytest_gpu.txt; tail -4 $OUT/pytest_gpu.txt
+  timeout 2700 python -m pytest tests -m gpu -q 2>&1 | tail -30 > $OUT/pytest_gpu.txt; tail -4 $OUT/pytest_gpu.txt
 elif [ "$TESTS" = "fast" ]; then
   timeout 1800 python -m pytest tests/test_dgt_gpu.py -m gpu -q -x -k "fixture or pinned or pair_path or full_size" 2>&1 | tail -30 > $OUT/pytest_gpu.txt; tail -4 $OUT/pytest_gpu.txt
 fi

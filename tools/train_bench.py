@@ -67,6 +67,30 @@ def run(workload='qm9', batch=0, steps=10, warmup=3, seed=42):
         losses.append(float(step_fn(state, data)))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # What a real training loop sees: a shuffling loader hands over NEW atom counts every step, so the engine cache of
+    # models/dgt.py never hits — every step pays jodo_train_create (host tables, upload) and the host transfer of the counts.
+    # Batches are generated up front and already on the device (the loader itself is outside the path).
+    dist_ = get_node_dist(load_dataset_info(info))
+    fresh = []
+    for k in range(warmup + steps):
+        nk = dist_.sample(B).tolist()
+        fresh.append({kk: v.to(dev) for kk, v in synthetic_batch(cfg, nk, seed + 1 + k).items()})
+    for k in range(warmup):
+        float(step_fn(state, fresh[k]))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(warmup, warmup + steps):
+        losses.append(float(step_fn(state, fresh[k])))
+    torch.cuda.synchronize()
+    dt_fresh = (time.perf_counter() - t0) / steps
+    # engine creation alone (host side of a new batch): n_host -> handle + tables + upload
+    tcr = time.perf_counter()
+    for k in range(3):
+        model._train_engines.clear()
+        model._train_engine(fresh[k]['atom_mask'].unsqueeze(-1), fresh[k]['edge_mask'], dev)
+    torch.cuda.synchronize()
+    create_ms = (time.perf_counter() - tcr) / 3 * 1e3
+    del fresh
     # where a step's wall time goes (host-synchronised sections over the same step, 6 repetitions)
     loss_fn = L.get_sde_graph_loss_fn(ns, True, get_data_scaler(cfg), cfg, None)
     opt_fn = L.optimization_manager(cfg)
@@ -108,7 +132,11 @@ def run(workload='qm9', batch=0, steps=10, warmup=3, seed=42):
     hp = O.Hyper.from_config(cfg)
     f_fwd = O.algorithmic_flops(hp, n_nodes, shared_time=False)['total']
     peak = 157.3e12
-    return dict(workload=name, batch=B, steps=steps, s_per_step=dt, molecules_per_s=B / dt, loss_first=losses[0], loss_last=losses[-1],
+    return dict(workload=name, batch=B, steps=steps, s_per_step=dt_fresh, molecules_per_s=B / dt_fresh,
+                fresh_batches=dict(s_per_step=dt_fresh, molecules_per_s=B / dt_fresh, engine_create_ms=create_ms,
+                                   note='every step a new draw of atom counts (engine cache never hits): the headline'),
+                fixed_batch=dict(s_per_step=dt, molecules_per_s=B / dt, note='one batch repeated (engine cache hits): round 4\'s figure'),
+                loss_first=losses[0], loss_last=losses[-1],
                 forward_ms=fwd, backward_ms=bwd, sections_ms=sec, forward_algorithmic_flops=f_fwd,
                 forward_frac_of_fp32_mfma_peak=f_fwd / (fwd * 1e-3) / peak, backward_frac_of_fp32_mfma_peak=2 * f_fwd / (bwd * 1e-3) / peak,
                 note='one optimiser step = (50 %: no-grad self-conditioning forward) + grad forward + backward + AdamW / clipping / EMA; '
