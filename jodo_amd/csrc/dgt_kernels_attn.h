@@ -63,13 +63,22 @@ struct AttnT {
     static constexpr int PHB = WQK_ ? 1 : (VAR_ == 0 ? 1 : (VAR_ == 2 ? D_ / 32 : 4));   // message blocks per hand-over phase
     static constexpr int NQB = WQK_ ? 14 : 8;                      // 32-row blocks of q / k / lin_edge0
     static constexpr int KQE = D_ / 32;                            // weight quads per output block for K = De
-    static constexpr int PG = (D_ % 256 == 0) ? 8 : 4;             // quads in flight (must divide KQE)
+#ifndef JODO_X_ATT_PG384                                           // experiment builds (tools/gpu_attn384_ab.sh): -DJODO_X_ATT_...
+#define JODO_X_ATT_PG384 4
+#endif
+#ifndef JODO_X_ATT_PREF384
+#define JODO_X_ATT_PREF384 0
+#endif
+#ifndef JODO_X_ATT_LDSS384
+#define JODO_X_ATT_LDSS384 1
+#endif
+    static constexpr int PG = (D_ % 256 == 0) ? 8 : (D_ == 384 ? JODO_X_ATT_PG384 : 4);   // quads in flight (must divide KQE)
     static constexpr bool PH = (D_ / 16 == 16) && !(D_ > 256);     // C = 16: a half-lane's registers belong to heads 2b + half only, so it
     static constexpr int NS = PH ? 8 : 16;                         // tracks 8 heads (slot k = head 2k + half) instead of all 16
-    static constexpr bool PREF = !(D_ > 256);                      // request the next source's edge row one iteration ahead (D/8 registers)
+    static constexpr bool PREF = !(D_ > 256) || JODO_X_ATT_PREF384 != 0;   // request the next source's edge row one iteration ahead (D/8 registers)
     static constexpr bool QK2 = false;   // q / k rows two blocks ahead in two register sets: measured SLOWER on MI355X (QM9 B = 2500: attention
                                          // 3.91 -> 4.00 ms/step, 455 -> 490 registers) — the block's wait is issue, not row latency; kept as a switch
-    static constexpr bool LDSS = D_ > 256;                         // running softmax state in LDS (registers are short at nf = 384:
+    static constexpr bool LDSS = D_ > 256 && JODO_X_ATT_LDSS384 != 0;   // running softmax state in LDS (registers are short at nf = 384:
                                                                    // D/2 accumulators + D/8 inputs per lane; LDS is free, no resident weights)
     static constexpr float INV_SQRT_C = D_ == 256 ? 0.25f : (D_ == 384 ? 0.20412414523193150f : (D_ == 128 ? 0.35355339059327379f : 0.f));
     static constexpr int M_EDGE = 6 * D_, M_GBF = 6 * D_ + 6 * (D_ / 4) + 2 * D_;

@@ -24,6 +24,7 @@
 #include "jodo_hip_internal.h"
 #include "train_gemm.h"
 #include "train_ops.h"
+#include "train_fused.h"
 
 using namespace jt;
 
@@ -56,6 +57,8 @@ struct Bufs {
     // scratch shared by all phases
     float *tE_D[3], *tE_De[4], *tE_QK, *tE_rD, *tE_H, *tN_D[4], *tN_QK[2], *tN_rD, *tN_De, *tRow[3], *tE3[3], *tN3[4], *tcatn, *tcate;
     float *dtau, *dtemb, *dnmod, *demod, *dqmod, *dgm, *tB_T[2], *tB_cD[2], *part, *part2, *rowpart, *splitk;
+    float* fpack;                     // packed MFMA operands of the fused forward chains, one slice per block (train_fused.h)
+    size_t fpack_block;
     size_t splitk_floats, part_floats, part2_floats;
 };
 
@@ -75,6 +78,7 @@ struct jodo_train {
     int gbf_means, gbf_stds, time_w;
     std::vector<BlkIx> blk;
     size_t ws_bytes;
+    int fused;                        // 1: the three per-edge chains of a block run as fused strip kernels (train_fused.hip)
 };
 
 namespace {
@@ -126,6 +130,9 @@ void layout(const jodo_train& t, Arena& a, Bufs& b) {
     const size_t need = ((rows + 1023) / 1024 + 1) * (size_t)D * (2 * D + 2 * De);
     if (b.splitk_floats > need) b.splitk_floats = need;
     b.splitk = a.f(b.splitk_floats);
+    const FusedDims fd{t.D, t.De, t.r, t.QK, t.ce, t.L};
+    b.fpack_block = fused_pack_layout(fd).total;
+    b.fpack = a.f(b.fpack_block * L);
 }
 
 struct Ctx {
@@ -274,22 +281,39 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
         c.lin(b.tau, T, B, T, c.p(ix.eq_time.w), T, 2 * D, c.p(ix.eq_time.b), k.qmod, 2 * D, 0);
         c.lin(b.tau, T, B, T, c.p(ix.gbf_time.w), T, 2, c.p(ix.gbf_time.b), k.gm, 2, 0);
         // distances, Gaussian basis, edge_emb([G, e]) and the two modulated LayerNorms (:279-296)
-        JT_LAUNCH(k_dist2, R, s, tp, (const float*)b.pos[l], k.d2);
-        JT_LAUNCH(k_gbf_fwd, (long)R * De, s, (long)R, De, (const float*)k.d2, tp.edge_mol, (const float*)k.gm, c.p(ix.gbf_means), c.p(ix.gbf_stds),
-                           (const int*)nullptr, k.G, De, 0);
-        float* e1 = b.tE_De[0];
-        c.lin(k.G, De, R, De, c.p(ix.edge_emb.w), 2 * De, De, c.p(ix.edge_emb.b), e1, De, 0);
-        c.lin(b.e[l], De, R, De, c.p(ix.edge_emb.w) + De, 2 * De, De, nullptr, e1, De, 1);
-        c.stats(R, De, e1, b.tRow[0], k.rs_e1);
-        c.ln_mod(R, De, e1, b.tRow[0], k.rs_e1, tp.edge_mol, k.emod, 6 * De, 0, De, k.xh_e1, k.et);
+        const FusedDims fd{D, De, r, QK, t.ce, L};
+        FusedBlockParams fp;
+        FusedTopo ft{R, tp.edge_a, tp.edge_c, tp.edge_mol};
+        float* fpk = b.fpack + (size_t)l * b.fpack_block;
+        if (t.fused) {
+            fp.edge_emb_w = c.p(ix.edge_emb.w); fp.edge_emb_b = c.p(ix.edge_emb.b); fp.le0 = c.p(ix.le0); fp.le1 = c.p(ix.le1);
+            fp.ff3_w = c.p(ix.ff3.w); fp.ff3_b = c.p(ix.ff3.b); fp.ff4_w = c.p(ix.ff4.w); fp.ff4_b = c.p(ix.ff4.b);
+            fp.ero_w = c.p(ix.edge_ro.w); fp.ero_b = c.p(ix.edge_ro.b); fp.in_w = c.p(ix.eq_in.w); fp.in_b = c.p(ix.eq_in.b);
+            fp.c0_w = c.p(ix.eq_c0.w); fp.c0_b = c.p(ix.eq_c0.b); fp.c2_w = c.p(ix.eq_c2); fp.n2e_b = c.p(ix.n2e.b);
+            fp.gbf_means = c.p(ix.gbf_means); fp.gbf_stds = c.p(ix.gbf_stds);
+            fused_pack_block(s, fd, fp, fpk);
+            // chain A: d2 -> G -> edge_emb -> LN1 -> modulate -> tanh(lin_edge0 / lin_edge1), one kernel (train_fused.hip)
+            fused_chain_a(s, fd, ft, fp, fpk, b.pos[l], k.gm, b.e[l], k.emod, k.d2, k.G, k.xh_e1, k.rs_e1, k.et, k.t0, k.t1);
+        } else {
+            JT_LAUNCH(k_dist2, R, s, tp, (const float*)b.pos[l], k.d2);
+            JT_LAUNCH(k_gbf_fwd, (long)R * De, s, (long)R, De, (const float*)k.d2, tp.edge_mol, (const float*)k.gm, c.p(ix.gbf_means), c.p(ix.gbf_stds),
+                               (const int*)nullptr, k.G, De, 0);
+            float* e1 = b.tE_De[0];
+            c.lin(k.G, De, R, De, c.p(ix.edge_emb.w), 2 * De, De, c.p(ix.edge_emb.b), e1, De, 0);
+            c.lin(b.e[l], De, R, De, c.p(ix.edge_emb.w) + De, 2 * De, De, nullptr, e1, De, 1);
+            c.stats(R, De, e1, b.tRow[0], k.rs_e1);
+            c.ln_mod(R, De, e1, b.tRow[0], k.rs_e1, tp.edge_mol, k.emod, 6 * De, 0, De, k.xh_e1, k.et);
+        }
         c.stats(Nn, D, b.h[l], b.tRow[0], k.rs_h);
         c.ln_mod(Nn, D, b.h[l], b.tRow[0], k.rs_h, tp.node_mol, k.nmod, 6 * D, 0, D, k.xh_h, k.ht);
         // attention (layers.py:131-186)
         c.lin(k.ht, D, Nn, D, c.p(ix.query.w), D, QK, c.p(ix.query.b), k.q, QK, 0);
         c.lin(k.ht, D, Nn, D, c.p(ix.key.w), D, QK, c.p(ix.key.b), k.k, QK, 0);
         c.lin(k.ht, D, Nn, D, c.p(ix.value.w), D, D, c.p(ix.value.b), k.v, D, 0);
-        c.lin_tanh(k.et, De, R, De, c.p(ix.le0), De, QK, nullptr, k.t0);
-        c.lin_tanh(k.et, De, R, De, c.p(ix.le1), De, D, nullptr, k.t1);
+        if (!t.fused) {
+            c.lin_tanh(k.et, De, R, De, c.p(ix.le0), De, QK, nullptr, k.t0);
+            c.lin_tanh(k.et, De, R, De, c.p(ix.le1), De, D, nullptr, k.t1);
+        }
         JT_LAUNCH(k_attn_scores, (long)R * H, s, tp, H, t.XH, t.SC, 1.f / sqrtf((float)t.C), (const float*)k.q, (const float*)k.k,
                            (const float*)k.t0, (const float*)b.adj2d, (const float*)b.adjsp, k.alpha);
         JT_LAUNCH(k_attn_softmax, (long)Nn * H, s, tp, H, k.alpha);
@@ -297,16 +321,22 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
                            c.drop(0.f, seed, l, SITE_ALPHA), k.hhat);     // p = 0: see SITE_ALPHA
         c.lin(k.hhat, D, Nn, D, c.p(ix.n2e.w), D, De, nullptr, k.n2e, De, 0);
         // edges: gated residual, LayerNorm2 + modulate, FFN (:313-317)
-        float* x1e = b.tE_De[0];
-        JT_LAUNCH(k_edge_bcast, (long)R * De, s, tp, De, (const float*)b.e[l], (const float*)k.n2e, (const float*)k.n2e, c.p(ix.n2e.b),
-                           (const float*)k.emod, 6 * De, 2 * De, x1e);
-        c.stats(R, De, x1e, b.tRow[0], k.rs_en);
-        c.ln_mod(R, De, x1e, b.tRow[0], k.rs_en, tp.edge_mol, k.emod, 6 * De, 3 * De, 4 * De, k.xh_en, k.en);
-        c.lin_silu(k.en, De, R, De, c.p(ix.ff3.w), De, r * De, c.p(ix.ff3.b), k.f3, k.a3, c.drop(p_drop, seed, l, SITE_A3));
-        c.lin(k.a3, r * De, R, r * De, c.p(ix.ff4.w), r * De, De, c.p(ix.ff4.b), k.f4, De, 0);
-        JT_LAUNCH(k_drop, (long)R * De, s, (long)R * De, (const float*)k.f4, b.tE_De[1], c.drop(p_drop, seed, l, SITE_F4));
-        JT_LAUNCH(k_gate_add, (long)R * De, s, (long)R, De, (const float*)k.en, (const float*)b.tE_De[1], tp.edge_mol, (const float*)k.emod,
-                           6 * De, 5 * De, b.e[l + 1]);
+        if (t.fused) {
+            // chain B: residual -> LN2 -> modulate -> ff_linear3 -> SiLU, dropout -> ff_linear4 -> dropout -> gate -> readout (:570), one kernel
+            fused_chain_b(s, fd, ft, fp, fpk, b.e[l], k.n2e, k.emod, c.drop(p_drop, seed, l, SITE_A3), c.drop(p_drop, seed, l, SITE_F4), k.xh_en, k.rs_en,
+                          k.en, k.f3, k.a3, k.f4, b.e[l + 1], b.eh, t.cate, De + l * t.ce);
+        } else {
+            float* x1e = b.tE_De[0];
+            JT_LAUNCH(k_edge_bcast, (long)R * De, s, tp, De, (const float*)b.e[l], (const float*)k.n2e, (const float*)k.n2e, c.p(ix.n2e.b),
+                               (const float*)k.emod, 6 * De, 2 * De, x1e);
+            c.stats(R, De, x1e, b.tRow[0], k.rs_en);
+            c.ln_mod(R, De, x1e, b.tRow[0], k.rs_en, tp.edge_mol, k.emod, 6 * De, 3 * De, 4 * De, k.xh_en, k.en);
+            c.lin_silu(k.en, De, R, De, c.p(ix.ff3.w), De, r * De, c.p(ix.ff3.b), k.f3, k.a3, c.drop(p_drop, seed, l, SITE_A3));
+            c.lin(k.a3, r * De, R, r * De, c.p(ix.ff4.w), r * De, De, c.p(ix.ff4.b), k.f4, De, 0);
+            JT_LAUNCH(k_drop, (long)R * De, s, (long)R * De, (const float*)k.f4, b.tE_De[1], c.drop(p_drop, seed, l, SITE_F4));
+            JT_LAUNCH(k_gate_add, (long)R * De, s, (long)R, De, (const float*)k.en, (const float*)b.tE_De[1], tp.edge_mol, (const float*)k.emod,
+                               6 * De, 5 * De, b.e[l + 1]);
+        }
         // nodes: gated residual, LayerNorm2 + modulate, FFN (:307-311)
         float* x1n = b.tN_D[0];
         JT_LAUNCH(k_gate_add, (long)Nn * D, s, (long)Nn, D, (const float*)b.h[l], (const float*)k.hhat, tp.node_mol, (const float*)k.nmod,
@@ -324,21 +354,26 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
         float *hr = b.tN_D[0], *hc = b.tN_D[1], *pre = b.tE_D[0];
         c.lin(b.h[l + 1], D, Nn, D, Win, ldw, D, nullptr, hr, D, 0);
         c.lin(b.h[l + 1], D, Nn, D, Win + D, ldw, D, nullptr, hc, D, 0);
-        c.lin(b.e[l + 1], De, R, De, Win + 2 * D, ldw, D, c.p(ix.eq_in.b), pre, D, 0);
-        c.lin(k.G, De, R, De, Win + 2 * D + De, ldw, D, nullptr, pre, D, 1);
-        JT_LAUNCH(k_edge_bcast, (long)R * D, s, tp, D, (const float*)pre, (const float*)hr, (const float*)hc, (const float*)nullptr,
-                           (const float*)nullptr, 0, 0, b.tE_D[1]);
-        c.stats(R, D, b.tE_D[1], b.tRow[0], k.rs_pre);
-        c.ln_mod(R, D, b.tE_D[1], b.tRow[0], k.rs_pre, tp.edge_mol, k.qmod, 2 * D, 0, D, k.xh_pre, k.u);
-        c.lin_silu(k.u, D, R, D, c.p(ix.eq_c0.w), D, D, c.p(ix.eq_c0.b), k.c0pre, k.c0a, nod);
-        c.lin_tanh(k.c0a, D, R, D, c.p(ix.eq_c2), D, 3, nullptr, k.inv);
+        if (t.fused) {
+            // chain C: input_lin -> LN -> modulate -> coord_mlp.0 -> SiLU -> coord_mlp.2 -> tanh, one kernel
+            fused_chain_c(s, fd, ft, fp, fpk, b.e[l + 1], k.G, hr, hc, k.qmod, k.xh_pre, k.rs_pre, k.u, k.c0pre, k.c0a, k.inv);
+        } else {
+            c.lin(b.e[l + 1], De, R, De, Win + 2 * D, ldw, D, c.p(ix.eq_in.b), pre, D, 0);
+            c.lin(k.G, De, R, De, Win + 2 * D + De, ldw, D, nullptr, pre, D, 1);
+            JT_LAUNCH(k_edge_bcast, (long)R * D, s, tp, D, (const float*)pre, (const float*)hr, (const float*)hc, (const float*)nullptr,
+                               (const float*)nullptr, 0, 0, b.tE_D[1]);
+            c.stats(R, D, b.tE_D[1], b.tRow[0], k.rs_pre);
+            c.ln_mod(R, D, b.tE_D[1], b.tRow[0], k.rs_pre, tp.edge_mol, k.qmod, 2 * D, 0, D, k.xh_pre, k.u);
+            c.lin_silu(k.u, D, R, D, c.p(ix.eq_c0.w), D, D, c.p(ix.eq_c0.b), k.c0pre, k.c0a, nod);
+            c.lin_tanh(k.c0a, D, R, D, c.p(ix.eq_c2), D, 3, nullptr, k.inv);
+        }
         JT_LAUNCH(k_coord_fwd, R, s, tp, (const float*)b.pos[l], (const float*)k.inv, (const float*)b.adj2d, (const float*)b.adjsp,
                            c.p(ix.eq_scale), b.tE3[0]);
         JT_LAUNCH(k_coord_sum, (long)Nn * 3, s, tp, (const float*)b.pos[l], (const float*)b.tE3[0], b.tN3[0]);
         JT_LAUNCH(k_center, (long)B * 3, s, tp, (const float*)b.tN3[0], (const int*)nullptr, b.pos[l + 1]);
         // readouts written into the head inputs in place (:569-570)
         c.lin(b.h[l + 1], D, Nn, D, c.p(ix.node_ro.w), D, t.cn, c.p(ix.node_ro.b), b.ah + D + l * t.cn, t.catn, 0);
-        c.lin(b.e[l + 1], De, R, De, c.p(ix.edge_ro.w), De, t.ce, c.p(ix.edge_ro.b), b.eh + De + l * t.ce, t.cate, 0);
+        if (!t.fused) c.lin(b.e[l + 1], De, R, De, c.p(ix.edge_ro.w), De, t.ce, c.p(ix.edge_ro.b), b.eh + De + l * t.ce, t.cate, 0);
     }
     // heads and outputs (:572-594)
     head_fwd(c, b.ah, t.catn, Nn, t.catn, t.np0, t.np2, t.np4, D, D / 2, nd, b.nh1pre, b.nh1, b.nh2pre, b.nh2, b.atom, nd);
@@ -661,6 +696,10 @@ int jodo_train_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes,
         k.node_ro = lin("node_" + std::to_string(l), t->cn, D); k.edge_ro = lin("edge_" + std::to_string(l), t->ce, De);
     }
     if (!missing.empty()) { delete t; return jodo_set_error(JODO_ERR_ARG, "jodo_train_create: parameter '%s' missing or mis-sized", missing.c_str()); }
+    {
+        const FusedDims fd{t->D, t->De, t->r, t->QK, t->ce, t->L};
+        t->fused = fused_available(fd) ? 1 : 0;
+    }
     Arena a{nullptr, 0}; Bufs bufs;
     layout(*t, a, bufs);
     t->ws_bytes = a.off;
@@ -671,6 +710,15 @@ int jodo_train_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes,
 void jodo_train_destroy(jodo_train* t) { delete t; }
 size_t jodo_train_desc_bytes(const jodo_train* t) { return t ? t->tables.size() * sizeof(int) : 0; }
 size_t jodo_train_workspace_bytes(const jodo_train* t) { return t ? t->ws_bytes : 0; }
+// option 0: fused per-edge forward chains (train_fused.hip): 1 (default where the width is supported) / 0 (op-by-op, the reference form)
+int jodo_train_set_option(jodo_train* t, int option, int value) {
+    if (!t) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: null handle");
+    if (option != 0 || (value != 0 && value != 1)) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: option %d value %d", option, value);
+    const FusedDims fd{t->D, t->De, t->r, t->QK, t->ce, t->L};
+    if (value && !fused_available(fd)) return jodo_set_error(JODO_ERR_UNSUPPORTED, "jodo_train_set_option: fused chains are not built for this shape");
+    t->fused = value;
+    return JODO_OK;
+}
 // tests: where a kept activation lives in the workspace.  what 0 = hhat (attention output [Nn, D]), 1 = alpha (softmax weights
 // [R, H]) of block `layer`
 int jodo_train_debug_locate(const jodo_train* t, int what, int layer, size_t* byte_offset, size_t* count) {

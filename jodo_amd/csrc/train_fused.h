@@ -1,0 +1,50 @@
+// Fused forward chains of the training step on the strip model (train_fused.hip; round 5).
+//
+// The grad-enabled forward of round 4 evaluated every per-edge operation of a block as a launch of its own (a GEMM per projection,
+// elementwise kernels between them: ~60 launches per block, every [R, 64] .. [R, 256] intermediate through HBM twice).  The three
+// per-edge chains of EquivariantMixBlock.forward (mol_gnn.py:270-322) are now one kernel each, written like the inference kernels
+// (dgt_device.h: a wave owns 32 edge rows, projections on v_mfma_f32_32x32x2_f32 with the accumulator of one projection as the B
+// operand of the next) with an ACTIVATION-SAVE epilogue: everything jodo_train_backward reads is stored exactly where the op-by-op
+// forward stored it, so the backward is unchanged.
+//   chain A  d2 -> GBF -> edge_emb([G ; e]) -> LayerNorm1 -> modulate -> tanh(lin_edge0), tanh(lin_edge1)        (:279-296, layers.py:165-184)
+//   chain B  e + g1 * node2edge -> LayerNorm2 -> modulate -> ff_linear3 -> SiLU, dropout -> ff_linear4 -> dropout -> gate -> readout (:313-317, :570)
+//   chain C  input_lin([h_row ; h_col ; e ; G]) -> LayerNorm -> modulate -> coord_mlp.0 -> SiLU -> coord_mlp.2 -> tanh  (mol_gnn.py:71-84)
+// The parameters change every optimiser step, so their MFMA operand images are packed by a small kernel per block and forward
+// (fused_pack_block) into the workspace.  The host-emulation build of the CPU suite (tests/emul) has no matrix instructions: there
+// fused_available() is false and dgt_train.hip runs the op-by-op sequence, which stays in the library as the reference form.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "train_common.h"
+
+namespace jt {
+
+struct FusedDims { int D, De, r, QK, ce, L; };
+
+// floats of packed operands per block; offsets (floats) of the pieces inside a block's slice
+struct FusedPackLayout { size_t ee, l0, l1, ff3, ff4, ero, in_eg, c0, tab, total; };
+FusedPackLayout fused_pack_layout(const FusedDims& d);
+
+bool fused_available(const FusedDims& d);
+
+struct FusedBlockParams {       // device pointers of one block's parameters (PyTorch layouts)
+    const float *edge_emb_w, *edge_emb_b, *le0, *le1, *ff3_w, *ff3_b, *ff4_w, *ff4_b, *ero_w, *ero_b, *in_w, *in_b, *c0_w, *c0_b, *c2_w, *n2e_b;
+    const float *gbf_means, *gbf_stds;
+};
+
+struct FusedTopo { int R; const int *edge_a, *edge_c, *edge_mol; };
+
+void fused_pack_block(hipStream_t s, const FusedDims& d, const FusedBlockParams& p, float* packed);
+
+// chain A.  pos [Nn, 3]; gm [B, 2] (scale, shift); e_in [R, De]; emod [B, 6 De] (shift at 0, scale at De)
+void fused_chain_a(hipStream_t s, const FusedDims& d, const FusedTopo& t, const FusedBlockParams& p, const float* packed, const float* pos, const float* gm,
+                   const float* e_in, const float* emod, float* d2, float* G, float* xh_e1, float* rs_e1, float* et, float* t0, float* t1);
+// chain B.  n2e [Nn, De] (node2edge_lin(hhat), bias not yet added); emod: g1 at 2 De, shift2 at 3 De, scale2 at 4 De, g2 at 5 De
+void fused_chain_b(hipStream_t s, const FusedDims& d, const FusedTopo& t, const FusedBlockParams& p, const float* packed, const float* e_in, const float* n2e,
+                   const float* emod, Drop drop_a3, Drop drop_f4, float* xh_en, float* rs_en, float* en, float* f3, float* a3, float* f4, float* e_out,
+                   float* eh, int ld_eh, int eh_col);
+// chain C.  hr / hc [Nn, D] = W_row h, W_col h; qmod [B, 2 D] (shift at 0, scale at D)
+void fused_chain_c(hipStream_t s, const FusedDims& d, const FusedTopo& t, const FusedBlockParams& p, const float* packed, const float* e_in, const float* G,
+                   const float* hr, const float* hc, const float* qmod, float* xh_pre, float* rs_pre, float* u, float* c0pre, float* c0a, float* inv);
+
+}  // namespace jt

@@ -1,0 +1,427 @@
+// Fused forward chains of the training step (see train_fused.h).  gfx950 only; strip model of dgt_device.h.
+#include <hip/hip_runtime.h>
+#include "dgt_kernels_attn.h"          // gbf_n (the Gaussian basis of the inference kernels), dgt_device.h
+#include "train_fused.h"
+#include "jodo_hip_internal.h"
+
+namespace {
+using namespace jd;
+
+template <int D_>
+struct FD {
+    static constexpr int D = D_, De = D_ / 4, ND = D_ / 32, NE = D_ / 128, HD = D_ / 2, HE = D_ / 8;
+    static constexpr int KQD = D_ / 8, KQE = D_ / 32;
+    static constexpr int PG = (D_ % 256 == 0) ? 8 : 4;
+};
+
+// LayerNorm (no affine, eps 1e-6, biased variance) over 2 NR features of an item; x becomes the normalised row, returns rstd
+template <int NR>
+__device__ __forceinline__ float layer_norm_rs(float (&x)[NR]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) s += x[i];
+    const float mean = pair_sum(s) * (1.f / (2 * NR));
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { x[i] -= mean; q = fmaf(x[i], x[i], q); }
+    const float rstd = 1.f / sqrtf(pair_sum(q) * (1.f / (2 * NR)) + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) x[i] *= rstd;
+    return rstd;
+}
+
+// dropout multipliers of 16 consecutive elements idx0 .. idx0 + 15 (idx0 a multiple of 4): the masks of train_common.h drop_mul,
+// four elements per Philox call instead of one
+__device__ __forceinline__ void drop16(const jt::Drop& d, unsigned long long idx0, float (&m)[16]) {
+    if (d.p <= 0.f) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) m[s] = 1.f;
+        return;
+    }
+    const float keep = 1.f / (1.f - d.p);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned long long g = (idx0 >> 2) + q;
+        unsigned u[4];
+        jt::philox4((unsigned)g, (unsigned)(g >> 32), d.site, 0x4a4f444fu, (unsigned)d.seed, (unsigned)(d.seed >> 32), u);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m[q * 4 + c] = ((float)(u[c] >> 8) * (1.0f / 16777216.0f)) < d.p ? 0.f : keep;
+    }
+}
+
+struct Common {
+    int R;
+    const int *ea, *ec, *em;
+    const float* packed;               // this block's packed operands
+    unsigned oEE, oL0, oL1, oF3, oF4, oRO, oIN, oC0;      // byte offsets inside `packed`
+    const float* tab;                  // Gaussian table [3][De]
+};
+
+struct ArgsA {
+    Common c;
+    const float *pos, *gm, *e_in, *emod, *ee_b;
+    float *d2, *G, *xh, *rs, *et, *t0, *t1;
+    int QK;
+};
+
+template <int D>
+__global__ __launch_bounds__(64, 1) void k_chain_a(ArgsA A) {
+    using X = FD<D>;
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const long r = (long)blockIdx.x * 32 + j;
+    const bool valid = r < A.c.R;
+    const long rc = valid ? r : (long)A.c.R - 1;
+    const int a = A.c.ea[rc], c = A.c.ec[rc], mol = A.c.em[rc];
+    const float dx = A.pos[a * 3] - A.pos[c * 3], dy = A.pos[a * 3 + 1] - A.pos[c * 3 + 1], dz = A.pos[a * 3 + 2] - A.pos[c * 3 + 2];
+    const float d2 = dx * dx + dy * dy + dz * dz;
+    if (valid && half == 0) A.d2[r] = d2;
+    const WSrc ws = make_wsrc(A.c.packed, lane);
+    WPipe<X::PG> wp;
+    wpipe_prime(wp, ws, A.c.oEE);
+    float G[X::HE], e[X::HE], x[X::HE];
+    gbf_n<X::NE>(d2, A.gm[mol * 2], A.gm[mol * 2 + 1], A.c.tab, half, G);
+    load_nat<X::NE>(A.e_in + rc * X::De, half, e);
+    if (valid) store_nat<X::NE>(A.G + r * X::De, half, G);
+#pragma unroll
+    for (int b = 0; b < X::NE; ++b) {                                 // edge_emb([G ; e])
+        const unsigned cg = A.c.oEE + (unsigned)(b * 2 * X::KQE) * 1024, ce = cg + X::KQE * 1024;
+        float bb[16];
+        load16(A.ee_b + b * 32 + half * 16, bb);
+        f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cg, ce, G, zero16());
+        acc = mfma_block_p<X::KQE>(wp, ws, ce, b + 1 < X::NE ? ce + X::KQE * 1024 : A.c.oL0, e, acc);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) x[b * 16 + s] = acc[s] + bb[s];
+    }
+    const float rstd = layer_norm_rs<X::HE>(x);
+    if (valid) {
+        store_nat<X::NE>(A.xh + r * X::De, half, x);
+        if (half == 0) A.rs[r] = rstd;
+    }
+    const float* mr = A.emod + (long)mol * 6 * X::De;
+    modulate<X::NE>(x, mr, mr + X::De, half);
+    if (valid) store_nat<X::NE>(A.et + r * X::De, half, x);
+    const int nb0 = (A.QK + 31) / 32;
+#pragma unroll 1
+    for (int b = 0; b < nb0; ++b) {                                   // tanh(lin_edge0 et)
+        const unsigned cur = A.c.oL0 + (unsigned)(b * X::KQE) * 1024;
+        f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cur, b + 1 < nb0 ? cur + X::KQE * 1024 : A.c.oL1, x, zero16());
+        float T[16];
+        tanh16(acc, T);
+        if (valid) {
+            float* o = A.t0 + r * A.QK + b * 32 + half * 16;          // rows of QK floats are 8-byte aligned (QK is even)
+#pragma unroll
+            for (int s = 0; s < 16; s += 2)
+                if (b * 32 + half * 16 + s < A.QK) *reinterpret_cast<float2*>(o + s) = make_float2(T[s], T[s + 1]);
+        }
+    }
+#pragma unroll 1
+    for (int b = 0; b < X::ND; ++b) {                                 // tanh(lin_edge1 et)
+        const unsigned cur = A.c.oL1 + (unsigned)(b * X::KQE) * 1024;
+        f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cur, b + 1 < X::ND ? cur + X::KQE * 1024 : A.c.oL1, x, zero16());
+        float T[16];
+        tanh16(acc, T);
+        if (valid) store16(A.t1 + r * D + b * 32 + half * 16, T);
+    }
+}
+
+struct ArgsB {
+    Common c;
+    const float *e_in, *n2e, *n2e_b, *emod, *b3, *b4, *bro;
+    jt::Drop d3, d4;
+    float *xh, *rs, *en, *f3, *a3, *f4, *e_out, *eh;
+    int ld_eh, eh_col, ce;
+};
+
+template <int D, int RR>
+__global__ __launch_bounds__(64, 1) void k_chain_b(ArgsB A) {
+    using X = FD<D>;
+    constexpr int HID = RR * X::De, NCH = HID / 64, KQ4 = HID / 8;
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const long r = (long)blockIdx.x * 32 + j;
+    const bool valid = r < A.c.R;
+    const long rc = valid ? r : (long)A.c.R - 1;
+    const int a = A.c.ea[rc], c = A.c.ec[rc], mol = A.c.em[rc];
+    const float* mr = A.emod + (long)mol * 6 * X::De;
+    const WSrc ws = make_wsrc(A.c.packed, lane);
+    WPipe<X::PG> wp;
+    wpipe_prime(wp, ws, A.c.oF3);
+    float x[X::HE];
+#pragma unroll
+    for (int b = 0; b < X::NE; ++b) {                                 // x1 = e + g1 (n2e_a + n2e_c + bias)
+        float e[16], ta[16], tc[16], g[16], bb[16];
+        const int f0 = b * 32 + half * 16;
+        load16(A.e_in + rc * X::De + f0, e);
+        load16(A.n2e + (long)a * X::De + f0, ta);
+        load16(A.n2e + (long)c * X::De + f0, tc);
+        load16(mr + 2 * X::De + f0, g);
+        load16(A.n2e_b + f0, bb);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) x[b * 16 + s] = fmaf(g[s], ta[s] + tc[s] + bb[s], e[s]);
+    }
+    const float rstd = layer_norm_rs<X::HE>(x);
+    if (valid) {
+        store_nat<X::NE>(A.xh + r * X::De, half, x);
+        if (half == 0) A.rs[r] = rstd;
+    }
+    modulate<X::NE>(x, mr + 3 * X::De, mr + 4 * X::De, half);
+    if (valid) store_nat<X::NE>(A.en + r * X::De, half, x);
+    f32x16 o[X::NE];
+#pragma unroll
+    for (int b = 0; b < X::NE; ++b) o[b] = zero16();
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+        float hid[32];
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+            const int hb = ch * 2 + b2, f0 = hb * 32 + half * 16;
+            const unsigned cur = A.c.oF3 + (unsigned)(hb * X::KQE) * 1024;
+            const unsigned nxt = b2 == 0 ? cur + X::KQE * 1024 : A.c.oF4 + (unsigned)(ch * 8) * 1024;
+            float bb[16], pre[16], act[16], m[16];
+            load16(A.b3 + f0, bb);
+            f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cur, nxt, x, zero16());
+            drop16(A.d3, (unsigned long long)rc * HID + f0, m);
+#pragma unroll
+            for (int s = 0; s < 16; s += 2) {
+                const f32x2 p = pk2(acc[s], acc[s + 1]) + pk2(bb[s], bb[s + 1]);
+                const f32x2 v = silu_f2(p) * pk2(m[s], m[s + 1]);
+                pre[s] = p.x; pre[s + 1] = p.y; act[s] = v.x; act[s + 1] = v.y;
+                hid[b2 * 16 + s] = v.x; hid[b2 * 16 + s + 1] = v.y;
+            }
+            if (valid) { store16(A.f3 + r * HID + f0, pre); store16(A.a3 + r * HID + f0, act); }
+        }
+#pragma unroll
+        for (int ob = 0; ob < X::NE; ++ob) {
+            const unsigned cur = A.c.oF4 + (unsigned)(ob * KQ4 + ch * 8) * 1024;
+            const unsigned nxt = ob + 1 < X::NE ? A.c.oF4 + (unsigned)((ob + 1) * KQ4 + ch * 8) * 1024
+                                                : (ch + 1 < NCH ? A.c.oF3 + (unsigned)((ch + 1) * 2 * X::KQE) * 1024 : A.c.oRO);
+            o[ob] = mfma_block_p<8>(wp, ws, cur, nxt, hid, o[ob]);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < X::NE; ++b) {                                 // f4 (kept before its dropout), e' = en + g2 * dropout(f4)
+        const int f0 = b * 32 + half * 16;
+        float bb[16], g[16], m[16], f4[16];
+        load16(A.b4 + f0, bb);
+        load16(mr + 5 * X::De + f0, g);
+        drop16(A.d4, (unsigned long long)rc * X::De + f0, m);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            f4[s] = o[b][s] + bb[s];
+            x[b * 16 + s] = fmaf(g[s], f4[s] * m[s], x[b * 16 + s]);
+        }
+        if (valid) store16(A.f4 + r * X::De + f0, f4);
+    }
+    if (valid) store_nat<X::NE>(A.e_out + r * X::De, half, x);
+    {   // readout edge_l(e') -> the head input, ce valid columns
+        f32x16 acc = mfma_block_p<X::KQE>(wp, ws, A.c.oRO, A.c.oRO, x, zero16());
+        if (valid) {
+            float* o2 = A.eh + r * A.ld_eh + A.eh_col + half * 16;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                if (half * 16 + s < A.ce) o2[s] = acc[s] + A.bro[half * 16 + s];
+        }
+    }
+}
+
+struct ArgsC {
+    Common c;
+    const float *e_in, *G, *hr, *hc, *in_b, *qmod, *b0, *w2;
+    float *xh, *rs, *u, *c0pre, *c0a, *inv;
+};
+
+#ifndef JODO_X_CHAINC_OCC                                              // experiment builds: waves per SIMD the compiler must leave room for
+#define JODO_X_CHAINC_OCC 1
+#endif
+template <int D>
+__global__ __launch_bounds__(64, JODO_X_CHAINC_OCC) void k_chain_c(ArgsC A) {
+    using X = FD<D>;
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const long r = (long)blockIdx.x * 32 + j;
+    const bool valid = r < A.c.R;
+    const long rc = valid ? r : (long)A.c.R - 1;
+    const int a = A.c.ea[rc], c = A.c.ec[rc], mol = A.c.em[rc];
+    const WSrc ws = make_wsrc(A.c.packed, lane);
+    WPipe<X::PG> wp;
+    wpipe_prime(wp, ws, A.c.oIN);
+    float e[X::HE], G[X::HE], u[X::HD];
+    load_nat<X::NE>(A.e_in + rc * X::De, half, e);
+    load_nat<X::NE>(A.G + rc * X::De, half, G);
+#pragma unroll
+    for (int b = 0; b < X::ND; ++b) {                                 // pre = W_e e + W_g G + b + W_row h_a + W_col h_c
+        const unsigned we = A.c.oIN + (unsigned)(b * 2 * X::KQE) * 1024, wg = we + X::KQE * 1024;
+        const int f0 = b * 32 + half * 16;
+        float bb[16], t1[16], t2[16];
+        load16(A.in_b + f0, bb);
+        load16(A.hr + (long)a * D + f0, t1);
+        load16(A.hc + (long)c * D + f0, t2);
+        f32x16 acc = mfma_block_p<X::KQE>(wp, ws, we, wg, e, zero16());
+        acc = mfma_block_p<X::KQE>(wp, ws, wg, b + 1 < X::ND ? wg + X::KQE * 1024 : A.c.oC0, G, acc);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) u[b * 16 + s] = (acc[s] + bb[s]) + (t1[s] + t2[s]);
+    }
+    const float rstd = layer_norm_rs<X::HD>(u);
+    if (valid) {
+        store_nat<X::ND>(A.xh + r * D, half, u);
+        if (half == 0) A.rs[r] = rstd;
+    }
+    const float* mr = A.qmod + (long)mol * 2 * D;
+    modulate<X::ND>(u, mr, mr + D, half);
+    if (valid) store_nat<X::ND>(A.u + r * D, half, u);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll 1
+    for (int b = 0; b < X::ND; ++b) {                                 // coord_mlp.0 -> SiLU -> coord_mlp.2
+        const unsigned cur = A.c.oC0 + (unsigned)(b * X::KQD) * 1024;
+        const int f0 = b * 32 + half * 16;
+        float bb[16], k0[16], k1[16], k2[16], pre[16], act[16];
+        load16(A.b0 + f0, bb);
+        load16(A.w2 + f0, k0);
+        load16(A.w2 + D + f0, k1);
+        load16(A.w2 + 2 * D + f0, k2);
+        f32x16 acc = mfma_block_p<X::KQD>(wp, ws, cur, b + 1 < X::ND ? cur + X::KQD * 1024 : A.c.oC0, u, zero16());
+#pragma unroll
+        for (int s = 0; s < 16; s += 2) {
+            const f32x2 p = pk2(acc[s], acc[s + 1]) + pk2(bb[s], bb[s + 1]);
+            const f32x2 v = silu_f2(p);
+            pre[s] = p.x; pre[s + 1] = p.y; act[s] = v.x; act[s + 1] = v.y;
+            c0 = fmaf(v.x, k0[s], c0); c0 = fmaf(v.y, k0[s + 1], c0);
+            c1 = fmaf(v.x, k1[s], c1); c1 = fmaf(v.y, k1[s + 1], c1);
+            c2 = fmaf(v.x, k2[s], c2); c2 = fmaf(v.y, k2[s + 1], c2);
+        }
+        if (valid) { store16(A.c0pre + r * D + f0, pre); store16(A.c0a + r * D + f0, act); }
+    }
+    c0 = tanh_f(pair_sum(c0)); c1 = tanh_f(pair_sum(c1)); c2 = tanh_f(pair_sum(c2));
+    if (valid && half == 0) { A.inv[r * 3] = c0; A.inv[r * 3 + 1] = c1; A.inv[r * 3 + 2] = c2; }
+}
+
+// ---- operand packing: PyTorch [out, in] (row stride ld, first column col0) -> [out block][quad][lane] float4 in the natural maps
+// of dgt_pack.cpp (register R of half h = feature (R / 16) 32 + 16 h + R % 16 on both sides); rows >= n_out are zero
+struct PackItem { const float* w; int ld, col0, n_out, nb, kq; unsigned dst; };      // dst in floats, nb output blocks, kq quads per block
+struct PackArgs { PackItem it[8]; int first[9]; float* out; const float *means, *stds; int De; unsigned tab; };
+
+__global__ __launch_bounds__(64) void k_pack(PackArgs P) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (q >= P.first[8]) {                                            // the Gaussian table [3][De]: mu | 1 / sigma | 1 / (sqrt(2 * 3.14159) sigma)
+        for (int k = lane; k < P.De; k += 64) {
+            float mu = 0.f, is = 1.f, cf = 0.f;
+            if (k > 0) {
+                const float sd = fabsf(P.stds[k - 1]) + 1e-5f;
+                mu = P.means[k - 1]; is = 1.f / sd; cf = 1.f / (2.5066272f * sd);
+            }
+            P.out[P.tab + k] = mu; P.out[P.tab + P.De + k] = is; P.out[P.tab + 2 * P.De + k] = cf;
+        }
+        return;
+    }
+    int m = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (q >= P.first[i]) m = i;
+    const PackItem it = P.it[m];
+    const int loc = q - P.first[m], b = loc / it.kq, kq = loc % it.kq;
+    const int i = lane & 31, kh = lane >> 5, oh = (i >> 2) & 1, os = (i & 3) + 4 * (i >> 3);
+    const int row = b * 32 + oh * 16 + os;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int R = kq * 4 + c, col = (R / 16) * 32 + kh * 16 + (R % 16);
+        v[c] = row < it.n_out ? it.w[(long)row * it.ld + it.col0 + col] : 0.f;
+    }
+    reinterpret_cast<float4*>(P.out + it.dst)[(long)loc * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+Common common_of(const jt::FusedDims& d, const jt::FusedTopo& t, const float* packed) {
+    const jt::FusedPackLayout L = jt::fused_pack_layout(d);
+    Common c;
+    c.R = t.R; c.ea = t.edge_a; c.ec = t.edge_c; c.em = t.edge_mol; c.packed = packed;
+    c.oEE = (unsigned)(L.ee * 4); c.oL0 = (unsigned)(L.l0 * 4); c.oL1 = (unsigned)(L.l1 * 4); c.oF3 = (unsigned)(L.ff3 * 4);
+    c.oF4 = (unsigned)(L.ff4 * 4); c.oRO = (unsigned)(L.ero * 4); c.oIN = (unsigned)(L.in_eg * 4); c.oC0 = (unsigned)(L.c0 * 4);
+    c.tab = packed + L.tab;
+    return c;
+}
+
+}  // namespace
+
+namespace jt {
+
+FusedPackLayout fused_pack_layout(const FusedDims& d) {
+    FusedPackLayout L;
+    const size_t De = d.De, D = d.D, qkp = (size_t)(d.QK + 31) / 32 * 32;
+    size_t o = 0;
+    L.ee = o; o += De * 2 * De;
+    L.l0 = o; o += qkp * De;
+    L.l1 = o; o += D * De;
+    L.ff3 = o; o += (size_t)d.r * De * De;
+    L.ff4 = o; o += De * d.r * De;
+    L.ero = o; o += 32 * De;
+    L.in_eg = o; o += D * 2 * De;
+    L.c0 = o; o += D * D;
+    L.tab = o; o += 3 * De;
+    L.total = (o + 63) / 64 * 64;
+    return L;
+}
+
+bool fused_available(const FusedDims& d) {
+    return (d.D == 128 || d.D == 256 || d.D == 384) && (d.r == 2 || d.r == 4) && d.De == d.D / 4 && d.ce >= 1 && d.ce <= 32 && d.QK % 2 == 0 &&
+           d.QK <= d.D && (d.r * d.De) % 64 == 0;
+}
+
+void fused_pack_block(hipStream_t s, const FusedDims& d, const FusedBlockParams& p, float* packed) {
+    const FusedPackLayout L = fused_pack_layout(d);
+    const int De = d.De, D = d.D;
+    PackArgs P;
+    auto item = [](const float* w, int ld, int col0, int n_out, int K, size_t dst) {
+        PackItem it; it.w = w; it.ld = ld; it.col0 = col0; it.n_out = n_out; it.nb = (n_out + 31) / 32; it.kq = K / 8; it.dst = (unsigned)dst; return it;
+    };
+    P.it[0] = item(p.edge_emb_w, 2 * De, 0, De, 2 * De, L.ee);
+    P.it[1] = item(p.le0, De, 0, d.QK, De, L.l0);
+    P.it[2] = item(p.le1, De, 0, D, De, L.l1);
+    P.it[3] = item(p.ff3_w, De, 0, d.r * De, De, L.ff3);
+    P.it[4] = item(p.ff4_w, d.r * De, 0, De, d.r * De, L.ff4);
+    P.it[5] = item(p.ero_w, De, 0, d.ce, De, L.ero);
+    P.it[6] = item(p.in_w, 2 * D + 2 * De, 2 * D, D, 2 * De, L.in_eg);
+    P.it[7] = item(p.c0_w, D, 0, D, D, L.c0);
+    P.first[0] = 0;
+    for (int i = 0; i < 8; ++i) P.first[i + 1] = P.first[i] + P.it[i].nb * P.it[i].kq;
+    P.out = packed; P.means = p.gbf_means; P.stds = p.gbf_stds; P.De = De; P.tab = (unsigned)L.tab;
+    hipLaunchKernelGGL(k_pack, dim3(P.first[8] + 1), dim3(64), 0, s, P);
+}
+
+void fused_chain_a(hipStream_t s, const FusedDims& d, const FusedTopo& t, const FusedBlockParams& p, const float* packed, const float* pos, const float* gm,
+                   const float* e_in, const float* emod, float* d2, float* G, float* xh_e1, float* rs_e1, float* et, float* t0, float* t1) {
+    ArgsA A;
+    A.c = common_of(d, t, packed);
+    A.pos = pos; A.gm = gm; A.e_in = e_in; A.emod = emod; A.ee_b = p.edge_emb_b;
+    A.d2 = d2; A.G = G; A.xh = xh_e1; A.rs = rs_e1; A.et = et; A.t0 = t0; A.t1 = t1; A.QK = d.QK;
+    const dim3 grid((unsigned)((t.R + 31) / 32));
+    if (d.D == 128) hipLaunchKernelGGL(k_chain_a<128>, grid, dim3(64), 0, s, A);
+    else if (d.D == 256) hipLaunchKernelGGL(k_chain_a<256>, grid, dim3(64), 0, s, A);
+    else hipLaunchKernelGGL(k_chain_a<384>, grid, dim3(64), 0, s, A);
+}
+
+void fused_chain_b(hipStream_t s, const FusedDims& d, const FusedTopo& t, const FusedBlockParams& p, const float* packed, const float* e_in, const float* n2e,
+                   const float* emod, Drop drop_a3, Drop drop_f4, float* xh_en, float* rs_en, float* en, float* f3, float* a3, float* f4, float* e_out,
+                   float* eh, int ld_eh, int eh_col) {
+    ArgsB A;
+    A.c = common_of(d, t, packed);
+    A.e_in = e_in; A.n2e = n2e; A.n2e_b = p.n2e_b; A.emod = emod; A.b3 = p.ff3_b; A.b4 = p.ff4_b; A.bro = p.ero_b;
+    A.d3 = drop_a3; A.d4 = drop_f4;
+    A.xh = xh_en; A.rs = rs_en; A.en = en; A.f3 = f3; A.a3 = a3; A.f4 = f4; A.e_out = e_out; A.eh = eh; A.ld_eh = ld_eh; A.eh_col = eh_col; A.ce = d.ce;
+    const dim3 grid((unsigned)((t.R + 31) / 32));
+#define JT_B(DD, RR) hipLaunchKernelGGL((k_chain_b<DD, RR>), grid, dim3(64), 0, s, A)
+    if (d.D == 128) { if (d.r == 2) JT_B(128, 2); else JT_B(128, 4); }
+    else if (d.D == 256) { if (d.r == 2) JT_B(256, 2); else JT_B(256, 4); }
+    else { if (d.r == 2) JT_B(384, 2); else JT_B(384, 4); }
+#undef JT_B
+}
+
+void fused_chain_c(hipStream_t s, const FusedDims& d, const FusedTopo& t, const FusedBlockParams& p, const float* packed, const float* e_in, const float* G,
+                   const float* hr, const float* hc, const float* qmod, float* xh_pre, float* rs_pre, float* u, float* c0pre, float* c0a, float* inv) {
+    ArgsC A;
+    A.c = common_of(d, t, packed);
+    A.e_in = e_in; A.G = G; A.hr = hr; A.hc = hc; A.in_b = p.in_b; A.qmod = qmod; A.b0 = p.c0_b; A.w2 = p.c2_w;
+    A.xh = xh_pre; A.rs = rs_pre; A.u = u; A.c0pre = c0pre; A.c0a = c0a; A.inv = inv;
+    const dim3 grid((unsigned)((t.R + 31) / 32));
+    if (d.D == 128) hipLaunchKernelGGL(k_chain_c<128>, grid, dim3(64), 0, s, A);
+    else if (d.D == 256) hipLaunchKernelGGL(k_chain_c<256>, grid, dim3(64), 0, s, A);
+    else hipLaunchKernelGGL(k_chain_c<384>, grid, dim3(64), 0, s, A);
+}
+
+}  // namespace jt

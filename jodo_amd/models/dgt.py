@@ -332,7 +332,8 @@ class _DGTBase(nn.Module):
             n_host = np.ascontiguousarray(host[:B])
         else:
             n_host = n_nodes.cpu().numpy()
-        key = (str(device), N) + tuple(int(v) for v in n_host)
+        opts = dict(getattr(self, 'train_options', None) or {})        # {jodo_train_set_option: value}, e.g. {0: 0}: op-by-op forward (tests)
+        key = (str(device), N, tuple(sorted(opts.items()))) + tuple(int(v) for v in n_host)
         cache = self.__dict__.setdefault('_train_engines', {})
         eng = cache.pop(key, None)
         if eng is None:
@@ -341,7 +342,7 @@ class _DGTBase(nn.Module):
             if named is None:
                 named = self.__dict__['_train_named'] = TrainEngine.named_table([(k, tuple(v.shape)) for k, v in self.state_dict().items()])
             pool = self.__dict__.setdefault('_train_pool', TrainEngine.new_pool())     # the activation workspace(s) of this module
-            eng = TrainEngine(self._cfg(), n_host, N, named, device, pool=pool)
+            eng = TrainEngine(self._cfg(), n_host, N, named, device, pool=pool, options=opts)
             while len(cache) >= 16:                             # handles are small (index tables); the workspace is shared
                 cache.pop(next(iter(cache)))
         cache[key] = eng                                        # most recently used last

@@ -96,7 +96,7 @@ class TrainEngine:
         reused and ITS backward raises."""
         return {'slots': [{'buf': None, 'stamp': 0, 'live': False} for _ in range(slots)], 'stamp': 0}
 
-    def __init__(self, cfg_struct, n_nodes, N, named_shapes, device, lib=None, stream_ptr=None, pool=None):
+    def __init__(self, cfg_struct, n_nodes, N, named_shapes, device, lib=None, stream_ptr=None, pool=None, options=None):
         self.L = lib if lib is not None else capi.lib()
         self._check = capi.check if lib is None else self._check_foreign
         self._stream = stream_ptr if stream_ptr is not None else capi.current_stream_ptr
@@ -113,6 +113,8 @@ class TrainEngine:
         self.L.jodo_train_workspace_bytes.restype = ctypes.c_size_t
         self.L.jodo_train_desc_bytes.argtypes = [ctypes.c_void_p]
         self.L.jodo_train_workspace_bytes.argtypes = [ctypes.c_void_p]
+        for opt, val in (options or {}).items():                 # jodo_train_set_option, e.g. {0: 0} = op-by-op forward (tests)
+            self._check(self.L.jodo_train_set_option(self.handle, int(opt), int(val)), 'jodo_train_set_option')
         self.desc = torch.empty(self.L.jodo_train_desc_bytes(self.handle), dtype=torch.uint8, device=device)
         # The activation workspace (2.6 GB at QM9 batch 128) is shared by every engine of a module through `pool`: data loaders
         # produce a new set of atom counts every step, so handles come and go while the pool's buffers, grown to the largest request,

@@ -65,3 +65,18 @@ void gemm(hipStream_t, int tA, int tB, int M, int N, int K, const float* A, int 
         }
 }
 }
+
+// The fused forward chains (jodo_amd/csrc/train_fused.hip) are matrix-instruction kernels: not available to the host emulation, which
+// runs — and thereby checks — the op-by-op sequence they replace.
+#include "train_fused.h"
+namespace jt {
+FusedPackLayout fused_pack_layout(const FusedDims&) { return FusedPackLayout{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+bool fused_available(const FusedDims&) { return false; }
+void fused_pack_block(hipStream_t, const FusedDims&, const FusedBlockParams&, float*) {}
+void fused_chain_a(hipStream_t, const FusedDims&, const FusedTopo&, const FusedBlockParams&, const float*, const float*, const float*, const float*,
+                   const float*, float*, float*, float*, float*, float*, float*, float*) {}
+void fused_chain_b(hipStream_t, const FusedDims&, const FusedTopo&, const FusedBlockParams&, const float*, const float*, const float*, const float*, Drop,
+                   Drop, float*, float*, float*, float*, float*, float*, float*, float*, int, int) {}
+void fused_chain_c(hipStream_t, const FusedDims&, const FusedTopo&, const FusedBlockParams&, const float*, const float*, const float*, const float*,
+                   const float*, const float*, float*, float*, float*, float*, float*, float*) {}
+}

@@ -112,13 +112,19 @@ def debug_fetch(model, what, count):
 # reference's own operation order.  Every comparison is logged (gpurun_out/parity_errors.jsonl) so that DESIGN.md quotes measured
 # numbers.
 FWD_ATOL, FWD_RTOL, K64 = 2e-5, 1e-4, 4.0
-# Two documented exceptions to K64 (measured on MI355X, round 4, gpurun_out/r04a/parity_errors.jsonl):
-#  * K64_LARGE: nf = 384, or a molecule with n > 128 atoms (position sums over > 128 neighbours; the kernels' hoisted algebra sums
-#    W0 (.) images of the three parts of `pre` that the reference adds before the LayerNorm).  Measured worst: 13.5 x the float32
-#    oracle's own error at nf 384 (3.99e-5 absolute on positions of size 3.5), 5.4 x at n = 150 (2.3e-4 against 4.3e-5).
+# Two documented exceptions to K64 (measured on MI355X):
+#  * K64_LARGE: nf = 384, or a molecule with n > 128 atoms.  Round 4 needed 16 here (13.5 x at nf 384, 6.7 x / 2.9e-4 at n = 150) and
+#    round 5 found the digit: every neighbour's position increment was added into the running position (up to 180 roundings at
+#    ulp(|x| ~ 4) per block); summed among themselves first, as the reference does (advance_position, dgt_kernels_common.h), n = 150
+#    is at 8e-5 - 1.3e-4 and nf 384 at 2e-5.  Measured in ONE process (tools/err_by_block.py: same inputs, oracle32 and oracle64 from
+#    the same run) the kernels are now within 1.7 - 4.2 x of the float32 oracle on every output; the suite's log still shows up to
+#    8.3 x because the float32 oracle's own error moves by 2 x with torch's CPU thread count (1.1e-5 vs 2.5e-5 on the same inputs:
+#    reduction order), so the regime keeps a factor 10 (worst logged 8.3), down from 16.  The rest is MFMA accumulation order: one fp32 chain over
+#    K = 1024 / 1536 hidden features where the CPU sums blocked (h after block 0: 1.3e-5 against the oracle's 1.8e-6, equal from
+#    block 4 on).
 #  * K64_HARD: the adversarial-weights stress (trunk gain 3 - 5, outputs 1e3 - 1e7, float32 oracle 1e-2 - 1e3 from float64):
-#    measured worst 13 x.
-K64_LARGE, K64_HARD = 16.0, 16.0
+#    measured worst 14.5 x (edges; not a position sum).
+K64_LARGE, K64_HARD = 10.0, 16.0
 
 
 def k64_for(hp, n_nodes):

@@ -122,6 +122,40 @@ def test_attention_kernel_variants_agree():
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
 
 
+@pytest.mark.parametrize("cfg_name,n_nodes,over,uniform", [
+    ('vpsde_qm9_uncond_jodo', [29, 1, 2, 18, 18, 7, 23, 12, 12, 9] * 7, {}, True),        # 434 pair items: two waves under option 2; folded + rotated
+    ('vpsde_qm9_uncond_jodo', [29, 1, 2, 18, 18, 7, 23, 12, 12, 9] * 3, {}, False),       # per-molecule rows at nf 256: the unfolded hoisted form, four waves
+    ('vpsde_qm9_cond_jodo', [27, 9, 14, 20, 5] * 6, {}, True),                             # conditional model
+    ('vpsde_geom_uncond_jodo', [44, 33, 12, 2, 1], dict(nf=384), True),                   # nf 384 folded (12 output blocks dealt to 2 / 4 waves)
+    ('vpsde_geom_uncond_jodo', [40, 33, 7], dict(nf=128, n_layers=6), True),
+])
+def test_pair_update_z_split_agrees(cfg_name, n_nodes, over, uniform):
+    """JODO_OPT_Z_SPLIT (round 5): the pair-update items of a launch's last round run as workgroups of 4 (<= 256 items, default) or 2
+    (<= 512 items, option value 2) waves that share the output blocks of the per-pair coord_mlp.0 projection; their partial
+    coord_mlp.2 dot products meet in LDS in wave order.  Same items, another summation order of 2 x 3 numbers per pair: outputs
+    within the single-forward tolerance of the one-wave form (option 0) and of the oracle, and bit-deterministic."""
+    cfg = make_config(cfg_name, **over)
+    hp = O.Hyper.from_config(cfg)
+    xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=23)
+    if uniform:
+        nl[:] = 0.3
+    outs = {}
+    for z in (0, 1, 2):
+        model = make_model(cfg, 5, DEV, gain=1.3, coord_scale=0.05)
+        model.plan_options = {12: z}
+        o1 = run(model, xh, ex, nl, nm, em, None, None, ctx)
+        outs[z] = (o1, run(model, xh, ex, nl, nm, em, o1[0], o1[1], ctx))
+        again = run(model, xh, ex, nl, nm, em, o1[0], o1[1], ctx)
+        assert torch.equal(again[0], outs[z][1][0]) and torch.equal(again[1], outs[z][1][1])
+    sd = state_dict_cpu(model)
+    check64(outs[1][0], sd, hp, xh, nm, em, ex, None, None, nl, ctx, 'z split (default), first step', k=k64_for(hp, n_nodes))
+    for z in (1, 2):
+        for step in (0, 1):
+            close(outs[z][step][0], outs[0][step][0], atol=2e-5)
+            close(outs[z][step][1], outs[0][step][1], atol=2e-5)
+    assert not torch.equal(outs[2][1][0], outs[0][1][0])               # the split really ran (another summation order)
+
+
 @pytest.mark.parametrize("cfg_name,n_nodes,gain,over", [
     ('vpsde_qm9_uncond_jodo', [6, 11, 20, 29, 1, 2], 1.0, {}),
     ('vpsde_qm9_uncond_jodo', [5] * 14 + [19] * 10, 1.5, {}),                            # several strips
