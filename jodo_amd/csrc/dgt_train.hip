@@ -196,8 +196,13 @@ struct Ctx {
     // LayerNorm + modulate backward: modulation gradients into dmods[:, sh], [:, sc] (written), dx (acc)
     void ln_mod_bwd(long rows, int F, const float* dy, const float* xhat, const float* rstd, const int* row_mol, const int* seg_off, const float* mods,
                     int ldm, int sh, int sc, float* dmods, float* dx, int acc) const {
-        seg(F, seg_off, dy, nullptr, dmods, ldm, sh);
-        seg(F, seg_off, dy, xhat, dmods, ldm, sc);
+        // d shift = sum dy, d scale = sum dy xhat per molecule: one pass (edge rows: two levels over the plan's chunks)
+        if (seg_off == tp.edge_off) {
+            JT_LAUNCH(k_seg_part2, (long)tp.NC * F, s, tp.NC, F, tp.ec_off, dy, xhat, b.part);
+            JT_LAUNCH(k_seg_fin2, (long)t.B * 2 * F, s, t.B, F, tp.ec_mol_off, (const float*)b.part, dmods, ldm, sh, sc);
+        } else {
+            JT_LAUNCH(k_seg_colsum2, (long)t.B * F, s, t.B, F, seg_off, dy, xhat, dmods, ldm, sh, sc);
+        }
         JT_LAUNCH(k_ln_bwd_part, rows * 8, s, rows, F, dy, xhat, row_mol, mods, ldm, sc, b.rowpart);
         JT_LAUNCH(k_ln_bwd_stats, rows, s, rows, F, (const float*)b.rowpart, b.tRow[0], b.tRow[1]);
         JT_LAUNCH(k_ln_bwd_apply, rows * F, s, rows, F, dy, xhat, rstd, (const float*)b.tRow[0], (const float*)b.tRow[1], row_mol, mods,

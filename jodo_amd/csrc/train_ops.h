@@ -198,6 +198,35 @@ __global__ void k_seg_fin(int S, int F, const int* __restrict__ mol_off, const f
     float* o = out + (long)s * ldo + ocol + f;
     *o = acc ? *o + (float)t : (float)t;
 }
+// both sums a LayerNorm + modulate backward needs, in one pass over the rows (round 5: the two used to be two launches each):
+// out[s, c1 + f] = sum a[r, f],  out[s, c2 + f] = sum a[r, f] b[r, f]   (same loops, same order: bit-identical to the separate sums)
+__global__ void k_seg_colsum2(int S, int F, const int* __restrict__ off, const float* __restrict__ a, const float* __restrict__ b,
+                              float* __restrict__ out, int ldo, int c1, int c2) {
+    JT_IDX((long)S * F);
+    const int s = (int)(i_ / F), f = (int)(i_ % F);
+    double t = 0.0, u = 0.0;
+#pragma unroll 8
+    for (long r = off[s]; r < off[s + 1]; ++r) { const float av = a[r * F + f]; t += (double)av; u += (double)(av * b[r * F + f]); }
+    out[(long)s * ldo + c1 + f] = (float)t;
+    out[(long)s * ldo + c2 + f] = (float)u;
+}
+__global__ void k_seg_part2(int NC, int F, const int* __restrict__ ec_off, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part) {
+    JT_IDX((long)NC * F);
+    const int c = (int)(i_ / F), f = (int)(i_ % F);
+    double t = 0.0, u = 0.0;
+#pragma unroll 8
+    for (long r = ec_off[c]; r < ec_off[c + 1]; ++r) { const float av = a[r * F + f]; t += (double)av; u += (double)(av * b[r * F + f]); }
+    part[(long)c * 2 * F + f] = (float)t;
+    part[(long)c * 2 * F + F + f] = (float)u;
+}
+__global__ void k_seg_fin2(int S, int F, const int* __restrict__ mol_off, const float* __restrict__ part, float* __restrict__ out, int ldo, int c1, int c2) {
+    JT_IDX((long)S * 2 * F);
+    const int s = (int)(i_ / (2 * F)), g = (int)(i_ % (2 * F));
+    double t = 0.0;
+#pragma unroll 8
+    for (int c = mol_off[s]; c < mol_off[s + 1]; ++c) t += (double)part[(long)c * 2 * F + g];
+    out[(long)s * ldo + (g < F ? c1 + g : c2 + g - F)] = (float)t;
+}
 // column sums of a [rows, F] (row stride lda) in two deterministic stages: part[c, f] = sum of chunk c, then out[f] (+)= sum_c
 __global__ void k_colsum_part(long rows, int F, int chunk, const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, float* __restrict__ part) {
     const long nchunks = (rows + chunk - 1) / chunk;
