@@ -57,7 +57,8 @@ struct Bufs {
     // scratch shared by all phases
     float *tE_D[3], *tE_De[4], *tE_QK, *tE_rD, *tE_H, *tN_D[4], *tN_QK[2], *tN_rD, *tN_De, *tRow[3], *tE3[3], *tN3[4], *tcatn, *tcate;
     float *dtau, *dtemb, *dnmod, *demod, *dqmod, *dgm, *tB_T[2], *tB_cD[2], *part, *part2, *rowpart, *splitk;
-    float* fpack;                     // packed MFMA operands of the fused forward chains, one slice per block (train_fused.h)
+    float* fpack;                     // packed MFMA operands of the fused chains (forward + transposed images), one slice per block (train_fused.h)
+    float* tE_De2[3];                 // scratch of the fused backward chains: df4 | den | de1
     size_t fpack_block;
     size_t splitk_floats, part_floats, part2_floats;
 };
@@ -79,6 +80,7 @@ struct jodo_train {
     std::vector<BlkIx> blk;
     size_t ws_bytes;
     int fused;                        // 1: the three per-edge chains of a block run as fused strip kernels (train_fused.hip)
+    int fused_bwd;                    // 1: their input-gradient sides too (the weight-gradient products stay GEMMs)
 };
 
 namespace {
@@ -131,8 +133,9 @@ void layout(const jodo_train& t, Arena& a, Bufs& b) {
     if (b.splitk_floats > need) b.splitk_floats = need;
     b.splitk = a.f(b.splitk_floats);
     const FusedDims fd{t.D, t.De, t.r, t.QK, t.ce, t.L};
-    b.fpack_block = fused_pack_layout(fd).total;
+    b.fpack_block = fused_pack_layout(fd).total_bwd;
     b.fpack = a.f(b.fpack_block * L);
+    for (int s = 0; s < 3; ++s) b.tE_De2[s] = a.f(R * De);
 }
 
 struct Ctx {
@@ -455,15 +458,34 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         JT_LAUNCH(k_coord_bwd, R, s, tp, (const float*)b.pos[l], (const float*)k.inv, (const float*)b.adj2d, (const float*)b.adjsp,
                            c.p(ix.eq_scale), (const float*)dxp, dinv, ddiff, b.tRow[2]);
         c.colsum(b.tRow[2], 1, nullptr, 0, R, 1, c.g(ix.eq_scale));
-        JT_LAUNCH(k_tanh_bwd, (long)R * 3, s, (long)R * 3, (const float*)k.inv, dinv);
-        c.lin_dw(dinv, 3, R, 3, k.c0a, D, D, c.g(ix.eq_c2), D);
-        float* dc0 = b.tE_D[0];
-        c.lin_dx(dinv, 3, R, 3, c.p(ix.eq_c2), D, D, dc0, D, 0);
-        c.silu_bwd((long)R * D, k.c0pre, dc0, dc0, nod);
-        c.lin_dw(dc0, D, R, D, k.u, D, D, c.g(ix.eq_c0.w), D, c.g(ix.eq_c0.b));
-        float *du = b.tE_D[1], *dpre = b.tE_D[2];
-        c.lin_dx(dc0, D, R, D, c.p(ix.eq_c0.w), D, D, du, D, 0);
-        c.ln_mod_bwd(R, D, du, k.xh_pre, k.rs_pre, tp.edge_mol, tp.edge_off, k.qmod, 2 * D, 0, D, b.dqmod, dpre, 0);
+        const FusedDims fd{D, De, r, QK, t.ce, L};
+        FusedBlockParams fp;
+        FusedTopo ft{R, tp.edge_a, tp.edge_c, tp.edge_mol};
+        float* fpk = b.fpack + (size_t)l * b.fpack_block;
+        float *dc0 = b.tE_D[0], *du = b.tE_D[1], *dpre = b.tE_D[2], *dG = b.tE_De[0];
+        if (t.fused_bwd) {
+            fp.edge_emb_w = c.p(ix.edge_emb.w); fp.edge_emb_b = c.p(ix.edge_emb.b); fp.le0 = c.p(ix.le0); fp.le1 = c.p(ix.le1);
+            fp.ff3_w = c.p(ix.ff3.w); fp.ff3_b = c.p(ix.ff3.b); fp.ff4_w = c.p(ix.ff4.w); fp.ff4_b = c.p(ix.ff4.b);
+            fp.ero_w = c.p(ix.edge_ro.w); fp.ero_b = c.p(ix.edge_ro.b); fp.in_w = c.p(ix.eq_in.w); fp.in_b = c.p(ix.eq_in.b);
+            fp.c0_w = c.p(ix.eq_c0.w); fp.c0_b = c.p(ix.eq_c0.b); fp.c2_w = c.p(ix.eq_c2); fp.n2e_b = c.p(ix.n2e.b);
+            fp.gbf_means = c.p(ix.gbf_means); fp.gbf_stds = c.p(ix.gbf_stds);
+            fused_pack_block_bwd(s, fd, fp, fpk);
+            // chain C': tanh', coord_mlp.2^T, SiLU', coord_mlp.0^T, LayerNorm + modulate backward, input_lin[e ; G]^T — one kernel; it leaves
+            // dinv (in place), dc0, du, dpre for the weight-gradient products and the modulation sums below, adds into de and writes dG
+            fused_bwd_c(s, fd, ft, fp, fpk, k.inv, dinv, k.c0pre, k.xh_pre, k.rs_pre, k.qmod, dc0, du, dpre, de, dG);
+            c.lin_dw(dinv, 3, R, 3, k.c0a, D, D, c.g(ix.eq_c2), D);
+            c.lin_dw(dc0, D, R, D, k.u, D, D, c.g(ix.eq_c0.w), D, c.g(ix.eq_c0.b));
+            JT_LAUNCH(k_seg_part2, (long)tp.NC * D, s, tp.NC, D, tp.ec_off, (const float*)du, (const float*)k.xh_pre, b.part);
+            JT_LAUNCH(k_seg_fin2, (long)B * 2 * D, s, B, D, tp.ec_mol_off, (const float*)b.part, b.dqmod, 2 * D, 0, D);
+        } else {
+            JT_LAUNCH(k_tanh_bwd, (long)R * 3, s, (long)R * 3, (const float*)k.inv, dinv);
+            c.lin_dw(dinv, 3, R, 3, k.c0a, D, D, c.g(ix.eq_c2), D);
+            c.lin_dx(dinv, 3, R, 3, c.p(ix.eq_c2), D, D, dc0, D, 0);
+            c.silu_bwd((long)R * D, k.c0pre, dc0, dc0, nod);
+            c.lin_dw(dc0, D, R, D, k.u, D, D, c.g(ix.eq_c0.w), D, c.g(ix.eq_c0.b));
+            c.lin_dx(dc0, D, R, D, c.p(ix.eq_c0.w), D, D, du, D, 0);
+            c.ln_mod_bwd(R, D, du, k.xh_pre, k.rs_pre, tp.edge_mol, tp.edge_off, k.qmod, 2 * D, 0, D, b.dqmod, dpre, 0);
+        }
         mod_bwd(c, ix.eq_time, b.dqmod, 2 * D);
         const int ldw = 2 * D + 2 * De;
         const float* Win = c.p(ix.eq_in.w); float* dWin = c.g(ix.eq_in.w);
@@ -475,21 +497,35 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         c.lin_dw(dpre, D, R, D, k.G, De, De, dWin + 2 * D + De, ldw);
         c.lin_dx(dhr, D, Nn, D, Win, ldw, D, dh, D, 1);
         c.lin_dx(dhc, D, Nn, D, Win + D, ldw, D, dh, D, 1);
-        c.lin_dx(dpre, D, R, D, Win + 2 * D, ldw, De, de, De, 1);
-        float* dG = b.tE_De[0];
-        c.lin_dx(dpre, D, R, D, Win + 2 * D + De, ldw, De, dG, De, 0);
+        if (!t.fused_bwd) {
+            c.lin_dx(dpre, D, R, D, Win + 2 * D, ldw, De, de, De, 1);
+            c.lin_dx(dpre, D, R, D, Win + 2 * D + De, ldw, De, dG, De, 0);
+        }
         // ---- edge FFN, LayerNorm2 + modulate, gated residual (phase D)
         float *dten = b.tE_De[1], *tE = b.tE_rD;
-        JT_LAUNCH(k_drop, (long)R * De, s, (long)R * De, (const float*)k.f4, dten, c.drop(p_drop, seed, l, SITE_F4));
-        c.seg(De, tp.edge_off, de, dten, b.demod, 6 * De, 5 * De);                                   // d eg2
-        JT_LAUNCH(k_gate_bwd, (long)R * De, s, (long)R, De, (const float*)de, tp.edge_mol, (const float*)k.emod, 6 * De, 5 * De, dten, 0);
-        JT_LAUNCH(k_drop, (long)R * De, s, (long)R * De, (const float*)dten, dten, c.drop(p_drop, seed, l, SITE_F4));
-        c.lin_dw(dten, De, R, De, k.a3, r * De, r * De, c.g(ix.ff4.w), r * De, c.g(ix.ff4.b));
-        c.lin_dx(dten, De, R, De, c.p(ix.ff4.w), r * De, r * De, tE, r * De, 0);
-        c.silu_bwd((long)R * r * De, k.f3, tE, tE, c.drop(p_drop, seed, l, SITE_A3));
-        c.lin_dw(tE, r * De, R, r * De, k.en, De, De, c.g(ix.ff3.w), De, c.g(ix.ff3.b));
-        c.lin_dx(tE, r * De, R, r * De, c.p(ix.ff3.w), De, De, de, De, 1);                          // de is now d en
-        c.ln_mod_bwd(R, De, de, k.xh_en, k.rs_en, tp.edge_mol, tp.edge_off, k.emod, 6 * De, 3 * De, 4 * De, b.demod, de_prev, 0);   // de_prev = d x1e = d e[l] (residual)
+        if (t.fused_bwd) {
+            // chain B': dropout / gate backward, ff_linear4^T, SiLU' x dropout, ff_linear3^T, LayerNorm2 + modulate backward — one kernel; it leaves
+            // dropout(f4) in dten (d g2 sums), d f4 and d hidden for the weight-gradient products, d en for the modulation sums, and writes de_prev
+            float *df4 = b.tE_De2[0], *den = b.tE_De2[1];
+            fused_bwd_b(s, fd, ft, fp, fpk, de, k.f4, k.f3, k.xh_en, k.rs_en, k.emod, c.drop(p_drop, seed, l, SITE_A3), c.drop(p_drop, seed, l, SITE_F4),
+                        dten, df4, tE, den, de_prev);
+            c.seg(De, tp.edge_off, de, dten, b.demod, 6 * De, 5 * De);                               // d eg2
+            c.lin_dw(df4, De, R, De, k.a3, r * De, r * De, c.g(ix.ff4.w), r * De, c.g(ix.ff4.b));
+            c.lin_dw(tE, r * De, R, r * De, k.en, De, De, c.g(ix.ff3.w), De, c.g(ix.ff3.b));
+            JT_LAUNCH(k_seg_part2, (long)tp.NC * De, s, tp.NC, De, tp.ec_off, (const float*)den, (const float*)k.xh_en, b.part);
+            JT_LAUNCH(k_seg_fin2, (long)B * 2 * De, s, B, De, tp.ec_mol_off, (const float*)b.part, b.demod, 6 * De, 3 * De, 4 * De);
+        } else {
+            JT_LAUNCH(k_drop, (long)R * De, s, (long)R * De, (const float*)k.f4, dten, c.drop(p_drop, seed, l, SITE_F4));
+            c.seg(De, tp.edge_off, de, dten, b.demod, 6 * De, 5 * De);                                   // d eg2
+            JT_LAUNCH(k_gate_bwd, (long)R * De, s, (long)R, De, (const float*)de, tp.edge_mol, (const float*)k.emod, 6 * De, 5 * De, dten, 0);
+            JT_LAUNCH(k_drop, (long)R * De, s, (long)R * De, (const float*)dten, dten, c.drop(p_drop, seed, l, SITE_F4));
+            c.lin_dw(dten, De, R, De, k.a3, r * De, r * De, c.g(ix.ff4.w), r * De, c.g(ix.ff4.b));
+            c.lin_dx(dten, De, R, De, c.p(ix.ff4.w), r * De, r * De, tE, r * De, 0);
+            c.silu_bwd((long)R * r * De, k.f3, tE, tE, c.drop(p_drop, seed, l, SITE_A3));
+            c.lin_dw(tE, r * De, R, r * De, k.en, De, De, c.g(ix.ff3.w), De, c.g(ix.ff3.b));
+            c.lin_dx(tE, r * De, R, r * De, c.p(ix.ff3.w), De, De, de, De, 1);                          // de is now d en
+            c.ln_mod_bwd(R, De, de, k.xh_en, k.rs_en, tp.edge_mol, tp.edge_off, k.emod, 6 * De, 3 * De, 4 * De, b.demod, de_prev, 0);   // de_prev = d x1e = d e[l] (residual)
+        }
         float* ehat = dten;
         JT_LAUNCH(k_edge_bcast, (long)R * De, s, tp, De, (const float*)nullptr, (const float*)k.n2e, (const float*)k.n2e, c.p(ix.n2e.b),
                            (const float*)nullptr, 0, 0, ehat);
@@ -529,9 +565,16 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         JT_LAUNCH(k_attn_bwd_t0, (long)R * QK, s, tp, H, t.XH, t.SC, isc, (const float*)dS, (const float*)k.q, (const float*)k.k, (const float*)k.t0, dt0);
         float* det = b.tE_De[1];
         c.lin_dw(dt1, D, R, D, k.et, De, De, c.g(ix.le1), De);
-        c.lin_dx(dt1, D, R, D, c.p(ix.le1), De, De, det, De, 0);
         c.lin_dw(dt0, QK, R, QK, k.et, De, De, c.g(ix.le0), De);
-        c.lin_dx(dt0, QK, R, QK, c.p(ix.le0), De, De, det, De, 1);
+        float* de1 = t.fused_bwd ? b.tE_De2[2] : b.tE_De[1];
+        if (t.fused_bwd) {
+            // chain A': lin_edge1^T, lin_edge0^T, LayerNorm1 + modulate backward, edge_emb^T — one kernel; it leaves det for the modulation
+            // sums and de1 for the weight-gradient products, and adds into dG and de_prev
+            fused_bwd_a(s, fd, ft, fp, fpk, dt1, dt0, k.xh_e1, k.rs_e1, k.emod, det, de1, dG, de_prev);
+        } else {
+            c.lin_dx(dt1, D, R, D, c.p(ix.le1), De, De, det, De, 0);
+            c.lin_dx(dt0, QK, R, QK, c.p(ix.le0), De, De, det, De, 1);
+        }
         float* dht = b.tN_D[0];
         c.lin_dw(dv, D, Nn, D, k.ht, D, D, c.g(ix.value.w), D, c.g(ix.value.b));
         c.lin_dx(dv, D, Nn, D, c.p(ix.value.w), D, D, dht, D, 0);
@@ -540,13 +583,19 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         c.lin_dw(dk, QK, Nn, QK, k.ht, D, D, c.g(ix.key.w), D, c.g(ix.key.b));
         c.lin_dx(dk, QK, Nn, QK, c.p(ix.key.w), D, D, dht, D, 1);
         // ---- the two modulated LayerNorms at the top of the block, edge_emb([G, e])
-        float* de1 = b.tE_De[1];
-        c.ln_mod_bwd(R, De, det, k.xh_e1, k.rs_e1, tp.edge_mol, tp.edge_off, k.emod, 6 * De, 0, De, b.demod, de1, 0);      // in place: dx written after its own row was read
+        if (t.fused_bwd) {
+            JT_LAUNCH(k_seg_part2, (long)tp.NC * De, s, tp.NC, De, tp.ec_off, (const float*)det, (const float*)k.xh_e1, b.part);
+            JT_LAUNCH(k_seg_fin2, (long)B * 2 * De, s, B, De, tp.ec_mol_off, (const float*)b.part, b.demod, 6 * De, 0, De);
+        } else {
+            c.ln_mod_bwd(R, De, det, k.xh_e1, k.rs_e1, tp.edge_mol, tp.edge_off, k.emod, 6 * De, 0, De, b.demod, de1, 0);      // in place: dx written after its own row was read
+        }
         mod_bwd(c, ix.edge_time, b.demod, 6 * De);
         c.lin_dw(de1, De, R, De, k.G, De, De, c.g(ix.edge_emb.w), 2 * De, c.g(ix.edge_emb.b));
         c.lin_dw(de1, De, R, De, b.e[l], De, De, c.g(ix.edge_emb.w) + De, 2 * De);
-        c.lin_dx(de1, De, R, De, c.p(ix.edge_emb.w), 2 * De, De, dG, De, 1);
-        c.lin_dx(de1, De, R, De, c.p(ix.edge_emb.w) + De, 2 * De, De, de_prev, De, 1);
+        if (!t.fused_bwd) {
+            c.lin_dx(de1, De, R, De, c.p(ix.edge_emb.w), 2 * De, De, dG, De, 1);
+            c.lin_dx(de1, De, R, De, c.p(ix.edge_emb.w) + De, 2 * De, De, de_prev, De, 1);
+        }
         c.ln_mod_bwd(Nn, D, dht, k.xh_h, k.rs_h, tp.node_mol, tp.node_off, k.nmod, 6 * D, 0, D, b.dnmod, dh_prev, 1);
         mod_bwd(c, ix.node_time, b.dnmod, 6 * D);
         // ---- Gaussian basis and distances -> positions of the block input
@@ -704,6 +753,7 @@ int jodo_train_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes,
     {
         const FusedDims fd{t->D, t->De, t->r, t->QK, t->ce, t->L};
         t->fused = fused_available(fd) ? 1 : 0;
+        t->fused_bwd = t->fused;
     }
     Arena a{nullptr, 0}; Bufs bufs;
     layout(*t, a, bufs);
@@ -716,12 +766,13 @@ void jodo_train_destroy(jodo_train* t) { delete t; }
 size_t jodo_train_desc_bytes(const jodo_train* t) { return t ? t->tables.size() * sizeof(int) : 0; }
 size_t jodo_train_workspace_bytes(const jodo_train* t) { return t ? t->ws_bytes : 0; }
 // option 0: fused per-edge forward chains (train_fused.hip): 1 (default where the width is supported) / 0 (op-by-op, the reference form)
+// option 1: the same for the input-gradient side of the backward
 int jodo_train_set_option(jodo_train* t, int option, int value) {
     if (!t) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: null handle");
-    if (option != 0 || (value != 0 && value != 1)) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: option %d value %d", option, value);
+    if ((option != 0 && option != 1) || (value != 0 && value != 1)) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: option %d value %d", option, value);
     const FusedDims fd{t->D, t->De, t->r, t->QK, t->ce, t->L};
     if (value && !fused_available(fd)) return jodo_set_error(JODO_ERR_UNSUPPORTED, "jodo_train_set_option: fused chains are not built for this shape");
-    t->fused = value;
+    if (option == 0) t->fused = value; else t->fused_bwd = value;
     return JODO_OK;
 }
 // tests: where a kept activation lives in the workspace.  what 0 = hhat (attention output [Nn, D]), 1 = alpha (softmax weights

@@ -22,7 +22,8 @@ namespace jt {
 struct FusedDims { int D, De, r, QK, ce, L; };
 
 // floats of packed operands per block; offsets (floats) of the pieces inside a block's slice
-struct FusedPackLayout { size_t ee, l0, l1, ff3, ff4, ero, in_eg, c0, tab, total; };
+struct FusedPackLayout { size_t ee, l0, l1, ff3, ff4, ero, in_eg, c0, tab, total;                      // forward images
+                         size_t c0t, int_eg, ff4t, ff3t, l1t, l0t, eet, total_bwd; };   // transposed images of the backward chains (after `total`)
 FusedPackLayout fused_pack_layout(const FusedDims& d);
 
 bool fused_available(const FusedDims& d);
@@ -35,6 +36,8 @@ struct FusedBlockParams {       // device pointers of one block's parameters (Py
 struct FusedTopo { int R; const int *edge_a, *edge_c, *edge_mol; };
 
 void fused_pack_block(hipStream_t s, const FusedDims& d, const FusedBlockParams& p, float* packed);
+// transposed operand images for the backward chains (dX = W^T dY on the same MFMA orientation), into packed + layout offsets *t
+void fused_pack_block_bwd(hipStream_t s, const FusedDims& d, const FusedBlockParams& p, float* packed);
 
 // chain A.  pos [Nn, 3]; gm [B, 2] (scale, shift); e_in [R, De]; emod [B, 6 De] (shift at 0, scale at De)
 void fused_chain_a(hipStream_t s, const FusedDims& d, const FusedTopo& t, const FusedBlockParams& p, const float* packed, const float* pos, const float* gm,
@@ -46,5 +49,22 @@ void fused_chain_b(hipStream_t s, const FusedDims& d, const FusedTopo& t, const 
 // chain C.  hr / hc [Nn, D] = W_row h, W_col h; qmod [B, 2 D] (shift at 0, scale at D)
 void fused_chain_c(hipStream_t s, const FusedDims& d, const FusedTopo& t, const FusedBlockParams& p, const float* packed, const float* e_in, const float* G,
                    const float* hr, const float* hc, const float* qmod, float* xh_pre, float* rs_pre, float* u, float* c0pre, float* c0a, float* inv);
+
+
+// ---- backward: the input-gradient side of the same three chains (round 5).  Each kernel walks one chain backwards for 32 edge rows per
+// wave and stores exactly the arrays the remaining launches read: the dY operands of the weight-gradient products (which stay GEMMs: their
+// contraction index is the row) and of the per-molecule modulation sums.
+// chain C':  dinv (in place: x (1 - inv^2)) -> d coord_mlp.0 output dc0 [R, D] -> du = W0^T dc0 [R, D] -> LayerNorm + modulate backward ->
+//            dpre [R, D] -> de += W_e^T dpre, dG = W_g^T dpre
+void fused_bwd_c(hipStream_t s, const FusedDims& d, const FusedTopo& t, const FusedBlockParams& p, const float* packed, const float* inv, float* dinv,
+                 const float* c0pre, const float* xh_pre, const float* rs_pre, const float* qmod, float* dc0, float* du, float* dpre, float* de, float* dG);
+// chain B':  de_out -> f4d = dropout(f4) (for d g2), df4 = g2 de_out mask -> dhid = (W4^T df4) mask3 SiLU'(f3) [R, r De] -> den = de_out + W3^T dhid
+//            -> LayerNorm2 + modulate backward -> de_prev (written)
+void fused_bwd_b(hipStream_t s, const FusedDims& d, const FusedTopo& t, const FusedBlockParams& p, const float* packed, const float* de_out, const float* f4,
+                 const float* f3, const float* xh_en, const float* rs_en, const float* emod, Drop drop_a3, Drop drop_f4, float* f4d, float* df4, float* dhid,
+                 float* den, float* de_prev);
+// chain A':  det = lin_edge1^T dt1 + lin_edge0^T dt0 [R, De] -> LayerNorm1 + modulate backward -> de1 -> dG += W_G^T de1, de_prev += W_e^T de1
+void fused_bwd_a(hipStream_t s, const FusedDims& d, const FusedTopo& t, const FusedBlockParams& p, const float* packed, const float* dt1, const float* dt0,
+                 const float* xh_e1, const float* rs_e1, const float* emod, float* det, float* de1, float* dG, float* de_prev);
 
 }  // namespace jt

@@ -54,6 +54,7 @@ struct Common {
     const int *ea, *ec, *em;
     const float* packed;               // this block's packed operands
     unsigned oEE, oL0, oL1, oF3, oF4, oRO, oIN, oC0;      // byte offsets inside `packed`
+    unsigned oC0T, oINT, oF4T, oF3T, oL1T, oL0T, oEET;    // transposed images (backward chains)
     const float* tab;                  // Gaussian table [3][De]
 };
 
@@ -293,9 +294,256 @@ __global__ __launch_bounds__(64, JODO_X_CHAINC_OCC) void k_chain_c(ArgsC A) {
     if (valid && half == 0) { A.inv[r * 3] = c0; A.inv[r * 3 + 1] = c1; A.inv[r * 3 + 2] = c2; }
 }
 
+// d/dx x sigmoid(x) = s (1 + x (1 - s)), element pairs on the packed pipe
+__device__ __forceinline__ f32x2 dsilu_f2(f32x2 x) {
+    const f32x2 t = x * -1.4426950408889634f;
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+    e = e + 1.f;
+    f32x2 sg;
+    sg.x = fast_rcp(e.x); sg.y = fast_rcp(e.y);
+    return sg * __builtin_elementwise_fma(x, (f32x2)(1.f) - sg, (f32x2)(1.f));
+}
+
+// LayerNorm + modulate backward of one row held in registers: g = dy (1 + sc); dx = rstd (g - mean(g) - xhat mean(g xhat)).
+// dy in / dx out in `v`; xh: the saved normalised row; sc: this lane's modulation scale row (natural order)
+template <int NB, bool KEEP = true>       // KEEP: the saved row stays in registers between the two passes (short rows); otherwise it is read twice
+__device__ __forceinline__ void ln_mod_bwd_regs(float (&v)[NB * 16], const float* __restrict__ xh_row, const float* __restrict__ sc, float rstd, int half) {
+    float c1 = 0.f, c2 = 0.f;
+    float xh[KEEP ? NB * 16 : 1];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float g[16], x[16];
+        load16(sc + b * 32 + half * 16, g);
+        load16(xh_row + b * 32 + half * 16, x);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float gv = v[b * 16 + s] * (1.f + g[s]);
+            v[b * 16 + s] = gv;
+            if constexpr (KEEP) xh[b * 16 + s] = x[s];
+            c1 += gv; c2 = fmaf(gv, x[s], c2);
+        }
+    }
+    c1 = pair_sum(c1) * (1.f / (NB * 32)); c2 = pair_sum(c2) * (1.f / (NB * 32));
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int i = 0; i < NB * 16; ++i) v[i] = rstd * (v[i] - c1 - xh[i] * c2);
+    } else {
+        pipeline_fence();
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float x[16];
+            load16(xh_row + b * 32 + half * 16, x);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) v[b * 16 + s] = rstd * (v[b * 16 + s] - c1 - x[s] * c2);
+        }
+    }
+}
+
+struct ArgsBC {
+    Common c;
+    const float *inv, *c0pre, *xh, *rs, *qmod, *w2;
+    float *dinv, *dc0, *du, *dpre, *de, *dG;
+};
+
+template <int D>
+__global__ __launch_bounds__(64, 1) void k_bwd_c(ArgsBC A) {
+    using X = FD<D>;
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const long r = (long)blockIdx.x * 32 + j;
+    const bool valid = r < A.c.R;
+    const long rc = valid ? r : (long)A.c.R - 1;
+    const int mol = A.c.em[rc];
+    float d0, d1, d2;
+    {
+        const float i0 = A.inv[rc * 3], i1 = A.inv[rc * 3 + 1], i2 = A.inv[rc * 3 + 2];
+        d0 = A.dinv[rc * 3] * (1.f - i0 * i0); d1 = A.dinv[rc * 3 + 1] * (1.f - i1 * i1); d2 = A.dinv[rc * 3 + 2] * (1.f - i2 * i2);
+    }
+    const WSrc ws = make_wsrc(A.c.packed, lane);
+    WPipe<X::PG> wp;
+    wpipe_prime(wp, ws, A.c.oC0T);
+    float v[X::HD];
+#pragma unroll
+    for (int b = 0; b < X::ND; ++b) {                                 // dc0 = (W2^T dinv') SiLU'(c0pre)
+        const int f0 = b * 32 + half * 16;
+        float k0[16], k1[16], k2[16], pre[16], o[16];
+        load16(A.w2 + f0, k0); load16(A.w2 + D + f0, k1); load16(A.w2 + 2 * D + f0, k2);
+        load16(A.c0pre + rc * D + f0, pre);
+#pragma unroll
+        for (int s = 0; s < 16; s += 2) {
+            const f32x2 da = pk2(fmaf(d0, k0[s], fmaf(d1, k1[s], d2 * k2[s])), fmaf(d0, k0[s + 1], fmaf(d1, k1[s + 1], d2 * k2[s + 1])));
+            const f32x2 g = da * dsilu_f2(pk2(pre[s], pre[s + 1]));
+            o[s] = g.x; o[s + 1] = g.y; v[b * 16 + s] = g.x; v[b * 16 + s + 1] = g.y;
+        }
+        if (valid) store16(A.dc0 + r * D + f0, o);
+    }
+    __syncthreads();                                                  // (one wave: orders the in-place dinv update behind every lane's read)
+    if (valid && half == 0) { A.dinv[r * 3] = d0; A.dinv[r * 3 + 1] = d1; A.dinv[r * 3 + 2] = d2; }
+    float u[X::HD];
+#pragma unroll
+    for (int b = 0; b < X::ND; ++b) {                                 // du = W0^T dc0
+        const unsigned cur = A.c.oC0T + (unsigned)(b * X::KQD) * 1024;
+        f32x16 acc = mfma_block_p<X::KQD>(wp, ws, cur, b + 1 < X::ND ? cur + X::KQD * 1024 : A.c.oINT, v, zero16());
+        float o[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { o[s] = acc[s]; u[b * 16 + s] = acc[s]; }
+        if (valid) store16(A.du + r * D + b * 32 + half * 16, o);
+    }
+    ln_mod_bwd_regs<X::ND, (D <= 256)>(u, A.xh + rc * D, A.qmod + (long)mol * 2 * D + D, A.rs[rc], half);
+    if (valid) store_nat<X::ND>(A.dpre + r * D, half, u);
+#pragma unroll
+    for (int b = 0; b < 2 * X::NE; ++b) {                             // de += W_e^T dpre, dG = W_g^T dpre
+        const unsigned cur = A.c.oINT + (unsigned)(b * X::KQD) * 1024;
+        f32x16 acc = mfma_block_p<X::KQD>(wp, ws, cur, b + 1 < 2 * X::NE ? cur + X::KQD * 1024 : A.c.oINT, u, zero16());
+        float o[16];
+        if (b < X::NE) {
+            float* dst = A.de + rc * X::De + b * 32 + half * 16;
+            load16(dst, o);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) o[s] += acc[s];
+            if (valid) store16(dst, o);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) o[s] = acc[s];
+            if (valid) store16(A.dG + r * X::De + (b - X::NE) * 32 + half * 16, o);
+        }
+    }
+}
+
+struct ArgsBB {
+    Common c;
+    const float *de_out, *f4, *f3, *xh, *rs, *emod;
+    jt::Drop d3, d4;
+    float *f4d, *df4, *dhid, *den, *de_prev;
+};
+
+template <int D, int RR>
+__global__ __launch_bounds__(64, 1) void k_bwd_b(ArgsBB A) {
+    using X = FD<D>;
+    constexpr int HID = RR * X::De, NHB = HID / 32, KQ4 = HID / 8;
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const long r = (long)blockIdx.x * 32 + j;
+    const bool valid = r < A.c.R;
+    const long rc = valid ? r : (long)A.c.R - 1;
+    const int mol = A.c.em[rc];
+    const float* mr = A.emod + (long)mol * 6 * X::De;
+    const WSrc ws = make_wsrc(A.c.packed, lane);
+    WPipe<X::PG> wp;
+    wpipe_prime(wp, ws, A.c.oF4T);
+    float dout[X::HE], df4[X::HE];
+#pragma unroll
+    for (int b = 0; b < X::NE; ++b) {                                 // f4d = dropout(f4) (d g2 sums), df4 = g2 de_out mask
+        const int f0 = b * 32 + half * 16;
+        float de[16], f4[16], g[16], m[16], o1[16], o2[16];
+        load16(A.de_out + rc * X::De + f0, de);
+        load16(A.f4 + rc * X::De + f0, f4);
+        load16(mr + 5 * X::De + f0, g);
+        drop16(A.d4, (unsigned long long)rc * X::De + f0, m);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            o1[s] = f4[s] * m[s];
+            o2[s] = g[s] * de[s] * m[s];
+            dout[b * 16 + s] = de[s]; df4[b * 16 + s] = o2[s];
+        }
+        if (valid) { store16(A.f4d + r * X::De + f0, o1); store16(A.df4 + r * X::De + f0, o2); }
+    }
+    float dh[HID / 2];
+#pragma unroll
+    for (int hb = 0; hb < NHB; ++hb) {                                // dhid = (W4^T df4) mask3 SiLU'(f3)
+        const int f0 = hb * 32 + half * 16;
+        const unsigned cur = A.c.oF4T + (unsigned)(hb * X::KQE) * 1024;
+        float pre[16], m[16], o[16];
+        load16(A.f3 + rc * HID + f0, pre);
+        f32x16 acc = mfma_block_p<X::KQE>(wp, ws, cur, hb + 1 < NHB ? cur + X::KQE * 1024 : A.c.oF3T, df4, zero16());
+        drop16(A.d3, (unsigned long long)rc * HID + f0, m);
+#pragma unroll
+        for (int s = 0; s < 16; s += 2) {
+            const f32x2 g = pk2(acc[s], acc[s + 1]) * pk2(m[s], m[s + 1]) * dsilu_f2(pk2(pre[s], pre[s + 1]));
+            o[s] = g.x; o[s + 1] = g.y; dh[hb * 16 + s] = g.x; dh[hb * 16 + s + 1] = g.y;
+        }
+        if (valid) store16(A.dhid + r * HID + f0, o);
+    }
+#pragma unroll
+    for (int b = 0; b < X::NE; ++b) {                                 // den = de_out + W3^T dhid
+        const unsigned cur = A.c.oF3T + (unsigned)(b * KQ4) * 1024;
+        f32x16 acc = mfma_block_p<KQ4>(wp, ws, cur, b + 1 < X::NE ? cur + KQ4 * 1024 : A.c.oF3T, dh, zero16());
+        float o[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { dout[b * 16 + s] += acc[s]; o[s] = dout[b * 16 + s]; }
+        if (valid) store16(A.den + r * X::De + b * 32 + half * 16, o);
+    }
+    ln_mod_bwd_regs<X::NE>(dout, A.xh + rc * X::De, mr + 4 * X::De, A.rs[rc], half);
+    if (valid) store_nat<X::NE>(A.de_prev + r * X::De, half, dout);
+}
+
+struct ArgsBA {
+    Common c;
+    const float *dt1, *dt0, *xh, *rs, *emod;
+    float *det, *de1, *dG, *de_prev;
+    int QK;
+};
+
+template <int D>
+__global__ __launch_bounds__(64, 1) void k_bwd_a(ArgsBA A) {
+    using X = FD<D>;
+    const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    const long r = (long)blockIdx.x * 32 + j;
+    const bool valid = r < A.c.R;
+    const long rc = valid ? r : (long)A.c.R - 1;
+    const int mol = A.c.em[rc];
+    const float* mr = A.emod + (long)mol * 6 * X::De;
+    const WSrc ws = make_wsrc(A.c.packed, lane);
+    WPipe<X::PG> wp;
+    wpipe_prime(wp, ws, A.c.oL1T);
+    float x[X::HD];
+    load_nat<X::ND>(A.dt1 + rc * D, half, x);
+    f32x16 acc[X::NE];
+#pragma unroll
+    for (int b = 0; b < X::NE; ++b) {                                 // det = lin_edge1^T dt1 ...
+        const unsigned cur = A.c.oL1T + (unsigned)(b * X::KQD) * 1024;
+        acc[b] = mfma_block_p<X::KQD>(wp, ws, cur, b + 1 < X::NE ? cur + X::KQD * 1024 : A.c.oL0T, x, zero16());
+    }
+    {
+        const float* row = A.dt0 + rc * A.QK;                         // rows of QK floats: 8-byte aligned, the tail of the last block is zero
+#pragma unroll
+        for (int b = 0; b < X::ND; ++b)
+#pragma unroll
+            for (int s = 0; s < 16; s += 2) {
+                const int f = b * 32 + half * 16 + s;
+                float2 t = make_float2(0.f, 0.f);
+                if (f < A.QK) t = *reinterpret_cast<const float2*>(row + f);
+                x[b * 16 + s] = t.x; x[b * 16 + s + 1] = t.y;
+            }
+    }
+    float v[X::HE];
+#pragma unroll
+    for (int b = 0; b < X::NE; ++b) {                                 // ... + lin_edge0^T dt0
+        const unsigned cur = A.c.oL0T + (unsigned)(b * X::KQD) * 1024;
+        acc[b] = mfma_block_p<X::KQD>(wp, ws, cur, b + 1 < X::NE ? cur + X::KQD * 1024 : A.c.oEET, x, acc[b]);
+        float o[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { o[s] = acc[b][s]; v[b * 16 + s] = acc[b][s]; }
+        if (valid) store16(A.det + r * X::De + b * 32 + half * 16, o);
+    }
+    ln_mod_bwd_regs<X::NE>(v, A.xh + rc * X::De, mr + X::De, A.rs[rc], half);
+    if (valid) store_nat<X::NE>(A.de1 + r * X::De, half, v);
+#pragma unroll
+    for (int b = 0; b < 2 * X::NE; ++b) {                             // dG += W_G^T de1, de_prev += W_e^T de1
+        const unsigned cur = A.c.oEET + (unsigned)(b * X::KQE) * 1024;
+        f32x16 a2 = mfma_block_p<X::KQE>(wp, ws, cur, b + 1 < 2 * X::NE ? cur + X::KQE * 1024 : A.c.oEET, v, zero16());
+        float* dst = (b < X::NE ? A.dG + rc * X::De + b * 32 : A.de_prev + rc * X::De + (b - X::NE) * 32) + half * 16;
+        float o[16];
+        load16(dst, o);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) o[s] += a2[s];
+        if (valid) store16(dst, o);
+    }
+}
+
 // ---- operand packing: PyTorch [out, in] (row stride ld, first column col0) -> [out block][quad][lane] float4 in the natural maps
 // of dgt_pack.cpp (register R of half h = feature (R / 16) 32 + 16 h + R % 16 on both sides); rows >= n_out are zero
-struct PackItem { const float* w; int ld, col0, n_out, nb, kq; unsigned dst; };      // dst in floats, nb output blocks, kq quads per block
+struct PackItem { const float* w; int ld, col0, n_out, nb, kq; unsigned dst; int trans, n_in; };   // dst in floats, nb output blocks, kq quads per block;
+                                                                                                  // trans: element (row, col) = w[col * ld + col0 + row] (W^T), cols >= n_in are zero
 struct PackArgs { PackItem it[8]; int first[9]; float* out; const float *means, *stds; int De; unsigned tab; };
 
 __global__ __launch_bounds__(64) void k_pack(PackArgs P) {
@@ -322,7 +570,7 @@ __global__ __launch_bounds__(64) void k_pack(PackArgs P) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int R = kq * 4 + c, col = (R / 16) * 32 + kh * 16 + (R % 16);
-        v[c] = row < it.n_out ? it.w[(long)row * it.ld + it.col0 + col] : 0.f;
+        v[c] = (row < it.n_out && col < it.n_in) ? (it.trans ? it.w[(long)col * it.ld + it.col0 + row] : it.w[(long)row * it.ld + it.col0 + col]) : 0.f;
     }
     reinterpret_cast<float4*>(P.out + it.dst)[(long)loc * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
 }
@@ -333,6 +581,8 @@ Common common_of(const jt::FusedDims& d, const jt::FusedTopo& t, const float* pa
     c.R = t.R; c.ea = t.edge_a; c.ec = t.edge_c; c.em = t.edge_mol; c.packed = packed;
     c.oEE = (unsigned)(L.ee * 4); c.oL0 = (unsigned)(L.l0 * 4); c.oL1 = (unsigned)(L.l1 * 4); c.oF3 = (unsigned)(L.ff3 * 4);
     c.oF4 = (unsigned)(L.ff4 * 4); c.oRO = (unsigned)(L.ero * 4); c.oIN = (unsigned)(L.in_eg * 4); c.oC0 = (unsigned)(L.c0 * 4);
+    c.oC0T = (unsigned)(L.c0t * 4); c.oINT = (unsigned)(L.int_eg * 4); c.oF4T = (unsigned)(L.ff4t * 4); c.oF3T = (unsigned)(L.ff3t * 4);
+    c.oL1T = (unsigned)(L.l1t * 4); c.oL0T = (unsigned)(L.l0t * 4); c.oEET = (unsigned)(L.eet * 4);
     c.tab = packed + L.tab;
     return c;
 }
@@ -355,6 +605,15 @@ FusedPackLayout fused_pack_layout(const FusedDims& d) {
     L.c0 = o; o += D * D;
     L.tab = o; o += 3 * De;
     L.total = (o + 63) / 64 * 64;
+    o = L.total;
+    L.c0t = o; o += D * D;                       // out D (inputs of coord_mlp.0), K = D
+    L.int_eg = o; o += 2 * De * D;               // out 2 De ([e ; G] columns of input_lin), K = D
+    L.ff4t = o; o += (size_t)d.r * De * De;      // out r De, K = De
+    L.ff3t = o; o += De * d.r * De;              // out De, K = r De
+    L.l1t = o; o += De * D;                      // out De, K = D
+    L.l0t = o; o += De * D;                      // out De, K = D (lin_edge0 has QK <= D rows: the rest of K is zero)
+    L.eet = o; o += 2 * De * De;                 // out 2 De ([G ; e] columns of edge_emb), K = De
+    L.total_bwd = (o + 63) / 64 * 64;
     return L;
 }
 
@@ -368,7 +627,7 @@ void fused_pack_block(hipStream_t s, const FusedDims& d, const FusedBlockParams&
     const int De = d.De, D = d.D;
     PackArgs P;
     auto item = [](const float* w, int ld, int col0, int n_out, int K, size_t dst) {
-        PackItem it; it.w = w; it.ld = ld; it.col0 = col0; it.n_out = n_out; it.nb = (n_out + 31) / 32; it.kq = K / 8; it.dst = (unsigned)dst; return it;
+        PackItem it; it.w = w; it.ld = ld; it.col0 = col0; it.n_out = n_out; it.nb = (n_out + 31) / 32; it.kq = K / 8; it.dst = (unsigned)dst; it.trans = 0; it.n_in = K; return it;
     };
     P.it[0] = item(p.edge_emb_w, 2 * De, 0, De, 2 * De, L.ee);
     P.it[1] = item(p.le0, De, 0, d.QK, De, L.l0);
@@ -422,6 +681,67 @@ void fused_chain_c(hipStream_t s, const FusedDims& d, const FusedTopo& t, const 
     if (d.D == 128) hipLaunchKernelGGL(k_chain_c<128>, grid, dim3(64), 0, s, A);
     else if (d.D == 256) hipLaunchKernelGGL(k_chain_c<256>, grid, dim3(64), 0, s, A);
     else hipLaunchKernelGGL(k_chain_c<384>, grid, dim3(64), 0, s, A);
+}
+
+void fused_pack_block_bwd(hipStream_t s, const FusedDims& d, const FusedBlockParams& p, float* packed) {
+    const FusedPackLayout L = fused_pack_layout(d);
+    const int De = d.De, D = d.D;
+    PackArgs P;
+    auto item = [](const float* w, int ld, int col0, int n_out, int K, int n_in, size_t dst) {
+        PackItem it; it.w = w; it.ld = ld; it.col0 = col0; it.n_out = n_out; it.nb = (n_out + 31) / 32; it.kq = K / 8; it.dst = (unsigned)dst; it.trans = 1; it.n_in = n_in; return it;
+    };
+    P.it[0] = item(p.c0_w, D, 0, D, D, D, L.c0t);
+    P.it[1] = item(p.in_w, 2 * D + 2 * De, 2 * D, 2 * De, D, D, L.int_eg);
+    P.it[2] = item(p.ff4_w, d.r * De, 0, d.r * De, De, De, L.ff4t);
+    P.it[3] = item(p.ff3_w, De, 0, De, d.r * De, d.r * De, L.ff3t);
+    P.it[4] = item(p.le1, De, 0, De, D, D, L.l1t);
+    P.it[5] = item(p.le0, De, 0, De, D, d.QK, L.l0t);
+    P.it[6] = item(p.edge_emb_w, 2 * De, 0, 2 * De, De, De, L.eet);
+    P.it[7] = P.it[6]; P.it[7].nb = 0;
+    P.first[0] = 0;
+    for (int i = 0; i < 8; ++i) P.first[i + 1] = P.first[i] + P.it[i].nb * P.it[i].kq;
+    P.out = packed; P.means = nullptr; P.stds = nullptr; P.De = 0; P.tab = 0;
+    hipLaunchKernelGGL(k_pack, dim3(P.first[8]), dim3(64), 0, s, P);
+}
+
+void fused_bwd_c(hipStream_t s, const FusedDims& d, const FusedTopo& t, const FusedBlockParams& p, const float* packed, const float* inv, float* dinv,
+                 const float* c0pre, const float* xh_pre, const float* rs_pre, const float* qmod, float* dc0, float* du, float* dpre, float* de, float* dG) {
+    ArgsBC A;
+    A.c = common_of(d, t, packed);
+    A.inv = inv; A.c0pre = c0pre; A.xh = xh_pre; A.rs = rs_pre; A.qmod = qmod; A.w2 = p.c2_w;
+    A.dinv = dinv; A.dc0 = dc0; A.du = du; A.dpre = dpre; A.de = de; A.dG = dG;
+    const dim3 grid((unsigned)((t.R + 31) / 32));
+    if (d.D == 128) hipLaunchKernelGGL(k_bwd_c<128>, grid, dim3(64), 0, s, A);
+    else if (d.D == 256) hipLaunchKernelGGL(k_bwd_c<256>, grid, dim3(64), 0, s, A);
+    else hipLaunchKernelGGL(k_bwd_c<384>, grid, dim3(64), 0, s, A);
+}
+
+void fused_bwd_b(hipStream_t s, const FusedDims& d, const FusedTopo& t, const FusedBlockParams& p, const float* packed, const float* de_out, const float* f4,
+                 const float* f3, const float* xh_en, const float* rs_en, const float* emod, Drop drop_a3, Drop drop_f4, float* f4d, float* df4, float* dhid,
+                 float* den, float* de_prev) {
+    (void)p;
+    ArgsBB A;
+    A.c = common_of(d, t, packed);
+    A.de_out = de_out; A.f4 = f4; A.f3 = f3; A.xh = xh_en; A.rs = rs_en; A.emod = emod; A.d3 = drop_a3; A.d4 = drop_f4;
+    A.f4d = f4d; A.df4 = df4; A.dhid = dhid; A.den = den; A.de_prev = de_prev;
+    const dim3 grid((unsigned)((t.R + 31) / 32));
+#define JT_B(DD, RR) hipLaunchKernelGGL((k_bwd_b<DD, RR>), grid, dim3(64), 0, s, A)
+    if (d.D == 128) { if (d.r == 2) JT_B(128, 2); else JT_B(128, 4); }
+    else if (d.D == 256) { if (d.r == 2) JT_B(256, 2); else JT_B(256, 4); }
+    else { if (d.r == 2) JT_B(384, 2); else JT_B(384, 4); }
+#undef JT_B
+}
+
+void fused_bwd_a(hipStream_t s, const FusedDims& d, const FusedTopo& t, const FusedBlockParams& p, const float* packed, const float* dt1, const float* dt0,
+                 const float* xh_e1, const float* rs_e1, const float* emod, float* det, float* de1, float* dG, float* de_prev) {
+    (void)p;
+    ArgsBA A;
+    A.c = common_of(d, t, packed);
+    A.dt1 = dt1; A.dt0 = dt0; A.xh = xh_e1; A.rs = rs_e1; A.emod = emod; A.det = det; A.de1 = de1; A.dG = dG; A.de_prev = de_prev; A.QK = d.QK;
+    const dim3 grid((unsigned)((t.R + 31) / 32));
+    if (d.D == 128) hipLaunchKernelGGL(k_bwd_a<128>, grid, dim3(64), 0, s, A);
+    else if (d.D == 256) hipLaunchKernelGGL(k_bwd_a<256>, grid, dim3(64), 0, s, A);
+    else hipLaunchKernelGGL(k_bwd_a<384>, grid, dim3(64), 0, s, A);
 }
 
 }  // namespace jt

@@ -70,7 +70,7 @@ void gemm(hipStream_t, int tA, int tB, int M, int N, int K, const float* A, int 
 // runs — and thereby checks — the op-by-op sequence they replace.
 #include "train_fused.h"
 namespace jt {
-FusedPackLayout fused_pack_layout(const FusedDims&) { return FusedPackLayout{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+FusedPackLayout fused_pack_layout(const FusedDims&) { return FusedPackLayout{}; }
 bool fused_available(const FusedDims&) { return false; }
 void fused_pack_block(hipStream_t, const FusedDims&, const FusedBlockParams&, float*) {}
 void fused_chain_a(hipStream_t, const FusedDims&, const FusedTopo&, const FusedBlockParams&, const float*, const float*, const float*, const float*,
@@ -79,4 +79,13 @@ void fused_chain_b(hipStream_t, const FusedDims&, const FusedTopo&, const FusedB
                    Drop, float*, float*, float*, float*, float*, float*, float*, float*, int, int) {}
 void fused_chain_c(hipStream_t, const FusedDims&, const FusedTopo&, const FusedBlockParams&, const float*, const float*, const float*, const float*,
                    const float*, const float*, float*, float*, float*, float*, float*, float*) {}
+}
+namespace jt {
+void fused_pack_block_bwd(hipStream_t, const FusedDims&, const FusedBlockParams&, float*) {}
+void fused_bwd_c(hipStream_t, const FusedDims&, const FusedTopo&, const FusedBlockParams&, const float*, const float*, float*, const float*, const float*,
+                 const float*, const float*, float*, float*, float*, float*, float*) {}
+void fused_bwd_b(hipStream_t, const FusedDims&, const FusedTopo&, const FusedBlockParams&, const float*, const float*, const float*, const float*, const float*,
+                 const float*, const float*, Drop, Drop, float*, float*, float*, float*, float*) {}
+void fused_bwd_a(hipStream_t, const FusedDims&, const FusedTopo&, const FusedBlockParams&, const float*, const float*, const float*, const float*, const float*,
+                 const float*, float*, float*, float*, float*) {}
 }

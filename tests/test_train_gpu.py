@@ -327,31 +327,35 @@ def test_fused_forward_chains_equal_the_op_by_op_forward(cfg_name, n_nodes, over
     model.train()
     assert model.dropout_p > 0
     res = {}
-    for fused in (1, 0):
-        model.train_options = {0: fused}
+    for fused in ((1, 1), (1, 0), (0, 0)):                             # (forward chains, backward chains): fused / fused forward only / op by op
+        model.train_options = {0: fused[0], 1: fused[1]}
         model.zero_grad()
         torch.manual_seed(77)                                          # the dropout seed is drawn from torch's generator
         ox, oe = model(d(nl), d(xh), d(nm), d(em), d(ctx), edge_x=d(ex), cond_x=d(cx), cond_edge_x=d(cex), noise_level=d(nl))
         ((ox * d(d_x)).sum() + (oe * d(d_e)).sum()).backward()
         res[fused] = (ox.detach().cpu(), oe.detach().cpu(), [p.grad.detach().cpu().clone() for p in model.parameters()])
-    assert len(model._train_engines) == 2                              # two handles: one per option set
-    close(res[1][0], res[0][0], atol=2e-5)
-    close(res[1][1], res[0][1], atol=2e-5)
-    assert not torch.equal(res[1][0], res[0][0])                       # (different arithmetic: not the same code twice)
-    bad = []
-    for (name, _), a, b in zip(model.named_parameters(), res[1][2], res[0][2]):
-        scale = float(b.abs().max())
-        err = float((a - b).abs().max())
-        # (the Gaussian-layer and time-path gradients amplify forward rounding ~1e4 x, DESIGN.md 9a: measured 3.3e-4 on one dist_layer.stds)
-        tol = 1e-3 if ('dist_layer' in name or 'time_mlp' in name) else 2e-4
-        if not err <= tol * max(scale, 1e-12) + 1e-9:
-            bad.append("%s: %.3e of %.3e" % (name, err, scale))
-    assert not bad, "fused vs op-by-op gradients differ:\n  " + "\n  ".join(bad[:30])
+    assert len(model._train_engines) == 3                              # one handle per option set
+    ref = res[(0, 0)]
+    close(res[(1, 1)][0], ref[0], atol=2e-5)
+    close(res[(1, 1)][1], ref[1], atol=2e-5)
+    assert not torch.equal(res[(1, 1)][0], ref[0])                     # (different arithmetic: not the same code twice)
+    assert torch.equal(res[(1, 1)][0], res[(1, 0)][0])                 # the backward option does not touch the forward
+    for key in ((1, 1), (1, 0)):
+        bad = []
+        for (name, _), a, b in zip(model.named_parameters(), res[key][2], ref[2]):
+            scale = float(b.abs().max())
+            err = float((a - b).abs().max())
+            # (the Gaussian-layer and time-path gradients amplify forward rounding ~1e4 x, DESIGN.md 9a: measured 3.3e-4 on one dist_layer.stds)
+            tol = 1e-3 if ('dist_layer' in name or 'time_mlp' in name) else 2e-4
+            if not err <= tol * max(scale, 1e-12) + 1e-9:
+                bad.append("%s: %.3e of %.3e" % (name, err, scale))
+        assert not bad, "fused %s vs op-by-op gradients differ:\n  " % (key,) + "\n  ".join(bad[:30])
+    assert any(not torch.equal(a, b) for a, b in zip(res[(1, 1)][2], res[(1, 0)][2]))       # the fused backward really ran
     # eval mode, no dropout: both against the inference kernels (a third implementation)
     model.eval()
     with torch.no_grad():
         ix, ie = model(d(nl), d(xh), d(nm), d(em), d(ctx), edge_x=d(ex), cond_x=d(cx), cond_edge_x=d(cex), noise_level=d(nl))
-    model.train_options = {0: 1}
+    model.train_options = {0: 1, 1: 1}
     ox, oe = model(d(nl), d(xh), d(nm), d(em), d(ctx), edge_x=d(ex), cond_x=d(cx), cond_edge_x=d(cex), noise_level=d(nl))
     close(ox.detach(), ix, atol=2e-5)
     close(oe.detach(), ie, atol=2e-5)
