@@ -59,6 +59,7 @@ struct Bufs {
     float *dtau, *dtemb, *dnmod, *demod, *dqmod, *dgm, *tB_T[2], *tB_cD[2], *part, *part2, *rowpart, *splitk;
     float* fpack;                     // packed MFMA operands of the fused chains (forward + transposed images), one slice per block (train_fused.h)
     float* tE_De2[3];                 // scratch of the fused backward chains: df4 | den | de1
+    float *Wall, *ball, *mods_all, *dmods_all, *dWall, *dball;      // batched modulation projections (train_ops.h ModTable)
     size_t fpack_block;
     size_t splitk_floats, part_floats, part2_floats;
 };
@@ -81,6 +82,7 @@ struct jodo_train {
     size_t ws_bytes;
     int fused;                        // 1: the three per-edge chains of a block run as fused strip kernels (train_fused.hip)
     int fused_bwd;                    // 1: their input-gradient sides too (the weight-gradient products stay GEMMs)
+    int Mtot;                         // modulation floats per molecule: 2 (top-level GBF) + L (6 D + 6 De + 2 D + 2)
 };
 
 namespace {
@@ -136,6 +138,8 @@ void layout(const jodo_train& t, Arena& a, Bufs& b) {
     b.fpack_block = fused_pack_layout(fd).total_bwd;
     b.fpack = a.f(b.fpack_block * L);
     for (int s = 0; s < 3; ++s) b.tE_De2[s] = a.f(R * De);
+    const size_t Mt = (size_t)t.Mtot;
+    b.Wall = a.f(Mt * T); b.ball = a.f(Mt); b.mods_all = a.f(B * Mt); b.dmods_all = a.f(B * Mt); b.dWall = a.f(Mt * T); b.dball = a.f(Mt);
 }
 
 struct Ctx {
@@ -251,6 +255,18 @@ void head_bwd(const Ctx& c, const float* X, int ldx, long rows, int K, Lin l0, L
     c.lin_dx(t1, H1, rows, H1, c.p(l0.w), K, K, dX, lddx, acc);
 }
 
+// the 4 L + 1 modulation projections in the order of their columns in [., Mtot]: top-level GBF | per block node, edge, equi, GBF
+int mod_entries(const jodo_train& t, Lin* lin, int* F, int* col) {
+    int n = 0, at = 0;
+    auto add = [&](Lin l, int f) { lin[n] = l; F[n] = f; col[n] = at; at += f; ++n; };
+    add(t.gbf_time, 2);
+    for (int l = 0; l < t.L; ++l) {
+        const BlkIx& ix = t.blk[l];
+        add(ix.node_time, 6 * t.D); add(ix.edge_time, 6 * t.De); add(ix.eq_time, 2 * t.D); add(ix.gbf_time, 2);
+    }
+    return n;
+}
+
 void forward(const Ctx& c, const float* xh, const float* edge_x, const float* cond_x, const float* cond_edge_x, const float* nl, const float* context,
              float p_drop, unsigned long long seed, float* out_xh, float* out_edge) {
     const jodo_train& t = c.t; Bufs& b = c.b; const Topo& tp = c.tp; hipStream_t s = c.s;
@@ -275,7 +291,21 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
     }
     c.silu((long)B * T, b.temb, b.tau, nod);
     // embeddings (:547-560); the first-step switch of :544 is the device flag [3]
-    c.lin(b.tau, T, B, T, c.p(t.gbf_time.w), T, 2, c.p(t.gbf_time.b), b.gm_top, 2, 0);
+    {   // every modulation row of every block in ONE product (train_ops.h ModTable): gather the weights, project, hand the rows out
+        ModTable M;
+        Lin lin[MOD_MAX]; int F[MOD_MAX], col[MOD_MAX];
+        M.n = mod_entries(t, lin, F, col);
+        int fmax = 0;
+        for (int i = 0; i < M.n; ++i) {
+            M.w[i] = c.p(lin[i].w); M.bias[i] = c.p(lin[i].b); M.F[i] = F[i]; M.col[i] = col[i];
+            const int l = (i - 1) / 4, k = (i - 1) % 4;
+            M.out[i] = i == 0 ? b.gm_top : (k == 0 ? b.blk[l].nmod : (k == 1 ? b.blk[l].emod : (k == 2 ? b.blk[l].qmod : b.blk[l].gm)));
+            fmax = F[i] > fmax ? F[i] : fmax;
+        }
+        hipLaunchKernelGGL(k_mod_gather, dim3((unsigned)(((long)fmax * T + 255) / 256), (unsigned)M.n), dim3(256), 0, s, M, T, b.Wall, b.ball);
+        c.lin(b.tau, T, B, T, b.Wall, T, t.Mtot, b.ball, b.mods_all, t.Mtot, 0);
+        hipLaunchKernelGGL(k_mod_scatter, dim3((unsigned)(((long)B * fmax + 255) / 256), (unsigned)M.n), dim3(256), 0, s, M, B, t.Mtot, (const float*)b.mods_all);
+    }
     JT_LAUNCH(k_gbf_fwd, (long)R * De, s, (long)R, De, (const float*)b.d2c, tp.edge_mol, (const float*)b.gm_top, c.p(t.gbf_means), c.p(t.gbf_stds),
                        (const int*)(b.flags + 3), b.ein, ldin, 2 * ch);
     c.lin(b.ein, ldin, R, ldin, c.p(t.edge_emb.w), ldin, De, c.p(t.edge_emb.b), b.e[0], De, 0);
@@ -284,10 +314,6 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
     c.copy2d(R, De, b.e[0], De, 0, b.eh, t.cate, 0, 0);
     for (int l = 0; l < L; ++l) {
         const BlkIx& ix = t.blk[l]; BlkBuf& k = b.blk[l];
-        c.lin(b.tau, T, B, T, c.p(ix.node_time.w), T, 6 * D, c.p(ix.node_time.b), k.nmod, 6 * D, 0);
-        c.lin(b.tau, T, B, T, c.p(ix.edge_time.w), T, 6 * De, c.p(ix.edge_time.b), k.emod, 6 * De, 0);
-        c.lin(b.tau, T, B, T, c.p(ix.eq_time.w), T, 2 * D, c.p(ix.eq_time.b), k.qmod, 2 * D, 0);
-        c.lin(b.tau, T, B, T, c.p(ix.gbf_time.w), T, 2, c.p(ix.gbf_time.b), k.gm, 2, 0);
         // distances, Gaussian basis, edge_emb([G, e]) and the two modulated LayerNorms (:279-296)
         const FusedDims fd{D, De, r, QK, t.ce, L};
         FusedBlockParams fp;
@@ -393,11 +419,27 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
     JT_LAUNCH(k_node_out, (long)B * t.N * (3 + nd), s, tp, nd, (const float*)b.posf, (const float*)b.atom, out_xh);
 }
 
-// one modulation projection: dW += dmod^T tau, db += column sums, dtau += dmod W
+// one modulation projection's gradient rows: parked in their columns of dmods_all; the products (dW += dmod^T tau, db += column sums,
+// dtau += dmod W) run once for all of them at the end of the backward (mod_bwd_all)
 void mod_bwd(const Ctx& c, Lin lin, const float* dmod, int F) {
     const jodo_train& t = c.t;
-    c.lin_dw(dmod, F, t.B, F, c.b.tau, t.T, t.T, c.g(lin.w), t.T, c.g(lin.b));
-    c.lin_dx(dmod, F, t.B, F, c.p(lin.w), t.T, t.T, c.b.dtau, t.T, 1);
+    Lin ls[MOD_MAX]; int Fs[MOD_MAX], col[MOD_MAX];
+    const int n = mod_entries(t, ls, Fs, col);
+    for (int i = 0; i < n; ++i)
+        if (ls[i].w == lin.w) { c.copy2d(t.B, F, dmod, F, 0, c.b.dmods_all, t.Mtot, col[i], 0); return; }
+}
+void mod_bwd_all(const Ctx& c) {
+    const jodo_train& t = c.t; Bufs& b = c.b; hipStream_t s = c.s;
+    (void)hipMemsetAsync(b.dWall, 0, (size_t)t.Mtot * t.T * 4, s);
+    (void)hipMemsetAsync(b.dball, 0, (size_t)t.Mtot * 4, s);
+    c.lin_dw(b.dmods_all, t.Mtot, t.B, t.Mtot, b.tau, t.T, t.T, b.dWall, t.T, b.dball);
+    c.lin_dx(b.dmods_all, t.Mtot, t.B, t.Mtot, b.Wall, t.T, t.T, b.dtau, t.T, 1);
+    ModGradTable M;
+    Lin lin[MOD_MAX]; int F[MOD_MAX], col[MOD_MAX];
+    M.n = mod_entries(t, lin, F, col);
+    int fmax = 0;
+    for (int i = 0; i < M.n; ++i) { M.gw[i] = c.g(lin[i].w); M.gb[i] = c.g(lin[i].b); M.F[i] = F[i]; M.col[i] = col[i]; fmax = F[i] > fmax ? F[i] : fmax; }
+    hipLaunchKernelGGL(k_mod_scatter_grads, dim3((unsigned)(((long)fmax * t.T + 255) / 256), (unsigned)M.n), dim3(256), 0, s, M, t.T, (const float*)b.dWall, (const float*)b.dball);
 }
 
 void gbf_bwd(const Ctx& c, long rows, const float* d2, const float* gm, int means, int stds, Lin time, const float* dG, int ldg, int gcol, float* dd2) {
@@ -615,7 +657,8 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
     // the top-level Gaussian layer saw the self-conditioning distances, or nothing at all on a first step (flag [3] == 0: G0 = 0)
     JT_LAUNCH(k_scale_if_zero, (long)R * De, s, (long)R * De, dG0, (const int*)(b.flags + 3));
     gbf_bwd(c, R, b.d2c, b.gm_top, t.gbf_means, t.gbf_stds, t.gbf_time, dG0, De, 0, nullptr);
-    // time embedding
+    // every modulation projection at once, then the time embedding
+    mod_bwd_all(c);
     c.silu_bwd((long)B * T, b.temb, b.dtau, b.dtemb, nod);
     if (t.cc > 0) {
         const int cD = t.cc * D;
@@ -654,6 +697,8 @@ int jodo_train_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes,
         return jodo_set_error(JODO_ERR_UNSUPPORTED, "jodo_train_create: nf %d / n_heads %d / n_extra_heads %d", cfg->nf, cfg->n_heads, cfg->n_extra);
     // k_row_part / k_ln_bwd_part (train_ops.h) cut a LayerNorm row of De = nf / 4 features into eight equal parts, and the MLP heads
     // halve D and De: a width that is not a multiple of 32 would silently drop trailing features from the statistics
+    if (cfg->n_layers < 1 || cfg->n_layers > 16)
+        return jodo_set_error(JODO_ERR_UNSUPPORTED, "jodo_train_create: n_layers %d (1 .. 16: the batched modulation tables hold 4 x 16 + 1 projections)", cfg->n_layers);
     if (cfg->nf % 32)
         return jodo_set_error(JODO_ERR_UNSUPPORTED, "jodo_train_create: nf %d is not a multiple of 32 (LayerNorm rows of nf / 4 features are reduced in eight equal parts)", cfg->nf);
     jodo_train* t = new jodo_train();
@@ -754,6 +799,7 @@ int jodo_train_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes,
         const FusedDims fd{t->D, t->De, t->r, t->QK, t->ce, t->L};
         t->fused = fused_available(fd) ? 1 : 0;
         t->fused_bwd = t->fused;
+        t->Mtot = 2 + t->L * (6 * t->D + 6 * t->De + 2 * t->D + 2);
     }
     Arena a{nullptr, 0}; Bufs bufs;
     layout(*t, a, bufs);
