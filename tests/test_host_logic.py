@@ -145,3 +145,23 @@ def test_plan_options_are_range_checked():
         assert lib.jodo_plan_set_option(h, 99, 0) == -1
     finally:
         lib.jodo_plan_destroy(h)
+
+
+def test_scaling_prediction_runs_on_the_host():
+    """jodo_amd/scaling.py: per-rank executed work of a sharded run from the library's own work model, no GPU.  Equal shares
+    predict efficiency 1; a share with one large molecule more predicts less; LPT dealing is never worse than contiguous slices."""
+    import torch
+    from jodo_amd import scaling
+    from jodo_amd.models import get_model_class, load_dataset_info, get_node_dist
+    from helpers import make_config
+    cfg = make_config('vpsde_geom_uncond_jodo')
+    cs = get_model_class(cfg.model.name)(cfg)._cfg()
+    same = scaling.predict_weak(cs, [[40, 30, 20, 10]] * 4, 1)
+    assert same['ranks'] == 4 and abs(same['predicted_efficiency'] - 1.0) < 1e-12
+    skew = scaling.predict_weak(cs, [[40, 30, 20, 10], [150, 30, 20, 10]], 1)
+    assert skew['predicted_efficiency'] < 0.9 and skew['sum_n2_per_rank'][1] > skew['sum_n2_per_rank'][0]
+    torch.manual_seed(3)
+    n_all = get_node_dist(load_dataset_info('geom_with_h_1')).sample(256).tolist()
+    dealt = scaling.predict_dealt(cs, n_all, 4, 64, 1)
+    assert dealt['lpt']['predicted_efficiency'] >= dealt['contiguous']['predicted_efficiency'] - 1e-3
+    assert sum(dealt['lpt']['molecules_per_rank']) == 256 and sum(dealt['contiguous']['molecules_per_rank']) == 256
