@@ -491,6 +491,31 @@ def main():
                               'clock (weights already packed); eager draws the per-step noise inside the update kernel '
                               '(Philox), eager_torch_randn with three torch.randn launches per step (the reference RNG stream)'
                               % int(cfg.sampling.steps))
+    # ---- BASELINE configs[4]'s own metric: one complete round of the hybrid DPM-solver at 50 NFE (conditional workload only) --------------
+    dpm_round = None
+    if world == 1 and dims.cond_ch and not args.no_full_round:
+        try:
+            import copy
+            cfg2 = copy.deepcopy(cfg)
+            cfg2.sampling.method = 'fast'                       # mix_dpm_solver.py; the keys the reference's cond config lacks take the
+            cfg2.sampling.steps = 50                            # values of its uncond config (configs/vpsde_qm9_uncond_jodo.py:102-103)
+            cfg2.sampling['dpm_solver_method'] = 'singlestep_fixed'
+            cfg2.sampling['dpm_solver_order'] = 2
+            fn = get_sampling_fn(cfg2, ns, nodes_dist, B, B, get_data_inverse_scaler(cfg2), prop_dist=prop, return_raw=True)
+            with contextlib.redirect_stdout(sys.stderr):
+                torch.manual_seed(cfg.seed)
+                fn(model)                                       # warm round (plans, first-touch)
+                torch.cuda.synchronize()
+                tr = time.perf_counter()
+                mols = fn(model)
+                torch.cuda.synchronize()
+                tr = time.perf_counter() - tr
+            dpm_round = {'nfe': 50, 'round_seconds': tr, 'molecules': len(mols), 'value': len(mols) / tr, 'unit': 'molecules/s',
+                         'ms_per_evaluation_incl_everything': tr / 50 * 1e3,
+                         'note': 'get_sampling_fn(method=fast: DPM_Solver_hybrid, singlestep_fixed order 2, 50 NFE) -> device decode -> host tuples, '
+                                 'one call, wall clock (BASELINE configs[4]: QM9 conditional + mix_dpm_solver 50 steps, per-GPU share)'}
+        except Exception as exc:
+            dpm_round = {'error': repr(exc)}
     # ---- under a launcher (any N): one complete SHARDED round + the RCCL gather of the generated molecules --------------------------------
     sharded = None
     if use_dist and not args.no_full_round:
@@ -642,6 +667,7 @@ def main():
             'steady_state': steady,
             'full_round': full_round,
             'sharded_round': sharded,
+            'dpm_round': dpm_round,
             'scaling_prediction': scaling_pred,
             'molecules_decoded': n_total, 'nan_guard': bool(nan_fired),
             'device_flags': dict(zip(('nan', 'first_step', 'uniform_t', 'cond_nonzero', 'asymmetric_edges'), flags_now[:5])),
