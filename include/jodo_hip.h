@@ -348,7 +348,10 @@ size_t jodo_train_desc_bytes(const jodo_train* t);
 size_t jodo_train_workspace_bytes(const jodo_train* t);
 /* option 0 = fused per-edge forward chains (csrc/train_fused.hip: edge_emb -> LN -> lin_edge0 / 1; edge FFN; input_lin -> LN -> coord_mlp as
  * one strip-model kernel each, activations saved where the backward expects them): 1 (default) / 0 (one launch per operation);
- * option 1 = the input-gradient side of the same chains in the backward (the weight-gradient products stay GEMMs): 1 (default) / 0 */
+ * option 1 = the input-gradient side of the same chains in the backward (the weight-gradient products stay GEMMs): 1 (default) / 0;
+ * option 2 = 1 (default): forwards keep every activation a backward reads; 0: the following forwards will not be differentiated (the
+ *            no-grad self-conditioning forward of a training step, losses.py:335-339) and skip those stores — jodo_train_backward after
+ *            such a forward is undefined */
 int jodo_train_set_option(jodo_train* t, int option, int value);
 /* tests: byte offset and element count of a kept activation inside the workspace; what 0 = hhat [Nn, D] (TransMixLayer's output,
  * layers.py:153), 1 = alpha [R, H] (softmax weights, layers.py:178) of block `layer` */

@@ -60,6 +60,7 @@ struct Bufs {
     float* fpack;                     // packed MFMA operands of the fused chains (forward + transposed images), one slice per block (train_fused.h)
     float* tE_De2[3];                 // scratch of the fused backward chains: df4 | den | de1
     float *Wall, *ball, *mods_all, *dmods_all, *dWall, *dball;      // batched modulation projections (train_ops.h ModTable)
+    float *Wqkv, *bqkv, *qkv, *dqkv, *dWqkv, *dbqkv;                // lin_query / lin_key / lin_value of a block as one product: [L][2 QK + D, D] gathered weights
     size_t fpack_block;
     size_t splitk_floats, part_floats, part2_floats;
 };
@@ -82,6 +83,7 @@ struct jodo_train {
     size_t ws_bytes;
     int fused;                        // 1: the three per-edge chains of a block run as fused strip kernels (train_fused.hip)
     int fused_bwd;                    // 1: their input-gradient sides too (the weight-gradient products stay GEMMs)
+    int save_activations;             // option 2: 0 = the following forwards are not followed by a backward (no-grad self-conditioning call)
     int Mtot;                         // modulation floats per molecule: 2 (top-level GBF) + L (6 D + 6 De + 2 D + 2)
 };
 
@@ -140,6 +142,8 @@ void layout(const jodo_train& t, Arena& a, Bufs& b) {
     for (int s = 0; s < 3; ++s) b.tE_De2[s] = a.f(R * De);
     const size_t Mt = (size_t)t.Mtot;
     b.Wall = a.f(Mt * T); b.ball = a.f(Mt); b.mods_all = a.f(B * Mt); b.dmods_all = a.f(B * Mt); b.dWall = a.f(Mt * T); b.dball = a.f(Mt);
+    const size_t F3 = 2 * QK + D;
+    b.Wqkv = a.f(L * F3 * D); b.bqkv = a.f(L * F3); b.qkv = a.f(Nn * F3); b.dqkv = a.f(Nn * F3); b.dWqkv = a.f(L * F3 * D); b.dbqkv = a.f(L * F3);
 }
 
 struct Ctx {
@@ -306,6 +310,21 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
         c.lin(b.tau, T, B, T, b.Wall, T, t.Mtot, b.ball, b.mods_all, t.Mtot, 0);
         hipLaunchKernelGGL(k_mod_scatter, dim3((unsigned)(((long)B * fmax + 255) / 256), (unsigned)M.n), dim3(256), 0, s, M, B, t.Mtot, (const float*)b.mods_all);
     }
+    const int F3 = 2 * QK + D;
+    {   // lin_query, lin_key, lin_value of every block share their input (the modulated LayerNorm1 of h): their weights are gathered into
+        // [L][2 QK + D, D] once per forward so that a block needs ONE product instead of three (and its backward two instead of six)
+        ModTable M;
+        M.n = 3 * L;
+        for (int l = 0; l < L; ++l) {
+            const BlkIx& ix = t.blk[l];
+            const Lin ls[3] = {ix.query, ix.key, ix.value};
+            for (int j = 0; j < 3; ++j) {
+                const int i = 3 * l + j;
+                M.w[i] = c.p(ls[j].w); M.bias[i] = c.p(ls[j].b); M.out[i] = nullptr; M.F[i] = j < 2 ? QK : D; M.col[i] = l * F3 + j * QK;
+            }
+        }
+        hipLaunchKernelGGL(k_mod_gather, dim3((unsigned)(((long)D * D + 255) / 256), (unsigned)M.n), dim3(256), 0, s, M, D, b.Wqkv, b.bqkv);
+    }
     JT_LAUNCH(k_gbf_fwd, (long)R * De, s, (long)R, De, (const float*)b.d2c, tp.edge_mol, (const float*)b.gm_top, c.p(t.gbf_means), c.p(t.gbf_stds),
                        (const int*)(b.flags + 3), b.ein, ldin, 2 * ch);
     c.lin(b.ein, ldin, R, ldin, c.p(t.edge_emb.w), ldin, De, c.p(t.edge_emb.b), b.e[0], De, 0);
@@ -317,7 +336,7 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
         // distances, Gaussian basis, edge_emb([G, e]) and the two modulated LayerNorms (:279-296)
         const FusedDims fd{D, De, r, QK, t.ce, L};
         FusedBlockParams fp;
-        FusedTopo ft{R, tp.edge_a, tp.edge_c, tp.edge_mol};
+        FusedTopo ft{R, tp.edge_a, tp.edge_c, tp.edge_mol, t.save_activations};
         float* fpk = b.fpack + (size_t)l * b.fpack_block;
         if (t.fused) {
             fp.edge_emb_w = c.p(ix.edge_emb.w); fp.edge_emb_b = c.p(ix.edge_emb.b); fp.le0 = c.p(ix.le0); fp.le1 = c.p(ix.le1);
@@ -341,9 +360,14 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
         c.stats(Nn, D, b.h[l], b.tRow[0], k.rs_h);
         c.ln_mod(Nn, D, b.h[l], b.tRow[0], k.rs_h, tp.node_mol, k.nmod, 6 * D, 0, D, k.xh_h, k.ht);
         // attention (layers.py:131-186)
-        c.lin(k.ht, D, Nn, D, c.p(ix.query.w), D, QK, c.p(ix.query.b), k.q, QK, 0);
-        c.lin(k.ht, D, Nn, D, c.p(ix.key.w), D, QK, c.p(ix.key.b), k.k, QK, 0);
-        c.lin(k.ht, D, Nn, D, c.p(ix.value.w), D, D, c.p(ix.value.b), k.v, D, 0);
+        {   // q | k | v in one product on the gathered weights, then handed out to their arrays
+            c.lin(k.ht, D, Nn, D, b.Wqkv + (size_t)l * F3 * D, D, F3, b.bqkv + (size_t)l * F3, b.qkv, F3, 0);
+            ModTable M;
+            M.n = 3;
+            float* outs[3] = {k.q, k.k, k.v};
+            for (int j = 0; j < 3; ++j) { M.w[j] = nullptr; M.bias[j] = nullptr; M.out[j] = outs[j]; M.F[j] = j < 2 ? QK : D; M.col[j] = j * QK; }
+            hipLaunchKernelGGL(k_mod_scatter, dim3((unsigned)(((long)Nn * D + 255) / 256), 3u), dim3(256), 0, s, M, Nn, F3, (const float*)b.qkv);
+        }
         if (!t.fused) {
             c.lin_tanh(k.et, De, R, De, c.p(ix.le0), De, QK, nullptr, k.t0);
             c.lin_tanh(k.et, De, R, De, c.p(ix.le1), De, D, nullptr, k.t1);
@@ -473,6 +497,8 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         i = j;
     }
     (void)hipMemsetAsync(b.dtau, 0, (size_t)B * T * 4, s);
+    (void)hipMemsetAsync(b.dWqkv, 0, (size_t)L * (2 * QK + D) * D * 4, s);
+    (void)hipMemsetAsync(b.dbqkv, 0, (size_t)L * (2 * QK + D) * 4, s);
     // outputs -> packed gradients; final centring (skipped, gradient zero, when the NaN guard fired)
     float *dposf = b.tN3[0], *datom = b.tN_De, *dEp = b.tE3[0];
     JT_LAUNCH(k_node_out_bwd, (long)Nn * (3 + nd), s, tp, nd, d_out_xh, dposf, datom);
@@ -618,12 +644,16 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
             c.lin_dx(dt0, QK, R, QK, c.p(ix.le0), De, De, det, De, 1);
         }
         float* dht = b.tN_D[0];
-        c.lin_dw(dv, D, Nn, D, k.ht, D, D, c.g(ix.value.w), D, c.g(ix.value.b));
-        c.lin_dx(dv, D, Nn, D, c.p(ix.value.w), D, D, dht, D, 0);
-        c.lin_dw(dq, QK, Nn, QK, k.ht, D, D, c.g(ix.query.w), D, c.g(ix.query.b));
-        c.lin_dx(dq, QK, Nn, QK, c.p(ix.query.w), D, D, dht, D, 1);
-        c.lin_dw(dk, QK, Nn, QK, k.ht, D, D, c.g(ix.key.w), D, c.g(ix.key.b));
-        c.lin_dx(dk, QK, Nn, QK, c.p(ix.key.w), D, D, dht, D, 1);
+        {   // d q | d k | d v side by side: one weight-gradient and one input-gradient product on the gathered weights of the forward
+            const int F3 = 2 * QK + D;
+            ModTable M;
+            M.n = 3;
+            float* srcs[3] = {dq, dk, dv};
+            for (int j = 0; j < 3; ++j) { M.w[j] = nullptr; M.bias[j] = nullptr; M.out[j] = srcs[j]; M.F[j] = j < 2 ? QK : D; M.col[j] = j * QK; }
+            hipLaunchKernelGGL(k_mod_gather_cols, dim3((unsigned)(((long)Nn * D + 255) / 256), 3u), dim3(256), 0, s, M, Nn, F3, b.dqkv);
+            c.lin_dw(b.dqkv, F3, Nn, F3, k.ht, D, D, b.dWqkv + (size_t)l * F3 * D, D, b.dbqkv + (size_t)l * F3);
+            c.lin_dx(b.dqkv, F3, Nn, F3, b.Wqkv + (size_t)l * F3 * D, D, D, dht, D, 0);
+        }
         // ---- the two modulated LayerNorms at the top of the block, edge_emb([G, e])
         if (t.fused_bwd) {
             JT_LAUNCH(k_seg_part2, (long)tp.NC * De, s, tp.NC, De, tp.ec_off, (const float*)det, (const float*)k.xh_e1, b.part);
@@ -657,6 +687,17 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
     // the top-level Gaussian layer saw the self-conditioning distances, or nothing at all on a first step (flag [3] == 0: G0 = 0)
     JT_LAUNCH(k_scale_if_zero, (long)R * De, s, (long)R * De, dG0, (const int*)(b.flags + 3));
     gbf_bwd(c, R, b.d2c, b.gm_top, t.gbf_means, t.gbf_stds, t.gbf_time, dG0, De, 0, nullptr);
+    {   // the gathered q | k | v weight gradients of every block back to their tensors
+        const int F3 = 2 * QK + D;
+        ModGradTable M;
+        M.n = 3 * L;
+        for (int l = 0; l < L; ++l) {
+            const BlkIx& ix = t.blk[l];
+            const Lin ls[3] = {ix.query, ix.key, ix.value};
+            for (int j = 0; j < 3; ++j) { const int i = 3 * l + j; M.gw[i] = c.g(ls[j].w); M.gb[i] = c.g(ls[j].b); M.F[i] = j < 2 ? QK : D; M.col[i] = l * F3 + j * QK; }
+        }
+        hipLaunchKernelGGL(k_mod_scatter_grads, dim3((unsigned)(((long)D * D + 255) / 256), (unsigned)M.n), dim3(256), 0, s, M, D, (const float*)b.dWqkv, (const float*)b.dbqkv);
+    }
     // every modulation projection at once, then the time embedding
     mod_bwd_all(c);
     c.silu_bwd((long)B * T, b.temb, b.dtau, b.dtemb, nod);
@@ -799,6 +840,7 @@ int jodo_train_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes,
         const FusedDims fd{t->D, t->De, t->r, t->QK, t->ce, t->L};
         t->fused = fused_available(fd) ? 1 : 0;
         t->fused_bwd = t->fused;
+        t->save_activations = 1;
         t->Mtot = 2 + t->L * (6 * t->D + 6 * t->De + 2 * t->D + 2);
     }
     Arena a{nullptr, 0}; Bufs bufs;
@@ -813,9 +855,12 @@ size_t jodo_train_desc_bytes(const jodo_train* t) { return t ? t->tables.size() 
 size_t jodo_train_workspace_bytes(const jodo_train* t) { return t ? t->ws_bytes : 0; }
 // option 0: fused per-edge forward chains (train_fused.hip): 1 (default where the width is supported) / 0 (op-by-op, the reference form)
 // option 1: the same for the input-gradient side of the backward
+// option 2: 1 (default) every forward keeps what a backward needs; 0: the following forwards will not be differentiated (the no-grad
+//           self-conditioning forward of a training step): the fused chains skip the stores only a backward reads
 int jodo_train_set_option(jodo_train* t, int option, int value) {
     if (!t) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: null handle");
-    if ((option != 0 && option != 1) || (value != 0 && value != 1)) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: option %d value %d", option, value);
+    if (option < 0 || option > 2 || (value != 0 && value != 1)) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: option %d value %d", option, value);
+    if (option == 2) { t->save_activations = value; return JODO_OK; }
     const FusedDims fd{t->D, t->De, t->r, t->QK, t->ce, t->L};
     if (value && !fused_available(fd)) return jodo_set_error(JODO_ERR_UNSUPPORTED, "jodo_train_set_option: fused chains are not built for this shape");
     if (option == 0) t->fused = value; else t->fused_bwd = value;

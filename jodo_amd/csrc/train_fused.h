@@ -33,7 +33,8 @@ struct FusedBlockParams {       // device pointers of one block's parameters (Py
     const float *gbf_means, *gbf_stds;
 };
 
-struct FusedTopo { int R; const int *edge_a, *edge_c, *edge_mol; };
+struct FusedTopo { int R; const int *edge_a, *edge_c, *edge_mol; int save = 1; };   // save = 0: a forward without a backward (activations only the
+                                                                                     // backward reads are not stored)
 
 void fused_pack_block(hipStream_t s, const FusedDims& d, const FusedBlockParams& p, float* packed);
 // transposed operand images for the backward chains (dX = W^T dY on the same MFMA orientation), into packed + layout offsets *t

@@ -56,6 +56,8 @@ struct Common {
     unsigned oEE, oL0, oL1, oF3, oF4, oRO, oIN, oC0;      // byte offsets inside `packed`
     unsigned oC0T, oINT, oF4T, oF3T, oL1T, oL0T, oEET;    // transposed images (backward chains)
     const float* tab;                  // Gaussian table [3][De]
+    int save;                          // 0: a forward no backward will follow (the no-grad self-conditioning call): activations only the
+                                       // backward reads are not stored
 };
 
 struct ArgsA {
@@ -75,7 +77,8 @@ __global__ __launch_bounds__(64, 1) void k_chain_a(ArgsA A) {
     const int a = A.c.ea[rc], c = A.c.ec[rc], mol = A.c.em[rc];
     const float dx = A.pos[a * 3] - A.pos[c * 3], dy = A.pos[a * 3 + 1] - A.pos[c * 3 + 1], dz = A.pos[a * 3 + 2] - A.pos[c * 3 + 2];
     const float d2 = dx * dx + dy * dy + dz * dz;
-    if (valid && half == 0) A.d2[r] = d2;
+    const bool keep = valid && A.c.save != 0;
+    if (keep && half == 0) A.d2[r] = d2;
     const WSrc ws = make_wsrc(A.c.packed, lane);
     WPipe<X::PG> wp;
     wpipe_prime(wp, ws, A.c.oEE);
@@ -94,13 +97,13 @@ __global__ __launch_bounds__(64, 1) void k_chain_a(ArgsA A) {
         for (int s = 0; s < 16; ++s) x[b * 16 + s] = acc[s] + bb[s];
     }
     const float rstd = layer_norm_rs<X::HE>(x);
-    if (valid) {
+    if (keep) {
         store_nat<X::NE>(A.xh + r * X::De, half, x);
         if (half == 0) A.rs[r] = rstd;
     }
     const float* mr = A.emod + (long)mol * 6 * X::De;
     modulate<X::NE>(x, mr, mr + X::De, half);
-    if (valid) store_nat<X::NE>(A.et + r * X::De, half, x);
+    if (keep) store_nat<X::NE>(A.et + r * X::De, half, x);
     const int nb0 = (A.QK + 31) / 32;
 #pragma unroll 1
     for (int b = 0; b < nb0; ++b) {                                   // tanh(lin_edge0 et)
@@ -159,13 +162,14 @@ __global__ __launch_bounds__(64, 1) void k_chain_b(ArgsB A) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) x[b * 16 + s] = fmaf(g[s], ta[s] + tc[s] + bb[s], e[s]);
     }
+    const bool keep = valid && A.c.save != 0;
     const float rstd = layer_norm_rs<X::HE>(x);
-    if (valid) {
+    if (keep) {
         store_nat<X::NE>(A.xh + r * X::De, half, x);
         if (half == 0) A.rs[r] = rstd;
     }
     modulate<X::NE>(x, mr + 3 * X::De, mr + 4 * X::De, half);
-    if (valid) store_nat<X::NE>(A.en + r * X::De, half, x);
+    if (keep) store_nat<X::NE>(A.en + r * X::De, half, x);
     f32x16 o[X::NE];
 #pragma unroll
     for (int b = 0; b < X::NE; ++b) o[b] = zero16();
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(64, 1) void k_chain_b(ArgsB A) {
                 pre[s] = p.x; pre[s + 1] = p.y; act[s] = v.x; act[s + 1] = v.y;
                 hid[b2 * 16 + s] = v.x; hid[b2 * 16 + s + 1] = v.y;
             }
-            if (valid) { store16(A.f3 + r * HID + f0, pre); store16(A.a3 + r * HID + f0, act); }
+            if (keep) { store16(A.f3 + r * HID + f0, pre); store16(A.a3 + r * HID + f0, act); }
         }
 #pragma unroll
         for (int ob = 0; ob < X::NE; ++ob) {
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(64, 1) void k_chain_b(ArgsB A) {
             f4[s] = o[b][s] + bb[s];
             x[b * 16 + s] = fmaf(g[s], f4[s] * m[s], x[b * 16 + s]);
         }
-        if (valid) store16(A.f4 + r * X::De + f0, f4);
+        if (keep) store16(A.f4 + r * X::De + f0, f4);
     }
     if (valid) store_nat<X::NE>(A.e_out + r * X::De, half, x);
     {   // readout edge_l(e') -> the head input, ce valid columns
@@ -260,14 +264,15 @@ __global__ __launch_bounds__(64, JODO_X_CHAINC_OCC) void k_chain_c(ArgsC A) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) u[b * 16 + s] = (acc[s] + bb[s]) + (t1[s] + t2[s]);
     }
+    const bool keep = valid && A.c.save != 0;
     const float rstd = layer_norm_rs<X::HD>(u);
-    if (valid) {
+    if (keep) {
         store_nat<X::ND>(A.xh + r * D, half, u);
         if (half == 0) A.rs[r] = rstd;
     }
     const float* mr = A.qmod + (long)mol * 2 * D;
     modulate<X::ND>(u, mr, mr + D, half);
-    if (valid) store_nat<X::ND>(A.u + r * D, half, u);
+    if (keep) store_nat<X::ND>(A.u + r * D, half, u);
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll 1
     for (int b = 0; b < X::ND; ++b) {                                 // coord_mlp.0 -> SiLU -> coord_mlp.2
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(64, JODO_X_CHAINC_OCC) void k_chain_c(ArgsC A) {
             c1 = fmaf(v.x, k1[s], c1); c1 = fmaf(v.y, k1[s + 1], c1);
             c2 = fmaf(v.x, k2[s], c2); c2 = fmaf(v.y, k2[s + 1], c2);
         }
-        if (valid) { store16(A.c0pre + r * D + f0, pre); store16(A.c0a + r * D + f0, act); }
+        if (keep) { store16(A.c0pre + r * D + f0, pre); store16(A.c0a + r * D + f0, act); }
     }
     c0 = tanh_f(pair_sum(c0)); c1 = tanh_f(pair_sum(c1)); c2 = tanh_f(pair_sum(c2));
     if (valid && half == 0) { A.inv[r * 3] = c0; A.inv[r * 3 + 1] = c1; A.inv[r * 3 + 2] = c2; }
@@ -576,6 +581,7 @@ __global__ __launch_bounds__(64) void k_pack(PackArgs P) {
 }
 
 Common common_of(const jt::FusedDims& d, const jt::FusedTopo& t, const float* packed) {
+    // (t.save: jt::FusedTopo carries the forward's save flag; the backward chains ignore it)
     const jt::FusedPackLayout L = jt::fused_pack_layout(d);
     Common c;
     c.R = t.R; c.ea = t.edge_a; c.ec = t.edge_c; c.em = t.edge_mol; c.packed = packed;
@@ -584,6 +590,7 @@ Common common_of(const jt::FusedDims& d, const jt::FusedTopo& t, const float* pa
     c.oC0T = (unsigned)(L.c0t * 4); c.oINT = (unsigned)(L.int_eg * 4); c.oF4T = (unsigned)(L.ff4t * 4); c.oF3T = (unsigned)(L.ff3t * 4);
     c.oL1T = (unsigned)(L.l1t * 4); c.oL0T = (unsigned)(L.l0t * 4); c.oEET = (unsigned)(L.eet * 4);
     c.tab = packed + L.tab;
+    c.save = t.save;
     return c;
 }
 

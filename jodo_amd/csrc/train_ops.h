@@ -127,6 +127,14 @@ __global__ void k_mod_scatter(ModTable M, int B, int Mtot, const float* __restri
     const long b = e / M.F[i]; const int f = (int)(e % M.F[i]);
     M.out[i][e] = all[b * Mtot + M.col[i] + f];
 }
+// the inverse of k_mod_scatter: all[b, col_i + f] = out_i[b, f]   (gradient rows of projections that share an input, gathered for ONE product)
+__global__ void k_mod_gather_cols(ModTable M, int B, int Mtot, float* __restrict__ all) {
+    const int i = blockIdx.y;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)B * M.F[i]) return;
+    const long b = e / M.F[i]; const int f = (int)(e % M.F[i]);
+    all[b * Mtot + M.col[i] + f] = M.out[i][e];
+}
 // blockIdx.y = projection; gw_i[f, k] += dWall[(col_i + f) T + k], gb_i[f] += dball[col_i + f]
 __global__ void k_mod_scatter_grads(ModGradTable M, int T, const float* __restrict__ dWall, const float* __restrict__ dball) {
     const int i = blockIdx.y;

@@ -366,7 +366,9 @@ class _DGTBase(nn.Module):
         if wants_grad:
             out_x, out_e = dgt_autograd(*args, params)
         else:
-            out_x, out_e = eng.forward([q.detach().contiguous() for q in params], *args[3:], p, seed)
+            # (nobody differentiates this call — the self-conditioning forward of a training step: backward-only stores are skipped)
+            out_x, out_e = eng.forward([q.detach().contiguous() for q in params], *args[3:], p, seed,
+                                       save_activations=bool(getattr(self, 'train_save_always', False)))      # (True: A/B runs of tools/train_bench.py)
         self.last_flags = eng.flags
         return out_x, out_e
 

@@ -158,7 +158,7 @@ class TrainEngine:
         slot['stamp'], slot['live'] = pool['stamp'], bool(keep)
         return slot
 
-    def forward(self, params, xh, edge_x, cond_x, cond_edge_x, noise_level, context, dropout_p, seed, keep=False):
+    def forward(self, params, xh, edge_x, cond_x, cond_edge_x, noise_level, context, dropout_p, seed, keep=False, save_activations=True):
         """params: contiguous float32 tensors in the order of `named_shapes`.  Returns (out_xh, out_edge); the activations stay
         in a workspace slot of the pool (self.stamp names it) — until the next forward, or, with keep=True, until `backward` /
         `release` has been called for that stamp."""
@@ -166,6 +166,9 @@ class TrainEngine:
         slot = self._take_slot(xh.device, keep)
         self._slot, self.stamp = slot, slot['stamp']
         out_x, out_e = torch.empty_like(xh), torch.empty_like(edge_x)
+        if bool(save_activations) != getattr(self, '_saving', True):    # option 2: a forward nobody differentiates skips backward-only stores
+            self._check(self.L.jodo_train_set_option(self.handle, 2, 1 if save_activations else 0), 'jodo_train_set_option')
+            self._saving = bool(save_activations)
         self._check(self.L.jodo_train_forward(
             self.handle, capi.ptr(self.desc), self._ptrs(params), self.n_params, capi.ptr(xh), capi.ptr(edge_x), capi.ptr(cond_x),
             capi.ptr(cond_edge_x), capi.ptr(noise_level), capi.ptr(context), ctypes.c_float(dropout_p), ctypes.c_uint64(seed),

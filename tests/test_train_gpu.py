@@ -351,6 +351,18 @@ def test_fused_forward_chains_equal_the_op_by_op_forward(cfg_name, n_nodes, over
                 bad.append("%s: %.3e of %.3e" % (name, err, scale))
         assert not bad, "fused %s vs op-by-op gradients differ:\n  " % (key,) + "\n  ".join(bad[:30])
     assert any(not torch.equal(a, b) for a, b in zip(res[(1, 1)][2], res[(1, 0)][2]))       # the fused backward really ran
+    # the no-grad call of a training step (self-conditioning forward, losses.py:335-339: dropout active, nothing differentiated) skips
+    # the stores only a backward reads (jodo_train_set_option 2): same outputs bit for bit, and a grad-enabled call afterwards still works
+    model.train_options = {0: 1, 1: 1}
+    with torch.no_grad():
+        torch.manual_seed(77)
+        nx, ne = model(d(nl), d(xh), d(nm), d(em), d(ctx), edge_x=d(ex), cond_x=d(cx), cond_edge_x=d(cex), noise_level=d(nl))
+    assert torch.equal(nx.cpu(), res[(1, 1)][0]) and torch.equal(ne.cpu(), res[(1, 1)][1])
+    model.zero_grad()
+    torch.manual_seed(77)
+    ox, oe = model(d(nl), d(xh), d(nm), d(em), d(ctx), edge_x=d(ex), cond_x=d(cx), cond_edge_x=d(cex), noise_level=d(nl))
+    ((ox * d(d_x)).sum() + (oe * d(d_e)).sum()).backward()
+    assert all(torch.equal(p.grad.cpu(), g) for p, g in zip(model.parameters(), res[(1, 1)][2]))
     # eval mode, no dropout: both against the inference kernels (a third implementation)
     model.eval()
     with torch.no_grad():

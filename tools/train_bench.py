@@ -38,7 +38,7 @@ def synthetic_batch(cfg, n_nodes, seed):
                 edge_one_hot=eoh * em.reshape(B, N, N, 1), formal_charges=torch.randint(-1, 2, (B, N, 1), generator=g).float() * nm)
 
 
-def run(workload='qm9', batch=0, steps=10, warmup=3, seed=42):
+def run(workload='qm9', batch=0, steps=10, warmup=3, seed=42, options=None, save_always=False):
     from jodo_amd import configs, losses as L
     from jodo_amd.diffusion import NoiseScheduleVP
     from jodo_amd.models import get_model_class, deterministic_init_, load_dataset_info, get_node_dist
@@ -54,6 +54,8 @@ def run(workload='qm9', batch=0, steps=10, warmup=3, seed=42):
     n_nodes = get_node_dist(load_dataset_info(info)).sample(B).tolist()
     data = synthetic_batch(cfg, n_nodes, seed)
     model = deterministic_init_(get_model_class(cfg.model.name)(cfg), seed=seed).to(dev)
+    model.train_options = dict(options or {})          # jodo_train_set_option values (A/B runs), e.g. {0: 0, 1: 0} = op-by-op
+    model.train_save_always = bool(save_always)
     ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
     state = dict(model=model, optimizer=L.get_optimizer(cfg, model.parameters()),
                  ema=ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_decay), step=1)
@@ -186,8 +188,11 @@ if __name__ == '__main__':
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--cpu', action='store_true', help='also time the host port of the same forward + backward (small batch)')
+    ap.add_argument('--train-opt', action='append', default=[], help='jodo_train_set_option=value (A/B runs), e.g. 0=0 1=0: op-by-op forward / backward')
+    ap.add_argument('--save-always', action='store_true', help='the no-grad self-conditioning forward keeps its activations too (round-4 behaviour)')
     a = ap.parse_args()
-    out = run(a.workload, a.batch, a.steps, a.warmup)
+    out = run(a.workload, a.batch, a.steps, a.warmup, options={int(o.split('=')[0]): int(o.split('=')[1]) for o in a.train_opt}, save_always=a.save_always)
+    out['train_options'] = a.train_opt; out['save_always'] = a.save_always
     if a.cpu:
         out['cpu'] = cpu_step(a.workload)
         out['gpu_over_cpu_forward_backward'] = (out['batch'] / ((out['forward_ms'] + out['backward_ms']) * 1e-3)) / out['cpu']['molecules_per_s']
