@@ -351,7 +351,9 @@ size_t jodo_train_workspace_bytes(const jodo_train* t);
  * option 1 = the input-gradient side of the same chains in the backward (the weight-gradient products stay GEMMs): 1 (default) / 0;
  * option 2 = 1 (default): forwards keep every activation a backward reads; 0: the following forwards will not be differentiated (the
  *            no-grad self-conditioning forward of a training step, losses.py:335-339) and skip those stores — jodo_train_backward after
- *            such a forward is undefined */
+ *            such a forward is undefined;
+ * option 3 = 1 (default): the backward's weight-gradient products are queued and run in grouped launches (csrc/train_gemm.hip
+ *            gemm_dw_group: same plans and arithmetic as one launch each, bit-identical gradients); 0: one launch per product */
 int jodo_train_set_option(jodo_train* t, int option, int value);
 /* tests: byte offset and element count of a kept activation inside the workspace; what 0 = hhat [Nn, D] (TransMixLayer's output,
  * layers.py:153), 1 = alpha [R, H] (softmax weights, layers.py:178) of block `layer` */

@@ -61,8 +61,11 @@ struct Bufs {
     float* tE_De2[3];                 // scratch of the fused backward chains: df4 | den | de1
     float *Wall, *ball, *mods_all, *dmods_all, *dWall, *dball;      // batched modulation projections (train_ops.h ModTable)
     float *Wqkv, *bqkv, *qkv, *dqkv, *dWqkv, *dbqkv;                // lin_query / lin_key / lin_value of a block as one product: [L][2 QK + D, D] gathered weights
+    float *dwg;                                                     // split-K partial tiles of a grouped weight-gradient launch (gemm_dw_group)
+    float *tN_D2[2];                                                // d h_row | d h_col of input_lin while their weight-gradient products are queued
     size_t fpack_block;
-    size_t splitk_floats, part_floats, part2_floats;
+    size_t splitk_floats, part_floats, part2_floats, dwg_floats;
+    std::vector<GemmJob> dwq;                                       // weight-gradient products waiting for the next Ctx::flush_dw
 };
 
 }  // namespace
@@ -83,6 +86,7 @@ struct jodo_train {
     size_t ws_bytes;
     int fused;                        // 1: the three per-edge chains of a block run as fused strip kernels (train_fused.hip)
     int fused_bwd;                    // 1: their input-gradient sides too (the weight-gradient products stay GEMMs)
+    int group_dw;                     // option 3: 1 = the backward's weight-gradient products are queued and launched in groups (gemm_dw_group)
     int save_activations;             // option 2: 0 = the following forwards are not followed by a backward (no-grad self-conditioning call)
     int Mtot;                         // modulation floats per molecule: 2 (top-level GBF) + L (6 D + 6 De + 2 D + 2)
 };
@@ -136,6 +140,9 @@ void layout(const jodo_train& t, Arena& a, Bufs& b) {
     const size_t need = ((rows + 1023) / 1024 + 1) * (size_t)D * (2 * D + 2 * De);
     if (b.splitk_floats > need) b.splitk_floats = need;
     b.splitk = a.f(b.splitk_floats);
+    b.dwg_floats = 6 * b.splitk_floats;      // the partial tiles of about a dozen queued products (a group is cut where they do not fit)
+    b.dwg = a.f(b.dwg_floats);
+    for (int s = 0; s < 2; ++s) b.tN_D2[s] = a.f(Nn * D);
     const FusedDims fd{t.D, t.De, t.r, t.QK, t.ce, t.L};
     b.fpack_block = fused_pack_layout(fd).total_bwd;
     b.fpack = a.f(b.fpack_block * L);
@@ -170,9 +177,20 @@ struct Ctx {
     }
     // dW[N, K] (lddw) += dY[rows, N]^T X[rows, K]
     // db (optional): the bias gradient, db[N] += column sums of dY, computed by the same launch
+    // With option 3 (default) the product is QUEUED: it runs, with every other product queued since, in the one launch of the next
+    // flush_dw() — which the caller places before anything overwrites an operand (dY, X) of a queued product.
     void lin_dw(const float* dY, int ldy, int rows, int N, const float* X, int ldx, int K, float* dW, int lddw, float* db = nullptr) const {
+        if (t.group_dw && t.fused_bwd) {                     // (the op-by-op backward reuses operands in place: launched at once)
+            b.dwq.push_back(GemmJob{N, K, rows, dY, ldy, X, ldx, dW, lddw, db});
+            return;
+        }
         GemmEpi e; e.act = 0; e.out2 = nullptr; e.drop = drop(0.f, 0, 0, 0); e.dbias = db;
         gemm(s, 1, 0, N, K, rows, dY, ldy, X, ldx, dW, lddw, nullptr, 1, b.splitk, b.splitk_floats, &e);
+    }
+    void flush_dw() const {
+        if (b.dwq.empty()) return;
+        gemm_dw_group(s, b.dwq.data(), (int)b.dwq.size(), b.dwg, b.dwg_floats, b.splitk_floats);
+        b.dwq.clear();
     }
     // out[F] += column sums of a[rows, F] (row stride lda), optionally of a * bb: 32-row partial sums, then partial sums of those
     // until at most 64 rows are left (every level a launch with rows x F / 32 threads; fixed order, no atomics)
@@ -257,6 +275,7 @@ void head_bwd(const Ctx& c, const float* X, int ldx, long rows, int K, Lin l0, L
     c.silu_bwd(rows * H1, p1, t1, t1, nod);
     c.lin_dw(t1, H1, rows, H1, X, ldx, K, c.g(l0.w), K, c.g(l0.b));
     c.lin_dx(t1, H1, rows, H1, c.p(l0.w), K, K, dX, lddx, acc);
+    c.flush_dw();                                            // t1 / t2 are the next head's scratch too
 }
 
 // the 4 L + 1 modulation projections in the order of their columns in [., Mtot]: top-level GBF | per block node, edge, equi, GBF
@@ -457,6 +476,7 @@ void mod_bwd_all(const Ctx& c) {
     (void)hipMemsetAsync(b.dWall, 0, (size_t)t.Mtot * t.T * 4, s);
     (void)hipMemsetAsync(b.dball, 0, (size_t)t.Mtot * 4, s);
     c.lin_dw(b.dmods_all, t.Mtot, t.B, t.Mtot, b.tau, t.T, t.T, b.dWall, t.T, b.dball);
+    c.flush_dw();
     c.lin_dx(b.dmods_all, t.Mtot, t.B, t.Mtot, b.Wall, t.T, t.T, b.dtau, t.T, 1);
     ModGradTable M;
     Lin lin[MOD_MAX]; int F[MOD_MAX], col[MOD_MAX];
@@ -557,7 +577,7 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         mod_bwd(c, ix.eq_time, b.dqmod, 2 * D);
         const int ldw = 2 * D + 2 * De;
         const float* Win = c.p(ix.eq_in.w); float* dWin = c.g(ix.eq_in.w);
-        float *dhr = b.tN_D[0], *dhc = b.tN_D[1];
+        float *dhr = b.tN_D2[0], *dhc = b.tN_D2[1];           // (not tN_D[0 .. 1]: d hhat / d tn below, while these products are queued)
         JT_LAUNCH(k_edge_to_node, (long)Nn * D, s, tp, D, (const float*)dpre, dhr, dhc, 0);
         c.lin_dw(dhr, D, Nn, D, b.h[l + 1], D, D, dWin, ldw);
         c.lin_dw(dhc, D, Nn, D, b.h[l + 1], D, D, dWin + D, ldw);
@@ -622,6 +642,7 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         c.seg(D, tp.node_off, dh_prev, k.hhat, b.dnmod, 6 * D, 2 * D);                               // d ng1
         JT_LAUNCH(k_gate_bwd, (long)Nn * D, s, (long)Nn, D, (const float*)dh_prev, tp.node_mol, (const float*)k.nmod, 6 * D, 2 * D, dhhat, 1);
         // ---- attention backwards
+        c.flush_dw();                                        // d tn (tN_D[1]) and d c0 (tE_D[0]) are d v and d t1 from here on
         const float isc = 1.f / sqrtf((float)t.C);
         const Drop da = c.drop(0.f, seed, l, SITE_ALPHA);                    // p = 0: see SITE_ALPHA
         float *dv = b.tN_D[1], *dt1 = b.tE_D[0], *dS = b.tE_H, *dq = b.tN_QK[0], *dk = b.tN_QK[1], *dt0 = b.tE_QK;
@@ -671,6 +692,7 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         c.ln_mod_bwd(Nn, D, dht, k.xh_h, k.rs_h, tp.node_mol, tp.node_off, k.nmod, 6 * D, 0, D, b.dnmod, dh_prev, 1);
         mod_bwd(c, ix.node_time, b.dnmod, 6 * D);
         // ---- Gaussian basis and distances -> positions of the block input
+        c.flush_dw();                                        // gbf_bwd's partial sums live in tE_QK (d t0), and the next block reuses everything
         float* dd2 = b.tRow[0];
         gbf_bwd(c, R, k.d2, k.gm, ix.gbf_means, ix.gbf_stds, ix.gbf_time, dG, De, 0, dd2);
         JT_LAUNCH(k_dist2_bwd, (long)R * 3, s, tp, (const float*)b.pos[l], (const float*)dd2, ddiff);
@@ -682,6 +704,7 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
     c.copy2d(R, De, deh, t.cate, 0, de, De, 0, 1);
     c.lin_dw(dh, D, Nn, D, b.nin, 2 * nd, 2 * nd, c.g(t.node_emb.w), 2 * nd, c.g(t.node_emb.b));
     c.lin_dw(de, De, R, De, b.ein, ldin, ldin, c.g(t.edge_emb.w), ldin, c.g(t.edge_emb.b));
+    c.flush_dw();
     float* dG0 = b.tE_De[0];
     c.lin_dx(de, De, R, De, c.p(t.edge_emb.w) + 2 * ch, ldin, De, dG0, De, 0);
     // the top-level Gaussian layer saw the self-conditioning distances, or nothing at all on a first step (flag [3] == 0: G0 = 0)
@@ -716,6 +739,7 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
     c.lin_dw(b.tB_T[0], T, B, T, b.feat, F17, F17, c.g(t.time1.w), F17, c.g(t.time1.b));
     c.lin_dx(b.tB_T[0], T, B, T, c.p(t.time1.w), F17, F17, b.tB_T[1], F17, 0);
     JT_LAUNCH(k_time_feat_bwd, t.half, s, B, t.half, nl, c.p(t.time_w), (const float*)b.tB_T[1], c.g(t.time_w));
+    c.flush_dw();                                            // the time / context MLPs' products: their operands are final where they are queued
 }
 
 Topo make_topo(const jodo_train& t, const void* desc_dev) {
@@ -841,6 +865,7 @@ int jodo_train_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes,
         t->fused = fused_available(fd) ? 1 : 0;
         t->fused_bwd = t->fused;
         t->save_activations = 1;
+        t->group_dw = 1;
         t->Mtot = 2 + t->L * (6 * t->D + 6 * t->De + 2 * t->D + 2);
     }
     Arena a{nullptr, 0}; Bufs bufs;
@@ -857,10 +882,13 @@ size_t jodo_train_workspace_bytes(const jodo_train* t) { return t ? t->ws_bytes 
 // option 1: the same for the input-gradient side of the backward
 // option 2: 1 (default) every forward keeps what a backward needs; 0: the following forwards will not be differentiated (the no-grad
 //           self-conditioning forward of a training step): the fused chains skip the stores only a backward reads
+// option 3: 1 (default) the backward's weight-gradient products run in grouped launches (train_gemm.hip gemm_dw_group); 0: one launch
+//           (+ one split-K sum) each — same plans, same arithmetic, bit-identical gradients
 int jodo_train_set_option(jodo_train* t, int option, int value) {
     if (!t) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: null handle");
-    if (option < 0 || option > 2 || (value != 0 && value != 1)) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: option %d value %d", option, value);
+    if (option < 0 || option > 3 || (value != 0 && value != 1)) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: option %d value %d", option, value);
     if (option == 2) { t->save_activations = value; return JODO_OK; }
+    if (option == 3) { t->group_dw = value; return JODO_OK; }
     const FusedDims fd{t->D, t->De, t->r, t->QK, t->ce, t->L};
     if (value && !fused_available(fd)) return jodo_set_error(JODO_ERR_UNSUPPORTED, "jodo_train_set_option: fused chains are not built for this shape");
     if (option == 0) t->fused = value; else t->fused_bwd = value;

@@ -13,6 +13,15 @@ namespace jt {
 struct GemmEpi { int act; float* out2; Drop drop; float* dbias; };
 void gemm(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
           const float* bias, int acc, float* ws, size_t ws_floats, const GemmEpi* epi = nullptr);
+// Weight-gradient products queued by the backward and launched together (train_gemm.hip gemm_dw_group):
+//     C[M, N] (ldc) += A[K, M]^T (lda) B[K, N] (ldb),   dbias[M] += column sums of A   (dbias may be NULL)
+// — what gemm(s, 1, 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 1, ws, plan_floats, {dbias}) computes, bit for bit.
+struct GemmJob { int M, N, K; const float* A; int lda; const float* B; int ldb; float* C; int ldc; float* dbias; };
+void gemm_dw_group(hipStream_t s, const GemmJob* jobs, int n, float* ws, size_t ws_floats, size_t plan_floats);
+// the table a grouped launch carries in its kernel arguments (device side of gemm_dw_group)
+#define GEMM_GROUP_MAX 24
+struct GemmGroupJob { const float *A, *B; float *C, *part, *dbias; int M, N, K, kchunk, lda, ldb, ldc, nx, ny, nz, vecA, vecB, wg0, sb0; };
+struct GemmGroup { int n; GemmGroupJob j[GEMM_GROUP_MAX]; };
 __host__ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, float v, float* C, long cidx, long didx) {
     if (e.act == 1) C[cidx] = tanhf(v);
     else { C[cidx] = v; e.out2[cidx] = silu_f(v) * drop_mul(e.drop, (unsigned long long)didx); }

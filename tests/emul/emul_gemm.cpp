@@ -71,6 +71,15 @@ void gemm(hipStream_t, int tA, int tB, int M, int N, int K, const float* A, int 
 #include "train_fused.h"
 namespace jt {
 FusedPackLayout fused_pack_layout(const FusedDims&) { return FusedPackLayout{}; }
+// the grouped weight-gradient launch: job by job (the device form runs the same plans in one launch, bit-identical to its own
+// job-by-job form)
+void gemm_dw_group(hipStream_t s, const GemmJob* jobs, int n, float* ws, size_t, size_t plan_floats) {
+    for (int i = 0; i < n; ++i) {
+        const GemmJob& q = jobs[i];
+        GemmEpi e; e.act = 0; e.out2 = nullptr; e.drop.p = 0.f; e.drop.seed = 0; e.drop.site = 0; e.dbias = q.dbias;
+        gemm(s, 1, 0, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, nullptr, 1, ws, plan_floats, &e);
+    }
+}
 bool fused_available(const FusedDims&) { return false; }
 void fused_pack_block(hipStream_t, const FusedDims&, const FusedBlockParams&, float*) {}
 void fused_chain_a(hipStream_t, const FusedDims&, const FusedTopo&, const FusedBlockParams&, const float*, const float*, const float*, const float*,

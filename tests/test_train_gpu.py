@@ -351,6 +351,15 @@ def test_fused_forward_chains_equal_the_op_by_op_forward(cfg_name, n_nodes, over
                 bad.append("%s: %.3e of %.3e" % (name, err, scale))
         assert not bad, "fused %s vs op-by-op gradients differ:\n  " % (key,) + "\n  ".join(bad[:30])
     assert any(not torch.equal(a, b) for a, b in zip(res[(1, 1)][2], res[(1, 0)][2]))       # the fused backward really ran
+    # the weight-gradient products of the fused backward run in grouped launches (train_gemm.hip gemm_dw_group, option 3): the same
+    # plans and the same arithmetic as one launch per product — every gradient bit for bit
+    model.train_options = {0: 1, 1: 1, 3: 0}
+    model.zero_grad()
+    torch.manual_seed(77)
+    ox, oe = model(d(nl), d(xh), d(nm), d(em), d(ctx), edge_x=d(ex), cond_x=d(cx), cond_edge_x=d(cex), noise_level=d(nl))
+    ((ox * d(d_x)).sum() + (oe * d(d_e)).sum()).backward()
+    diff = [name for (name, _), p, g in zip(model.named_parameters(), model.parameters(), res[(1, 1)][2]) if not torch.equal(p.grad.cpu(), g)]
+    assert not diff, "grouped and one-by-one weight gradients differ: %s" % diff[:20]
     # the no-grad call of a training step (self-conditioning forward, losses.py:335-339: dropout active, nothing differentiated) skips
     # the stores only a backward reads (jodo_train_set_option 2): same outputs bit for bit, and a grad-enabled call afterwards still works
     model.train_options = {0: 1, 1: 1}
