@@ -375,6 +375,19 @@ int jodo_train_gemm(int tA, int tB, int M, int N, int K, const float* A, int lda
 int jodo_train_gemm_ex(int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                        const float* bias, int act, float* out2, float* dbias, float* ws, size_t ws_floats, void* stream);
 
+/* ---- optimiser side of the training step on flat buffers (csrc/train_optim.hip; host mirror: jodo_amd/optim.py) ----------------------
+ * jodo_adam_step  <- optimizer.step() of the optimisers get_optimizer builds, losses.py:14-26: torch.optim.AdamW(amsgrad=True,
+ *   weight_decay=1e-12) (decoupled = 1) or torch.optim.Adam (decoupled = 0: L2 term added to the gradient), torch's single-tensor
+ *   formulas, on n contiguous floats at once: every parameter of the module a slice of p, its gradient the same slice of g, m / v / vmax
+ *   the moment buffers (vmax only with amsgrad).  step = 1 for the first update (bias corrections 1 - beta^step, formed in double).
+ * jodo_gradnorm_clip  <- gradient_clipping, losses.py:29-50, with the history of recent gradient norms (Queue, :53-72) on the device:
+ *   state_dev = double[52] (history[50], count, next slot; the caller writes {3000, 0, ..., count = 1, slot = 1} once, :77-78);
+ *   norm_dev = the gradient's 2-norm; writes coef_dev = min(1, allowed / (norm + 1e-6)), allowed_dev = min(1.5 mean + 2 std, max_grad),
+ *   and pushes min(norm, allowed) to the history.  No host synchronisation: the caller multiplies the flat gradient by *coef_dev. */
+int jodo_adam_step(int64_t n, float* p, const float* g, float* m, float* v, float* vmax, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int64_t step, int decoupled, int amsgrad, void* stream);
+int jodo_gradnorm_clip(const float* norm_dev, double* state_dev, double max_grad, float* coef_dev, float* allowed_dev, void* stream);
+
 const char* jodo_last_error(void);
 
 /* measurement helper (synchronises, default stream): fp32 MFMA throughput of the box in TFLOP/s from a

@@ -512,7 +512,11 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         char* beg = reinterpret_cast<char*>(c.g(i));
         size_t bytes = t.numel[i] * 4;
         int j = i + 1;
-        while (j < t.n_params && reinterpret_cast<char*>(c.g(j)) == beg + bytes) { bytes += t.numel[j] * 4; ++j; }
+        // (adjacent, or behind an alignment gap of a few floats — jodo_amd/optim.py slice_offsets — which is filled along)
+        while (j < t.n_params && reinterpret_cast<char*>(c.g(j)) >= beg + bytes && reinterpret_cast<char*>(c.g(j)) - (beg + bytes) < 64) {
+            bytes = (size_t)(reinterpret_cast<char*>(c.g(j)) - beg) + t.numel[j] * 4;
+            ++j;
+        }
         (void)hipMemsetAsync(beg, 0, bytes, s);
         i = j;
     }

@@ -23,13 +23,20 @@ from .utils import expand_dims, get_self_cond_fn
 
 
 def get_optimizer(config, params):
-    """losses.py:14-27 of the reference: the same torch optimisers with the same hyper-parameters.  On the GPU the update runs as
-    torch's fused multi-tensor kernel (one launch over all 351 tensors instead of a dozen foreach passes: clipping + update 4.0 -> 3.3 ms
-    per step at QM9, 2.6 ms with the clipping on the flat gradient buffer below);
-    JODO_OPTIM_FUSED=0 keeps torch's default implementation."""
+    """losses.py:14-27 of the reference: the same optimisers with the same hyper-parameters.  On the GPU the parameters are moved onto
+    one flat buffer and the update is one kernel over it (jodo_amd/optim.py FlatAdam -> jodo_adam_step: torch's single-tensor Adam / AdamW
+    formulas; clipping + update 3.2 ms -> a few launches per step at QM9, where the 351-tensor multi-tensor pass was bound by its host
+    side).  JODO_OPTIM_FLAT=0 keeps torch's fused multi-tensor optimisers (round 4's form), JODO_OPTIM_FUSED=0 torch's defaults; CPU
+    parameters always get torch's own."""
     o = config.optim
     params = list(params)
-    fused = bool(params) and all(p.is_cuda for p in params) and os.environ.get('JODO_OPTIM_FUSED', '1') != '0'
+    on_gpu = bool(params) and all(p.is_cuda for p in params)
+    if on_gpu and os.environ.get('JODO_OPTIM_FLAT', '1') != '0' and o.optimizer in ('Adam', 'AdamW'):
+        from .optim import FlatAdam
+        if o.optimizer == 'Adam':
+            return FlatAdam(params, lr=o.lr, betas=(o.beta1, 0.999), eps=o.eps, weight_decay=o.weight_decay, amsgrad=False, decoupled=False)
+        return FlatAdam(params, lr=o.lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-12, amsgrad=True, decoupled=True)
+    fused = on_gpu and os.environ.get('JODO_OPTIM_FUSED', '1') != '0'
     if o.optimizer == 'Adam':
         return torch.optim.Adam(params, lr=o.lr, betas=(o.beta1, 0.999), eps=o.eps, weight_decay=o.weight_decay, fused=fused or None)
     if o.optimizer == 'AdamW':
@@ -60,29 +67,9 @@ class Queue:
 def _flat_gradient(params):
     """The one buffer every p.grad is a slice of (jodo_train_backward writes all gradients into one allocation, jodo_amd/train.py;
     autograd hands the slices to p.grad without copying), as a 1-D tensor over that storage — or None when the gradients are ordinary
-    separate tensors, or do not tile their storage exactly."""
-    store, spans, dtype = None, [], None
-    for p in params:
-        g = p.grad
-        if g is None or not g.is_contiguous() or g.dtype != torch.float32:
-            return None
-        st = g.untyped_storage()
-        if store is None:
-            store, dtype = st, g.dtype
-        elif st.data_ptr() != store.data_ptr():
-            return None
-        spans.append((g.storage_offset(), g.numel()))
-    if store is None:
-        return None
-    spans.sort()
-    at = 0
-    for off, n in spans:
-        if off != at:
-            return None
-        at += n
-    if at * 4 != store.nbytes():
-        return None
-    return torch.empty(0, dtype=dtype, device=params[0].grad.device).set_(store, 0, (at,))
+    separate tensors, or do not tile their storage in the layout of jodo_amd/optim.py slice_offsets."""
+    from .optim import flat_view
+    return flat_view([p.grad for p in params])
 
 
 def _clip_grad_norm(params, max_norm):
@@ -115,15 +102,31 @@ def optimization_manager(config):
     gradnorm_queue = Queue()
     gradnorm_queue.add(3000)                       # large first entry, flushed by the history
     disable_log = config.optim.disable_grad_log
+    device_queue = {}                              # device -> DeviceGradNormQueue (the same history, kept where the gradient is)
 
     def optimize_fn(optimizer, params, step, lr=config.optim.lr, warmup=config.optim.warmup, grad_clip=config.optim.grad_clip):
         if warmup > 0:
             for g in optimizer.param_groups:
                 g['lr'] = lr * np.minimum(step / warmup, 1.0)
         if grad_clip >= 0:
-            gradient_clipping(params, gradnorm_queue, grad_clip, disable_log)
+            params = list(params)
+            flat = None
+            if grad_clip > 1.0 and disable_log and params and params[0].is_cuda and os.environ.get('JODO_OPTIM_FLAT', '1') != '0':
+                from .optim import flat_gradient
+                flat = flat_gradient(params)
+            if flat is not None:
+                # nothing is printed, so nothing on the host needs the norm: history, decision and scaling stay on the device
+                # (jodo_gradnorm_clip) and the step runs without a host synchronisation
+                dq = device_queue.get(flat.device)
+                if dq is None:
+                    from .optim import DeviceGradNormQueue
+                    dq = device_queue[flat.device] = DeviceGradNormQueue(flat.device, first=3000.0)
+                dq.clip_(flat, grad_clip)
+            else:
+                gradient_clipping(params, gradnorm_queue, grad_clip, disable_log)
         optimizer.step()
 
+    optimize_fn.gradnorm_queue, optimize_fn.device_queue = gradnorm_queue, device_queue     # (tests read the histories)
     return optimize_fn
 
 

@@ -30,14 +30,40 @@ class ExponentialMovingAverage:
             self.num_updates += 1
             d = min(d, (1 + self.num_updates) / (10 + self.num_updates))
         # the reference's per-tensor `s.sub_((1 - d) * (s - p))` (models/ema.py:38-40) as three multi-tensor launches instead of
-        # 3 x 351: the same three roundings per element, bit-identical (tests/test_losses_host.py), 1 050 launches fewer per step
+        # 3 x 351: the same three roundings per element, bit-identical (tests/test_losses_host.py), 1 050 launches fewer per step.
+        # Parameters that are slices of one flat buffer (jodo_amd/optim.py FlatAdam): the shadow is flattened the same way once and
+        # the three operations run on the two flat tensors — no per-tensor host work at all (same roundings again).
         with torch.no_grad():
             params = self._trainable(parameters)
             if len(params) != len(self.shadow_params):
                 raise ValueError(f'EMA holds {len(self.shadow_params)} tensors, the model has {len(params)} trainable parameters')
+            flat_p = self._flat_params(params)
+            if flat_p is not None:
+                delta = self._flat_shadow - flat_p
+                delta.mul_(1.0 - d)
+                self._flat_shadow.sub_(delta)
+                return
             delta = torch._foreach_sub(self.shadow_params, params)
             torch._foreach_mul_(delta, 1.0 - d)
             torch._foreach_sub_(self.shadow_params, delta)
+
+    def _flat_params(self, params):
+        """The parameters' flat buffer when they have one AND the shadow could be flattened to match it (done on first use)."""
+        if not params or not params[0].is_cuda:
+            return None
+        from ..optim import flat_parameters, flatten_parameters, flat_total
+        total = getattr(self, '_total', None)
+        if total is None:
+            total = self._total = flat_total(params)
+        flat_p = flat_parameters(params, total)
+        if flat_p is None:
+            return None
+        if getattr(self, '_flat_shadow', None) is None or self._flat_shadow_of is not self.shadow_params:
+            if any(s.shape != p.shape or s.device != p.device or s.dtype != torch.float32 for s, p in zip(self.shadow_params, params)):
+                return None
+            self._flat_shadow = flatten_parameters(self.shadow_params)       # (shadow tensors are plain tensors: `.data` re-pointing works on them too)
+            self._flat_shadow_of = self.shadow_params
+        return flat_p
 
     def copy_to(self, parameters):
         params = self._trainable(parameters)

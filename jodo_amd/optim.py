@@ -1,0 +1,227 @@
+"""Optimiser side of the training step on flat buffers (host mirror of csrc/train_optim.hip).
+
+The reference builds `torch.optim.AdamW(params, amsgrad=True, weight_decay=1e-12)` or `torch.optim.Adam` (losses.py:14-26), clips the
+gradient against the recent history of its norm (gradient_clipping :29-50, Queue :53-72) and keeps an exponential moving average of
+the 351 parameter tensors (models/ema.py).  On the GPU each of those was a pass over a LIST of tensors — list building, per-tensor state
+look-ups and a host synchronisation for the norm, 4.6 ms of a 23 ms step at the QM9 batch with the card idle.  Here
+
+  * `flatten_parameters` re-points every parameter at its slice of ONE allocation (values kept; `p.data_ptr()` changes once),
+  * `FlatAdam` is a `torch.optim.Optimizer` whose `step()` is one kernel over that allocation (`jodo_adam_step`), with the moment
+    buffers flat as well and exposed per parameter (as views) through the usual `optimizer.state[p]` / `state_dict()`,
+  * `DeviceGradNormQueue` keeps the clipping history on the device (`jodo_gradnorm_clip`): no host synchronisation in a step.
+
+There is no CPU fallback: `get_optimizer` (jodo_amd/losses.py) hands CPU parameters to torch's own optimisers, and FlatAdam refuses them.
+"""
+import ctypes
+
+import torch
+
+from . import capi
+
+
+ALIGN = 4          # floats: every slice starts on a 16-byte boundary (the training GEMM's 16-byte loads, csrc/train_gemm.hip, need that of
+                   # weights and gradients; a 3-float bias would otherwise push everything behind it off alignment)
+
+
+def slice_offsets(numels, align=ALIGN):
+    """Start of every slice in a flat buffer (floats) and the buffer's length: slices in order, each start rounded up to `align`; the
+    gaps (at most align - 1 floats each) stay zero for ever — zero gradient, zero moments, zero update."""
+    offs, at = [], 0
+    for n in numels:
+        at = (at + align - 1) // align * align
+        offs.append(at)
+        at += n
+    return offs, (at + align - 1) // align * align
+
+
+def flat_view(tensors):
+    """The 1-D tensor over the storage that `tensors` tile in list order with the slice_offsets layout (float32, contiguous) — or None."""
+    if not tensors or tensors[0] is None:
+        return None
+    t0 = tensors[0]
+    store = t0.untyped_storage()
+    base = store.data_ptr()
+    if any(t is None for t in tensors):
+        return None
+    offs, total = slice_offsets([t.numel() for t in tensors])
+    for t, o in zip(tensors, offs):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.untyped_storage().data_ptr() != base or t.storage_offset() != o:
+            return None
+    if total * 4 != store.nbytes():
+        return None
+    return torch.empty(0, dtype=torch.float32, device=t0.device).set_(store, 0, (total,))
+
+
+def carve(flat, shapes, offsets):
+    """The slices of `flat` as tensors of the given shapes."""
+    out = []
+    for shp, o in zip(shapes, offsets):
+        n = 1
+        for d in shp:
+            n *= d
+        out.append(flat[o:o + n].view(shp))
+    return out
+
+
+def flatten_parameters(params):
+    """Re-point every parameter at its slice of one new allocation (registration order, slice_offsets layout, values copied).  Returns the
+    flat tensor; parameters that already have that layout are left where they are."""
+    params = list(params)
+    flat = flat_view([p.data for p in params])
+    if flat is not None:
+        return flat
+    if any(p.dtype != torch.float32 for p in params):
+        raise TypeError("flatten_parameters: float32 parameters only")
+    offs, total = slice_offsets([p.numel() for p in params])
+    flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+    with torch.no_grad():
+        for p, piece in zip(params, carve(flat, [tuple(p.shape) for p in params], offs)):
+            piece.copy_(p.data)
+            p.data = piece
+    return flat
+
+
+def _cheap_flat(t0, t1, total):
+    """first / last slice and the storage's size: the per-step form of flat_view (the slices in between come from the same loop)"""
+    if t0 is None or t1 is None or t0.dtype != torch.float32:
+        return None
+    store = t0.untyped_storage()
+    end = (t1.storage_offset() + t1.numel() + ALIGN - 1) // ALIGN * ALIGN
+    if store.nbytes() != 4 * total or t0.storage_offset() != 0 or t1.untyped_storage().data_ptr() != store.data_ptr() or end != total:
+        return None
+    return torch.empty(0, dtype=torch.float32, device=t0.device).set_(store, 0, (total,))
+
+
+def flat_total(params):
+    return slice_offsets([p.numel() for p in params])[1]
+
+
+def flat_parameters(params, total=None):
+    """The flat buffer `params` (a list) are slices of, or None (cheap check: see _cheap_flat)."""
+    if not params[0].is_cuda:
+        return None
+    return _cheap_flat(params[0].data, params[-1].data, flat_total(params) if total is None else total)
+
+
+def flat_gradient(params, total=None, full_check=False):
+    """The flat gradient buffer of `params` (a list) — jodo_amd/train.py hands every gradient out as a slice of one allocation with the
+    slice_offsets layout — or None when the gradients are ordinary separate tensors."""
+    if total is None:
+        total = flat_total(params)
+    if not full_check:
+        base = _cheap_flat(params[0].grad, params[-1].grad, total)
+        if base is not None:
+            return base
+    return flat_view([p.grad for p in params])
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam (decoupled=False) / AdamW (decoupled=True) on one flat parameter buffer: the single-tensor formulas of
+    torch/optim/adam.py / adamw.py, one launch per step.  One parameter group; `param_groups[0]['lr']` may be changed between steps
+    (the reference's warm-up does, losses.py:84-86)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, decoupled=True):
+        params = list(params)
+        if not params or isinstance(params[0], dict):
+            raise ValueError("FlatAdam takes one flat list of parameters")
+        if not all(p.is_cuda for p in params):
+            raise capi.JodoHipError("FlatAdam runs on the GPU only (no CPU fallback): use torch.optim for CPU parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, decoupled=decoupled))
+        self._params = params
+        self._flat = flatten_parameters(params)
+        self._total = self._flat.numel()
+        self._m = torch.zeros_like(self._flat)
+        self._v = torch.zeros_like(self._flat)
+        self._vmax = torch.zeros_like(self._flat) if amsgrad else None
+        self._step = 0
+        self._step_t = torch.zeros((), dtype=torch.float32)          # one host tensor shared by every state entry, like torch's 'step'
+        self._checked = False
+        shapes = self._shapes = [tuple(p.shape) for p in params]
+        offs = self._offs = slice_offsets([p.numel() for p in params])[0]
+        ms, vs = carve(self._m, shapes, offs), carve(self._v, shapes, offs)
+        xs = carve(self._vmax, shapes, offs) if amsgrad else None
+        for i, p in enumerate(params):
+            st = self.state[p]
+            st['step'] = self._step_t
+            st['exp_avg'], st['exp_avg_sq'] = ms[i], vs[i]
+            if amsgrad:
+                st['max_exp_avg_sq'] = xs[i]
+        L = capi.lib()
+        L.jodo_adam_step.argtypes = [ctypes.c_int64] + [ctypes.c_void_p] * 5 + [ctypes.c_double] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                                                                                      ctypes.c_void_p]
+        self._L = L
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        g = self.param_groups[0]
+        if flat_parameters(self._params, self._total) is None:
+            raise RuntimeError("FlatAdam: the parameters were moved off the flat buffer (model.to(...) after the optimiser was built?)")
+        grad = flat_gradient(self._params, self._total, full_check=not self._checked)
+        self._checked = True
+        if grad is None:                                             # ordinary separate gradients: gathered into one buffer (one launch)
+            if any(p.grad is None for p in self._params):
+                raise RuntimeError("FlatAdam: every parameter needs a gradient (the HIP training path writes all of them)")
+            grad = torch.zeros_like(self._flat)
+            torch._foreach_copy_(carve(grad, self._shapes, self._offs), [p.grad for p in self._params])
+        self._step += 1
+        self._step_t.fill_(self._step)
+        b1, b2 = g['betas']
+        capi.check(self._L.jodo_adam_step(self._total, capi.ptr(self._flat), capi.ptr(grad), capi.ptr(self._m), capi.ptr(self._v), capi.ptr(self._vmax),
+                                          float(g['lr']), float(b1), float(b2), float(g['eps']), float(g['weight_decay']), self._step,
+                                          1 if g['decoupled'] else 0, 1 if g['amsgrad'] else 0, capi.current_stream_ptr()), 'jodo_adam_step')
+        # the kernel wrote through raw pointers: tell autograd / the packed-weight cache of the HIP module (models/dgt.py _weights)
+        torch.autograd.graph.increment_version(self._params)
+        return loss
+
+    def load_state_dict(self, state_dict):
+        """Values go INTO the flat moment buffers (torch's loader would replace the per-parameter views by separate tensors)."""
+        packed = state_dict['state']
+        for i, p in enumerate(self._params):
+            src = packed.get(i)
+            if src is None:
+                continue
+            st = self.state[p]
+            for k in ('exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'):
+                if k in st and k in src:
+                    st[k].copy_(src[k])
+            self._step = int(src['step'])
+        self._step_t.fill_(self._step)
+        for k, v in state_dict['param_groups'][0].items():
+            if k != 'params':
+                self.param_groups[0][k] = v
+
+
+class DeviceGradNormQueue:
+    """The reference's Queue of recent gradient norms (losses.py:53-72: newest first, at most 50, mean / std of what is there) kept on the
+    device together with the clipping decision that reads it (jodo_gradnorm_clip): a step never waits for the norm."""
+
+    def __init__(self, device, first=3000.0, max_len=50):
+        if max_len != 50:
+            raise ValueError("the device history holds 50 norms")
+        st = torch.zeros(52, dtype=torch.float64)
+        st[0], st[50], st[51] = first, 1, 1
+        self.state = st.to(device)
+        self.coef = torch.ones((), dtype=torch.float32, device=device)
+        self.allowed = torch.zeros((), dtype=torch.float32, device=device)
+        L = capi.lib()
+        L.jodo_gradnorm_clip.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self._L = L
+
+    def clip_(self, flat_grad, max_grad):
+        """flat_grad *= min(1, allowed / (|flat_grad| + 1e-6)), allowed = min(1.5 mean + 2 std of the history, max_grad); the history
+        gets min(norm, allowed).  Returns the (device) norm before clipping."""
+        total = torch.linalg.vector_norm(flat_grad, 2.0)
+        capi.check(self._L.jodo_gradnorm_clip(capi.ptr(total), capi.ptr(self.state), float(max_grad), capi.ptr(self.coef), capi.ptr(self.allowed),
+                                              capi.current_stream_ptr()), 'jodo_gradnorm_clip')
+        flat_grad.mul_(self.coef)
+        return total
+
+    def items(self):
+        """The history as a host list, newest first (synchronises; tests and logging)."""
+        st = self.state.cpu()
+        cnt, nxt = int(st[50]), int(st[51])
+        return [float(st[(nxt - 1 - i) % 50]) for i in range(cnt)]

@@ -195,13 +195,16 @@ class TrainEngine:
         if slot is None:
             raise RuntimeError("the activations of this forward were overwritten by later training-path forwards of the same module "
                                "(%d activation workspaces per module, INTEGRATION.md §5); call backward earlier" % len(self.pool['slots']))
-        # one allocation for all gradients (the library then zeroes them with a single fill)
-        sizes = [p.numel() for p in params]
-        flat = torch.empty(sum(sizes), dtype=torch.float32, device=params[0].device)
-        grads, off = [], 0
-        for p, n in zip(params, sizes):
-            grads.append(flat[off:off + n].view(p.shape))
-            off += n
+        # one allocation for all gradients (the library then zeroes them with a single fill), every slice on a 16-byte boundary — the
+        # layout of jodo_amd/optim.py slice_offsets, which the flat optimiser's parameter buffer has too
+        lay = self.__dict__.get('_grad_layout')
+        if lay is None:
+            from .optim import slice_offsets
+            offs, total = slice_offsets([p.numel() for p in params])
+            lay = self._grad_layout = ([tuple(p.shape) for p in params], offs, total)
+        from .optim import carve
+        flat = torch.empty(lay[2], dtype=torch.float32, device=params[0].device)
+        grads = carve(flat, lay[0], lay[1])
         self._check(self.L.jodo_train_backward(
             self.handle, capi.ptr(self.desc), self._ptrs(params), self._ptrs(grads), self.n_params, capi.ptr(noise_level),
             capi.ptr(d_out_x), capi.ptr(d_out_e), ctypes.c_float(dropout_p), ctypes.c_uint64(seed), capi.ptr(slot['buf']),

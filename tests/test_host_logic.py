@@ -165,3 +165,25 @@ def test_scaling_prediction_runs_on_the_host():
     dealt = scaling.predict_dealt(cs, n_all, 4, 64, 1)
     assert dealt['lpt']['predicted_efficiency'] >= dealt['contiguous']['predicted_efficiency'] - 1e-3
     assert sum(dealt['lpt']['molecules_per_rank']) == 256 and sum(dealt['contiguous']['molecules_per_rank']) == 256
+
+
+def test_flatten_parameters_keeps_values_order_and_views():
+    """jodo_amd/optim.py flatten_parameters (host logic of the flat optimiser): every parameter becomes a slice of one buffer in
+    registration order, values kept; flat_view recognises exactly that layout."""
+    import torch
+    from jodo_amd import optim as JO
+    g = torch.Generator().manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in [(3, 5), (7,), (2, 2, 2)]]
+    want = [p.detach().clone() for p in ps]
+    assert JO.flat_view([p.data for p in ps]) is None
+    flat = JO.flatten_parameters(ps)
+    assert JO.slice_offsets([15, 7, 8]) == ([0, 16, 24], 32)                       # every slice on a 16-byte boundary
+    assert flat.numel() == 32 and all(torch.equal(p.data, w) for p, w in zip(ps, want))
+    assert torch.equal(flat[:15], want[0].reshape(-1)) and float(flat[15]) == 0.0 and torch.equal(flat[16:23], want[1]) and float(flat[23]) == 0.0
+    again = JO.flat_view([p.data for p in ps])
+    assert again is not None and again.data_ptr() == flat.data_ptr()
+    assert JO.flatten_parameters(ps).data_ptr() == flat.data_ptr()                 # already flat: left where they are
+    flat.mul_(2.0)
+    assert all(torch.equal(p.data, 2.0 * w) for p, w in zip(ps, want))            # views, not copies
+    assert JO.flat_view([ps[1].data, ps[0].data, ps[2].data]) is None             # order matters
+    assert JO.flat_view([p.data for p in ps[:2]]) is None                         # must tile the whole storage

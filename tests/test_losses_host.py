@@ -126,15 +126,17 @@ def test_clipping_on_the_flat_gradient_buffer_is_clip_grad_norm():
     from jodo_amd import losses as L
     g = torch.Generator().manual_seed(3)
     shapes = [(5, 7), (11,), (2, 3, 2)]
-    flat = torch.randn(sum(torch.Size(s).numel() for s in shapes), generator=g) * 10
+    from jodo_amd.optim import slice_offsets
+    offs, total = slice_offsets([torch.Size(s).numel() for s in shapes])   # every slice on a 16-byte boundary: 0, 36, 48 of 60 floats
+    assert offs == [0, 36, 48] and total == 60
+    flat = torch.zeros(total)
     a = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
     b = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
-    off = 0
-    for pa, pb in zip(a, b):
+    for pa, pb, off in zip(a, b, offs):
         n = pa.numel()
+        flat[off:off + n] = torch.randn(n, generator=g) * 10
         pa.grad = flat[off:off + n].view(pa.shape).detach()          # what autograd leaves in p.grad: an alias without a base
         pb.grad = flat[off:off + n].view(pb.shape).clone()
-        off += n
     fa = L._flat_gradient(a)
     assert fa is not None and fa.data_ptr() == flat.data_ptr() and fa.shape == flat.shape and L._flat_gradient(b) is None
     want = torch.nn.utils.clip_grad_norm_(b, max_norm=2.5, norm_type=2.0)
