@@ -359,6 +359,9 @@ int jodo_train_set_option(jodo_train* t, int option, int value);
  * layers.py:153), 1 = alpha [R, H] (softmax weights, layers.py:178) of block `layer` */
 int jodo_train_debug_locate(const jodo_train* t, int what, int layer, size_t* byte_offset, size_t* count);
 int jodo_train_upload(jodo_train* t, void* desc_dev, void* stream);
+/* the host image jodo_train_upload copies (jodo_train_desc_bytes() bytes, owned by the handle): callers that stage it through pinned
+ * memory themselves upload it without jodo_train_upload's stream synchronisation */
+const void* jodo_train_desc_host(const jodo_train* t);
 int jodo_train_forward(jodo_train* t, const void* desc_dev, const float* const* params_dev, int n_params, const float* xh,
                        const float* edge_x, const float* cond_x, const float* cond_edge_x, const float* noise_level,
                        const float* context, float dropout_p, uint64_t seed, float* out_xh, float* out_edge, int32_t* flags_out,
@@ -375,7 +378,7 @@ int jodo_train_gemm(int tA, int tB, int M, int N, int K, const float* A, int lda
 int jodo_train_gemm_ex(int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                        const float* bias, int act, float* out2, float* dbias, float* ws, size_t ws_floats, void* stream);
 
-/* ---- optimiser side of the training step on flat buffers (csrc/train_optim.hip; host mirror: jodo_amd/optim.py) ----------------------
+/* ---- optimiser side of the training step on flat buffers (csrc/train_step.hip; host mirror: jodo_amd/optim.py) ----------------------
  * jodo_adam_step  <- optimizer.step() of the optimisers get_optimizer builds, losses.py:14-26: torch.optim.AdamW(amsgrad=True,
  *   weight_decay=1e-12) (decoupled = 1) or torch.optim.Adam (decoupled = 0: L2 term added to the gradient), torch's single-tensor
  *   formulas, on n contiguous floats at once: every parameter of the module a slice of p, its gradient the same slice of g, m / v / vmax
@@ -387,6 +390,10 @@ int jodo_train_gemm_ex(int tA, int tB, int M, int N, int K, const float* A, int 
 int jodo_adam_step(int64_t n, float* p, const float* g, float* m, float* v, float* vmax, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int64_t step, int decoupled, int amsgrad, void* stream);
 int jodo_gradnorm_clip(const float* norm_dev, double* state_dev, double max_grad, float* coef_dev, float* allowed_dev, void* stream);
+/* jodo_kabsch_rotations  <- kabsch_batch, losses.py:424-434, behind the covariance einsum: A_dev [B, 3, 3] (A = P^T Q per molecule) ->
+ *   R_dev [B, 3, 3] = U diag(1, 1, sign det A) V^T of A = U S V^T.  Replaces torch.linalg.svd + det + diag_embed + einsum, whose error
+ *   check synchronises the host with the device (the last synchronisation of a training step). */
+int jodo_kabsch_rotations(int B, const float* A_dev, float* R_dev, void* stream);
 
 const char* jodo_last_error(void);
 

@@ -915,6 +915,9 @@ int jodo_train_debug_locate(const jodo_train* t, int what, int layer, size_t* by
     *count = n;
     return JODO_OK;
 }
+// the host image of the index tables (jodo_train_desc_bytes() bytes, alive as long as the handle): a caller that stages it through
+// pinned memory uploads without the stream synchronisation of jodo_train_upload (jodo_amd/train.py does)
+const void* jodo_train_desc_host(const jodo_train* t) { return t ? t->tables.data() : nullptr; }
 int jodo_train_upload(jodo_train* t, void* desc_dev, void* stream) {
     if (!t || !desc_dev) return jodo_set_error(JODO_ERR_ARG, "jodo_train_upload: null argument");
     (void)hipMemcpyAsync(desc_dev, t->tables.data(), t->tables.size() * sizeof(int), hipMemcpyHostToDevice, static_cast<hipStream_t>(stream));

@@ -1,9 +1,12 @@
-// Optimiser side of the training step (/root/reference/losses.py:14-26 get_optimizer, :29-50 gradient_clipping,
+// The small kernels of a training step outside the network: optimiser update, clipping decision, Kabsch rotations.
+// Optimiser side ( /root/reference/losses.py:14-26 get_optimizer, :29-50 gradient_clipping,
 // :75-94 optimization_manager) on FLAT buffers: every parameter of the module is a slice of one allocation (jodo_amd/optim.py
 // flatten_parameters), the gradients already are (jodo_amd/train.py), so the update is ONE elementwise kernel over ~5.6 M floats
 // instead of a multi-tensor pass over 351 tensors whose host side (list building, per-tensor state look-ups) cost 3 ms of a 23 ms step —
 // and the adaptive clipping's history lives on the device, so that a step has no host synchronisation left between its backward and the
 // next batch.  Both are HBM streams: p, g, m, v, vmax read + p, m, v, vmax written = 36 bytes per parameter.
+// Loss side (losses.py:424-434 kabsch_batch): the rotation of the Kabsch alignment per molecule, in place of torch.linalg.svd — whose
+// error check reads `info` back and was the last host synchronisation of a step.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -75,6 +78,64 @@ __global__ void k_gradnorm_clip(const float* __restrict__ norm, double* __restri
     st[51] = (double)((slot + 1) % 50);
 }
 
+// Kabsch rotation of one molecule from its 3 x 3 covariance A = P^T Q (losses.py:426-432):  A = U S V^T,  R = U diag(1, 1, sign det A) V^T.
+// One thread per molecule, in double: Jacobi eigen-decomposition of A^T A gives V (a proper rotation, columns ordered by descending
+// eigenvalue) ; u1 = A v1 / |.|, u2 = A v2 made orthogonal to u1, and the third pair follows from the other two — with V proper,
+// sign(det A) u3 = u1 x u2 whatever the sign of det A:   R = u1 v1^T + u2 v2^T + (u1 x u2) v3^T.
+// (det A == 0 exactly — an all-zero A — drops the third term like the reference's sign(0) = 0.)
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__global__ void k_kabsch(int B, const float* __restrict__ Ain, float* __restrict__ Rout) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double A[3][3], K[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = (double)Ain[b * 9 + i * 3 + j];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) K[i][j] = A[0][i] * A[0][j] + A[1][i] * A[1][j] + A[2][i] * A[2][j];
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        const double off = K[0][1] * K[0][1] + K[0][2] * K[0][2] + K[1][2] * K[1][2];
+        const double dia = K[0][0] * K[0][0] + K[1][1] * K[1][1] + K[2][2] * K[2][2];
+        if (off <= 1e-40 * dia || off == 0.0) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (K[p][q] == 0.0) continue;
+                const double theta = (K[q][q] - K[p][p]) / (2.0 * K[p][q]);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) { const double kp = K[k][p], kq = K[k][q]; K[k][p] = c * kp - s * kq; K[k][q] = s * kp + c * kq; }
+                for (int k = 0; k < 3; ++k) { const double kp = K[p][k], kq = K[q][k]; K[p][k] = c * kp - s * kq; K[q][k] = s * kp + c * kq; }
+                for (int k = 0; k < 3; ++k) { const double vp = V[k][p], vq = V[k][q]; V[k][p] = c * vp - s * vq; V[k][q] = s * vp + c * vq; }
+            }
+    }
+    // columns by descending eigenvalue
+    int o[3] = {0, 1, 2};
+    double ev[3] = {K[0][0], K[1][1], K[2][2]};
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2 - i; ++j)
+        if (ev[o[j]] < ev[o[j + 1]]) { const int tmp = o[j]; o[j] = o[j + 1]; o[j + 1] = tmp; }
+    double v1[3], v2[3], v3[3], u1[3], u2[3], u3[3];
+    for (int k = 0; k < 3; ++k) { v1[k] = V[k][o[0]]; v2[k] = V[k][o[1]]; }
+    cross3(v1, v2, v3);                                        // V proper
+    for (int i = 0; i < 3; ++i) { u1[i] = A[i][0] * v1[0] + A[i][1] * v1[1] + A[i][2] * v1[2]; u2[i] = A[i][0] * v2[0] + A[i][1] * v2[1] + A[i][2] * v2[2]; }
+    double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+    if (n1 > 0.0) { for (int i = 0; i < 3; ++i) u1[i] /= n1; } else { u1[0] = 1.0; u1[1] = u1[2] = 0.0; }
+    const double d12 = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
+    for (int i = 0; i < 3; ++i) u2[i] -= d12 * u1[i];
+    double n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+    if (n2 > 1e-150) { for (int i = 0; i < 3; ++i) u2[i] /= n2; }
+    else {                                                     // rank one: any unit vector orthogonal to u1
+        const int m = fabs(u1[0]) <= fabs(u1[1]) ? (fabs(u1[0]) <= fabs(u1[2]) ? 0 : 2) : (fabs(u1[1]) <= fabs(u1[2]) ? 1 : 2);
+        double e[3] = {0, 0, 0}; e[m] = 1.0;
+        cross3(u1, e, u2);
+        n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+        for (int i = 0; i < 3; ++i) u2[i] /= n2;
+    }
+    cross3(u1, u2, u3);
+    const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) + A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+    const double w3 = det == 0.0 ? 0.0 : 1.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rout[b * 9 + i * 3 + j] = (float)(u1[i] * v1[j] + u2[i] * v2[j] + w3 * u3[i] * v3[j]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -91,6 +152,12 @@ int jodo_adam_step(int64_t n, float* p, const float* g, float* m, float* v, floa
     const long quads = (n + 3) / 4;
     hipLaunchKernelGGL(k_adam, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)n, p, g, m, v, vmax, a);
     return jodo_check_launch("k_adam");
+}
+
+int jodo_kabsch_rotations(int B, const float* A_dev, float* R_dev, void* stream) {
+    if (B <= 0 || !A_dev || !R_dev) return jodo_set_error(JODO_ERR_ARG, "jodo_kabsch_rotations: null / empty argument");
+    hipLaunchKernelGGL(k_kabsch, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, B, A_dev, R_dev);
+    return jodo_check_launch("k_kabsch");
 }
 
 int jodo_gradnorm_clip(const float* norm_dev, double* state_dev, double max_grad, float* coef_dev, float* allowed_dev, void* stream) {

@@ -134,6 +134,13 @@ def get_step_fn(noise_scheduler, train, optimize_fn, scaler, config, prop_dist=N
     if not config.pred_edge or config.only_2D:
         raise NotImplementedError("the HIP path implements the 3D graph model (pred_edge, not only_2D)")
     loss_fn = get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_dist)
+    # A step on the HIP module has no host synchronisation of its own (tests/test_train_gpu.py), so the host could queue arbitrarily far
+    # ahead of the card (its side of a QM9 step is ~9 ms, the card's ~18).  The step therefore waits for the step BEFORE the one it has
+    # just queued: the card always has a whole step of work left, the queue — and the batches, staging buffers and activations it pins —
+    # never holds more than two.  JODO_TRAIN_RUNAHEAD = number of steps the host may be ahead (default 1; 0: wait for every step;
+    # -1: unbounded).
+    runahead = int(os.environ.get('JODO_TRAIN_RUNAHEAD', '1'))
+    in_flight = []
 
     def step_fn(state, batch):
         model = state['model']
@@ -145,6 +152,12 @@ def get_step_fn(noise_scheduler, train, optimize_fn, scaler, config, prop_dist=N
             optimize_fn(optimizer, model.parameters(), step=state['step'])
             state['step'] += 1
             state['ema'].update(model.parameters())
+            if loss.is_cuda and runahead >= 0:
+                ev = torch.cuda.Event()
+                ev.record()
+                in_flight.append(ev)
+                while len(in_flight) > runahead:
+                    in_flight.pop(0).synchronize()
             return loss
         averaged = state['ema']                      # evaluation runs under the averaged weights, then puts the live ones back
         with torch.no_grad():
@@ -171,6 +184,17 @@ def _weights_changed(model):
 def kabsch_batch(coords_pred, coords_tar):
     """Per molecule the rotation R minimising |coords_pred - coords_tar R^T| (Kabsch): A = P^T Q = U S V^T, R = U diag(1, 1, sign det A) V^T."""
     A = torch.einsum('...ki,...kj->...ij', coords_pred, coords_tar)
+    if A.is_cuda and A.dim() == 3 and A.dtype == torch.float32:
+        # one thread per molecule (csrc/train_step.hip k_kabsch: Jacobi in double) instead of torch.linalg.svd, whose error check reads
+        # `info` back: the last host synchronisation of a training step
+        import ctypes
+        from . import capi
+        A = A.contiguous()
+        R = torch.empty_like(A)
+        lib = capi.lib()
+        lib.jodo_kabsch_rotations.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        capi.check(lib.jodo_kabsch_rotations(A.shape[0], capi.ptr(A), capi.ptr(R), capi.current_stream_ptr()), 'jodo_kabsch_rotations')
+        return R
     U, _, Vt = torch.linalg.svd(A)
     fix = torch.ones(A.size(0), 3, device=A.device, dtype=A.dtype)
     fix[:, -1] = torch.sign(torch.det(A))
@@ -191,13 +215,86 @@ def get_align_noise(z_t, xh, alpha_t, sigma_t, noise, node_mask):
     return noise
 
 
+class _PinnedStager:
+    """Persistent pinned staging buffers for the host -> device copies of a batch: a ring of three sets (one per batch in flight), a
+    set reused only after the copies that last read it have completed.  (torch's `pin_memory()` allocates page-locked memory per call:
+    20 ms per QM9 batch, measured.)"""
+
+    def __init__(self, depth=3):
+        self.sets = [dict() for _ in range(depth)]
+        self.events = [None] * depth
+        self.at, self.cur = 0, 0
+
+    def begin(self):
+        self.cur = self.at
+        self.at = (self.at + 1) % len(self.sets)
+        if self.events[self.cur] is not None:
+            self.events[self.cur].synchronize()
+
+    def put(self, key, t, dev):
+        n = t.numel()
+        buf = self.sets[self.cur].get(key)
+        if buf is None or buf.numel() < n or buf.dtype != t.dtype:
+            buf = self.sets[self.cur][key] = torch.empty(int(n * 1.25) + 16, dtype=t.dtype, pin_memory=True)
+        view = buf[:n].view(t.shape)
+        # numpy, not Tensor.copy_: above its grain size a CPU torch operation opens an OpenMP region, and the pool's threads then spin on
+        # every core for a while — next to the thread that launches kernels and autograd's backward thread (measured: a QM9 step took
+        # 33 - 40 ms instead of 19 with three such copies in it)
+        np.copyto(view.numpy(), t.detach().contiguous().numpy())
+        return view.to(dev, non_blocking=True)
+
+    def end(self):
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[self.cur] = ev
+
+
+_STAGERS = {}
+
+
+def _host_counts(atom_mask, edge_mask):
+    """Atom counts of a batch that is still on the host (the reference's loader yields CPU tensors, moved to the device by
+    process_edge_batch, losses.py:470-476) — with the layout check the HIP training path otherwise runs on the device and reads back
+    (prefix node masks, edge mask = node x node without the diagonal).  None for batches that are already on a device."""
+    if atom_mask.device.type != 'cpu' or edge_mask.device.type != 'cpu':
+        return None
+    # (numpy throughout: single-threaded — see _PinnedStager.put)
+    B, N = atom_mask.shape[0], atom_mask.shape[1]
+    nm = atom_mask.detach().reshape(B, N).numpy()
+    counts = np.rint(nm.sum(1)).astype(np.int32)
+    prefix = np.arange(N)[None, :] < counts[:, None]
+    if not np.array_equal(prefix.astype(nm.dtype), nm):
+        raise ValueError("node_mask must be a prefix mask (real atoms first)")
+    want = prefix[:, :, None] & prefix[:, None, :] & ~np.eye(N, dtype=bool)[None]
+    em = edge_mask.detach().reshape(B, N, N).numpy()
+    if not np.array_equal(want.astype(em.dtype), em):
+        raise ValueError("edge_mask must be node_mask x node_mask with the diagonal removed")
+    return counts
+
+
 @torch.no_grad()
 def process_edge_batch(batch, device, include_charges, scaler, prop_norm):
     """Batch dict of the data loader -> (xh [B,N,3+nd], edge_x [B,N,N,ch], node_mask [B,N,1], edge_mask, context): positions
     centred per molecule, everything through the training scaler, conditioning properties standardised by their (mean, mad)."""
-    on = lambda key: batch[key].to(device)
+    dev = torch.device(device)
+    stage = None
+    if dev.type == 'cuda' and any(torch.is_tensor(v) and v.device.type == 'cpu' for v in batch.values()):
+        stage = _STAGERS.setdefault(str(dev), _PinnedStager())
+        stage.begin()
+
+    def on(key):
+        t = batch[key]
+        if stage is not None and t.device.type == 'cpu':
+            # the loader's CPU tensor goes through a pinned staging buffer and an asynchronous copy: `.to(device)` of pageable memory
+            # waits for everything queued on the stream (the previous step's backward and update) before it even starts
+            return stage.put(key, t, dev)
+        return t.to(dev)
+
     node_mask, edge_mask = on('atom_mask').unsqueeze(2), on('edge_mask')
-    charges = on('formal_charges') if include_charges else torch.zeros(0, device=device)
+    counts = _host_counts(batch['atom_mask'], batch['edge_mask'])
+    if counts is not None:
+        node_mask._jodo_counts = counts                      # read by the HIP module's training path (models/dgt.py _train_engine)
+    charges = on('formal_charges') if include_charges else torch.zeros(0, device=dev)
     centred = remove_mean_with_mask(on('positions'), node_mask)
     pos, atoms, charges, edges = scaler(centred, on('atom_one_hot'), charges, node_mask, on('edge_one_hot'), edge_mask)
     context = None
@@ -205,6 +302,8 @@ def process_edge_batch(batch, device, include_charges, scaler, prop_norm):
         context = on('context')
         for col, stats in enumerate(prop_norm.values()):
             context[:, col] = (context[:, col] - stats['mean']) / stats['mad']
+    if stage is not None:
+        stage.end()
     return torch.cat([pos, atoms, charges], dim=2), edges, node_mask, edge_mask, context
 
 

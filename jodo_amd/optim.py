@@ -1,4 +1,4 @@
-"""Optimiser side of the training step on flat buffers (host mirror of csrc/train_optim.hip).
+"""Optimiser side of the training step on flat buffers (host mirror of csrc/train_step.hip).
 
 The reference builds `torch.optim.AdamW(params, amsgrad=True, weight_decay=1e-12)` or `torch.optim.Adam` (losses.py:14-26), clips the
 gradient against the recent history of its norm (gradient_clipping :29-50, Queue :53-72) and keeps an exponential moving average of

@@ -121,7 +121,7 @@ class TrainEngine:
         # serve them all.  A slot's stamp names the forward whose activations it holds.
         self.ws_bytes = int(self.L.jodo_train_workspace_bytes(self.handle))
         self.pool = pool if pool is not None else self.new_pool()
-        self._check(self.L.jodo_train_upload(self.handle, capi.ptr(self.desc), self._stream()), 'jodo_train_upload')
+        self._upload_tables()
         self.flags = torch.zeros(8, dtype=torch.int32, device=device)
         self._slot = None
 
@@ -136,6 +136,33 @@ class TrainEngine:
             self.L.jodo_train_destroy(self.handle)
         except Exception:
             pass
+
+    def _upload_tables(self):
+        """Index tables -> device without a stream synchronisation: the handle's host image is staged through one of the pool's pinned
+        buffers (a ring of four; a buffer is reused only after the copy that last read it has completed) and copied asynchronously on
+        the current stream.  (jodo_train_upload, the plain C entry, synchronises instead: a shuffling loader creates an engine per
+        step, and that synchronisation was the last one left in a training step.)"""
+        n = int(self.desc.numel())
+        if self._stream is not capi.current_stream_ptr:          # a caller-chosen stream: the plain (synchronising) upload on that stream
+            self._check(self.L.jodo_train_upload(self.handle, capi.ptr(self.desc), self._stream()), 'jodo_train_upload')
+            return
+        ring = self.pool.setdefault('pin', {'bufs': [None] * 4, 'events': [None] * 4, 'next': 0})
+        i = ring['next']
+        ring['next'] = (i + 1) % len(ring['bufs'])
+        if ring['events'][i] is not None:
+            ring['events'][i].synchronize()
+        if ring['bufs'][i] is None or ring['bufs'][i].numel() < n:
+            ring['bufs'][i] = torch.empty(int(n * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+        self.L.jodo_train_desc_host.restype = ctypes.c_void_p
+        self.L.jodo_train_desc_host.argtypes = [ctypes.c_void_p]
+        src = self.L.jodo_train_desc_host(self.handle)
+        if not src:
+            raise capi.JodoHipError("jodo_train_desc_host returned NULL")
+        ctypes.memmove(ring['bufs'][i].data_ptr(), src, n)
+        self.desc.copy_(ring['bufs'][i][:n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring['events'][i] = ev
 
     @staticmethod
     def _ptrs(tensors):

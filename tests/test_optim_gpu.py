@@ -142,3 +142,25 @@ def test_flat_ema_update_is_the_per_tensor_update_bit_for_bit():
     ema_a.update(pa); ema_b.update(pb)
     for sa, sb in zip(ema_a.shadow_params, ema_b.shadow_params):
         assert torch.equal(sa, sb)
+
+
+def test_kabsch_rotations_match_the_svd_form():
+    """kabsch_batch (losses.py:424-434) on the device runs jodo_kabsch_rotations instead of torch.linalg.svd (which synchronises): the
+    same rotation U diag(1, 1, sign det A) V^T — proper and improper covariances, near-aligned point sets, and what it is used for
+    (get_align_position)."""
+    g = torch.Generator().manual_seed(5)
+    B, N = 300, 19
+    P = torch.randn(B, N, 3, generator=g)
+    Q = torch.randn(B, N, 3, generator=g)
+    rot = L.kabsch_batch(torch.randn(B, 4, 3, generator=g), torch.randn(B, 4, 3, generator=g))           # CPU: the reference's SVD form
+    Q[:100] = torch.einsum('bij,bnj->bni', rot[:100], P[:100]) + 0.01 * torch.randn(100, N, 3, generator=g)   # nearly a rotated copy
+    Q[100:150] = -Q[100:150]
+    want = L.kabsch_batch(P.double(), Q.double())                                                         # CPU float64, SVD
+    got = L.kabsch_batch(P.to(DEV), Q.to(DEV))
+    assert got.is_cuda and got.dtype == torch.float32
+    A = torch.einsum('...ki,...kj->...ij', P.double(), Q.double())
+    assert int((torch.det(A) < 0).sum()) > 20 and int((torch.det(A) > 0).sum()) > 20
+    torch.testing.assert_close(got.cpu().double(), want, rtol=0, atol=5e-6)
+    z = torch.cat([P, torch.zeros(B, N, 2)], -1).to(DEV)
+    x = torch.cat([Q, torch.zeros(B, N, 2)], -1).to(DEV)
+    torch.testing.assert_close(L.get_align_position(z, x).cpu().double(), L.get_align_position(z.cpu().double(), x.cpu().double()), rtol=0, atol=2e-5)

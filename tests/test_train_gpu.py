@@ -433,6 +433,50 @@ def test_training_steps_through_get_step_fn():
     close(got[1], want[1], atol=2e-5)
 
 
+def test_a_training_step_on_loader_batches_does_not_synchronise():
+    """The reference's loop (run_lib.py:346-351) hands CPU batch dicts to the step.  On the HIP module such a step — batch upload,
+    engine creation for new atom counts, both forwards, backward, clipping against the device-side history, FlatAdam, EMA — contains no
+    host synchronisation (torch's sync debug mode raises on one), so the host queues ahead of the card; and it computes the same
+    thing as the step on device-resident batches (which reads the atom counts back)."""
+    import random
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    from tools.train_bench import synthetic_batch
+    from jodo_amd import losses as L
+    from jodo_amd.diffusion import NoiseScheduleVP
+    from jodo_amd.models.ema import ExponentialMovingAverage
+    from jodo_amd.utils import get_data_scaler
+    from jodo_amd.optim import FlatAdam
+    cfg = make_config('vpsde_qm9_uncond_jodo')
+    cfg.device = torch.device(DEV)
+    counts = [[5, 9, 4, 12, 7, 9], [6, 6, 11, 3, 8, 10], [7, 5, 9, 9, 4, 13], [12, 4, 6, 8, 8, 5]]
+    batches = [synthetic_batch(cfg, c, 60 + i) for i, c in enumerate(counts)]
+
+    def run(on_device):
+        torch.manual_seed(5); random.seed(5)
+        model = make_model(cfg, 6, DEV, gain=1.0, coord_scale=0.05)
+        ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
+        state = dict(model=model, optimizer=L.get_optimizer(cfg, model.parameters()), ema=ExponentialMovingAverage(model.parameters(), decay=0.999), step=1)
+        assert isinstance(state['optimizer'], FlatAdam)
+        step_fn = L.get_step_fn(ns, True, L.optimization_manager(cfg), get_data_scaler(cfg), cfg)
+        out = []
+        for i, b in enumerate(batches):
+            if on_device:
+                b = {k: v.to(DEV) for k, v in b.items()}
+            elif i >= 2:                                                   # (the first steps allocate: workspaces, pinned staging buffers)
+                torch.cuda.set_sync_debug_mode('error')
+            try:
+                out.append(step_fn(state, b).detach())
+            finally:
+                torch.cuda.set_sync_debug_mode('default')
+        return [float(x) for x in out], [p.detach().cpu().clone() for p in model.parameters()]
+
+    la, pa = run(False)
+    lb, pb = run(True)
+    assert all(np.isfinite(la)) and la == lb
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb))
+
+
 def test_varying_batches_share_one_workspace():
     """Data loaders hand over different atom counts every step: every batch shape gets its own handle, all of them share the module's
     activation workspaces (grown to the largest request; a plain forward / backward loop stays in ONE of them).  Gradients of a batch do
