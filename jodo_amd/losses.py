@@ -140,6 +140,8 @@ def get_step_fn(noise_scheduler, train, optimize_fn, scaler, config, prop_dist=N
     # never holds more than two.  JODO_TRAIN_RUNAHEAD = number of steps the host may be ahead (default 1; 0: wait for every step;
     # -1: unbounded).
     runahead = int(os.environ.get('JODO_TRAIN_RUNAHEAD', '1'))
+    data_parallel = torch.distributed.is_available() and os.environ.get('JODO_TRAIN_ALLREDUCE', '1') != '0'
+
     in_flight = []
 
     def step_fn(state, batch):
@@ -149,6 +151,10 @@ def get_step_fn(noise_scheduler, train, optimize_fn, scaler, config, prop_dist=N
             optimizer.zero_grad()
             loss = loss_fn(model, batch)
             loss.backward()
+            if data_parallel and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                # one process per GPU, each on its own molecules: one all-reduce over the flat gradient buffer (jodo_amd/dist.py)
+                from .dist import allreduce_gradients
+                allreduce_gradients(list(model.parameters()), weight=batch['atom_mask'].shape[0])
             optimize_fn(optimizer, model.parameters(), step=state['step'])
             state['step'] += 1
             state['ema'].update(model.parameters())

@@ -175,3 +175,76 @@ def test_shard_range_covers_everything():
         spans = [shard_range(n, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _train_worker(rank, world, port, q):
+    """One rank of a data-parallel training step on the CPU: the training kernels' host-emulation build (tests/emul) computes this
+    rank's gradients, jodo_amd/dist.py allreduce_gradients averages them over the flat buffer."""
+    import ctypes
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    from helpers import make_config, make_model, masks, random_inputs
+    from jodo_amd.dist import allreduce_gradients
+    from jodo_amd.train import TrainEngine
+    from oracle import dgt_oracle as O
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    emul = ctypes.CDLL(os.path.join(here, 'emul', 'libjodo_train_emul.so'))
+    cfg = make_config('vpsde_qm9_uncond_jodo')
+    model = make_model(cfg, 3)
+    hp = O.Hyper.from_config(cfg)
+    n_all = [4, 7, 3, 6, 5]                                   # ragged shards: 3 + 2 molecules
+    named = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    params = [v.detach().float().contiguous() for v in model.state_dict().values()]
+
+    def grads_of(n_nodes, lo, hi, scale):
+        """gradient of scale * sum_b <d_b, out_b> over molecules lo .. hi - 1 of the full batch's random inputs"""
+        xh, ex, nl, ctx, nm, em = random_inputs(hp, n_all, seed=9)
+        g = torch.Generator().manual_seed(17)
+        d_x, d_e = torch.randn(xh.shape, generator=g), torch.randn(ex.shape, generator=g)
+        N = max(n_nodes)
+        cut = lambda t, dims: t[(slice(lo, hi),) + (slice(0, N),) * dims].contiguous()
+        eng = TrainEngine(model._cfg(), n_nodes, N, named, 'cpu', lib=emul, stream_ptr=lambda: ctypes.c_void_p(0))
+        nm_, em_ = masks(n_nodes)
+        xs, es = cut(xh, 1) * nm_, cut(ex, 2) * em_.reshape(len(n_nodes), N, N, 1)
+        eng.forward(params, xs, es, None, None, nl[lo:hi].contiguous(), None, 0.0, 0)
+        return eng.backward(params, nl[lo:hi].contiguous(), (cut(d_x, 1) * nm_ * scale).contiguous(),
+                            (cut(d_e, 2) * em_.reshape(len(n_nodes), N, N, 1) * scale).contiguous(), 0.0, 0)
+
+    lo, hi = shard_range(len(n_all), rank, world)
+    mine = grads_of(n_all[lo:hi], lo, hi, 1.0 / (hi - lo))    # this rank's MEAN over its molecules
+    ps = [torch.nn.Parameter(p.clone()) for p in params]
+    for p, g in zip(ps, mine):
+        p.grad = g
+    flat = allreduce_gradients(ps, weight=hi - lo)
+    ok = flat is not None and flat.numel() >= sum(p.numel() for p in ps)
+    want = grads_of(n_all, 0, len(n_all), 1.0 / len(n_all))   # the whole batch's mean on one process
+    worst = 0.0
+    for p, w in zip(ps, want):
+        scale = float(w.abs().max())
+        worst = max(worst, float((p.grad - w).abs().max()) / max(scale, 1e-12) if scale > 0 else float(p.grad.abs().max()))
+    q.put((rank, bool(ok), worst))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_gradients_world2():
+    """Two ranks with 3 and 2 molecules: after allreduce_gradients every rank holds the gradient of the mean over all 5 — what one
+    process computes on the whole batch (to float32 reorder noise: the ranks' batches have different row orders and split-K slices)."""
+    import subprocess
+    subprocess.run(['make', '-C', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emul')], check=True, capture_output=True)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[:2] for r in res] == [(0, True), (1, True)]
+    assert max(r[2] for r in res) < 2e-4, res
