@@ -81,7 +81,12 @@ def test_flat_adam_takes_the_flat_gradient_and_resumes_from_a_state_dict():
         got = JO.flat_gradient(pa, total)
         assert got is not None and got.data_ptr() == flat.data_ptr()
         opt.step()
-    sd = copy.deepcopy(opt.state_dict())
+    import io
+    buf = io.BytesIO()
+    torch.save(opt.state_dict(), buf)                                                      # the way utils.save_checkpoint stores it (utils.py:23-30)
+    assert buf.tell() < 4 * 4 * total * 4                                                   # the shared moment buffers are written once, not once per view
+    buf.seek(0)
+    sd = torch.load(buf, map_location=DEV)
     pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
     opt2 = JO.FlatAdam(pb, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-12, amsgrad=True, decoupled=True)
     opt2.load_state_dict(sd)
