@@ -232,6 +232,10 @@ struct Ctx {
         } else {
             JT_LAUNCH(k_seg_colsum2, (long)t.B * F, s, t.B, F, seg_off, dy, xhat, dmods, ldm, sh, sc);
         }
+        if (t.fused_bwd && seg_off != tp.edge_off) {             // node rows: the two row means and the result in one launch, a wave per row
+            fused_node_ln_mod_bwd(s, rows, F, dy, xhat, rstd, row_mol, mods, ldm, sc, dx, acc);
+            return;
+        }
         JT_LAUNCH(k_ln_bwd_part, rows * 8, s, rows, F, dy, xhat, row_mol, mods, ldm, sc, b.rowpart);
         JT_LAUNCH(k_ln_bwd_stats, rows, s, rows, F, (const float*)b.rowpart, b.tRow[0], b.tRow[1]);
         JT_LAUNCH(k_ln_bwd_apply, rows * F, s, rows, F, dy, xhat, rstd, (const float*)b.tRow[0], (const float*)b.tRow[1], row_mol, mods,
@@ -240,7 +244,11 @@ struct Ctx {
     // per-molecule sums: edge rows in two levels, node rows (at most 181 per molecule) directly
     void seg(int F, const int* off, const float* a, const float* bb, float* out, int ldo, int ocol) const {
         if (off == tp.edge_off) seg_edge(F, a, bb, out, ldo, ocol);
-        else JT_LAUNCH(k_seg_colsum, (long)t.B * F, s, t.B, F, off, a, bb, out, ldo, ocol, 0);
+        else JT_LAUNCH(k_seg_colsum, (long)t.B * F, s, t.B, F, off, a, bb, out, ldo, ocol, 0, drop(0.f, 0, 0, 0));
+    }
+    // node rows: out[mol, ocol + f] = sum_rows a (bb * dropout)
+    void seg_node_drop(int F, const float* a, const float* bb, Drop db, float* out, int ldo, int ocol) const {
+        JT_LAUNCH(k_seg_colsum, (long)t.B * F, s, t.B, F, tp.node_off, a, bb, out, ldo, ocol, 0, db);
     }
     void copy2d(long rows, int F, const float* src, int lds, int scol, float* dst, int ldd, int dcol, int acc) const {
         JT_LAUNCH(k_copy2d, rows * F, s, rows, F, src, lds, scol, dst, ldd, dcol, acc);
@@ -376,8 +384,11 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
             c.stats(R, De, e1, b.tRow[0], k.rs_e1);
             c.ln_mod(R, De, e1, b.tRow[0], k.rs_e1, tp.edge_mol, k.emod, 6 * De, 0, De, k.xh_e1, k.et);
         }
-        c.stats(Nn, D, b.h[l], b.tRow[0], k.rs_h);
-        c.ln_mod(Nn, D, b.h[l], b.tRow[0], k.rs_h, tp.node_mol, k.nmod, 6 * D, 0, D, k.xh_h, k.ht);
+        if (t.fused) fused_node_ln_mod(s, Nn, D, b.h[l], nullptr, tp.node_mol, k.nmod, 6 * D, 0, 0, D, k.xh_h, k.rs_h, k.ht);
+        else {
+            c.stats(Nn, D, b.h[l], b.tRow[0], k.rs_h);
+            c.ln_mod(Nn, D, b.h[l], b.tRow[0], k.rs_h, tp.node_mol, k.nmod, 6 * D, 0, D, k.xh_h, k.ht);
+        }
         // attention (layers.py:131-186)
         {   // q | k | v in one product on the gathered weights, then handed out to their arrays
             c.lin(k.ht, D, Nn, D, b.Wqkv + (size_t)l * F3 * D, D, F3, b.bqkv + (size_t)l * F3, b.qkv, F3, 0);
@@ -415,16 +426,20 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
                                6 * De, 5 * De, b.e[l + 1]);
         }
         // nodes: gated residual, LayerNorm2 + modulate, FFN (:307-311)
-        float* x1n = b.tN_D[0];
-        JT_LAUNCH(k_gate_add, (long)Nn * D, s, (long)Nn, D, (const float*)b.h[l], (const float*)k.hhat, tp.node_mol, (const float*)k.nmod,
-                           6 * D, 2 * D, x1n);
-        c.stats(Nn, D, x1n, b.tRow[0], k.rs_hn);
-        c.ln_mod(Nn, D, x1n, b.tRow[0], k.rs_hn, tp.node_mol, k.nmod, 6 * D, 3 * D, 4 * D, k.xh_hn, k.hn);
+        if (t.fused) {
+            // gated residual, row statistics, LayerNorm2 + modulate: one launch (a wave per row)
+            fused_node_ln_mod(s, Nn, D, b.h[l], k.hhat, tp.node_mol, k.nmod, 6 * D, 2 * D, 3 * D, 4 * D, k.xh_hn, k.rs_hn, k.hn);
+        } else {
+            float* x1n = b.tN_D[0];
+            JT_LAUNCH(k_gate_add, (long)Nn * D, s, (long)Nn, D, (const float*)b.h[l], (const float*)k.hhat, tp.node_mol, (const float*)k.nmod,
+                               6 * D, 2 * D, x1n);
+            c.stats(Nn, D, x1n, b.tRow[0], k.rs_hn);
+            c.ln_mod(Nn, D, x1n, b.tRow[0], k.rs_hn, tp.node_mol, k.nmod, 6 * D, 3 * D, 4 * D, k.xh_hn, k.hn);
+        }
         c.lin_silu(k.hn, D, Nn, D, c.p(ix.ff1.w), D, r * D, c.p(ix.ff1.b), k.f1, k.a1, c.drop(p_drop, seed, l, SITE_A1));
         c.lin(k.a1, r * D, Nn, r * D, c.p(ix.ff2.w), r * D, D, c.p(ix.ff2.b), k.f2, D, 0);
-        JT_LAUNCH(k_drop, (long)Nn * D, s, (long)Nn * D, (const float*)k.f2, b.tN_D[1], c.drop(p_drop, seed, l, SITE_F2));
-        JT_LAUNCH(k_gate_add, (long)Nn * D, s, (long)Nn, D, (const float*)k.hn, (const float*)b.tN_D[1], tp.node_mol, (const float*)k.nmod,
-                           6 * D, 5 * D, b.h[l + 1]);
+        JT_LAUNCH(k_drop_gate_add, (long)Nn * D, s, (long)Nn, D, (const float*)k.hn, (const float*)k.f2, c.drop(p_drop, seed, l, SITE_F2), tp.node_mol,
+                           (const float*)k.nmod, 6 * D, 5 * D, b.h[l + 1]);       // h' = hn + g2 dropout(ff2)
         // equivariant update (mol_gnn.py:71-94): input_lin([h_row, h_col, e, G]) factored per node / per edge
         const int ldw = 2 * D + 2 * De;
         const float* Win = c.p(ix.eq_in.w);
@@ -633,10 +648,9 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         c.lin_dx(dn2e, De, Nn, De, c.p(ix.n2e.w), D, D, dhhat, D, 0);
         // ---- node FFN, LayerNorm2 + modulate, gated residual
         float *dtn = b.tN_D[1], *tNr = b.tN_rD;
-        JT_LAUNCH(k_drop, (long)Nn * D, s, (long)Nn * D, (const float*)k.f2, dtn, c.drop(p_drop, seed, l, SITE_F2));
-        c.seg(D, tp.node_off, dh, dtn, b.dnmod, 6 * D, 5 * D);                                       // d ng2
-        JT_LAUNCH(k_gate_bwd, (long)Nn * D, s, (long)Nn, D, (const float*)dh, tp.node_mol, (const float*)k.nmod, 6 * D, 5 * D, dtn, 0);
-        JT_LAUNCH(k_drop, (long)Nn * D, s, (long)Nn * D, (const float*)dtn, dtn, c.drop(p_drop, seed, l, SITE_F2));
+        c.seg_node_drop(D, dh, k.f2, c.drop(p_drop, seed, l, SITE_F2), b.dnmod, 6 * D, 5 * D);       // d ng2 = sum dh dropout(f2)
+        JT_LAUNCH(k_gate_drop_bwd, (long)Nn * D, s, (long)Nn, D, (const float*)dh, tp.node_mol, (const float*)k.nmod, 6 * D, 5 * D, dtn,
+                           c.drop(p_drop, seed, l, SITE_F2));                                        // d f2 = (g2 dh) mask
         c.lin_dw(dtn, D, Nn, D, k.a1, r * D, r * D, c.g(ix.ff2.w), r * D, c.g(ix.ff2.b));
         c.lin_dx(dtn, D, Nn, D, c.p(ix.ff2.w), r * D, r * D, tNr, r * D, 0);
         c.silu_bwd((long)Nn * r * D, k.f1, tNr, tNr, c.drop(p_drop, seed, l, SITE_A1));

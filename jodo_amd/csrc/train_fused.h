@@ -68,4 +68,12 @@ void fused_bwd_b(hipStream_t s, const FusedDims& d, const FusedTopo& t, const Fu
 void fused_bwd_a(hipStream_t s, const FusedDims& d, const FusedTopo& t, const FusedBlockParams& p, const float* packed, const float* dt1, const float* dt0,
                  const float* xh_e1, const float* rs_e1, const float* emod, float* det, float* de1, float* dG, float* de_prev);
 
+// ---- node rows (F = D in {128, 256, 384}): LayerNorm + modulate with its row statistics in one launch, one wave per row.
+// forward:  x = res_b ? a + mods[mol, g_off + f] res_b : a;  xhat, rstd kept;  y = xhat (1 + mods[mol, sc_off + f]) + mods[mol, sh_off + f]
+void fused_node_ln_mod(hipStream_t s, long rows, int F, const float* a, const float* res_b, const int* row_mol, const float* mods, int ldm, int g_off,
+                       int sh_off, int sc_off, float* xhat, float* rstd, float* y);
+// backward: dx (+)= rstd (g - mean(g) - xhat mean(g xhat)),  g = dy (1 + mods[mol, sc_off + f])   (the modulation sums stay k_seg_colsum2)
+void fused_node_ln_mod_bwd(hipStream_t s, long rows, int F, const float* dy, const float* xhat, const float* rstd, const int* row_mol, const float* mods,
+                           int ldm, int sc_off, float* dx, int acc);
+
 }  // namespace jt

@@ -751,4 +751,88 @@ void fused_bwd_a(hipStream_t s, const FusedDims& d, const FusedTopo& t, const Fu
     else hipLaunchKernelGGL(k_bwd_a<384>, grid, dim3(64), 0, s, A);
 }
 
+// ---- node rows: LayerNorm + modulate, one wave per row (round 5, second half) -------------------------------------------------------
+// The op-by-op form is three launches per LayerNorm (eight partial sums per row, their combination, the normalisation) and one more
+// for the gated residual in front of the second one — cooperation-free kernels for the host emulation, ~5 us each whatever their size.
+// Here a wave owns a row (NV = F / 64 values per lane, consecutive lanes on consecutive features), the two row means are butterfly sums.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+//   x = RES ? a + g[mol] b : a;   xhat = (x - mean) rstd (kept);   y = xhat (1 + sc[mol]) + sh[mol]
+template <int NV, bool RES>
+__global__ __launch_bounds__(256) void k_node_ln_mod(long rows, const float* __restrict__ a, const float* __restrict__ b, const int* __restrict__ row_mol,
+                                                     const float* __restrict__ mods, int ldm, int g_off, int sh_off, int sc_off, float* __restrict__ xhat,
+                                                     float* __restrict__ rstd_out, float* __restrict__ y) {
+    constexpr int F = NV * 64;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float* m = mods + (long)row_mol[r] * ldm;
+    float x[NV], s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int f = lane + 64 * j;
+        x[j] = a[r * F + f];
+        if (RES) x[j] += m[g_off + f] * b[r * F + f];
+        s += x[j];
+    }
+    const float mean = wave_sum(s) * (1.f / F);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { x[j] -= mean; q += x[j] * x[j]; }
+    const float rstd = 1.f / sqrtf(wave_sum(q) * (1.f / F) + 1e-6f);
+    if (lane == 0) rstd_out[r] = rstd;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int f = lane + 64 * j;
+        const float xh = x[j] * rstd;
+        xhat[r * F + f] = xh;
+        y[r * F + f] = xh * (1.f + m[sc_off + f]) + m[sh_off + f];
+    }
+}
+//   g = dy (1 + sc[mol]);   dx (+)= rstd (g - mean(g) - xhat mean(g xhat))
+template <int NV>
+__global__ __launch_bounds__(256) void k_node_ln_mod_bwd(long rows, const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                         const int* __restrict__ row_mol, const float* __restrict__ mods, int ldm, int sc_off, float* dx, int acc) {
+    constexpr int F = NV * 64;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float* m = mods + (long)row_mol[r] * ldm + sc_off;
+    float g[NV], xh[NV], c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int f = lane + 64 * j;
+        g[j] = dy[r * F + f] * (1.f + m[f]);
+        xh[j] = xhat[r * F + f];
+        c1 += g[j]; c2 = fmaf(g[j], xh[j], c2);
+    }
+    c1 = wave_sum(c1) * (1.f / F); c2 = wave_sum(c2) * (1.f / F);
+    const float rs = rstd[r];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int f = lane + 64 * j;
+        const float v = rs * (g[j] - c1 - xh[j] * c2);
+        dx[r * F + f] = acc ? dx[r * F + f] + v : v;
+    }
+}
+
+void fused_node_ln_mod(hipStream_t s, long rows, int F, const float* a, const float* res_b, const int* row_mol, const float* mods, int ldm, int g_off,
+                       int sh_off, int sc_off, float* xhat, float* rstd, float* y) {
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define JT_N(NV) do { if (res_b) hipLaunchKernelGGL((k_node_ln_mod<NV, true>), grid, block, 0, s, rows, a, res_b, row_mol, mods, ldm, g_off, sh_off, sc_off, xhat, rstd, y); \
+                      else hipLaunchKernelGGL((k_node_ln_mod<NV, false>), grid, block, 0, s, rows, a, res_b, row_mol, mods, ldm, g_off, sh_off, sc_off, xhat, rstd, y); } while (0)
+    if (F == 128) JT_N(2); else if (F == 256) JT_N(4); else JT_N(6);
+#undef JT_N
+}
+void fused_node_ln_mod_bwd(hipStream_t s, long rows, int F, const float* dy, const float* xhat, const float* rstd, const int* row_mol, const float* mods,
+                           int ldm, int sc_off, float* dx, int acc) {
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (F == 128) hipLaunchKernelGGL(k_node_ln_mod_bwd<2>, grid, block, 0, s, rows, dy, xhat, rstd, row_mol, mods, ldm, sc_off, dx, acc);
+    else if (F == 256) hipLaunchKernelGGL(k_node_ln_mod_bwd<4>, grid, block, 0, s, rows, dy, xhat, rstd, row_mol, mods, ldm, sc_off, dx, acc);
+    else hipLaunchKernelGGL(k_node_ln_mod_bwd<6>, grid, block, 0, s, rows, dy, xhat, rstd, row_mol, mods, ldm, sc_off, dx, acc);
+}
+
 }  // namespace jt

@@ -210,12 +210,16 @@ __global__ void k_ln_bwd_apply(long rows, int F, const float* dy, const float* _
 
 // ================================================================ segment / column reductions ==================================
 // out[s, ocol + f] (+)= sum over rows r in [off[s], off[s + 1]) of a[r, f] * (b ? b[r, f] : 1)
+// (db: dropout applied to b on the fly — b * mask, then the product: the same roundings as a k_drop pass over b in front)
 __global__ void k_seg_colsum(int S, int F, const int* __restrict__ off, const float* __restrict__ a, const float* __restrict__ b,
-                             float* __restrict__ out, int ldo, int ocol, int acc) {
+                             float* __restrict__ out, int ldo, int ocol, int acc, Drop db) {
     JT_IDX((long)S * F);
     const int s = (int)(i_ / F), f = (int)(i_ % F);
     double t = 0.0;                                  // gradient sums cancel: accumulated in double, stored in float
-    if (b) {
+    if (b && db.p > 0.f) {
+#pragma unroll 8
+        for (long r = off[s]; r < off[s + 1]; ++r) t += (double)(a[r * F + f] * (b[r * F + f] * drop_mul(db, (unsigned long long)(r * F + f))));
+    } else if (b) {
 #pragma unroll 8
         for (long r = off[s]; r < off[s + 1]; ++r) t += (double)(a[r * F + f] * b[r * F + f]);
     } else {
@@ -317,6 +321,20 @@ __global__ void k_gate_bwd(long rows, int F, const float* __restrict__ dy, const
     const long r = i_ / F; const int f = (int)(i_ % F);
     const float v = mods[(long)row_mol[r] * ldm + g_off + f] * dy[i_];
     db[i_] = acc ? db[i_] + v : v;
+}
+// db = (g[mol] * dy) * dropout — the gate's backward and the dropout's backward behind it in one pass (same roundings as the two)
+__global__ void k_gate_drop_bwd(long rows, int F, const float* __restrict__ dy, const int* __restrict__ row_mol, const float* __restrict__ mods,
+                                int ldm, int g_off, float* __restrict__ db, Drop d) {
+    JT_IDX(rows * F);
+    const long r = i_ / F; const int f = (int)(i_ % F);
+    db[i_] = (mods[(long)row_mol[r] * ldm + g_off + f] * dy[i_]) * drop_mul(d, (unsigned long long)i_);
+}
+// y = a + g[mol] * (b * dropout) — dropout and the gated residual behind it in one pass (same roundings as k_drop + k_gate_add)
+__global__ void k_drop_gate_add(long rows, int F, const float* __restrict__ a, const float* __restrict__ b, Drop d, const int* __restrict__ row_mol,
+                                const float* __restrict__ mods, int ldm, int g_off, float* __restrict__ y) {
+    JT_IDX(rows * F);
+    const long r = i_ / F; const int f = (int)(i_ % F);
+    y[i_] = a[i_] + mods[(long)row_mol[r] * ldm + g_off + f] * (b[i_] * drop_mul(d, (unsigned long long)i_));
 }
 // edge rows: y[(a, c), f] = base[(a, c), f] + g * (p[a, f] + q[c, f] + bias[f]);  g = mods[mol, g_off + f] or 1 (mods NULL); base NULL = 0
 __global__ void k_edge_bcast(Topo t, int F, const float* __restrict__ base, const float* __restrict__ p, const float* __restrict__ q,

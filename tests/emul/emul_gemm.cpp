@@ -97,4 +97,6 @@ void fused_bwd_b(hipStream_t, const FusedDims&, const FusedTopo&, const FusedBlo
                  const float*, const float*, Drop, Drop, float*, float*, float*, float*, float*) {}
 void fused_bwd_a(hipStream_t, const FusedDims&, const FusedTopo&, const FusedBlockParams&, const float*, const float*, const float*, const float*, const float*,
                  const float*, float*, float*, float*, float*) {}
+void fused_node_ln_mod(hipStream_t, long, int, const float*, const float*, const int*, const float*, int, int, int, int, float*, float*, float*) {}
+void fused_node_ln_mod_bwd(hipStream_t, long, int, const float*, const float*, const float*, const int*, const float*, int, int, float*, int) {}
 }
