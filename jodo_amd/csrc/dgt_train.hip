@@ -66,6 +66,10 @@ struct Bufs {
     size_t fpack_block;
     size_t splitk_floats, part_floats, part2_floats, dwg_floats;
     std::vector<GemmJob> dwq;                                       // weight-gradient products waiting for the next Ctx::flush_dw
+    float* finpart;                                                 // partial sums of the reductions whose later stages are queued (Ctx::flush_fin)
+    size_t finpart_floats, fin_used;
+    std::vector<FinJob> finq;
+    bool defer_fin;                                                 // the backward queues; the forward (and everything outside it) launches at once
 };
 
 }  // namespace
@@ -143,6 +147,13 @@ void layout(const jodo_train& t, Arena& a, Bufs& b) {
     b.dwg_floats = 6 * b.splitk_floats;      // the partial tiles of about a dozen queued products (a group is cut where they do not fit)
     b.dwg = a.f(b.dwg_floats);
     for (int s = 0; s < 2; ++s) b.tN_D2[s] = a.f(Nn * D);
+    b.finpart_floats = (size_t)4 << 20;
+    {   // one block's queued reductions: three two-sum passes (D, De, De), four plain ones (De, De, 1, 1) over NC chunks, column partials
+        const size_t nc = (size_t)t.NC + 1, colp = (rows + 31) / 32 + 64;
+        const size_t need = nc * (2 * D + 4 * De + 2 * De + 2) + colp * (De + 1 + 2 * De) + 65536;
+        if (b.finpart_floats < need) b.finpart_floats = need;
+    }
+    b.finpart = a.f(b.finpart_floats); b.fin_used = 0; b.defer_fin = false;
     const FusedDims fd{t.D, t.De, t.r, t.QK, t.ce, t.L};
     b.fpack_block = fused_pack_layout(fd).total_bwd;
     b.fpack = a.f(b.fpack_block * L);
@@ -196,6 +207,20 @@ struct Ctx {
     // until at most 64 rows are left (every level a launch with rows x F / 32 threads; fixed order, no atomics)
     void colsum(const float* a, int lda, const float* bb, int ldb, long rows, int F, float* out) const {
         const int chunk = 32;
+        if (b.defer_fin) {
+            // first level now (it reads the caller's array), the rest queued: one more level down to at most 64 rows, then the final sum
+            long n = (rows + chunk - 1) / chunk;
+            float* p1 = fin_alloc((size_t)n * F);
+            JT_LAUNCH(k_colsum_part, n * F, s, rows, F, chunk, a, lda, bb, ldb, p1);
+            if (n > 64) {
+                const long c2 = n <= 2048 ? 32 : (n + 63) / 64, n2 = (n + c2 - 1) / c2;
+                float* p2 = fin_alloc((size_t)n2 * F);
+                push_fin(FinJob{p1, p2, nullptr, FIN_COLPART, F, (int)n, 0, 0, (int)c2, 0, 0});
+                p1 = p2; n = n2;
+            }
+            push_fin(FinJob{p1, out, nullptr, FIN_COL, F, (int)n, 0, 0, 0, 1, 0});
+            return;
+        }
         float* dst = b.part; float* other = b.part2;
         long n = rows;
         while (true) {
@@ -209,8 +234,49 @@ struct Ctx {
     }
     // per-molecule sums over EDGE rows (two levels over the plan's chunks), out[mol, ocol + f] written
     void seg_edge(int F, const float* a, const float* bb, float* out, int ldo, int ocol) const {
-        JT_LAUNCH(k_seg_part, (long)tp.NC * F, s, tp.NC, F, tp.ec_off, a, bb, b.part);
-        JT_LAUNCH(k_seg_fin, (long)t.B * F, s, t.B, F, tp.ec_mol_off, (const float*)b.part, out, ldo, ocol, 0);
+        float* part = b.defer_fin ? fin_alloc((size_t)tp.NC * F) : b.part;
+        JT_LAUNCH(k_seg_part, (long)tp.NC * F, s, tp.NC, F, tp.ec_off, a, bb, part);
+        if (b.defer_fin) push_fin(FinJob{part, out, tp.ec_mol_off, FIN_SEG, F, t.B, ldo, ocol, 0, 0, 0});
+        else JT_LAUNCH(k_seg_fin, (long)t.B * F, s, t.B, F, tp.ec_mol_off, (const float*)part, out, ldo, ocol, 0);
+    }
+    // the two sums of a LayerNorm + modulate backward over edge rows: out[mol, c1 + f] = sum a, out[mol, c2 + f] = sum a bb
+    void seg2_edge(int F, const float* a, const float* bb, float* out, int ldo, int c1, int c2) const {
+        float* part = b.defer_fin ? fin_alloc((size_t)tp.NC * 2 * F) : b.part;
+        JT_LAUNCH(k_seg_part2, (long)tp.NC * F, s, tp.NC, F, tp.ec_off, a, bb, part);
+        if (b.defer_fin) push_fin(FinJob{part, out, tp.ec_mol_off, FIN_SEG2, F, t.B, ldo, c1, c2, 0, 0});
+        else JT_LAUNCH(k_seg_fin2, (long)t.B * 2 * F, s, t.B, F, tp.ec_mol_off, (const float*)part, out, ldo, c1, c2);
+    }
+    // queued later stages of reductions (train_ops.h k_fin_group): a region of partial sums per queued job, all of them in one launch
+    // (second-level column partials first, in a launch of their own) at flush_fin() — which the backward calls once per block
+    float* fin_alloc(size_t n) const {
+        n = (n + 63) / 64 * 64;
+        if (b.fin_used + n > b.finpart_floats) flush_fin();
+        if (n > b.finpart_floats) { fprintf(stderr, "jodo train: %zu floats of reduction scratch asked, %zu there\n", n, b.finpart_floats); abort(); }
+        float* p = b.finpart + b.fin_used;
+        b.fin_used += n;
+        return p;
+    }
+    void push_fin(const FinJob& j) const { b.finq.push_back(j); }
+    void flush_fin() const {
+        for (int phase = 0; phase < 2; ++phase) {
+            FinTable T; T.n = 0;
+            int blocks = 0;
+            auto launch = [&]() {
+                if (T.n) hipLaunchKernelGGL(k_fin_group, dim3((unsigned)blocks), dim3(256), 0, s, T);
+                T.n = 0; blocks = 0;
+            };
+            for (const FinJob& q : b.finq) {
+                if ((q.kind == FIN_COLPART) != (phase == 0)) continue;
+                if (T.n == FIN_MAX) launch();
+                FinJob j = q;
+                j.blk0 = blocks;
+                blocks += (int)((fin_threads(j) + 255) / 256);
+                T.j[T.n++] = j;
+            }
+            launch();
+        }
+        b.finq.clear();
+        b.fin_used = 0;
     }
     void silu(long n, const float* x, float* y, Drop d) const { JT_LAUNCH(k_silu_fwd, n, s, n, x, y, d); }
     void silu_bwd(long n, const float* x, const float* dy, float* dx, Drop d) const { JT_LAUNCH(k_silu_bwd, n, s, n, x, dy, dx, d); }
@@ -223,15 +289,12 @@ struct Ctx {
         JT_LAUNCH(k_ln_mod_fwd, rows * F, s, rows, F, x, mean, rstd, row_mol, mods, ldm, sh, sc, xhat, y);
     }
     // LayerNorm + modulate backward: modulation gradients into dmods[:, sh], [:, sc] (written), dx (acc)
+    // (dmods: row stride ldd — the block's columns of the [B, Mtot] array of all modulation gradients)
     void ln_mod_bwd(long rows, int F, const float* dy, const float* xhat, const float* rstd, const int* row_mol, const int* seg_off, const float* mods,
-                    int ldm, int sh, int sc, float* dmods, float* dx, int acc) const {
+                    int ldm, int sh, int sc, float* dmods, int ldd, float* dx, int acc) const {
         // d shift = sum dy, d scale = sum dy xhat per molecule: one pass (edge rows: two levels over the plan's chunks)
-        if (seg_off == tp.edge_off) {
-            JT_LAUNCH(k_seg_part2, (long)tp.NC * F, s, tp.NC, F, tp.ec_off, dy, xhat, b.part);
-            JT_LAUNCH(k_seg_fin2, (long)t.B * 2 * F, s, t.B, F, tp.ec_mol_off, (const float*)b.part, dmods, ldm, sh, sc);
-        } else {
-            JT_LAUNCH(k_seg_colsum2, (long)t.B * F, s, t.B, F, seg_off, dy, xhat, dmods, ldm, sh, sc);
-        }
+        if (seg_off == tp.edge_off) seg2_edge(F, dy, xhat, dmods, ldd, sh, sc);
+        else JT_LAUNCH(k_seg_colsum2, (long)t.B * F, s, t.B, F, seg_off, dy, xhat, dmods, ldd, sh, sc);
         if (t.fused_bwd && seg_off != tp.edge_off) {             // node rows: the two row means and the result in one launch, a wave per row
             fused_node_ln_mod_bwd(s, rows, F, dy, xhat, rstd, row_mol, mods, ldm, sc, dx, acc);
             return;
@@ -477,14 +540,13 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
     JT_LAUNCH(k_node_out, (long)B * t.N * (3 + nd), s, tp, nd, (const float*)b.posf, (const float*)b.atom, out_xh);
 }
 
-// one modulation projection's gradient rows: parked in their columns of dmods_all; the products (dW += dmod^T tau, db += column sums,
-// dtau += dmod W) run once for all of them at the end of the backward (mod_bwd_all)
-void mod_bwd(const Ctx& c, Lin lin, const float* dmod, int F) {
-    const jodo_train& t = c.t;
-    Lin ls[MOD_MAX]; int Fs[MOD_MAX], col[MOD_MAX];
-    const int n = mod_entries(t, ls, Fs, col);
-    for (int i = 0; i < n; ++i)
-        if (ls[i].w == lin.w) { c.copy2d(t.B, F, dmod, F, 0, c.b.dmods_all, t.Mtot, col[i], 0); return; }
+// Modulation gradients: every reduction that produces one writes straight into its columns of dmods_all [B, Mtot] (mod_entries order);
+// the products (dW += dmod^T tau, db += column sums, dtau += dmod W) run once for all of them at the end of the backward (mod_bwd_all).
+// Columns of block l: node | edge | equivariant | Gaussian layer; the top-level Gaussian layer's two are columns 0 .. 1.
+struct ModCols { int node, edge, eq, gbf; };
+ModCols mod_cols(const jodo_train& t, int l) {
+    const int base = 2 + l * (6 * t.D + 6 * t.De + 2 * t.D + 2);
+    return ModCols{base, base + 6 * t.D, base + 6 * t.D + 6 * t.De, base + 6 * t.D + 6 * t.De + 2 * t.D};
 }
 void mod_bwd_all(const Ctx& c) {
     const jodo_train& t = c.t; Bufs& b = c.b; hipStream_t s = c.s;
@@ -501,19 +563,18 @@ void mod_bwd_all(const Ctx& c) {
     hipLaunchKernelGGL(k_mod_scatter_grads, dim3((unsigned)(((long)fmax * t.T + 255) / 256), (unsigned)M.n), dim3(256), 0, s, M, t.T, (const float*)b.dWall, (const float*)b.dball);
 }
 
-void gbf_bwd(const Ctx& c, long rows, const float* d2, const float* gm, int means, int stds, Lin time, const float* dG, int ldg, int gcol, float* dd2) {
+void gbf_bwd(const Ctx& c, long rows, const float* d2, const float* gm, int means, int stds, float* dgm, int ldd, const float* dG, int ldg, int gcol, float* dd2) {
     const jodo_train& t = c.t; Bufs& b = c.b; hipStream_t s = c.s;
     const int De = t.De, K = De - 1;
     JT_LAUNCH(k_gbf_bwd_row, rows, s, rows, De, d2, c.tp.edge_mol, gm, c.p(means), c.p(stds), dG, ldg, gcol, b.tRow[2], dd2, 0);
-    c.seg_edge(1, b.tRow[2], d2, b.dgm, 2, 0);              // d scale = sum dx' d2,  d shift = sum dx'  per molecule
-    c.seg_edge(1, b.tRow[2], nullptr, b.dgm, 2, 1);
+    c.seg_edge(1, b.tRow[2], d2, dgm, ldd, 0);              // d scale = sum dx' d2,  d shift = sum dx'  per molecule
+    c.seg_edge(1, b.tRow[2], nullptr, dgm, ldd, 1);
     const int chunk = 32;
     const long nch = (rows + chunk - 1) / chunk;
     float *pm = b.tE_QK, *ps = b.tE_QK + nch * K;            // (the attention scratch is free here)
     JT_LAUNCH(k_gbf_bwd_par, nch * K, s, rows, De, chunk, d2, c.tp.edge_mol, gm, c.p(means), c.p(stds), dG, ldg, gcol, pm, ps);
     c.colsum(pm, K, nullptr, 0, nch, K, c.g(means));
     c.colsum(ps, K, nullptr, 0, nch, K, c.g(stds));
-    mod_bwd(c, time, b.dgm, 2);
 }
 
 void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float* d_out_edge, float p_drop, unsigned long long seed) {
@@ -535,6 +596,9 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         (void)hipMemsetAsync(beg, 0, bytes, s);
         i = j;
     }
+    b.defer_fin = true;                                      // later stages of the reductions are queued and run once per block (flush_fin)
+    b.finq.clear(); b.fin_used = 0;
+    const int Mt = t.Mtot;
     (void)hipMemsetAsync(b.dtau, 0, (size_t)B * T * 4, s);
     (void)hipMemsetAsync(b.dWqkv, 0, (size_t)L * (2 * QK + D) * D * 4, s);
     (void)hipMemsetAsync(b.dbqkv, 0, (size_t)L * (2 * QK + D) * 4, s);
@@ -554,6 +618,8 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
     (void)hipMemsetAsync(de, 0, (size_t)R * De * 4, s);           // so that part of dah / deh joins d h[0] / d e[0] after the loop
     for (int l = L - 1; l >= 0; --l) {
         const BlkIx& ix = t.blk[l]; BlkBuf& k = b.blk[l];
+        const ModCols mc = mod_cols(t, l);
+        float *dnmod = b.dmods_all + mc.node, *demod = b.dmods_all + mc.edge, *dqmod = b.dmods_all + mc.eq, *dgm = b.dmods_all + mc.gbf;   // row stride Mt
         // readouts
         c.lin_dw(dah + D + l * t.cn, t.catn, Nn, t.cn, b.h[l + 1], D, D, c.g(ix.node_ro.w), D, c.g(ix.node_ro.b));
         c.lin_dx(dah + D + l * t.cn, t.catn, Nn, t.cn, c.p(ix.node_ro.w), D, D, dh, D, 1);
@@ -582,8 +648,7 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
             fused_bwd_c(s, fd, ft, fp, fpk, k.inv, dinv, k.c0pre, k.xh_pre, k.rs_pre, k.qmod, dc0, du, dpre, de, dG);
             c.lin_dw(dinv, 3, R, 3, k.c0a, D, D, c.g(ix.eq_c2), D);
             c.lin_dw(dc0, D, R, D, k.u, D, D, c.g(ix.eq_c0.w), D, c.g(ix.eq_c0.b));
-            JT_LAUNCH(k_seg_part2, (long)tp.NC * D, s, tp.NC, D, tp.ec_off, (const float*)du, (const float*)k.xh_pre, b.part);
-            JT_LAUNCH(k_seg_fin2, (long)B * 2 * D, s, B, D, tp.ec_mol_off, (const float*)b.part, b.dqmod, 2 * D, 0, D);
+            c.seg2_edge(D, du, k.xh_pre, dqmod, Mt, 0, D);
         } else {
             JT_LAUNCH(k_tanh_bwd, (long)R * 3, s, (long)R * 3, (const float*)k.inv, dinv);
             c.lin_dw(dinv, 3, R, 3, k.c0a, D, D, c.g(ix.eq_c2), D);
@@ -591,9 +656,8 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
             c.silu_bwd((long)R * D, k.c0pre, dc0, dc0, nod);
             c.lin_dw(dc0, D, R, D, k.u, D, D, c.g(ix.eq_c0.w), D, c.g(ix.eq_c0.b));
             c.lin_dx(dc0, D, R, D, c.p(ix.eq_c0.w), D, D, du, D, 0);
-            c.ln_mod_bwd(R, D, du, k.xh_pre, k.rs_pre, tp.edge_mol, tp.edge_off, k.qmod, 2 * D, 0, D, b.dqmod, dpre, 0);
+            c.ln_mod_bwd(R, D, du, k.xh_pre, k.rs_pre, tp.edge_mol, tp.edge_off, k.qmod, 2 * D, 0, D, dqmod, Mt, dpre, 0);
         }
-        mod_bwd(c, ix.eq_time, b.dqmod, 2 * D);
         const int ldw = 2 * D + 2 * De;
         const float* Win = c.p(ix.eq_in.w); float* dWin = c.g(ix.eq_in.w);
         float *dhr = b.tN_D2[0], *dhc = b.tN_D2[1];           // (not tN_D[0 .. 1]: d hhat / d tn below, while these products are queued)
@@ -616,14 +680,13 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
             float *df4 = b.tE_De2[0], *den = b.tE_De2[1];
             fused_bwd_b(s, fd, ft, fp, fpk, de, k.f4, k.f3, k.xh_en, k.rs_en, k.emod, c.drop(p_drop, seed, l, SITE_A3), c.drop(p_drop, seed, l, SITE_F4),
                         dten, df4, tE, den, de_prev);
-            c.seg(De, tp.edge_off, de, dten, b.demod, 6 * De, 5 * De);                               // d eg2
+            c.seg(De, tp.edge_off, de, dten, demod, Mt, 5 * De);                                     // d eg2
             c.lin_dw(df4, De, R, De, k.a3, r * De, r * De, c.g(ix.ff4.w), r * De, c.g(ix.ff4.b));
             c.lin_dw(tE, r * De, R, r * De, k.en, De, De, c.g(ix.ff3.w), De, c.g(ix.ff3.b));
-            JT_LAUNCH(k_seg_part2, (long)tp.NC * De, s, tp.NC, De, tp.ec_off, (const float*)den, (const float*)k.xh_en, b.part);
-            JT_LAUNCH(k_seg_fin2, (long)B * 2 * De, s, B, De, tp.ec_mol_off, (const float*)b.part, b.demod, 6 * De, 3 * De, 4 * De);
+            c.seg2_edge(De, den, k.xh_en, demod, Mt, 3 * De, 4 * De);
         } else {
             JT_LAUNCH(k_drop, (long)R * De, s, (long)R * De, (const float*)k.f4, dten, c.drop(p_drop, seed, l, SITE_F4));
-            c.seg(De, tp.edge_off, de, dten, b.demod, 6 * De, 5 * De);                                   // d eg2
+            c.seg(De, tp.edge_off, de, dten, demod, Mt, 5 * De);                                         // d eg2
             JT_LAUNCH(k_gate_bwd, (long)R * De, s, (long)R, De, (const float*)de, tp.edge_mol, (const float*)k.emod, 6 * De, 5 * De, dten, 0);
             JT_LAUNCH(k_drop, (long)R * De, s, (long)R * De, (const float*)dten, dten, c.drop(p_drop, seed, l, SITE_F4));
             c.lin_dw(dten, De, R, De, k.a3, r * De, r * De, c.g(ix.ff4.w), r * De, c.g(ix.ff4.b));
@@ -631,12 +694,12 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
             c.silu_bwd((long)R * r * De, k.f3, tE, tE, c.drop(p_drop, seed, l, SITE_A3));
             c.lin_dw(tE, r * De, R, r * De, k.en, De, De, c.g(ix.ff3.w), De, c.g(ix.ff3.b));
             c.lin_dx(tE, r * De, R, r * De, c.p(ix.ff3.w), De, De, de, De, 1);                          // de is now d en
-            c.ln_mod_bwd(R, De, de, k.xh_en, k.rs_en, tp.edge_mol, tp.edge_off, k.emod, 6 * De, 3 * De, 4 * De, b.demod, de_prev, 0);   // de_prev = d x1e = d e[l] (residual)
+            c.ln_mod_bwd(R, De, de, k.xh_en, k.rs_en, tp.edge_mol, tp.edge_off, k.emod, 6 * De, 3 * De, 4 * De, demod, Mt, de_prev, 0);   // de_prev = d x1e = d e[l] (residual)
         }
         float* ehat = dten;
         JT_LAUNCH(k_edge_bcast, (long)R * De, s, tp, De, (const float*)nullptr, (const float*)k.n2e, (const float*)k.n2e, c.p(ix.n2e.b),
                            (const float*)nullptr, 0, 0, ehat);
-        c.seg(De, tp.edge_off, de_prev, ehat, b.demod, 6 * De, 2 * De);                             // d eg1
+        c.seg(De, tp.edge_off, de_prev, ehat, demod, Mt, 2 * De);                                   // d eg1
         float* dehat = dten;
         JT_LAUNCH(k_gate_bwd, (long)R * De, s, (long)R, De, (const float*)de_prev, tp.edge_mol, (const float*)k.emod, 6 * De, 2 * De, dehat, 0);
         c.colsum(dehat, De, nullptr, 0, R, De, c.g(ix.n2e.b));
@@ -648,7 +711,7 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         c.lin_dx(dn2e, De, Nn, De, c.p(ix.n2e.w), D, D, dhhat, D, 0);
         // ---- node FFN, LayerNorm2 + modulate, gated residual
         float *dtn = b.tN_D[1], *tNr = b.tN_rD;
-        c.seg_node_drop(D, dh, k.f2, c.drop(p_drop, seed, l, SITE_F2), b.dnmod, 6 * D, 5 * D);       // d ng2 = sum dh dropout(f2)
+        c.seg_node_drop(D, dh, k.f2, c.drop(p_drop, seed, l, SITE_F2), dnmod, Mt, 5 * D);             // d ng2 = sum dh dropout(f2)
         JT_LAUNCH(k_gate_drop_bwd, (long)Nn * D, s, (long)Nn, D, (const float*)dh, tp.node_mol, (const float*)k.nmod, 6 * D, 5 * D, dtn,
                            c.drop(p_drop, seed, l, SITE_F2));                                        // d f2 = (g2 dh) mask
         c.lin_dw(dtn, D, Nn, D, k.a1, r * D, r * D, c.g(ix.ff2.w), r * D, c.g(ix.ff2.b));
@@ -656,8 +719,8 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         c.silu_bwd((long)Nn * r * D, k.f1, tNr, tNr, c.drop(p_drop, seed, l, SITE_A1));
         c.lin_dw(tNr, r * D, Nn, r * D, k.hn, D, D, c.g(ix.ff1.w), D, c.g(ix.ff1.b));
         c.lin_dx(tNr, r * D, Nn, r * D, c.p(ix.ff1.w), D, D, dh, D, 1);                              // dh is now d hn
-        c.ln_mod_bwd(Nn, D, dh, k.xh_hn, k.rs_hn, tp.node_mol, tp.node_off, k.nmod, 6 * D, 3 * D, 4 * D, b.dnmod, dh_prev, 0);      // dh_prev = d x1n = d h[l] (residual)
-        c.seg(D, tp.node_off, dh_prev, k.hhat, b.dnmod, 6 * D, 2 * D);                               // d ng1
+        c.ln_mod_bwd(Nn, D, dh, k.xh_hn, k.rs_hn, tp.node_mol, tp.node_off, k.nmod, 6 * D, 3 * D, 4 * D, dnmod, Mt, dh_prev, 0);      // dh_prev = d x1n = d h[l] (residual)
+        c.seg(D, tp.node_off, dh_prev, k.hhat, dnmod, Mt, 2 * D);                                    // d ng1
         JT_LAUNCH(k_gate_bwd, (long)Nn * D, s, (long)Nn, D, (const float*)dh_prev, tp.node_mol, (const float*)k.nmod, 6 * D, 2 * D, dhhat, 1);
         // ---- attention backwards
         c.flush_dw();                                        // d tn (tN_D[1]) and d c0 (tE_D[0]) are d v and d t1 from here on
@@ -695,26 +758,24 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         }
         // ---- the two modulated LayerNorms at the top of the block, edge_emb([G, e])
         if (t.fused_bwd) {
-            JT_LAUNCH(k_seg_part2, (long)tp.NC * De, s, tp.NC, De, tp.ec_off, (const float*)det, (const float*)k.xh_e1, b.part);
-            JT_LAUNCH(k_seg_fin2, (long)B * 2 * De, s, B, De, tp.ec_mol_off, (const float*)b.part, b.demod, 6 * De, 0, De);
+            c.seg2_edge(De, det, k.xh_e1, demod, Mt, 0, De);
         } else {
-            c.ln_mod_bwd(R, De, det, k.xh_e1, k.rs_e1, tp.edge_mol, tp.edge_off, k.emod, 6 * De, 0, De, b.demod, de1, 0);      // in place: dx written after its own row was read
+            c.ln_mod_bwd(R, De, det, k.xh_e1, k.rs_e1, tp.edge_mol, tp.edge_off, k.emod, 6 * De, 0, De, demod, Mt, de1, 0);      // in place: dx written after its own row was read
         }
-        mod_bwd(c, ix.edge_time, b.demod, 6 * De);
         c.lin_dw(de1, De, R, De, k.G, De, De, c.g(ix.edge_emb.w), 2 * De, c.g(ix.edge_emb.b));
         c.lin_dw(de1, De, R, De, b.e[l], De, De, c.g(ix.edge_emb.w) + De, 2 * De);
         if (!t.fused_bwd) {
             c.lin_dx(de1, De, R, De, c.p(ix.edge_emb.w), 2 * De, De, dG, De, 1);
             c.lin_dx(de1, De, R, De, c.p(ix.edge_emb.w) + De, 2 * De, De, de_prev, De, 1);
         }
-        c.ln_mod_bwd(Nn, D, dht, k.xh_h, k.rs_h, tp.node_mol, tp.node_off, k.nmod, 6 * D, 0, D, b.dnmod, dh_prev, 1);
-        mod_bwd(c, ix.node_time, b.dnmod, 6 * D);
+        c.ln_mod_bwd(Nn, D, dht, k.xh_h, k.rs_h, tp.node_mol, tp.node_off, k.nmod, 6 * D, 0, D, dnmod, Mt, dh_prev, 1);
         // ---- Gaussian basis and distances -> positions of the block input
         c.flush_dw();                                        // gbf_bwd's partial sums live in tE_QK (d t0), and the next block reuses everything
         float* dd2 = b.tRow[0];
-        gbf_bwd(c, R, k.d2, k.gm, ix.gbf_means, ix.gbf_stds, ix.gbf_time, dG, De, 0, dd2);
+        gbf_bwd(c, R, k.d2, k.gm, ix.gbf_means, ix.gbf_stds, dgm, Mt, dG, De, 0, dd2);
         JT_LAUNCH(k_dist2_bwd, (long)R * 3, s, tp, (const float*)b.pos[l], (const float*)dd2, ddiff);
         JT_LAUNCH(k_diff_to_node, (long)Nn * 3, s, tp, (const float*)ddiff, (const float*)dxp, dpos_prev);
+        c.flush_fin();                                       // this block's queued reduction stages: two launches
         std::swap(dh, dh_prev); std::swap(de, de_prev); std::swap(dpos, dpos_prev);
     }
     // embeddings
@@ -727,7 +788,8 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
     c.lin_dx(de, De, R, De, c.p(t.edge_emb.w) + 2 * ch, ldin, De, dG0, De, 0);
     // the top-level Gaussian layer saw the self-conditioning distances, or nothing at all on a first step (flag [3] == 0: G0 = 0)
     JT_LAUNCH(k_scale_if_zero, (long)R * De, s, (long)R * De, dG0, (const int*)(b.flags + 3));
-    gbf_bwd(c, R, b.d2c, b.gm_top, t.gbf_means, t.gbf_stds, t.gbf_time, dG0, De, 0, nullptr);
+    gbf_bwd(c, R, b.d2c, b.gm_top, t.gbf_means, t.gbf_stds, b.dmods_all, Mt, dG0, De, 0, nullptr);
+    c.flush_fin();
     {   // the gathered q | k | v weight gradients of every block back to their tensors
         const int F3 = 2 * QK + D;
         ModGradTable M;
@@ -758,6 +820,8 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
     c.lin_dx(b.tB_T[0], T, B, T, c.p(t.time1.w), F17, F17, b.tB_T[1], F17, 0);
     JT_LAUNCH(k_time_feat_bwd, t.half, s, B, t.half, nl, c.p(t.time_w), (const float*)b.tB_T[1], c.g(t.time_w));
     c.flush_dw();                                            // the time / context MLPs' products: their operands are final where they are queued
+    c.flush_fin();
+    b.defer_fin = false;
 }
 
 Topo make_topo(const jodo_train& t, const void* desc_dev) {

@@ -306,6 +306,59 @@ __global__ void k_colsum_fin(long nchunks, int F, const float* __restrict__ part
     out[i_] = acc ? out[i_] + (float)t : (float)t;
 }
 
+// The second (and third) stages of the reductions above, MANY IN ONE LAUNCH (round 5, second half): the backward queues them — every
+// queued reduction keeps its partial sums in a region of its own — and runs the queue once per block.  Same loops as k_seg_fin,
+// k_seg_fin2, k_colsum_fin and a second-level k_colsum_part (chunk rows per output row): bit-identical to the launch-each form.
+enum { FIN_SEG = 0, FIN_SEG2 = 1, FIN_COL = 2, FIN_COLPART = 3 };
+struct FinJob { const float* part; float* out; const int* off; int kind, F, n, ldo, c1, c2, acc, blk0; };
+#define FIN_MAX 24
+struct FinTable { int n; FinJob j[FIN_MAX]; };
+inline long fin_threads(const FinJob& J) {
+    if (J.kind == FIN_SEG) return (long)J.n * J.F;
+    if (J.kind == FIN_SEG2) return (long)J.n * 2 * J.F;
+    if (J.kind == FIN_COL) return J.F;
+    return (long)((J.n + J.c2 - 1) / J.c2) * J.F;             // FIN_COLPART: c2 = rows per chunk
+}
+__global__ void k_fin_group(FinTable T) {
+    int ji = 0;
+    const int blk = (int)blockIdx.x;
+    while (ji + 1 < T.n && blk >= T.j[ji + 1].blk0) ++ji;
+    const FinJob& J = T.j[ji];
+    const long i_ = (long)(blk - J.blk0) * (long)blockDim.x + (long)threadIdx.x;
+    const int F = J.F;
+    if (J.kind == FIN_SEG) {
+        if (i_ >= (long)J.n * F) return;
+        const int s = (int)(i_ / F), f = (int)(i_ % F);
+        double t = 0.0;
+#pragma unroll 8
+        for (int c = J.off[s]; c < J.off[s + 1]; ++c) t += (double)J.part[(long)c * F + f];
+        float* o = J.out + (long)s * J.ldo + J.c1 + f;
+        *o = J.acc ? *o + (float)t : (float)t;
+    } else if (J.kind == FIN_SEG2) {
+        if (i_ >= (long)J.n * 2 * F) return;
+        const int s = (int)(i_ / (2 * F)), g = (int)(i_ % (2 * F));
+        double t = 0.0;
+#pragma unroll 8
+        for (int c = J.off[s]; c < J.off[s + 1]; ++c) t += (double)J.part[(long)c * 2 * F + g];
+        J.out[(long)s * J.ldo + (g < F ? J.c1 + g : J.c2 + g - F)] = (float)t;
+    } else if (J.kind == FIN_COL) {
+        if (i_ >= F) return;
+        double t = 0.0;
+#pragma unroll 8
+        for (long c = 0; c < J.n; ++c) t += (double)J.part[c * F + i_];
+        J.out[i_] = J.acc ? J.out[i_] + (float)t : (float)t;
+    } else {
+        const long chunk = J.c2, nch = (J.n + chunk - 1) / chunk;
+        if (i_ >= nch * F) return;
+        const long c = i_ / F; const int f = (int)(i_ % F);
+        const long r1 = (c + 1) * chunk < J.n ? (c + 1) * chunk : J.n;
+        double t = 0.0;
+#pragma unroll 8
+        for (long r = c * chunk; r < r1; ++r) t += (double)J.part[r * F + f];
+        J.out[i_] = (float)t;
+    }
+}
+
 // ================================================================ gates, broadcasts between node and edge arrays ================
 // y = a + g[mol] * b
 __global__ void k_gate_add(long rows, int F, const float* __restrict__ a, const float* __restrict__ b, const int* __restrict__ row_mol,
