@@ -353,7 +353,9 @@ size_t jodo_train_workspace_bytes(const jodo_train* t);
  *            no-grad self-conditioning forward of a training step, losses.py:335-339) and skip those stores — jodo_train_backward after
  *            such a forward is undefined;
  * option 3 = 1 (default): the backward's weight-gradient products are queued and run in grouped launches (csrc/train_gemm.hip
- *            gemm_dw_group: same plans and arithmetic as one launch each, bit-identical gradients); 0: one launch per product */
+ *            gemm_dw_group: same plans and arithmetic as one launch each, bit-identical gradients); 0: one launch per product;
+ * option 4 = 1 (default where built): the attention of a block as one forward and two backward launches, a wave per atom (bit-identical to
+ *            the op-by-op kernels); 0: scores | softmax | messages and their six backward kernels */
 int jodo_train_set_option(jodo_train* t, int option, int value);
 /* tests: byte offset and element count of a kept activation inside the workspace; what 0 = hhat [Nn, D] (TransMixLayer's output,
  * layers.py:153), 1 = alpha [R, H] (softmax weights, layers.py:178) of block `layer` */

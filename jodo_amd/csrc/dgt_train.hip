@@ -90,6 +90,7 @@ struct jodo_train {
     size_t ws_bytes;
     int fused;                        // 1: the three per-edge chains of a block run as fused strip kernels (train_fused.hip)
     int fused_bwd;                    // 1: their input-gradient sides too (the weight-gradient products stay GEMMs)
+    int fused_attn;                   // option 4: 1 = attention forward / backward as wave-per-atom kernels (train_fused.hip; bit-identical to the op-by-op ones)
     int group_dw;                     // option 3: 1 = the backward's weight-gradient products are queued and launched in groups (gemm_dw_group)
     int save_activations;             // option 2: 0 = the following forwards are not followed by a backward (no-grad self-conditioning call)
     int Mtot;                         // modulation floats per molecule: 2 (top-level GBF) + L (6 D + 6 De + 2 D + 2)
@@ -465,11 +466,17 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
             c.lin_tanh(k.et, De, R, De, c.p(ix.le0), De, QK, nullptr, k.t0);
             c.lin_tanh(k.et, De, R, De, c.p(ix.le1), De, D, nullptr, k.t1);
         }
-        JT_LAUNCH(k_attn_scores, (long)R * H, s, tp, H, t.XH, t.SC, 1.f / sqrtf((float)t.C), (const float*)k.q, (const float*)k.k,
-                           (const float*)k.t0, (const float*)b.adj2d, (const float*)b.adjsp, k.alpha);
-        JT_LAUNCH(k_attn_softmax, (long)Nn * H, s, tp, H, k.alpha);
-        JT_LAUNCH(k_attn_msg, (long)Nn * D, s, tp, D, H, (const float*)k.v, (const float*)k.t1, (const float*)k.alpha,
-                           c.drop(0.f, seed, l, SITE_ALPHA), k.hhat);     // p = 0: see SITE_ALPHA
+        const AttnTopo at{Nn, t.N, tp.node_mol, tp.nn, tp.node_off, tp.edge_off};
+        if (t.fused_attn) {
+            // scores | column softmax | messages in one launch, a wave per target atom (train_fused.hip; bit-identical to the three below)
+            fused_attn_fwd(s, at, D, H, t.XH, t.SC, 1.f / sqrtf((float)t.C), k.q, k.k, k.t0, b.adj2d, b.adjsp, k.v, k.t1, k.alpha, k.hhat);
+        } else {
+            JT_LAUNCH(k_attn_scores, (long)R * H, s, tp, H, t.XH, t.SC, 1.f / sqrtf((float)t.C), (const float*)k.q, (const float*)k.k,
+                               (const float*)k.t0, (const float*)b.adj2d, (const float*)b.adjsp, k.alpha);
+            JT_LAUNCH(k_attn_softmax, (long)Nn * H, s, tp, H, k.alpha);
+            JT_LAUNCH(k_attn_msg, (long)Nn * D, s, tp, D, H, (const float*)k.v, (const float*)k.t1, (const float*)k.alpha,
+                               c.drop(0.f, seed, l, SITE_ALPHA), k.hhat);     // p = 0: see SITE_ALPHA
+        }
         c.lin(k.hhat, D, Nn, D, c.p(ix.n2e.w), D, De, nullptr, k.n2e, De, 0);
         // edges: gated residual, LayerNorm2 + modulate, FFN (:313-317)
         if (t.fused) {
@@ -727,12 +734,18 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         const float isc = 1.f / sqrtf((float)t.C);
         const Drop da = c.drop(0.f, seed, l, SITE_ALPHA);                    // p = 0: see SITE_ALPHA
         float *dv = b.tN_D[1], *dt1 = b.tE_D[0], *dS = b.tE_H, *dq = b.tN_QK[0], *dk = b.tN_QK[1], *dt0 = b.tE_QK;
-        JT_LAUNCH(k_attn_bwd_v, (long)Nn * D, s, tp, D, H, (const float*)dhhat, (const float*)k.t1, (const float*)k.alpha, da, dv);
-        JT_LAUNCH(k_attn_bwd_t1, (long)R * D, s, tp, D, H, (const float*)dhhat, (const float*)k.v, (const float*)k.t1, (const float*)k.alpha, da, dt1);
-        JT_LAUNCH(k_attn_bwd_alpha, (long)R * H, s, tp, D, H, (const float*)dhhat, (const float*)k.v, (const float*)k.t1, da, dS);
-        JT_LAUNCH(k_attn_bwd_softmax, (long)Nn * H, s, tp, H, (const float*)k.alpha, dS);
-        JT_LAUNCH(k_attn_bwd_qk, (long)Nn * QK, s, tp, H, t.XH, t.SC, isc, (const float*)dS, (const float*)k.q, (const float*)k.k, (const float*)k.t0, dq, dk);
-        JT_LAUNCH(k_attn_bwd_t0, (long)R * QK, s, tp, H, t.XH, t.SC, isc, (const float*)dS, (const float*)k.q, (const float*)k.k, (const float*)k.t0, dt0);
+        if (t.fused_attn) {
+            // target side (d alpha, softmax backward, d t1, d q, d t0) and source side (d v, d k): two launches, bit-identical to the six below
+            const AttnTopo at{Nn, t.N, tp.node_mol, tp.nn, tp.node_off, tp.edge_off};
+            fused_attn_bwd(s, at, D, H, t.XH, t.SC, isc, dhhat, k.q, k.k, k.v, k.t0, k.t1, k.alpha, dS, dt1, dt0, dq, dk, dv);
+        } else {
+            JT_LAUNCH(k_attn_bwd_v, (long)Nn * D, s, tp, D, H, (const float*)dhhat, (const float*)k.t1, (const float*)k.alpha, da, dv);
+            JT_LAUNCH(k_attn_bwd_t1, (long)R * D, s, tp, D, H, (const float*)dhhat, (const float*)k.v, (const float*)k.t1, (const float*)k.alpha, da, dt1);
+            JT_LAUNCH(k_attn_bwd_alpha, (long)R * H, s, tp, D, H, (const float*)dhhat, (const float*)k.v, (const float*)k.t1, da, dS);
+            JT_LAUNCH(k_attn_bwd_softmax, (long)Nn * H, s, tp, H, (const float*)k.alpha, dS);
+            JT_LAUNCH(k_attn_bwd_qk, (long)Nn * QK, s, tp, H, t.XH, t.SC, isc, (const float*)dS, (const float*)k.q, (const float*)k.k, (const float*)k.t0, dq, dk);
+            JT_LAUNCH(k_attn_bwd_t0, (long)R * QK, s, tp, H, t.XH, t.SC, isc, (const float*)dS, (const float*)k.q, (const float*)k.k, (const float*)k.t0, dt0);
+        }
         float* det = b.tE_De[1];
         c.lin_dw(dt1, D, R, D, k.et, De, De, c.g(ix.le1), De);
         c.lin_dw(dt0, QK, R, QK, k.et, De, De, c.g(ix.le0), De);
@@ -948,6 +961,7 @@ int jodo_train_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes,
         t->fused_bwd = t->fused;
         t->save_activations = 1;
         t->group_dw = 1;
+        t->fused_attn = t->fused && fused_attention_available(t->D, t->H, t->N) ? 1 : 0;
         t->Mtot = 2 + t->L * (6 * t->D + 6 * t->De + 2 * t->D + 2);
     }
     Arena a{nullptr, 0}; Bufs bufs;
@@ -964,13 +978,21 @@ size_t jodo_train_workspace_bytes(const jodo_train* t) { return t ? t->ws_bytes 
 // option 1: the same for the input-gradient side of the backward
 // option 2: 1 (default) every forward keeps what a backward needs; 0: the following forwards will not be differentiated (the no-grad
 //           self-conditioning forward of a training step): the fused chains skip the stores only a backward reads
+// option 4: 1 (default where built) attention forward in one launch and backward in two (train_fused.hip k_attn_fwd / k_attn_bwd_tgt / _src:
+//           a wave per atom, every sum in the op-by-op kernels' order — bit-identical); 0: scores | softmax | messages and six backward kernels
 // option 3: 1 (default) the backward's weight-gradient products run in grouped launches (train_gemm.hip gemm_dw_group); 0: one launch
 //           (+ one split-K sum) each — same plans, same arithmetic, bit-identical gradients
 int jodo_train_set_option(jodo_train* t, int option, int value) {
     if (!t) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: null handle");
-    if (option < 0 || option > 3 || (value != 0 && value != 1)) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: option %d value %d", option, value);
+    if (option < 0 || option > 4 || (value != 0 && value != 1)) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: option %d value %d", option, value);
     if (option == 2) { t->save_activations = value; return JODO_OK; }
     if (option == 3) { t->group_dw = value; return JODO_OK; }
+    if (option == 4) {
+        if (value && !(fused_available(FusedDims{t->D, t->De, t->r, t->QK, t->ce, t->L}) && fused_attention_available(t->D, t->H, t->N)))
+            return jodo_set_error(JODO_ERR_UNSUPPORTED, "jodo_train_set_option: the fused attention kernels are not built for this shape");
+        t->fused_attn = value;
+        return JODO_OK;
+    }
     const FusedDims fd{t->D, t->De, t->r, t->QK, t->ce, t->L};
     if (value && !fused_available(fd)) return jodo_set_error(JODO_ERR_UNSUPPORTED, "jodo_train_set_option: fused chains are not built for this shape");
     if (option == 0) t->fused = value; else t->fused_bwd = value;

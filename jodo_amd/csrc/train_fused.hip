@@ -835,4 +835,254 @@ void fused_node_ln_mod_bwd(hipStream_t s, long rows, int F, const float* dy, con
     else hipLaunchKernelGGL(k_node_ln_mod_bwd<6>, grid, block, 0, s, rows, dy, xhat, rstd, row_mol, mods, ldm, sc_off, dx, acc);
 }
 
+// ---- attention of a block (layers.py:131-186), forward in one launch and backward in two (round 5, second half) ----------------------
+// The op-by-op form is scores | column softmax | messages (three launches, the [R, H] scores through memory twice) and six launches
+// backwards; each walks the molecule's n x n tile with one thread per output.  Here a wave owns one TARGET atom c (forward, and the
+// target-side half of the backward) or one SOURCE atom a (the other half): its rows (a, c) are read once per pass, the [n, H] scores /
+// weights of the atom live in LDS, and every sum runs in the order of the op-by-op kernels — the results are bit-identical to them.
+// One wave per workgroup (its __syncthreads() is a wave barrier), n <= ATT_NMAX.
+constexpr int ATT_NMAX = 192;
+
+__device__ __forceinline__ void att_ids(const AttnTopo& t, int node, int& b, int& n, int& i, long& e0, long& n0) {
+    b = t.node_mol[node]; n = t.nn[b]; n0 = t.node_off[b]; i = node - (int)n0; e0 = t.edge_off[b];
+}
+
+// forward: S[(a, c), hd] -> alpha (kept) -> hhat[c, f] = sum_a v[a, f] t1[(a, c), f] alpha[(a, c), f / C].
+// W waves per target: they share the sources in the score pass and the FEATURES in the message pass (NV / W of the NV 64-feature slices
+// each), so no sum changes its order.
+template <int NV, int W>
+__global__ __launch_bounds__(64 * W) void k_attn_fwd(AttnTopo t, int H, int XH, int SC, float inv_sqrt_c, const float* __restrict__ q, const float* __restrict__ k,
+                                                     const float* __restrict__ t0, const float* __restrict__ adj2d, const float* __restrict__ adjsp,
+                                                     const float* __restrict__ v, const float* __restrict__ t1, float* __restrict__ alpha, float* __restrict__ hhat) {
+    constexpr int D = NV * 64, NW = NV / W;
+    static_assert(NV % W == 0, "the waves of a target share the 64-feature slices evenly");
+    extern __shared__ float att_lds[];                            // [N][16] scores / weights of this target (N = the batch's largest molecule) | max, sum
+    float (*A)[16] = reinterpret_cast<float (*)[16]>(att_lds);
+    float (*MS)[16] = reinterpret_cast<float (*)[16]>(att_lds + (size_t)t.N * 16);
+    const int node = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = tid >> 4, hd = tid & 15;      // g: 0 .. 4 W - 1
+    int b, n, c; long e0, n0;
+    att_ids(t, node, b, n, c, e0, n0);
+    const int QK = (H - XH) * SC, C = D / H;
+    // scores: thread (g, hd) takes head hd of the sources a = g, g + 4 W, ...
+    if (hd < H) {
+        for (int a = g; a < n; a += 4 * W) {
+            const long r = e0 + (long)a * n + c;
+            float s;
+            if (hd < XH) s = ((hd == 0 ? adj2d[r] : adjsp[r]) > 0.f) ? 1.f : -1e10f;
+            else {
+                const float* qq = q + (long)node * QK + (hd - XH) * SC;
+                const float* kk = k + (n0 + a) * QK + (hd - XH) * SC;
+                const float* tt = t0 + r * QK + (hd - XH) * SC;
+                float acc = 0.f;
+#pragma unroll 6
+                for (int j = 0; j < SC; ++j) acc += qq[j] * kk[j] * tt[j];
+                s = acc * inv_sqrt_c;
+            }
+            A[a][hd] = s;
+        }
+    }
+    __syncthreads();
+    // column softmax over the sources a != c, one lane per head, sequentially like k_attn_softmax
+    if (tid < H) {
+        float m = -INFINITY;
+        for (int a = 0; a < n; ++a) if (a != c) m = fmaxf(m, A[a][tid]);
+        float sum = 0.f;
+        for (int a = 0; a < n; ++a) if (a != c) sum += expf(A[a][tid] - m);
+        MS[0][tid] = m; MS[1][tid] = sum;
+    }
+    __syncthreads();
+    if (hd < H) {
+        const float m = MS[0][hd], sum = MS[1][hd];
+        for (int a = g; a < n; a += 4 * W) {
+            const float wgt = a == c ? 0.f : expf(A[a][hd] - m) / (sum + 1e-16f);
+            A[a][hd] = wgt;
+            alpha[(e0 + (long)a * n + c) * H + hd] = wgt;
+        }
+    }
+    __syncthreads();
+    // messages: wave w takes the features lane + 64 j, j = w NW .. (w + 1) NW - 1
+    float acc[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) acc[j] = 0.f;
+#pragma unroll 4
+    for (int a = 0; a < n; ++a) {
+        const long r = e0 + (long)a * n + c;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int f = lane + 64 * (w * NW + j);
+            acc[j] += v[(n0 + a) * D + f] * t1[r * D + f] * A[a][f / C];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) hhat[(long)node * D + lane + 64 * (w * NW + j)] = acc[j];
+}
+
+// backward, target side (W waves per target c): d alpha -> d S (softmax backward, kept for the source side) -> d t1, d q, d t0.
+// W = 4 at small batches (a QM9 batch of 128 molecules has 2 260 atoms: two waves per SIMD cannot hide their own load latency): the
+// waves share the sources (a = w, w + W, ...), the partial d q sums meet in LDS in the order w = 0 .. W - 1.
+template <int NV, int W>
+__global__ __launch_bounds__(64 * W) void k_attn_bwd_tgt(AttnTopo t, int H, int XH, int SC, float inv_sqrt_c, const float* __restrict__ dhhat,
+                                                         const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                         const float* __restrict__ t0, const float* __restrict__ t1, const float* __restrict__ alpha,
+                                                         float* __restrict__ dS, float* __restrict__ dt1, float* __restrict__ dq, float* __restrict__ dt0) {
+    constexpr int D = NV * 64;
+    extern __shared__ float att_lds[];                            // alpha [N][16] | d alpha, then d S [N][16] | 16 dots | W partial rows of d q
+    float (*A)[16] = reinterpret_cast<float (*)[16]>(att_lds);
+    float (*G)[16] = reinterpret_cast<float (*)[16]>(att_lds + (size_t)t.N * 16);
+    float* DOT = att_lds + (size_t)t.N * 32;
+    float* PQ = DOT + 16;
+    const int node = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = (tid >> 4), hd = tid & 15;      // g: 0 .. 4 W - 1
+    int b, n, c; long e0, n0;
+    att_ids(t, node, b, n, c, e0, n0);
+    const int QK = (H - XH) * SC, C = D / H;
+    if (hd < H) {
+        const float* dh = dhhat + (long)node * D + hd * C;
+        for (int a = g; a < n; a += 4 * W) {
+            const long r = e0 + (long)a * n + c;
+            const float* vv = v + (n0 + a) * D + hd * C;
+            const float* tt = t1 + r * D + hd * C;
+            float s = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < C; ++j) s += dh[j] * vv[j] * tt[j];
+            G[a][hd] = s;
+            A[a][hd] = alpha[r * H + hd];
+        }
+    }
+    __syncthreads();
+    if (tid < H) {
+        float dot = 0.f;
+        for (int a = 0; a < n; ++a) dot += A[a][tid] * G[a][tid];
+        DOT[tid] = dot;
+    }
+    __syncthreads();
+    if (hd < H) {
+        const float dot = DOT[hd];
+        for (int a = g; a < n; a += 4 * W) {
+            const float ds = A[a][hd] * (G[a][hd] - dot);
+            G[a][hd] = ds;
+            dS[(e0 + (long)a * n + c) * H + hd] = ds;
+        }
+    }
+    __syncthreads();
+    float dhv[NV], qv[NV], sq[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int f = lane + 64 * j;
+        dhv[j] = dhhat[(long)node * D + f];
+        qv[j] = f < QK ? q[(long)node * QK + f] : 0.f;
+        sq[j] = 0.f;
+    }
+#pragma unroll 4
+    for (int a = w; a < n; a += W) {
+        const long r = e0 + (long)a * n + c;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int f = lane + 64 * j;
+            const float tv = t1[r * D + f];
+            dt1[r * D + f] = dhv[j] * v[(n0 + a) * D + f] * A[a][f / C] * (1.f - tv * tv);
+            if (f < QK) {
+                const float ds = G[a][XH + f / SC], kv = k[(n0 + a) * QK + f], t0v = t0[r * QK + f];
+                sq[j] += ds * kv * t0v;
+                dt0[r * QK + f] = ds * qv[j] * kv * inv_sqrt_c * (1.f - t0v * t0v);
+            }
+        }
+    }
+    if (W > 1) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) PQ[w * D + lane + 64 * j] = sq[j];
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                float tsum = PQ[lane + 64 * j];
+                for (int x = 1; x < W; ++x) tsum += PQ[x * D + lane + 64 * j];
+                sq[j] = tsum;
+            }
+        }
+    }
+    if (w == 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int f = lane + 64 * j;
+            if (f < QK) dq[(long)node * QK + f] = sq[j] * inv_sqrt_c;
+        }
+    }
+}
+
+// backward, source side (W waves per source a): d v[a, f] = sum_c dhhat[c, f] t1[(a, c), f] alpha[(a, c), f / C];
+// d k[a, j] = sum_c d S[(a, c), hd(j)] q[c, j] t0[(a, c), j] / sqrt(C)
+template <int NV, int W>
+__global__ __launch_bounds__(64 * W) void k_attn_bwd_src(AttnTopo t, int H, int XH, int SC, float inv_sqrt_c, const float* __restrict__ dhhat,
+                                                         const float* __restrict__ q, const float* __restrict__ t0, const float* __restrict__ t1,
+                                                         const float* __restrict__ alpha, const float* __restrict__ dS, float* __restrict__ dv,
+                                                         float* __restrict__ dk) {
+    constexpr int D = NV * 64;
+    extern __shared__ float att_lds[];                            // W partial rows of d v | of d k
+    const int node = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int b, n, a; long e0, n0;
+    att_ids(t, node, b, n, a, e0, n0);
+    const int QK = (H - XH) * SC, C = D / H;
+    float sv[NV], sk[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { sv[j] = 0.f; sk[j] = 0.f; }
+#pragma unroll 4
+    for (int c = w; c < n; c += W) {
+        const long r = e0 + (long)a * n + c;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int f = lane + 64 * j;
+            sv[j] += dhhat[(n0 + c) * D + f] * t1[r * D + f] * alpha[r * H + f / C];
+            if (f < QK) sk[j] += dS[r * H + XH + f / SC] * q[(n0 + c) * QK + f] * t0[r * QK + f];
+        }
+    }
+    if (W > 1) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { att_lds[w * D + lane + 64 * j] = sv[j]; att_lds[(W + w) * D + lane + 64 * j] = sk[j]; }
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                float tv = att_lds[lane + 64 * j], tk = att_lds[W * D + lane + 64 * j];
+                for (int x = 1; x < W; ++x) { tv += att_lds[x * D + lane + 64 * j]; tk += att_lds[(W + x) * D + lane + 64 * j]; }
+                sv[j] = tv; sk[j] = tk;
+            }
+        }
+    }
+    if (w == 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int f = lane + 64 * j;
+            dv[(long)node * D + f] = sv[j];
+            if (f < QK) dk[(long)node * QK + f] = sk[j] * inv_sqrt_c;
+        }
+    }
+}
+
+bool fused_attention_available(int D, int H, int N) { return (D == 128 || D == 256 || D == 384) && H <= 16 && N <= ATT_NMAX; }
+
+void fused_attn_fwd(hipStream_t s, const AttnTopo& t, int D, int H, int XH, int SC, float inv_sqrt_c, const float* q, const float* k, const float* t0,
+                    const float* adj2d, const float* adjsp, const float* v, const float* t1, float* alpha, float* hhat) {
+    const dim3 grid((unsigned)t.Nn);
+    const unsigned lds = (unsigned)(((size_t)t.N * 16 + 32) * sizeof(float));
+    const bool wide = t.Nn < 16384;                          // few atoms: several waves per target (same arithmetic)
+#define JT_AF(NV, WW) hipLaunchKernelGGL((k_attn_fwd<NV, WW>), grid, dim3(64 * WW), lds, s, t, H, XH, SC, inv_sqrt_c, q, k, t0, adj2d, adjsp, v, t1, alpha, hhat)
+    if (D == 128) { if (wide) JT_AF(2, 2); else JT_AF(2, 1); }
+    else if (D == 256) { if (wide) JT_AF(4, 4); else JT_AF(4, 1); }
+    else { if (wide) JT_AF(6, 3); else JT_AF(6, 1); }
+#undef JT_AF
+}
+void fused_attn_bwd(hipStream_t s, const AttnTopo& t, int D, int H, int XH, int SC, float inv_sqrt_c, const float* dhhat, const float* q, const float* k,
+                    const float* v, const float* t0, const float* t1, const float* alpha, float* dS, float* dt1, float* dt0, float* dq, float* dk, float* dv) {
+    const dim3 grid((unsigned)t.Nn);
+    // few atoms (the reference's training batches): four waves per atom; batches that fill the card on their own: one
+    const int W = t.Nn < 16384 ? 4 : 1;
+    const unsigned lds_t = (unsigned)(((size_t)t.N * 32 + 16 + (size_t)W * D) * sizeof(float)), lds_s = (unsigned)((size_t)2 * W * D * sizeof(float));
+#define JT_AB(NV, WW) do { \
+        hipLaunchKernelGGL((k_attn_bwd_tgt<NV, WW>), grid, dim3(64 * WW), lds_t, s, t, H, XH, SC, inv_sqrt_c, dhhat, q, k, v, t0, t1, alpha, dS, dt1, dq, dt0); \
+        hipLaunchKernelGGL((k_attn_bwd_src<NV, WW>), grid, dim3(64 * WW), lds_s, s, t, H, XH, SC, inv_sqrt_c, dhhat, q, t0, t1, alpha, (const float*)dS, dv, dk); } while (0)
+    if (W == 4) { if (D == 128) JT_AB(2, 4); else if (D == 256) JT_AB(4, 4); else JT_AB(6, 4); }
+    else { if (D == 128) JT_AB(2, 1); else if (D == 256) JT_AB(4, 1); else JT_AB(6, 1); }
+#undef JT_AB
+}
+
 }  // namespace jt

@@ -99,4 +99,9 @@ void fused_bwd_a(hipStream_t, const FusedDims&, const FusedTopo&, const FusedBlo
                  const float*, float*, float*, float*, float*) {}
 void fused_node_ln_mod(hipStream_t, long, int, const float*, const float*, const int*, const float*, int, int, int, int, float*, float*, float*) {}
 void fused_node_ln_mod_bwd(hipStream_t, long, int, const float*, const float*, const float*, const int*, const float*, int, int, float*, int) {}
+bool fused_attention_available(int, int, int) { return false; }
+void fused_attn_fwd(hipStream_t, const AttnTopo&, int, int, int, int, float, const float*, const float*, const float*, const float*, const float*, const float*,
+                    const float*, float*, float*) {}
+void fused_attn_bwd(hipStream_t, const AttnTopo&, int, int, int, int, float, const float*, const float*, const float*, const float*, const float*, const float*,
+                    const float*, float*, float*, float*, float*, float*, float*) {}
 }

@@ -360,6 +360,20 @@ def test_fused_forward_chains_equal_the_op_by_op_forward(cfg_name, n_nodes, over
     ((ox * d(d_x)).sum() + (oe * d(d_e)).sum()).backward()
     diff = [name for (name, _), p, g in zip(model.named_parameters(), model.parameters(), res[(1, 1)][2]) if not torch.equal(p.grad.cpu(), g)]
     assert not diff, "grouped and one-by-one weight gradients differ: %s" % diff[:20]
+    # the attention of a block runs as one forward and two backward launches, a wave per atom (train_fused.hip k_attn_*, option 4), with
+    # the forward's sums in the order of the op-by-op kernels (outputs bit for bit), the backward's partial sums shared by four waves
+    model.train_options = {0: 1, 1: 1, 4: 0}
+    model.zero_grad()
+    torch.manual_seed(77)
+    ox, oe = model(d(nl), d(xh), d(nm), d(em), d(ctx), edge_x=d(ex), cond_x=d(cx), cond_edge_x=d(cex), noise_level=d(nl))
+    ((ox * d(d_x)).sum() + (oe * d(d_e)).sum()).backward()
+    assert torch.equal(ox.detach().cpu(), res[(1, 1)][0]) and torch.equal(oe.detach().cpu(), res[(1, 1)][1])
+    bad = []
+    for (name, _), p, g in zip(model.named_parameters(), model.parameters(), res[(1, 1)][2]):
+        scale, err = float(g.abs().max()), float((p.grad.cpu() - g).abs().max())
+        if not err <= (1e-3 if ('dist_layer' in name or 'time_mlp' in name) else 2e-4) * max(scale, 1e-12) + 1e-9:
+            bad.append("%s: %.3e of %.3e" % (name, err, scale))
+    assert not bad, "wave-per-atom and op-by-op attention differ in the gradients of:\n  " + "\n  ".join(bad[:20])     # (backward: other sum order, float32 noise)
     # the no-grad call of a training step (self-conditioning forward, losses.py:335-339: dropout active, nothing differentiated) skips
     # the stores only a backward reads (jodo_train_set_option 2): same outputs bit for bit, and a grad-enabled call afterwards still works
     model.train_options = {0: 1, 1: 1}
