@@ -14,7 +14,7 @@ with_bwd = len(sys.argv) > 3 and sys.argv[3] == 'bwd'        # also run loss.bac
 cfg = configs.get('vpsde_qm9_uncond_jodo')
 dev = torch.device('cuda:0')
 cfg.device = dev
-B = int(cfg.training.batch_size)
+B = int(os.environ.get("JODO_PROF_BATCH", cfg.training.batch_size))
 torch.manual_seed(42)
 n_nodes = get_node_dist(load_dataset_info('qm9_with_h')).sample(B).tolist()
 model = deterministic_init_(get_model_class(cfg.model.name)(cfg), seed=42).to(dev)
