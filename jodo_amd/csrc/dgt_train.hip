@@ -466,7 +466,7 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
             c.lin_tanh(k.et, De, R, De, c.p(ix.le0), De, QK, nullptr, k.t0);
             c.lin_tanh(k.et, De, R, De, c.p(ix.le1), De, D, nullptr, k.t1);
         }
-        const AttnTopo at{Nn, t.N, tp.node_mol, tp.nn, tp.node_off, tp.edge_off};
+        const AttnTopo at{Nn, t.N, tp.node_mol, tp.nn, tp.node_off, tp.edge_off, t.fused_attn == 2 ? 1 : 0};
         if (t.fused_attn) {
             // scores | column softmax | messages in one launch, a wave per target atom (train_fused.hip; bit-identical to the three below)
             fused_attn_fwd(s, at, D, H, t.XH, t.SC, 1.f / sqrtf((float)t.C), k.q, k.k, k.t0, b.adj2d, b.adjsp, k.v, k.t1, k.alpha, k.hhat);
@@ -736,7 +736,7 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         float *dv = b.tN_D[1], *dt1 = b.tE_D[0], *dS = b.tE_H, *dq = b.tN_QK[0], *dk = b.tN_QK[1], *dt0 = b.tE_QK;
         if (t.fused_attn) {
             // target side (d alpha, softmax backward, d t1, d q, d t0) and source side (d v, d k): two launches, bit-identical to the six below
-            const AttnTopo at{Nn, t.N, tp.node_mol, tp.nn, tp.node_off, tp.edge_off};
+            const AttnTopo at{Nn, t.N, tp.node_mol, tp.nn, tp.node_off, tp.edge_off, t.fused_attn == 2 ? 1 : 0};
             fused_attn_bwd(s, at, D, H, t.XH, t.SC, isc, dhhat, k.q, k.k, k.v, k.t0, k.t1, k.alpha, dS, dt1, dt0, dq, dk, dv);
         } else {
             JT_LAUNCH(k_attn_bwd_v, (long)Nn * D, s, tp, D, H, (const float*)dhhat, (const float*)k.t1, (const float*)k.alpha, da, dv);
@@ -979,12 +979,13 @@ size_t jodo_train_workspace_bytes(const jodo_train* t) { return t ? t->ws_bytes 
 // option 2: 1 (default) every forward keeps what a backward needs; 0: the following forwards will not be differentiated (the no-grad
 //           self-conditioning forward of a training step): the fused chains skip the stores only a backward reads
 // option 4: 1 (default where built) attention forward in one launch and backward in two (train_fused.hip k_attn_fwd / k_attn_bwd_tgt / _src:
-//           a wave per atom, every sum in the op-by-op kernels' order — bit-identical); 0: scores | softmax | messages and six backward kernels
+//           one to four waves per atom, the forward's sums in the op-by-op kernels' order — bit-identical); 0: scores | softmax | messages and six
+//           backward kernels; 2: the one-wave-per-atom form that batches above 16 k atoms take (tests)
 // option 3: 1 (default) the backward's weight-gradient products run in grouped launches (train_gemm.hip gemm_dw_group); 0: one launch
 //           (+ one split-K sum) each — same plans, same arithmetic, bit-identical gradients
 int jodo_train_set_option(jodo_train* t, int option, int value) {
     if (!t) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: null handle");
-    if (option < 0 || option > 4 || (value != 0 && value != 1)) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: option %d value %d", option, value);
+    if (option < 0 || option > 4 || (value != 0 && value != 1 && !(option == 4 && value == 2))) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: option %d value %d", option, value);
     if (option == 2) { t->save_activations = value; return JODO_OK; }
     if (option == 3) { t->group_dw = value; return JODO_OK; }
     if (option == 4) {

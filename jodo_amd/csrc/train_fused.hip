@@ -1064,7 +1064,7 @@ void fused_attn_fwd(hipStream_t s, const AttnTopo& t, int D, int H, int XH, int 
                     const float* adj2d, const float* adjsp, const float* v, const float* t1, float* alpha, float* hhat) {
     const dim3 grid((unsigned)t.Nn);
     const unsigned lds = (unsigned)(((size_t)t.N * 16 + 32) * sizeof(float));
-    const bool wide = t.Nn < 16384;                          // few atoms: several waves per target (same arithmetic)
+    const bool wide = t.Nn < 16384 && !t.one_wave;                          // few atoms: several waves per target (same arithmetic)
 #define JT_AF(NV, WW) hipLaunchKernelGGL((k_attn_fwd<NV, WW>), grid, dim3(64 * WW), lds, s, t, H, XH, SC, inv_sqrt_c, q, k, t0, adj2d, adjsp, v, t1, alpha, hhat)
     if (D == 128) { if (wide) JT_AF(2, 2); else JT_AF(2, 1); }
     else if (D == 256) { if (wide) JT_AF(4, 4); else JT_AF(4, 1); }
@@ -1075,7 +1075,7 @@ void fused_attn_bwd(hipStream_t s, const AttnTopo& t, int D, int H, int XH, int 
                     const float* v, const float* t0, const float* t1, const float* alpha, float* dS, float* dt1, float* dt0, float* dq, float* dk, float* dv) {
     const dim3 grid((unsigned)t.Nn);
     // few atoms (the reference's training batches): four waves per atom; batches that fill the card on their own: one
-    const int W = t.Nn < 16384 ? 4 : 1;
+    const int W = (t.Nn < 16384 && !t.one_wave) ? 4 : 1;
     const unsigned lds_t = (unsigned)(((size_t)t.N * 32 + 16 + (size_t)W * D) * sizeof(float)), lds_s = (unsigned)((size_t)2 * W * D * sizeof(float));
 #define JT_AB(NV, WW) do { \
         hipLaunchKernelGGL((k_attn_bwd_tgt<NV, WW>), grid, dim3(64 * WW), lds_t, s, t, H, XH, SC, inv_sqrt_c, dhhat, q, k, v, t0, t1, alpha, dS, dt1, dq, dt0); \

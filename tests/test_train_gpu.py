@@ -334,7 +334,7 @@ def test_fused_forward_chains_equal_the_op_by_op_forward(cfg_name, n_nodes, over
         ox, oe = model(d(nl), d(xh), d(nm), d(em), d(ctx), edge_x=d(ex), cond_x=d(cx), cond_edge_x=d(cex), noise_level=d(nl))
         ((ox * d(d_x)).sum() + (oe * d(d_e)).sum()).backward()
         res[fused] = (ox.detach().cpu(), oe.detach().cpu(), [p.grad.detach().cpu().clone() for p in model.parameters()])
-    assert len(model._train_engines) == 3                              # one handle per option set
+    assert len(model._train_engines) == 3                              # one handle per option set (so far)
     ref = res[(0, 0)]
     close(res[(1, 1)][0], ref[0], atol=2e-5)
     close(res[(1, 1)][1], ref[1], atol=2e-5)
@@ -368,12 +368,23 @@ def test_fused_forward_chains_equal_the_op_by_op_forward(cfg_name, n_nodes, over
     ox, oe = model(d(nl), d(xh), d(nm), d(em), d(ctx), edge_x=d(ex), cond_x=d(cx), cond_edge_x=d(cex), noise_level=d(nl))
     ((ox * d(d_x)).sum() + (oe * d(d_e)).sum()).backward()
     assert torch.equal(ox.detach().cpu(), res[(1, 1)][0]) and torch.equal(oe.detach().cpu(), res[(1, 1)][1])
-    bad = []
-    for (name, _), p, g in zip(model.named_parameters(), model.parameters(), res[(1, 1)][2]):
-        scale, err = float(g.abs().max()), float((p.grad.cpu() - g).abs().max())
-        if not err <= (1e-3 if ('dist_layer' in name or 'time_mlp' in name) else 2e-4) * max(scale, 1e-12) + 1e-9:
-            bad.append("%s: %.3e of %.3e" % (name, err, scale))
-    assert not bad, "wave-per-atom and op-by-op attention differ in the gradients of:\n  " + "\n  ".join(bad[:20])     # (backward: other sum order, float32 noise)
+    def grads_close(what):
+        bad = []
+        for (name, _), p, g in zip(model.named_parameters(), model.parameters(), res[(1, 1)][2]):
+            scale, err = float(g.abs().max()), float((p.grad.cpu() - g).abs().max())
+            if not err <= (1e-3 if ('dist_layer' in name or 'time_mlp' in name) else 2e-4) * max(scale, 1e-12) + 1e-9:
+                bad.append("%s: %.3e of %.3e" % (name, err, scale))
+        assert not bad, what + " differ in the gradients of:\n  " + "\n  ".join(bad[:20])     # (backward: other sum order, float32 noise)
+
+    grads_close("wave-per-atom and op-by-op attention")
+    # ... and the one-wave-per-atom form that batches above 16 k atoms take (option 4 = 2): forward bit for bit again
+    model.train_options = {0: 1, 1: 1, 4: 2}
+    model.zero_grad()
+    torch.manual_seed(77)
+    ox, oe = model(d(nl), d(xh), d(nm), d(em), d(ctx), edge_x=d(ex), cond_x=d(cx), cond_edge_x=d(cex), noise_level=d(nl))
+    ((ox * d(d_x)).sum() + (oe * d(d_e)).sum()).backward()
+    assert torch.equal(ox.detach().cpu(), res[(1, 1)][0]) and torch.equal(oe.detach().cpu(), res[(1, 1)][1])
+    grads_close("one-wave and four-wave attention")
     # the no-grad call of a training step (self-conditioning forward, losses.py:335-339: dropout active, nothing differentiated) skips
     # the stores only a backward reads (jodo_train_set_option 2): same outputs bit for bit, and a grad-enabled call afterwards still works
     model.train_options = {0: 1, 1: 1}
