@@ -56,7 +56,7 @@ struct Bufs {
     float *nh1pre, *nh1, *nh2pre, *nh2, *atom, *x1pre[2], *x1[2], *x2pre[2], *x2[2], *Ep, *posf;
     // scratch shared by all phases
     float *tE_D[3], *tE_De[4], *tE_QK, *tE_rD, *tE_H, *tN_D[4], *tN_QK[2], *tN_rD, *tN_De, *tRow[3], *tE3[3], *tN3[4], *tcatn, *tcate;
-    float *dtau, *dtemb, *dnmod, *demod, *dqmod, *dgm, *tB_T[2], *tB_cD[2], *part, *part2, *rowpart, *splitk;
+    float *dtau, *dtemb, *tB_T[2], *tB_cD[2], *part, *part2, *rowpart, *splitk;
     float* fpack;                     // packed MFMA operands of the fused chains (forward + transposed images), one slice per block (train_fused.h)
     float* tE_De2[3];                 // scratch of the fused backward chains: df4 | den | de1
     float *Wall, *ball, *mods_all, *dmods_all, *dWall, *dball;      // batched modulation projections (train_ops.h ModTable)
@@ -132,7 +132,7 @@ void layout(const jodo_train& t, Arena& a, Bufs& b) {
     for (int s = 0; s < 3; ++s) b.tE3[s] = a.f(R * 3);
     for (int s = 0; s < 4; ++s) b.tN3[s] = a.f(Nn * 3);
     b.tcatn = a.f(Nn * t.catn); b.tcate = a.f(R * t.cate);
-    b.dtau = a.f(B * T); b.dtemb = a.f(B * T); b.dnmod = a.f(B * 6 * D); b.demod = a.f(B * 6 * De); b.dqmod = a.f(B * 2 * D); b.dgm = a.f(B * 2);
+    b.dtau = a.f(B * T); b.dtemb = a.f(B * T);       // (modulation gradients go straight into dmods_all)
     for (int s = 0; s < 2; ++s) { b.tB_T[s] = a.f(B * T); b.tB_cD[s] = a.f(B * cc * D); }
     const size_t rows = R > Nn ? R : Nn;
     const size_t maxF = std::max<size_t>({(size_t)6 * D, T, r * D});
@@ -237,6 +237,13 @@ struct Ctx {
     void seg_edge(int F, const float* a, const float* bb, float* out, int ldo, int ocol) const {
         float* part = b.defer_fin ? fin_alloc((size_t)tp.NC * F) : b.part;
         JT_LAUNCH(k_seg_part, (long)tp.NC * F, s, tp.NC, F, tp.ec_off, a, bb, part);
+        if (b.defer_fin) push_fin(FinJob{part, out, tp.ec_mol_off, FIN_SEG, F, t.B, ldo, ocol, 0, 0, 0});
+        else JT_LAUNCH(k_seg_fin, (long)t.B * F, s, t.B, F, tp.ec_mol_off, (const float*)part, out, ldo, ocol, 0);
+    }
+    // out[mol, ocol + f] = sum over the molecule's edge rows of a[(a, c), f] (p[a, f] + p[c, f] + bias[f])
+    void seg_edge_ehat(int F, const float* a, const float* p, const float* bias, float* out, int ldo, int ocol) const {
+        float* part = b.defer_fin ? fin_alloc((size_t)tp.NC * F) : b.part;
+        JT_LAUNCH(k_seg_part_ehat, (long)tp.NC * F, s, tp, F, a, p, bias, part);
         if (b.defer_fin) push_fin(FinJob{part, out, tp.ec_mol_off, FIN_SEG, F, t.B, ldo, ocol, 0, 0, 0});
         else JT_LAUNCH(k_seg_fin, (long)t.B * F, s, t.B, F, tp.ec_mol_off, (const float*)part, out, ldo, ocol, 0);
     }
@@ -574,8 +581,7 @@ void gbf_bwd(const Ctx& c, long rows, const float* d2, const float* gm, int mean
     const jodo_train& t = c.t; Bufs& b = c.b; hipStream_t s = c.s;
     const int De = t.De, K = De - 1;
     JT_LAUNCH(k_gbf_bwd_row, rows, s, rows, De, d2, c.tp.edge_mol, gm, c.p(means), c.p(stds), dG, ldg, gcol, b.tRow[2], dd2, 0);
-    c.seg_edge(1, b.tRow[2], d2, dgm, ldd, 0);              // d scale = sum dx' d2,  d shift = sum dx'  per molecule
-    c.seg_edge(1, b.tRow[2], nullptr, dgm, ldd, 1);
+    c.seg2_edge(1, b.tRow[2], d2, dgm, ldd, 1, 0);          // d shift = sum dx' (column 1), d scale = sum dx' d2 (column 0) per molecule, one pass
     const int chunk = 32;
     const long nch = (rows + chunk - 1) / chunk;
     float *pm = b.tE_QK, *ps = b.tE_QK + nch * K;            // (the attention scratch is free here)
@@ -703,16 +709,13 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
             c.lin_dx(tE, r * De, R, r * De, c.p(ix.ff3.w), De, De, de, De, 1);                          // de is now d en
             c.ln_mod_bwd(R, De, de, k.xh_en, k.rs_en, tp.edge_mol, tp.edge_off, k.emod, 6 * De, 3 * De, 4 * De, demod, Mt, de_prev, 0);   // de_prev = d x1e = d e[l] (residual)
         }
-        float* ehat = dten;
-        JT_LAUNCH(k_edge_bcast, (long)R * De, s, tp, De, (const float*)nullptr, (const float*)k.n2e, (const float*)k.n2e, c.p(ix.n2e.b),
-                           (const float*)nullptr, 0, 0, ehat);
-        c.seg(De, tp.edge_off, de_prev, ehat, demod, Mt, 2 * De);                                   // d eg1
+        // d eg1 = sum over the molecule of d x1e * ehat, ehat = node2edge_lin(h_a) + node2edge_lin(h_c) + bias formed on the fly
+        c.seg_edge_ehat(De, de_prev, k.n2e, c.p(ix.n2e.b), demod, Mt, 2 * De);
         float* dehat = dten;
         JT_LAUNCH(k_gate_bwd, (long)R * De, s, (long)R, De, (const float*)de_prev, tp.edge_mol, (const float*)k.emod, 6 * De, 2 * De, dehat, 0);
         c.colsum(dehat, De, nullptr, 0, R, De, c.g(ix.n2e.b));
         float* dn2e = b.tN_De;
-        JT_LAUNCH(k_edge_to_node, (long)Nn * De, s, tp, De, (const float*)dehat, dn2e, (float*)nullptr, 0);
-        JT_LAUNCH(k_edge_to_node, (long)Nn * De, s, tp, De, (const float*)dehat, (float*)nullptr, dn2e, 1);
+        JT_LAUNCH(k_edge_to_node, (long)Nn * De, s, tp, De, (const float*)dehat, dn2e, dn2e, 0);       // row sums + column sums (both atoms of an edge)
         c.lin_dw(dn2e, De, Nn, De, k.hhat, D, D, c.g(ix.n2e.w), D);
         float* dhhat = b.tN_D[0];
         c.lin_dx(dn2e, De, Nn, De, c.p(ix.n2e.w), D, D, dhhat, D, 0);

@@ -244,6 +244,19 @@ __global__ void k_seg_part(int NC, int F, const int* __restrict__ ec_off, const 
     }
     part[i_] = (float)t;
 }
+// the same with b = ehat computed on the fly: ehat[(a, c), f] = p[a, f] + p[c, f] + bias[f] (node2edge_lin of both atoms of the edge)
+// — the roundings of k_edge_bcast followed by k_seg_part, without the [R, F] array in between
+__global__ void k_seg_part_ehat(Topo t, int F, const float* __restrict__ a, const float* __restrict__ p, const float* __restrict__ bias,
+                                float* __restrict__ part) {
+    JT_IDX((long)t.NC * F);
+    const int c = (int)(i_ / F), f = (int)(i_ % F);
+    const float bv = bias[f];
+    double s = 0.0;
+#pragma unroll 8
+    for (long r = t.ec_off[c]; r < t.ec_off[c + 1]; ++r)
+        s += (double)(a[r * F + f] * (p[(long)t.edge_a[r] * F + f] + p[(long)t.edge_c[r] * F + f] + bv));
+    part[i_] = (float)s;
+}
 __global__ void k_seg_fin(int S, int F, const int* __restrict__ mol_off, const float* __restrict__ part, float* __restrict__ out, int ldo, int ocol, int acc) {
     JT_IDX((long)S * F);
     const int s = (int)(i_ / F), f = (int)(i_ % F);
@@ -398,12 +411,23 @@ __global__ void k_edge_bcast(Topo t, int F, const float* __restrict__ base, cons
     const float g = mods ? mods[(long)t.edge_mol[r] * ldm + g_off + f] : 1.f;
     y[i_] = (base ? base[i_] : 0.f) + g * v;
 }
-// node sums of an edge array: rowsum[a, f] = sum_c x[(a, c), f]; colsum[c, f] = sum_a x[(a, c), f]   (either output may be NULL; acc)
+// node sums of an edge array: rowsum[a, f] = sum_c x[(a, c), f]; colsum[c, f] = sum_a x[(a, c), f]   (either output may be NULL; acc);
+// rowsum == colsum: that array gets row sum + column sum (what the two passes with acc = 0, 1 left there: one launch instead of two)
 __global__ void k_edge_to_node(Topo t, int F, const float* __restrict__ x, float* rowsum, float* colsum, int acc) {
     JT_IDX((long)t.Nn * F);
     const int node = (int)(i_ / F), f = (int)(i_ % F);
     const int b = t.node_mol[node], n = t.nn[b], i = node - t.node_off[b];
     const long e0 = t.edge_off[b];
+    if (rowsum && rowsum == colsum) {
+        float sr = 0.f, sc = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < n; ++c) sr += x[(e0 + (long)i * n + c) * F + f];
+#pragma unroll 8
+        for (int a = 0; a < n; ++a) sc += x[(e0 + (long)a * n + i) * F + f];
+        const float v = sr + sc;
+        rowsum[i_] = acc ? rowsum[i_] + v : v;
+        return;
+    }
     if (rowsum) {
         float s = 0.f;
 #pragma unroll 8
