@@ -674,7 +674,7 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         const int ldw = 2 * D + 2 * De;
         const float* Win = c.p(ix.eq_in.w); float* dWin = c.g(ix.eq_in.w);
         float *dhr = b.tN_D2[0], *dhc = b.tN_D2[1];           // (not tN_D[0 .. 1]: d hhat / d tn below, while these products are queued)
-        JT_LAUNCH(k_edge_to_node, (long)Nn * D, s, tp, D, (const float*)dpre, dhr, dhc, 0);
+        JT_LAUNCH(k_edge_to_node, (long)Nn * D, s, tp, D, (const float*)dpre, dhr, dhc, 0, (const float*)nullptr, 0, 0);
         c.lin_dw(dhr, D, Nn, D, b.h[l + 1], D, D, dWin, ldw);
         c.lin_dw(dhc, D, Nn, D, b.h[l + 1], D, D, dWin + D, ldw);
         c.lin_dw(dpre, D, R, D, b.e[l + 1], De, De, dWin + 2 * D, ldw, c.g(ix.eq_in.b));
@@ -711,12 +711,13 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         }
         // d eg1 = sum over the molecule of d x1e * ehat, ehat = node2edge_lin(h_a) + node2edge_lin(h_c) + bias formed on the fly
         c.seg_edge_ehat(De, de_prev, k.n2e, c.p(ix.n2e.b), demod, Mt, 2 * De);
-        float* dehat = dten;
-        JT_LAUNCH(k_gate_bwd, (long)R * De, s, (long)R, De, (const float*)de_prev, tp.edge_mol, (const float*)k.emod, 6 * De, 2 * De, dehat, 0);
-        c.colsum(dehat, De, nullptr, 0, R, De, c.g(ix.n2e.b));
+        // d ehat = g1 d x1e reaches node2edge_lin through both atoms of an edge: d n2e[i] = g1 (sum_c d x1e[(i, c)] + sum_a d x1e[(a, i)]) — the
+        // gate is per molecule, so it multiplies the node sums (no [R, De] array of gated rows).  The bias saw every edge once, the node
+        // sums see it twice: d bias = sum_edges d ehat = 0.5 sum_nodes d n2e, which rides on the weight-gradient product as its bias
+        // gradient and is halved (exactly) for all blocks at the end of the backward.
         float* dn2e = b.tN_De;
-        JT_LAUNCH(k_edge_to_node, (long)Nn * De, s, tp, De, (const float*)dehat, dn2e, dn2e, 0);       // row sums + column sums (both atoms of an edge)
-        c.lin_dw(dn2e, De, Nn, De, k.hhat, D, D, c.g(ix.n2e.w), D);
+        JT_LAUNCH(k_edge_to_node, (long)Nn * De, s, tp, De, (const float*)de_prev, dn2e, dn2e, 0, (const float*)k.emod, 6 * De, 2 * De);
+        c.lin_dw(dn2e, De, Nn, De, k.hhat, D, D, c.g(ix.n2e.w), D, c.g(ix.n2e.b));
         float* dhhat = b.tN_D[0];
         c.lin_dx(dn2e, De, Nn, De, c.p(ix.n2e.w), D, D, dhhat, D, 0);
         // ---- node FFN, LayerNorm2 + modulate, gated residual
@@ -838,6 +839,12 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
     c.flush_dw();                                            // the time / context MLPs' products: their operands are final where they are queued
     c.flush_fin();
     b.defer_fin = false;
+    for (int l0 = 0; l0 < L; l0 += 16) {                     // node2edge bias gradients: the node sums counted every edge twice (see the block loop)
+        ScaleTable S;
+        S.n_arrays = L - l0 < 16 ? L - l0 : 16;
+        for (int i = 0; i < S.n_arrays; ++i) S.x[i] = c.g(t.blk[l0 + i].n2e.b);
+        JT_LAUNCH(k_scale_arrays, (long)S.n_arrays * De, s, S, De, 0.5f);
+    }
 }
 
 Topo make_topo(const jodo_train& t, const void* desc_dev) {

@@ -372,6 +372,13 @@ __global__ void k_fin_group(FinTable T) {
     }
 }
 
+// x_i *= scale for up to 16 small arrays of n floats (one launch at the end of the backward: see the node2edge bias gradients)
+struct ScaleTable { int n_arrays; float* x[16]; };
+__global__ void k_scale_arrays(ScaleTable T, int n, float scale) {
+    JT_IDX((long)T.n_arrays * n);
+    T.x[i_ / n][i_ % n] *= scale;
+}
+
 // ================================================================ gates, broadcasts between node and edge arrays ================
 // y = a + g[mol] * b
 __global__ void k_gate_add(long rows, int F, const float* __restrict__ a, const float* __restrict__ b, const int* __restrict__ row_mol,
@@ -413,7 +420,10 @@ __global__ void k_edge_bcast(Topo t, int F, const float* __restrict__ base, cons
 }
 // node sums of an edge array: rowsum[a, f] = sum_c x[(a, c), f]; colsum[c, f] = sum_a x[(a, c), f]   (either output may be NULL; acc);
 // rowsum == colsum: that array gets row sum + column sum (what the two passes with acc = 0, 1 left there: one launch instead of two)
-__global__ void k_edge_to_node(Topo t, int F, const float* __restrict__ x, float* rowsum, float* colsum, int acc) {
+// mods (rowsum == colsum only): the sum is multiplied by the molecule's gate mods[mol, g_off + f] — the gate's backward folded in (the gate
+// is the same for every edge of the molecule, so it leaves the sum)
+__global__ void k_edge_to_node(Topo t, int F, const float* __restrict__ x, float* rowsum, float* colsum, int acc,
+                               const float* __restrict__ mods, int ldm, int g_off) {
     JT_IDX((long)t.Nn * F);
     const int node = (int)(i_ / F), f = (int)(i_ % F);
     const int b = t.node_mol[node], n = t.nn[b], i = node - t.node_off[b];
@@ -424,7 +434,8 @@ __global__ void k_edge_to_node(Topo t, int F, const float* __restrict__ x, float
         for (int c = 0; c < n; ++c) sr += x[(e0 + (long)i * n + c) * F + f];
 #pragma unroll 8
         for (int a = 0; a < n; ++a) sc += x[(e0 + (long)a * n + i) * F + f];
-        const float v = sr + sc;
+        float v = sr + sc;
+        if (mods) v *= mods[(long)b * ldm + g_off + f];
         rowsum[i_] = acc ? rowsum[i_] + v : v;
         return;
     }
