@@ -356,7 +356,9 @@ size_t jodo_train_workspace_bytes(const jodo_train* t);
  *            gemm_dw_group: same plans and arithmetic as one launch each, bit-identical gradients); 0: one launch per product;
  * option 4 = 1 (default where built): the attention of a block as one forward and two backward launches, one to four waves per atom (forward
  *            bit-identical to the op-by-op kernels); 0: scores | softmax | messages and their six backward kernels; 2: the one-wave-per-atom
- *            form of batches above 16 k atoms whatever the batch (tests) */
+ *            form of batches above 16 k atoms whatever the batch (tests);
+ * option 5 = the Gaussian layer's backward as one wave-per-chunk pass: 1 (default) for batches of >= 4 096 chunks of 32 edge rows (it loses
+ *            below), 0 never, 2 always (tests) */
 int jodo_train_set_option(jodo_train* t, int option, int value);
 /* tests: byte offset and element count of a kept activation inside the workspace; what 0 = hhat [Nn, D] (TransMixLayer's output,
  * layers.py:153), 1 = alpha [R, H] (softmax weights, layers.py:178) of block `layer` */

@@ -90,6 +90,7 @@ struct jodo_train {
     size_t ws_bytes;
     int fused;                        // 1: the three per-edge chains of a block run as fused strip kernels (train_fused.hip)
     int fused_bwd;                    // 1: their input-gradient sides too (the weight-gradient products stay GEMMs)
+    int gbf_chunk;                    // option 5: the Gaussian layer's backward as one pass over 32-row chunks: 0 never, 1 (default) batches of >= 4 096 chunks, 2 always (tests)
     int fused_attn;                   // option 4: 1 = attention forward / backward as wave-per-atom kernels (train_fused.hip; bit-identical to the op-by-op ones)
     int group_dw;                     // option 3: 1 = the backward's weight-gradient products are queued and launched in groups (gemm_dw_group)
     int save_activations;             // option 2: 0 = the following forwards are not followed by a backward (no-grad self-conditioning call)
@@ -580,12 +581,19 @@ void mod_bwd_all(const Ctx& c) {
 void gbf_bwd(const Ctx& c, long rows, const float* d2, const float* gm, int means, int stds, float* dgm, int ldd, const float* dG, int ldg, int gcol, float* dd2) {
     const jodo_train& t = c.t; Bufs& b = c.b; hipStream_t s = c.s;
     const int De = t.De, K = De - 1;
-    JT_LAUNCH(k_gbf_bwd_row, rows, s, rows, De, d2, c.tp.edge_mol, gm, c.p(means), c.p(stds), dG, ldg, gcol, b.tRow[2], dd2, 0);
-    c.seg2_edge(1, b.tRow[2], d2, dgm, ldd, 1, 0);          // d shift = sum dx' (column 1), d scale = sum dx' d2 (column 0) per molecule, one pass
     const int chunk = 32;
     const long nch = (rows + chunk - 1) / chunk;
     float *pm = b.tE_QK, *ps = b.tE_QK + nch * K;            // (the attention scratch is free here)
-    JT_LAUNCH(k_gbf_bwd_par, nch * K, s, rows, De, chunk, d2, c.tp.edge_mol, gm, c.p(means), c.p(stds), dG, ldg, gcol, pm, ps);
+    if (t.fused_bwd && De <= 129 && (t.gbf_chunk == 2 || (t.gbf_chunk == 1 && nch >= 4096))) {
+        // d x' per row and the chunk partials of d means / d stds in one pass: a wave per 32-row chunk, a lane per Gaussian (train_fused.hip).
+        // Batches that fill the card only: batch 2 048 backward 90.5 -> 88.0 ms; at the reference's batch (1 344 chunks) a wave walking its
+        // 32 rows is slower than 43 k independent threads (backward 8.98 -> 9.16 ms)
+        fused_gbf_bwd(s, rows, De, d2, c.tp.edge_mol, gm, c.p(means), c.p(stds), dG, ldg, gcol, b.tRow[2], dd2, 0, pm, ps);
+    } else {
+        JT_LAUNCH(k_gbf_bwd_row, rows, s, rows, De, d2, c.tp.edge_mol, gm, c.p(means), c.p(stds), dG, ldg, gcol, b.tRow[2], dd2, 0);
+        JT_LAUNCH(k_gbf_bwd_par, nch * K, s, rows, De, chunk, d2, c.tp.edge_mol, gm, c.p(means), c.p(stds), dG, ldg, gcol, pm, ps);
+    }
+    c.seg2_edge(1, b.tRow[2], d2, dgm, ldd, 1, 0);          // d shift = sum dx' (column 1), d scale = sum dx' d2 (column 0) per molecule, one pass
     c.colsum(pm, K, nullptr, 0, nch, K, c.g(means));
     c.colsum(ps, K, nullptr, 0, nch, K, c.g(stds));
 }
@@ -971,6 +979,7 @@ int jodo_train_create(const jodo_cfg* cfg, int B, int N, const int32_t* n_nodes,
         t->fused_bwd = t->fused;
         t->save_activations = 1;
         t->group_dw = 1;
+        t->gbf_chunk = 1;
         t->fused_attn = t->fused && fused_attention_available(t->D, t->H, t->N) ? 1 : 0;
         t->Mtot = 2 + t->L * (6 * t->D + 6 * t->De + 2 * t->D + 2);
     }
@@ -988,6 +997,8 @@ size_t jodo_train_workspace_bytes(const jodo_train* t) { return t ? t->ws_bytes 
 // option 1: the same for the input-gradient side of the backward
 // option 2: 1 (default) every forward keeps what a backward needs; 0: the following forwards will not be differentiated (the no-grad
 //           self-conditioning forward of a training step): the fused chains skip the stores only a backward reads
+// option 5: the Gaussian layer's backward (d x' per row + chunk partials of d means / d stds) as one wave-per-chunk pass (train_fused.hip
+//           k_gbf_bwd_chunk): 1 (default) for batches of at least 4 096 chunks of 32 edge rows, 0 never, 2 always (tests)
 // option 4: 1 (default where built) attention forward in one launch and backward in two (train_fused.hip k_attn_fwd / k_attn_bwd_tgt / _src:
 //           one to four waves per atom, the forward's sums in the op-by-op kernels' order — bit-identical); 0: scores | softmax | messages and six
 //           backward kernels; 2: the one-wave-per-atom form that batches above 16 k atoms take (tests)
@@ -995,9 +1006,10 @@ size_t jodo_train_workspace_bytes(const jodo_train* t) { return t ? t->ws_bytes 
 //           (+ one split-K sum) each — same plans, same arithmetic, bit-identical gradients
 int jodo_train_set_option(jodo_train* t, int option, int value) {
     if (!t) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: null handle");
-    if (option < 0 || option > 4 || (value != 0 && value != 1 && !(option == 4 && value == 2))) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: option %d value %d", option, value);
+    if (option < 0 || option > 5 || (value != 0 && value != 1 && !(option >= 4 && value == 2))) return jodo_set_error(JODO_ERR_ARG, "jodo_train_set_option: option %d value %d", option, value);
     if (option == 2) { t->save_activations = value; return JODO_OK; }
     if (option == 3) { t->group_dw = value; return JODO_OK; }
+    if (option == 5) { t->gbf_chunk = value; return JODO_OK; }
     if (option == 4) {
         if (value && !(fused_available(FusedDims{t->D, t->De, t->r, t->QK, t->ce, t->L}) && fused_attention_available(t->D, t->H, t->N)))
             return jodo_set_error(JODO_ERR_UNSUPPORTED, "jodo_train_set_option: the fused attention kernels are not built for this shape");

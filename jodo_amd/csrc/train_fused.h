@@ -85,4 +85,9 @@ void fused_attn_fwd(hipStream_t s, const AttnTopo& t, int D, int H, int XH, int 
 void fused_attn_bwd(hipStream_t s, const AttnTopo& t, int D, int H, int XH, int SC, float inv_sqrt_c, const float* dhhat, const float* q, const float* k,
                     const float* v, const float* t0, const float* t1, const float* alpha, float* dS, float* dt1, float* dt0, float* dq, float* dk, float* dv);
 
+// ---- Gaussian layer backward in one pass over 32-row chunks (a wave per chunk, a lane per Gaussian; De <= 129): d x' per row (dxp, and
+// dd2 (+)= d x' (1 + scale)) and the chunk partials of d means / d stds, [ceil(rows / 32), De - 1] each, for the column sums
+void fused_gbf_bwd(hipStream_t s, long rows, int De, const float* d2, const int* row_mol, const float* gm, const float* means, const float* stds, const float* dG,
+                   int ldg, int gcol, float* dxp, float* dd2, int acc, float* part_m, float* part_s);
+
 }  // namespace jt

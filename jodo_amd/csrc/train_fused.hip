@@ -1085,4 +1085,72 @@ void fused_attn_bwd(hipStream_t s, const AttnTopo& t, int D, int H, int XH, int 
 #undef JT_AB
 }
 
+// ---- Gaussian layer, backward (layers.py CondGaussianLayer; train_ops.h k_gbf_bwd_row + k_gbf_bwd_par) in one pass -------------------
+// The op-by-op pair evaluates every Gaussian twice (once per row for d x', once per (chunk, k) for the parameter gradients) with one
+// thread walking a row's 63 terms, resp. a chunk's 32 rows.  Here a wave owns a 32-row chunk, lane = Gaussian k (k + 64 for De = 96): the
+// row's dG is one coalesced load, d x' is a butterfly sum over the lanes (in double, like the sequential sum it replaces), the
+// parameter partials of the chunk accumulate per lane in double and land where k_gbf_bwd_par put them.
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+template <int KV>
+__global__ __launch_bounds__(256) void k_gbf_bwd_chunk(long rows, int De, const float* __restrict__ d2, const int* __restrict__ row_mol, const float* __restrict__ gm,
+                                                       const float* __restrict__ means, const float* __restrict__ stds, const float* __restrict__ dG, int ldg,
+                                                       int gcol, float* __restrict__ dxp, float* dd2, int acc, float* __restrict__ part_m,
+                                                       float* __restrict__ part_s) {
+    const int K = De - 1, lane = threadIdx.x & 63;
+    const long c = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nchunks = (rows + 31) / 32;
+    if (c >= nchunks) return;
+    const long r0 = c * 32, r1 = r0 + 32 < rows ? r0 + 32 : rows;
+    float mk[KV], sd[KV], sg[KV];
+    double dm[KV], ds[KV];
+#pragma unroll
+    for (int j = 0; j < KV; ++j) {
+        const int k = lane + 64 * j;
+        const float w = k < K ? stds[k] : 1.f;
+        mk[j] = k < K ? means[k] : 0.f;
+        sd[j] = fabsf(w) + 1e-5f; sg[j] = w < 0.f ? -1.f : (w > 0.f ? 1.f : 0.f);
+        dm[j] = 0.0; ds[j] = 0.0;
+    }
+    for (long r = r0; r < r1; ++r) {
+        const float* g = gm + (long)row_mol[r] * 2;
+        const float g0 = g[0] + 1.f, x = d2[r] * g0 + g[1];
+        const float* d = dG + r * ldg + gcol;
+        double part = 0.0;
+#pragma unroll
+        for (int j = 0; j < KV; ++j) {
+            const int k = lane + 64 * j;
+            if (k < K) {
+                const float z = (x - mk[j]) / sd[j];
+                const float gk = expf(-0.5f * (z * z)) / (2.5066272f * sd[j]);
+                const float dv = d[1 + k];
+                part += (double)(dv * gk * (-z / sd[j]));
+                const float dg = dv * gk;
+                dm[j] += (double)(dg * (z / sd[j]));
+                ds[j] += (double)(dg * ((z * z - 1.f) / sd[j]) * sg[j]);
+            }
+        }
+        const double sum = wave_sum_d(part) + (double)d[0];
+        if (lane == 0) {
+            const float sv = (float)sum;
+            dxp[r] = sv;
+            if (dd2) dd2[r] = (acc ? dd2[r] : 0.f) + sv * g0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KV; ++j) {
+        const int k = lane + 64 * j;
+        if (k < K) { part_m[c * K + k] = (float)dm[j]; part_s[c * K + k] = (float)ds[j]; }
+    }
+}
+void fused_gbf_bwd(hipStream_t s, long rows, int De, const float* d2, const int* row_mol, const float* gm, const float* means, const float* stds, const float* dG,
+                   int ldg, int gcol, float* dxp, float* dd2, int acc, float* part_m, float* part_s) {
+    const long nchunks = (rows + 31) / 32;
+    const dim3 grid((unsigned)((nchunks + 3) / 4)), block(256);
+    if (De - 1 <= 64) hipLaunchKernelGGL(k_gbf_bwd_chunk<1>, grid, block, 0, s, rows, De, d2, row_mol, gm, means, stds, dG, ldg, gcol, dxp, dd2, acc, part_m, part_s);
+    else hipLaunchKernelGGL(k_gbf_bwd_chunk<2>, grid, block, 0, s, rows, De, d2, row_mol, gm, means, stds, dG, ldg, gcol, dxp, dd2, acc, part_m, part_s);
+}
+
 }  // namespace jt

@@ -104,4 +104,6 @@ void fused_attn_fwd(hipStream_t, const AttnTopo&, int, int, int, int, float, con
                     const float*, float*, float*) {}
 void fused_attn_bwd(hipStream_t, const AttnTopo&, int, int, int, int, float, const float*, const float*, const float*, const float*, const float*, const float*,
                     const float*, float*, float*, float*, float*, float*, float*) {}
+void fused_gbf_bwd(hipStream_t, long, int, const float*, const int*, const float*, const float*, const float*, const float*, int, int, float*, float*, int,
+                   float*, float*) {}
 }

@@ -385,6 +385,14 @@ def test_fused_forward_chains_equal_the_op_by_op_forward(cfg_name, n_nodes, over
     ((ox * d(d_x)).sum() + (oe * d(d_e)).sum()).backward()
     assert torch.equal(ox.detach().cpu(), res[(1, 1)][0]) and torch.equal(oe.detach().cpu(), res[(1, 1)][1])
     grads_close("one-wave and four-wave attention")
+    # the Gaussian layer's backward as one pass over 32-row chunks (train_fused.hip k_gbf_bwd_chunk; by default only batches of >= 4 096
+    # chunks take it — option 5 = 2 forces it): the same gradients (d x' is a butterfly sum over the Gaussians, in double like the sequential one)
+    model.train_options = {0: 1, 1: 1, 5: 2}
+    model.zero_grad()
+    torch.manual_seed(77)
+    ox, oe = model(d(nl), d(xh), d(nm), d(em), d(ctx), edge_x=d(ex), cond_x=d(cx), cond_edge_x=d(cex), noise_level=d(nl))
+    ((ox * d(d_x)).sum() + (oe * d(d_e)).sum()).backward()
+    grads_close("chunk-pass and op-by-op Gaussian layer backward")     # (in fact bit-equal here: both forms sum in double and round once)
     # the no-grad call of a training step (self-conditioning forward, losses.py:335-339: dropout active, nothing differentiated) skips
     # the stores only a backward reads (jodo_train_set_option 2): same outputs bit for bit, and a grad-enabled call afterwards still works
     model.train_options = {0: 1, 1: 1}
