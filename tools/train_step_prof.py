@@ -62,7 +62,7 @@ model = deterministic_init_(get_model_class(cfg.model.name)(cfg), seed=42).to(de
 ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
 state = dict(model=model, optimizer=L.get_optimizer(cfg, model.parameters()), ema=ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_decay), step=1)
 step_fn = L.get_step_fn(ns, True, L.optimization_manager(cfg), get_data_scaler(cfg), cfg)
-batches = [{k: v.to(dev) for k, v in synthetic_batch(cfg, dist_.sample(B).tolist(), 43 + i).items()} for i in range(3 + steps)]
+batches = [synthetic_batch(cfg, dist_.sample(B).tolist(), 43 + i) for i in range(3 + steps)]      # CPU dicts, as the reference's loader hands them over
 for i in range(3):
     step_fn(state, batches[i])
 torch.cuda.synchronize()
