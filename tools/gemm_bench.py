@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jodo_amd import capi
 
-R, Nn = 43000, 2300
+R, Nn = int(os.environ.get('GEMM_R', 43000)), int(os.environ.get('GEMM_NN', 2300))
 SHAPES = [('fwd  c0      ', 0, 1, R, 256, 256), ('fwd  input_e ', 0, 1, R, 256, 64), ('fwd  lin_e1  ', 0, 1, R, 256, 64), ('fwd  ff3     ', 0, 1, R, 128, 64),
           ('fwd  ff4     ', 0, 1, R, 64, 128), ('fwd  ee      ', 0, 1, R, 64, 64), ('fwd  node ff1', 0, 1, Nn, 512, 256), ('fwd  mods    ', 0, 1, 128, 1536, 1024),
           ('dX   c0      ', 0, 0, R, 256, 256), ('dX   lin_e1  ', 0, 0, R, 64, 256), ('dX   ff4     ', 0, 0, R, 128, 64),
