@@ -160,21 +160,46 @@ class FlatAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         if flat_parameters(self._params, self._total) is None:
             raise RuntimeError("FlatAdam: the parameters were moved off the flat buffer (model.to(...) after the optimiser was built?)")
-        grad = flat_gradient(self._params, self._total, full_check=not self._checked)
-        self._checked = True
-        if grad is None:                                             # ordinary separate gradients: gathered into one buffer (one launch)
-            if any(p.grad is None for p in self._params):
-                raise RuntimeError("FlatAdam: every parameter needs a gradient (the HIP training path writes all of them)")
-            grad = torch.zeros_like(self._flat)
-            torch._foreach_copy_(carve(grad, self._shapes, self._offs), [p.grad for p in self._params])
         self._step += 1
         self._step_t.fill_(self._step)
         b1, b2 = g['betas']
-        capi.check(self._L.jodo_adam_step(self._total, capi.ptr(self._flat), capi.ptr(grad), capi.ptr(self._m), capi.ptr(self._v), capi.ptr(self._vmax),
-                                          float(g['lr']), float(b1), float(b2), float(g['eps']), float(g['weight_decay']), self._step,
-                                          1 if g['decoupled'] else 0, 1 if g['amsgrad'] else 0, capi.current_stream_ptr()), 'jodo_adam_step')
+
+        def launch(lo, hi, grad):                                     # floats lo .. hi of the flat buffers, grad = the gradient of that range
+            sub = lambda t_: None if t_ is None else t_[lo:hi]
+            capi.check(self._L.jodo_adam_step(hi - lo, capi.ptr(self._flat[lo:hi]), capi.ptr(grad), capi.ptr(self._m[lo:hi]), capi.ptr(self._v[lo:hi]),
+                                              capi.ptr(sub(self._vmax)), float(g['lr']), float(b1), float(b2), float(g['eps']), float(g['weight_decay']),
+                                              self._step, 1 if g['decoupled'] else 0, 1 if g['amsgrad'] else 0, capi.current_stream_ptr()), 'jodo_adam_step')
+
+        have = [p.grad is not None for p in self._params]
+        if all(have):
+            grad = flat_gradient(self._params, self._total, full_check=not self._checked)
+            self._checked = True
+            if grad is None:                                         # ordinary separate gradients: gathered into one buffer (one launch)
+                grad = torch.zeros_like(self._flat)
+                torch._foreach_copy_(carve(grad, self._shapes, self._offs), [p.grad for p in self._params])
+            launch(0, self._total, grad)
+            touched = self._params
+        else:
+            # parameters without a gradient are left alone, as torch's optimisers leave them (frozen layers): one launch per run of
+            # consecutive parameters that have one (slices start on 16-byte boundaries, so every run does).  All runs share this
+            # optimiser's step count (torch counts steps per parameter).
+            touched, i, n = [], 0, len(self._params)
+            while i < n:
+                if not have[i]:
+                    i += 1
+                    continue
+                j = i
+                while j < n and have[j]:
+                    j += 1
+                lo, hi = self._offs[i], self._offs[j - 1] + self._params[j - 1].numel()
+                grad = torch.zeros(hi - lo, dtype=torch.float32, device=self._flat.device)
+                torch._foreach_copy_(carve(grad, self._shapes[i:j], [o - lo for o in self._offs[i:j]]), [p.grad for p in self._params[i:j]])
+                launch(lo, hi, grad)
+                touched += self._params[i:j]
+                i = j
         # the kernel wrote through raw pointers: tell autograd / the packed-weight cache of the HIP module (models/dgt.py _weights)
-        torch.autograd.graph.increment_version(self._params)
+        if touched:
+            torch.autograd.graph.increment_version(touched)
         return loss
 
     def load_state_dict(self, state_dict):

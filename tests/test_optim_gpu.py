@@ -169,3 +169,21 @@ def test_kabsch_rotations_match_the_svd_form():
     z = torch.cat([P, torch.zeros(B, N, 2)], -1).to(DEV)
     x = torch.cat([Q, torch.zeros(B, N, 2)], -1).to(DEV)
     torch.testing.assert_close(L.get_align_position(z, x).cpu().double(), L.get_align_position(z.cpu().double(), x.cpu().double()), rtol=0, atol=2e-5)
+
+
+def test_flat_adam_leaves_parameters_without_a_gradient_alone():
+    """Frozen layers: torch's optimisers skip parameters whose .grad is None; FlatAdam updates the runs of consecutive parameters that
+    have one and leaves the others bit for bit where they were (moments too)."""
+    pa, pb = _params(4), _params(4)
+    ref = torch.optim.AdamW(pa, lr=1e-3, amsgrad=True, weight_decay=1e-12)
+    opt = JO.FlatAdam(pb, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-12, amsgrad=True, decoupled=True)
+    frozen = (1, 4)                                                                       # the 3-float and the [129, 17] tensor
+    before = [pb[i].detach().clone() for i in frozen]
+    for step in range(1, 4):
+        for i, (a, b, g) in enumerate(zip(pa, pb, _grads(step, seed=6))):
+            a.grad, b.grad = (None, None) if i in frozen else (g.clone(), g.clone())
+        ref.step(); opt.step()
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        torch.testing.assert_close(b.data, a.data, rtol=2e-6, atol=1e-9)
+    for i, w in zip(frozen, before):
+        assert torch.equal(pb[i].data, w) and float(opt.state[pb[i]]['exp_avg'].abs().max()) == 0.0
