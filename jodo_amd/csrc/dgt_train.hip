@@ -212,11 +212,13 @@ struct Ctx {
         if (b.defer_fin) {
             // first level now (it reads the caller's array), the rest queued: one more level down to at most 64 rows, then the final sum
             long n = (rows + chunk - 1) / chunk;
-            float* p1 = fin_alloc((size_t)n * F);
+            const long c2 = n <= 2048 ? 32 : (n + 63) / 64, n2 = n > 64 ? (n + c2 - 1) / c2 : 0;
+            // both levels' partial sums in ONE allocation: a second fin_alloc could flush the queue and hand out the first region again
+            const size_t n1f = ((size_t)n * F + 63) / 64 * 64;
+            float* p1 = fin_alloc(n1f + (size_t)n2 * F);
             JT_LAUNCH(k_colsum_part, n * F, s, rows, F, chunk, a, lda, bb, ldb, p1);
             if (n > 64) {
-                const long c2 = n <= 2048 ? 32 : (n + 63) / 64, n2 = (n + c2 - 1) / c2;
-                float* p2 = fin_alloc((size_t)n2 * F);
+                float* p2 = p1 + n1f;
                 push_fin(FinJob{p1, p2, nullptr, FIN_COLPART, F, (int)n, 0, 0, (int)c2, 0, 0});
                 p1 = p2; n = n2;
             }
