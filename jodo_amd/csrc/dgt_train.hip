@@ -45,6 +45,7 @@ struct Arena {
 
 struct BlkBuf {
     float *nmod, *emod, *qmod, *gm, *d2, *G, *xh_e1, *rs_e1, *et, *xh_h, *rs_h, *ht, *q, *k, *v, *t0, *t1, *alpha, *hhat, *n2e;
+    float* qkv;                       // q | k | v side by side, [Nn, 2 QK + D]: what the merged projection writes and the wave-per-atom attention reads
     float *xh_hn, *rs_hn, *hn, *f1, *a1, *f2, *xh_en, *rs_en, *en, *f3, *a3, *f4, *xh_pre, *rs_pre, *u, *c0pre, *c0a, *inv;
 };
 struct Bufs {
@@ -60,7 +61,7 @@ struct Bufs {
     float* fpack;                     // packed MFMA operands of the fused chains (forward + transposed images), one slice per block (train_fused.h)
     float* tE_De2[3];                 // scratch of the fused backward chains: df4 | den | de1
     float *Wall, *ball, *mods_all, *dmods_all, *dWall, *dball;      // batched modulation projections (train_ops.h ModTable)
-    float *Wqkv, *bqkv, *qkv, *dqkv, *dWqkv, *dbqkv;                // lin_query / lin_key / lin_value of a block as one product: [L][2 QK + D, D] gathered weights
+    float *Wqkv, *bqkv, *dqkv, *dWqkv, *dbqkv;                // lin_query / lin_key / lin_value of a block as one product: [L][2 QK + D, D] gathered weights
     float *dwg;                                                     // split-K partial tiles of a grouped weight-gradient launch (gemm_dw_group)
     float *tN_D2[2];                                                // d h_row | d h_col of input_lin while their weight-gradient products are queued
     size_t fpack_block;
@@ -115,6 +116,7 @@ void layout(const jodo_train& t, Arena& a, Bufs& b) {
         k.nmod = a.f(B * 6 * D); k.emod = a.f(B * 6 * De); k.qmod = a.f(B * 2 * D); k.gm = a.f(B * 2);
         k.d2 = a.f(R); k.G = a.f(R * De); k.xh_e1 = a.f(R * De); k.rs_e1 = a.f(R); k.et = a.f(R * De);
         k.xh_h = a.f(Nn * D); k.rs_h = a.f(Nn); k.ht = a.f(Nn * D); k.q = a.f(Nn * QK); k.k = a.f(Nn * QK); k.v = a.f(Nn * D);
+        k.qkv = a.f(Nn * (2 * QK + D));
         k.t0 = a.f(R * QK); k.t1 = a.f(R * D); k.alpha = a.f(R * H); k.hhat = a.f(Nn * D); k.n2e = a.f(Nn * De);
         k.xh_hn = a.f(Nn * D); k.rs_hn = a.f(Nn); k.hn = a.f(Nn * D); k.f1 = a.f(Nn * r * D); k.a1 = a.f(Nn * r * D); k.f2 = a.f(Nn * D);
         k.xh_en = a.f(R * De); k.rs_en = a.f(R); k.en = a.f(R * De); k.f3 = a.f(R * r * De); k.a3 = a.f(R * r * De); k.f4 = a.f(R * De);
@@ -163,7 +165,7 @@ void layout(const jodo_train& t, Arena& a, Bufs& b) {
     const size_t Mt = (size_t)t.Mtot;
     b.Wall = a.f(Mt * T); b.ball = a.f(Mt); b.mods_all = a.f(B * Mt); b.dmods_all = a.f(B * Mt); b.dWall = a.f(Mt * T); b.dball = a.f(Mt);
     const size_t F3 = 2 * QK + D;
-    b.Wqkv = a.f(L * F3 * D); b.bqkv = a.f(L * F3); b.qkv = a.f(Nn * F3); b.dqkv = a.f(Nn * F3); b.dWqkv = a.f(L * F3 * D); b.dbqkv = a.f(L * F3);
+    b.Wqkv = a.f(L * F3 * D); b.bqkv = a.f(L * F3); b.dqkv = a.f(Nn * F3); b.dWqkv = a.f(L * F3 * D); b.dbqkv = a.f(L * F3);
 }
 
 struct Ctx {
@@ -465,21 +467,24 @@ void forward(const Ctx& c, const float* xh, const float* edge_x, const float* co
         }
         // attention (layers.py:131-186)
         {   // q | k | v in one product on the gathered weights, then handed out to their arrays
-            c.lin(k.ht, D, Nn, D, b.Wqkv + (size_t)l * F3 * D, D, F3, b.bqkv + (size_t)l * F3, b.qkv, F3, 0);
-            ModTable M;
-            M.n = 3;
-            float* outs[3] = {k.q, k.k, k.v};
-            for (int j = 0; j < 3; ++j) { M.w[j] = nullptr; M.bias[j] = nullptr; M.out[j] = outs[j]; M.F[j] = j < 2 ? QK : D; M.col[j] = j * QK; }
-            hipLaunchKernelGGL(k_mod_scatter, dim3((unsigned)(((long)Nn * D + 255) / 256), 3u), dim3(256), 0, s, M, Nn, F3, (const float*)b.qkv);
+            c.lin(k.ht, D, Nn, D, b.Wqkv + (size_t)l * F3 * D, D, F3, b.bqkv + (size_t)l * F3, k.qkv, F3, 0);
+            if (!t.fused_attn) {                               // (the op-by-op attention kernels read compact q, k, v)
+                ModTable M;
+                M.n = 3;
+                float* outs[3] = {k.q, k.k, k.v};
+                for (int j = 0; j < 3; ++j) { M.w[j] = nullptr; M.bias[j] = nullptr; M.out[j] = outs[j]; M.F[j] = j < 2 ? QK : D; M.col[j] = j * QK; }
+                hipLaunchKernelGGL(k_mod_scatter, dim3((unsigned)(((long)Nn * D + 255) / 256), 3u), dim3(256), 0, s, M, Nn, F3, (const float*)k.qkv);
+            }
         }
         if (!t.fused) {
             c.lin_tanh(k.et, De, R, De, c.p(ix.le0), De, QK, nullptr, k.t0);
             c.lin_tanh(k.et, De, R, De, c.p(ix.le1), De, D, nullptr, k.t1);
         }
-        const AttnTopo at{Nn, t.N, tp.node_mol, tp.nn, tp.node_off, tp.edge_off, t.fused_attn == 2 ? 1 : 0};
+        const AttnTopo at{Nn, t.N, tp.node_mol, tp.nn, tp.node_off, tp.edge_off, t.fused_attn == 2 ? 1 : 0, F3, F3, F3, F3};
         if (t.fused_attn) {
-            // scores | column softmax | messages in one launch, a wave per target atom (train_fused.hip; bit-identical to the three below)
-            fused_attn_fwd(s, at, D, H, t.XH, t.SC, 1.f / sqrtf((float)t.C), k.q, k.k, k.t0, b.adj2d, b.adjsp, k.v, k.t1, k.alpha, k.hhat);
+            // scores | column softmax | messages in one launch, a wave per target atom (train_fused.hip; bit-identical to the three below);
+            // q, k, v read where the merged projection wrote them
+            fused_attn_fwd(s, at, D, H, t.XH, t.SC, 1.f / sqrtf((float)t.C), k.qkv, k.qkv + QK, k.t0, b.adj2d, b.adjsp, k.qkv + 2 * QK, k.t1, k.alpha, k.hhat);
         } else {
             JT_LAUNCH(k_attn_scores, (long)R * H, s, tp, H, t.XH, t.SC, 1.f / sqrtf((float)t.C), (const float*)k.q, (const float*)k.k,
                                (const float*)k.t0, (const float*)b.adj2d, (const float*)b.adjsp, k.alpha);
@@ -750,8 +755,11 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         float *dv = b.tN_D[1], *dt1 = b.tE_D[0], *dS = b.tE_H, *dq = b.tN_QK[0], *dk = b.tN_QK[1], *dt0 = b.tE_QK;
         if (t.fused_attn) {
             // target side (d alpha, softmax backward, d t1, d q, d t0) and source side (d v, d k): two launches, bit-identical to the six below
-            const AttnTopo at{Nn, t.N, tp.node_mol, tp.nn, tp.node_off, tp.edge_off, t.fused_attn == 2 ? 1 : 0};
-            fused_attn_bwd(s, at, D, H, t.XH, t.SC, isc, dhhat, k.q, k.k, k.v, k.t0, k.t1, k.alpha, dS, dt1, dt0, dq, dk, dv);
+            const int F3a = 2 * QK + D;
+            const AttnTopo at{Nn, t.N, tp.node_mol, tp.nn, tp.node_off, tp.edge_off, t.fused_attn == 2 ? 1 : 0, F3a, F3a, F3a, F3a};
+            // (d q | d k | d v land side by side in b.dqkv, where the merged projection's backward reads them)
+            fused_attn_bwd(s, at, D, H, t.XH, t.SC, isc, dhhat, k.qkv, k.qkv + QK, k.qkv + 2 * QK, k.t0, k.t1, k.alpha, dS, dt1, dt0, b.dqkv, b.dqkv + QK,
+                           b.dqkv + 2 * QK);
         } else {
             JT_LAUNCH(k_attn_bwd_v, (long)Nn * D, s, tp, D, H, (const float*)dhhat, (const float*)k.t1, (const float*)k.alpha, da, dv);
             JT_LAUNCH(k_attn_bwd_t1, (long)R * D, s, tp, D, H, (const float*)dhhat, (const float*)k.v, (const float*)k.t1, (const float*)k.alpha, da, dt1);
@@ -779,7 +787,7 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
             M.n = 3;
             float* srcs[3] = {dq, dk, dv};
             for (int j = 0; j < 3; ++j) { M.w[j] = nullptr; M.bias[j] = nullptr; M.out[j] = srcs[j]; M.F[j] = j < 2 ? QK : D; M.col[j] = j * QK; }
-            hipLaunchKernelGGL(k_mod_gather_cols, dim3((unsigned)(((long)Nn * D + 255) / 256), 3u), dim3(256), 0, s, M, Nn, F3, b.dqkv);
+            if (!t.fused_attn) hipLaunchKernelGGL(k_mod_gather_cols, dim3((unsigned)(((long)Nn * D + 255) / 256), 3u), dim3(256), 0, s, M, Nn, F3, b.dqkv);
             c.lin_dw(b.dqkv, F3, Nn, F3, k.ht, D, D, b.dWqkv + (size_t)l * F3 * D, D, b.dbqkv + (size_t)l * F3);
             c.lin_dx(b.dqkv, F3, Nn, F3, b.Wqkv + (size_t)l * F3 * D, D, D, dht, D, 0);
         }

@@ -78,7 +78,13 @@ void fused_node_ln_mod_bwd(hipStream_t s, long rows, int F, const float* dy, con
 
 // ---- attention of a block: forward in one launch, backward in two (a wave per target / per source atom; bit-identical to the op-by-op
 // kernels of train_ops.h: scores | softmax | messages and their six backward kernels).  No dropout on the weights (SITE_ALPHA is p = 0).
-struct AttnTopo { int Nn, N; const int *node_mol, *nn, *node_off, *edge_off; int one_wave; };      // N: the largest molecule of the batch (LDS per atom); one_wave: tests force the large-batch form
+struct AttnTopo {
+    int Nn, N;                                   // N: the largest molecule of the batch (LDS per atom)
+    const int *node_mol, *nn, *node_off, *edge_off;
+    int one_wave;                                // tests force the large-batch form
+    int ldqk, ldv, ldd_qk, ldd_v;                // row strides of q / k, of v, of d q / d k, of d v: q | k | v of a block live side by side in one
+                                                 // [Nn, 2 QK + D] array (the merged projection's output), and so do their gradients
+};
 bool fused_attention_available(int D, int H, int N);       // widths 128 / 256 / 384, at most 16 heads, molecules of at most 192 atoms
 void fused_attn_fwd(hipStream_t s, const AttnTopo& t, int D, int H, int XH, int SC, float inv_sqrt_c, const float* q, const float* k, const float* t0,
                     const float* adj2d, const float* adjsp, const float* v, const float* t1, float* alpha, float* hhat);

@@ -870,8 +870,8 @@ __global__ __launch_bounds__(64 * W) void k_attn_fwd(AttnTopo t, int H, int XH, 
             float s;
             if (hd < XH) s = ((hd == 0 ? adj2d[r] : adjsp[r]) > 0.f) ? 1.f : -1e10f;
             else {
-                const float* qq = q + (long)node * QK + (hd - XH) * SC;
-                const float* kk = k + (n0 + a) * QK + (hd - XH) * SC;
+                const float* qq = q + (long)node * t.ldqk + (hd - XH) * SC;
+                const float* kk = k + (n0 + a) * t.ldqk + (hd - XH) * SC;
                 const float* tt = t0 + r * QK + (hd - XH) * SC;
                 float acc = 0.f;
 #pragma unroll 6
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(64 * W) void k_attn_fwd(AttnTopo t, int H, int XH, 
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             const int f = lane + 64 * (w * NW + j);
-            acc[j] += v[(n0 + a) * D + f] * t1[r * D + f] * A[a][f / C];
+            acc[j] += v[(n0 + a) * t.ldv + f] * t1[r * D + f] * A[a][f / C];
         }
     }
 #pragma unroll
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(64 * W) void k_attn_bwd_tgt(AttnTopo t, int H, int 
         const float* dh = dhhat + (long)node * D + hd * C;
         for (int a = g; a < n; a += 4 * W) {
             const long r = e0 + (long)a * n + c;
-            const float* vv = v + (n0 + a) * D + hd * C;
+            const float* vv = v + (n0 + a) * t.ldv + hd * C;
             const float* tt = t1 + r * D + hd * C;
             float s = 0.f;
 #pragma unroll 8
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(64 * W) void k_attn_bwd_tgt(AttnTopo t, int H, int 
     for (int j = 0; j < NV; ++j) {
         const int f = lane + 64 * j;
         dhv[j] = dhhat[(long)node * D + f];
-        qv[j] = f < QK ? q[(long)node * QK + f] : 0.f;
+        qv[j] = f < QK ? q[(long)node * t.ldqk + f] : 0.f;
         sq[j] = 0.f;
     }
 #pragma unroll 4
@@ -979,9 +979,9 @@ __global__ __launch_bounds__(64 * W) void k_attn_bwd_tgt(AttnTopo t, int H, int 
         for (int j = 0; j < NV; ++j) {
             const int f = lane + 64 * j;
             const float tv = t1[r * D + f];
-            dt1[r * D + f] = dhv[j] * v[(n0 + a) * D + f] * A[a][f / C] * (1.f - tv * tv);
+            dt1[r * D + f] = dhv[j] * v[(n0 + a) * t.ldv + f] * A[a][f / C] * (1.f - tv * tv);
             if (f < QK) {
-                const float ds = G[a][XH + f / SC], kv = k[(n0 + a) * QK + f], t0v = t0[r * QK + f];
+                const float ds = G[a][XH + f / SC], kv = k[(n0 + a) * t.ldqk + f], t0v = t0[r * QK + f];
                 sq[j] += ds * kv * t0v;
                 dt0[r * QK + f] = ds * qv[j] * kv * inv_sqrt_c * (1.f - t0v * t0v);
             }
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(64 * W) void k_attn_bwd_tgt(AttnTopo t, int H, int 
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int f = lane + 64 * j;
-            if (f < QK) dq[(long)node * QK + f] = sq[j] * inv_sqrt_c;
+            if (f < QK) dq[(long)node * t.ldd_qk + f] = sq[j] * inv_sqrt_c;
         }
     }
 }
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(64 * W) void k_attn_bwd_src(AttnTopo t, int H, int 
         for (int j = 0; j < NV; ++j) {
             const int f = lane + 64 * j;
             sv[j] += dhhat[(n0 + c) * D + f] * t1[r * D + f] * alpha[r * H + f / C];
-            if (f < QK) sk[j] += dS[r * H + XH + f / SC] * q[(n0 + c) * QK + f] * t0[r * QK + f];
+            if (f < QK) sk[j] += dS[r * H + XH + f / SC] * q[(n0 + c) * t.ldqk + f] * t0[r * QK + f];
         }
     }
     if (W > 1) {
@@ -1052,8 +1052,8 @@ __global__ __launch_bounds__(64 * W) void k_attn_bwd_src(AttnTopo t, int H, int 
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int f = lane + 64 * j;
-            dv[(long)node * D + f] = sv[j];
-            if (f < QK) dk[(long)node * QK + f] = sk[j] * inv_sqrt_c;
+            dv[(long)node * t.ldd_v + f] = sv[j];
+            if (f < QK) dk[(long)node * t.ldd_qk + f] = sk[j] * inv_sqrt_c;
         }
     }
 }
