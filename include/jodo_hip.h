@@ -412,6 +412,20 @@ int jodo_debug_mfma_peak(int iters, int chains, int waves_per_simd, float* sink_
  * {(0,0),(4,0),(8,0),(12,0),(16,0),(4,1),(4,2)}. */
 int jodo_debug_mfma_valu(int iters, int nv, int nt, int waves_per_simd, float* sink_dev, float* tflops_out);
 
+/* ---- gate experiments of the opt-in split-bf16 (three-term, fp32-equivalent) MFMA form (csrc/dgt_split.{h,hip}; no reference
+ * counterpart; measurement helpers, never on the data path) ----
+ * jodo_debug_mfma_bf16_valu: `chains` (1 | 2) dependent v_mfma_f32_32x32x16_bf16 chains per wave with nv in {0,2,4,6,8,16} (one chain)
+ *   or {0,4,8,16} (two chains) independent v_fma issued behind every MFMA; returns the matrix TFLOP/s (bf16 flops).
+ * jodo_debug_pack_split: a row-major [n_out, n_in] matrix -> its f32 packing and its split packing (hi / mid / lo bf16 terms), host.
+ * jodo_debug_chain: y [rows, 256] = W x for x [rows, K], K in {128, 256}, in the strip model with streamed weights; mode 0 exact fp32
+ *   MFMA, 1 split form (one accumulator), 2 split form (corrections in their own accumulator); tiles = item tiles per wave (2: split
+ *   modes, K = 128).  iters > 1 repeats the projection in registers (timing; y then holds a digest); ms_out != NULL times the launch
+ *   with HIP events (synchronises). */
+int jodo_debug_mfma_bf16_valu(int iters, int nv, int chains, int waves_per_simd, float* sink_dev, float* tflops_out);
+int jodo_debug_pack_split(const float* W, int n_out, int n_in, float* f32_packed_host, void* split_packed_host);
+int jodo_debug_chain(int mode, int K, int tiles, const float* x, int rows, const float* wf, const void* wsp, float* y, int iters,
+                     float* ms_out, void* stream);
+
 int jodo_debug_mlp(const float* x, int rows, const float* w1, const float* b1, const float* w2,
                    const float* b2, float* y, void* stream);
 

@@ -189,6 +189,48 @@ struct Packer {
     }
 };
 
+// ---- split-bf16 packing (opt-in bf16x3 form of a projection, dgt_split.h) ----
+// float -> bf16 bits, round to nearest even (finite inputs)
+inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_float(uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+// w = hi + mid + lo, each term rounded to nearest; the residuals w - hi and (w - hi) - mid are exact in fp32
+inline void split3(float w, uint16_t (&t)[3]) {
+    t[0] = bf16_rne(w);
+    const float r1 = w - bf16_to_float(t[0]);
+    t[1] = bf16_rne(r1);
+    const float r2 = r1 - bf16_to_float(t[1]);
+    t[2] = bf16_rne(r2);
+}
+// W [n_out][ld] row-major -> [out block][K16 step][term][64 lanes][8 bf16]: lane l supplies row (l & 31) (the accumulator image of
+// put_proj) and the input columns of the f32 k-steps 8 G + j, j = 0..7, of half l >> 5 — the same in_map / out_map as the f32 form.
+std::vector<uint16_t> pack_proj_split(const float* W, int64_t ld, const IMap& in, const OMap& out) {
+    const size_t ksteps = in.size() / 2, nb = out.size() / 32, ns = ksteps / 8;
+    std::vector<uint16_t> p(nb * ns * 3 * 64 * 8, 0);
+    for (size_t b = 0; b < nb; ++b)
+        for (size_t g = 0; g < ns; ++g)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, kh = lane >> 5, oh = (i >> 2) & 1, os = (i & 3) + 4 * (i >> 3);
+                const int64_t row = out[(b * 2 + oh) * 16 + os];
+                for (int j = 0; j < 8; ++j) {
+                    const int64_t col = in[(g * 8 + j) * 2 + kh];
+                    uint16_t t[3] = {0, 0, 0};
+                    if (row >= 0 && col >= 0) split3(W[row * ld + col], t);
+                    for (int term = 0; term < 3; ++term) p[(((b * ns + g) * 3 + term) * 64 + lane) * 8 + j] = t[term];
+                }
+            }
+    return p;
+}
+
 struct Lookup {
     std::unordered_map<std::string, const jodo_tensor*> m;
     std::string missing;
@@ -476,5 +518,21 @@ extern "C" int jodo_edge_ffn_pack(int De, int mlp_ratio, const float* W3, const 
     if (P.blob.size() > cap_floats) return jodo_set_error(JODO_ERR_ARG, "edge_ffn_pack: buffer of %zu floats, need %zu", cap_floats, P.blob.size());
     std::memcpy(packed_host, P.blob.data(), P.blob.size() * sizeof(float));
     for (int i = 0; i < 4; ++i) offs4[i] = P.offs[i];
+    return JODO_OK;
+}
+
+// debug / gate experiments (csrc/dgt_split.hip): W [n_out, n_in] row-major, natural maps -> the f32 packing (n_out * n_in floats) and
+// the split packing (n_out * n_in * 3 bf16) of the same projection, both into host buffers.
+extern "C" int jodo_debug_pack_split(const float* W, int n_out, int n_in, float* f32_packed_host, void* split_packed_host) {
+    if (!W || n_out <= 0 || n_in <= 0 || n_out % 32 || n_in % 32) return jodo_set_error(JODO_ERR_ARG, "debug_pack_split: sizes must be multiples of 32");
+    if (f32_packed_host) {
+        Packer P;
+        P.put_proj(W, n_in, nat_in(n_in), nat_out(n_out));
+        std::memcpy(f32_packed_host, P.blob.data(), sizeof(float) * (size_t)n_out * n_in);
+    }
+    if (split_packed_host) {
+        const std::vector<uint16_t> s = pack_proj_split(W, n_in, nat_in(n_in), nat_out(n_out));
+        std::memcpy(split_packed_host, s.data(), sizeof(uint16_t) * s.size());
+    }
     return JODO_OK;
 }
