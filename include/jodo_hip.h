@@ -36,9 +36,12 @@ extern "C" {
 
 /* Model hyper-parameters (config.model.* / config.data.* of the reference's configs). */
 typedef struct {
-    int32_t nf;          /* D: node hidden width: 256 or 384 (README.md:168 `--config.model.nf 384`) */
-    int32_t n_layers;    /* L: the per-block readouts 2D // L and 2De // L must fit their padded slots D/4 and
-                            16 (nf 256) / 32 (nf 384), i.e. L >= 8; the Python module additionally asks for even L */
+    int32_t nf;          /* D: node hidden width: 128, 256 or 384 (README.md:150,162 the GEOM "Base" model `--config.model.nf 128`,
+                            :168 `--config.model.nf 384`); anything else -> JODO_ERR_UNSUPPORTED */
+    int32_t n_layers;    /* L in [1, 32] with: the per-block edge readout 2De // L at most one 32-row block wide (L >= 2 / 4 / 6 at
+                            nf 128 / 256 / 384), and the edge head's input De + L * cep a multiple of 32, cep = that readout padded to
+                            16 or 32 (at nf 128, and at nf 256 with L >= 8, this means even L); the Python module further asks for
+                            L <= 16 and a head input of 96..480 except 448.  Tested: L = 6 (nf 128), 8 and 10 (nf 256), 10 (nf 384) */
     int32_t n_heads;     /* H (16)                                              */
     int32_t n_extra;     /* XH: adjacency heads (2)                             */
     int32_t mlp_ratio;   /* r                                                   */

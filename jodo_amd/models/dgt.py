@@ -160,7 +160,7 @@ class _DGTBase(nn.Module):
 
         # ---- runtime state (not part of state_dict) ----
         self._packed = None           # (version_key, blob_dev, woff_host ctypes array)
-        self._plans = {}              # plan cache keyed by the mask tensor identity
+        self._plans = {}              # plan cache keyed by the mask storage (address, shape, version), see _plan
         self._splits = {}             # sub-batch splits of n_streams > 1, keyed likewise
         self.n_streams = 1            # > 1: sub-batches evaluated concurrently on that many HIP streams (_forward_split)
         self._cfg_struct = None
@@ -210,11 +210,14 @@ class _DGTBase(nn.Module):
 
     # -- plans ---------------------------------------------------------------------------------
     def _plan(self, node_mask, edge_mask, device, validate=True):
-        # keyed by tensor identity; the entry keeps the mask alive so its storage cannot be recycled
-        # for a different mask while the plan is cached (data_ptr alone is not a safe key)
-        key = id(node_mask)
+        # keyed by the mask's storage address, shape and version counter; the entry keeps the mask alive, so its storage cannot be
+        # recycled for a different mask while the plan is cached (data_ptr alone would not be a safe key).  Not by tensor identity:
+        # torch.nn.DataParallel — how the reference's create_model wraps the model (models/utils.py:27) — scatters every call's
+        # arguments, and with one device that hands the module a fresh VIEW of the same mask on every call (same storage, same
+        # version counter); identity would rebuild the plan on each of a round's 1000 calls.
+        key = (node_mask.data_ptr(), tuple(node_mask.shape), tuple(node_mask.stride()), str(node_mask.device))
         plan = self._plans.get(key)
-        if plan is not None and plan['mask'] is node_mask and plan['mask_version'] == node_mask._version:
+        if plan is not None and plan['mask_version'] == node_mask._version:
             return plan
         self._recheck_weights()                          # new batch (= new sampling round): catch `.data` weight updates
         B, N = node_mask.shape[0], node_mask.shape[1]
@@ -256,6 +259,16 @@ class _DGTBase(nn.Module):
             L.jodo_plan_destroy(old['handle'])
         self._plans[key] = plan
         return plan
+
+    def _replicate_for_data_parallel(self):
+        """torch.nn.DataParallel with more than one device (the reference's create_model on a multi-GPU node, models/utils.py:27)
+        shallow-copies the module into worker threads every forward: the copies would share this module's plan cache, ctypes
+        handles and the packed weight blob on cuda:0.  Multi-GPU here is one process per GPU with the batch sharded by the sampler."""
+        raise RuntimeError(
+            "jodo_amd %s cannot be replicated by torch.nn.DataParallel over several devices: its plans, workspace and packed weights "
+            "belong to one device.  Run one process per GPU (python -m torch.distributed.run --nproc-per-node N ...) and pass "
+            "shard=(rank, world) to jodo_amd.sampling.get_sampling_fn (jodo_amd/dist.py, INTEGRATION.md section 3); "
+            "DataParallel(model, device_ids=[one device]) is supported." % type(self).__name__)
 
     def __del__(self):
         try:

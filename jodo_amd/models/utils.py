@@ -8,8 +8,10 @@ Same public names, argument meaning and error behaviour as /root/reference/model
 `create_model` differs from the reference in one deliberate way: the reference wraps the model in
 `torch.nn.DataParallel` (:27, single process, per-forward parameter broadcast).  Here multi-GPU is
 one process per GPU with the batch sharded by the sampler (jodo_amd/dist.py), so the model is
-returned bare by default; `wrap='dataparallel_keys'` returns a thin wrapper exposing the same
-`module.`-prefixed state_dict keys so reference checkpoints load with strict=True.
+wrapped by default (`wrap='dataparallel_keys'`) in a thin module exposing the same `module.`-prefixed
+state_dict keys so reference checkpoints load with strict=True; `wrap='dataparallel'` is the reference's
+own `torch.nn.DataParallel` on the model's single device (supported: DataParallel over one device calls
+the module in place); over several devices the modules raise instead of being replicated.
 """
 import torch
 
@@ -59,6 +61,13 @@ def create_model(config, wrap='dataparallel_keys'):
     model = model.to(config.device)
     if wrap == 'dataparallel_keys':
         model = _ModulePrefix(model)
+    elif wrap == 'dataparallel':
+        # exactly the reference's wrapper (models/utils.py:27), on the ONE device the model lives on: DataParallel then calls the
+        # module in place (no replicas); over several devices the DGT modules refuse to be replicated (_replicate_for_data_parallel)
+        dev = torch.device(config.device)
+        model = torch.nn.DataParallel(model, device_ids=[dev.index if dev.index is not None else torch.cuda.current_device()])
+    elif wrap is not None:
+        raise ValueError("wrap in {'dataparallel_keys', 'dataparallel', None}")
     return model
 
 

@@ -202,6 +202,13 @@ class TrainEngine:
             capi.ptr(out_x), capi.ptr(out_e), capi.ptr(self.flags), capi.ptr(slot['buf']), self._stream()), 'jodo_train_forward')
         return out_x, out_e
 
+    def release(self, stamp):
+        """The activations of forward `stamp` are no longer needed (its backward ran, or never will): its slot may serve the next
+        forward.  Called by `backward`, and by the autograd node's guard when a graph is dropped without a backward (an exception
+        between forward and backward, a train-mode forward run for logging) — without it the slot stayed live forever and the
+        following forward / backward loop allocated, and kept, a second workspace (gigabytes, see above)."""
+        release_slot(self.pool, stamp)
+
     def slot_of(self, stamp):
         for s_ in self.pool['slots']:
             if s_['stamp'] == stamp and s_['buf'] is not None:
@@ -236,8 +243,28 @@ class TrainEngine:
             self.handle, capi.ptr(self.desc), self._ptrs(params), self._ptrs(grads), self.n_params, capi.ptr(noise_level),
             capi.ptr(d_out_x), capi.ptr(d_out_e), ctypes.c_float(dropout_p), ctypes.c_uint64(seed), capi.ptr(slot['buf']),
             self._stream()), 'jodo_train_backward')
-        slot['live'] = False                                     # (a second backward over the same activations still works until a forward takes the slot)
+        slot['live'] = False                                     # = release(stamp); a second backward over the same activations still works until a forward takes the slot
         return grads
+
+
+def release_slot(pool, stamp):
+    for s_ in pool['slots']:
+        if s_['stamp'] == stamp:
+            s_['live'] = False
+
+
+class _SlotGuard:
+    """Lives on the autograd context of one training-path forward; when the context dies (backward done and graph freed, or the
+    graph dropped without a backward) the forward's workspace slot is released."""
+
+    def __init__(self, pool, stamp):
+        self.pool, self.stamp = pool, stamp
+
+    def __del__(self):
+        try:
+            release_slot(self.pool, self.stamp)
+        except Exception:
+            pass
 
 
 class _DGTTrainFn(torch.autograd.Function):
@@ -250,6 +277,7 @@ class _DGTTrainFn(torch.autograd.Function):
         out_x, out_e = engine.forward(ps, xh, edge_x, cond_x, cond_edge_x, noise_level, context, dropout_p, seed, keep=True)
         ctx.engine, ctx.dropout_p, ctx.seed, ctx.ps, ctx.nl = engine, dropout_p, seed, ps, noise_level
         ctx.stamp = engine.stamp
+        ctx.slot_guard = _SlotGuard(engine.pool, engine.stamp)       # releases the slot when this context is dropped, backward or not
         return out_x, out_e
 
     @staticmethod

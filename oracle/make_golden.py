@@ -24,6 +24,8 @@ cond_DGT_concat with `jodo_amd.models.init_utils.deterministic_init_` (weights a
   traj_geom_anc3.npz                           3-step ancestral trajectory of the GEOM model (3 bond channels: aromatic decode)
   grad_qm9.npz                                 the reference's own training loss + loss.backward() gradients of selected
                                                parameters on a small batch (pins the oracle's autograd)
+  traj_qm9_cfg0.npz                            BASELINE configs[0] at its own size: the reference's get_sampling_fn, batch 64, 50 ancestral
+                                               steps, CPU; end state + decodes + seed (the noise is regenerated from the seed)
   traj_cond_dpm_multi8.npz / _single3.npz / _single1.npz
                                                hybrid DPM-solver: 2nd-order multistep (8 NFE), single-step order 3
                                                (6 NFE) and order 1 (3 NFE)
@@ -419,6 +421,86 @@ def cond_eval_fixture(ref, fname, steps=4, n_nodes=(9, 5, 17, 12, 3, 18), batch=
     print(fname, 'ok; score', score, 'atoms', [int(m[0].shape[0]) for m in mols])
 
 
+def cfg0_fixture(ref, fname, batch=64, steps=50, seed=42, model_seed=42):
+    """BASELINE.json configs[0] at its own size: the reference's own get_sampling_fn (sampling.py:148-232) — vpsde_qm9_uncond_jodo,
+    batch 64, 50 ancestral steps, PyTorch CPU — one round, seeded `torch.manual_seed(seed)` right before the call, so every draw
+    (atom counts from the reference's DistributionNodes over its own histogram, z_T, edge_z_T, the per-step noise) is a function of the
+    seed and is NOT stored: the replay regenerates it from the CPU generator in the same order (jodo_amd.sampling shard_mode='parity').
+    Stored: what the sampler returned (sampling.py:591-594), what post_process / mol_process made of it (before the final shuffle),
+    the drawn atom counts and two checksums of the noise stream.  Heads scaled like every trajectory fixture (decodes not degenerate)."""
+    import random
+    cfg, model = build_reference_model(ref, 'vpsde_qm9_uncond_jodo', model_seed, head_gain=HEAD_GAIN)
+    cfg.sampling.steps = steps
+    assert cfg.sampling.method == 'ancestral'
+    S = ref.sampling
+    ns = ref.diffusion.noise_schedule.NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0,
+                                                      continuous_beta_1=cfg.sde.continuous_beta_1)
+    # datasets/datasets_config.py by path: the package's __init__ pulls in the PyG data pipeline (not on this path, not importable here)
+    import importlib.util
+    from oracle.ref_import import REFERENCE_ROOT
+    spec = importlib.util.spec_from_file_location('jodo_ref_datasets_config', os.path.join(REFERENCE_ROOT, 'datasets', 'datasets_config.py'))
+    dsc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dsc)
+    info = dsc.get_dataset_info(cfg.data.info_name)
+    nodes_dist = ref.models.node_distribution.get_node_dist(info)
+    inv = ref.utils.get_data_inverse_scaler(cfg)
+    fn = S.get_sampling_fn(cfg, ns, nodes_dist, batch, batch, inv)
+    rec = {}
+    orig_sampling, orig_pp, orig_mp = S.AncestralSampler.sampling, S.post_process, S.mol_process
+    orig_n, orig_e = S.sample_combined_position_feature_noise, S.sample_symmetric_edge_feature_noise
+    sums = {'node': [], 'edge': []}
+
+    def rec_sampling(self, model_, z, node_mask, edge_mask, edge_z, context):
+        rec['z'], rec['nm'], rec['em'] = z.clone(), node_mask.clone(), edge_mask.clone()
+        out = orig_sampling(self, model_, z, node_mask, edge_mask, edge_z, context)
+        rec['x_mean'], rec['edge_x_mean'] = out[0].clone(), out[1].clone()
+        return out
+
+    def rec_pp(*a, **k):
+        out = orig_pp(*a, **k)
+        rec['pos'], rec['one_hot'], rec['fc'], rec['et'] = [t.clone() for t in out]
+        return out
+
+    def rec_mp(one_hot, pos, fc, n_nodes, edge_types):
+        rec['n_nodes'] = torch.as_tensor(n_nodes).clone()
+        return orig_mp(one_hot, pos, fc, n_nodes, edge_types)
+
+    def rn(*a, **k):
+        v = orig_n(*a, **k)
+        sums['node'].append(float(v.double().sum()))
+        return v
+
+    def re_(*a, **k):
+        v = orig_e(*a, **k)
+        sums['edge'].append(float(v.double().abs().sum()))
+        return v
+
+    S.AncestralSampler.sampling, S.post_process, S.mol_process = rec_sampling, rec_pp, rec_mp
+    S.sample_combined_position_feature_noise, S.sample_symmetric_edge_feature_noise = rn, re_
+    try:
+        torch.manual_seed(seed)
+        random.seed(seed)
+        mols = fn(model)
+    finally:
+        S.AncestralSampler.sampling, S.post_process, S.mol_process = orig_sampling, orig_pp, orig_mp
+        S.sample_combined_position_feature_noise, S.sample_symmetric_edge_feature_noise = orig_n, orig_e
+    assert len(mols) == batch and len(sums['node']) == steps + 1 and len(sums['edge']) == steps + 1     # z_T + one draw per step
+    x_mean, e_mean, nm, em = rec['x_mean'], rec['edge_x_mean'], rec['nm'], rec['em']
+    B, N = x_mean.shape[0], x_mean.shape[1]
+    _, h_cat, h_int, h_edge = inv(x_mean[:, :, :3], x_mean[:, :, 3:-1], x_mean[:, :, -1:], nm, e_mean, em)
+    top2 = h_cat.topk(2, dim=2).values
+    m_atom = (top2[..., 0] - top2[..., 1])[nm[..., 0] > 0].min().item()
+    emk = em.reshape(B, N, N) > 0
+    m_exist = (h_edge[..., 0] - 0.5).abs()[emk].min().item()
+    np.savez_compressed(os.path.join(OUT, fname), torch_num_threads=torch.get_num_threads(), cfg_name='vpsde_qm9_uncond_jodo', seed=seed,
+                        model_seed=model_seed, steps=steps, batch=batch, head_gain=HEAD_GAIN, n_nodes=rec['n_nodes'].numpy(),
+                        z_sum=float(rec['z'].double().sum()), node_noise_sums=np.array(sums['node']), edge_noise_sums=np.array(sums['edge']),
+                        x_mean=x_mean.numpy(), edge_x_mean=e_mean.numpy(), pos=rec['pos'].numpy(), atom_type=rec['one_hot'].argmax(2).numpy(),
+                        fc=rec['fc'].numpy(), edge_type=rec['et'].numpy(), margins=np.array([m_atom, m_exist]))
+    print(fname, 'ok; n_nodes', rec['n_nodes'].tolist()[:8], '... margins atom/exist', m_atom, m_exist,
+          'atom types', np.unique(rec['one_hot'].argmax(2).numpy()), 'bond types', np.unique(rec['et'].numpy()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
@@ -444,6 +526,8 @@ def main():
         ('traj_cond_dpm_single3.npz', lambda f: dpm_fixture(ref, f, nfe=6, seed=33, method='singlestep_fixed', order=3)),
         ('traj_cond_dpm_single1.npz', lambda f: dpm_fixture(ref, f, nfe=3, seed=34, method='singlestep_fixed', order=1)),
         ('cond_eval.npz', lambda f: cond_eval_fixture(ref, f)),
+        # BASELINE configs[0] at its own size (batch 64, 50 steps) through the reference's get_sampling_fn
+        ('traj_qm9_cfg0.npz', lambda f: cfg0_fixture(ref, f)),
     ]
     want = sys.argv[1:]
     for fname, job in jobs:

@@ -11,9 +11,11 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     # The CPU oracle is plain torch; on a GPU box with hundreds of hardware threads torch's default thread count makes its small
     # ops crawl (bench.py measured 170x between 32 and 256 threads on the EPYC 9575F host), and the oracle is most of the GPU
-    # suite's wall time.
+    # suite's wall time.  EIGHT threads, always: the float32 oracle's own distance from float64 — the yardstick of
+    # helpers.close64 — moves by 2x with the thread count (CPU GEMM blocking = summation order), every fixture under tests/golden
+    # was recorded at 8 threads (its `torch_num_threads` field), and a yardstick must not depend on the box.
     import torch
-    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 32)))
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 8)))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
 

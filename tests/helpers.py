@@ -113,18 +113,22 @@ def debug_fetch(model, what, count):
 # numbers.
 FWD_ATOL, FWD_RTOL, K64 = 2e-5, 1e-4, 4.0
 # Two documented exceptions to K64 (measured on MI355X):
-#  * K64_LARGE: nf = 384, or a molecule with n > 128 atoms.  Round 4 needed 16 here (13.5 x at nf 384, 6.7 x / 2.9e-4 at n = 150) and
-#    round 5 found the digit: every neighbour's position increment was added into the running position (up to 180 roundings at
-#    ulp(|x| ~ 4) per block); summed among themselves first, as the reference does (advance_position, dgt_kernels_common.h), n = 150
-#    is at 8e-5 - 1.3e-4 and nf 384 at 2e-5.  Measured in ONE process (tools/err_by_block.py: same inputs, oracle32 and oracle64 from
-#    the same run) the kernels are now within 1.7 - 4.2 x of the float32 oracle on every output; the suite's log still shows up to
-#    8.3 x because the float32 oracle's own error moves by 2 x with torch's CPU thread count (1.1e-5 vs 2.5e-5 on the same inputs:
-#    reduction order), so the regime keeps a factor 10 (worst logged 8.3), down from 16.  The rest is MFMA accumulation order: one fp32 chain over
-#    K = 1024 / 1536 hidden features where the CPU sums blocked (h after block 0: 1.3e-5 against the oracle's 1.8e-6, equal from
-#    block 4 on).
+#  * K64_LARGE: nf = 384, or a molecule with n > 128 atoms.  Round 4 needed 16 here, round 5 found the digit (every neighbour's position
+#    increment was added into the running position; summed among themselves first, as the reference does — advance_position,
+#    dgt_kernels_common.h) and kept 10 only because the yardstick itself moved: the float32 oracle's distance from float64 changes by
+#    2 x with torch's CPU thread count (GEMM blocking = summation order), and the GPU box ran it at 32 threads.  Round 6 pins the
+#    yardstick (tests/conftest.py: 8 threads, what every fixture records) and sets the factor to what the log then shows: 6.
+#    What is left above K64 = 4 has a name (tools/err_terms.py, profiles/r06_err_terms.txt): the Gaussian distance basis.  A basis
+#    function of width sigma turns an error dx of the modulated distance x = d^2 (1 + scale) + shift into 0.24 dx / sigma^2 of the
+#    feature; the test initialisation draws sigma = |w| + 1e-5 as small as 0.0097 among the 95 Gaussians of nf 384 (0.030 among the
+#    63 of nf 256), i.e. a gain of 2 500 on a few ulps of x.  Widening that one Gaussian to 0.2 takes the nf 384 edge state after
+#    block 0 from 1.04e-4 to 5.9e-5; narrowing the narrowest one of nf 256 to 0.0097 takes the kernels from 1.8e-5 to 7.5e-5 AND the
+#    float32 oracle from 3.2e-5 to 1.0e-4: both are fp32 evaluations of an ill-conditioned function, which of them lands further from
+#    float64 on a given batch is chance.  The constant 1.0e-4 "from block 0" of profiles/r05_err_by_block.txt is this term entering
+#    through the top-level edge embedding and riding the residual stream, not accumulation.
 #  * K64_HARD: the adversarial-weights stress (trunk gain 3 - 5, outputs 1e3 - 1e7, float32 oracle 1e-2 - 1e3 from float64):
 #    measured worst 14.5 x (edges; not a position sum).
-K64_LARGE, K64_HARD = 10.0, 16.0
+K64_LARGE, K64_HARD = 6.0, 16.0
 
 
 def k64_for(hp, n_nodes):

@@ -394,6 +394,102 @@ def test_ancestral_trajectory_with_hip_model(fname, fused_on):
     check_decodes(cfg, fx, x_mean, e_mean, nm, em)
 
 
+def test_drop_in_under_the_references_dataparallel_wrapper(tmp_path):
+    """The boundary where the reference puts it (models/utils.py:24-28): the registered class is built from the config, moved to
+    config.device and wrapped in torch.nn.DataParallel; a checkpoint written the reference's way (`module.`-prefixed keys,
+    utils.py:23-30) is loaded into that wrapper with strict=True (utils.py:17); the reference's recorded 5-step trajectory then runs
+    through the WRAPPED model.  DataParallel over one device scatters the arguments (fresh views of the masks every call) and calls
+    the module in place: the plan cache must recognise the views, not rebuild a plan per call."""
+    from jodo_amd.diffusion import NoiseScheduleVP
+    from jodo_amd.models import utils as mutils
+    from jodo_amd.models.ema import ExponentialMovingAverage
+    from jodo_amd.sampling import AncestralSampler
+    from jodo_amd.utils import get_self_cond_fn, restore_checkpoint, save_checkpoint
+    fx = load_fixture('traj_qm9_anc5.npz')
+    cfg = make_config(str(fx['cfg_name']))
+    cfg.device = torch.device(DEV)
+    # the checkpoint: the fixture's weights, saved from a DataParallel-wrapped model as the reference's training loop does
+    src = torch.nn.DataParallel(make_model(cfg, int(fx['seed']), DEV, head_gain=float(fx['head_gain'])), device_ids=[0])
+    path = str(tmp_path / 'checkpoint_dp.pth')
+    save_checkpoint(path, dict(optimizer=torch.optim.Adam(src.parameters()), model=src,
+                               ema=ExponentialMovingAverage(src.parameters(), decay=0.999), step=9))
+    assert all(k.startswith('module.') for k in torch.load(path)['model'])
+    # the model: exactly create_model's three steps (registry lookup, .to(device), DataParallel), then the strict load
+    model = mutils.create_model(cfg, wrap='dataparallel')
+    assert isinstance(model, torch.nn.DataParallel) and type(model.module).__name__ == 'DGT_concat'
+    state = dict(optimizer=torch.optim.Adam(model.parameters()), model=model, ema=ExponentialMovingAverage(model.parameters(), decay=0.999), step=0)
+    state = restore_checkpoint(path, state, cfg.device)
+    assert state['step'] == 9
+    model.eval()
+    nm, em = masks(fx['n_nodes'].tolist(), DEV)
+    ns = NoiseScheduleVP(cfg.sde.schedule)
+    noise = {'node': torch.from_numpy(fx['node_noise']).to(DEV), 'edge': torch.from_numpy(fx['edge_noise']).to(DEV)}
+    sampler = AncestralSampler(ns, torch.linspace(ns.T, 1e-3, int(fx['steps'])), True, True, True,
+                               get_self_cond_fn(cfg), noise_fn=lambda i, kind, like: noise[kind][i], fused=True)
+    with torch.no_grad():
+        x_mean, e_mean = sampler.sampling(model, torch.from_numpy(fx['z']).to(DEV), nm, em, torch.from_numpy(fx['edge_z']).to(DEV), None)
+    close(x_mean, torch.from_numpy(fx['x_mean']), atol=1e-3, rtol=0)
+    close(e_mean, torch.from_numpy(fx['edge_x_mean']), atol=1e-3, rtol=0)
+    check_decodes(cfg, fx, x_mean, e_mean, nm, em)
+    assert len(model.module._plans) == 1, "one batch, one plan: the scattered mask views must hit the plan cache"
+
+
+def test_baseline_config0_at_its_own_size_through_get_sampling_fn():
+    """BASELINE.json configs[0] — vpsde_qm9_uncond_jodo, batch 64, 50 ancestral steps — as the REFERENCE ran it on the CPU
+    (tests/golden/traj_qm9_cfg0.npz: its own get_sampling_fn, sampling.py:148-232, seeded torch.manual_seed(42)), replayed through this
+    package's get_sampling_fn on the GPU: shard=(0, 1) in parity mode re-draws the unsharded run's atom counts and every noise tensor
+    from the CPU generator in the reference's order (checked against the fixture's stream checksums), the score network is the HIP
+    path.  End state at the K-step tolerance (K <= 50, atol 1e-3), decodes bit-identical above margin."""
+    import jodo_amd.sampling as JS
+    from jodo_amd.diffusion import NoiseScheduleVP
+    from jodo_amd.models import get_node_dist, load_dataset_info
+    from jodo_amd.utils import get_data_inverse_scaler
+    fx = load_fixture('traj_qm9_cfg0.npz')
+    cfg = make_config(str(fx['cfg_name']))
+    cfg.device = torch.device(DEV)
+    cfg.sampling.steps = int(fx['steps'])
+    B = int(fx['batch'])
+    model = make_model(cfg, int(fx['model_seed']), DEV, head_gain=float(fx['head_gain']))
+    ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
+    fn = JS.get_sampling_fn(cfg, ns, get_node_dist(load_dataset_info(cfg.data.info_name)), B, B, get_data_inverse_scaler(cfg),
+                            shard=(0, 1), shard_mode='parity', seed=int(fx['seed']))
+    rec, sums = {}, {'node': [], 'edge': []}
+    orig_sampling, orig_n, orig_e = JS.AncestralSampler.sampling, JS.sample_combined_position_feature_noise, JS.sample_symmetric_edge_feature_noise
+
+    def rec_sampling(self, model_, z, node_mask, edge_mask, edge_z, context):
+        out = orig_sampling(self, model_, z, node_mask, edge_mask, edge_z, context)
+        rec['x_mean'], rec['edge_x_mean'], rec['nm'], rec['em'] = out[0], out[1], node_mask, edge_mask
+        return out
+
+    def rn(*a, **k):
+        v = orig_n(*a, **k)
+        sums['node'].append(float(v.double().sum()))
+        return v
+
+    def re_(*a, **k):
+        v = orig_e(*a, **k)
+        sums['edge'].append(float(v.double().abs().sum()))
+        return v
+
+    JS.AncestralSampler.sampling, JS.sample_combined_position_feature_noise, JS.sample_symmetric_edge_feature_noise = rec_sampling, rn, re_
+    try:
+        mols = fn(model)
+    finally:
+        JS.AncestralSampler.sampling, JS.sample_combined_position_feature_noise, JS.sample_symmetric_edge_feature_noise = orig_sampling, orig_n, orig_e
+    # the replayed RNG stream is the reference's: atom counts and every draw's checksum
+    assert [int(m[0].shape[0]) for m in mols] == fx['n_nodes'].tolist()
+    assert np.allclose(sums['node'], fx['node_noise_sums'], rtol=0, atol=1e-9) and np.allclose(sums['edge'], fx['edge_noise_sums'], rtol=0, atol=1e-9)
+    close(rec['x_mean'], torch.from_numpy(fx['x_mean']), atol=1e-3, rtol=0)
+    close(rec['edge_x_mean'], torch.from_numpy(fx['edge_x_mean']), atol=1e-3, rtol=0)
+    print("config 0 (B = %d, %d steps) end state vs the reference's: max |dx| %.2e, max |de| %.2e" % (
+        B, int(fx['steps']), (rec['x_mean'].cpu() - torch.from_numpy(fx['x_mean'])).abs().max(),
+        (rec['edge_x_mean'].cpu() - torch.from_numpy(fx['edge_x_mean'])).abs().max()))
+    check_decodes(cfg, fx, rec['x_mean'], rec['edge_x_mean'], rec['nm'], rec['em'])
+    # and the molecules the sampling function returned are the decoded tensors, cut to size (mol_process, sampling.py:12-32)
+    dec = fn.last_decoded[0]
+    assert np.array_equal(dec[1].cpu().numpy()[0, :mols[0][1].shape[0]], mols[0][1].numpy())
+
+
 @pytest.mark.parametrize("fused_on", [True, False])
 @pytest.mark.parametrize("fname", ['traj_cond_dpm4.npz', 'traj_cond_dpm_multi8.npz', 'traj_cond_dpm_single3.npz',
                                    'traj_cond_dpm_single1.npz'])

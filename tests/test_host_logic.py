@@ -35,6 +35,23 @@ def test_create_model_exposes_dataparallel_keys():
     assert sum(p.numel() for p in m.parameters()) == 27538584
 
 
+def test_dataparallel_replication_is_refused_with_directions():
+    """The reference's create_model wraps the model in torch.nn.DataParallel (models/utils.py:27).  Over ONE device that calls the
+    module in place (tests/test_dgt_gpu.py runs a trajectory that way); over several it would shallow-copy the module — plan cache,
+    ctypes handles and the packed blob of cuda:0 included — into worker threads every forward: refused, naming the replacement."""
+    for name in ('DGT_concat', 'cond_DGT_concat'):
+        cfg = configs.get('vpsde_qm9_cond_jodo' if name.startswith('cond') else 'vpsde_qm9_uncond_jodo')
+        model = get_model_class(name)(cfg)
+        with pytest.raises(RuntimeError, match=r'shard=\(rank, world\)'):
+            model._replicate_for_data_parallel()
+        with pytest.raises(RuntimeError, match='one process per GPU'):
+            model._replicate_for_data_parallel()
+    cfg = configs.get('vpsde_qm9_uncond_jodo')
+    cfg.device = 'cpu'
+    with pytest.raises(ValueError):
+        mutils.create_model(cfg, wrap='replicas')
+
+
 def test_unsupported_settings_fail_loudly():
     # (n_layers = 3 at nf 256: the per-block edge readout, 2 De / 3 = 42 features, does not fit one 32-row block)
     for key, val in (('dist_gbf', False), ('cond_time', False), ('pred_data', False), ('nf', 512), ('n_layers', 3)):

@@ -564,6 +564,31 @@ def test_varying_batches_share_one_workspace():
     del o2, o3
 
 
+def test_a_dropped_graph_releases_its_workspace():
+    """A grad-enabled forward whose backward never runs (the graph is dropped: an exception between forward and backward, a train-mode
+    forward for logging) must not keep its activation workspace live: the forward / backward loop that follows stays in ONE workspace
+    (round-5 advisor finding: the stale slot was never reclaimed and a second multi-gigabyte buffer was allocated and kept)."""
+    from helpers import random_inputs
+    cfg = make_config('vpsde_qm9_uncond_jodo')
+    model = make_model(cfg, 5, DEV)
+    hp = O.Hyper.from_config(cfg)
+    d = lambda x: None if x is None else x.to(DEV)
+    xh, ex, nl, ctx, nm, em = random_inputs(hp, [5, 9, 3], seed=1)
+    nl, xh, nm, em, ex = d(nl), d(xh), d(nm), d(em), d(ex)
+    call = lambda: model(nl, xh, nm, em, edge_x=ex, cond_x=None, cond_edge_x=None, noise_level=nl)
+    out = call()                                         # grad-enabled, never differentiated
+    slots = model._train_pool['slots']
+    assert sum(s_['live'] for s_ in slots) == 1
+    del out                                              # the graph dies -> the slot is free again
+    assert sum(s_['live'] for s_ in slots) == 0
+    for _ in range(3):
+        model.zero_grad()
+        ox, oe = call()
+        (ox.square().sum() + oe.square().sum()).backward()
+    assert len([s_ for s_ in slots if s_['buf'] is not None]) == 1, "the loop after a dropped graph must stay in one workspace"
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 64, 1187), (256, 64, 50000), (252, 256, 300), (3, 256, 9000)])
 def test_train_gemm_bias_gradient_rides_on_the_weight_gradient(M, N, K):
     """dW += dY^T X with db += column sums of dY from the same launch (with and without split-K), against float64."""
