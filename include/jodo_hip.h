@@ -196,6 +196,13 @@ enum jodo_plan_option {
     JODO_OPT_Z_SPLIT = 12,        /* 1 (default): when the LAST round of the pair update's launch (n_pitems mod 1024) has at most 256 items, they run as
                                    * workgroups of 4 waves that share the per-pair coord_mlp.0 output blocks (k_edge_update_sym<.., ZW = 4>); 2: also
                                    * 2 waves for 257 .. 512 items (measured slower on MI355X, kept for A/B runs); 0: one wave per item throughout */
+    JODO_OPT_SPLIT_BF16 = 13,     /* 0 (default): every projection runs on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  1 (OPT-IN, nf 256
+                                   * unconditional models, pinned symmetric + shared-row paths, rotated statistics on, weights handed over with
+                                   * jodo_plan_set_split_weights): the folded pair update runs its projections in the split-bf16 form — every
+                                   * operand as hi + mid + lo bf16 terms, six v_mfma_f32_32x32x16_bf16 products per K = 16 step, fp32
+                                   * accumulation: fp32-equivalent arithmetic (dropped terms <= 3 * 2^-26 relative; profiles/r06_split_gate.txt)
+                                   * at 6/16 of the matrix cycles (csrc/dgt_kernels_split.h).  Results differ from the default path in the
+                                   * last bits; the default and every headline number stay exact fp32.  Ignored when a precondition fails. */
     JODO_OPT_COUNT
 };
 int jodo_plan_set_option(jodo_plan* plan, int option, int value);
@@ -414,6 +421,17 @@ int jodo_debug_mfma_peak(int iters, int chains, int waves_per_simd, float* sink_
  * issued after every MFMA: tells whether vector work hides under the matrix pipe.  (nv, nt) in
  * {(0,0),(4,0),(8,0),(12,0),(16,0),(4,1),(4,2)}. */
 int jodo_debug_mfma_valu(int iters, int nv, int nt, int waves_per_simd, float* sink_dev, float* tflops_out);
+
+/* ---- opt-in split-bf16 pair update (JODO_OPT_SPLIT_BF16; no reference counterpart: an alternative arithmetic form of
+ * MultiCondEquiUpdate + the edge FFN, models/mol_gnn.py:71-94, :313-317) ----
+ * jodo_dgt_split_size: bytes of the static weight tape (all blocks / one block) for this configuration; JODO_ERR_UNSUPPORTED unless
+ *   nf = 256 and cond_ch = 0.
+ * jodo_dgt_pack_split_host: the tape (edge FFN, readout, triangular factor of the rotated statistics as hi | mid | lo bf16 terms, in
+ *   consumption order) from the same named fp32 tensors jodo_dgt_pack_weights takes, into a host buffer.
+ * jodo_plan_set_split_weights: device copy of that tape for this plan (caller-owned, must outlive the plan's forwards; NULL clears). */
+int jodo_dgt_split_size(const jodo_cfg* cfg, size_t* total_bytes, size_t* block_bytes);
+int jodo_dgt_pack_split_host(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, void* host, size_t cap_bytes);
+int jodo_plan_set_split_weights(jodo_plan* plan, const void* tape_dev, size_t bytes);
 
 /* ---- gate experiments of the opt-in split-bf16 (three-term, fp32-equivalent) MFMA form (csrc/dgt_split.{h,hip}; no reference
  * counterpart; measurement helpers, never on the data path) ----

@@ -91,3 +91,24 @@ def pack_weights(cfg_struct, state_dict, device=None):
                                       ctypes.c_size_t(n_floats.value), woff, n_woff.value, current_stream_ptr()),
               'jodo_dgt_pack_weights')
     return blob, woff, n_woff.value
+
+
+def pack_split_tape(cfg_struct, state_dict, device=None):
+    """The static weight tape of the OPT-IN split-bf16 pair update (jodo_dgt_pack_split_host; JODO_OPT_SPLIT_BF16): a uint8 tensor
+    (CPU, or uploaded to `device`).  Raises JodoHipError for configurations the split form is not built for (nf != 256, conditional)."""
+    import numpy as np
+    import torch
+    L = lib()
+    keep, arr = [], (JodoTensor * len(state_dict))()
+    for i, (k, v) in enumerate(state_dict.items()):
+        t = np.ascontiguousarray(v.detach().float().cpu().numpy())
+        shp = (ctypes.c_int64 * max(t.ndim, 1))(*t.shape)
+        name = k.encode()
+        keep.append((t, shp, name))
+        arr[i] = JodoTensor(name, t.ctypes.data_as(ctypes.c_void_p), shp, t.ndim)
+    total, per_block = ctypes.c_size_t(), ctypes.c_size_t()
+    check(L.jodo_dgt_split_size(ctypes.byref(cfg_struct), ctypes.byref(total), ctypes.byref(per_block)), 'jodo_dgt_split_size')
+    tape = torch.empty(total.value, dtype=torch.uint8)
+    check(L.jodo_dgt_pack_split_host(ctypes.byref(cfg_struct), arr, len(keep), ctypes.c_void_p(tape.data_ptr()), ctypes.c_size_t(total.value)),
+          'jodo_dgt_pack_split_host')
+    return tape if device is None else tape.to(device)

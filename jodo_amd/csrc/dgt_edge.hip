@@ -1,6 +1,7 @@
 // Edge kernels of a DGT block: launch code + instantiations (see dgt_launch.h for why this is its own translation unit).
 #include "dgt_kernels_attn.h"
 #include "dgt_kernels_wide.h"
+#include "dgt_kernels_split.h"
 #include "dgt_launch.h"
 
 using namespace jd;
@@ -52,7 +53,17 @@ int launch_update_sym(jodo_plan* p, hipStream_t st, KArgs& A) {
     }
     // shared modulation row (device flag): the variant with the folded coord_mlp.0 does the work instead
     // (A.rot: LayerNorm statistics in the rotated basis the node kernels of this forward wrote — decided by the launcher, not a flag)
-    if (run_fold && A.rot) { if (d.r == 2) launch_sym_variant<D, 2, true, true>(st, A, p->n_pitems, zw); else launch_sym_variant<D, 4, true, true>(st, A, p->n_pitems, zw); }
+    // opt-in split-bf16 form (JODO_OPT_SPLIT_BF16; jodo_dgt_forward checked the preconditions and set A.wsplit): four items per workgroup
+    bool split_ran = false;
+    if constexpr (D == 256) {
+        if (run_fold && !run_plain && A.rot == 1 && A.wsplit && A.mfold_s) {
+            const int wgs = (p->n_pitems + 31) / 32 * 8;
+            if (d.r == 2) hipLaunchKernelGGL((split::k_edge_update_sym_split<256, 2>), dim3(wgs), dim3(split::SPLIT_WAVES * 64), 0, st, A);
+            else hipLaunchKernelGGL((split::k_edge_update_sym_split<256, 4>), dim3(wgs), dim3(split::SPLIT_WAVES * 64), 0, st, A);
+            split_ran = true;
+        }
+    }
+    if (run_fold && A.rot && !split_ran) { if (d.r == 2) launch_sym_variant<D, 2, true, true>(st, A, p->n_pitems, zw); else launch_sym_variant<D, 4, true, true>(st, A, p->n_pitems, zw); }
     if (run_fold && !A.rot) { if (d.r == 2) launch_sym_variant<D, 2, true, false>(st, A, p->n_pitems, zw); else launch_sym_variant<D, 4, true, false>(st, A, p->n_pitems, zw); }
     if (run_plain && split) {
         A.item0 = full; A.dir_split = 1;

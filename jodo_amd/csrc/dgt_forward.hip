@@ -53,6 +53,7 @@ void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
     A.ehid = ws_ptr<float>(ws, w.ehid); A.epred = ws_ptr<float>(ws, w.epred);
     A.e_out = ws_ptr<float>(ws, w.e2);
     A.dposE = ws_ptr<float>(ws, w.dposE); A.gramE = ws_ptr<float>(ws, w.gramE);
+    A.wsplit = nullptr; A.mfold_s = nullptr;               // the opt-in split-bf16 pair update: decided per forward (jodo_dgt_forward)
 }
 
 int rowgemm(hipStream_t st, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* Wp, const float* bias,
@@ -260,10 +261,10 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
             F.c0[l] = l < d.L ? woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + JB_C0_W] : 0;
             F.ine[l] = l < d.L ? woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + (A.rot ? JB_INEC_W : JB_INE_W)] : 0;     // rot: centred factor
         }
-        LAUNCH((wide::k_fold_coord<D, D / 16>), d.L * (D / 32) * (d.De / 4), 64, A, F, A.mfold, 0);
+        LAUNCH((wide::k_fold_coord<D, D / 16>), d.L * (D / 32) * (d.De / 4), 64, A, F, A.mfold, 0, A.mfold_s);
         if (A.rot) {                               // F_l = W0 diag(1 + sc_l) Q_l^T: what k_node_ab applies to the rotated rows
             for (int l = 0; l < d.L; ++l) F.ine[l] = woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + JB_QT_W];
-            LAUNCH((wide::k_fold_coord<D, D / 8>), d.L * (D / 32) * (D / 8), 64, A, F, A.ffold, 1);
+            LAUNCH((wide::k_fold_coord<D, D / 8>), d.L * (D / 32) * (D / 8), 64, A, F, A.ffold, 1, (unsigned short*)nullptr);
         }
     }
     pro.reset();
@@ -281,6 +282,8 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
         A.layer = l;
         A.mod_base = 32 + (int64_t)l * d.MB;
         for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + i];
+        // split-bf16 pair update (opt-in; A.mfold_s != NULL says jodo_dgt_forward found its preconditions met): this block's weight tape
+        A.wsplit = A.mfold_s ? reinterpret_cast<const unsigned short*>(static_cast<const char*>(p->split_w) + (size_t)l * (p->split_bytes / d.L)) : nullptr;
         A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
         {
             ProfScope ps(p, st, JODO_PROF_NODE_PRE);
@@ -420,6 +423,16 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     A.pin_uni = p->opt[JODO_OPT_PIN_UNIFORM_T]; A.pre_mode = 0; A.strip0 = 0; A.item0 = 0; A.dir_split = 0; A.rot = 0; A.mix_nw = 0; A.ab0 = 0; A.ab1 = 0; A.g0 = 0; A.g1 = 0; A.fuse_next = 0; A.mod_base_next = 0;
     for (int i = 0; i < 6; ++i) A.wbn[i] = 0;
     fill_ws(A, p, workspace);
+    // JODO_OPT_SPLIT_BF16 (opt-in): the folded pair update in the split-bf16 form.  Only where its preconditions hold — nf 256,
+    // unconditional, both paths pinned (symmetric inputs, shared modulation row: what a sampler pins after its first self-conditioned
+    // evaluation), rotated statistics in their default form, one circulant offset per item, the weight tape handed over — otherwise the
+    // exact-fp32 kernels run as always.
+    if (p->opt[JODO_OPT_SPLIT_BF16] == 1 && p->split_w && d.D == 256 && d.cond_ch == 0 && !p->force_directed && p->n_pitems > 0 && p->pitems_single &&
+        p->opt[JODO_OPT_PIN_SYMMETRIC] == 1 && p->opt[JODO_OPT_PIN_UNIFORM_T] == 1 && p->opt[JODO_OPT_ROT_STATS] == 1) {
+        size_t total = 0, per_block = 0;
+        if (jodo_dgt_split_size(&p->cfg, &total, &per_block) == JODO_OK && total == p->split_bytes)
+            A.mfold_s = ws_ptr<unsigned short>(workspace, p->ws.mfold_s);
+    }
     float* posbuf[2] = {ws_ptr<float>(workspace, p->ws.pos0), ws_ptr<float>(workspace, p->ws.pos1)};
     A.pos_in = posbuf[0]; A.pos_out = posbuf[1];
     A.flags = flags_dev;

@@ -36,6 +36,10 @@ struct KArgs {
     float *e, *ehid, *epred, *dposE, *gramE;
     float* e_out;                         // edge state written by the update kernels (ping-pong with e: never in place,
                                           // two workgroups of a direction-split item read the same input rows)
+    // opt-in split-bf16 pair update (JODO_OPT_SPLIT_BF16, dgt_kernels_split.h): the static weight tape of the current block (NULL = off)
+    // and the split image of the folded coord_mlp.0 matrices of all blocks (k_fold_coord writes it when mfold_s != NULL)
+    const unsigned short* wsplit;
+    unsigned short* mfold_s;
     int* flags;
     unsigned long long* dbgt;             // debug: per-phase cycle sums (builds with -DJODO_PHASE_TIMING only)
     // API tensors

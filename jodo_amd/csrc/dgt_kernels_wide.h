@@ -412,7 +412,7 @@ __global__ __launch_bounds__(64) void k_node_gram(KArgs A) { node_gram_body<D>(A
 // coord_mlp.0 sits at lane (s & 3) + 4 h + 8 (s >> 2) of block o / 32 (o % 32 = 16 h + s), its column j at register
 // m = 16 (j / 32) + j % 16 of half (j % 32) / 16.  One float4 of M per thread, sums in double; 2 x 134 MFLOP per forward.
 template <int D, int KQI>     // KQI = quads per output block of the right-hand factor: 2 KQE ([e ; G] part of input_lin), KQD (Q^T)
-__global__ __launch_bounds__(64) void k_fold_coord(KArgs A, FoldOffs F, float* out, int need_rot) {
+__global__ __launch_bounds__(64) void k_fold_coord(KArgs A, FoldOffs F, float* out, int need_rot, unsigned short* out_s = nullptr) {
     if (!A.flags[FLAG_UNIFORM_T] || (need_rot && !rot_active(A))) return;
     using X = Dim<D>;
     constexpr int PER_L = X::ND * KQI;
@@ -438,7 +438,29 @@ __global__ __launch_bounds__(64) void k_fold_coord(KArgs A, FoldOffs F, float* o
             }
         }
     }
-    reinterpret_cast<float4*>(out)[((size_t)l * PER_L + r) * 64 + lane] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+    const float m4[4] = {(float)a0, (float)a1, (float)a2, (float)a3};
+    reinterpret_cast<float4*>(out)[((size_t)l * PER_L + r) * 64 + lane] = make_float4(m4[0], m4[1], m4[2], m4[3]);
+    if (out_s) {
+        // split image for the opt-in split-bf16 pair update (dgt_split.h): the SAME fp32 matrix as three bf16 terms, hi + mid + lo == m
+        // exactly; quad q holds the f32 k-steps 4q .. 4q + 3 = elements 4 (q & 1) .. + 3 of K16 step q / 2
+        // layout [l][out block][K16 step][term][lane][8]
+        unsigned short t[3][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const __bf16 h = (__bf16)m4[c];
+            const float r1 = m4[c] - (float)h;
+            const __bf16 m = (__bf16)r1;
+            const __bf16 lo = (__bf16)(r1 - (float)m);
+            t[0][c] = __builtin_bit_cast(unsigned short, h); t[1][c] = __builtin_bit_cast(unsigned short, m); t[2][c] = __builtin_bit_cast(unsigned short, lo);
+        }
+        constexpr int NS = KQI / 2;
+        const size_t stepbase = (((size_t)l * X::ND + nb) * NS + (q >> 1)) * 3;
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+            unsigned short* dst = out_s + ((stepbase + term) * 64 + lane) * 8 + 4 * (q & 1);
+            *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)t[term][0] | ((unsigned)t[term][1] << 16), (unsigned)t[term][2] | ((unsigned)t[term][3] << 16));
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

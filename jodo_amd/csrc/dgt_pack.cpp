@@ -521,6 +521,70 @@ extern "C" int jodo_edge_ffn_pack(int De, int mlp_ratio, const float* W3, const 
     return JODO_OK;
 }
 
+// ---- split-bf16 weight TAPE of the pair update (JODO_OPT_SPLIT_BF16; csrc/dgt_kernels_split.h) ----
+// The opt-in split form of k_edge_update_sym (folded, rotated statistics) reads its per-block static weights — edge FFN, readout,
+// the triangular factor L of the rotated statistics — as ONE contiguous run of K16 steps (3 KiB each: hi | mid | lo terms) in exactly
+// the order it consumes them, so that a workgroup can stream it through an LDS ring chunk by chunk:
+//   for every hidden chunk c of 64:  ff_linear3 output blocks 2c, 2c + 1 (De / 16 steps each), then ff_linear4 output blocks
+//                                    0 .. De / 32 - 1, their steps 4c .. 4c + 3 (the chunk's 64 hidden features)
+//   the readout edge_l (De / 16 steps)
+//   L blocks b = NB2 - 1 .. 0, steps 2b .. NSL - 1 each (upper block triangle; shortest block first, as the f32 kernel walks them)
+// The folded coord_mlp.0 matrix follows from the workspace (k_fold_coord writes its split image per forward).
+static int split_tape_steps(const DgtDims& d) {
+    const int NCH = d.r * d.De / 64, NSE = d.De / 16, NE = d.De / 32, NB2 = 2 * NE;
+    int lq = 0;
+    for (int b = 0; b < NB2; ++b) lq += 2 * (NB2 - b);
+    return NCH * (2 * NSE + NE * 4) + NSE + lq;
+}
+
+static int pack_split_tape(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, std::vector<uint16_t>& tape, size_t* block_elems) {
+    DgtDims d;
+    int rc = dgt_dims_from_cfg(cfg, &d);
+    if (rc != JODO_OK) return rc;
+    if (d.D != 256 || d.cond_ch != 0) return jodo_set_error(JODO_ERR_UNSUPPORTED, "split-bf16 pair update: built for nf = 256 unconditional models (got nf %d, cond_ch %d)", d.D, d.cond_ch);
+    const int D = d.D, De = d.De, L = d.L, r = d.r, ce = (2 * De) / L, KIN = 2 * D + 2 * De;
+    Lookup lk;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (!tensors[i].name || !tensors[i].data) return jodo_set_error(JODO_ERR_ARG, "pack_split: tensor %d has a null field", i);
+        std::string nm(tensors[i].name);
+        if (nm.rfind("module.", 0) == 0) nm = nm.substr(7);
+        lk.m[nm] = &tensors[i];
+    }
+    const int NCH = r * De / 64, NSE = De / 16, NE = De / 32, NB2 = 2 * NE, NS4 = r * De / 16, NSL = 2 * De / 16;
+    constexpr size_t STEP = 3 * 64 * 8;                 // uint16 per (block, step)
+    const size_t per_block = (size_t)split_tape_steps(d) * STEP;
+    *block_elems = per_block;
+    tape.clear();
+    tape.reserve(per_block * L);
+    auto slice = [&](const std::vector<uint16_t>& p, int ns, int blk, int s0, int s1) {      // steps [s0, s1) of output block blk
+        const uint16_t* src = p.data() + ((size_t)blk * ns + s0) * STEP;
+        tape.insert(tape.end(), src, src + (size_t)(s1 - s0) * STEP);
+    };
+    for (int l = 0; l < L; ++l) {
+        const std::string b = "e_block_" + std::to_string(l);
+        const float* w3 = lk.get(b + ".ff_linear3.weight", (int64_t)r * De * De);
+        const float* w4 = lk.get(b + ".ff_linear4.weight", (int64_t)De * r * De);
+        const float* wro = lk.get("edge_" + std::to_string(l) + ".weight", (int64_t)ce * De);
+        const float* win = lk.get(b + ".equi_update.input_lin.weight", (int64_t)D * KIN);
+        const float* bin = lk.get(b + ".equi_update.input_lin.bias", D);
+        if (!w3 || !w4 || !wro || !win || !bin) return jodo_set_error(JODO_ERR_ARG, "pack_split: missing or mis-sized tensor '%s'", lk.missing.c_str());
+        const std::vector<uint16_t> p3 = pack_proj_split(w3, De, nat_in(De), nat_out(r * De));
+        const std::vector<uint16_t> p4 = pack_proj_split(w4, (int64_t)r * De, nat_in(r * De), nat_out(De));
+        const std::vector<uint16_t> pro = pack_proj_split(wro, De, nat_in(De), nat_out(32, ce));
+        const RotStats rs = rot_stats(win, bin, D, De);
+        const std::vector<uint16_t> plq = pack_proj_split(rs.lq.data(), 2 * De, cat(nat_in(De), nat_in(De, De)), nat_out(2 * De));
+        for (int c = 0; c < NCH; ++c) {
+            slice(p3, NSE, 2 * c, 0, NSE);
+            slice(p3, NSE, 2 * c + 1, 0, NSE);
+            for (int ob = 0; ob < NE; ++ob) slice(p4, NS4, ob, 4 * c, 4 * c + 4);
+        }
+        slice(pro, NSE, 0, 0, NSE);
+        for (int k = 0; k < NB2; ++k) { const int blk = NB2 - 1 - k; slice(plq, NSL, blk, 2 * blk, NSL); }
+    }
+    if (tape.size() != per_block * L) return jodo_set_error(JODO_ERR_ARG, "pack_split: internal tape size");
+    return JODO_OK;
+}
+
 // debug / gate experiments (csrc/dgt_split.hip): W [n_out, n_in] row-major, natural maps -> the f32 packing (n_out * n_in floats) and
 // the split packing (n_out * n_in * 3 bf16) of the same projection, both into host buffers.
 extern "C" int jodo_debug_pack_split(const float* W, int n_out, int n_in, float* f32_packed_host, void* split_packed_host) {
@@ -534,5 +598,28 @@ extern "C" int jodo_debug_pack_split(const float* W, int n_out, int n_in, float*
         const std::vector<uint16_t> s = pack_proj_split(W, n_in, nat_in(n_in), nat_out(n_out));
         std::memcpy(split_packed_host, s.data(), sizeof(uint16_t) * s.size());
     }
+    return JODO_OK;
+}
+
+// The static weight tape of the opt-in split-bf16 pair update: sizes, then the tape itself into a host buffer (the caller uploads it
+// and hands the device copy to jodo_plan_set_split_weights).
+extern "C" int jodo_dgt_split_size(const jodo_cfg* cfg, size_t* total_bytes, size_t* block_bytes) {
+    if (!cfg || !total_bytes || !block_bytes) return jodo_set_error(JODO_ERR_ARG, "split_size: null argument");
+    DgtDims d;
+    const int rc = dgt_dims_from_cfg(cfg, &d);
+    if (rc != JODO_OK) return rc;
+    if (d.D != 256 || d.cond_ch != 0) return jodo_set_error(JODO_ERR_UNSUPPORTED, "split-bf16 pair update: built for nf = 256 unconditional models (got nf %d, cond_ch %d)", d.D, d.cond_ch);
+    *block_bytes = (size_t)split_tape_steps(d) * 3072;
+    *total_bytes = *block_bytes * d.L;
+    return JODO_OK;
+}
+extern "C" int jodo_dgt_pack_split_host(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, void* host, size_t cap_bytes) {
+    if (!cfg || !tensors || !host) return jodo_set_error(JODO_ERR_ARG, "pack_split: null argument");
+    std::vector<uint16_t> tape;
+    size_t per_block = 0;
+    const int rc = pack_split_tape(cfg, tensors, n_tensors, tape, &per_block);
+    if (rc != JODO_OK) return rc;
+    if (tape.size() * sizeof(uint16_t) > cap_bytes) return jodo_set_error(JODO_ERR_ARG, "pack_split: buffer of %zu bytes, need %zu", cap_bytes, tape.size() * sizeof(uint16_t));
+    std::memcpy(host, tape.data(), tape.size() * sizeof(uint16_t));
     return JODO_OK;
 }

@@ -118,6 +118,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     p->B = B; p->N = N; p->max_blocks = -1; p->last_pos_buf = 0; p->last_e_buf = 0;
     p->opt[JODO_OPT_FUSE_NEXT_QKV] = 1; p->opt[JODO_OPT_DIR_SPLIT] = 1; p->opt[JODO_OPT_NODE_POST_WAVES] = 0; p->opt[JODO_OPT_ATTN_VARIANT] = 0; p->opt[JODO_OPT_HEADS_MIX] = 1; p->opt[JODO_OPT_HALF_ROWS] = 1; p->opt[JODO_OPT_PRE_EMBED] = 1; p->opt[JODO_OPT_AB_PRE] = 1; p->opt[JODO_OPT_Z_SPLIT] = 1;
     p->opt[JODO_OPT_PIN_SYMMETRIC] = 0; p->opt[JODO_OPT_PIN_UNIFORM_T] = 0; p->opt[JODO_OPT_ROT_STATS] = 1; p->opt[JODO_OPT_NODE_MIX] = 1;
+    p->opt[JODO_OPT_SPLIT_BF16] = 0; p->split_w = nullptr; p->split_bytes = 0;
     p->prof_enabled = 0; p->force_directed = 0; p->dbg_timing = nullptr;
 
     // molecules by descending size (stable): neighbouring lanes share n, big work first
@@ -177,6 +178,8 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         for (int q = 0; q < parts; ++q) { pi_strip.push_back(s); pi_t0.push_back(q * chunk); pi_t1.push_back(std::min(dmax, (q + 1) * chunk)); }
     }
     p->n_pitems = (int)pi_strip.size();
+    p->pitems_single = 1;
+    for (size_t i = 0; i < pi_strip.size(); ++i) if (pi_t1[i] - pi_t0[i] != 1) p->pitems_single = 0;
     {   // one pair-update item per workgroup
         const std::vector<int> ord = xcd_order(pi_strip, 1);
         permute(pi_strip, ord); permute(pi_t0, ord); permute(pi_t1, ord);
@@ -402,7 +405,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     w.feat = take(NP * d.ndp * f); w.h = take(NP * d.D * f); w.hhat = take(NP * amax_parts * d.D * f);
     w.astat = take(NP * amax_parts * 32 * f);
     w.q = take(NP * d.QKP * f); w.k = take(NP * d.QKP * f); w.v = take(NP * d.D * f); w.n2e = take(NP * d.De * f);
-    w.wrow = take(NP * d.D * f); w.wcol = take(NP * d.D * f); w.ua = take(NP * d.D * f); w.ub = take(NP * d.D * f); w.rmean = take(NP * 2 * f); w.mfold = take((size_t)d.L * d.D * 2 * d.De * f); w.ffold = take((size_t)d.L * d.D * d.D * f); w.ahid = take(NP * d.KNH * f);
+    w.wrow = take(NP * d.D * f); w.wcol = take(NP * d.D * f); w.ua = take(NP * d.D * f); w.ub = take(NP * d.D * f); w.rmean = take(NP * 2 * f); w.mfold = take((size_t)d.L * d.D * 2 * d.De * f); w.mfold_s = take((size_t)d.L * d.D * 2 * d.De * 6); w.ffold = take((size_t)d.L * d.D * d.D * f); w.ahid = take(NP * d.KNH * f);
     w.apred = take(NP * 32 * f);
     w.eflag = take(R * sizeof(int32_t)); w.e = take(R * d.De * f); w.e2 = take(R * d.De * f);
     w.ehid = take(R * d.KEH * f); w.epred = take(R * 4 * f); w.dposE = take(R * 4 * f); w.gramE = take(R * f);
@@ -546,6 +549,8 @@ extern "C" int jodo_plan_set_option(jodo_plan* p, int option, int value) {
     if (option < 0 || option >= JODO_OPT_COUNT) return jodo_set_error(JODO_ERR_ARG, "plan_set_option: unknown option %d", option);
     if (option == JODO_OPT_NODE_POST_WAVES && value != 0 && value != 1 && value != 2 && value != 4 && value != 12 && value != 14)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: node-post waves per strip must be 0 (auto), 1, 2 or 4");
+    if (option == JODO_OPT_SPLIT_BF16 && value != 0 && value != 1)
+        return jodo_set_error(JODO_ERR_ARG, "plan_set_option: the split-bf16 pair update is a switch (0 or 1), got %d", value);
     if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT || option == JODO_OPT_NODE_MIX || option == JODO_OPT_HEADS_MIX || option == JODO_OPT_HALF_ROWS || option == JODO_OPT_PRE_EMBED || option == JODO_OPT_AB_PRE) && value != 0 && value != 1)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: option %d is a switch (0 or 1), got %d", option, value);
     if (option == JODO_OPT_Z_SPLIT && (value < 0 || value > 2))
@@ -615,6 +620,17 @@ extern "C" int jodo_debug_attn_schedule(const jodo_plan* p, int64_t* o) {
         }
         o[4] = lo; o[5] = hi; o[6] = mi; o[7] = idle;
     }
+    return JODO_OK;
+}
+extern "C" int jodo_plan_set_split_weights(jodo_plan* p, const void* tape_dev, size_t bytes) {
+    if (!p) return jodo_set_error(JODO_ERR_ARG, "null plan");
+    if (tape_dev) {
+        size_t total = 0, per_block = 0;
+        const int rc = jodo_dgt_split_size(&p->cfg, &total, &per_block);
+        if (rc != JODO_OK) return rc;
+        if (bytes != total) return jodo_set_error(JODO_ERR_ARG, "set_split_weights: %zu bytes, this configuration's tape has %zu", bytes, total);
+    }
+    p->split_w = tape_dev; p->split_bytes = tape_dev ? bytes : 0;
     return JODO_OK;
 }
 extern "C" int jodo_debug_set_max_blocks(jodo_plan* p, int mb) {

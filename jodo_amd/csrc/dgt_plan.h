@@ -69,6 +69,7 @@ struct WsLayout {   // byte offsets into the workspace
     size_t hid1, temb, tembs, mods, condh, condh2;
     size_t pos0, pos1, dpos, cpos, feat, h, hhat, astat, q, k, v, n2e, wrow, wcol, ua, ub, rmean, mfold, ffold, ahid, apred;
     size_t eflag, e, e2, ehid, epred, dposE, gramE;
+    size_t mfold_s;                  // split-bf16 image of mfold (JODO_OPT_SPLIT_BF16): [L][D / 32][2 De / 16][3][64][8] bf16
     size_t total;
 };
 
@@ -97,6 +98,9 @@ struct jodo_plan {
     int last_pos_buf;                // debug: which pos buffer holds the latest positions
     int last_e_buf;                  // debug: which edge-state buffer holds the latest state
     int opt[JODO_OPT_COUNT];         // jodo_plan_set_option values
+    const void* split_w;             // jodo_plan_set_split_weights: device tape of the split-bf16 pair update (caller-owned) and its size
+    size_t split_bytes;
+    int pitems_single;               // every pair-update item is exactly one circulant offset (what the split kernel's lock-step workgroups need)
     int gt_cache_full, gt_cache_count;   // Gram tiles whose strips all lie below gt_cache_full (tiles are sorted by their larger strip)
 };
 

@@ -167,6 +167,13 @@ class _DGTBase(nn.Module):
         self.register_load_state_dict_post_hook(_drop_packed_after_load)
         self.last_flags = None        # device int32[8] of the last call (NaN guard etc.)
         self.warn_nan = True
+        # OPT-IN (default off): under pinned paths (pin_paths: what the samplers do after a round's first self-conditioned evaluation)
+        # the folded pair update runs its projections in the split-bf16 form — three bf16 terms per operand, six bf16 MFMAs per K = 16
+        # step, fp32 accumulation: fp32-equivalent arithmetic, not bit-identical to the default (csrc/dgt_kernels_split.h,
+        # JODO_OPT_SPLIT_BF16).  nf 256 unconditional models only; ignored elsewhere.  The default path and every headline number
+        # stay exact fp32.
+        self.split_bf16 = False
+        self._split_tape = None       # (weights key, device uint8 tensor): the split form's static weight tape
 
     # -- C structs ---------------------------------------------------------------------------
     class _Cfg(ctypes.Structure):
@@ -505,6 +512,18 @@ class _DGTBase(nn.Module):
             capi.check(L.jodo_plan_set_option(plan['handle'], 4, 2 if f[4] else 1), 'jodo_plan_set_option')
             capi.check(L.jodo_plan_set_option(plan['handle'], 5, 1 if f[2] else 2), 'jodo_plan_set_option')
             plan['pinned'] = True
+            if self.split_bf16 and self.dims.D == 256 and not self.conditional and not f[4] and f[2]:
+                tape = self._split_weights(plan['ws'].device)
+                capi.check(L.jodo_plan_set_split_weights(plan['handle'], capi.ptr(tape), ctypes.c_size_t(tape.numel())), 'jodo_plan_set_split_weights')
+                capi.check(L.jodo_plan_set_option(plan['handle'], 13, 1), 'jodo_plan_set_option')
+                plan['split_tape'] = tape                     # keeps the device copy alive as long as the plan may use it
+
+    def _split_weights(self, device):
+        """Device copy of the split-bf16 weight tape of the current parameters (re-packed when the packed blob is)."""
+        key = self._weights(device)[0]
+        if self._split_tape is None or self._split_tape[0] != key:
+            self._split_tape = (key, capi.pack_split_tape(self._cfg(), self.state_dict(), device))
+        return self._split_tape[1]
 
     def unpin_paths(self):
         """End of the scope of pin_paths(): every cached plan goes back to launching all kernel variants and letting the device
@@ -516,6 +535,7 @@ class _DGTBase(nn.Module):
             if plan.get('pinned'):
                 capi.check(L.jodo_plan_set_option(plan['handle'], 4, 0), 'jodo_plan_set_option')
                 capi.check(L.jodo_plan_set_option(plan['handle'], 5, 0), 'jodo_plan_set_option')
+                capi.check(L.jodo_plan_set_option(plan['handle'], 13, 0), 'jodo_plan_set_option')
                 plan['pinned'] = False
 
     # -- measurement plumbing (bench.py): HIP-event class timers and the executed-work model of the last call's plan(s) --

@@ -12,7 +12,7 @@ import torch
 from oracle import dgt_oracle as O
 
 from helpers import (check_decodes, close64, debug_fetch, load_fixture, make_config, make_model, masks, oracle_32_64, random_inputs,
-                     reference_blocks_dense, state_dict_cpu, K64, K64_HARD, k64_for)
+                     reference_blocks_dense, state_dict_cpu, K64, K64_HARD, K64_ROT_BIG, k64_for)
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -227,8 +227,9 @@ def test_rotated_statistics_match_plain_fold_and_oracle(cfg_name, n_nodes, gain,
             r2 = oracle_32_64(sd, hp, xh, nm, em, ex, r1[0][0], r1[0][1], nl)
         outs[rot] = (o1, run(model, xh, ex, nl, nm, em, r1[0][0], r1[0][1]))     # self-conditioned on the oracle's prediction: same inputs
         for step, got, (r32, r64) in ((1, outs[rot][0], r1), (2, outs[rot][1], r2)):
-            close64(got[0], r32[0], r64[0], 'rot %d step %d nodes' % (rot, step), k=k64_for(hp, n_nodes))
-            close64(got[1], r32[1], r64[1], 'rot %d step %d edges' % (rot, step), k=k64_for(hp, n_nodes))
+            kk = K64_ROT_BIG if max(n_nodes) > 128 else k64_for(hp, n_nodes)       # helpers.py: the one named exception (n = 150 at gain 1.5)
+            close64(got[0], r32[0], r64[0], 'rot %d step %d nodes' % (rot, step), k=kk)
+            close64(got[1], r32[1], r64[1], 'rot %d step %d edges' % (rot, step), k=kk)
     e32 = max(float((r1[0][k].double() - r1[1][k]).abs().max()) for k in (0, 1))
     for k in (0, 1):
         close(outs[1][k][0], outs[0][k][0], atol=max(4e-5, 8 * e32), rtol=2e-4)

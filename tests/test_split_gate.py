@@ -58,3 +58,99 @@ def test_split_projection_is_as_good_as_the_fp32_chain(rows):
         err[mode] = float((y.cpu().double() - y64).abs().max())
     assert err[0] < 5e-6                                          # the product form: a K = 256 fp32 fma chain
     assert err[1] <= 2.0 * err[0] and err[2] <= 2.0 * err[0], err
+
+
+def test_split_tape_is_the_consumption_order_of_the_pair_update():
+    """jodo_dgt_pack_split_host: per block [for every hidden chunk c: ff_linear3 output blocks 2c, 2c + 1 | ff_linear4 output blocks, steps
+    4c .. 4c + 3] [readout] [L blocks, shortest first] as K16 steps of 3 KiB — checked slice by slice against the generic split packing
+    of the same matrices (jodo_debug_pack_split, natural maps)."""
+    from jodo_amd import configs
+    from jodo_amd.models import get_model_class, deterministic_init_
+    cfg = configs.get('vpsde_qm9_uncond_jodo')
+    model = deterministic_init_(get_model_class('DGT_concat')(cfg), seed=3)
+    sd = model.state_dict()
+    tape = capi.pack_split_tape(model._cfg(), sd).numpy().view(np.uint16)
+    De, r, L = 64, cfg.model.mlp_ratio, cfg.model.n_layers
+    STEP = 3 * 64 * 8
+    NCH, NSE, NE, NB2 = r * De // 64, De // 16, De // 32, 2 * (De // 32)
+    steps = NCH * (2 * NSE + NE * 4) + NSE + sum(2 * (NB2 - b) for b in range(NB2))
+    assert tape.size == L * steps * STEP and steps == 56
+    for l in (0, L - 1):
+        blk = tape[l * steps * STEP:(l + 1) * steps * STEP].reshape(steps, STEP)
+        _, s3 = _pack(sd['e_block_%d.ff_linear3.weight' % l].numpy())
+        _, s4 = _pack(sd['e_block_%d.ff_linear4.weight' % l].numpy())
+        s3 = s3.reshape(r * De // 32, NSE, STEP)
+        s4 = s4.reshape(NE, r * De // 16, STEP)
+        at = 0
+        for c in range(NCH):
+            for b2 in range(2):
+                assert np.array_equal(blk[at:at + NSE], s3[2 * c + b2]); at += NSE
+            for ob in range(NE):
+                assert np.array_equal(blk[at:at + 4], s4[ob, 4 * c:4 * c + 4]); at += 4
+        # readout: edge_l [2 De / L = 16, De], rows padded to one 32-row block
+        wro = np.zeros((32, De), dtype=np.float32)
+        w = sd['edge_%d.weight' % l].numpy()
+        wro[:w.shape[0]] = w
+        _, sro = _pack(wro)
+        assert np.array_equal(blk[at:at + NSE], sro.reshape(1, NSE, STEP)[0]); at += NSE
+        assert steps - at == 20                                   # L: 2 + 4 + 6 + 8 steps
+    # configurations the split form is not built for are refused by name
+    cfg384 = configs.get('vpsde_geom_uncond_jodo')
+    cfg384.model.nf = 384
+    with pytest.raises(capi.JodoHipError, match='nf = 256'):
+        capi.pack_split_tape(get_model_class('DGT_concat')(cfg384)._cfg(), {})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name,n_nodes,over", [
+    ('vpsde_qm9_uncond_jodo', [3, 9, 17, 29, 12, 5, 1, 2, 28, 29, 29, 18, 7] * 3, {}),                 # r = 2, several strips, idle waves
+    ('vpsde_geom_uncond_jodo', [44, 45, 7, 70, 33], {}),                                                # r = 4, L = 10
+])
+def test_split_bf16_pair_update_against_the_default_path_and_float64(cfg_name, n_nodes, over):
+    """JODO_OPT_SPLIT_BF16 (opt-in, model.split_bf16 = True; takes effect under pin_paths): the folded pair update with split-bf16
+    projections.  (a) it really runs (outputs differ from the exact-fp32 path in the last bits), (b) it stays within a small multiple of
+    fp32 rounding of the default path, (c) it is held to the float64 oracle at the SAME stated tolerance / K64 as the default path,
+    first-step and self-conditioned evaluation."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import K64, close64, make_config, make_model, oracle_32_64, random_inputs, state_dict_cpu
+    from oracle import dgt_oracle as O
+    DEV = 'cuda:0'
+    cfg = make_config(cfg_name, **over)
+    hp = O.Hyper.from_config(cfg)
+    xh, ex, nl, ctx, nm, em = random_inputs(hp, n_nodes, seed=23)
+    nl = torch.full_like(nl, 0.3)                              # one noise level: the shared modulation row of sampling
+    d = lambda x: None if x is None else x.to(DEV)
+    nmd, emd = d(nm), d(em)
+
+    def run(model, cx, cex):
+        with torch.no_grad():
+            o = model(d(nl), d(xh), nmd, emd, edge_x=d(ex), cond_x=d(cx), cond_edge_x=d(cex), noise_level=d(nl))
+        torch.cuda.synchronize()
+        return o[0].cpu(), o[1].cpu()
+
+    outs = {}
+    for split in (False, True):
+        model = make_model(cfg, 13, DEV)
+        model.split_bf16 = split
+        first = run(model, None, None)
+        run(model, first[0], first[1])
+        model.pin_paths()                                      # what a sampler does after its first self-conditioned evaluation
+        assert model._last_plan.get('pinned') and (('split_tape' in model._last_plan) == split)
+        o2 = run(model, first[0], first[1])
+        o1 = run(model, None, None)
+        assert model.take_nan_count() == 0
+        outs[split] = (o1, o2)
+        if not split:
+            sd = state_dict_cpu(model)
+    for k in (0, 1):
+        for j in (0, 1):
+            a, b = outs[True][k][j], outs[False][k][j]
+            assert not torch.equal(a, b), "the split kernel did not run"
+            assert float((a - b).abs().max()) <= 2e-5 + 1e-4 * float(b.abs().max()), float((a - b).abs().max())
+    r1 = oracle_32_64(sd, hp, xh, nm, em, ex, None, None, nl)
+    r2 = oracle_32_64(sd, hp, xh, nm, em, ex, outs[False][0][0], outs[False][0][1], nl)
+    for step, (r32, r64) in ((0, r1), (1, r2)):
+        for split in (False, True):
+            close64(outs[split][step][0], r32[0], r64[0], 'split_bf16=%s step %d nodes' % (split, step + 1), k=K64)
+            close64(outs[split][step][1], r32[1], r64[1], 'split_bf16=%s step %d edges' % (split, step + 1), k=K64)
