@@ -30,6 +30,8 @@ The JSON line also carries
                 three edge kernels with GB/s against the 8 TB/s peak; null when no committed pass matches
                 this workload
   steady_state  >= 100 timed steps (when --steps is smaller) — the per-step figure SURVEY.md §8d asks for
+  split_bf16_opt_in   the same step with the OPT-IN split-bf16 pair update (JODO_OPT_SPLIT_BF16; its own dtype label); never the
+                headline: `value`, `dtype` and `roofline` above are the exact-fp32 default path
   full_round    one complete 1000-step round through the public entry points (get_sampling_fn -> sampler
                 -> device decode -> host tuples), wall clock: the end-to-end molecules/s, not extrapolated
   cpu_baseline  BASELINE config 1 in full (QM9, batch 64, 50 ancestral steps) with the port of the
@@ -452,6 +454,38 @@ def main():
             steady = {'steps': 100, 'ms_per_step': (time.perf_counter() - ts0) * 10.0}
         steady['value'] = B / (SAMPLING_STEPS * steady['ms_per_step'] * 1e-3)
         steady['unit'] = 'molecules/s'
+    # ---- OPT-IN split-bf16 pair update (JODO_OPT_SPLIT_BF16), reported under its own key with its own dtype label: the headline above
+    # and every roofline figure are the exact-fp32 default.  nf 256 unconditional workloads only; 50 steps with the pair-update class
+    # bracketed.  Parity of this path: tests/test_split_gate.py (same stated tolerance / K64 as the default).
+    split_info = None
+    if not args.graph and world == 1 and dims.D == 256 and not dims.cond_ch and not args.no_pin:
+        try:
+            with torch.no_grad():
+                model.unpin_paths()
+                model.split_bf16 = True
+                model.pin_paths()                          # (re-pins the last call's plan; hands the weight tape over)
+                i0 = args.warmup + args.steps + (100 if steady is not None else 0)
+                for i in range(i0, i0 + 3):
+                    st = sampler.step(model, i, st, node_mask, edge_mask, context)
+                model.profile_enable(16 + 6)
+                torch.cuda.synchronize()
+                tsp = time.perf_counter()
+                for i in range(i0 + 3, i0 + 53):
+                    st = sampler.step(model, i, st, node_mask, edge_mask, context)
+                torch.cuda.synchronize()
+                tsp = (time.perf_counter() - tsp) / 50
+                sms, scnt = model.profile_read()
+                model.profile_enable(0)
+            split_info = {'dtype': 'bf16x3 (three-term split operands, fp32 accumulate: fp32-equivalent, not bit-identical)',
+                          'scope': 'pair update only (k_edge_update_sym_split); every other kernel exact fp32',
+                          'ms_per_step': tsp * 1e3, 'value': B / (SAMPLING_STEPS * tsp), 'unit': 'molecules/s',
+                          'pair_update_avg_launch_ms': (sms[6] / scnt[6]) if scnt[6] else None, 'launches': scnt[6],
+                          'nan_guard': bool(model.nan_guard_fired())}
+        except Exception as exc:                           # the extra must never take the headline down with it
+            split_info = {'error': repr(exc)}
+        finally:
+            model.split_bf16 = False
+            model.unpin_paths()
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -647,6 +681,10 @@ def main():
                                  'same command (`hbm.source`), not from this run.  reference_formulation_ratio = the SURVEY.md 8d count '
                                  '(reference formulation: per directed edge, no pair symmetry, coord_mlp.0 per edge) / time / peak: an '
                                  'algorithmic speed-up figure, > 1 is not a hardware fraction',
+                         'selection_rule': 'the larger of the attention (2) and pair-update (6) classes over the warm-up steps: under pinned paths '
+                                           'each is ONE dispatch per block, i.e. the single kernel a profiler ranks first; the node class (three '
+                                           'dispatches per block) can lead the class table and is reported as dominant_class (rounds 1-4 put the '
+                                           'leading CLASS here: not comparable across that change)',
                          'avg_launch_ms': dom_ms, 'launches': dom_n,
                          'executed_mfma_flops_per_launch': mfma_launch,
                          'mfma_frac': achieved / PEAK_FP32_MFMA,
@@ -665,6 +703,7 @@ def main():
             'kernel_ms': {k: round(v[0] * (v[1] / args.steps), 4) for k, v in per_class.items() if v[1] > 0},
             'hip_graph_replay': graph_info,
             'steady_state': steady,
+            'split_bf16_opt_in': split_info,
             'full_round': full_round,
             'sharded_round': sharded,
             'dpm_round': dpm_round,

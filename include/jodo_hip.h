@@ -311,28 +311,6 @@ int jodo_decode(int B, int N, int atom_types, int include_fc, int edge_ch, int c
                 const float* xh, const float* edge_x, float* pos_out, uint8_t* atom_type_out, int8_t* fc_out,
                 uint8_t* edge_type_out, void* stream);
 
-/* ---- training side, first slice ------------------------------------------------------------------
- * jodo_edge_ffn_backward  <- the autograd of loss.backward() (losses.py:286-385) through phase D of EquivariantMixBlock.forward,
- *                            models/mol_gnn.py:313-317:  x1 = e_in + eg1 ehat;  xn = LN(x1)(1 + ec2) + es2;
- *                            e_out = xn + eg2 (W4 SiLU(W3 xn + b3) + b4)   (ehat = node2edge_lin(h_attn_i + h_attn_j)).
- *   rows edge rows [rows, De] (e_in, ehat, d_out = d loss / d e_out; outputs d_e_in, d_ehat); mods [n_mod_rows, 6 De] = the six
- *   chunks of edge_time_mlp (es1 ec1 eg1 es2 ec2 eg2, mol_gnn.py:289-290) per modulation row (= per molecule in training, losses.py:313);
- *   row_mod [rows] modulation row of an edge row, mod_off [n_mod_rows + 1] its contiguous row range; packed_w / woff4 from
- *   jodo_edge_ffn_pack (W3 = ff_linear3.weight [r De, De], W4 = ff_linear4.weight [De, r De]); b3, b4 plain biases.
- *   Outputs (all fully written): d_e_in, d_ehat [rows, De]; d_mods [n_mod_rows, 6 De] (chunks es1, ec1 = 0); dW3 [r De, De],
- *   db3 [r De], dW4 [De, r De], db4 [De] in PyTorch layout.  Activations are recomputed, not saved; sums run in a fixed order
- *   (bit-deterministic).  This slice is built for De = 64, mlp_ratio = 2 (the QM9 configs); other shapes -> JODO_ERR_UNSUPPORTED.
- *   workspace: jodo_edge_ffn_backward_workspace(rows, De, mlp_ratio) bytes of device scratch. */
-size_t jodo_edge_ffn_pack_size(int De, int mlp_ratio);
-int jodo_edge_ffn_pack(int De, int mlp_ratio, const float* W3_host, const float* W4_host, float* packed_host, size_t cap_floats,
-                       int64_t* offs4);
-size_t jodo_edge_ffn_backward_workspace(int rows, int De, int mlp_ratio);
-int jodo_edge_ffn_backward(int rows, int De, int mlp_ratio, int n_mod_rows, const float* e_in, const float* ehat,
-                           const int32_t* row_mod, const int32_t* mod_off, const float* mods, const float* packed_w,
-                           const int64_t* woff4, const float* b3, const float* b4, const float* d_out, float* d_e_in,
-                           float* d_ehat, float* d_mods, float* dW3, float* db3, float* dW4, float* db4, void* workspace,
-                           void* stream);
-
 /* ---- training step: the whole network ------------------------------------------------------------------
  * jodo_train_forward   <- the grad-enabled model call of get_sde_graph_loss_fn, losses.py:335-343 (DGT_concat.forward /
  *                         Cond_DGT_concat.forward under model.train(): dropout in the four FFN positions, mol_gnn.py:262-268; NOT on the
@@ -381,6 +359,9 @@ int jodo_train_forward(jodo_train* t, const void* desc_dev, const float* const* 
                        const float* edge_x, const float* cond_x, const float* cond_edge_x, const float* noise_level,
                        const float* context, float dropout_p, uint64_t seed, float* out_xh, float* out_edge, int32_t* flags_out,
                        void* workspace, void* stream);
+/* jodo_train_backward writes (not accumulates) every gradient: the grads_dev buffers are zeroed first, and where two of them lie less
+ * than 16 bytes apart (sub-allocations of one buffer with 16-byte aligned slices, jodo_amd/optim.py slice_offsets) the bytes BETWEEN them
+ * are zeroed as well — do not keep live data in such a gap. */
 int jodo_train_backward(jodo_train* t, const void* desc_dev, const float* const* params_dev, float* const* grads_dev, int n_params,
                         const float* noise_level, const float* d_out_xh, const float* d_out_edge, float dropout_p, uint64_t seed,
                         void* workspace, void* stream);

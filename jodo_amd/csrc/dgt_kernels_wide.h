@@ -14,6 +14,9 @@
 #pragma once
 #include "dgt_kernels_common.h"
 #include "dgt_kernels_attn.h"
+#ifndef JODO_X_UPD_EARLY
+#define JODO_X_UPD_EARLY 0        // experiment switch of the pair update's item top (see k_edge_update_sym)
+#endif
 
 namespace jd {
 namespace wide {
@@ -674,11 +677,23 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
     // global memory each read was an exposed L1 round trip between two MFMA blocks, from LDS it is a short ds_read
     __shared__ float4 w2s[HOIST ? 3 * D / 4 : 1];
     __shared__ float zred[ZW > 1 ? (ZW - 1) * 12 * 64 : 1];     // partial coord_mlp.2 dot products of waves 1 .. ZW - 1
+#if (JODO_X_UPD_EARLY & 2)
+    // experiment (round 6, cycle budget of profiles/r06_cycle_budget.txt: the item's top holds 10.9 k of its 24.6 k waiting cycles):
+    // coord_mlp.2 is requested here and parked in LDS only when the first tail is near — nothing waits for it at the top
+    constexpr int W2N = (3 * D / 4 + ZW * 64 - 1) / (ZW * 64);
+    float4 w2r[HOIST ? W2N : 1];
+    if constexpr (HOIST) {
+        const float4* src = reinterpret_cast<const float4*>(A.W + A.wb[JB_C2_W]);
+#pragma unroll
+        for (int i = 0; i < W2N; ++i) { const int k = (int)threadIdx.x + i * ZW * 64; w2r[i] = src[k < 3 * D / 4 ? k : 0]; }
+    }
+#else
     if constexpr (HOIST) {
         const float4* src = reinterpret_cast<const float4*>(A.W + A.wb[JB_C2_W]);
         for (int i = threadIdx.x; i < 3 * D / 4; i += ZW * 64) w2s[i] = src[i];
         __syncthreads();
     }
+#endif
     // (Tried and dropped: the trunk's other item-invariant vectors — modulation chunks, biases, Gaussian table, 3 KiB — from an
     // LDS page as well: pair update 6.18 -> 6.77 ms/step at QM9 B = 2500, 55.3 -> 58.3 at nf = 384.  Their global loads are
     // requested far ahead and overlap; the ds_reads wait in order behind each other.)
@@ -696,7 +711,40 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
         const float* bro_ = cst + A.wb[JB_ERO_B];
         const BRow wrow_i = brow(A.wrow, X::ND, L.v, half), wcol_i = brow(A.wcol, X::ND, L.v, half);
         const BRow wrow_j = brow(A.wrow, X::ND, P.u, half), wcol_j = brow(A.wcol, X::ND, P.u, half);
+#if (JODO_X_UPD_EARLY & 1)
+        // the partner's position first, then the pair's edge row and the two node2edge rows: all requested NOW through buffer
+        // descriptors (ordered by the fence; plain global loads are sunk to their use), consumed behind the Gaussian basis
+        const __amdgpu_buffer_rsrc_t rpos = __builtin_amdgcn_make_buffer_rsrc(A.pos_out, 0, 0x7fffffff, 0x00020000);
+        const u32x4 pur = __builtin_amdgcn_raw_buffer_load_b128(rpos, (unsigned)P.u * 16u, 0, 0);
+        // edge rows of a strip's molecules lie within a few hundred MB of the strip's first molecule: descriptor at that row, 32-bit offsets
+        const int eoff0 = __builtin_amdgcn_readfirstlane(L.eoff);
+        const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(A.e + (size_t)eoff0 * X::De, 0, 0x7fffffff, 0x00020000);
+        const unsigned evoff = (unsigned)(((P.rij - (size_t)eoff0) * X::De + half * 16) * 4);
+        float er[X::HE], tar[X::HE], tcr[X::HE];
+        {
+            const BRow ra = brow(A.n2e, X::NE, L.v, half), rc = brow(A.n2e, X::NE, P.u, half);
+#pragma unroll
+            for (int b = 0; b < X::NE; ++b) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(re, evoff, (unsigned)(b * 128 + q * 16), 0);
+                    er[b * 16 + q * 4 + 0] = __uint_as_float(v.x); er[b * 16 + q * 4 + 1] = __uint_as_float(v.y);
+                    er[b * 16 + q * 4 + 2] = __uint_as_float(v.z); er[b * 16 + q * 4 + 3] = __uint_as_float(v.w);
+                }
+                float t16[16];
+                bload16(ra, b, t16);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) tar[b * 16 + s] = t16[s];
+                bload16(rc, b, t16);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) tcr[b * 16 + s] = t16[s];
+            }
+        }
+        pipeline_fence();
+        const float4 pu = make_float4(__uint_as_float(pur.x), __uint_as_float(pur.y), __uint_as_float(pur.z), __uint_as_float(pur.w));
+#else
         const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[P.u];
+#endif
         const float dx = pv.x - pu.x, dy = pv.y - pu.y, dz = pv.z - pu.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
         float G[X::HE];
@@ -704,13 +752,20 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
         // ---- edge residual + LN2 + modulate (symmetric) ----
         float en[X::HE];
         {
+#if !(JODO_X_UPD_EARLY & 1)
             const TRow ra = trow(A.n2e, X::NE, L.v, half), rc = trow(A.n2e, X::NE, P.u, half);
+#endif
 #pragma unroll
             for (int b = 0; b < X::NE; ++b) {
                 float e[16], ta[16], tc2[16], g[16], bb[16];
+#if (JODO_X_UPD_EARLY & 1)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) { e[s] = er[b * 16 + s]; ta[s] = tar[b * 16 + s]; tc2[s] = tcr[b * 16 + s]; }
+#else
                 load16(A.e + P.rij * X::De + b * 32 + half * 16, e);
                 load16T(ra, b, ta);
                 load16T(rc, b, tc2);
+#endif
                 load16(eg1_ + b * 32 + half * 16, g);
                 load16(n2bias_ + b * 32 + half * 16, bb);
 #pragma unroll
@@ -792,6 +847,15 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
             }
         }
         PT(2);
+#if (JODO_X_UPD_EARLY & 2)
+        if constexpr (HOIST) {
+            if (t == t0) {
+#pragma unroll
+                for (int i = 0; i < W2N; ++i) { const int k = (int)threadIdx.x + i * ZW * 64; if (k < 3 * D / 4) w2s[k] = w2r[i]; }
+                __syncthreads();
+            }
+        }
+#endif
         if constexpr (HOIST) {
             // ---- coord_mlp.0 pushed through the LayerNorm: ONE D x D projection per pair instead of one per direction ----
             // u = LN(pre) (1 + sc) + sh with pre = S + R_a + C_c (R = W_row h + b, C = W_col h) is affine in pre once its

@@ -499,28 +499,6 @@ extern "C" int jodo_dgt_pack_weights(const jodo_cfg* cfg, const jodo_tensor* ten
 }
 
 
-// ---- training slice (csrc/train_kernels.hip): the four natural-order projections of an edge FFN --------------------------------
-// W3 = ff_linear3.weight [r De, De], W4 = ff_linear4.weight [De, r De] (PyTorch [out, in], host pointers) ->
-// packed | W3 | W4 | W4^T | W3^T |, offsets (floats) in offs4.  The transposes feed dX = W^T dY on the same MFMA orientation.
-extern "C" size_t jodo_edge_ffn_pack_size(int De, int mlp_ratio) { return (size_t)4 * De * De * mlp_ratio + 4 * 64; }
-extern "C" int jodo_edge_ffn_pack(int De, int mlp_ratio, const float* W3, const float* W4, float* packed_host, size_t cap_floats,
-                                  int64_t* offs4) {
-    if (De <= 0 || De % 32 || mlp_ratio <= 0 || !W3 || !W4 || !packed_host || !offs4) return jodo_set_error(JODO_ERR_ARG, "edge_ffn_pack: bad argument");
-    const int H = De * mlp_ratio;
-    std::vector<float> w4t((size_t)H * De), w3t((size_t)De * H);
-    for (int i = 0; i < De; ++i) for (int k = 0; k < H; ++k) w4t[(size_t)k * De + i] = W4[(size_t)i * H + k];
-    for (int k = 0; k < H; ++k) for (int i = 0; i < De; ++i) w3t[(size_t)i * H + k] = W3[(size_t)k * De + i];
-    Packer P;
-    P.put_proj(W3, De, nat_in(De), nat_out(H));
-    P.put_proj(W4, H, nat_in(H), nat_out(De));
-    P.put_proj(w4t.data(), De, nat_in(De), nat_out(H));
-    P.put_proj(w3t.data(), H, nat_in(H), nat_out(De));
-    if (P.blob.size() > cap_floats) return jodo_set_error(JODO_ERR_ARG, "edge_ffn_pack: buffer of %zu floats, need %zu", cap_floats, P.blob.size());
-    std::memcpy(packed_host, P.blob.data(), P.blob.size() * sizeof(float));
-    for (int i = 0; i < 4; ++i) offs4[i] = P.offs[i];
-    return JODO_OK;
-}
-
 // ---- split-bf16 weight TAPE of the pair update (JODO_OPT_SPLIT_BF16; csrc/dgt_kernels_split.h) ----
 // The opt-in split form of k_edge_update_sym (folded, rotated statistics) reads its per-block static weights — edge FFN, readout,
 // the triangular factor L of the rotated statistics — as ONE contiguous run of K16 steps (3 KiB each: hi | mid | lo terms) in exactly

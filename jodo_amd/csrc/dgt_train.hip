@@ -616,8 +616,10 @@ void backward(const Ctx& c, const float* nl, const float* d_out_xh, const float*
         char* beg = reinterpret_cast<char*>(c.g(i));
         size_t bytes = t.numel[i] * 4;
         int j = i + 1;
-        // (adjacent, or behind an alignment gap of a few floats — jodo_amd/optim.py slice_offsets — which is filled along)
-        while (j < t.n_params && reinterpret_cast<char*>(c.g(j)) >= beg + bytes && reinterpret_cast<char*>(c.g(j)) - (beg + bytes) < 64) {
+        // (adjacent, or behind the alignment padding of jodo_amd/optim.py slice_offsets — slices start on 16-byte boundaries, so a gap
+        // is under 16 bytes — which is filled along: the norm of the whole flat buffer is taken, padding included.  Contract stated in
+        // include/jodo_hip.h at jodo_train_backward: bytes between two gradient buffers less than 16 bytes apart are zeroed too)
+        while (j < t.n_params && reinterpret_cast<char*>(c.g(j)) >= beg + bytes && reinterpret_cast<char*>(c.g(j)) - (beg + bytes) < 16) {
             bytes = (size_t)(reinterpret_cast<char*>(c.g(j)) - beg) + t.numel[j] * 4;
             ++j;
         }

@@ -81,13 +81,24 @@ def flatten_parameters(params):
     return flat
 
 
-def _cheap_flat(t0, t1, total):
-    """first / last slice and the storage's size: the per-step form of flat_view (the slices in between come from the same loop)"""
-    if t0 is None or t1 is None or t0.dtype != torch.float32:
+def _ptr_flat(tensors, total):
+    """Per-step form of flat_view: EVERY tensor must sit at its slice of one allocation (address compare per tensor: a few hundred
+    integer compares, no device work, no synchronisation).  Round 5 compared only the first and the last slice; a middle gradient
+    replaced by a separate tensor (a hook, `p.grad = ...`, partial accumulation) then went unnoticed and the kernel read stale bytes
+    of the old flat buffer (round-5 advisor finding)."""
+    t0 = tensors[0]
+    if t0 is None or t0.dtype != torch.float32:
         return None
     store = t0.untyped_storage()
-    end = (t1.storage_offset() + t1.numel() + ALIGN - 1) // ALIGN * ALIGN
-    if store.nbytes() != 4 * total or t0.storage_offset() != 0 or t1.untyped_storage().data_ptr() != store.data_ptr() or end != total:
+    base = store.data_ptr()
+    if store.nbytes() != 4 * total or t0.storage_offset() != 0:
+        return None
+    at = 0
+    for t in tensors:
+        if t is None or t.dtype != torch.float32 or t.data_ptr() != base + 4 * at or not t.is_contiguous():
+            return None
+        at = (at + t.numel() + ALIGN - 1) // ALIGN * ALIGN
+    if at != total:
         return None
     return torch.empty(0, dtype=torch.float32, device=t0.device).set_(store, 0, (total,))
 
@@ -97,10 +108,10 @@ def flat_total(params):
 
 
 def flat_parameters(params, total=None):
-    """The flat buffer `params` (a list) are slices of, or None (cheap check: see _cheap_flat)."""
+    """The flat buffer `params` (a list) are slices of, or None (address check of every parameter: see _ptr_flat)."""
     if not params[0].is_cuda:
         return None
-    return _cheap_flat(params[0].data, params[-1].data, flat_total(params) if total is None else total)
+    return _ptr_flat([p.data for p in params], flat_total(params) if total is None else total)
 
 
 def flat_gradient(params, total=None, full_check=False):
@@ -109,7 +120,7 @@ def flat_gradient(params, total=None, full_check=False):
     if total is None:
         total = flat_total(params)
     if not full_check:
-        base = _cheap_flat(params[0].grad, params[-1].grad, total)
+        base = _ptr_flat([p.grad for p in params], total)
         if base is not None:
             return base
     return flat_view([p.grad for p in params])
@@ -202,22 +213,50 @@ class FlatAdam(torch.optim.Optimizer):
             torch.autograd.graph.increment_version(touched)
         return loss
 
+    _HYPER = ('lr', 'betas', 'eps', 'weight_decay', 'amsgrad', 'decoupled')
+
     def load_state_dict(self, state_dict):
-        """Values go INTO the flat moment buffers (torch's loader would replace the per-parameter views by separate tensors)."""
+        """Values go INTO the flat moment buffers (torch's loader would replace the per-parameter views by separate tensors).  Accepts
+        this class's own state_dict and a torch.optim.Adam / AdamW one of the same parameter list (the reference's checkpoints,
+        utils.py:7-20): one parameter group over exactly these parameters, state for all of them or for none; only the
+        hyper-parameters this optimiser implements are taken, `maximize` is refused."""
+        groups = state_dict['param_groups']
+        if len(groups) != 1:
+            raise ValueError("FlatAdam.load_state_dict: %d parameter groups, this optimiser has one" % len(groups))
+        if len(groups[0].get('params', ())) != len(self._params):
+            raise ValueError("FlatAdam.load_state_dict: the saved group holds %d parameters, this optimiser %d" %
+                             (len(groups[0].get('params', ())), len(self._params)))
+        if groups[0].get('maximize', False):
+            raise ValueError("FlatAdam.load_state_dict: maximize=True is not implemented")
+        if bool(groups[0].get('amsgrad', False)) != bool(self.param_groups[0]['amsgrad']):
+            raise ValueError("FlatAdam.load_state_dict: amsgrad=%s in the file, %s here (the max-moment buffer is allocated at construction)" %
+                             (groups[0].get('amsgrad', False), self.param_groups[0]['amsgrad']))
         packed = state_dict['state']
-        for i, p in enumerate(self._params):
-            src = packed.get(i)
-            if src is None:
-                continue
-            st = self.state[p]
-            for k in ('exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'):
-                if k in st and k in src:
-                    st[k].copy_(src[k])
-            self._step = int(src['step'])
+        have = [i in packed for i in range(len(self._params))]
+        if any(have) and not all(have):
+            raise ValueError("FlatAdam.load_state_dict: state for %d of %d parameters (all or none)" % (sum(have), len(have)))
+        if all(have):
+            steps = set()
+            for i, p in enumerate(self._params):
+                src, st = packed[i], self.state[p]
+                for k in ('exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'):
+                    if k in st:
+                        if k not in src:
+                            raise ValueError("FlatAdam.load_state_dict: parameter %d has no '%s'" % (i, k))
+                        st[k].copy_(src[k])
+                steps.add(int(src['step']))
+            if len(steps) != 1:
+                raise ValueError("FlatAdam.load_state_dict: per-parameter step counts differ (%s); this optimiser keeps one" % sorted(steps)[:4])
+            self._step = steps.pop()
+        else:
+            self._step = 0
+            self._m.zero_(); self._v.zero_()
+            if self._vmax is not None:
+                self._vmax.zero_()
         self._step_t.fill_(self._step)
-        for k, v in state_dict['param_groups'][0].items():
-            if k != 'params':
-                self.param_groups[0][k] = v
+        for k in self._HYPER:
+            if k in groups[0]:
+                self.param_groups[0][k] = groups[0][k]
 
 
 class DeviceGradNormQueue:

@@ -98,6 +98,33 @@ def test_flat_adam_takes_the_flat_gradient_and_resumes_from_a_state_dict():
         assert torch.equal(a.data, b.data)
     with pytest.raises(Exception):
         JO.FlatAdam([torch.nn.Parameter(torch.zeros(3))], lr=1e-3)                          # CPU parameters: refused, no fallback
+    # a MIDDLE gradient replaced by a separate tensor (a hook, a manual assignment) is noticed every step: the flat view is refused and
+    # the step gathers the real gradients instead of reading stale bytes of the old flat buffer (round-5 advisor finding)
+    flat = set_flat_grads(pa, 7); set_flat_grads(pb, 7)
+    mid = len(pa) // 2
+    fresh = torch.full_like(pa[mid], 0.125)
+    pa[mid].grad = fresh.clone(); pb[mid].grad = fresh.clone()
+    assert JO.flat_gradient(pa, total) is None
+    flat[offs[mid]:offs[mid] + pa[mid].numel()] = 1e6            # what a stale read would pick up
+    before = pa[mid].detach().clone()
+    opt.step()
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in pb]
+    for r, p in zip(ref, pb):
+        r.grad = p.grad.detach().clone()
+    opt2.step()
+    assert torch.equal(pa[mid].data, pb[mid].data) and float((pa[mid] - before).abs().max()) < 1e-2
+    # load_state_dict validates what it is given
+    sd2 = opt.state_dict()
+    bad = dict(state=sd2['state'], param_groups=[dict(sd2['param_groups'][0], params=list(range(len(pa) - 1)))])
+    with pytest.raises(ValueError, match='parameters'):
+        opt2.load_state_dict(bad)
+    part = dict(state={0: sd2['state'][0]}, param_groups=sd2['param_groups'])
+    with pytest.raises(ValueError, match='all or none'):
+        opt2.load_state_dict(part)
+    with pytest.raises(ValueError, match='maximize'):
+        opt2.load_state_dict(dict(state=sd2['state'], param_groups=[dict(sd2['param_groups'][0], maximize=True)]))
+    opt2.load_state_dict(dict(state=sd2['state'], param_groups=[dict(sd2['param_groups'][0], foreach=None, fused=None, capturable=False)]))
+    assert 'capturable' not in opt2.param_groups[0] and 'fused' not in opt2.param_groups[0]
 
 
 def test_device_gradnorm_queue_follows_the_host_clipping():
