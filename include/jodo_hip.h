@@ -405,12 +405,14 @@ int jodo_debug_mfma_valu(int iters, int nv, int nt, int waves_per_simd, float* s
 
 /* ---- opt-in split-bf16 pair update (JODO_OPT_SPLIT_BF16; no reference counterpart: an alternative arithmetic form of
  * MultiCondEquiUpdate + the edge FFN, models/mol_gnn.py:71-94, :313-317) ----
- * jodo_dgt_split_size: bytes of the static weight tape (all blocks / one block) for this configuration; JODO_ERR_UNSUPPORTED unless
- *   nf = 256 and cond_ch = 0.
- * jodo_dgt_pack_split_host: the tape (edge FFN, readout, triangular factor of the rotated statistics as hi | mid | lo bf16 terms, in
- *   consumption order) from the same named fp32 tensors jodo_dgt_pack_weights takes, into a host buffer.
+ * jodo_dgt_split_size: bytes of the static weight tapes for this configuration — all of them, one block's PAIR tape (edge FFN, readout,
+ *   triangular factor of the rotated statistics: k_edge_update_sym_split), one block's NODE tape (node2edge, node FFN, rotated W_row /
+ *   W_col, readout, the next block's q / k / v: k_node_post_split; 0 when the width-generic node kernels run, jodo_cfg.layout = 1);
+ *   JODO_ERR_UNSUPPORTED unless nf = 256 and cond_ch = 0.  Layout of the buffer: L pair tapes, then L node tapes.
+ * jodo_dgt_pack_split_host: the tapes (hi | mid | lo bf16 terms of every weight, in consumption order) from the same named fp32 tensors
+ *   jodo_dgt_pack_weights takes, into a host buffer.
  * jodo_plan_set_split_weights: device copy of that tape for this plan (caller-owned, must outlive the plan's forwards; NULL clears). */
-int jodo_dgt_split_size(const jodo_cfg* cfg, size_t* total_bytes, size_t* block_bytes);
+int jodo_dgt_split_size(const jodo_cfg* cfg, size_t* total_bytes, size_t* pair_block_bytes, size_t* node_block_bytes);
 int jodo_dgt_pack_split_host(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, void* host, size_t cap_bytes);
 int jodo_plan_set_split_weights(jodo_plan* plan, const void* tape_dev, size_t bytes);
 

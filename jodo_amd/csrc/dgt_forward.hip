@@ -3,6 +3,7 @@
 // synchronisation, no allocation.
 #include "dgt_kernels_pre.h"
 #include "dgt_kernels_node.h"
+#include "dgt_kernels_split_node.h"
 #include "dgt_kernels_post.h"
 #include "dgt_kernels_wide.h"
 #include "jodo_hip_internal.h"
@@ -53,7 +54,7 @@ void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
     A.ehid = ws_ptr<float>(ws, w.ehid); A.epred = ws_ptr<float>(ws, w.epred);
     A.e_out = ws_ptr<float>(ws, w.e2);
     A.dposE = ws_ptr<float>(ws, w.dposE); A.gramE = ws_ptr<float>(ws, w.gramE);
-    A.wsplit = nullptr; A.mfold_s = nullptr;               // the opt-in split-bf16 pair update: decided per forward (jodo_dgt_forward)
+    A.wsplit = nullptr; A.wsplit_node = nullptr; A.mfold_s = nullptr;      // the opt-in split-bf16 kernels: decided per forward (jodo_dgt_forward)
 }
 
 int rowgemm(hipStream_t st, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* Wp, const float* bias,
@@ -178,12 +179,21 @@ int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A, bool with_ab, b
     const int full = (force && !rem_only) ? (force == 1 ? p->n_strips : 0) : (p->n_strips / 1024) * 1024;
     const int rem = p->n_strips - full;
     const int nw = rem_only ? force - 10 : (force ? force : (rem <= 256 ? 4 : (rem <= 512 ? 2 : 1)));
-    if (full > 0) {
+    // opt-in split-bf16 form (JODO_OPT_SPLIT_BF16; jodo_dgt_forward checked the preconditions): every strip through k_node_post_split, four
+    // per workgroup; k_node_ab / the Gram tiles (exact fp32) follow as launches of their own
+    const bool split_node = A.wsplit_node != nullptr && A.rot == 1;
+    if (split_node) {
+        A.strip0 = 0;
+        const int wgs = (p->n_strips + 3) / 4;
+        if (d.r == 2) { LAUNCH((split::k_node_post_split<2, 1>), wgs, split::SPLIT_WAVES * 64, A); LAUNCH((split::k_node_post_split<2, 2>), wgs, split::SPLIT_WAVES * 64, A); }
+        else { LAUNCH((split::k_node_post_split<4, 1>), wgs, split::SPLIT_WAVES * 64, A); LAUNCH((split::k_node_post_split<4, 2>), wgs, split::SPLIT_WAVES * 64, A); }
+    }
+    if (full > 0 && !split_node) {
         A.strip0 = 0;
         if (d.r == 2) LAUNCH(k_node_post<2>, full, 64, A); else LAUNCH(k_node_post<4>, full, 64, A);
     }
     A.ab0 = 0; A.ab1 = 2 * p->n_strips; A.g0 = 0; A.g1 = A.rot ? p->n_gtiles : 0; A.mix_nw = 0;
-    const bool mix = with_ab && full > 0 && rem > 0 && nw >= 2 && p->opt[JODO_OPT_NODE_MIX] != 0;
+    const bool mix = !split_node && with_ab && full > 0 && rem > 0 && nw >= 2 && p->opt[JODO_OPT_NODE_MIX] != 0;
     if (mix) {
         if (p->gt_cache_full != full) {                      // Gram tiles among the strips of the full rounds: a prefix of the sorted list
             const int32_t* sa = p->desc.data() + p->off_gt_sa, *sc = p->desc.data() + p->off_gt_sc;
@@ -204,7 +214,7 @@ int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A, bool with_ab, b
         A.ab0 = 0; A.g0 = 0;
         return JODO_OK;
     }
-    if (rem > 0) {
+    if (rem > 0 && !split_node) {
         A.strip0 = full;
         if (nw == 1) { if (d.r == 2) LAUNCH(k_node_post<2>, rem, 64, A); else LAUNCH(k_node_post<4>, rem, 64, A); }
         else if (nw == 2) { if (d.r == 2) LAUNCH((k_node_postw<2, 2>), rem, 128, A); else LAUNCH((k_node_postw<4, 2>), rem, 128, A); }
@@ -283,7 +293,14 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
         A.mod_base = 32 + (int64_t)l * d.MB;
         for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + i];
         // split-bf16 pair update (opt-in; A.mfold_s != NULL says jodo_dgt_forward found its preconditions met): this block's weight tape
-        A.wsplit = A.mfold_s ? reinterpret_cast<const unsigned short*>(static_cast<const char*>(p->split_w) + (size_t)l * (p->split_bytes / d.L)) : nullptr;
+        A.wsplit = nullptr; A.wsplit_node = nullptr;
+        if (A.mfold_s) {
+            size_t total = 0, pair_block = 0, node_block = 0;
+            (void)jodo_dgt_split_size(&p->cfg, &total, &pair_block, &node_block);
+            const char* base = static_cast<const char*>(p->split_w);
+            A.wsplit = reinterpret_cast<const unsigned short*>(base + (size_t)l * pair_block);
+            if (node_block > 0) A.wsplit_node = reinterpret_cast<const unsigned short*>(base + (size_t)d.L * pair_block + (size_t)l * node_block);
+        }
         A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
         {
             ProfScope ps(p, st, JODO_PROF_NODE_PRE);
@@ -429,8 +446,8 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     // exact-fp32 kernels run as always.
     if (p->opt[JODO_OPT_SPLIT_BF16] == 1 && p->split_w && d.D == 256 && d.cond_ch == 0 && !p->force_directed && p->n_pitems > 0 && p->pitems_single &&
         p->opt[JODO_OPT_PIN_SYMMETRIC] == 1 && p->opt[JODO_OPT_PIN_UNIFORM_T] == 1 && p->opt[JODO_OPT_ROT_STATS] == 1) {
-        size_t total = 0, per_block = 0;
-        if (jodo_dgt_split_size(&p->cfg, &total, &per_block) == JODO_OK && total == p->split_bytes)
+        size_t total = 0, per_block = 0, node_block = 0;
+        if (jodo_dgt_split_size(&p->cfg, &total, &per_block, &node_block) == JODO_OK && total == p->split_bytes)
             A.mfold_s = ws_ptr<unsigned short>(workspace, p->ws.mfold_s);
     }
     float* posbuf[2] = {ws_ptr<float>(workspace, p->ws.pos0), ws_ptr<float>(workspace, p->ws.pos1)};

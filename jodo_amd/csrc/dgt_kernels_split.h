@@ -71,7 +71,7 @@ __device__ __forceinline__ void tape_start(Tape& T) {
 }
 
 // NS consecutive tape steps: acc += W_steps * act.  The block starts W0 steps into chunk g (W0 is known at compile time everywhere: the
-// tape sections are unrolled straight-line code, and the one real loop — the Z blocks — advances by whole chunks); g moves on.
+// tape sections are unrolled straight-line code, and the real loops advance by whole chunks); g moves on.
 template <int NS, int W0>
 __device__ __forceinline__ f32x16 tape_block(Tape& T, int& g, const Split8* act, f32x16 acc) {
     static_assert(W0 >= 0 && W0 < CH_STEPS, "offset inside a chunk");
@@ -86,6 +86,84 @@ __device__ __forceinline__ f32x16 tape_block(Tape& T, int& g, const Split8* act,
         acc = mfma_step_s(wh, wm, wl, act[s], acc);
     }
     g += (W0 + NS) / CH_STEPS;
+    return acc;
+}
+
+// ---- the node kernel's ring (k_node_post_split: ONE workgroup per CU, so nothing covers what a chunk boundary costs) ----
+// Measured on MI355X (SQ counters of tools/gpu_split_pmc.sh): with four-step chunks the waves of k_node_post_split sit parked 44 % of
+// their cycles — about 900 cycles at each of a strip's 304 chunk boundaries (commit, LDS wait, barrier behind the slowest of four waves);
+// reading fragments a step ahead and a second stage set (two periods of prefetch distance) moved that by 0 / 4 %: it is the boundary
+// itself.  So this ring takes CHS = 8 steps per chunk (24 KiB, three slots = 72 KiB: the node kernel has the CU's LDS to itself) and
+// halves their number; every block of the node tape is a whole number of such chunks except the four-step ff_linear2 pieces, which
+// come in pairs (H = the piece's half of the chunk).
+constexpr int N_CHS = 8;
+constexpr int N_CH_BYTES = N_CHS * 3072;
+constexpr int N_SLOTS = 3;
+constexpr int N_LOADS = N_CH_BYTES / SPLIT_WAVES / 1024;      // 16-byte loads per lane and chunk (6)
+struct Tape2 {
+    __amdgpu_buffer_rsrc_t rs;
+    int ntot;
+    unsigned ld_off, rd_off;
+    char* ring;
+    u32x4 stage[N_LOADS];
+    u32x4 cur[3];                                    // the NEXT step's three fragments, read one step ahead (one wave per SIMD: nothing else covers
+                                                     // the LDS round trip — four waves ask for 12 KiB at once right behind every barrier)
+};
+__device__ __forceinline__ void tape2_request(Tape2& T, int g) {
+    if (g >= T.ntot) return;
+#pragma unroll
+    for (int i = 0; i < N_LOADS; ++i)
+        T.stage[i] = __builtin_amdgcn_raw_buffer_load_b128(T.rs, T.ld_off + (unsigned)i * 1024u, (unsigned)g * N_CH_BYTES, 0);
+}
+__device__ __forceinline__ void tape2_commit(Tape2& T, int g) {
+    if (g >= T.ntot) return;
+    char* dst = T.ring + (g % N_SLOTS) * N_CH_BYTES + T.ld_off;
+#pragma unroll
+    for (int i = 0; i < N_LOADS; ++i) *reinterpret_cast<u32x4*>(dst + i * 1024) = T.stage[i];
+}
+__device__ __forceinline__ void tape2_boundary(Tape2& T, int g) {
+    tape2_commit(T, g + 1);
+    __syncthreads();
+    tape2_request(T, g + 2);
+    pipeline_fence();
+}
+__device__ __forceinline__ void tape2_start(Tape2& T, int g0) {      // g0: first chunk this launch consumes
+    tape2_request(T, g0);
+    tape2_commit(T, g0);
+    tape2_request(T, g0 + 1);
+    pipeline_fence();
+    __syncthreads();                                 // every wave's quarter of the first chunk is visible: read its first step
+    const char* src = T.ring + (g0 % N_SLOTS) * N_CH_BYTES + T.rd_off;
+    T.cur[0] = *reinterpret_cast<const u32x4*>(src);
+    T.cur[1] = *reinterpret_cast<const u32x4*>(src + 1024);
+    T.cur[2] = *reinterpret_cast<const u32x4*>(src + 2048);
+}
+// NS steps starting H steps into chunk g (H = 0 or, for the second of a pair of four-step pieces, 4); g moves on when the chunk is done
+template <int NS, int H, bool TWO = false>            // TWO: two alternating accumulators (mfma_step_s2; measured: no gain, kept selectable)
+__device__ __forceinline__ f32x16 tape2_block(Tape2& T, int& g, const Split8* act, f32x16 acc) {
+    static_assert((H + NS) % N_CHS == 0 || (H == 0 && NS < N_CHS), "a block ends on a chunk boundary or is the first half of a chunk");
+    f32x16 acc2 = zero16();                          // second accumulator (mfma_step_s2): neighbouring MFMAs independent
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int w = (H + s) % N_CHS, gi = g + (H + s) / N_CHS;
+        if (w == 0) tape2_boundary(T, gi);
+        // this step's fragments were read during the previous step (the tape is consumed strictly in order; chunk g + 1 is committed
+        // before the barrier of boundary(g), so its first step may be read during the last step of chunk g); now the next step's
+        const bf16x8 wh = as_bf16x8(T.cur[0]), wm = as_bf16x8(T.cur[1]), wl = as_bf16x8(T.cur[2]);
+        const int wn = (H + s + 1) % N_CHS, gn = g + (H + s + 1) / N_CHS;
+        const char* nx = T.ring + (gn % N_SLOTS) * N_CH_BYTES + wn * 3072 + T.rd_off;
+        T.cur[0] = *reinterpret_cast<const u32x4*>(nx);
+        T.cur[1] = *reinterpret_cast<const u32x4*>(nx + 1024);
+        T.cur[2] = *reinterpret_cast<const u32x4*>(nx + 2048);
+        pipeline_fence();
+        if constexpr (TWO) mfma_step_s2(wh, wm, wl, act[s], acc, acc2);
+        else acc = mfma_step_s(wh, wm, wl, act[s], acc);
+    }
+    g += (H + NS) / N_CHS;
+    if constexpr (TWO) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
+    }
     return acc;
 }
 

@@ -515,11 +515,22 @@ static int split_tape_steps(const DgtDims& d) {
     return NCH * (2 * NSE + NE * 4) + NSE + lq;
 }
 
-static int pack_split_tape(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, std::vector<uint16_t>& tape, size_t* block_elems) {
+// The NODE tape (tuned nf = 256 kernel set only; k_node_post_split, dgt_kernels_split.h), per block, in the order k_node_post consumes its
+// weights, every projection K = 256 -> 16 steps per output block:
+//   node2edge_lin (2 blocks) | for every hidden chunk c of 64: ff_linear1 blocks 2c, 2c + 1, then ff_linear2 blocks 0 .. 7, their steps
+//   4c .. 4c + 3 | for b = 0 .. 7: Q P W_row block b, Q P W_col block b (the rotated images, dgt_pack.cpp rot_stats) | node_l readout
+//   (2 blocks) | the NEXT block's lin_query, lin_key, lin_value (8 blocks each, the tuned q / k arrangement; zero for the last block)
+static int split_node_tape_steps(const DgtDims& d) {
+    if (d.wide) return 0;
+    return 2 * 16 + d.r * 4 * (2 * 16 + 8 * 4) + 16 * 16 + 2 * 16 + 24 * 16;
+}
+
+static int pack_split_tape(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, std::vector<uint16_t>& tape, size_t* block_elems,
+                           size_t* node_block_elems) {
     DgtDims d;
     int rc = dgt_dims_from_cfg(cfg, &d);
     if (rc != JODO_OK) return rc;
-    if (d.D != 256 || d.cond_ch != 0) return jodo_set_error(JODO_ERR_UNSUPPORTED, "split-bf16 pair update: built for nf = 256 unconditional models (got nf %d, cond_ch %d)", d.D, d.cond_ch);
+    if (d.D != 256 || d.cond_ch != 0) return jodo_set_error(JODO_ERR_UNSUPPORTED, "split-bf16 form: built for nf = 256 unconditional models (got nf %d, cond_ch %d)", d.D, d.cond_ch);
     const int D = d.D, De = d.De, L = d.L, r = d.r, ce = (2 * De) / L, KIN = 2 * D + 2 * De;
     Lookup lk;
     for (int i = 0; i < n_tensors; ++i) {
@@ -538,6 +549,7 @@ static int pack_split_tape(const jodo_cfg* cfg, const jodo_tensor* tensors, int 
         const uint16_t* src = p.data() + ((size_t)blk * ns + s0) * STEP;
         tape.insert(tape.end(), src, src + (size_t)(s1 - s0) * STEP);
     };
+    std::vector<RotStats> rsv((size_t)L);              // the QR factors of every block: shared by the pair tape (L) and the node tape (Q P W_row / W_col)
     for (int l = 0; l < L; ++l) {
         const std::string b = "e_block_" + std::to_string(l);
         const float* w3 = lk.get(b + ".ff_linear3.weight", (int64_t)r * De * De);
@@ -549,7 +561,8 @@ static int pack_split_tape(const jodo_cfg* cfg, const jodo_tensor* tensors, int 
         const std::vector<uint16_t> p3 = pack_proj_split(w3, De, nat_in(De), nat_out(r * De));
         const std::vector<uint16_t> p4 = pack_proj_split(w4, (int64_t)r * De, nat_in(r * De), nat_out(De));
         const std::vector<uint16_t> pro = pack_proj_split(wro, De, nat_in(De), nat_out(32, ce));
-        const RotStats rs = rot_stats(win, bin, D, De);
+        rsv[(size_t)l] = rot_stats(win, bin, D, De);
+        const RotStats& rs = rsv[(size_t)l];
         const std::vector<uint16_t> plq = pack_proj_split(rs.lq.data(), 2 * De, cat(nat_in(De), nat_in(De, De)), nat_out(2 * De));
         for (int c = 0; c < NCH; ++c) {
             slice(p3, NSE, 2 * c, 0, NSE);
@@ -560,6 +573,56 @@ static int pack_split_tape(const jodo_cfg* cfg, const jodo_tensor* tensors, int 
         for (int k = 0; k < NB2; ++k) { const int blk = NB2 - 1 - k; slice(plq, NSL, blk, 2 * blk, NSL); }
     }
     if (tape.size() != per_block * L) return jodo_set_error(JODO_ERR_ARG, "pack_split: internal tape size");
+    // ---- node tapes behind the pair tapes ----
+    const size_t node_block = (size_t)split_node_tape_steps(d) * STEP;
+    *node_block_elems = node_block;
+    if (node_block > 0) {
+        const int QK = d.SH * d.SC, cn = (2 * D) / L;
+        const OMap qk = qk_out(d.SH, d.SC);
+        if ((int)qk.size() != 256 || d.cnp != 64) return jodo_set_error(JODO_ERR_UNSUPPORTED, "pack_split: node tape expects the tuned nf 256 layouts");
+        tape.reserve(tape.size() + node_block * L);
+        for (int l = 0; l < L; ++l) {
+            const std::string b = "e_block_" + std::to_string(l);
+            const float* wn2e = lk.get(b + ".node2edge_lin.weight", (int64_t)De * D);
+            const float* w1 = lk.get(b + ".ff_linear1.weight", (int64_t)r * D * D);
+            const float* w2 = lk.get(b + ".ff_linear2.weight", (int64_t)D * r * D);
+            const float* wnro = lk.get("node_" + std::to_string(l) + ".weight", (int64_t)cn * D);
+            const float* win = lk.get(b + ".equi_update.input_lin.weight", (int64_t)D * KIN);
+            const float* bin = lk.get(b + ".equi_update.input_lin.bias", D);
+            if (!wn2e || !w1 || !w2 || !wnro || !win || !bin) return jodo_set_error(JODO_ERR_ARG, "pack_split: missing or mis-sized tensor '%s'", lk.missing.c_str());
+            const size_t at0 = tape.size();
+            const std::vector<uint16_t> pn2e = pack_proj_split(wn2e, D, nat_in(D), nat_out(De));
+            const std::vector<uint16_t> p1 = pack_proj_split(w1, D, nat_in(D), nat_out(r * D));
+            const std::vector<uint16_t> p2 = pack_proj_split(w2, (int64_t)r * D, nat_in(r * D), nat_out(D));
+            const RotStats& rs = rsv[(size_t)l];
+            const std::vector<uint16_t> prow = pack_proj_split(rs.rowq.data(), D, nat_in(D), nat_out(D));
+            const std::vector<uint16_t> pcol = pack_proj_split(rs.colq.data(), D, nat_in(D), nat_out(D));
+            const std::vector<uint16_t> pnro = pack_proj_split(wnro, D, nat_in(D), nat_out(d.cnp, cn));
+            for (int blk = 0; blk < 2; ++blk) slice(pn2e, 16, blk, 0, 16);
+            for (int c = 0; c < r * 4; ++c) {
+                slice(p1, 16, 2 * c, 0, 16);
+                slice(p1, 16, 2 * c + 1, 0, 16);
+                for (int ob = 0; ob < 8; ++ob) slice(p2, r * 16, ob, 4 * c, 4 * c + 4);
+            }
+            for (int blk = 0; blk < 8; ++blk) { slice(prow, 16, blk, 0, 16); slice(pcol, 16, blk, 0, 16); }
+            for (int blk = 0; blk < 2; ++blk) slice(pnro, 16, blk, 0, 16);
+            if (l + 1 < L) {
+                const std::string a = "e_block_" + std::to_string(l + 1) + ".attn_mpnn";
+                const float* wq = lk.get(a + ".lin_query.weight", (int64_t)QK * D);
+                const float* wk = lk.get(a + ".lin_key.weight", (int64_t)QK * D);
+                const float* wv = lk.get(a + ".lin_value.weight", (int64_t)D * D);
+                if (!wq || !wk || !wv) return jodo_set_error(JODO_ERR_ARG, "pack_split: missing or mis-sized tensor '%s'", lk.missing.c_str());
+                const std::vector<uint16_t> pq = pack_proj_split(wq, D, nat_in(D), qk), pk = pack_proj_split(wk, D, nat_in(D), qk);
+                const std::vector<uint16_t> pv = pack_proj_split(wv, D, nat_in(D), nat_out(D));
+                for (int blk = 0; blk < 8; ++blk) slice(pq, 16, blk, 0, 16);
+                for (int blk = 0; blk < 8; ++blk) slice(pk, 16, blk, 0, 16);
+                for (int blk = 0; blk < 8; ++blk) slice(pv, 16, blk, 0, 16);
+            } else {
+                tape.resize(tape.size() + (size_t)24 * 16 * STEP, 0);
+            }
+            if (tape.size() - at0 != node_block) return jodo_set_error(JODO_ERR_ARG, "pack_split: internal node tape size");
+        }
+    }
     return JODO_OK;
 }
 
@@ -581,21 +644,22 @@ extern "C" int jodo_debug_pack_split(const float* W, int n_out, int n_in, float*
 
 // The static weight tape of the opt-in split-bf16 pair update: sizes, then the tape itself into a host buffer (the caller uploads it
 // and hands the device copy to jodo_plan_set_split_weights).
-extern "C" int jodo_dgt_split_size(const jodo_cfg* cfg, size_t* total_bytes, size_t* block_bytes) {
-    if (!cfg || !total_bytes || !block_bytes) return jodo_set_error(JODO_ERR_ARG, "split_size: null argument");
+extern "C" int jodo_dgt_split_size(const jodo_cfg* cfg, size_t* total_bytes, size_t* pair_block_bytes, size_t* node_block_bytes) {
+    if (!cfg || !total_bytes || !pair_block_bytes || !node_block_bytes) return jodo_set_error(JODO_ERR_ARG, "split_size: null argument");
     DgtDims d;
     const int rc = dgt_dims_from_cfg(cfg, &d);
     if (rc != JODO_OK) return rc;
-    if (d.D != 256 || d.cond_ch != 0) return jodo_set_error(JODO_ERR_UNSUPPORTED, "split-bf16 pair update: built for nf = 256 unconditional models (got nf %d, cond_ch %d)", d.D, d.cond_ch);
-    *block_bytes = (size_t)split_tape_steps(d) * 3072;
-    *total_bytes = *block_bytes * d.L;
+    if (d.D != 256 || d.cond_ch != 0) return jodo_set_error(JODO_ERR_UNSUPPORTED, "split-bf16 form: built for nf = 256 unconditional models (got nf %d, cond_ch %d)", d.D, d.cond_ch);
+    *pair_block_bytes = (size_t)split_tape_steps(d) * 3072;
+    *node_block_bytes = (size_t)split_node_tape_steps(d) * 3072;
+    *total_bytes = (*pair_block_bytes + *node_block_bytes) * d.L;
     return JODO_OK;
 }
 extern "C" int jodo_dgt_pack_split_host(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, void* host, size_t cap_bytes) {
     if (!cfg || !tensors || !host) return jodo_set_error(JODO_ERR_ARG, "pack_split: null argument");
     std::vector<uint16_t> tape;
-    size_t per_block = 0;
-    const int rc = pack_split_tape(cfg, tensors, n_tensors, tape, &per_block);
+    size_t per_block = 0, node_block = 0;
+    const int rc = pack_split_tape(cfg, tensors, n_tensors, tape, &per_block, &node_block);
     if (rc != JODO_OK) return rc;
     if (tape.size() * sizeof(uint16_t) > cap_bytes) return jodo_set_error(JODO_ERR_ARG, "pack_split: buffer of %zu bytes, need %zu", cap_bytes, tape.size() * sizeof(uint16_t));
     std::memcpy(host, tape.data(), tape.size() * sizeof(uint16_t));

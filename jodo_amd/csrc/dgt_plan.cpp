@@ -625,8 +625,8 @@ extern "C" int jodo_debug_attn_schedule(const jodo_plan* p, int64_t* o) {
 extern "C" int jodo_plan_set_split_weights(jodo_plan* p, const void* tape_dev, size_t bytes) {
     if (!p) return jodo_set_error(JODO_ERR_ARG, "null plan");
     if (tape_dev) {
-        size_t total = 0, per_block = 0;
-        const int rc = jodo_dgt_split_size(&p->cfg, &total, &per_block);
+        size_t total = 0, per_block = 0, node_block = 0;
+        const int rc = jodo_dgt_split_size(&p->cfg, &total, &per_block, &node_block);
         if (rc != JODO_OK) return rc;
         if (bytes != total) return jodo_set_error(JODO_ERR_ARG, "set_split_weights: %zu bytes, this configuration's tape has %zu", bytes, total);
     }

@@ -2,8 +2,8 @@
 # Profile pass of one bench workload: rocprofv3 kernel stats, FETCH_SIZE / WRITE_SIZE passes (traffic summary for bench.py)
 # and, with "sq", the SQ issue-mix passes + the executed-work check.   gpurun -- 'bash tools/gpu_profile.sh qm9 r04P sq'
 W=${1:-qm9}; TAG=${2:-r04P}; OUT=$PWD/gpurun_out/$TAG; ROOTD=$PWD; mkdir -p $OUT; export TMPDIR=/tmp
-CMD="python bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-full-round"
-PCMD="python $ROOTD/bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-full-round"
+CMD="python bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-full-round --no-split-leg"
+PCMD="python $ROOTD/bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-full-round --no-split-leg"
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$W -o trace -- $PCMD > $OUT/prof_bench_$W.json 2> $OUT/prof_$W.err )
 f=$(find $OUT/prof_$W -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" $OUT/kernel_stats_$W.csv && head -14 "$f" | cut -c1-150
