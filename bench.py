@@ -644,7 +644,8 @@ def main():
                 for r_ in range(8):
                     torch.manual_seed(cfg.seed + r_)
                     draws.append(nodes_dist.sample(B).tolist())
-                scaling_pred = {'weak_scaling_as_bench_runs_it': {str(n_): scaling.predict_weak(model._cfg(), draws[:n_], int(shared_row), fr)
+                scaling_pred = {'kind': 'model',          # NOT a measurement and not a SCALE line: a host-side balance prediction
+                                'weak_scaling_as_bench_runs_it': {str(n_): scaling.predict_weak(model._cfg(), draws[:n_], int(shared_row), fr)
                                                                    for n_ in (2, 4, 8)},
                                 'note': 'host-side prediction, not a measurement: executed MFMA flops of every rank\'s own draw (seed + rank) from '
                                         'jodo_plan_work; predicted_efficiency = mean / max over ranks; *_time_model weights the classes by the '

@@ -81,6 +81,11 @@ def main():
         'edge_attn': E * (De * 4 + 4) + Nn * (De * 16) * 4,             # e in (+ flags), message sums out
         'edge_scores': E * (De * 4 + 4 + De * 4 + 64),                  # e in, et + 16 scores out
         'edge_msgs': E * (De * 4 + 64) + Nn * (De * 16) * 4,            # et + scores in, message partial sums out
+        # node class (k_node_post + k_node_ab + Gram tiles): SURVEY.md 8d's per-node term of the fused-per-block floor, h in + h out +
+        # positions = n (2 D 4 + 24) bytes — 93.4 MB at QM9 B = 2500.  What the class actually moves on top of it (q / k / v, the two
+        # input_lin halves and their coord_mlp.0 images, node2edge, the readout: the per-node arrays that feed the edge kernels) is
+        # implementation traffic of the strip model, 4 x this figure in writes alone (round-5 review)
+        'node_post': Nn * (2 * 4 * De * 4 + 24),
     }
     kernels = {}
     for cls, _ in CLASSES:
