@@ -459,7 +459,7 @@ def main():
     # and every roofline figure are the exact-fp32 default.  nf 256 unconditional workloads only; 50 steps with the pair-update class
     # bracketed.  Parity of this path: tests/test_split_gate.py (same stated tolerance / K64 as the default).
     split_info = None
-    if not args.graph and world == 1 and dims.D == 256 and not dims.cond_ch and not args.no_pin and not args.no_split_leg:
+    if not args.graph and world == 1 and dims.D in (256, 384) and not dims.cond_ch and not args.no_pin and not args.no_split_leg:
         try:
             with torch.no_grad():
                 model.unpin_paths()
@@ -478,7 +478,7 @@ def main():
                 sms, scnt = model.profile_read()
                 model.profile_enable(0)
             split_info = {'dtype': 'bf16x3 (three-term split operands, fp32 accumulate: fp32-equivalent, not bit-identical)',
-                          'scope': 'pair update (k_edge_update_sym_split) and node kernel (k_node_post_split); attention, k_node_ab, Gram tiles, embeddings, heads exact fp32',
+                          'scope': 'pair update (k_edge_update_sym_split) and, at nf 256, the node kernel (k_node_post_split); attention, k_node_ab, Gram tiles, embeddings, heads exact fp32',
                           'ms_per_step': tsp * 1e3, 'value': B / (SAMPLING_STEPS * tsp), 'unit': 'molecules/s',
                           'pair_update_avg_launch_ms': (sms[6] / scnt[6]) if scnt[6] else None, 'launches': scnt[6],
                           'nan_guard': bool(model.nan_guard_fired())}

@@ -196,7 +196,7 @@ enum jodo_plan_option {
     JODO_OPT_Z_SPLIT = 12,        /* 1 (default): when the LAST round of the pair update's launch (n_pitems mod 1024) has at most 256 items, they run as
                                    * workgroups of 4 waves that share the per-pair coord_mlp.0 output blocks (k_edge_update_sym<.., ZW = 4>); 2: also
                                    * 2 waves for 257 .. 512 items (measured slower on MI355X, kept for A/B runs); 0: one wave per item throughout */
-    JODO_OPT_SPLIT_BF16 = 13,     /* 0 (default): every projection runs on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  1 (OPT-IN, nf 256
+    JODO_OPT_SPLIT_BF16 = 13,     /* 0 (default): every projection runs on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  1 (OPT-IN, nf 256 / 384
                                    * unconditional models, pinned symmetric + shared-row paths, rotated statistics on, weights handed over with
                                    * jodo_plan_set_split_weights): the folded pair update runs its projections in the split-bf16 form — every
                                    * operand as hi + mid + lo bf16 terms, six v_mfma_f32_32x32x16_bf16 products per K = 16 step, fp32
@@ -408,7 +408,7 @@ int jodo_debug_mfma_valu(int iters, int nv, int nt, int waves_per_simd, float* s
  * jodo_dgt_split_size: bytes of the static weight tapes for this configuration — all of them, one block's PAIR tape (edge FFN, readout,
  *   triangular factor of the rotated statistics: k_edge_update_sym_split), one block's NODE tape (node2edge, node FFN, rotated W_row /
  *   W_col, readout, the next block's q / k / v: k_node_post_split; 0 when the width-generic node kernels run, jodo_cfg.layout = 1);
- *   JODO_ERR_UNSUPPORTED unless nf = 256 and cond_ch = 0.  Layout of the buffer: L pair tapes, then L node tapes.
+ *   JODO_ERR_UNSUPPORTED unless nf is 256 or 384 and cond_ch = 0.  Layout of the buffer: L pair tapes, then L node tapes.
  * jodo_dgt_pack_split_host: the tapes (hi | mid | lo bf16 terms of every weight, in consumption order) from the same named fp32 tensors
  *   jodo_dgt_pack_weights takes, into a host buffer.
  * jodo_plan_set_split_weights: device copy of that tape for this plan (caller-owned, must outlive the plan's forwards; NULL clears). */

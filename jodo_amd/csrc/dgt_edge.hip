@@ -55,11 +55,11 @@ int launch_update_sym(jodo_plan* p, hipStream_t st, KArgs& A) {
     // (A.rot: LayerNorm statistics in the rotated basis the node kernels of this forward wrote — decided by the launcher, not a flag)
     // opt-in split-bf16 form (JODO_OPT_SPLIT_BF16; jodo_dgt_forward checked the preconditions and set A.wsplit): four items per workgroup
     bool split_ran = false;
-    if constexpr (D == 256) {
+    if constexpr (D == 256 || D == 384) {
         if (run_fold && !run_plain && A.rot == 1 && A.wsplit && A.mfold_s) {
             const int wgs = (p->n_pitems + 31) / 32 * 8;
-            if (d.r == 2) hipLaunchKernelGGL((split::k_edge_update_sym_split<256, 2>), dim3(wgs), dim3(split::SPLIT_WAVES * 64), 0, st, A);
-            else hipLaunchKernelGGL((split::k_edge_update_sym_split<256, 4>), dim3(wgs), dim3(split::SPLIT_WAVES * 64), 0, st, A);
+            if (d.r == 2) hipLaunchKernelGGL((split::k_edge_update_sym_split<D, 2>), dim3(wgs), dim3(split::SPLIT_WAVES * 64), 0, st, A);
+            else hipLaunchKernelGGL((split::k_edge_update_sym_split<D, 4>), dim3(wgs), dim3(split::SPLIT_WAVES * 64), 0, st, A);
             split_ran = true;
         }
     }

@@ -444,7 +444,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     // unconditional, both paths pinned (symmetric inputs, shared modulation row: what a sampler pins after its first self-conditioned
     // evaluation), rotated statistics in their default form, one circulant offset per item, the weight tape handed over — otherwise the
     // exact-fp32 kernels run as always.
-    if (p->opt[JODO_OPT_SPLIT_BF16] == 1 && p->split_w && d.D == 256 && d.cond_ch == 0 && !p->force_directed && p->n_pitems > 0 && p->pitems_single &&
+    if (p->opt[JODO_OPT_SPLIT_BF16] == 1 && p->split_w && (d.D == 256 || d.D == 384) && d.cond_ch == 0 && !p->force_directed && p->n_pitems > 0 && p->pitems_single &&
         p->opt[JODO_OPT_PIN_SYMMETRIC] == 1 && p->opt[JODO_OPT_PIN_UNIFORM_T] == 1 && p->opt[JODO_OPT_ROT_STATS] == 1) {
         size_t total = 0, per_block = 0, node_block = 0;
         if (jodo_dgt_split_size(&p->cfg, &total, &per_block, &node_block) == JODO_OK && total == p->split_bytes)

@@ -173,9 +173,12 @@ __device__ __forceinline__ void split_regs(const float (&x)[NR], Split8* out) {
     for (int g = 0; g < NR / 8; ++g) out[g] = split8(&x[8 * g]);
 }
 
+// nf 256: 252 registers, two workgroups per CU (two waves per SIMD), no scratch.  nf 384: [e ; G] alone is 12 Split8 = 144 registers; held
+// to 256 the kernel spills 296 B per lane and is still the faster form (GEOM nf 384 B = 1250, pair update per block: fp32 4 209 us, one wave
+// per SIMD with 312 registers 3 283, two waves per SIMD 3 142: profiles/r06_split_ab_geom384.txt).
 template <int D, int R>
 __global__ __launch_bounds__(SPLIT_WAVES * 64, 2) void k_edge_update_sym_split(KArgs A) {
-    static_assert(D == 256, "the split-bf16 pair update is built for nf = 256");
+    static_assert(D == 256 || D == 384, "the split-bf16 pair update is built for nf = 256 and nf = 384");
     if (A.flags[FLAG_ASYM] || !A.flags[FLAG_UNIFORM_T]) return;      // (the launcher only runs this under both pins; a violated pin is
                                                                       // reported by k_finalize_nodes like for every pinned launch)
     using X = wide::Dim<D>;
@@ -184,7 +187,9 @@ __global__ __launch_bounds__(SPLIT_WAVES * 64, 2) void k_edge_update_sym_split(K
     constexpr int NB2 = 2 * X::NE;                   // blocks of the triangular factor L (4)
     constexpr int NSZ = 2 * NSE;                     // steps of a K = 2 De projection (8)
     constexpr int STATIC_STEPS = NCH * (2 * NSE + X::NE * 4) + NSE + NB2 * (NB2 + 1);
-    static_assert(STATIC_STEPS % CH_STEPS == 0 && NSZ % CH_STEPS == 0 && NSE % CH_STEPS == 0 && CH_STEPS == 4, "tape sections end on chunk boundaries");
+    constexpr int CHUNK_STEPS_FFN = 2 * NSE + X::NE * 4;   // steps of one hidden chunk: two ff_linear3 blocks + NE ff_linear4 pieces
+    static_assert(STATIC_STEPS % CH_STEPS == 0 && NSZ % CH_STEPS == 0 && CHUNK_STEPS_FFN % CH_STEPS == 0 && (2 * NSE) % CH_STEPS == 0 && CH_STEPS == 4,
+                  "tape sections end on chunk boundaries (K = De blocks of 6 steps at nf 384 start 0 or 2 steps into a chunk)");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, jl = lane & 31, half = lane >> 5;
     // items: workgroup w lives on XCD w % 8; the plan's item order puts the items of XCD x at indices = x (mod 8) (xcd_order), so the
     // four waves take four of "their" XCD's items
@@ -255,21 +260,21 @@ __global__ __launch_bounds__(SPLIT_WAVES * 64, 2) void k_edge_update_sym_split(K
         f32x16 o[X::NE];
 #pragma unroll
         for (int b = 0; b < X::NE; ++b) o[b] = zero16();
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
+        static_for<NCH>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
             float hid[32];
-#pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2) {
+            static_for<2>([&](auto bc) {
+                constexpr int b2 = decltype(bc)::value;
                 float bb[16];
                 load16(b3_ + (c * 2 + b2) * 32 + half * 16, bb);
-                const f32x16 acc = tape_block<NSE, 0>(T, g, zs, zero16());
+                const f32x16 acc = tape_block<NSE, (b2 * NSE) % CH_STEPS>(T, g, zs, zero16());
                 silu_bias16(acc, bb, hid + b2 * 16);
-            }
+            });
             Split8 hs[4];
             split_regs<32>(hid, hs);
 #pragma unroll
             for (int ob = 0; ob < X::NE; ++ob) o[ob] = tape_block<4, 0>(T, g, hs, o[ob]);
-        }
+        });
 #pragma unroll
         for (int b = 0; b < X::NE; ++b) {
             float ob4[16], og2[16];
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(SPLIT_WAVES * 64, 2) void k_edge_update_sym_split(K
     {
         float bb[16];
         load16(bro_ + half * 16, bb);
-        const f32x16 acc = tape_block<NSE, 0>(T, g, zs, zero16());
+        const f32x16 acc = tape_block<NSE, 0>(T, g, zs, zero16());      // (the readout starts a chunk: NCH whole FFN chunks precede it)
         float rr[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) rr[s] = acc[s] + bb[s];
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(SPLIT_WAVES * 64, 2) void k_edge_update_sym_split(K
         float n0[16], n1[16], n2[16], n3[16];
         bload16(wrow_i, b, n0); bload16(wcol_j, b, n1); bload16(wrow_j, b, n2); bload16(wcol_i, b, n3);
         pipeline_fence();
-        const f32x16 acc = tape_block<2 * (NB2 - b), (k * (k + 1)) % CH_STEPS>(T, g, zs + 2 * b, zero16());      // blocks of 2, 4, 6, 8 steps
+        const f32x16 acc = tape_block<2 * (NB2 - b), (NSE + k * (k + 1)) % CH_STEPS>(T, g, zs + 2 * b, zero16());      // blocks of 2, 4, 6, 8 (, 10, 12) steps behind the readout's NSE
 #pragma unroll
         for (int s = 0; s < 16; s += 2) {
             const f32x2 sv = pk2(acc[s], acc[s + 1]);

@@ -530,7 +530,7 @@ static int pack_split_tape(const jodo_cfg* cfg, const jodo_tensor* tensors, int 
     DgtDims d;
     int rc = dgt_dims_from_cfg(cfg, &d);
     if (rc != JODO_OK) return rc;
-    if (d.D != 256 || d.cond_ch != 0) return jodo_set_error(JODO_ERR_UNSUPPORTED, "split-bf16 form: built for nf = 256 unconditional models (got nf %d, cond_ch %d)", d.D, d.cond_ch);
+    if ((d.D != 256 && d.D != 384) || d.cond_ch != 0) return jodo_set_error(JODO_ERR_UNSUPPORTED, "split-bf16 form: built for nf = 256 / 384 unconditional models (got nf %d, cond_ch %d)", d.D, d.cond_ch);
     const int D = d.D, De = d.De, L = d.L, r = d.r, ce = (2 * De) / L, KIN = 2 * D + 2 * De;
     Lookup lk;
     for (int i = 0; i < n_tensors; ++i) {
@@ -649,7 +649,7 @@ extern "C" int jodo_dgt_split_size(const jodo_cfg* cfg, size_t* total_bytes, siz
     DgtDims d;
     const int rc = dgt_dims_from_cfg(cfg, &d);
     if (rc != JODO_OK) return rc;
-    if (d.D != 256 || d.cond_ch != 0) return jodo_set_error(JODO_ERR_UNSUPPORTED, "split-bf16 form: built for nf = 256 unconditional models (got nf %d, cond_ch %d)", d.D, d.cond_ch);
+    if ((d.D != 256 && d.D != 384) || d.cond_ch != 0) return jodo_set_error(JODO_ERR_UNSUPPORTED, "split-bf16 form: built for nf = 256 / 384 unconditional models (got nf %d, cond_ch %d)", d.D, d.cond_ch);
     *pair_block_bytes = (size_t)split_tape_steps(d) * 3072;
     *node_block_bytes = (size_t)split_node_tape_steps(d) * 3072;
     *total_bytes = (*pair_block_bytes + *node_block_bytes) * d.L;

@@ -170,7 +170,7 @@ class _DGTBase(nn.Module):
         # OPT-IN (default off): under pinned paths (pin_paths: what the samplers do after a round's first self-conditioned evaluation)
         # the folded pair update runs its projections in the split-bf16 form — three bf16 terms per operand, six bf16 MFMAs per K = 16
         # step, fp32 accumulation: fp32-equivalent arithmetic, not bit-identical to the default (csrc/dgt_kernels_split.h,
-        # JODO_OPT_SPLIT_BF16).  nf 256 unconditional models only; ignored elsewhere.  The default path and every headline number
+        # JODO_OPT_SPLIT_BF16).  nf 256 (pair update + node kernel) and nf 384 (pair update) unconditional models; ignored elsewhere.  The default path and every headline number
         # stay exact fp32.
         self.split_bf16 = False
         self._split_tape = None       # (weights key, device uint8 tensor): the split form's static weight tape
@@ -512,7 +512,7 @@ class _DGTBase(nn.Module):
             capi.check(L.jodo_plan_set_option(plan['handle'], 4, 2 if f[4] else 1), 'jodo_plan_set_option')
             capi.check(L.jodo_plan_set_option(plan['handle'], 5, 1 if f[2] else 2), 'jodo_plan_set_option')
             plan['pinned'] = True
-            if self.split_bf16 and self.dims.D == 256 and not self.conditional and not f[4] and f[2]:
+            if self.split_bf16 and self.dims.D in (256, 384) and not self.conditional and not f[4] and f[2]:
                 tape = self._split_weights(plan['ws'].device)
                 capi.check(L.jodo_plan_set_split_weights(plan['handle'], capi.ptr(tape), ctypes.c_size_t(tape.numel())), 'jodo_plan_set_split_weights')
                 capi.check(L.jodo_plan_set_option(plan['handle'], 13, 1), 'jodo_plan_set_option')

@@ -113,16 +113,25 @@ def test_split_tape_is_the_consumption_order_of_the_pair_update():
         assert np.array_equal(blk[at:at + NSE], sro.reshape(1, NSE, STEP)[0]); at += NSE
         assert steps - at == 20                                   # L: 2 + 4 + 6 + 8 steps
     # configurations the split form is not built for are refused by name
+    cfg128 = configs.get('vpsde_geom_uncond_jodo')
+    cfg128.model.nf, cfg128.model.n_layers = 128, 6
+    with pytest.raises(capi.JodoHipError, match='nf = 256 / 384'):
+        capi.pack_split_tape(get_model_class('DGT_concat')(cfg128)._cfg(), {})
+    with pytest.raises(capi.JodoHipError, match='unconditional'):
+        capi.pack_split_tape(get_model_class('cond_DGT_concat')(configs.get('vpsde_qm9_cond_jodo'))._cfg(), {})
+    # nf 384: a pair tape only (its node kernels are the width-generic set): 192 steps per block at mlp_ratio 4
     cfg384 = configs.get('vpsde_geom_uncond_jodo')
     cfg384.model.nf = 384
-    with pytest.raises(capi.JodoHipError, match='nf = 256'):
-        capi.pack_split_tape(get_model_class('DGT_concat')(cfg384)._cfg(), {})
+    m384 = get_model_class('DGT_concat')(cfg384)
+    capi.check(capi.lib().jodo_dgt_split_size(ctypes.byref(m384._cfg()), ctypes.byref(total), ctypes.byref(pair_b), ctypes.byref(node_b)), 'split_size')
+    assert pair_b.value == 192 * 3072 and node_b.value == 0 and total.value == cfg384.model.n_layers * pair_b.value
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg_name,n_nodes,over", [
     ('vpsde_qm9_uncond_jodo', [3, 9, 17, 29, 12, 5, 1, 2, 28, 29, 29, 18, 7] * 3, {}),                 # r = 2, several strips, idle waves
     ('vpsde_geom_uncond_jodo', [44, 45, 7, 70, 33], {}),                                                # r = 4, L = 10
+    ('vpsde_geom_uncond_jodo', [44, 45, 7, 1, 2, 61], dict(nf=384)),                                    # nf 384: pair update only, one wave per SIMD
     # >= 1024 node strips: the node kernel also produces the next block's q / k / v (fuse_next), one full round + a remainder
     ('vpsde_qm9_uncond_jodo', ([29, 17, 23, 12, 9, 28, 19, 21, 18, 20] * 181)[:1805], {}),
 ])

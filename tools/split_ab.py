@@ -12,7 +12,8 @@ from jodo_amd.sampling import AncestralSampler, build_masks
 from jodo_amd.models.utils import sample_combined_position_feature_noise, sample_symmetric_edge_feature_noise
 from jodo_amd.utils import get_self_cond_fn
 
-WL = {'qm9': ('vpsde_qm9_uncond_jodo', 'qm9_with_h', 2500), 'geom': ('vpsde_geom_uncond_jodo', 'geom_with_h_1', 512)}
+WL = {'qm9': ('vpsde_qm9_uncond_jodo', 'qm9_with_h', 2500), 'geom': ('vpsde_geom_uncond_jodo', 'geom_with_h_1', 512),
+      'geom384': ('vpsde_geom_uncond_jodo', 'geom_with_h_1', 1250)}
 CLS = ['prologue', 'node_pre', 'attention', 'unused3', 'unused4', 'node_post', 'pair_update', 'heads']
 ap = argparse.ArgumentParser()
 ap.add_argument('--workload', default='qm9', choices=sorted(WL))
@@ -24,6 +25,8 @@ B = args.batch or B
 dev = torch.device('cuda:0')
 cfg = configs.get(cfg_name)
 cfg.device = dev
+if args.workload == 'geom384':
+    cfg.model.nf = 384                         # README.md:168 `--config.model.nf 384`
 lines = []
 
 
