@@ -202,7 +202,9 @@ enum jodo_plan_option {
                                    * operand as hi + mid + lo bf16 terms, six v_mfma_f32_32x32x16_bf16 products per K = 16 step, fp32
                                    * accumulation: fp32-equivalent arithmetic (dropped terms <= 3 * 2^-26 relative; profiles/r06_split_gate.txt)
                                    * at 6/16 of the matrix cycles (csrc/dgt_kernels_split.h).  Results differ from the default path in the
-                                   * last bits; the default and every headline number stay exact fp32.  Ignored when a precondition fails. */
+                                   * last bits; the default and every headline number stay exact fp32.  Ignored when a precondition fails.
+                                   * 2 (experiments): also the fused attention kernel (k_edge_attn variant 4, nf 256 tuned set, plans without
+                                   * molecules above an attention group) — parity-tested, measured 3 x SLOWER on MI355X (1.6 KB of scratch per lane), DESIGN.md 4i */
     JODO_OPT_COUNT
 };
 int jodo_plan_set_option(jodo_plan* plan, int option, int value);
@@ -407,12 +409,13 @@ int jodo_debug_mfma_valu(int iters, int nv, int nt, int waves_per_simd, float* s
  * MultiCondEquiUpdate + the edge FFN, models/mol_gnn.py:71-94, :313-317) ----
  * jodo_dgt_split_size: bytes of the static weight tapes for this configuration — all of them, one block's PAIR tape (edge FFN, readout,
  *   triangular factor of the rotated statistics: k_edge_update_sym_split), one block's NODE tape (node2edge, node FFN, rotated W_row /
- *   W_col, readout, the next block's q / k / v: k_node_post_split; 0 when the width-generic node kernels run, jodo_cfg.layout = 1);
- *   JODO_ERR_UNSUPPORTED unless nf is 256 or 384 and cond_ch = 0.  Layout of the buffer: L pair tapes, then L node tapes.
+ *   W_col, readout, the next block's q / k / v: k_node_post_split; 0 when the width-generic node kernels run, jodo_cfg.layout = 1), one
+ *   block's ATTENTION tape (edge_emb, lin_edge0, lin_edge1, cyclic: k_edge_attn variant 4; 0 outside the tuned nf 256 set);
+ *   JODO_ERR_UNSUPPORTED unless nf is 256 or 384 and cond_ch = 0.  Layout of the buffer: L pair tapes, then L node tapes, then L attention tapes.
  * jodo_dgt_pack_split_host: the tapes (hi | mid | lo bf16 terms of every weight, in consumption order) from the same named fp32 tensors
  *   jodo_dgt_pack_weights takes, into a host buffer.
  * jodo_plan_set_split_weights: device copy of that tape for this plan (caller-owned, must outlive the plan's forwards; NULL clears). */
-int jodo_dgt_split_size(const jodo_cfg* cfg, size_t* total_bytes, size_t* pair_block_bytes, size_t* node_block_bytes);
+int jodo_dgt_split_size(const jodo_cfg* cfg, size_t* total_bytes, size_t* pair_block_bytes, size_t* node_block_bytes, size_t* attn_block_bytes);
 int jodo_dgt_pack_split_host(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, void* host, size_t cap_bytes);
 int jodo_plan_set_split_weights(jodo_plan* plan, const void* tape_dev, size_t bytes);
 

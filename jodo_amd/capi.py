@@ -106,8 +106,9 @@ def pack_split_tape(cfg_struct, state_dict, device=None):
         name = k.encode()
         keep.append((t, shp, name))
         arr[i] = JodoTensor(name, t.ctypes.data_as(ctypes.c_void_p), shp, t.ndim)
-    total, per_block, node_block = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
-    check(L.jodo_dgt_split_size(ctypes.byref(cfg_struct), ctypes.byref(total), ctypes.byref(per_block), ctypes.byref(node_block)), 'jodo_dgt_split_size')
+    total, per_block, node_block, attn_block = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    check(L.jodo_dgt_split_size(ctypes.byref(cfg_struct), ctypes.byref(total), ctypes.byref(per_block), ctypes.byref(node_block), ctypes.byref(attn_block)),
+          'jodo_dgt_split_size')
     tape = torch.empty(total.value, dtype=torch.uint8)
     check(L.jodo_dgt_pack_split_host(ctypes.byref(cfg_struct), arr, len(keep), ctypes.c_void_p(tape.data_ptr()), ctypes.c_size_t(total.value)),
           'jodo_dgt_pack_split_host')

@@ -54,7 +54,7 @@ void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
     A.ehid = ws_ptr<float>(ws, w.ehid); A.epred = ws_ptr<float>(ws, w.epred);
     A.e_out = ws_ptr<float>(ws, w.e2);
     A.dposE = ws_ptr<float>(ws, w.dposE); A.gramE = ws_ptr<float>(ws, w.gramE);
-    A.wsplit = nullptr; A.wsplit_node = nullptr; A.mfold_s = nullptr;      // the opt-in split-bf16 kernels: decided per forward (jodo_dgt_forward)
+    A.wsplit = nullptr; A.wsplit_node = nullptr; A.wsplit_attn = nullptr; A.mfold_s = nullptr;      // the opt-in split-bf16 kernels: decided per forward (jodo_dgt_forward)
 }
 
 int rowgemm(hipStream_t st, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* Wp, const float* bias,
@@ -293,13 +293,14 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
         A.mod_base = 32 + (int64_t)l * d.MB;
         for (int i = 0; i < JB_BLOCK_COUNT; ++i) A.wb[i] = woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + i];
         // split-bf16 pair update (opt-in; A.mfold_s != NULL says jodo_dgt_forward found its preconditions met): this block's weight tape
-        A.wsplit = nullptr; A.wsplit_node = nullptr;
+        A.wsplit = nullptr; A.wsplit_node = nullptr; A.wsplit_attn = nullptr;
         if (A.mfold_s) {
-            size_t total = 0, pair_block = 0, node_block = 0;
-            (void)jodo_dgt_split_size(&p->cfg, &total, &pair_block, &node_block);
+            size_t total = 0, pair_block = 0, node_block = 0, attn_block = 0;
+            (void)jodo_dgt_split_size(&p->cfg, &total, &pair_block, &node_block, &attn_block);
             const char* base = static_cast<const char*>(p->split_w);
             A.wsplit = reinterpret_cast<const unsigned short*>(base + (size_t)l * pair_block);
             if (node_block > 0) A.wsplit_node = reinterpret_cast<const unsigned short*>(base + (size_t)d.L * pair_block + (size_t)l * node_block);
+            if (attn_block > 0 && p->opt[JODO_OPT_SPLIT_BF16] == 2) A.wsplit_attn = reinterpret_cast<const unsigned short*>(base + (size_t)d.L * (pair_block + node_block) + (size_t)l * attn_block);
         }
         A.pos_in = posbuf[cur]; A.pos_out = posbuf[cur ^ 1];
         {
@@ -444,10 +445,10 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
     // unconditional, both paths pinned (symmetric inputs, shared modulation row: what a sampler pins after its first self-conditioned
     // evaluation), rotated statistics in their default form, one circulant offset per item, the weight tape handed over — otherwise the
     // exact-fp32 kernels run as always.
-    if (p->opt[JODO_OPT_SPLIT_BF16] == 1 && p->split_w && (d.D == 256 || d.D == 384) && d.cond_ch == 0 && !p->force_directed && p->n_pitems > 0 && p->pitems_single &&
+    if (p->opt[JODO_OPT_SPLIT_BF16] >= 1 && p->split_w && (d.D == 256 || d.D == 384) && d.cond_ch == 0 && !p->force_directed && p->n_pitems > 0 && p->pitems_single &&
         p->opt[JODO_OPT_PIN_SYMMETRIC] == 1 && p->opt[JODO_OPT_PIN_UNIFORM_T] == 1 && p->opt[JODO_OPT_ROT_STATS] == 1) {
-        size_t total = 0, per_block = 0, node_block = 0;
-        if (jodo_dgt_split_size(&p->cfg, &total, &per_block, &node_block) == JODO_OK && total == p->split_bytes)
+        size_t total = 0, per_block = 0, node_block = 0, attn_block = 0;
+        if (jodo_dgt_split_size(&p->cfg, &total, &per_block, &node_block, &attn_block) == JODO_OK && total == p->split_bytes)
             A.mfold_s = ws_ptr<unsigned short>(workspace, p->ws.mfold_s);
     }
     float* posbuf[2] = {ws_ptr<float>(workspace, p->ws.pos0), ws_ptr<float>(workspace, p->ws.pos1)};

@@ -28,6 +28,7 @@
 // SC = 27), all weights streamed.  40 KiB of LDS carry the hand-over buffers.
 #pragma once
 #include "dgt_kernels_sym.h"
+#include "dgt_split.h"
 
 // per-phase cycle sums of the attention kernel (debug builds with -DJODO_PHASE_TIMING_ATTN; tools/phase_timing.py attn)
 #ifdef JODO_PHASE_TIMING_ATTN
@@ -57,10 +58,15 @@ struct AttnT {
     //   VAR 2: everything streamed, all message blocks handed over at once (128 KiB)
     //   VAR 3: edge_emb + the seven main blocks of lin_edge0 in LDS (88 KiB), its tail block streamed, four blocks per
     //          hand-over (64 KiB): exactly the 160 KiB of a CU
+    //   VAR 4 (OPT-IN, JODO_OPT_SPLIT_BF16): the split-bf16 form — every projection operand as three bf16 terms (dgt_split.h), all three
+    //          weight sets streamed through ONE LDS ring shared by the four waves (the cyclic tape of dgt_pack.cpp: edge_emb, lin_edge0,
+    //          lin_edge1 in consumption order, 80 K16 steps = 240 KiB per pair offset; resident they would be 288 KiB); messages handed
+    //          over block by block as in VAR 0
+    static constexpr bool SPLIT = !WQK_ && VAR_ == 4;
     static constexpr bool LDS_EE = !WQK_ && (VAR_ == 0 || VAR_ == 3);
-    static constexpr bool LDS_L0 = !WQK_ && VAR_ != 2;
+    static constexpr bool LDS_L0 = !WQK_ && VAR_ != 2 && VAR_ != 4;
     static constexpr bool LDS_TAIL = LDS_L0 && VAR_ != 3;          // tail block of lin_edge0 (tuned arrangement) resident too
-    static constexpr int PHB = WQK_ ? 1 : (VAR_ == 0 ? 1 : (VAR_ == 2 ? D_ / 32 : 4));   // message blocks per hand-over phase
+    static constexpr int PHB = WQK_ ? 1 : ((VAR_ == 0 || VAR_ == 4) ? 1 : (VAR_ == 2 ? D_ / 32 : 4));   // message blocks per hand-over phase
     static constexpr int NQB = WQK_ ? 14 : 8;                      // 32-row blocks of q / k / lin_edge0
     static constexpr int KQE = D_ / 32;                            // weight quads per output block for K = De
 #ifndef JODO_X_ATT_PG384                                           // experiment builds (tools/gpu_attn384_ab.sh): -DJODO_X_ATT_...
@@ -75,7 +81,7 @@ struct AttnT {
     static constexpr int PG = (D_ % 256 == 0) ? 8 : (D_ == 384 ? JODO_X_ATT_PG384 : 4);   // quads in flight (must divide KQE)
     static constexpr bool PH = (D_ / 16 == 16) && !(D_ > 256);     // C = 16: a half-lane's registers belong to heads 2b + half only, so it
     static constexpr int NS = PH ? 8 : 16;                         // tracks 8 heads (slot k = head 2k + half) instead of all 16
-    static constexpr bool PREF = !(D_ > 256) || JODO_X_ATT_PREF384 != 0;   // request the next source's edge row one iteration ahead (D/8 registers)
+    static constexpr bool PREF = (!(D_ > 256) || JODO_X_ATT_PREF384 != 0) && !(!WQK_ && VAR_ == 4);   // request the next source's edge row one iteration ahead (D/8 registers; not in the split form: its operands' split images need them)
     static constexpr bool QK2 = false;   // q / k rows two blocks ahead in two register sets: measured SLOWER on MI355X (QM9 B = 2500: attention
                                          // 3.91 -> 4.00 ms/step, 455 -> 490 registers) — the block's wait is issue, not row latency; kept as a switch
     static constexpr bool LDSS = D_ > 256 && JODO_X_ATT_LDSS384 != 0;   // running softmax state in LDS (registers are short at nf = 384:
@@ -120,6 +126,8 @@ struct AttnW {
     WSrc ws;
     unsigned oEE, oL0, oL1;
     WPipe<X::PG> wp;
+    splitc::TapeC T;        // SPLIT: the shared weight tape and the chunk this wave consumes next
+    int g;
 };
 
 // one K = De output block; `cur` / `nxt` are byte offsets for the streamed case, `wl` the LDS block for the resident case
@@ -142,6 +150,24 @@ __device__ __forceinline__ void attn_edge_input(const KArgs& A, AttnW<X>& w, con
     const float* bEE = cst + A.wb[JB_EE_B];
     float G[X::HE];
     gbf_n<X::NE>(d2, gscale, gshift, tab, half, G);
+    if constexpr (X::SPLIT) {
+        static_assert(X::HE == 32, "split form: nf 256");
+        Split8 Gs[4], es[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { Gs[q] = split8(&G[8 * q]); es[q] = split8(&e[8 * q]); }
+#pragma unroll
+        for (int b = 0; b < X::NE; ++b) {
+            float bb[16];
+            load16(bEE + b * 32 + half * 16, bb);
+            f32x16 acc = splitc::block4(w.T, w.g, Gs, zero16());
+            acc = splitc::block4(w.T, w.g, es, acc);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) x[b * 16 + s] = acc[s] + bb[s];
+        }
+        layer_norm<X::HE>(x);
+        modulate<X::NE>(x, es1, ec1, half);
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < X::NE; ++b) {
         const unsigned cg = w.oEE + (unsigned)(b * 2 * X::KQE) * 1024, ce = cg + X::KQE * 1024;
@@ -170,7 +196,7 @@ __device__ __forceinline__ void attn_rows(const BRow& qi, const BRow& ki, const 
 template <typename X, bool BOTH>
 __device__ __forceinline__ void attn_scores(AttnW<X>& w, const float (&x)[X::HE], const BRow& qi, const BRow& ki, const BRow& qj,
                                             const BRow& kj, int half, int f1, int f2, float (&S1)[16], float (&S2)[16],
-                                            QKRows (&rows)[X::QK2 ? 2 : 1]) {
+                                            QKRows (&rows)[X::QK2 ? 2 : 1], const Split8* xs = nullptr) {
     // rows[b & 1] (QK2) / rows[0] holds block b on entry to iteration b: blocks 0 (and 1) were requested by the caller
     constexpr int NM = X::WQK ? 14 : 7;                 // blocks reduced per head / per head pair
     float m1[X::WQK ? 1 : 7], m2[X::WQK ? 1 : 7];
@@ -193,7 +219,9 @@ __device__ __forceinline__ void attn_scores(AttnW<X>& w, const float (&x)[X::HE]
         };
         if constexpr (X::LDS_L0) pipeline_fence();
         const unsigned cur = w.oL0 + (unsigned)(b * X::KQE) * 1024;
-        f32x16 acc = attn_block<X, X::LDS_L0>(w, w.wL0 + (b * X::KQE) * 64, cur, b + 1 < X::NQB ? cur + X::KQE * 1024 : w.oL1, x, zero16(), next_rows);
+        f32x16 acc;
+        if constexpr (X::SPLIT) { next_rows(); pipeline_fence(); acc = splitc::block4(w.T, w.g, xs, zero16()); }
+        else acc = attn_block<X, X::LDS_L0>(w, w.wL0 + (b * X::KQE) * 64, cur, b + 1 < X::NQB ? cur + X::KQE * 1024 : w.oL1, x, zero16(), next_rows);
         float tt[16];
         tanh16(acc, tt);
         f32x2 s1a = {0.f, 0.f}, s1b = s1a, s2a = s1a, s2b = s1a;   // partial sums on the packed pipe, two chains per direction
@@ -219,7 +247,9 @@ __device__ __forceinline__ void attn_scores(AttnW<X>& w, const float (&x)[X::HE]
     }
     if constexpr (!X::WQK) {                           // tuned: half h of block b = head 2b + h (channels 0..15); tail block:
         float tl1[14], tl2[14];                        // register g of half h = head g, channel 16 + h
-        f32x16 acc = attn_block<X, X::LDS_TAIL>(w, w.wL0 + (7 * X::KQE) * 64, w.oL0 + (unsigned)(7 * X::KQE) * 1024, w.oL1, x, zero16());
+        f32x16 acc;
+        if constexpr (X::SPLIT) acc = splitc::block4(w.T, w.g, xs, zero16());
+        else acc = attn_block<X, X::LDS_TAIL>(w, w.wL0 + (7 * X::KQE) * 64, w.oL0 + (unsigned)(7 * X::KQE) * 1024, w.oL1, x, zero16());
 #pragma unroll
         for (int g = 0; g < 14; ++g) {
             const float tt = tanh_f(acc[g]);
@@ -278,7 +308,19 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
     w.oEE = (unsigned)(A.wb[JB_EE_W] * 4); w.oL0 = (unsigned)(A.wb[JB_LE0_W] * 4); w.oL1 = (unsigned)(A.wb[JB_LE1_W] * 4);
     // first block of the streamed ring of one iteration
     const unsigned ring0 = !X::LDS_EE ? w.oEE : ((X::LDS_L0 && !X::LDS_TAIL) ? w.oL0 + (unsigned)(7 * X::KQE) * 1024 : w.oL1);
-    wpipe_prime(w.wp, w.ws, ring0);
+    if constexpr (X::SPLIT) {
+        // the cyclic tape of this block (A.wsplit_attn): 2 x 8 + 8 x 4 + 8 x 4 = 80 steps = 20 chunks per pair offset / source; `wl` is the ring
+        w.T.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A.wsplit_attn), 0, 0x7fffffff, 0x00020000);
+        w.T.period = 20;
+        w.T.ntot = 20 * (t1 - t0);
+        w.T.ld_off = (unsigned)wave * 3072u + (unsigned)lane * 16u;
+        w.T.rd_off = (unsigned)lane * 16u;
+        w.T.ring = reinterpret_cast<char*>(const_cast<float4*>(wl));
+        w.g = 0;
+        if (t0 < t1) splitc::start(w.T);
+    } else {
+        wpipe_prime(w.wp, w.ws, ring0);
+    }
     float sm[X::LDSS ? 1 : X::NS], sl[X::LDSS ? 1 : X::NS];   // running max / sum of this target (X::NS head slots)
     float macc[X::HD];
 #pragma unroll
@@ -343,6 +385,11 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
         QKRows rows[X::QK2 ? 2 : 1];
         if constexpr (PREF) attn_rows<PAIR>(qi, ki, qj, kj, 0, rows[0]);
         attn_edge_input<X>(A, w, e, dx * dx + dy * dy + dz * dz, gscale, gshift, mrow, half, x);
+        Split8 xs[X::SPLIT ? 4 : 1];                    // SPLIT: et as split operands, for the 16 projection blocks of scores and messages
+        if constexpr (X::SPLIT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xs[q] = split8(&x[8 * q]);
+        }
         APT(1);
         if constexpr (PREF) {
             cur = source(t + 1 < t1 ? t + 1 : t);      // next source: its row, position and flags are requested now
@@ -355,7 +402,7 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
         float Sa[X::NS], R[X::LDSS ? 1 : X::NS];           // scores of the own source / of the handed-over source per head slot
         {
             float S1[16], S2[16];
-            attn_scores<X, PAIR>(w, x, qi, ki, qj, kj, half, fl1, fl2, S1, S2, rows);
+            attn_scores<X, PAIR>(w, x, qi, ki, qj, kj, half, fl1, fl2, S1, S2, rows, xs);
             float Sb[X::NS];
 #pragma unroll
             for (int k = 0; k < X::NS; ++k) {
@@ -437,7 +484,9 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
             };
             if (PAIR && X::PHB > 1 && b > 0 && b % X::PHB == 0) __syncthreads();      // the previous phase has been read everywhere
             const unsigned cur = w.oL1 + (unsigned)(b * X::KQE) * 1024;
-            f32x16 acc = mfma_block_p2<X::KQE>(w.wp, w.ws, cur, w.ws, b + 1 < X::ND ? cur + X::KQE * 1024 : ring0, x, zero16(), next_rows);
+            f32x16 acc;
+            if constexpr (X::SPLIT) { next_rows(); pipeline_fence(); acc = splitc::block4(w.T, w.g, xs, zero16()); }
+            else acc = mfma_block_p2<X::KQE>(w.wp, w.ws, cur, w.ws, b + 1 < X::ND ? cur + X::KQE * 1024 : ring0, x, zero16(), next_rows);
             float T[16];
             tanh16(acc, T);
             float sc_lo, sc_hi, p1_lo, p1_hi, p2_lo = 0.f, p2_hi = 0.f;
@@ -531,6 +580,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
     const bool pers = PAIR && A.pd.a_persist != 0;
     const int it0 = pers ? A.pd.aw_off[blockIdx.x] : (int)blockIdx.x, it1 = pers ? A.pd.aw_off[blockIdx.x + 1] : (int)blockIdx.x + 1;
     __shared__ float4 wl[(X::LDS_EE ? 32 * 64 : 0) + (X::LDS_L0 ? (X::LDS_TAIL ? 64 : 56) * 64 : 0) + (X::LDS_EE && !X::LDS_TAIL ? 0 : 1)];   // edge_emb (2 x 16 quads) | lin_edge0 (8 x 8 quads)
+    __shared__ float4 ringc[X::SPLIT ? splitc::RING_SLOTS * splitc::CH_BYTES / 16 : 1];   // SPLIT: the shared weight ring (36 KiB)
     __shared__ float4 sx[PAIR ? 2 * 256 : 1];            // scores handed to the partner: [quad][half * 128 + lane], heads 8h .. 8h + 7
     __shared__ float4 ux[PAIR ? (X::PHB == 1 ? 2 : X::PHB) * 4 * 256 : 1];   // unweighted messages: one block double buffered, or a phase of PHB blocks
     __shared__ float stt[X::LDSS ? 5 * 16 * 256 : 1];    // per thread: running max, sum | rescale, p(own source), p(handed-over source)
@@ -541,10 +591,15 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
         if (it > it0) __syncthreads();                  // the hand-over buffers of the previous item have been read everywhere
         if constexpr (PAIR) {
             const int grp = A.pd.ai_group[it], t0 = A.pd.ai_t0[it], t1 = A.pd.ai_t1[it], part = A.pd.ai_part[it];
-            if (A.pd.ai_dir[it]) attn_item<X, false>(A, wl, sx, ux, stt, grp, t0, t1, part);
-            else attn_item<X, true>(A, wl, sx, ux, stt, grp, t0, t1, part);
+            const float4* wl_ = X::SPLIT ? ringc : wl;
+            if constexpr (X::SPLIT) {                   // (the launcher takes this variant only for plans without directed-mode items in the pair
+                attn_item<X, true>(A, wl_, sx, ux, stt, grp, t0, t1, part);      // launch: a second item body doubles the kernel and spills)
+            } else {
+            if (A.pd.ai_dir[it]) attn_item<X, false>(A, wl_, sx, ux, stt, grp, t0, t1, part);
+            else attn_item<X, true>(A, wl_, sx, ux, stt, grp, t0, t1, part);
+            }
         } else {
-            attn_item<X, false>(A, wl, sx, ux, stt, A.pd.ad_group[it], A.pd.ad_t0[it], A.pd.ad_t1[it], A.pd.ad_part[it]);
+            attn_item<X, false>(A, X::SPLIT ? ringc : wl, sx, ux, stt, A.pd.ad_group[it], A.pd.ad_t0[it], A.pd.ad_t1[it], A.pd.ad_part[it]);
         }
     }
 }

@@ -39,6 +39,7 @@ struct KArgs {
     // opt-in split-bf16 pair update (JODO_OPT_SPLIT_BF16, dgt_kernels_split.h): the static weight tape of the current block (NULL = off)
     // and the split image of the folded coord_mlp.0 matrices of all blocks (k_fold_coord writes it when mfold_s != NULL)
     const unsigned short* wsplit;
+    const unsigned short* wsplit_attn;    // the cyclic tape of the fused attention kernel (k_edge_attn<., ., ., 4>), NULL = off
     const unsigned short* wsplit_node;    // the same for the node kernel of the tuned nf 256 set (k_node_post_split), NULL = off
     unsigned short* mfold_s;
     int* flags;

@@ -521,12 +521,17 @@ static int split_tape_steps(const DgtDims& d) {
 //   4c .. 4c + 3 | for b = 0 .. 7: Q P W_row block b, Q P W_col block b (the rotated images, dgt_pack.cpp rot_stats) | node_l readout
 //   (2 blocks) | the NEXT block's lin_query, lin_key, lin_value (8 blocks each, the tuned q / k arrangement; zero for the last block)
 static int split_node_tape_steps(const DgtDims& d) {
-    if (d.wide) return 0;
+    if (d.wide || d.D != 256) return 0;
     return 2 * 16 + d.r * 4 * (2 * 16 + 8 * 4) + 16 * 16 + 2 * 16 + 24 * 16;
 }
 
+// The ATTENTION tape (tuned nf = 256 kernel set; k_edge_attn variant 4), per block and CYCLIC — the same 80 steps for every pair offset:
+//   block edge_emb: output blocks 0, 1, 8 steps each ([G ; e]: 4 + 4) | lin_edge0: blocks 0 .. 7 in the tuned q / k arrangement, 4 steps
+//   each | lin_edge1: blocks 0 .. 7, 4 steps each
+static int split_attn_tape_steps(const DgtDims& d) { return (d.wide || d.D != 256) ? 0 : 2 * 8 + 8 * 4 + 8 * 4; }
+
 static int pack_split_tape(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, std::vector<uint16_t>& tape, size_t* block_elems,
-                           size_t* node_block_elems) {
+                           size_t* node_block_elems, size_t* attn_block_elems) {
     DgtDims d;
     int rc = dgt_dims_from_cfg(cfg, &d);
     if (rc != JODO_OK) return rc;
@@ -623,6 +628,28 @@ static int pack_split_tape(const jodo_cfg* cfg, const jodo_tensor* tensors, int 
             if (tape.size() - at0 != node_block) return jodo_set_error(JODO_ERR_ARG, "pack_split: internal node tape size");
         }
     }
+    // ---- attention tapes behind the node tapes ----
+    const size_t attn_block = (size_t)split_attn_tape_steps(d) * STEP;
+    *attn_block_elems = attn_block;
+    if (attn_block > 0) {
+        const int QK = d.SH * d.SC;
+        const OMap qk = qk_out(d.SH, d.SC);
+        for (int l = 0; l < L; ++l) {
+            const std::string b = "e_block_" + std::to_string(l), a = b + ".attn_mpnn";
+            const float* wee = lk.get(b + ".edge_emb.weight", (int64_t)De * 2 * De);
+            const float* wl0 = lk.get(a + ".lin_edge0.weight", (int64_t)QK * De);
+            const float* wl1 = lk.get(a + ".lin_edge1.weight", (int64_t)D * De);
+            if (!wee || !wl0 || !wl1) return jodo_set_error(JODO_ERR_ARG, "pack_split: missing or mis-sized tensor '%s'", lk.missing.c_str());
+            const size_t at0 = tape.size();
+            const std::vector<uint16_t> pee = pack_proj_split(wee, 2 * De, cat(nat_in(De), nat_in(De, De)), nat_out(De));
+            const std::vector<uint16_t> p0 = pack_proj_split(wl0, De, nat_in(De), qk);
+            const std::vector<uint16_t> p1 = pack_proj_split(wl1, De, nat_in(De), nat_out(D));
+            for (int blk = 0; blk < 2; ++blk) slice(pee, 8, blk, 0, 8);
+            for (int blk = 0; blk < 8; ++blk) slice(p0, 4, blk, 0, 4);
+            for (int blk = 0; blk < 8; ++blk) slice(p1, 4, blk, 0, 4);
+            if (tape.size() - at0 != attn_block) return jodo_set_error(JODO_ERR_ARG, "pack_split: internal attention tape size");
+        }
+    }
     return JODO_OK;
 }
 
@@ -644,22 +671,23 @@ extern "C" int jodo_debug_pack_split(const float* W, int n_out, int n_in, float*
 
 // The static weight tape of the opt-in split-bf16 pair update: sizes, then the tape itself into a host buffer (the caller uploads it
 // and hands the device copy to jodo_plan_set_split_weights).
-extern "C" int jodo_dgt_split_size(const jodo_cfg* cfg, size_t* total_bytes, size_t* pair_block_bytes, size_t* node_block_bytes) {
-    if (!cfg || !total_bytes || !pair_block_bytes || !node_block_bytes) return jodo_set_error(JODO_ERR_ARG, "split_size: null argument");
+extern "C" int jodo_dgt_split_size(const jodo_cfg* cfg, size_t* total_bytes, size_t* pair_block_bytes, size_t* node_block_bytes, size_t* attn_block_bytes) {
+    if (!cfg || !total_bytes || !pair_block_bytes || !node_block_bytes || !attn_block_bytes) return jodo_set_error(JODO_ERR_ARG, "split_size: null argument");
     DgtDims d;
     const int rc = dgt_dims_from_cfg(cfg, &d);
     if (rc != JODO_OK) return rc;
     if ((d.D != 256 && d.D != 384) || d.cond_ch != 0) return jodo_set_error(JODO_ERR_UNSUPPORTED, "split-bf16 form: built for nf = 256 / 384 unconditional models (got nf %d, cond_ch %d)", d.D, d.cond_ch);
     *pair_block_bytes = (size_t)split_tape_steps(d) * 3072;
     *node_block_bytes = (size_t)split_node_tape_steps(d) * 3072;
-    *total_bytes = (*pair_block_bytes + *node_block_bytes) * d.L;
+    *attn_block_bytes = (size_t)split_attn_tape_steps(d) * 3072;
+    *total_bytes = (*pair_block_bytes + *node_block_bytes + *attn_block_bytes) * d.L;
     return JODO_OK;
 }
 extern "C" int jodo_dgt_pack_split_host(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, void* host, size_t cap_bytes) {
     if (!cfg || !tensors || !host) return jodo_set_error(JODO_ERR_ARG, "pack_split: null argument");
     std::vector<uint16_t> tape;
-    size_t per_block = 0, node_block = 0;
-    const int rc = pack_split_tape(cfg, tensors, n_tensors, tape, &per_block, &node_block);
+    size_t per_block = 0, node_block = 0, attn_block = 0;
+    const int rc = pack_split_tape(cfg, tensors, n_tensors, tape, &per_block, &node_block, &attn_block);
     if (rc != JODO_OK) return rc;
     if (tape.size() * sizeof(uint16_t) > cap_bytes) return jodo_set_error(JODO_ERR_ARG, "pack_split: buffer of %zu bytes, need %zu", cap_bytes, tape.size() * sizeof(uint16_t));
     std::memcpy(host, tape.data(), tape.size() * sizeof(uint16_t));

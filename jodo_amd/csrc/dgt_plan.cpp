@@ -331,6 +331,8 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
         for (const It& it : pit) { ai_group.push_back(it.g); ai_t0.push_back(it.t0); ai_t1.push_back(it.t1); ai_part.push_back(it.part); }
         ai_dir.assign(pit.size(), 0);
         for (size_t i = 0; i < pit_dir.size(); ++i) ai_dir[i] = pit_dir[i];
+        p->n_ai_dir = 0;
+        for (size_t i = 0; i < ai_dir.size(); ++i) p->n_ai_dir += ai_dir[i] ? 1 : 0;
         for (const It& it : dit) { ad_group.push_back(it.g); ad_t0.push_back(it.t0); ad_t1.push_back(it.t1); ad_part.push_back(it.part); ad_big.push_back(it.big); }
         p->n_aitems = (int)pit.size(); p->n_aditems = (int)dit.size(); p->amax_parts = amax_parts;
         p->a_persist = persist ? 1 : 0;
@@ -549,8 +551,8 @@ extern "C" int jodo_plan_set_option(jodo_plan* p, int option, int value) {
     if (option < 0 || option >= JODO_OPT_COUNT) return jodo_set_error(JODO_ERR_ARG, "plan_set_option: unknown option %d", option);
     if (option == JODO_OPT_NODE_POST_WAVES && value != 0 && value != 1 && value != 2 && value != 4 && value != 12 && value != 14)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: node-post waves per strip must be 0 (auto), 1, 2 or 4");
-    if (option == JODO_OPT_SPLIT_BF16 && value != 0 && value != 1)
-        return jodo_set_error(JODO_ERR_ARG, "plan_set_option: the split-bf16 pair update is a switch (0 or 1), got %d", value);
+    if (option == JODO_OPT_SPLIT_BF16 && (value < 0 || value > 2))
+        return jodo_set_error(JODO_ERR_ARG, "plan_set_option: the split-bf16 form is 0 (off), 1 (pair update + node kernel) or 2 (also the attention kernel: experiments, measured slower), got %d", value);
     if ((option == JODO_OPT_FUSE_NEXT_QKV || option == JODO_OPT_DIR_SPLIT || option == JODO_OPT_NODE_MIX || option == JODO_OPT_HEADS_MIX || option == JODO_OPT_HALF_ROWS || option == JODO_OPT_PRE_EMBED || option == JODO_OPT_AB_PRE) && value != 0 && value != 1)
         return jodo_set_error(JODO_ERR_ARG, "plan_set_option: option %d is a switch (0 or 1), got %d", option, value);
     if (option == JODO_OPT_Z_SPLIT && (value < 0 || value > 2))
@@ -625,8 +627,8 @@ extern "C" int jodo_debug_attn_schedule(const jodo_plan* p, int64_t* o) {
 extern "C" int jodo_plan_set_split_weights(jodo_plan* p, const void* tape_dev, size_t bytes) {
     if (!p) return jodo_set_error(JODO_ERR_ARG, "null plan");
     if (tape_dev) {
-        size_t total = 0, per_block = 0, node_block = 0;
-        const int rc = jodo_dgt_split_size(&p->cfg, &total, &per_block, &node_block);
+        size_t total = 0, per_block = 0, node_block = 0, attn_block = 0;
+        const int rc = jodo_dgt_split_size(&p->cfg, &total, &per_block, &node_block, &attn_block);
         if (rc != JODO_OK) return rc;
         if (bytes != total) return jodo_set_error(JODO_ERR_ARG, "set_split_weights: %zu bytes, this configuration's tape has %zu", bytes, total);
     }

@@ -100,6 +100,7 @@ struct jodo_plan {
     int opt[JODO_OPT_COUNT];         // jodo_plan_set_option values
     const void* split_w;             // jodo_plan_set_split_weights: device tape of the split-bf16 pair update (caller-owned) and its size
     size_t split_bytes;
+    int n_ai_dir;                    // directed-mode items carried by the pair-mode attention launch (molecules above an attention group)
     int pitems_single;               // every pair-update item is exactly one circulant offset (what the split kernel's lock-step workgroups need)
     int gt_cache_full, gt_cache_count;   // Gram tiles whose strips all lie below gt_cache_full (tiles are sorted by their larger strip)
 };

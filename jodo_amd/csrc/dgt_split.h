@@ -117,4 +117,53 @@ __device__ __forceinline__ void mfma_block_s(WPipeS<PG>& p, const WSrc& w, unsig
     }
 }
 
+// ---- cyclic weight tape through an LDS ring (the attention kernel's split form: the same 80 K16 steps for every pair offset) ----
+// Same protocol as the pair update's ring (dgt_kernels_split.h): chunk g lives in slot g % 3; boundary(g) commits chunk g + 1 from the
+// stage registers, barriers, requests chunk g + 2.  Chunk g of the walk is chunk g % period of the tape.
+namespace splitc {
+constexpr int CH_STEPS = 4, CH_BYTES = CH_STEPS * 3072, RING_SLOTS = 3, WAVES = 4;
+struct TapeC {
+    __amdgpu_buffer_rsrc_t rs;
+    int period, ntot;                                // chunks per pass of the tape, chunks of this walk
+    unsigned ld_off, rd_off;
+    char* ring;
+    u32x4 stage[3];
+};
+__device__ __forceinline__ void request(TapeC& T, int g) {
+    if (g >= T.ntot) return;
+    const unsigned base = (unsigned)(g % T.period) * CH_BYTES;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T.stage[i] = __builtin_amdgcn_raw_buffer_load_b128(T.rs, T.ld_off + (unsigned)i * 1024u, base, 0);
+}
+__device__ __forceinline__ void commit(TapeC& T, int g) {
+    if (g >= T.ntot) return;
+    char* dst = T.ring + (g % RING_SLOTS) * CH_BYTES + T.ld_off;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(dst + i * 1024) = T.stage[i];
+}
+__device__ __forceinline__ void start(TapeC& T) {
+    request(T, 0);
+    commit(T, 0);
+    request(T, 1);
+    pipeline_fence();
+}
+// one chunk-aligned block of CH_STEPS steps (every K = De projection block of the attention kernel at nf 256): acc += W_chunk * act
+__device__ __forceinline__ f32x16 block4(TapeC& T, int& g, const Split8* act, f32x16 acc) {
+    commit(T, g + 1);
+    __syncthreads();
+    request(T, g + 2);
+    pipeline_fence();
+    const char* base = T.ring + (g % RING_SLOTS) * CH_BYTES + T.rd_off;
+#pragma unroll
+    for (int w = 0; w < CH_STEPS; ++w) {
+        const bf16x8 wh = as_bf16x8(*reinterpret_cast<const u32x4*>(base + w * 3072));
+        const bf16x8 wm = as_bf16x8(*reinterpret_cast<const u32x4*>(base + w * 3072 + 1024));
+        const bf16x8 wl = as_bf16x8(*reinterpret_cast<const u32x4*>(base + w * 3072 + 2048));
+        acc = mfma_step_s(wh, wm, wl, act[w], acc);
+    }
+    ++g;
+    return acc;
+}
+}  // namespace splitc
+
 }  // namespace jd

@@ -172,7 +172,7 @@ class _DGTBase(nn.Module):
         # step, fp32 accumulation: fp32-equivalent arithmetic, not bit-identical to the default (csrc/dgt_kernels_split.h,
         # JODO_OPT_SPLIT_BF16).  nf 256 (pair update + node kernel) and nf 384 (pair update) unconditional models; ignored elsewhere.  The default path and every headline number
         # stay exact fp32.
-        self.split_bf16 = False
+        self.split_bf16 = False       # True: pair update + node kernel; 'attention': also the attention kernel (experiments: measured slower)
         self._split_tape = None       # (weights key, device uint8 tensor): the split form's static weight tape
 
     # -- C structs ---------------------------------------------------------------------------
@@ -515,7 +515,7 @@ class _DGTBase(nn.Module):
             if self.split_bf16 and self.dims.D in (256, 384) and not self.conditional and not f[4] and f[2]:
                 tape = self._split_weights(plan['ws'].device)
                 capi.check(L.jodo_plan_set_split_weights(plan['handle'], capi.ptr(tape), ctypes.c_size_t(tape.numel())), 'jodo_plan_set_split_weights')
-                capi.check(L.jodo_plan_set_option(plan['handle'], 13, 1), 'jodo_plan_set_option')
+                capi.check(L.jodo_plan_set_option(plan['handle'], 13, 2 if self.split_bf16 == 'attention' else 1), 'jodo_plan_set_option')
                 plan['split_tape'] = tape                     # keeps the device copy alive as long as the plan may use it
 
     def _split_weights(self, device):
