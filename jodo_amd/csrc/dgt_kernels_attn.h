@@ -152,17 +152,32 @@ __device__ __forceinline__ void attn_edge_input(const KArgs& A, AttnW<X>& w, con
     gbf_n<X::NE>(d2, gscale, gshift, tab, half, G);
     if constexpr (X::SPLIT) {
         static_assert(X::HE == 32, "split form: nf 256");
-        Split8 Gs[4], es[4];
+        static_assert(X::NE == 2, "split form: nf 256");
+        // one operand's split image at a time (tape order: the G halves of both output blocks, then the e halves): 128-bit register tuples
+        // are what this kernel runs out of
+        f32x16 acc0, acc1;
+        {
+            Split8 os[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { Gs[q] = split8(&G[8 * q]); es[q] = split8(&e[8 * q]); }
+            for (int q = 0; q < 4; ++q) os[q] = split8(&G[8 * q]);
+            acc0 = splitc::block4(w.T, w.g, os, zero16());
+            acc1 = splitc::block4(w.T, w.g, os, zero16());
+        }
+        {
+            Split8 os[4];
 #pragma unroll
-        for (int b = 0; b < X::NE; ++b) {
+            for (int q = 0; q < 4; ++q) os[q] = split8(&e[8 * q]);
+            acc0 = splitc::block4(w.T, w.g, os, acc0);
+            acc1 = splitc::block4(w.T, w.g, os, acc1);
+        }
+        {
             float bb[16];
-            load16(bEE + b * 32 + half * 16, bb);
-            f32x16 acc = splitc::block4(w.T, w.g, Gs, zero16());
-            acc = splitc::block4(w.T, w.g, es, acc);
+            load16(bEE + half * 16, bb);
 #pragma unroll
-            for (int s = 0; s < 16; ++s) x[b * 16 + s] = acc[s] + bb[s];
+            for (int s = 0; s < 16; ++s) x[s] = acc0[s] + bb[s];
+            load16(bEE + 32 + half * 16, bb);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) x[16 + s] = acc1[s] + bb[s];
         }
         layer_norm<X::HE>(x);
         modulate<X::NE>(x, es1, ec1, half);

@@ -526,7 +526,7 @@ static int split_node_tape_steps(const DgtDims& d) {
 }
 
 // The ATTENTION tape (tuned nf = 256 kernel set; k_edge_attn variant 4), per block and CYCLIC — the same 80 steps for every pair offset:
-//   block edge_emb: output blocks 0, 1, 8 steps each ([G ; e]: 4 + 4) | lin_edge0: blocks 0 .. 7 in the tuned q / k arrangement, 4 steps
+//   block edge_emb: the G halves (4 steps) of output blocks 0, 1, then their e halves | lin_edge0: blocks 0 .. 7 in the tuned q / k arrangement, 4 steps
 //   each | lin_edge1: blocks 0 .. 7, 4 steps each
 static int split_attn_tape_steps(const DgtDims& d) { return (d.wide || d.D != 256) ? 0 : 2 * 8 + 8 * 4 + 8 * 4; }
 
@@ -644,7 +644,8 @@ static int pack_split_tape(const jodo_cfg* cfg, const jodo_tensor* tensors, int 
             const std::vector<uint16_t> pee = pack_proj_split(wee, 2 * De, cat(nat_in(De), nat_in(De, De)), nat_out(De));
             const std::vector<uint16_t> p0 = pack_proj_split(wl0, De, nat_in(De), qk);
             const std::vector<uint16_t> p1 = pack_proj_split(wl1, De, nat_in(De), nat_out(D));
-            for (int blk = 0; blk < 2; ++blk) slice(pee, 8, blk, 0, 8);
+            for (int blk = 0; blk < 2; ++blk) slice(pee, 8, blk, 0, 4);          // the G halves of both output blocks first, then the e halves:
+            for (int blk = 0; blk < 2; ++blk) slice(pee, 8, blk, 4, 8);          // only one operand's split image is live at a time
             for (int blk = 0; blk < 8; ++blk) slice(p0, 4, blk, 0, 4);
             for (int blk = 0; blk < 8; ++blk) slice(p1, 4, blk, 0, 4);
             if (tape.size() - at0 != attn_block) return jodo_set_error(JODO_ERR_ARG, "pack_split: internal attention tape size");

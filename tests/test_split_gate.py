@@ -86,7 +86,8 @@ def test_split_tape_is_the_consumption_order_of_the_pair_update():
     # attention tape of block 1: edge_emb ([G ; e] columns as they are: G first), lin_edge0 in the tuned q / k arrangement, lin_edge1
     attn = both[L * (steps + nsteps) * STEP:].reshape(L, asteps, STEP)
     _, see = _pack(sd['e_block_1.edge_emb.weight'].numpy())
-    assert np.array_equal(attn[1, :16], see.reshape(2 * 8, STEP))
+    see = see.reshape(2, 8, STEP)                                                    # G halves of both blocks first, then the e halves
+    assert np.array_equal(attn[1, :16], np.concatenate([see[0, :4], see[1, :4], see[0, 4:], see[1, 4:]]))
     _, sl1 = _pack(sd['e_block_1.attn_mpnn.lin_edge1.weight'].numpy())
     assert np.array_equal(attn[1, 48:], sl1.reshape(8 * 4, STEP))
     # node tape of block 0: node2edge_lin first, the next block's lin_value last; the last block's q / k / v section is zero
