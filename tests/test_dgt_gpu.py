@@ -371,17 +371,21 @@ def test_nan_guard_zeroes_positions():
     assert x[:, :, :3].abs().max() == 0                      # batch-global reset (mol_gnn.py:587-589)
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("fname,fused_on", [('traj_qm9_anc5.npz', True), ('traj_qm9_anc5.npz', False),
                                             ('traj_geom_anc3.npz', True), ('traj_geom_anc3.npz', False)])
-def test_ancestral_trajectory_with_hip_model(fname, fused_on):
+def test_ancestral_trajectory_with_hip_model(fname, fused_on, split):
     """The reference's recorded trajectory (its own noise draws replayed) with the HIP model; fused_on: the per-step update
-    runs as the fused kernel jodo_sampler_step on the recorded draws (the product path), otherwise op by op in torch."""
+    runs as the fused kernel jodo_sampler_step on the recorded draws (the product path), otherwise op by op in torch.
+    split: the same with the OPT-IN split-bf16 kernels (model.split_bf16; they take over when the sampler pins its paths after the first
+    self-conditioned evaluation) — same reference trajectory, same tolerance, same decodes."""
     from jodo_amd.diffusion import NoiseScheduleVP
     from jodo_amd.sampling import AncestralSampler
     from jodo_amd.utils import get_self_cond_fn
     fx = load_fixture(fname)
     cfg = make_config(str(fx['cfg_name']))
     model = make_model(cfg, int(fx['seed']), DEV, head_gain=float(fx['head_gain']))
+    model.split_bf16 = split
     nm, em = masks(fx['n_nodes'].tolist(), DEV)
     ns = NoiseScheduleVP(cfg.sde.schedule)
     noise = {'node': torch.from_numpy(fx['node_noise']).to(DEV), 'edge': torch.from_numpy(fx['edge_noise']).to(DEV)}
@@ -390,6 +394,7 @@ def test_ancestral_trajectory_with_hip_model(fname, fused_on):
     with torch.no_grad():
         x_mean, e_mean = sampler.sampling(model, torch.from_numpy(fx['z']).to(DEV), nm, em,
                                           torch.from_numpy(fx['edge_z']).to(DEV), None)
+    assert ('split_tape' in model._last_plan) == split          # the split kernels really ran from the pin on (or not at all)
     close(x_mean, torch.from_numpy(fx['x_mean']), atol=1e-3, rtol=0)
     close(e_mean, torch.from_numpy(fx['edge_x_mean']), atol=1e-3, rtol=0)
     check_decodes(cfg, fx, x_mean, e_mean, nm, em)
@@ -435,7 +440,8 @@ def test_drop_in_under_the_references_dataparallel_wrapper(tmp_path):
     assert len(model.module._plans) == 1, "one batch, one plan: the scattered mask views must hit the plan cache"
 
 
-def test_baseline_config0_at_its_own_size_through_get_sampling_fn():
+@pytest.mark.parametrize("split", [False, True])
+def test_baseline_config0_at_its_own_size_through_get_sampling_fn(split):
     """BASELINE.json configs[0] — vpsde_qm9_uncond_jodo, batch 64, 50 ancestral steps — as the REFERENCE ran it on the CPU
     (tests/golden/traj_qm9_cfg0.npz: its own get_sampling_fn, sampling.py:148-232, seeded torch.manual_seed(42)), replayed through this
     package's get_sampling_fn on the GPU: shard=(0, 1) in parity mode re-draws the unsharded run's atom counts and every noise tensor
@@ -451,6 +457,7 @@ def test_baseline_config0_at_its_own_size_through_get_sampling_fn():
     cfg.sampling.steps = int(fx['steps'])
     B = int(fx['batch'])
     model = make_model(cfg, int(fx['model_seed']), DEV, head_gain=float(fx['head_gain']))
+    model.split_bf16 = split                                     # True: the same replay with the opt-in split-bf16 kernels from the pin on
     ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
     fn = JS.get_sampling_fn(cfg, ns, get_node_dist(load_dataset_info(cfg.data.info_name)), B, B, get_data_inverse_scaler(cfg),
                             shard=(0, 1), shard_mode='parity', seed=int(fx['seed']))
@@ -482,8 +489,8 @@ def test_baseline_config0_at_its_own_size_through_get_sampling_fn():
     assert np.allclose(sums['node'], fx['node_noise_sums'], rtol=0, atol=1e-9) and np.allclose(sums['edge'], fx['edge_noise_sums'], rtol=0, atol=1e-9)
     close(rec['x_mean'], torch.from_numpy(fx['x_mean']), atol=1e-3, rtol=0)
     close(rec['edge_x_mean'], torch.from_numpy(fx['edge_x_mean']), atol=1e-3, rtol=0)
-    print("config 0 (B = %d, %d steps) end state vs the reference's: max |dx| %.2e, max |de| %.2e" % (
-        B, int(fx['steps']), (rec['x_mean'].cpu() - torch.from_numpy(fx['x_mean'])).abs().max(),
+    print("config 0 (B = %d, %d steps, split_bf16 = %s) end state vs the reference's: max |dx| %.2e, max |de| %.2e" % (
+        B, int(fx['steps']), split, (rec['x_mean'].cpu() - torch.from_numpy(fx['x_mean'])).abs().max(),
         (rec['edge_x_mean'].cpu() - torch.from_numpy(fx['edge_x_mean'])).abs().max()))
     check_decodes(cfg, fx, rec['x_mean'], rec['edge_x_mean'], rec['nm'], rec['em'])
     # and the molecules the sampling function returned are the decoded tensors, cut to size (mol_process, sampling.py:12-32)
@@ -513,8 +520,8 @@ def test_dpm_solver_trajectory_with_hip_model(fname, fused_on):
     close(ex, torch.from_numpy(fx['edge_x']), atol=1e-3, rtol=0)
 
 
-@pytest.mark.parametrize("fused_on", [True, False])
-def test_ancestral_50_steps_free_running_and_teacher_forced(fused_on):
+@pytest.mark.parametrize("fused_on,split", [(True, False), (False, False), (True, True)])
+def test_ancestral_50_steps_free_running_and_teacher_forced(fused_on, split):
     """K = 50: (a) free-running with the recorded noise (fused_on: updates by jodo_sampler_step), end state within the K-step tolerance and decodes
     bit-exact above margin; (b) teacher-forced: every one of the reference's 50 recorded step inputs through the
     kernels, against the reference's recorded prediction at the single-forward tolerance."""
@@ -524,6 +531,7 @@ def test_ancestral_50_steps_free_running_and_teacher_forced(fused_on):
     fx = load_fixture('traj_qm9_anc50.npz')
     cfg = make_config('vpsde_qm9_uncond_jodo')
     model = make_model(cfg, int(fx['seed']), DEV, head_gain=float(fx['head_gain']))
+    model.split_bf16 = split                                     # (True: 48 of the 50 free-running steps run the opt-in split-bf16 kernels)
     nm, em = masks(fx['n_nodes'].tolist(), DEV)
     ns = NoiseScheduleVP(cfg.sde.schedule)
     steps = int(fx['steps'])
@@ -536,8 +544,9 @@ def test_ancestral_50_steps_free_running_and_teacher_forced(fused_on):
     close(x_mean, torch.from_numpy(fx['x_mean']), atol=1e-3, rtol=0)
     close(e_mean, torch.from_numpy(fx['edge_x_mean']), atol=1e-3, rtol=0)
     check_decodes(cfg, fx, x_mean, e_mean, nm, em)
-    if not fused_on:
-        return                                                   # the teacher-forced half does not depend on the update path
+    assert ('split_tape' in model._last_plan) == split
+    if not fused_on or split:
+        return                                                   # the teacher-forced half does not depend on the update path (and runs unpinned: exact kernels)
     t = lambda k, i: torch.from_numpy(fx[k][i]).to(DEV)
     worst = 0.0
     with torch.no_grad():

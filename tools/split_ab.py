@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--workload', default='qm9', choices=sorted(WL))
 ap.add_argument('--steps', type=int, default=30)
 ap.add_argument('--batch', type=int, default=0)
+ap.add_argument('--round', type=int, default=0, help='also run a complete round of that many ancestral steps with both paths on identical in-kernel noise and compare the decoded molecules')
 args = ap.parse_args()
 cfg_name, info, B = WL[args.workload]
 B = args.batch or B
@@ -75,5 +76,31 @@ for k in a:
         say('after 5 identical-noise steps, state[%s]: max |split - default| %.3e (max |x| %.2f)' % (k, float((a[k] - b[k]).abs().max()), float(a[k].abs().max())))
 bd, bs = min(r[1] for r in res[False]), min(r[1] for r in res[True])
 say('pair update: exact fp32 %.1f us/block -> split bf16x3 %.1f us/block (x%.2f);  step %.3f -> %.3f ms' % (bd, bs, bd / bs, min(r[0] for r in res[False]), min(r[0] for r in res[True])))
+if args.round > 0:
+    # a complete round, both paths on the SAME in-kernel noise stream (Philox keyed by (seed, rank, round)): what SURVEY.md 8c asks of long
+    # runs is a statistical comparison; with identical noise the two paths can be compared molecule by molecule as well
+    import numpy as np
+    ts_r = torch.linspace(ns.T, 1e-3, args.round)
+    dec = {}
+    for split in (False, True):
+        model = deterministic_init_(get_model_class(cfg.model.name)(cfg), seed=cfg.seed).to(dev).eval()
+        model.split_bf16 = split
+        sampler = AncestralSampler(ns, ts_r, True, True, True, get_self_cond_fn(cfg), device_noise=fused.DeviceNoise.for_rank(cfg.seed, 0))
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            x_mean, e_mean = sampler.sampling(model, z, nm, em, ez, None)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            pos, at, fc, et = fused.decode(cfg, x_mean, e_mean, fused.n_nodes_from_mask(nm))
+        dec[split] = (x_mean.cpu(), e_mean.cpu(), pos.cpu(), at.cpu(), fc.cpu(), et.cpu())
+        say('%d-step round, split_bf16=%-5s %.2f s = %.1f molecules/s' % (args.round, split, dt, B / dt))
+    a, b = dec[False], dec[True]
+    real = (nm[..., 0] > 0).cpu()
+    emk = (em.reshape(B, N, N) > 0).cpu()
+    say('end of the %d-step round, split vs default on identical noise: max |x_mean diff| %.3e, max |edge_x_mean diff| %.3e; atom types equal on %.4f of the atoms, '
+        'charges on %.4f, bond types on %.4f of the edges; atom-type histogram default %s split %s' % (
+            args.round, float((a[0] - b[0]).abs().max()), float((a[1] - b[1]).abs().max()), float((a[3] == b[3])[real].float().mean()),
+            float((a[4] == b[4])[real].float().mean()), float((a[5] == b[5])[emk].float().mean()),
+            np.bincount(a[3][real].numpy(), minlength=cfg.data.atom_types).tolist(), np.bincount(b[3][real].numpy(), minlength=cfg.data.atom_types).tolist()))
 os.makedirs('gpurun_out', exist_ok=True)
 open('gpurun_out/split_ab_%s.txt' % args.workload, 'w').write('\n'.join(lines) + '\n')
