@@ -316,7 +316,9 @@ class _DGTBase(nn.Module):
         # plan first: building a plan for a new batch re-checks the weight fingerprint (`.data` updates such as the
         # reference's EMA copy_to / restore) and drops a stale blob BEFORE this call fetches it
         plan = self._plan(node_mask, edge_mask, dev)
-        _, blob, woff_c, n_woff = self._weights(dev)
+        wkey, blob, woff_c, n_woff = self._weights(dev)
+        if plan.get('split_tape') is not None and plan.get('split_key') != wkey:
+            self._hand_over_split(plan)                          # the weights changed under a pinned plan: the split tape follows the blob
         out_x = torch.empty_like(xh_)
         out_e = torch.empty_like(ex_)
         self._launch(plan, blob, woff_c, n_woff, xh_, ex_, cx_, cex_, nl_, ctx_, out_x, out_e)
@@ -513,10 +515,16 @@ class _DGTBase(nn.Module):
             capi.check(L.jodo_plan_set_option(plan['handle'], 5, 1 if f[2] else 2), 'jodo_plan_set_option')
             plan['pinned'] = True
             if self.split_bf16 and self.dims.D in (256, 384) and not self.conditional and not f[4] and f[2]:
-                tape = self._split_weights(plan['ws'].device)
-                capi.check(L.jodo_plan_set_split_weights(plan['handle'], capi.ptr(tape), ctypes.c_size_t(tape.numel())), 'jodo_plan_set_split_weights')
+                self._hand_over_split(plan)
                 capi.check(L.jodo_plan_set_option(plan['handle'], 13, 2 if self.split_bf16 == 'attention' else 1), 'jodo_plan_set_option')
-                plan['split_tape'] = tape                     # keeps the device copy alive as long as the plan may use it
+
+    def _hand_over_split(self, plan):
+        """The split-bf16 weight tape of the CURRENT parameters -> this plan (also called by forward when the packed blob was rebuilt
+        under a pinned plan: an optimiser step or load_state_dict between two calls on the same masks)."""
+        tape = self._split_weights(plan['ws'].device)
+        capi.check(capi.lib().jodo_plan_set_split_weights(plan['handle'], capi.ptr(tape), ctypes.c_size_t(tape.numel())), 'jodo_plan_set_split_weights')
+        plan['split_tape'] = tape                             # keeps the device copy alive as long as the plan may use it
+        plan['split_key'] = self._split_tape[0]
 
     def _split_weights(self, device):
         """Device copy of the split-bf16 weight tape of the current parameters (re-packed when the packed blob is)."""

@@ -186,6 +186,24 @@ def test_split_bf16_pair_update_against_the_default_path_and_float64(cfg_name, n
         outs[split] = (o1, o2)
         if not split:
             sd = state_dict_cpu(model)
+        elif mode is True and len(n_nodes) < 100:
+            # weights changed under the pinned plan (an optimiser step between two calls on the same masks): the split tape follows the
+            # packed blob — the perturbed model's split outputs equal a freshly built perturbed model's, not the stale tape's
+            with torch.no_grad():
+                for p_ in model.parameters():
+                    p_.mul_(1.0 + 1e-3)
+            moved = run(model, first[0], first[1])
+            fresh = make_model(cfg, 13, DEV)
+            with torch.no_grad():
+                for p_ in fresh.parameters():
+                    p_.mul_(1.0 + 1e-3)
+            fresh.split_bf16 = True
+            run(fresh, None, None); run(fresh, first[0], first[1]); fresh.pin_paths()
+            want = run(fresh, first[0], first[1])
+            assert torch.equal(moved[0], want[0]) and torch.equal(moved[1], want[1])
+            with torch.no_grad():
+                for p_ in model.parameters():
+                    p_.div_(1.0 + 1e-3)
     for k in (0, 1):
         for j in (0, 1):
             a, b = outs[True][k][j], outs[False][k][j]
