@@ -203,8 +203,9 @@ enum jodo_plan_option {
                                    * accumulation: fp32-equivalent arithmetic (dropped terms <= 3 * 2^-26 relative; profiles/r06_split_gate.txt)
                                    * at 6/16 of the matrix cycles (csrc/dgt_kernels_split.h).  Results differ from the default path in the
                                    * last bits; the default and every headline number stay exact fp32.  Ignored when a precondition fails.
-                                   * 2 (experiments): also the fused attention kernel (k_edge_attn variant 4, nf 256 tuned set, plans without
-                                   * molecules above an attention group) — parity-tested, measured 3 x SLOWER on MI355X (1.6 KB of scratch per lane), DESIGN.md 4i */
+                                   * 2 (experiments): also the fused attention kernel (k_edge_attn variants 4 + 5: two launches that share every
+                                   * item by heads; nf 256 tuned set, plans without molecules above an attention group) — parity-tested, measured
+                                   * 15 % SLOWER than the fp32 kernel on MI355X (513 against 447 us per block at QM9 B = 2500), DESIGN.md 4i */
     JODO_OPT_COUNT
 };
 int jodo_plan_set_option(jodo_plan* plan, int option, int value);
@@ -410,7 +411,8 @@ int jodo_debug_mfma_valu(int iters, int nv, int nt, int waves_per_simd, float* s
  * jodo_dgt_split_size: bytes of the static weight tapes for this configuration — all of them, one block's PAIR tape (edge FFN, readout,
  *   triangular factor of the rotated statistics: k_edge_update_sym_split), one block's NODE tape (node2edge, node FFN, rotated W_row /
  *   W_col, readout, the next block's q / k / v: k_node_post_split; 0 when the width-generic node kernels run, jodo_cfg.layout = 1), one
- *   block's ATTENTION tape (edge_emb, lin_edge0, lin_edge1, cyclic: k_edge_attn variant 4; 0 outside the tuned nf 256 set);
+ *   block's ATTENTION tapes (two cyclic tapes, one per launch of k_edge_attn variants 4 / 5: edge_emb, that launch's blocks of lin_edge0 and
+ *   lin_edge1; 0 outside the tuned nf 256 set);
  *   JODO_ERR_UNSUPPORTED unless nf is 256 or 384 and cond_ch = 0.  Layout of the buffer: L pair tapes, then L node tapes, then L attention tapes.
  * jodo_dgt_pack_split_host: the tapes (hi | mid | lo bf16 terms of every weight, in consumption order) from the same named fp32 tensors
  *   jodo_dgt_pack_weights takes, into a host buffer.

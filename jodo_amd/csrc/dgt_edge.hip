@@ -79,8 +79,14 @@ int launch_attn(jodo_plan* p, hipStream_t st, KArgs& A, bool pin_pair, bool pin_
     if (p->n_aitems > 0 && !pin_dir) {
         const int var = TUNED ? p->opt[JODO_OPT_ATTN_VARIANT] : 0;
         const int grid = p->a_persist ? JODO_ATT_SLOTS : p->n_aitems;          // persistent: one workgroup per slot of the plan's schedule
-        // opt-in split-bf16 form (JODO_OPT_SPLIT_BF16; jodo_dgt_forward checked the preconditions and set A.wsplit_attn): VAR 4
-        if (TUNED && A.wsplit_attn && pin_pair && p->n_ai_dir == 0) { if constexpr (TUNED) LAUNCH((k_edge_attn<D, false, true, 4>), grid, ATT_WAVES * 64, A); }
+        // opt-in split-bf16 form (JODO_OPT_SPLIT_BF16 = 2; jodo_dgt_forward checked the preconditions and set A.wsplit_attn): two launches,
+        // each half of the heads of every item (VAR 4: message blocks 0 .. 3, VAR 5: 4 .. 7; disjoint halves of every partial)
+        if (TUNED && A.wsplit_attn && pin_pair && p->n_ai_dir == 0) {
+            if constexpr (TUNED) {
+                LAUNCH((k_edge_attn<D, false, true, 4>), grid, ATT_WAVES * 64, A);
+                LAUNCH((k_edge_attn<D, false, true, 5>), grid, ATT_WAVES * 64, A);
+            }
+        }
         else if (var == 1) LAUNCH((k_edge_attn<D, !TUNED, true, TUNED ? 1 : 0>), grid, ATT_WAVES * 64, A);
         else if (var == 2) LAUNCH((k_edge_attn<D, !TUNED, true, TUNED ? 2 : 0>), grid, ATT_WAVES * 64, A);
         else if (var == 3) LAUNCH((k_edge_attn<D, !TUNED, true, TUNED ? 3 : 0>), grid, ATT_WAVES * 64, A);

@@ -58,15 +58,18 @@ struct AttnT {
     //   VAR 2: everything streamed, all message blocks handed over at once (128 KiB)
     //   VAR 3: edge_emb + the seven main blocks of lin_edge0 in LDS (88 KiB), its tail block streamed, four blocks per
     //          hand-over (64 KiB): exactly the 160 KiB of a CU
-    //   VAR 4 (OPT-IN, JODO_OPT_SPLIT_BF16): the split-bf16 form — every projection operand as three bf16 terms (dgt_split.h), all three
-    //          weight sets streamed through ONE LDS ring shared by the four waves (the cyclic tape of dgt_pack.cpp: edge_emb, lin_edge0,
-    //          lin_edge1 in consumption order, 80 K16 steps = 240 KiB per pair offset; resident they would be 288 KiB); messages handed
-    //          over block by block as in VAR 0
-    static constexpr bool SPLIT = !WQK_ && VAR_ == 4;
+    //   VAR 4 / 5 (OPT-IN, JODO_OPT_SPLIT_BF16 = 2): the split-bf16 form — every projection operand as three bf16 terms (dgt_split.h), all
+    //          three weight sets streamed through ONE LDS ring shared by the four waves (the cyclic tapes of dgt_pack.cpp).  The work of an
+    //          item is dealt to TWO launches by heads: VAR 4 owns message blocks 0 .. 3 (head slots 0 .. 3: the adjacency heads and learned
+    //          heads 0 .. 5, lin_edge0 blocks 0 .. 2 + its tail block), VAR 5 message blocks 4 .. 7 (slots 4 .. 7: learned heads 6 .. 13,
+    //          lin_edge0 blocks 3 .. 6 + tail).  Each carries 64 message accumulators instead of 128 — the one-launch form (round 6, first
+    //          attempt) needed 128 accumulators + the split operands, spilled 1.6 KB per lane and ran 3 x slower than the fp32 kernel.  The
+    //          price: the edge input (4 of 20 chunk blocks) is evaluated by both.  Messages handed over block by block as in VAR 0.
+    static constexpr bool SPLIT = !WQK_ && (VAR_ == 4 || VAR_ == 5);
     static constexpr bool LDS_EE = !WQK_ && (VAR_ == 0 || VAR_ == 3);
-    static constexpr bool LDS_L0 = !WQK_ && VAR_ != 2 && VAR_ != 4;
+    static constexpr bool LDS_L0 = !WQK_ && VAR_ != 2 && !SPLIT;
     static constexpr bool LDS_TAIL = LDS_L0 && VAR_ != 3;          // tail block of lin_edge0 (tuned arrangement) resident too
-    static constexpr int PHB = WQK_ ? 1 : ((VAR_ == 0 || VAR_ == 4) ? 1 : (VAR_ == 2 ? D_ / 32 : 4));   // message blocks per hand-over phase
+    static constexpr int PHB = WQK_ ? 1 : ((VAR_ == 0 || SPLIT) ? 1 : (VAR_ == 2 ? D_ / 32 : 4));   // message blocks per hand-over phase
     static constexpr int NQB = WQK_ ? 14 : 8;                      // 32-row blocks of q / k / lin_edge0
     static constexpr int KQE = D_ / 32;                            // weight quads per output block for K = De
 #ifndef JODO_X_ATT_PG384                                           // experiment builds (tools/gpu_attn384_ab.sh): -DJODO_X_ATT_...
@@ -81,11 +84,20 @@ struct AttnT {
     static constexpr int PG = (D_ % 256 == 0) ? 8 : (D_ == 384 ? JODO_X_ATT_PG384 : 4);   // quads in flight (must divide KQE)
     static constexpr bool PH = (D_ / 16 == 16) && !(D_ > 256);     // C = 16: a half-lane's registers belong to heads 2b + half only, so it
     static constexpr int NS = PH ? 8 : 16;                         // tracks 8 heads (slot k = head 2k + half) instead of all 16
-    static constexpr bool PREF = (!(D_ > 256) || JODO_X_ATT_PREF384 != 0) && !(!WQK_ && VAR_ == 4);   // request the next source's edge row one iteration ahead (D/8 registers; not in the split form: its operands' split images need them)
+    static constexpr bool PREF = (!(D_ > 256) || JODO_X_ATT_PREF384 != 0) && !SPLIT;   // request the next source's edge row one iteration ahead (D/8 registers; not in the split form: its operands' split images need them)
     static constexpr bool QK2 = false;   // q / k rows two blocks ahead in two register sets: measured SLOWER on MI355X (QM9 B = 2500: attention
                                          // 3.91 -> 4.00 ms/step, 455 -> 490 registers) — the block's wait is issue, not row latency; kept as a switch
     static constexpr bool LDSS = D_ > 256 && JODO_X_ATT_LDSS384 != 0;   // running softmax state in LDS (registers are short at nf = 384:
                                                                    // D/2 accumulators + D/8 inputs per lane; LDS is free, no resident weights)
+    // the share of one launch: head slots [SL0, SL0 + NSL) (PH: slot k = head 2k + half = message block k), score blocks [SB0, SB1) of
+    // lin_edge0 besides its tail block, learned heads [G0, G1) in the tail block; everything unless SPLIT
+    static constexpr int SL0 = SPLIT && VAR_ == 5 ? 4 : 0, NSL = SPLIT ? 4 : NS;
+    static constexpr int MB0 = SPLIT ? SL0 : 0, MB1 = SPLIT ? SL0 + 4 : D_ / 32;
+    static constexpr int SB0 = SPLIT && VAR_ == 5 ? 3 : 0, SB1 = SPLIT ? (VAR_ == 5 ? 7 : 3) : (WQK_ ? 14 : 7);
+    static constexpr int G0 = SPLIT && VAR_ == 5 ? 6 : 0, G1 = SPLIT && VAR_ == 4 ? 6 : 14;
+    static constexpr int TAPE_CHUNKS = 4 + (SB1 - SB0) + 1 + 4;    // SPLIT: chunks of four K16 steps per pair offset (12 / 13)
+    static constexpr int TAPE_FIRST = VAR_ == 5 ? 12 : 0;          // the second launch's tape follows the first's
+    static_assert(!SPLIT || (PH && D_ == 256), "split form: nf 256, one head slot per message block");
     static constexpr float INV_SQRT_C = D_ == 256 ? 0.25f : (D_ == 384 ? 0.20412414523193150f : (D_ == 128 ? 0.35355339059327379f : 0.f));
     static constexpr int M_EDGE = 6 * D_, M_GBF = 6 * D_ + 6 * (D_ / 4) + 2 * D_;
     static_assert(!(LDS_EE || LDS_L0) || D_ == 256, "LDS-resident weights are sized for nf = 256");
@@ -213,12 +225,11 @@ __device__ __forceinline__ void attn_scores(AttnW<X>& w, const float (&x)[X::HE]
                                             const BRow& kj, int half, int f1, int f2, float (&S1)[16], float (&S2)[16],
                                             QKRows (&rows)[X::QK2 ? 2 : 1], const Split8* xs = nullptr) {
     // rows[b & 1] (QK2) / rows[0] holds block b on entry to iteration b: blocks 0 (and 1) were requested by the caller
-    constexpr int NM = X::WQK ? 14 : 7;                 // blocks reduced per head / per head pair
-    float m1[X::WQK ? 1 : 7], m2[X::WQK ? 1 : 7];
+    float m1[X::WQK ? 1 : 7], m2[X::WQK ? 1 : 7];       // blocks reduced per head / per head pair
     S1[0] = (f1 & 1) ? 1.f : -1e10f; S1[1] = (f1 & 2) ? 1.f : -1e10f;           // extra heads, 0 -> -1e10 (layers.py:170-174)
     S2[0] = (f2 & 1) ? 1.f : -1e10f; S2[1] = (f2 & 2) ? 1.f : -1e10f;
 #pragma unroll
-    for (int b = 0; b < NM; ++b) {
+    for (int b = X::SB0; b < X::SB1; ++b) {
         float a1[16], a2[16];
         QKRows& R = rows[X::QK2 ? (b & 1) : 0];
 #pragma unroll
@@ -230,7 +241,8 @@ __device__ __forceinline__ void attn_scores(AttnW<X>& w, const float (&x)[X::HE]
         }
         auto next_rows = [&]() {                       // the set just consumed takes the block two (one) ahead
             constexpr int AHEAD = X::QK2 ? 2 : 1;
-            if (b + AHEAD < X::NQB) attn_rows<BOTH>(qi, ki, qj, kj, b + AHEAD, R);
+            if constexpr (X::SPLIT) attn_rows<BOTH>(qi, ki, qj, kj, b + 1 < X::SB1 ? b + 1 : X::NQB - 1, R);   // after its share: the tail block
+            else if (b + AHEAD < X::NQB) attn_rows<BOTH>(qi, ki, qj, kj, b + AHEAD, R);
         };
         if constexpr (X::LDS_L0) pipeline_fence();
         const unsigned cur = w.oL0 + (unsigned)(b * X::KQE) * 1024;
@@ -266,14 +278,14 @@ __device__ __forceinline__ void attn_scores(AttnW<X>& w, const float (&x)[X::HE]
         if constexpr (X::SPLIT) acc = splitc::block4(w.T, w.g, xs, zero16());
         else acc = attn_block<X, X::LDS_TAIL>(w, w.wL0 + (7 * X::KQE) * 64, w.oL0 + (unsigned)(7 * X::KQE) * 1024, w.oL1, x, zero16());
 #pragma unroll
-        for (int g = 0; g < 14; ++g) {
+        for (int g = X::G0; g < X::G1; ++g) {
             const float tt = tanh_f(acc[g]);
             const QKRows& R = rows[X::QK2 ? ((X::NQB - 1) & 1) : 0];
             tl1[g] = tt * R.qi[g] * R.kj[g];
             tl2[g] = BOTH ? tt * R.qj[g] * R.ki[g] : 0.f;
         }
 #pragma unroll
-        for (int g = 0; g < 14; ++g) {
+        for (int g = X::G0; g < X::G1; ++g) {
             const float o1 = ((g & 1) == half) ? m1[g >> 1] : 0.f;
             const float o2 = ((g & 1) == half) ? m2[g >> 1] : 0.f;
             S1[2 + g] = pair_sum(o1 + tl1[g]) * X::INV_SQRT_C;
@@ -324,10 +336,10 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
     // first block of the streamed ring of one iteration
     const unsigned ring0 = !X::LDS_EE ? w.oEE : ((X::LDS_L0 && !X::LDS_TAIL) ? w.oL0 + (unsigned)(7 * X::KQE) * 1024 : w.oL1);
     if constexpr (X::SPLIT) {
-        // the cyclic tape of this block (A.wsplit_attn): 2 x 8 + 8 x 4 + 8 x 4 = 80 steps = 20 chunks per pair offset / source; `wl` is the ring
-        w.T.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A.wsplit_attn), 0, 0x7fffffff, 0x00020000);
-        w.T.period = 20;
-        w.T.ntot = 20 * (t1 - t0);
+        // the cyclic tape of this launch's share (A.wsplit_attn: 12 chunks of four K16 steps for VAR 4, then 13 for VAR 5); `wl` is the ring
+        w.T.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A.wsplit_attn) + (size_t)X::TAPE_FIRST * (splitc::CH_BYTES / 2), 0, 0x7fffffff, 0x00020000);
+        w.T.period = X::TAPE_CHUNKS;
+        w.T.ntot = X::TAPE_CHUNKS * (t1 - t0);
         w.T.ld_off = (unsigned)wave * 3072u + (unsigned)lane * 16u;
         w.T.rd_off = (unsigned)lane * 16u;
         w.T.ring = reinterpret_cast<char*>(const_cast<float4*>(wl));
@@ -339,12 +351,12 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
     float sm[X::LDSS ? 1 : X::NS], sl[X::LDSS ? 1 : X::NS];   // running max / sum of this target (X::NS head slots)
     float macc[X::HD];
 #pragma unroll
-    for (int h = 0; h < X::NS; ++h) {
+    for (int h = X::SL0; h < X::SL0 + X::NSL; ++h) {
         if constexpr (X::LDSS) { stc[h * 256] = ATT_NEG; stc[(16 + h) * 256] = 0.f; }
         else { sm[h] = ATT_NEG; sl[h] = 0.f; }
     }
 #pragma unroll
-    for (int s = 0; s < X::HD; ++s) macc[s] = 0.f;
+    for (int s = X::MB0 * 16; s < X::MB1 * 16; ++s) macc[s] = 0.f;
     const int slot = half * ATT_LANES + ln;             // this lane's slot in the hand-over buffers
     // the source of iteration t (pair mode: partner (i + t + 1) mod n and the lane that hands its result over)
     struct Src { bool ok, rok; int u, rln; size_t r_in, r_out; };
@@ -398,7 +410,7 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
         const BRow qi = brow(A.q, X::NQB, L.v, half), ki = brow(A.k, X::NQB, L.v, half);
         const BRow qj = brow(A.q, X::NQB, u, half), kj = brow(A.k, X::NQB, u, half);
         QKRows rows[X::QK2 ? 2 : 1];
-        if constexpr (PREF) attn_rows<PAIR>(qi, ki, qj, kj, 0, rows[0]);
+        if constexpr (PREF) attn_rows<PAIR>(qi, ki, qj, kj, X::SB0, rows[0]);
         attn_edge_input<X>(A, w, e, dx * dx + dy * dy + dz * dz, gscale, gshift, mrow, half, x);
         Split8 xs[X::SPLIT ? 4 : 1];                    // SPLIT: et as split operands, for the 16 projection blocks of scores and messages
         if constexpr (X::SPLIT) {
@@ -410,7 +422,7 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
             cur = source(t + 1 < t1 ? t + 1 : t);      // next source: its row, position and flags are requested now
             request();
         } else {
-            attn_rows<PAIR>(qi, ki, qj, kj, 0, rows[0]);
+            attn_rows<PAIR>(qi, ki, qj, kj, X::SB0, rows[0]);
         }
         if constexpr (X::QK2) attn_rows<PAIR>(qi, ki, qj, kj, 1, rows[1]);   // second set: requested behind the edge-input projections
         // ---- scores ----
@@ -420,12 +432,14 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
             attn_scores<X, PAIR>(w, x, qi, ki, qj, kj, half, fl1, fl2, S1, S2, rows, xs);
             float Sb[X::NS];
 #pragma unroll
-            for (int k = 0; k < X::NS; ++k) {
+            for (int k = X::SL0; k < X::SL0 + X::NSL; ++k) {
                 Sa[k] = X::PH ? (half ? S1[2 * k + 1] : S1[2 * k]) : S1[k];
                 Sb[k] = X::PH ? (half ? S2[2 * k + 1] : S2[2 * k]) : S2[k];
             }
             if (PAIR) {                                 // PH: a half hands its 8 slots to the same half of the partner; otherwise half h
-                if constexpr (X::PH) {                  // hands over heads 8h .. 8h + 7 and the receiver reads both halves
+                if constexpr (X::SPLIT) {               // the launch's four slots
+                    sx[slot] = make_float4(Sb[X::SL0], Sb[X::SL0 + 1], Sb[X::SL0 + 2], Sb[X::SL0 + 3]);
+                } else if constexpr (X::PH) {           // hands over heads 8h .. 8h + 7 and the receiver reads both halves
                     sx[slot] = make_float4(Sb[0], Sb[1], Sb[2], Sb[3]);
                     sx[256 + slot] = make_float4(Sb[4], Sb[5], Sb[6], Sb[7]);
                 } else {
@@ -439,12 +453,15 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
         const BRow vj = brow(A.v, X::ND, u, half), vi = brow(A.v, X::ND, L.v, half);
         float vjn[16], vin[16];
         if constexpr (PREF) {
-            bload16(vj, 0, vjn);
-            if (PAIR) bload16(vi, 0, vin);
+            bload16(vj, X::MB0, vjn);
+            if (PAIR) bload16(vi, X::MB0, vin);
         }
         if (PAIR) {
             __syncthreads();
-            if constexpr (X::PH) {
+            if constexpr (X::SPLIT) {
+                const float4 a = sx[half * ATT_LANES + rln];
+                R[X::SL0] = a.x; R[X::SL0 + 1] = a.y; R[X::SL0 + 2] = a.z; R[X::SL0 + 3] = a.w;
+            } else if constexpr (X::PH) {
                 const float4 a = sx[half * ATT_LANES + rln], b = sx[256 + half * ATT_LANES + rln];
                 R[0] = a.x; R[1] = a.y; R[2] = a.z; R[3] = a.w; R[4] = b.x; R[5] = b.y; R[6] = b.z; R[7] = b.w;
             } else if constexpr (!X::LDSS) {
@@ -457,7 +474,7 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
         // ---- running softmax of this target: up to two new sources ----
         float sc[X::LDSS ? 1 : X::NS], p1[X::LDSS ? 1 : X::NS], p2[X::LDSS ? 1 : X::NS];
 #pragma unroll
-        for (int h = 0; h < X::NS; ++h) {
+        for (int h = X::SL0; h < X::SL0 + X::NSL; ++h) {
             const float m0 = X::LDSS ? stc[h * 256] : sm[h];
             // head h of the partner's hand-over: quad (h & 7) / 4 of half-slot h / 8, component h & 3
             const float rh = !PAIR ? 0.f : (X::LDSS ? reinterpret_cast<const float*>(sx + ((h & 7) / 4) * 256 + (h / 8) * ATT_LANES + rln)[h & 3] : R[h]);
@@ -480,11 +497,11 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
         // ---- messages: T1 = tanh(lin_edge1 x) once; own direction v_j * T1, partner's direction v_i * T1 ----
         const int rslot = half * ATT_LANES + rln;
         if constexpr (!PREF) {
-            bload16(vj, 0, vjn);
-            if (PAIR) bload16(vi, 0, vin);
+            bload16(vj, X::MB0, vjn);
+            if (PAIR) bload16(vi, X::MB0, vin);
         }
 #pragma unroll
-        for (int b = 0; b < X::ND; ++b) {
+        for (int b = X::MB0; b < X::MB1; ++b) {
             float vv[16], vo[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) { vv[s] = vjn[s]; vo[s] = PAIR ? vin[s] : 0.f; }
@@ -492,7 +509,7 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
             // gather ahead of the prefetch would have to land before the next block's MFMAs may start, behind it only
             // before their epilogue)
             auto next_rows = [&]() {
-                if (b + 1 < X::ND) {
+                if (b + 1 < X::MB1) {
                     bload16(vj, b + 1, vjn);
                     if (PAIR) bload16(vi, b + 1, vin);
                 }
@@ -559,11 +576,20 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
     APT(5);
     // ---- partial of this item: unnormalised sums + (max, sum) per head ----
     if (L.valid) {
-        store_nat<X::ND>(A.hhat + ((size_t)L.v * A.pd.amax_parts + part) * D, half, macc);
+        float* hrow = A.hhat + ((size_t)L.v * A.pd.amax_parts + part) * D;
+        if constexpr (X::SPLIT) {                       // this launch's four message blocks and head slots of the partial
+#pragma unroll
+            for (int b = X::MB0; b < X::MB1; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    reinterpret_cast<float4*>(hrow + b * 32 + half * 16)[q] = make_float4(macc[b * 16 + q * 4], macc[b * 16 + q * 4 + 1], macc[b * 16 + q * 4 + 2], macc[b * 16 + q * 4 + 3]);
+        } else {
+            store_nat<X::ND>(hrow, half, macc);
+        }
         float* sp = A.astat + ((size_t)L.v * A.pd.amax_parts + part) * 32;       // [16 maxima | 16 sums], head-indexed
         if constexpr (X::PH) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { sp[2 * k + half] = sm[k]; sp[16 + 2 * k + half] = sl[k]; }
+            for (int k = X::SL0; k < X::SL0 + X::NSL; ++k) { sp[2 * k + half] = sm[k]; sp[16 + 2 * k + half] = sl[k]; }
         } else {
             float fin[16];                              // half 0 stores the maxima, half 1 the sums (both halves hold both)
 #pragma unroll
@@ -577,6 +603,9 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
         }
     }
     APT(6);
+#ifdef JODO_PHASE_TIMING_ATTN
+    if constexpr (X::SPLIT) pt_acc[7] = w.T.bar;        // (inside the phases above: the ring's chunk boundaries, commit + barrier)
+#endif
     APT_FLUSH;
 }
 
@@ -585,8 +614,11 @@ __device__ __forceinline__ void attn_item(const KArgs& A, const float4* wl, floa
 // (ai_dir: every lane visits all its sources, no hand-over), so that symmetric inputs need one launch whatever the sizes.
 // PAIR = false: the directed launch (ad_* items), runs when the inputs are asymmetric (and for ad_big items: molecules larger than
 // a group when the pair launch does not carry them, i.e. fixed-chunk plans)
+#ifndef JODO_X_ATT_SPLIT_OCC
+#define JODO_X_ATT_SPLIT_OCC(VAR) 1
+#endif
 template <int D, bool WQK, bool PAIR, int VAR = 0>
-__global__ __launch_bounds__(ATT_WAVES * 64, 1) void k_edge_attn(KArgs A) {
+__global__ __launch_bounds__(ATT_WAVES * 64, JODO_X_ATT_SPLIT_OCC(VAR)) void k_edge_attn(KArgs A) {
     using X = AttnT<D, WQK, VAR>;
     const bool asym = A.flags[FLAG_ASYM] != 0;
     if (PAIR ? asym : !(asym || A.pd.ad_big[blockIdx.x])) return;

@@ -525,10 +525,12 @@ static int split_node_tape_steps(const DgtDims& d) {
     return 2 * 16 + d.r * 4 * (2 * 16 + 8 * 4) + 16 * 16 + 2 * 16 + 24 * 16;
 }
 
-// The ATTENTION tape (tuned nf = 256 kernel set; k_edge_attn variant 4), per block and CYCLIC — the same 80 steps for every pair offset:
-//   block edge_emb: the G halves (4 steps) of output blocks 0, 1, then their e halves | lin_edge0: blocks 0 .. 7 in the tuned q / k arrangement, 4 steps
-//   each | lin_edge1: blocks 0 .. 7, 4 steps each
-static int split_attn_tape_steps(const DgtDims& d) { return (d.wide || d.D != 256) ? 0 : 2 * 8 + 8 * 4 + 8 * 4; }
+// The ATTENTION tapes (tuned nf = 256 kernel set; k_edge_attn variants 4 and 5: the two launches that share an item by heads), per block and
+// CYCLIC — a launch walks the same steps for every pair offset.  Every entry is one K = De block of 4 steps:
+//   first launch (12 blocks):  edge_emb: the G halves of output blocks 0, 1, then their e halves | lin_edge0 blocks 0, 1, 2 and its tail block 7
+//                              (tuned q / k arrangement) | lin_edge1 blocks 0 .. 3
+//   second launch (13 blocks): edge_emb as above | lin_edge0 blocks 3 .. 6 and the tail block 7 | lin_edge1 blocks 4 .. 7
+static int split_attn_tape_steps(const DgtDims& d) { return (d.wide || d.D != 256) ? 0 : (12 + 13) * 4; }
 
 static int pack_split_tape(const jodo_cfg* cfg, const jodo_tensor* tensors, int n_tensors, std::vector<uint16_t>& tape, size_t* block_elems,
                            size_t* node_block_elems, size_t* attn_block_elems) {
@@ -644,10 +646,13 @@ static int pack_split_tape(const jodo_cfg* cfg, const jodo_tensor* tensors, int 
             const std::vector<uint16_t> pee = pack_proj_split(wee, 2 * De, cat(nat_in(De), nat_in(De, De)), nat_out(De));
             const std::vector<uint16_t> p0 = pack_proj_split(wl0, De, nat_in(De), qk);
             const std::vector<uint16_t> p1 = pack_proj_split(wl1, De, nat_in(De), nat_out(D));
-            for (int blk = 0; blk < 2; ++blk) slice(pee, 8, blk, 0, 4);          // the G halves of both output blocks first, then the e halves:
-            for (int blk = 0; blk < 2; ++blk) slice(pee, 8, blk, 4, 8);          // only one operand's split image is live at a time
-            for (int blk = 0; blk < 8; ++blk) slice(p0, 4, blk, 0, 4);
-            for (int blk = 0; blk < 8; ++blk) slice(p1, 4, blk, 0, 4);
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int blk = 0; blk < 2; ++blk) slice(pee, 8, blk, 0, 4);      // the G halves of both output blocks first, then the e halves:
+                for (int blk = 0; blk < 2; ++blk) slice(pee, 8, blk, 4, 8);      // only one operand's split image is live at a time
+                for (int blk = pass ? 3 : 0; blk < (pass ? 7 : 3); ++blk) slice(p0, 4, blk, 0, 4);
+                slice(p0, 4, 7, 0, 4);
+                for (int blk = pass * 4; blk < pass * 4 + 4; ++blk) slice(p1, 4, blk, 0, 4);
+            }
             if (tape.size() - at0 != attn_block) return jodo_set_error(JODO_ERR_ARG, "pack_split: internal attention tape size");
         }
     }

@@ -117,7 +117,7 @@ __device__ __forceinline__ void mfma_block_s(WPipeS<PG>& p, const WSrc& w, unsig
     }
 }
 
-// ---- cyclic weight tape through an LDS ring (the attention kernel's split form: the same 80 K16 steps for every pair offset) ----
+// ---- cyclic weight tape through an LDS ring (the attention kernel's split form: a launch walks the same 48 / 52 K16 steps for every pair offset) ----
 // Same protocol as the pair update's ring (dgt_kernels_split.h): chunk g lives in slot g % 3; boundary(g) commits chunk g + 1 from the
 // stage registers, barriers, requests chunk g + 2.  Chunk g of the walk is chunk g % period of the tape.
 namespace splitc {
@@ -128,6 +128,9 @@ struct TapeC {
     unsigned ld_off, rd_off;
     char* ring;
     u32x4 stage[3];
+#ifdef JODO_PHASE_TIMING_ATTN
+    unsigned long long bar = 0;                      // cycles between entering a chunk boundary and leaving its barrier
+#endif
 };
 __device__ __forceinline__ void request(TapeC& T, int g) {
     if (g >= T.ntot) return;
@@ -149,8 +152,16 @@ __device__ __forceinline__ void start(TapeC& T) {
 }
 // one chunk-aligned block of CH_STEPS steps (every K = De projection block of the attention kernel at nf 256): acc += W_chunk * act
 __device__ __forceinline__ f32x16 block4(TapeC& T, int& g, const Split8* act, f32x16 acc) {
+#ifdef JODO_PHASE_TIMING_ATTN
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
     commit(T, g + 1);
     __syncthreads();
+#ifdef JODO_PHASE_TIMING_ATTN
+    __builtin_amdgcn_sched_barrier(0);
+    T.bar += __builtin_readcyclecounter() - c0;
+#endif
     request(T, g + 2);
     pipeline_fence();
     const char* base = T.ring + (g % RING_SLOTS) * CH_BYTES + T.rd_off;

@@ -79,7 +79,7 @@ def test_split_tape_is_the_consumption_order_of_the_pair_update():
                                                                 ctypes.byref(attn_b)), 'split_size')
     size(model)
     nsteps = 2 * 16 + r * 4 * (2 * 16 + 8 * 4) + 16 * 16 + 2 * 16 + 24 * 16          # the node tape of the tuned nf 256 kernel set
-    asteps = 2 * 8 + 8 * 4 + 8 * 4                                                   # the (cyclic) attention tape
+    asteps = (12 + 13) * 4                                                           # the two (cyclic) attention tapes: one per launch
     assert steps == 56 and pair_b.value == steps * 3072 and node_b.value == nsteps * 3072 and attn_b.value == asteps * 3072
     assert both.size * 2 == total.value == L * (pair_b.value + node_b.value + attn_b.value)
     tape = both[:L * steps * STEP]
@@ -87,9 +87,13 @@ def test_split_tape_is_the_consumption_order_of_the_pair_update():
     attn = both[L * (steps + nsteps) * STEP:].reshape(L, asteps, STEP)
     _, see = _pack(sd['e_block_1.edge_emb.weight'].numpy())
     see = see.reshape(2, 8, STEP)                                                    # G halves of both blocks first, then the e halves
-    assert np.array_equal(attn[1, :16], np.concatenate([see[0, :4], see[1, :4], see[0, 4:], see[1, 4:]]))
+    ee = np.concatenate([see[0, :4], see[1, :4], see[0, 4:], see[1, 4:]])
     _, sl1 = _pack(sd['e_block_1.attn_mpnn.lin_edge1.weight'].numpy())
-    assert np.array_equal(attn[1, 48:], sl1.reshape(8 * 4, STEP))
+    sl1 = sl1.reshape(8, 4, STEP)
+    # first launch: edge_emb | lin_edge0 blocks 0 - 2 + tail | lin_edge1 blocks 0 - 3; second: edge_emb | lin_edge0 3 - 6 + tail | lin_edge1 4 - 7
+    assert np.array_equal(attn[1, :16], ee) and np.array_equal(attn[1, 48:64], ee)
+    assert np.array_equal(attn[1, 32:48], sl1[:4].reshape(16, STEP)) and np.array_equal(attn[1, 84:], sl1[4:].reshape(16, STEP))
+    assert np.array_equal(attn[1, 28:32], attn[1, 80:84])                             # the tail block of lin_edge0 closes both score sections
     # node tape of block 0: node2edge_lin first, the next block's lin_value last; the last block's q / k / v section is zero
     node = both[L * steps * STEP:L * (steps + nsteps) * STEP].reshape(L, nsteps, STEP)
     _, sn2e = _pack(sd['e_block_0.node2edge_lin.weight'].numpy())
@@ -171,7 +175,7 @@ def test_split_bf16_pair_update_against_the_default_path_and_float64(cfg_name, n
         return o[0].cpu(), o[1].cpu()
 
     if mode == 'attention' and (over.get('nf', 256) != 256 or len(n_nodes) > 100):
-        pytest.skip("the attention variant (JODO_OPT_SPLIT_BF16 = 2, experiments) is built for the tuned nf 256 set; one small case each")
+        pytest.skip("the attention variant (JODO_OPT_SPLIT_BF16 = 2, experiments: two launches by heads) is built for the tuned nf 256 set; one small case each")
     outs = {}
     for split in (False, True):
         model = make_model(cfg, 13, DEV)

@@ -20,6 +20,7 @@ ap.add_argument('--workload', default='qm9', choices=sorted(WL))
 ap.add_argument('--steps', type=int, default=30)
 ap.add_argument('--batch', type=int, default=0)
 ap.add_argument('--round', type=int, default=0, help='also run a complete round of that many ancestral steps with both paths on identical in-kernel noise and compare the decoded molecules')
+ap.add_argument('--attention', action='store_true', help="also time split_bf16 = 'attention' (option value 2: the two-launch split attention on top)")
 args = ap.parse_args()
 cfg_name, info, B = WL[args.workload]
 B = args.batch or B
@@ -47,7 +48,7 @@ ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta
 ts = torch.linspace(ns.T, 1e-3, 1000)
 say('# split-bf16 pair update A/B, %s B = %d, %s' % (args.workload, B, torch.cuda.get_device_name(0)))
 res, state5 = {}, {}
-for split in (False, True, False, True):
+for split in (False, True, False, True) + (('attention', 'attention') if args.attention else ()):
     model = deterministic_init_(get_model_class(cfg.model.name)(cfg), seed=cfg.seed).to(dev).eval()
     model.split_bf16 = split
     sampler = AncestralSampler(ns, ts, True, True, True, get_self_cond_fn(cfg), device_noise=fused.DeviceNoise.for_rank(cfg.seed, 0))
@@ -69,13 +70,20 @@ for split in (False, True, False, True):
     nb = cfg.model.n_layers
     say('split_bf16=%-5s  %.3f ms/step (class timers on)   pair update %.1f us/block   attention %.1f   node class %.1f us/block   nan %d' % (
         split, dt * 1e3, ms[6] / args.steps / nb * 1e3, ms[2] / args.steps / nb * 1e3, ms[5] / args.steps / nb * 1e3, model.take_nan_count()))
-    res.setdefault(split, []).append((dt * 1e3, ms[6] / args.steps / nb * 1e3))
+    res.setdefault(split, []).append((dt * 1e3, ms[6] / args.steps / nb * 1e3, ms[2] / args.steps / nb * 1e3))
 a, b = state5[False][1], state5[True][1]
 for k in a:
     if torch.is_tensor(a[k]) and a[k].dtype.is_floating_point and a[k].shape == b[k].shape:
         say('after 5 identical-noise steps, state[%s]: max |split - default| %.3e (max |x| %.2f)' % (k, float((a[k] - b[k]).abs().max()), float(a[k].abs().max())))
 bd, bs = min(r[1] for r in res[False]), min(r[1] for r in res[True])
 say('pair update: exact fp32 %.1f us/block -> split bf16x3 %.1f us/block (x%.2f);  step %.3f -> %.3f ms' % (bd, bs, bd / bs, min(r[0] for r in res[False]), min(r[0] for r in res[True])))
+if args.attention:
+    c = state5['attention'][1]
+    for k in a:
+        if torch.is_tensor(a[k]) and a[k].dtype.is_floating_point and a[k].shape == c[k].shape:
+            say("after 5 identical-noise steps, state[%s]: max |split 'attention' - default| %.3e" % (k, float((a[k] - c[k]).abs().max())))
+    say("attention: exact fp32 %.1f us/block -> two split launches %.1f us/block;  step with all three split kernels %.3f ms" % (
+        min(r[2] for r in res[False]), min(r[2] for r in res['attention']), min(r[0] for r in res['attention'])))
 if args.round > 0:
     # a complete round, both paths on the SAME in-kernel noise stream (Philox keyed by (seed, rank, round)): what SURVEY.md 8c asks of long
     # runs is a statistical comparison; with identical noise the two paths can be compared molecule by molecule as well
