@@ -17,6 +17,9 @@
 #ifndef JODO_X_UPD_EARLY
 #define JODO_X_UPD_EARLY 0        // experiment switch of the pair update's item top (see k_edge_update_sym)
 #endif
+#ifndef JODO_X_UPD_NEXT
+#define JODO_X_UPD_NEXT 0         // pair update: the NEXT offset's partner position / edge row / node2edge row requested behind the last
+#endif                            // weight prefetch of the current offset (items of several offsets; see k_edge_update_sym)
 
 namespace jd {
 namespace wide {
@@ -698,9 +701,48 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
     // LDS page as well: pair update 6.18 -> 6.77 ms/step at QM9 B = 2500, 55.3 -> 58.3 at nf = 384.  Their global loads are
     // requested far ahead and overlap; the ds_reads wait in order behind each other.)
     float park[HOIST ? 1 : (X::ND - PLB) * 16];
+#if JODO_X_UPD_NEXT
+    // NEXT: an item of several pair offsets requests the rows of offset t + 1 — partner position, the pair's edge row, the partner's
+    // node2edge row: 68 registers — behind the LAST weight prefetch of offset t (the hook of the last Z block): they travel under that
+    // block's MFMAs, its tails and the item end (~ 5 k cycles) instead of being waited for at the top of offset t + 1, and they stand
+    // behind every weight group offset t still waits for (loads return in order: requested any earlier they delay those).
+    constexpr bool NEXT = (JODO_X_UPD_NEXT != 0) && FOLD && ZW == 1;     // (the un-folded form keeps S (1 + sc) per lane: no room)
+    const int t_end = t1;                               // (the block loops below have locals named t0 / t1)
+    float er[NEXT ? X::HE : 1], tcr[NEXT ? X::HE : 1];
+    u32x4 pur = {0u, 0u, 0u, 0u};
+    const __amdgpu_buffer_rsrc_t rpos_n = __builtin_amdgcn_make_buffer_rsrc(A.pos_out, 0, 0x7fffffff, 0x00020000);
+    // edge rows of a strip's molecules lie within a few hundred MB of the strip's first molecule: descriptor at that row, 32-bit offsets
+    const int eoff0_n = __builtin_amdgcn_readfirstlane(L.eoff);
+    const __amdgpu_buffer_rsrc_t re_n = __builtin_amdgcn_make_buffer_rsrc(A.e + (size_t)eoff0_n * X::De, 0, 0x7fffffff, 0x00020000);
+    auto request_next = [&](int tn) {
+        {
+            const PairLane Pn = pair_of(L, tn + 1);
+            pur = __builtin_amdgcn_raw_buffer_load_b128(rpos_n, (unsigned)Pn.u * 16u, 0, 0);
+            const size_t rn = L.valid ? Pn.rij - (size_t)eoff0_n : 0;      // (padding lanes carry node 0's descriptors)
+            const unsigned evoff = (unsigned)((rn * X::De + half * 16) * 4);
+            const BRow rc = brow(A.n2e, X::NE, Pn.u, half);
+#pragma unroll
+            for (int b = 0; b < X::NE; ++b) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(re_n, evoff, (unsigned)(b * 128 + q * 16), 0);
+                    er[b * 16 + q * 4 + 0] = __uint_as_float(v.x); er[b * 16 + q * 4 + 1] = __uint_as_float(v.y);
+                    er[b * 16 + q * 4 + 2] = __uint_as_float(v.z); er[b * 16 + q * 4 + 3] = __uint_as_float(v.w);
+                }
+                float t16[16];
+                bload16(rc, b, t16);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) tcr[b * 16 + s] = t16[s];
+            }
+        }
+    };
+#endif
     PT_INIT
     for (int t = t0; t < t1; ++t) {
         const PairLane P = pair_of(L, t + 1);
+#if JODO_X_UPD_NEXT
+        const bool pre = NEXT && t > t0;                   // this offset's rows were requested by the previous one
+#endif
         const float* eg1_ = launder(eg1);
         const float* es2_ = eg1_ + X::De, *ec2_ = es2_ + X::De, *eg2_ = ec2_ + X::De;
         const float* qsh_ = launder(qsh);
@@ -742,6 +784,10 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
         }
         pipeline_fence();
         const float4 pu = make_float4(__uint_as_float(pur.x), __uint_as_float(pur.y), __uint_as_float(pur.z), __uint_as_float(pur.w));
+#elif JODO_X_UPD_NEXT
+        float4 pu;
+        if (pre) pu = make_float4(__uint_as_float(pur.x), __uint_as_float(pur.y), __uint_as_float(pur.z), __uint_as_float(pur.w));
+        else pu = reinterpret_cast<const float4*>(A.pos_out)[P.u];
 #else
         const float4 pu = reinterpret_cast<const float4*>(A.pos_out)[P.u];
 #endif
@@ -761,6 +807,15 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
 #if (JODO_X_UPD_EARLY & 1)
 #pragma unroll
                 for (int s = 0; s < 16; ++s) { e[s] = er[b * 16 + s]; ta[s] = tar[b * 16 + s]; tc2[s] = tcr[b * 16 + s]; }
+#elif JODO_X_UPD_NEXT
+                if (pre) {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) { e[s] = er[NEXT ? b * 16 + s : 0]; tc2[s] = tcr[NEXT ? b * 16 + s : 0]; }
+                } else {
+                    load16(A.e + P.rij * X::De + b * 32 + half * 16, e);
+                    load16T(rc, b, tc2);
+                }
+                load16T(ra, b, ta);
 #else
                 load16(A.e + P.rij * X::De + b * 32 + half * 16, e);
                 load16T(ra, b, ta);
@@ -972,6 +1027,9 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
                 auto next_rows = [&]() {                         // next block's rows (the last iteration re-requests its own),
                     const int bn = b + 1 < zb1 ? b + 1 : b;      // behind the last weight prefetch of this block
                     bload16(ua_i, bn, n0); bload16(ub_j, bn, n1); bload16(ua_j, bn, n2); bload16(ub_i, bn, n3);
+#if JODO_X_UPD_NEXT
+                    if constexpr (NEXT) { if (b + 1 == zb1 && t + 1 < t_end) request_next(t + 1); }
+#endif
                 };
                 if constexpr (!ROT) load16(wg_v + b * 32 + half * 16, wgb);
                 load16(bs_v + b * 32 + half * 16, bsb);
