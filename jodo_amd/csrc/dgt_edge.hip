@@ -19,6 +19,13 @@ void launch_sym_variant(hipStream_t st, KArgs& A, int n_items, int zw) {
     if (!(D == 256 || FOLD)) zw = 1;                      // (the un-hoisted form has no per-pair Z to deal out)
     const int full = zw > 1 ? (n_items / 1024) * 1024 : n_items, rem = n_items - full;
     A.item0 = 0; A.dir_split = 0;
+#if JODO_X_UPD_PERS
+    if (FOLD && full > 0) {                               // persistent: one workgroup per SIMD walks the items block index + k * 1024
+        A.pers_n = full;
+        hipLaunchKernelGGL((wide::k_edge_update_sym<D, R, FOLD, ROT>), dim3(full < 1024 ? full : 1024), dim3(64), 0, st, A);
+        A.pers_n = 0;
+    } else
+#endif
     if (full > 0) hipLaunchKernelGGL((wide::k_edge_update_sym<D, R, FOLD, ROT>), dim3(full), dim3(64), 0, st, A);
     if (rem > 0) {
         A.item0 = full;

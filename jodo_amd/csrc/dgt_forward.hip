@@ -54,6 +54,7 @@ void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
     A.ehid = ws_ptr<float>(ws, w.ehid); A.epred = ws_ptr<float>(ws, w.epred);
     A.e_out = ws_ptr<float>(ws, w.e2);
     A.dposE = ws_ptr<float>(ws, w.dposE); A.gramE = ws_ptr<float>(ws, w.gramE);
+    A.pers_n = 0;
     A.wsplit = nullptr; A.wsplit_node = nullptr; A.wsplit_attn = nullptr; A.mfold_s = nullptr;      // the opt-in split-bf16 kernels: decided per forward (jodo_dgt_forward)
 }
 

@@ -20,6 +20,7 @@ struct KArgs {
     int half_rows;                        // pinned symmetric inputs: of a molecule that fits an attention group only the edge row of a pair's EVALUATING lane
                                           // (pair_of: (i, i + d)) is ever read again, so e / ehid of the mirror row are not written
     int item0, dir_split;                 // pair update: first item of this launch; 1 = two workgroups per item, one direction each
+    int pers_n;                           // pair update, persistent launches (-DJODO_X_UPD_PERS experiment builds): items of this launch
     int mix_nw, ab0, ab1, g0, g1;         // k_node_mix: workgroups in the k_node_postw role; k_node_ab items [ab0, ab1); Gram tiles [g0, g1)
     int rot;                              // JODO_OPT_ROT_STATS and a launch sequence that can use it: under FLAG_UNIFORM_T && !FLAG_ASYM the node
                                           // kernels write Q P (W_row h + b), Q P W_col h and the pair update takes its LayerNorm statistics from them

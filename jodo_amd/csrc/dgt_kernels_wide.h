@@ -17,9 +17,13 @@
 #ifndef JODO_X_UPD_EARLY
 #define JODO_X_UPD_EARLY 0        // experiment switch of the pair update's item top (see k_edge_update_sym)
 #endif
+#ifndef JODO_X_UPD_PERS
+#define JODO_X_UPD_PERS 0         // pair update (folded form, one wave per item): persistent workgroups, the NEXT item's descriptor chain in flight
+#endif                            // under the current item (1), its partner rows too (2); see k_edge_update_sym.  Measured: 1 % / nothing
 #ifndef JODO_X_UPD_NEXT
 #define JODO_X_UPD_NEXT 0         // pair update: the NEXT offset's partner position / edge row / node2edge row requested behind the last
 #endif                            // weight prefetch of the current offset (items of several offsets; see k_edge_update_sym)
+#define JODO_X_UPD_ROWS (JODO_X_UPD_NEXT || JODO_X_UPD_PERS >= 2)   // PERS = 2: the same across the items of a persistent workgroup
 
 namespace jd {
 namespace wide {
@@ -655,15 +659,32 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
     static_assert(X::ND % ZW == 0, "Z blocks per wave");
     // dir_split: the items of a launch's sparsely filled last round get two workgroups each; both compute the
     // shared trunk, each evaluates one direction (item time x 0.64) — the trunk's stores come from direction 0
+#if JODO_X_UPD_PERS
+    // PERS (the launcher starts min(items, 1024) workgroups and sets A.pers_n = items of the launch): a workgroup walks the items block index
+    // + k * grid.  What a new workgroup pays per item — kernel
+    // arguments, coord_mlp.2 to LDS, the first weight group, item -> strip -> lane descriptors -> own position — is paid once, and the
+    // next item's descriptors are requested in the middle of the current one.
+    constexpr bool PERS = FOLD && ZW == 1;                   // (every launch of these instances is persistent: launch_sym_variant)
+    constexpr bool pers = PERS;
+    int it_c = A.item0 + (A.dir_split ? (int)(blockIdx.x >> 1) : (int)blockIdx.x);
+    int strip_c = A.pd.pitem_strip[it_c], t0_c = A.pd.pitem_t0[it_c], t1_c = A.pd.pitem_t1[it_c];
+    LaneNode L_c = lane_node(A, strip_c, jl);
+    float4 pv_c = reinterpret_cast<const float4*>(A.pos_out)[L_c.v];
+    const int dsel = A.dir_split ? (int)(blockIdx.x & 1) : -1;
+    const float* mrow = mod_row(A, L_c.b) + A.mod_base;     // (PERS: the shared row — FOLD runs under FLAG_UNIFORM_T only)
+#else
     const int it = A.item0 + (A.dir_split ? (int)(blockIdx.x >> 1) : (int)blockIdx.x);
     const int dsel = A.dir_split ? (int)(blockIdx.x & 1) : -1;
     const int strip = A.pd.pitem_strip[it], t0 = A.pd.pitem_t0[it], t1 = A.pd.pitem_t1[it];
     const LaneNode L = lane_node(A, strip, jl);
     const float* mrow = mod_row(A, L.b) + A.mod_base;
+#endif
     const float* eg1 = mrow + X::M_EDGE + 2 * X::De;
     const float* qsh = mrow + X::M_EQUI;
     const float gscale = mrow[X::M_GBF + 0], gshift = mrow[X::M_GBF + 1];
+#if !JODO_X_UPD_PERS
     const float4 pv = reinterpret_cast<const float4*>(A.pos_out)[L.v];
+#endif
     const float cscale = A.W[A.wb[JB_CSCALE]];
     const WSrc ws = make_wsrc(A.W, lane);
     const unsigned o3 = (unsigned)(A.wb[JB_FF3_W] * 4), o4 = (unsigned)(A.wb[JB_FF4_W] * 4);
@@ -701,24 +722,23 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
     // LDS page as well: pair update 6.18 -> 6.77 ms/step at QM9 B = 2500, 55.3 -> 58.3 at nf = 384.  Their global loads are
     // requested far ahead and overlap; the ds_reads wait in order behind each other.)
     float park[HOIST ? 1 : (X::ND - PLB) * 16];
-#if JODO_X_UPD_NEXT
+#if JODO_X_UPD_ROWS
     // NEXT: an item of several pair offsets requests the rows of offset t + 1 — partner position, the pair's edge row, the partner's
     // node2edge row: 68 registers — behind the LAST weight prefetch of offset t (the hook of the last Z block): they travel under that
     // block's MFMAs, its tails and the item end (~ 5 k cycles) instead of being waited for at the top of offset t + 1, and they stand
     // behind every weight group offset t still waits for (loads return in order: requested any earlier they delay those).
-    constexpr bool NEXT = (JODO_X_UPD_NEXT != 0) && FOLD && ZW == 1;     // (the un-folded form keeps S (1 + sc) per lane: no room)
-    const int t_end = t1;                               // (the block loops below have locals named t0 / t1)
+    constexpr bool NEXT = FOLD && ZW == 1;              // (the un-folded form keeps S (1 + sc) per lane: no room)
     float er[NEXT ? X::HE : 1], tcr[NEXT ? X::HE : 1];
     u32x4 pur = {0u, 0u, 0u, 0u};
     const __amdgpu_buffer_rsrc_t rpos_n = __builtin_amdgcn_make_buffer_rsrc(A.pos_out, 0, 0x7fffffff, 0x00020000);
-    // edge rows of a strip's molecules lie within a few hundred MB of the strip's first molecule: descriptor at that row, 32-bit offsets
-    const int eoff0_n = __builtin_amdgcn_readfirstlane(L.eoff);
-    const __amdgpu_buffer_rsrc_t re_n = __builtin_amdgcn_make_buffer_rsrc(A.e + (size_t)eoff0_n * X::De, 0, 0x7fffffff, 0x00020000);
-    auto request_next = [&](int tn) {
-        {
-            const PairLane Pn = pair_of(L, tn + 1);
+    auto request_rows = [&](const LaneNode& Lq, int tn) {   // rows of offset tn of the strip whose lanes are Lq
+        if constexpr (NEXT) {
+            // edge rows of a strip's molecules lie within a few hundred MB of the strip's first molecule: descriptor at that row, 32-bit offsets
+            const int eoff0_n = __builtin_amdgcn_readfirstlane(Lq.eoff);
+            const __amdgpu_buffer_rsrc_t re_n = __builtin_amdgcn_make_buffer_rsrc(A.e + (size_t)eoff0_n * X::De, 0, 0x7fffffff, 0x00020000);
+            const PairLane Pn = pair_of(Lq, tn + 1);
             pur = __builtin_amdgcn_raw_buffer_load_b128(rpos_n, (unsigned)Pn.u * 16u, 0, 0);
-            const size_t rn = L.valid ? Pn.rij - (size_t)eoff0_n : 0;      // (padding lanes carry node 0's descriptors)
+            const size_t rn = Lq.valid ? Pn.rij - (size_t)eoff0_n : 0;     // (padding lanes carry node 0's descriptors)
             const unsigned evoff = (unsigned)((rn * X::De + half * 16) * 4);
             const BRow rc = brow(A.n2e, X::NE, Pn.u, half);
 #pragma unroll
@@ -737,10 +757,33 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
         }
     };
 #endif
+#if JODO_X_UPD_PERS >= 2
+    request_rows(L_c, t0_c);                                // the first item's rows; every later item's come from the item before it
+#endif
+#if JODO_X_UPD_PERS
+    for (;;) {                                              // one pass per item (not persistent: exactly one)
+    const int strip = strip_c, t0 = t0_c, t1 = t1_c;
+    const LaneNode L = L_c;
+    const float4 pv = pv_c;
+#if JODO_X_UPD_ROWS
+    const int t_end = t1;                               // (the block loops below have locals named t0 / t1)
+#endif
+    // the next item of this workgroup: block index + k * grid (a ticket counter was tried first: hipcc turns the atomic into its wave-reduced
+    // form and waits for it with vmcnt(0) on the spot — one exposed atomic round trip and a drained weight pipe at every item top)
+    const int it_n = it_c + (int)gridDim.x;
+    const bool more = pers && it_n - A.item0 < A.pers_n;
+    it_c = more ? it_n : it_c;
+    const int strip_n = A.pd.pitem_strip[it_c], t0_n = A.pd.pitem_t0[it_c], t1_n = A.pd.pitem_t1[it_c];   // scalar loads, back long before the hook below
+#endif
+#if JODO_X_UPD_ROWS && !JODO_X_UPD_PERS
+    const int t_end = t1;
+#endif
     PT_INIT
     for (int t = t0; t < t1; ++t) {
         const PairLane P = pair_of(L, t + 1);
-#if JODO_X_UPD_NEXT
+#if JODO_X_UPD_PERS >= 2
+        constexpr bool pre = NEXT;                         // every offset's rows were requested by its predecessor (or the prologue)
+#elif JODO_X_UPD_ROWS
         const bool pre = NEXT && t > t0;                   // this offset's rows were requested by the previous one
 #endif
         const float* eg1_ = launder(eg1);
@@ -784,7 +827,7 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
         }
         pipeline_fence();
         const float4 pu = make_float4(__uint_as_float(pur.x), __uint_as_float(pur.y), __uint_as_float(pur.z), __uint_as_float(pur.w));
-#elif JODO_X_UPD_NEXT
+#elif JODO_X_UPD_ROWS
         float4 pu;
         if (pre) pu = make_float4(__uint_as_float(pur.x), __uint_as_float(pur.y), __uint_as_float(pur.z), __uint_as_float(pur.w));
         else pu = reinterpret_cast<const float4*>(A.pos_out)[P.u];
@@ -807,7 +850,7 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
 #if (JODO_X_UPD_EARLY & 1)
 #pragma unroll
                 for (int s = 0; s < 16; ++s) { e[s] = er[b * 16 + s]; ta[s] = tar[b * 16 + s]; tc2[s] = tcr[b * 16 + s]; }
-#elif JODO_X_UPD_NEXT
+#elif JODO_X_UPD_ROWS
                 if (pre) {
 #pragma unroll
                     for (int s = 0; s < 16; ++s) { e[s] = er[NEXT ? b * 16 + s : 0]; tc2[s] = tcr[NEXT ? b * 16 + s : 0]; }
@@ -869,6 +912,14 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
             if (!A.half_rows || L.n > PAIR_GROUP_LANES) store_nat<X::NE>(A.e_out + P.rji * X::De, half, en);
         }
         PT(1);
+#if JODO_X_UPD_PERS
+        if constexpr (pers) {                               // the next item's lane descriptors and own position (its strip is known since the item top)
+            strip_c = strip_n; t0_c = t0_n; t1_c = t1_n;
+            L_c = lane_node(A, strip_c, jl);
+            pv_c = reinterpret_cast<const float4*>(A.pos_out)[L_c.v];
+            pipeline_fence();
+        }
+#endif
         // per-node rows of the coord_mlp.0 hoist (own rows do not depend on the pair offset: without an opaque offset LICM
         // hoists and spills them)
         unsigned opq = 0;
@@ -1027,8 +1078,18 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
                 auto next_rows = [&]() {                         // next block's rows (the last iteration re-requests its own),
                     const int bn = b + 1 < zb1 ? b + 1 : b;      // behind the last weight prefetch of this block
                     bload16(ua_i, bn, n0); bload16(ub_j, bn, n1); bload16(ua_j, bn, n2); bload16(ub_i, bn, n3);
-#if JODO_X_UPD_NEXT
-                    if constexpr (NEXT) { if (b + 1 == zb1 && t + 1 < t_end) request_next(t + 1); }
+#if JODO_X_UPD_PERS >= 2
+                    if constexpr (NEXT) {                       // the next offset of this item, or the first one of the workgroup's next item
+                        if (b + 1 == zb1) {
+                            const bool in = t + 1 < t_end;
+                            LaneNode Lq;
+                            Lq.v = in ? L.v : L_c.v; Lq.b = in ? L.b : L_c.b; Lq.i = in ? L.i : L_c.i; Lq.n = in ? L.n : L_c.n;
+                            Lq.noff = in ? L.noff : L_c.noff; Lq.eoff = in ? L.eoff : L_c.eoff; Lq.valid = in ? L.valid : L_c.valid;
+                            request_rows(Lq, in ? t + 1 : t0_c);
+                        }
+                    }
+#elif JODO_X_UPD_ROWS
+                    if constexpr (NEXT) { if (b + 1 == zb1 && t + 1 < t_end) request_rows(L, t + 1); }
 #endif
                 };
                 if constexpr (!ROT) load16(wg_v + b * 32 + half * 16, wgb);
@@ -1225,6 +1286,10 @@ __global__ __launch_bounds__(ZW * 64, 1) void k_edge_update_sym(KArgs A) {
             }
         }
     }
+#if JODO_X_UPD_PERS
+    if (!more) break;
+    }
+#endif
     PT_FLUSH;
 }
 
