@@ -478,7 +478,7 @@ def main():
                 sms, scnt = model.profile_read()
                 model.profile_enable(0)
             split_info = {'dtype': 'bf16x3 (three-term split operands, fp32 accumulate: fp32-equivalent, not bit-identical)',
-                          'scope': 'pair update (k_edge_update_sym_split) and, at nf 256, the node kernel (k_node_post_split); attention, k_node_ab, Gram tiles, embeddings, heads exact fp32',
+                          'scope': 'pair update (k_edge_update_sym_split) and, at nf 256, the node kernels (k_node_post_split; k_node_ab_split where it is a launch of its own: >= 1024 node strips); attention, Gram tiles, embeddings, heads exact fp32',
                           'ms_per_step': tsp * 1e3, 'value': B / (SAMPLING_STEPS * tsp), 'unit': 'molecules/s',
                           'pair_update_avg_launch_ms': (sms[6] / scnt[6]) if scnt[6] else None, 'launches': scnt[6],
                           'nan_guard': bool(model.nan_guard_fired())}

@@ -201,7 +201,8 @@ enum jodo_plan_option {
                                    * jodo_plan_set_split_weights): the folded pair update runs its projections in the split-bf16 form — every
                                    * operand as hi + mid + lo bf16 terms, six v_mfma_f32_32x32x16_bf16 products per K = 16 step, fp32
                                    * accumulation: fp32-equivalent arithmetic (dropped terms <= 3 * 2^-26 relative; profiles/r06_split_gate.txt)
-                                   * at 6/16 of the matrix cycles (csrc/dgt_kernels_split.h).  Results differ from the default path in the
+                                   * at 6/16 of the matrix cycles (csrc/dgt_kernels_split.h); with the tuned nf 256 kernel set also the node kernels
+                                   * (k_node_post_split, k_node_ab_split: csrc/dgt_kernels_split_node.h).  Results differ from the default path in the
                                    * last bits; the default and every headline number stay exact fp32.  Ignored when a precondition fails.
                                    * 2 (experiments): also the fused attention kernel (k_edge_attn variants 4 + 5: two launches that share every
                                    * item by heads; nf 256 tuned set, plans without molecules above an attention group) — parity-tested, measured

@@ -55,7 +55,7 @@ void fill_ws(KArgs& A, const jodo_plan* p, void* ws) {
     A.e_out = ws_ptr<float>(ws, w.e2);
     A.dposE = ws_ptr<float>(ws, w.dposE); A.gramE = ws_ptr<float>(ws, w.gramE);
     A.pers_n = 0;
-    A.wsplit = nullptr; A.wsplit_node = nullptr; A.wsplit_attn = nullptr; A.mfold_s = nullptr;      // the opt-in split-bf16 kernels: decided per forward (jodo_dgt_forward)
+    A.wsplit = nullptr; A.wsplit_node = nullptr; A.wsplit_attn = nullptr; A.mfold_s = nullptr; A.ffold_s = nullptr;      // the opt-in split-bf16 kernels: decided per forward (jodo_dgt_forward)
 }
 
 int rowgemm(hipStream_t st, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* Wp, const float* bias,
@@ -189,6 +189,14 @@ int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A, bool with_ab, b
         if (d.r == 2) { LAUNCH((split::k_node_post_split<2, 1>), wgs, split::SPLIT_WAVES * 64, A); LAUNCH((split::k_node_post_split<2, 2>), wgs, split::SPLIT_WAVES * 64, A); }
         else { LAUNCH((split::k_node_post_split<4, 1>), wgs, split::SPLIT_WAVES * 64, A); LAUNCH((split::k_node_post_split<4, 2>), wgs, split::SPLIT_WAVES * 64, A); }
     }
+    // ... and the per-node coord_mlp.0 rows A' = F (Q P R), B' = F (Q P C) in the same form (four items per workgroup share F's tape) —
+    // where they would be a launch of their own anyway (>= 1024 strips: the node kernel produced the next q / k / v).  Below that they ride
+    // with the next block's q / k / v items in one fp32 launch that fills the chip better than two (GEOM B = 512: 16.27 against 16.45 ms/step).
+    const bool split_ab = split_node && with_ab && A.ffold_s != nullptr && !next_pre;
+    if (split_ab) {
+        A.ab0 = 0; A.ab1 = 2 * p->n_strips;
+        LAUNCH(split::k_node_ab_split, (2 * p->n_strips + split::SPLIT_WAVES - 1) / split::SPLIT_WAVES, split::SPLIT_WAVES * 64, A);
+    }
     if (full > 0 && !split_node) {
         A.strip0 = 0;
         if (d.r == 2) LAUNCH(k_node_post<2>, full, 64, A); else LAUNCH(k_node_post<4>, full, 64, A);
@@ -230,7 +238,7 @@ int launch_node_post_256(jodo_plan* p, hipStream_t st, KArgs& A, bool with_ab, b
         return JODO_OK;
     }
     if (with_ab) {
-        LAUNCH((wide::k_node_ab<256>), p->n_strips * 2, 64, A);
+        if (!split_ab) LAUNCH((wide::k_node_ab<256>), p->n_strips * 2, 64, A);
         if (A.rot && p->n_gtiles > 0) LAUNCH((wide::k_node_gram<256>), p->n_gtiles, 64, A);
     }
     return JODO_OK;
@@ -275,7 +283,7 @@ int forward_blocks(jodo_plan* p, hipStream_t st, KArgs& A, const int64_t* woff, 
         LAUNCH((wide::k_fold_coord<D, D / 16>), d.L * (D / 32) * (d.De / 4), 64, A, F, A.mfold, 0, A.mfold_s);
         if (A.rot) {                               // F_l = W0 diag(1 + sc_l) Q_l^T: what k_node_ab applies to the rotated rows
             for (int l = 0; l < d.L; ++l) F.ine[l] = woff[JW_GLOBAL_COUNT + l * JB_BLOCK_COUNT + JB_QT_W];
-            LAUNCH((wide::k_fold_coord<D, D / 8>), d.L * (D / 32) * (D / 8), 64, A, F, A.ffold, 1, (unsigned short*)nullptr);
+            LAUNCH((wide::k_fold_coord<D, D / 8>), d.L * (D / 32) * (D / 8), 64, A, F, A.ffold, 1, A.ffold_s);
         }
     }
     pro.reset();
@@ -451,6 +459,7 @@ extern "C" int jodo_dgt_forward(jodo_plan* p, const void* desc_dev, const float*
         size_t total = 0, per_block = 0, node_block = 0, attn_block = 0;
         if (jodo_dgt_split_size(&p->cfg, &total, &per_block, &node_block, &attn_block) == JODO_OK && total == p->split_bytes)
             A.mfold_s = ws_ptr<unsigned short>(workspace, p->ws.mfold_s);
+        if (A.mfold_s && node_block > 0) A.ffold_s = ws_ptr<unsigned short>(workspace, p->ws.ffold_s);   // tuned nf 256 set: k_node_ab_split
     }
     float* posbuf[2] = {ws_ptr<float>(workspace, p->ws.pos0), ws_ptr<float>(workspace, p->ws.pos1)};
     A.pos_in = posbuf[0]; A.pos_out = posbuf[1];

@@ -43,6 +43,7 @@ struct KArgs {
     const unsigned short* wsplit_attn;    // the cyclic tape of the fused attention kernel (k_edge_attn<., ., ., 4>), NULL = off
     const unsigned short* wsplit_node;    // the same for the node kernel of the tuned nf 256 set (k_node_post_split), NULL = off
     unsigned short* mfold_s;
+    unsigned short* ffold_s;              // split image of ffold (the rotated per-node factor F of every block): k_node_ab_split
     int* flags;
     unsigned long long* dbgt;             // debug: per-phase cycle sums (builds with -DJODO_PHASE_TIMING only)
     // API tensors

@@ -180,5 +180,66 @@ __global__ __launch_bounds__(SPLIT_WAVES * 64, 1) void k_node_post_split(KArgs A
     }
 }
 
+// OPT-IN split-bf16 form of k_node_ab under the rotated statistics (wide::node_ab_body, rot branch): the per-node rows of the coord_mlp.0
+// hoist, A' = F (Q P R_a) -> A.ua and B' = F (Q P C_c) -> A.ub, F = W0 diag(1 + sc) Q^T of this forward (k_fold_coord wrote its split image
+// A.ffold_s beside the fp32 one: the same matrix as three terms).  One (strip, piece) item per wave as in the fp32 kernel; the four items
+// of a workgroup share F's 128-step tape (384 KiB per block) through the ring — the fp32 kernel reads its 256 KiB per item from L2,
+// 2 x n_strips times (5.6 TB/s at QM9 B = 2500: that stream is what bounds it).
+__global__ __launch_bounds__(SPLIT_WAVES * 64, 2) void k_node_ab_split(KArgs A) {
+    if (A.flags[FLAG_ASYM] || !A.flags[FLAG_UNIFORM_T]) return;      // pinned paths only (the launcher checks)
+    constexpr int D = 256, ND = D / 32;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+    int item = A.ab0 + (int)blockIdx.x * SPLIT_WAVES + wave;
+    const bool live = item < A.ab1;                  // an idle wave walks the first item without stores: the ring needs all four waves
+    if (!live) item = A.ab0;
+    const int strip = item >> 1, piece = item & 1;
+    const LaneNode L = lane_node(A, strip, j);
+    __shared__ u32x4 ring[N_SLOTS * N_CH_BYTES / 16];
+    Tape2 T;
+    T.rs = __builtin_amdgcn_make_buffer_rsrc(A.ffold_s + (size_t)A.layer * D * D * 3, 0, 0x7fffffff, 0x00020000);
+    T.ntot = ND * (D / 16) / N_CHS;
+    T.ld_off = (unsigned)wave * (unsigned)(N_CH_BYTES / SPLIT_WAVES) + (unsigned)lane * 16u;
+    T.rd_off = (unsigned)lane * 16u;
+    T.ring = reinterpret_cast<char*>(ring);
+    int g = 0;
+    tape2_start(T, g);
+    // The row stays in fp32 (128 registers) and every K16 step's operand is split where it is used, once per output block: its split
+    // image would be 192 registers — one wave per SIMD, and a single in-order wave gets an MFMA out every 56 cycles (k_node_post_split).
+    // With 256 registers two workgroups share a CU and one wave's conversions run under the other's MFMAs.
+    float x[D / 2];
+    {
+        const TRow src = trow(piece == 0 ? A.wrow : A.wcol, ND, L.v, half);
+#pragma unroll
+        for (int b = 0; b < ND; ++b) {
+            float t[16];
+            load16T(src, b, t);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) x[b * 16 + s] = t[s];
+        }
+    }
+    float* dst = piece == 0 ? A.ua : A.ub;
+#pragma unroll 1
+    for (int b = 0; b < ND; ++b) {
+#pragma unroll
+        for (int s = 0; s < D / 2; ++s) asm volatile("" : "+v"(x[s]));      // (keeps the conversions inside the loop: hoisted they are the 192 registers again)
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int c = 0; c < D / 16 / N_CHS; ++c) {   // a chunk of the tape = eight steps = 64 features of the row, converted four steps at a time
+            static_assert(N_CHS == 8, "two half-chunks");
+            Split8 xs[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xs[q] = split8(&x[(c * 8 + q) * 8]);
+            acc = tape2_block<4, 0>(T, g, xs, acc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xs[q] = split8(&x[(c * 8 + 4 + q) * 8]);
+            acc = tape2_block<4, 4>(T, g, xs, acc);
+        }
+        float r[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) r[s] = acc[s];
+        if (live) store16T(dst, ND, L.v, half, b, r);
+    }
+}
+
 }  // namespace split
 }  // namespace jd

@@ -407,7 +407,7 @@ extern "C" int jodo_plan_create(const jodo_cfg* cfg, int B, int N, const int32_t
     w.feat = take(NP * d.ndp * f); w.h = take(NP * d.D * f); w.hhat = take(NP * amax_parts * d.D * f);
     w.astat = take(NP * amax_parts * 32 * f);
     w.q = take(NP * d.QKP * f); w.k = take(NP * d.QKP * f); w.v = take(NP * d.D * f); w.n2e = take(NP * d.De * f);
-    w.wrow = take(NP * d.D * f); w.wcol = take(NP * d.D * f); w.ua = take(NP * d.D * f); w.ub = take(NP * d.D * f); w.rmean = take(NP * 2 * f); w.mfold = take((size_t)d.L * d.D * 2 * d.De * f); w.mfold_s = take((size_t)d.L * d.D * 2 * d.De * 6); w.ffold = take((size_t)d.L * d.D * d.D * f); w.ahid = take(NP * d.KNH * f);
+    w.wrow = take(NP * d.D * f); w.wcol = take(NP * d.D * f); w.ua = take(NP * d.D * f); w.ub = take(NP * d.D * f); w.rmean = take(NP * 2 * f); w.mfold = take((size_t)d.L * d.D * 2 * d.De * f); w.mfold_s = take((size_t)d.L * d.D * 2 * d.De * 6); w.ffold_s = take((size_t)d.L * d.D * d.D * 6); w.ffold = take((size_t)d.L * d.D * d.D * f); w.ahid = take(NP * d.KNH * f);
     w.apred = take(NP * 32 * f);
     w.eflag = take(R * sizeof(int32_t)); w.e = take(R * d.De * f); w.e2 = take(R * d.De * f);
     w.ehid = take(R * d.KEH * f); w.epred = take(R * 4 * f); w.dposE = take(R * 4 * f); w.gramE = take(R * f);

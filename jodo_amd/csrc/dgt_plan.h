@@ -69,6 +69,7 @@ struct WsLayout {   // byte offsets into the workspace
     size_t hid1, temb, tembs, mods, condh, condh2;
     size_t pos0, pos1, dpos, cpos, feat, h, hhat, astat, q, k, v, n2e, wrow, wcol, ua, ub, rmean, mfold, ffold, ahid, apred;
     size_t eflag, e, e2, ehid, epred, dposE, gramE;
+    size_t ffold_s;                  // split-bf16 image of ffold: [L][D / 32][D / 16][3][64][8] bf16
     size_t mfold_s;                  // split-bf16 image of mfold (JODO_OPT_SPLIT_BF16): [L][D / 32][2 De / 16][3][64][8] bf16
     size_t total;
 };
