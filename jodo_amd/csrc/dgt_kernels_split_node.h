@@ -185,6 +185,10 @@ __global__ __launch_bounds__(SPLIT_WAVES * 64, 1) void k_node_post_split(KArgs A
 // A.ffold_s beside the fp32 one: the same matrix as three terms).  One (strip, piece) item per wave as in the fp32 kernel; the four items
 // of a workgroup share F's 128-step tape (384 KiB per block) through the ring — the fp32 kernel reads its 256 KiB per item from L2,
 // 2 x n_strips times (5.6 TB/s at QM9 B = 2500: that stream is what bounds it).
+// Measured (MI355X, QM9 B = 2500, rocprofv3): fp32 k_node_ab 131 us per launch -> 90 us in this form.  Equal: the row's split image in
+// registers (192, one wave per SIMD).  Slower: both pieces of a strip per wave through the same fragments (two independent accumulator
+// chains, half the LDS reads) — 128 us with the operands converted in the loop (one wave per SIMD: nothing hides 96 conversions per
+// step), 120 us with both rows' split images in registers (384 + accumulators: 212 B of scratch).
 __global__ __launch_bounds__(SPLIT_WAVES * 64, 2) void k_node_ab_split(KArgs A) {
     if (A.flags[FLAG_ASYM] || !A.flags[FLAG_UNIFORM_T]) return;      // pinned paths only (the launcher checks)
     constexpr int D = 256, ND = D / 32;
