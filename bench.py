@@ -297,6 +297,11 @@ def main():
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr',
                '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         os.execvpe(sys.executable, cmd, env)
+    # stdout carries exactly ONE line, the JSON record: whatever a library writes to file descriptor 1 during the run (RCCL's version banner
+    # on boxes that export NCCL_DEBUG=VERSION, HIP runtime notices) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -717,7 +722,7 @@ def main():
             print(json.dumps(per_class), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg.seed, config2_steps=args.cpu_config2_steps)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
