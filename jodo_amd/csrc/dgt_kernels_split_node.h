@@ -189,6 +189,10 @@ __global__ __launch_bounds__(SPLIT_WAVES * 64, 1) void k_node_post_split(KArgs A
 // registers (192, one wave per SIMD).  Slower: both pieces of a strip per wave through the same fragments (two independent accumulator
 // chains, half the LDS reads) — 128 us with the operands converted in the loop (one wave per SIMD: nothing hides 96 conversions per
 // step), 120 us with both rows' split images in registers (384 + accumulators: 212 B of scratch).
+// Faster alone, slower in the step: a K-major walk (k_fold_coord writing F's image as [step / 4][out block][step % 4]; 64 features of the row
+// converted once and applied to all eight output blocks, eight accumulators, 248 registers, two workgroups per CU) runs 69 us — and the
+// step around it 12.50 -> 12.72 ms on the same box, three alternations: the pair update 392 -> 409 us and the attention kernel 444 -> 461
+// with it (the denser launch costs the launches around it ~ 4 %; power, by every sign).  Not kept.
 __global__ __launch_bounds__(SPLIT_WAVES * 64, 2) void k_node_ab_split(KArgs A) {
     if (A.flags[FLAG_ASYM] || !A.flags[FLAG_UNIFORM_T]) return;      // pinned paths only (the launcher checks)
     constexpr int D = 256, ND = D / 32;

@@ -9,7 +9,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MF
   rm -rf $R/gpurun_out/split_pmc${i}_$WL
   timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/split_pmc${i}_$WL -o pmc -- python $R/tools/split_ab.py --workload $WL --steps 3 > $R/gpurun_out/split_pmc${i}_$WL.log 2>&1
   g=$(find $R/gpurun_out/split_pmc${i}_$WL -name "*counter_collection.csv" | head -1)
-  [ -n "$g" ] && python3 $R/tools/pmc_summary.py "$g" | grep -E "split|k_node_post<|k_edge_update_sym<" | head -8 | tee $R/gpurun_out/split_pmc${i}_$WL.txt
+  [ -n "$g" ] && python3 $R/tools/pmc_summary.py "$g" | grep -E "split|k_node_post<|k_node_ab<|k_edge_update_sym<" | head -12 | tee $R/gpurun_out/split_pmc${i}_$WL.txt
   rm -rf $R/gpurun_out/split_pmc${i}_$WL
   i=$((i+1))
 done
