@@ -905,9 +905,12 @@ def test_fused_decode_equals_post_process(cfg_name):
         fused.decode(cfg, xh.cpu(), ex, fused.n_nodes_from_mask(nm))
 
 
-def test_graph_replayed_sampling_round():
+@pytest.mark.parametrize("split", [False, True])
+def test_graph_replayed_sampling_round(split):
     """HIP-graph replay of the ancestral loop: every replayed step must (a) have evaluated the score network on
-    the state the previous step produced and (b) apply the reference update to its own recorded noise draws."""
+    the state the previous step produced and (b) apply the reference update to its own recorded noise draws.
+    split: the captured step holds the opt-in split-bf16 kernels (the round pins its paths before the capture); the eager re-evaluation
+    under the same pins reproduces it bit for bit, the exact-fp32 kernels (paths unpinned) to the stated tolerance."""
     from jodo_amd.diffusion import NoiseScheduleVP
     from jodo_amd.graphed import GraphedAncestralRound
     from jodo_amd.sampling import AncestralSampler, posterior_coefficients
@@ -919,6 +922,7 @@ def test_graph_replayed_sampling_round():
     nm, em = masks(n_nodes, DEV)
     B, N = len(n_nodes), max(n_nodes)
     model = make_model(cfg, 4, DEV, head_gain=10.0)
+    model.split_bf16 = split
     ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
     ts = torch.linspace(ns.T, 1e-3, 7)
     smp = AncestralSampler(ns, ts, True, True, True, get_self_cond_fn(cfg))
@@ -951,6 +955,16 @@ def test_graph_replayed_sampling_round():
             assert torch.equal(h['x_prev'], prev_state[0]) and torch.equal(h['e_prev'], prev_state[1])
         prev_pred, prev_state = (h['pred_keep'], h['epred_keep']), (h['x'], h['e'])
     assert torch.equal(x_mean, rnd.history[-1]['x_mean']) and not bool(torch.isnan(x_mean).any())
+    if split:                                                      # the split kernels really were what the graph replayed: the plan holds their
+        assert model._last_plan.get('split_tape') is not None      # tape, and the exact kernels (paths unpinned) give the last bits differently
+        model.unpin_paths()
+        h = rnd.history[-1]
+        nl = torch.full((B,), float(torch.log(alpha_t ** 2 / sigma_t ** 2)), device=DEV)
+        with torch.no_grad():
+            px, pe = model(nl, h['x_prev'], nm, em, edge_x=h['e_prev'], noise_level=nl, cond_x=rnd.history[-2]['pred_keep'], cond_edge_x=rnd.history[-2]['epred_keep'])
+        assert not (torch.equal(px, h['pred_keep']) and torch.equal(pe, h['epred_keep']))
+        for got, want in ((h['pred_keep'], px), (h['epred_keep'], pe)):
+            assert bool(((got - want).abs() <= 2e-5 + 1e-4 * want.abs()).all())
 
 
 @pytest.mark.parametrize("cfg_name,info,B,over", [
